@@ -1,0 +1,253 @@
+/* pt_api.h — C ABI of the MI355X path-tracing hot path.
+ *
+ * This is the drop-in boundary for the reference's PT hot path
+ * (/root/reference = gillett-hernandez/rust-pathtracer @ 2024_08_07):
+ *
+ *   pt_render            replaces  Renderer::render            src/renderer/mod.rs:107-112
+ *                                  TiledRenderer::render_sampled src/renderer/tiled.rs:279-542
+ *                                  PathTracingIntegrator::color src/integrator/pt.rs:397-615
+ *                                  random_walk                  src/integrator/utils.rs:152-376
+ *   pt_intersect         replaces  World::hit                   src/world/mod.rs:166-168
+ *                                  Accelerator::hit             src/accelerator/mod.rs:86-178
+ *   pt_bsdf_sample       replaces  Material::generate_and_evaluate src/materials/mod.rs:67-74
+ *   pt_bsdf_eval         replaces  Material::bsdf               src/materials/mod.rs:59-66
+ *   pt_emission          replaces  Material::emission           src/materials/mod.rs:115-117
+ *   pt_scene_create      takes the data the reference keeps in `World`
+ *                        (src/world/mod.rs:18-28) flattened to plain arrays:
+ *                        Instance/Aggregate (src/geometry/instance.rs:9-15,
+ *                        src/geometry/mod.rs:17-122), Mesh (src/geometry/mesh.rs:243-253),
+ *                        MaterialEnum (src/materials/mod.rs:275-283), Curve /
+ *                        CurveWithCDF (math crate; built in src/parsing/curves.rs:298-372),
+ *                        TexStack (src/texture.rs:236-264), EnvironmentMap
+ *                        (src/world/environment.rs:6-27), ProjectiveCamera
+ *                        (src/camera/projective_camera.rs:8-25).
+ *
+ * A per-sample FFI (SamplerIntegrator::color, src/integrator/mod.rs:125-140) is
+ * useless for a GPU, so the replacement plugs in at Renderer granularity: a
+ * Rust `impl Renderer for HipRenderer` flattens its `World` into a
+ * pt_scene_desc once and calls pt_render per RenderSettings (INTEGRATION.md
+ * shows that binding).
+ *
+ * Conventions: plain pointers and sizes only; the library copies everything it
+ * needs out of the descriptors during pt_scene_create (caller keeps ownership);
+ * every call returns PT_OK (0) or a nonzero pt_status and never throws or
+ * aborts across the boundary; pt_last_error() returns a thread-local message;
+ * a pt_scene may be used from one thread at a time; calls block until the
+ * result is complete.  All floats are IEEE f32, matrices are row-major 4x4.
+ *
+ * The CPU oracle (oracle/, test infrastructure only) exports the same
+ * signatures with the prefix ptref_ instead of pt_.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t pt_status;
+enum {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARGUMENT = 1,
+    PT_ERR_NO_DEVICE = 2,       /* no HIP device / HIP runtime failure: the product path never falls back to CPU */
+    PT_ERR_OUT_OF_MEMORY = 3,
+    PT_ERR_UNSUPPORTED = 4,
+    PT_ERR_DEVICE = 5
+};
+
+/* MaterialId (src/materials/mod.rs:22-27) packed into 32 bits: tag << 16 | index. */
+enum { PT_TAG_MATERIAL = 0, PT_TAG_LIGHT = 1, PT_TAG_CAMERA = 2 };
+#define PT_MATERIAL_ID(tag, index) ((((uint32_t)(tag)) << 16) | ((uint32_t)(index) & 0xffffu))
+#define PT_MATERIAL_TAG(id) (((id) >> 16) & 0x3u)
+#define PT_MATERIAL_INDEX(id) ((id) & 0xffffu)
+#define PT_MATERIAL_NONE 0xffffffffu /* Instance::material_id == None (src/geometry/instance.rs:13) */
+
+/* ---- spectral curves: math::curves::Curve as built by src/parsing/curves.rs:298-372 */
+enum {
+    PT_CURVE_LINEAR = 0,          /* Curve::Linear{signal,bounds,mode}: p0 = lower, p1 = upper, data = signal[count] */
+    PT_CURVE_TABULATED = 1,       /* Curve::Tabulated{signal:(x,y)[],mode}: data = x0,y0,x1,y1,... (count pairs) */
+    PT_CURVE_CAUCHY = 2,          /* Curve::Cauchy{a,b}: p0 = a, p1 = b */
+    PT_CURVE_EXPONENTIAL = 3,     /* Curve::Exponential{(offset,sigma_l,sigma_r,multiplier)[]}: data = count 4-tuples */
+    PT_CURVE_INV_EXPONENTIAL = 4, /* Curve::InverseExponential, same layout */
+    PT_CURVE_BLACKBODY = 5,       /* Curve::Blackbody{temperature,boost}: p0 = temperature, p1 = boost */
+    PT_CURVE_CONST = 6            /* Curve::Const(v): p0 = v */
+};
+enum { PT_INTERP_LINEAR = 0, PT_INTERP_NEAREST = 1, PT_INTERP_CUBIC = 2 };
+
+typedef struct pt_curve {
+    int32_t kind;
+    int32_t mode;          /* PT_INTERP_* for LINEAR / TABULATED */
+    float p0, p1;
+    uint32_t data_offset;  /* in floats, into pt_scene_desc::curve_data */
+    uint32_t data_count;   /* samples / pairs / 4-tuples */
+} pt_curve;
+
+/* ---- textures: src/texture.rs */
+enum { PT_TEXTURE1 = 1, PT_TEXTURE4 = 4 };
+typedef struct pt_texture_layer {
+    int32_t kind;          /* PT_TEXTURE1 (src/texture.rs:122-141) or PT_TEXTURE4 (src/texture.rs:24-119) */
+    int32_t curves[4];     /* curve indices; Texture1 uses curves[0] */
+    int32_t width, height;
+    uint64_t data_offset;  /* in floats, into texture_data; Texture1: w*h floats, Texture4: w*h*4 floats, row-major */
+} pt_texture_layer;
+typedef struct pt_texstack {  /* TexStack (src/texture.rs:236-264) = sum of layers */
+    int32_t first_layer, layer_count;
+} pt_texstack;
+
+/* ---- materials: src/materials */
+enum {
+    PT_MATERIAL_LAMBERTIAN = 0,    /* src/materials/lambertian.rs */
+    PT_MATERIAL_GGX = 1,           /* src/materials/ggx.rs */
+    PT_MATERIAL_DIFFUSE_LIGHT = 2, /* src/materials/diffuse_light.rs */
+    PT_MATERIAL_SHARP_LIGHT = 3    /* src/materials/sharp_light.rs */
+};
+enum { PT_SIDED_FORWARD = 0, PT_SIDED_REVERSE = 1, PT_SIDED_DUAL = 2 }; /* math::Sidedness */
+
+typedef struct pt_material {
+    int32_t kind;
+    int32_t texstack;      /* Lambertian::texture */
+    float alpha;           /* GGX::alpha */
+    int32_t curve_eta, curve_eta_o, curve_kappa; /* GGX spectral IOR curves */
+    int32_t curve_emit, curve_bounce;            /* DiffuseLight / SharpLight */
+    float sharpness;       /* SharpLight: the value from the scene file; the library applies 1 + |s| (sharp_light.rs:26) */
+    int32_t sidedness;
+} pt_material;
+
+/* ---- geometry: src/geometry */
+enum { PT_SHAPE_RECT = 0, PT_SHAPE_SPHERE = 1, PT_SHAPE_DISK = 2, PT_SHAPE_MESH = 3 };
+enum { PT_AXIS_X = 0, PT_AXIS_Y = 1, PT_AXIS_Z = 2 };
+
+typedef struct pt_mesh {          /* Mesh (src/geometry/mesh.rs:243-253) */
+    uint32_t vertex_offset;       /* in vertices (xyz triples) into pt_scene_desc::vertices */
+    uint32_t vertex_count;
+    uint32_t index_offset;        /* in uint32, into indices; 3 per face, relative to vertex_offset */
+    uint32_t face_count;
+    int32_t normal_offset;        /* in normals (xyz triples), indexed like vertices; -1 = no shading normals */
+    int32_t face_material_offset; /* into face_materials (packed MaterialId per face); -1 = Material(0) */
+} pt_mesh;
+
+typedef struct pt_instance {      /* Instance (src/geometry/instance.rs:9-15) + its Aggregate */
+    int32_t kind;                 /* PT_SHAPE_* */
+    int32_t has_transform;        /* Instance::transform.is_some() */
+    uint32_t material;            /* packed MaterialId override or PT_MATERIAL_NONE */
+    int32_t mesh;                 /* PT_SHAPE_MESH: index into meshes */
+    float origin[3];              /* rect / sphere / disk */
+    float size[2];                /* rect (src/geometry/rect.rs:16) */
+    float radius;                 /* sphere / disk */
+    int32_t axis;                 /* rect normal axis */
+    int32_t two_sided;            /* rect / disk */
+    float forward[16];            /* Transform3::forward, row-major */
+    float reverse[16];            /* Transform3::reverse (inverse) */
+} pt_instance;
+
+/* ---- environment: src/world/environment.rs:6-27 */
+enum { PT_ENV_CONSTANT = 0, PT_ENV_SUN = 1, PT_ENV_HDR = 2 };
+typedef struct pt_environment {
+    int32_t kind;
+    float strength;
+    int32_t curve;                /* Constant / Sun colour */
+    float angular_diameter;       /* Sun */
+    float sun_direction[3];       /* Sun */
+    int32_t texstack;             /* HDR texture stack */
+    float rotation_forward[16];   /* HDR */
+    float rotation_reverse[16];
+    int32_t importance_width;     /* HDR: baked importance map resolution; 0 = unbaked (uniform sampling) */
+    int32_t importance_height;
+    int32_t importance_luminance_curve; /* curve used as the luminance weight when baking (y_bar when -1) */
+} pt_environment;
+
+/* ---- camera: ProjectiveCamera (src/camera/projective_camera.rs:27-95, parse defaults src/parsing/cameras.rs:132-148) */
+typedef struct pt_camera {
+    float look_from[3], look_at[3], v_up[3];
+    float vfov;                   /* degrees */
+    float focal_distance;
+    float aperture_diameter;
+} pt_camera;
+
+typedef struct pt_scene_desc {
+    uint32_t curve_count;        const pt_curve* curves;
+    size_t curve_data_count;     const float* curve_data;
+    uint32_t layer_count;        const pt_texture_layer* layers;
+    uint32_t texstack_count;     const pt_texstack* texstacks;
+    size_t texture_data_count;   const float* texture_data;
+    uint32_t material_count;     const pt_material* materials; /* index 0 must be the error material (src/parsing/mod.rs:438-455) */
+    uint32_t mesh_count;         const pt_mesh* meshes;
+    size_t vertex_count;         const float* vertices;        /* xyz */
+    size_t index_count;          const uint32_t* indices;
+    size_t normal_count;         const float* normals;         /* xyz */
+    size_t face_material_count;  const uint32_t* face_materials;
+    uint32_t instance_count;     const pt_instance* instances; /* InstanceId = position in this array */
+    uint32_t camera_count;       const pt_camera* cameras;
+    pt_environment environment;
+    float env_sampling_probability; /* World::env_sampling_probability (src/world/mod.rs:26,170-176) */
+} pt_scene_desc;
+
+/* ---- render settings: RenderSettings (src/parsing/config.rs:45-62) + PathTracingIntegrator (src/integrator/pt.rs:16-26) */
+typedef struct pt_render_desc {
+    uint32_t width, height;
+    uint32_t spp;                /* min_samples */
+    uint32_t min_bounces;        /* russian_roulette_start_index (src/integrator/utils.rs:267) */
+    uint32_t max_bounces;
+    uint32_t light_samples;
+    uint32_t only_direct;
+    float wavelength_lo, wavelength_hi; /* default BOUNDED_VISIBLE_RANGE = [380,750] (src/integrator/mod.rs:65-68) */
+    uint32_t camera_index;
+    uint64_t seed;
+    uint32_t tile_width, tile_height;   /* RendererType::Tiled (src/parsing/config.rs:112-121); 0 = 32 */
+    uint32_t shard_index, shard_count;  /* this call renders tiles t with t % shard_count == shard_index; others stay zero. 0/0 = whole film */
+    uint32_t hero_wavelengths;   /* 1, or 4 for the hero-wavelength variant */
+    uint32_t first_sample;       /* render samples [first_sample, first_sample + sample_count) of the spp; */
+    uint32_t sample_count;       /* 0 = all spp. With a partial range the film holds the un-normalised running sum. */
+} pt_render_desc;
+
+typedef struct pt_profile {      /* Profile (src/profile.rs:2-8) + timing */
+    uint64_t bounce_rays, shadow_rays, light_rays, camera_rays, env_hits;
+    double seconds;              /* render loop only: the window of src/renderer/tiled.rs:294 -> :536 */
+    double kernel_seconds[8];    /* HIP-event time per stage: generate, extend, shade, shadow, accumulate, 3 spare */
+    uint64_t kernel_launches[8];
+} pt_profile;
+
+typedef struct pt_hit {          /* HitRecord (src/hittable.rs:7-16) */
+    float t;
+    float point[3];
+    float normal[3];
+    float uv[2];
+    uint32_t material;           /* packed MaterialId */
+    uint32_t instance;
+    int32_t valid;               /* 0 = miss */
+} pt_hit;
+
+typedef struct pt_scene pt_scene;
+
+pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out);
+void pt_scene_destroy(pt_scene* scene);
+const char* pt_last_error(void);
+
+/* Film: caller-allocated width*height*4 f32 (X,Y,Z,0), row-major, y = 0 is the
+ * top row (src/tonemap/mod.rs:237-239), already divided by spp (tiled.rs:396-398). */
+pt_status pt_render(pt_scene* scene, const pt_render_desc* desc, float* film_xyzw, pt_profile* profile);
+/* Same, but `film_device` is device memory (HBM) of the current HIP device, written on `hip_stream`
+ * (a hipStream_t, may be NULL); the call returns after the stream work is complete. */
+pt_status pt_render_device(pt_scene* scene, const pt_render_desc* desc, void* film_device,
+                           void* hip_stream, pt_profile* profile);
+
+/* Probes of the trait surface, used for parity tests of single stages. Host arrays in, host arrays out. */
+pt_status pt_intersect(pt_scene* scene, size_t n, const float* origins, const float* directions, pt_hit* hits);
+pt_status pt_bsdf_sample(pt_scene* scene, uint32_t material, size_t n, const float* lambda, const float* wi,
+                         const float* sample2d, float* f, float* wo, float* pdf);
+pt_status pt_bsdf_eval(pt_scene* scene, uint32_t material, size_t n, const float* lambda, const float* wi,
+                       const float* wo, float* f, float* pdf);
+pt_status pt_emission(pt_scene* scene, uint32_t material, size_t n, const float* lambda, const float* wi,
+                      float* emission);
+pt_status pt_curve_eval(pt_scene* scene, uint32_t curve, size_t n, const float* lambda, float* value);
+
+/* Library / device identification, e.g. "gfx950 ... 256 CUs". */
+const char* pt_device_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_API_H */

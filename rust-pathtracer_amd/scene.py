@@ -1,0 +1,498 @@
+"""Host-side scene assembly: builds the flat pt_scene_desc (include/pt_api.h) the way the
+reference's `construct_world` (src/parsing/mod.rs:145-563) builds a `World`, plus the
+benchmark scenes of BASELINE.json / SURVEY.md §8(d).
+
+This is the caller's side of the boundary (what a Rust `impl Renderer` would do when it
+flattens its `World`); nothing here is on the hot path.
+"""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+
+from . import api
+from .objmesh import load_obj
+
+_DATA = os.path.join(os.path.dirname(__file__), "data")
+EXTENDED_VISIBLE_RANGE = (370.0, 790.0)
+BOUNDED_VISIBLE_RANGE = (380.0, 750.0)
+_IDENTITY = np.eye(4, dtype=np.float64)
+
+
+def _spectra():
+    with open(os.path.join(_DATA, "spectra.json")) as f:
+        return json.load(f)
+
+
+# ---- Transform3 (math crate): from_stack(scale, rotate, translate) = T * R * S -------------------
+def transform_from_scale(s):
+    m = np.eye(4); m[0, 0], m[1, 1], m[2, 2] = s
+    return m
+
+
+def transform_from_translation(t):
+    m = np.eye(4); m[:3, 3] = t
+    return m
+
+
+def transform_from_axis_angle(axis, angle_rad):
+    a = np.asarray(axis, dtype=np.float64); a = a / np.linalg.norm(a)
+    c, s = math.cos(angle_rad), math.sin(angle_rad)
+    x, y, z = a
+    r = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s],
+                  [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s],
+                  [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]])
+    m = np.eye(4); m[:3, :3] = r
+    return m
+
+
+def transform_from_data(scale=None, rotate=None, translate=None):
+    """Transform3Data -> forward matrix (src/parsing/instance.rs:40-71): rotations given as
+    [(axis, degrees), ...] are applied in list order."""
+    m = np.eye(4)
+    if scale is not None:
+        m = transform_from_scale(scale) @ m
+    if rotate:
+        base = None
+        for axis, deg in rotate:
+            t = transform_from_axis_angle(axis, math.pi * deg / 180.0)
+            base = t if base is None else t @ base
+        m = base @ m
+    if translate is not None:
+        m = transform_from_translation(translate) @ m
+    return m
+
+
+class SceneBuilder:
+    def __init__(self):
+        self.curves = []          # api.Curve
+        self.curve_data = []      # floats
+        self.curve_names = {}
+        self.layers = []
+        self.texstacks = []
+        self.texture_data = []
+        self.texstack_names = {}
+        self.materials = []
+        self.material_ids = {}    # name -> packed MaterialId
+        self.meshes = []
+        self.vertices = []
+        self.indices = []
+        self.normals = []
+        self.face_materials = []
+        self.instances = []
+        self.cameras = []
+        self.environment = api.Environment()
+        self.environment.kind = api.ENV_CONSTANT
+        self.environment.curve = -1
+        self.environment.texstack = -1
+        self.env_sampling_probability = 0.5  # scene default (src/parsing/mod.rs:559)
+        # material 0 = mauve error light (src/parsing/mod.rs:438-455, src/curves.rs:41-48, 71-77)
+        mauve = self.curve_exponential("__mauve", [(650.0, 300.0, 300.0, 1.0), (460.0, 200.0, 400.0, 0.75)])
+        void = self.curve_flat("__cie_e_0", 0.0)
+        self.material_diffuse_light("error", mauve, void, api.SIDED_DUAL)
+
+    # ---- curves (src/parsing/curves.rs:298-372)
+    def _add_curve(self, name, kind, mode=0, p0=0.0, p1=0.0, data=()):
+        c = api.Curve(kind, mode, p0, p1, len(self.curve_data), 0)
+        data = [float(x) for x in data]
+        if kind == api.CURVE_TABULATED:
+            c.data_count = len(data) // 2
+        elif kind in (api.CURVE_EXPONENTIAL, api.CURVE_INV_EXPONENTIAL):
+            c.data_count = len(data) // 4
+        else:
+            c.data_count = len(data)
+        self.curve_data.extend(data)
+        self.curves.append(c)
+        idx = len(self.curves) - 1
+        if name is not None:
+            self.curve_names[name] = idx
+        return idx
+
+    def curve_flat(self, name, strength):  # CurveData::Flat -> Curve::Linear over EXTENDED_VISIBLE_RANGE
+        return self._add_curve(name, api.CURVE_LINEAR, api.INTERP_LINEAR, *EXTENDED_VISIBLE_RANGE, data=[strength])
+
+    def curve_cauchy(self, name, a, b):
+        return self._add_curve(name, api.CURVE_CAUCHY, 0, a, b)
+
+    def curve_blackbody(self, name, temperature, strength):
+        return self._add_curve(name, api.CURVE_BLACKBODY, 0, temperature, strength)
+
+    def curve_exponential(self, name, spikes):  # [(lambda, left_taper, right_taper, strength)]
+        return self._add_curve(name, api.CURVE_EXPONENTIAL, 0, data=[v for s in spikes for v in s])
+
+    def curve_simple_spike(self, name, lam, left_taper, right_taper, strength):
+        return self.curve_exponential(name, [(lam, left_taper, right_taper, strength)])
+
+    def curve_tabulated(self, name, xs, ys, mode=api.INTERP_CUBIC, x_scale=1.0, x_offset=0.0, y_scale=1.0, y_offset=0.0):
+        f32 = np.float32
+        data = []
+        for x, y in zip(xs, ys):  # DomainMapping: (x - offset) * scale, in f32 as the reference parses
+            data.append(float((f32(x) - f32(x_offset)) * f32(x_scale)))
+            data.append(float((f32(y) - f32(y_offset)) * f32(y_scale)))
+        return self._add_curve(name, api.CURVE_TABULATED, mode, data=data)
+
+    def curve_linear(self, name, start, step, ys, mode=api.INTERP_CUBIC, y_scale=1.0):
+        f32 = np.float32
+        end = float(f32(start) + f32(step) * f32(len(ys)))
+        return self._add_curve(name, api.CURVE_LINEAR, mode, float(start), end, data=[float(f32(y) * f32(y_scale)) for y in ys])
+
+    def curve(self, name):
+        return self.curve_names[name]
+
+    # ---- textures (src/parsing/texture.rs)
+    def texstack_texture1(self, name, curve, texels=None):
+        t = np.ones((1, 1), np.float32) if texels is None else np.asarray(texels, np.float32)
+        layer = api.TextureLayer(api.TEXTURE1, (C.c_int32 * 4)(curve, -1, -1, -1), t.shape[1], t.shape[0], len(self.texture_data))
+        self.texture_data.extend(t.reshape(-1).tolist())
+        self.layers.append(layer)
+        self.texstacks.append(api.TexStack(len(self.layers) - 1, 1))
+        self.texstack_names[name] = len(self.texstacks) - 1
+        return len(self.texstacks) - 1
+
+    def texstack_texture4(self, name, curves, texels):
+        t = np.asarray(texels, np.float32)
+        assert t.ndim == 3 and t.shape[2] == 4
+        layer = api.TextureLayer(api.TEXTURE4, (C.c_int32 * 4)(*curves), t.shape[1], t.shape[0], len(self.texture_data))
+        self.texture_data.extend(t.reshape(-1).tolist())
+        self.layers.append(layer)
+        self.texstacks.append(api.TexStack(len(self.layers) - 1, 1))
+        self.texstack_names[name] = len(self.texstacks) - 1
+        return len(self.texstacks) - 1
+
+    # ---- materials (src/parsing/material.rs:66-153; ids src/parsing/mod.rs:456-467)
+    def _add_material(self, name, m, is_light):
+        self.materials.append(m)
+        idx = len(self.materials) - 1
+        self.material_ids[name] = api.material_id(api.TAG_LIGHT if is_light else api.TAG_MATERIAL, idx)
+        return self.material_ids[name]
+
+    def material_lambertian(self, name, texstack):
+        return self._add_material(name, api.Material(api.MATERIAL_LAMBERTIAN, texstack, 0.0, -1, -1, -1, -1, -1, 0.0, 0), False)
+
+    def material_ggx(self, name, alpha, eta, eta_o, kappa):
+        return self._add_material(name, api.Material(api.MATERIAL_GGX, -1, alpha, eta, eta_o, kappa, -1, -1, 0.0, 0), False)
+
+    def material_diffuse_light(self, name, emit, bounce, sidedness):
+        return self._add_material(name, api.Material(api.MATERIAL_DIFFUSE_LIGHT, -1, 0.0, -1, -1, -1, emit, bounce, 0.0, sidedness), True)
+
+    def material_sharp_light(self, name, emit, bounce, sharpness, sidedness):
+        return self._add_material(name, api.Material(api.MATERIAL_SHARP_LIGHT, -1, 0.0, -1, -1, -1, emit, bounce, sharpness, sidedness), True)
+
+    def material(self, name):
+        return self.material_ids[name]
+
+    # ---- geometry
+    def add_mesh(self, positions, faces, normals=None, face_materials=None):
+        p = np.asarray(positions, np.float32).reshape(-1, 3)
+        f = np.asarray(faces, np.uint32).reshape(-1, 3)
+        m = api.Mesh(len(self.vertices) // 3, p.shape[0], len(self.indices), f.shape[0], -1, -1)
+        if normals is not None and len(normals):
+            n = np.asarray(normals, np.float32).reshape(-1, 3)
+            assert n.shape == p.shape
+            m.normal_offset = len(self.normals) // 3
+            self.normals.extend(n.reshape(-1).tolist())
+        if face_materials is not None:
+            fm = np.broadcast_to(np.asarray(face_materials, np.uint32), (f.shape[0],))
+            m.face_material_offset = len(self.face_materials)
+            self.face_materials.extend(fm.tolist())
+        self.vertices.extend(p.reshape(-1).tolist())
+        self.indices.extend(f.reshape(-1).tolist())
+        self.meshes.append(m)
+        return len(self.meshes) - 1
+
+    def _instance(self, kind, material, transform):
+        inst = api.Instance()
+        inst.kind = kind
+        inst.material = api.MATERIAL_NONE if material is None else material
+        fwd = _IDENTITY if transform is None else np.asarray(transform, np.float64)
+        inst.has_transform = 0 if transform is None else 1
+        inst.forward = (C.c_float * 16)(*fwd.astype(np.float32).reshape(-1).tolist())
+        inst.reverse = (C.c_float * 16)(*np.linalg.inv(fwd).astype(np.float32).reshape(-1).tolist())
+        self.instances.append(inst)
+        return inst
+
+    def add_rect(self, size, origin, axis, two_sided, material, transform=None):
+        inst = self._instance(api.SHAPE_RECT, material, transform)
+        inst.size = (C.c_float * 2)(*size); inst.origin = (C.c_float * 3)(*origin)
+        inst.axis = {"X": 0, "Y": 1, "Z": 2}[axis] if isinstance(axis, str) else axis
+        inst.two_sided = int(two_sided)
+        return len(self.instances) - 1
+
+    def add_sphere(self, radius, origin, material, transform=None):
+        inst = self._instance(api.SHAPE_SPHERE, material, transform)
+        inst.radius = radius; inst.origin = (C.c_float * 3)(*origin)
+        return len(self.instances) - 1
+
+    def add_disk(self, radius, origin, two_sided, material, transform=None):
+        inst = self._instance(api.SHAPE_DISK, material, transform)
+        inst.radius = radius; inst.origin = (C.c_float * 3)(*origin); inst.two_sided = int(two_sided)
+        return len(self.instances) - 1
+
+    def add_mesh_instance(self, mesh, material=None, transform=None):
+        inst = self._instance(api.SHAPE_MESH, material, transform)
+        inst.mesh = mesh
+        return len(self.instances) - 1
+
+    def add_camera(self, look_from, look_at, vfov, focal_distance=10.0, aperture_diameter=0.01, v_up=(0.0, 0.0, 1.0)):
+        self.cameras.append(api.Camera((C.c_float * 3)(*look_from), (C.c_float * 3)(*look_at), (C.c_float * 3)(*v_up),
+                                       vfov, focal_distance, aperture_diameter))
+        return len(self.cameras) - 1
+
+    def set_environment_constant(self, curve, strength):
+        self.environment.kind = api.ENV_CONSTANT
+        self.environment.curve = curve
+        self.environment.strength = strength
+
+    def set_environment_sun(self, curve, strength, angular_diameter, sun_direction):
+        self.environment.kind = api.ENV_SUN
+        self.environment.curve = curve
+        self.environment.strength = strength
+        self.environment.angular_diameter = angular_diameter
+        d = np.asarray(sun_direction, np.float64); d = d / np.linalg.norm(d)
+        self.environment.sun_direction = (C.c_float * 3)(*d.tolist())
+
+    # ---- flatten
+    def desc(self):
+        keep = {}
+
+        def arr(name, values, ctype):
+            n = max(len(values), 1)
+            a = (ctype * n)(*values) if len(values) else (ctype * n)()
+            keep[name] = a
+            return a
+
+        d = api.SceneDesc()
+        d.curve_count = len(self.curves); d.curves = arr("curves", self.curves, api.Curve)
+        cd = np.asarray(self.curve_data, np.float32); keep["cd"] = cd
+        d.curve_data_count = cd.size; d.curve_data = cd.ctypes.data_as(C.POINTER(C.c_float))
+        d.layer_count = len(self.layers); d.layers = arr("layers", self.layers, api.TextureLayer)
+        d.texstack_count = len(self.texstacks); d.texstacks = arr("texstacks", self.texstacks, api.TexStack)
+        td = np.asarray(self.texture_data, np.float32); keep["td"] = td
+        d.texture_data_count = td.size; d.texture_data = td.ctypes.data_as(C.POINTER(C.c_float))
+        d.material_count = len(self.materials); d.materials = arr("materials", self.materials, api.Material)
+        d.mesh_count = len(self.meshes); d.meshes = arr("meshes", self.meshes, api.Mesh)
+        vs = np.asarray(self.vertices, np.float32); keep["vs"] = vs
+        d.vertex_count = vs.size // 3; d.vertices = vs.ctypes.data_as(C.POINTER(C.c_float))
+        ix = np.asarray(self.indices, np.uint32); keep["ix"] = ix
+        d.index_count = ix.size; d.indices = ix.ctypes.data_as(C.POINTER(C.c_uint32))
+        ns = np.asarray(self.normals, np.float32); keep["ns"] = ns
+        d.normal_count = ns.size // 3; d.normals = ns.ctypes.data_as(C.POINTER(C.c_float))
+        fm = np.asarray(self.face_materials, np.uint32); keep["fm"] = fm
+        d.face_material_count = fm.size; d.face_materials = fm.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.instance_count = len(self.instances); d.instances = arr("instances", self.instances, api.Instance)
+        d.camera_count = len(self.cameras); d.cameras = arr("cameras", self.cameras, api.Camera)
+        d.environment = self.environment
+        d.env_sampling_probability = self.env_sampling_probability
+        return d, keep
+
+
+# =================================================================== library of named assets
+def add_library_curves(b, names):
+    """The subset of data/lib_curves.toml the benchmark scenes use."""
+    sp = _spectra()
+    for n in names:
+        if n in b.curve_names:
+            continue
+        if n == "flat_zero": b.curve_flat(n, 0.0)
+        elif n == "flat_one": b.curve_flat(n, 1.0)
+        elif n == "flat_78": b.curve_flat(n, 0.78)
+        elif n == "E5": b.curve_flat(n, 5.0)
+        elif n == "air_ior": b.curve_cauchy(n, 1.0002724293, 1.64748969205)
+        elif n in ("cornell_white", "cornell_green", "cornell_red", "cornell_light", "srgb_r", "srgb_g", "srgb_b"):
+            b.curve_tabulated(n, sp["tabulated"][n]["x"], sp["tabulated"][n]["y"])
+        elif n in ("gold_n", "gold_k", "copper_n", "copper_k"):
+            b.curve_tabulated(n, sp["tabulated"][n]["x"], sp["tabulated"][n]["y"], x_scale=1000.0)
+        elif n == "simple_sky_blue": b.curve_simple_spike(n, 500.0, 100.0, 100.0, 0.55)
+        elif n == "blackbody_5000k": b.curve_blackbody(n, 5000.0, 1.0)
+        elif n == "blackbody_3000k_x5": b.curve_blackbody(n, 3000.0, 5.0)
+        elif n == "fluorescent_x5":
+            l = sp["linear"]["fluorescent"]; b.curve_linear(n, l["start"], l["step"], l["y"], y_scale=5.0)
+        elif n == "xenon_x5":
+            l = sp["linear"]["xenon_lamp"]; b.curve_linear(n, l["start"], l["step"], l["y"], y_scale=5.0)
+        else:
+            raise KeyError(n)
+
+
+def add_library_material(b, name):
+    """The subset of data/lib_materials.toml (+ lib_textures.toml) the benchmark scenes use."""
+    if name in b.material_ids:
+        return b.material_ids[name]
+    if name.startswith("lambertian_"):
+        curve = {"lambertian_white": "cornell_white", "lambertian_green": "cornell_green", "lambertian_red": "cornell_red"}[name]
+        add_library_curves(b, [curve])
+        ts = b.texstack_texture1(name, b.curve(curve))  # Texture1 over single_pixel.png (1x1 white -> factor 1.0)
+        return b.material_lambertian(name, ts)
+    if name == "diffuse_light_cornell":
+        add_library_curves(b, ["cornell_light", "flat_78"])
+        return b.material_diffuse_light(name, b.curve("cornell_light"), b.curve("flat_78"), api.SIDED_REVERSE)
+    if name == "diffuse_light_flat_x5":
+        add_library_curves(b, ["E5", "flat_78"])
+        return b.material_diffuse_light(name, b.curve("E5"), b.curve("flat_78"), api.SIDED_DUAL)
+    if name == "sharp_light_fluorescent":
+        add_library_curves(b, ["fluorescent_x5", "flat_78"])
+        return b.material_sharp_light(name, b.curve("fluorescent_x5"), b.curve("flat_78"), 40.0, api.SIDED_REVERSE)
+    if name == "sharp_light":
+        add_library_curves(b, ["blackbody_5000k", "flat_78"])
+        return b.material_sharp_light(name, b.curve("blackbody_5000k"), b.curve("flat_78"), 400.0, api.SIDED_REVERSE)
+    ggx = {"ggx_glass": (0.0004, 1.4, 4500.0), "ggx_glass_rough": (0.2, 1.4, 4500.0),
+           "ggx_glass_dispersive": (0.0004, 1.4, 50000.0), "ggx_moissanite": (0.0004, 2.4, 34000.0)}
+    if name in ggx:
+        alpha, a, c = ggx[name]
+        add_library_curves(b, ["air_ior", "flat_zero"])
+        eta = b.curve_cauchy(name + ".eta", a, c)
+        return b.material_ggx(name, alpha, eta, b.curve("air_ior"), b.curve("flat_zero"))
+    metals = {"ggx_gold": ("gold", 0.004), "ggx_copper": ("copper", 0.002)}
+    if name in metals:
+        base, alpha = metals[name]
+        add_library_curves(b, ["air_ior", base + "_n", base + "_k"])
+        return b.material_ggx(name, alpha, b.curve(base + "_n"), b.curve("air_ior"), b.curve(base + "_k"))
+    raise KeyError(name)
+
+
+# =================================================================== benchmark scenes
+# The Cornell box measurements (Cornell University Program of Computer Graphics), millimetres, in the
+# original axes (x right-to-left, y up, z depth).  The reference's scene file places its camera and light
+# in metres with (x, y, z)_scene = (z, x, y)_cornell / 1000 (data/scenes/cornell_box.toml:13-38), and its
+# data/meshes/cornell_box.obj is absent from the tree, so the mesh is authored here.
+_CORNELL_QUADS = [
+    ("floor", "lambertian_white", [(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)]),
+    ("ceiling", "lambertian_white", [(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)]),
+    ("back_wall", "lambertian_white", [(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)]),
+    ("right_wall", "lambertian_green", [(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)]),
+    ("left_wall", "lambertian_red", [(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)]),
+    ("short_block", "lambertian_white", [
+        (130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114),
+        (290, 0, 114), (290, 165, 114), (240, 165, 272), (240, 0, 272),
+        (130, 0, 65), (130, 165, 65), (290, 165, 114), (290, 0, 114),
+        (82, 0, 225), (82, 165, 225), (130, 165, 65), (130, 0, 65),
+        (240, 0, 272), (240, 165, 272), (82, 165, 225), (82, 0, 225)]),
+    ("tall_block", "lambertian_white", [
+        (423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406),
+        (423, 0, 247), (423, 330, 247), (472, 330, 406), (472, 0, 406),
+        (472, 0, 406), (472, 330, 406), (314, 330, 456), (314, 0, 456),
+        (314, 0, 456), (314, 330, 456), (265, 330, 296), (265, 0, 296),
+        (265, 0, 296), (265, 330, 296), (423, 330, 247), (423, 0, 247)]),
+]
+
+
+def cornell_obj_text():
+    """The authored cornell_box.obj (+ usemtl names from data/lib_materials.toml), scene axes, metres."""
+    lines = ["# Cornell box, authored from the published measurements; metres; (x,y,z) = (depth, width, up)",
+             "mtllib cornell_box.mtl"]
+    nv = 0
+    for name, mtl, pts in _CORNELL_QUADS:
+        lines.append("o " + name)
+        lines.append("usemtl " + mtl)
+        uniq = []
+        for p in pts:
+            if p not in uniq:
+                uniq.append(p)
+        for (x, y, z) in uniq:
+            lines.append("v %.4f %.4f %.4f" % (z / 1000.0, x / 1000.0, y / 1000.0))
+        for q in range(0, len(pts), 4):
+            lines.append("f " + " ".join(str(nv + 1 + uniq.index(p)) for p in pts[q:q + 4]))
+        nv += len(uniq)
+    return "\n".join(lines) + "\n"
+
+
+def cornell_box():
+    """data/scenes/cornell_box.toml with the authored mesh: C1 / C2 / C5 of BASELINE.json."""
+    import tempfile
+    b = SceneBuilder()
+    add_library_curves(b, ["flat_zero"])
+    b.set_environment_constant(b.curve("flat_zero"), 0.0)
+    b.env_sampling_probability = 0.0
+    light = add_library_material(b, "diffuse_light_cornell")
+    for n in ("lambertian_green", "lambertian_red", "lambertian_white"):
+        add_library_material(b, n)
+    b.add_rect((0.105, 0.13), (0.278, 0.2795, 0.5487), "Z", False, light)
+    with tempfile.NamedTemporaryFile("w", suffix=".obj", delete=False) as f:
+        f.write(cornell_obj_text())
+        path = f.name
+    try:
+        models = load_obj(path)
+    finally:
+        os.unlink(path)
+    # mesh bundle "cornell_box;i": one instance per tobj model, material from the .mtl name (src/parsing/mod.rs:504-535)
+    for m in models:
+        p, n, f = m.arrays()
+        mesh = b.add_mesh(p, f, n, face_materials=b.material(m.material))
+        b.add_mesh_instance(mesh, None, None)
+    b.add_camera((-0.8, 0.278, 0.273), (0.0, 0.278, 0.273), 37.8, focal_distance=1.1, aperture_diameter=0.01)
+    return b
+
+
+def _npz_mesh(name):
+    z = np.load(os.path.join(_DATA, "meshes", name + ".npz"))
+    n = z["normals"]
+    return z["positions"], z["faces"], (n if n.shape[0] else None), str(z["material"])
+
+
+def cornell_gem():
+    """data/scenes/cornell_box_diamond_gem.toml (C3): env replaced by Constant 0 (its HDRI file is absent and
+    env_sampling_probability = 0)."""
+    b = SceneBuilder()
+    add_library_curves(b, ["flat_zero"])
+    b.set_environment_constant(b.curve("flat_zero"), 0.0)
+    b.env_sampling_probability = 0.0
+    light = add_library_material(b, "sharp_light_fluorescent")
+    white = add_library_material(b, "lambertian_white")
+    red = add_library_material(b, "lambertian_red")
+    green = add_library_material(b, "lambertian_green")
+    gem = add_library_material(b, "ggx_moissanite")
+    b.add_rect((0.4, 0.4), (0.0, 0.0, 0.9), "Z", False, light)
+    b.add_rect((2, 2), (0.0, 0.0, 1.0), "Z", True, white)
+    b.add_rect((2, 2), (0.0, 0.0, -1.0), "Z", True, white)
+    b.add_rect((2, 2), (0.0, 1.0, 0.0), "Y", True, red)
+    b.add_rect((2, 2), (0.0, -1.0, 0.0), "Y", True, green)
+    b.add_rect((2, 2), (1.0, 0.0, 0.0), "X", True, white)
+    p, f, n, mtl = _npz_mesh("brilliant_diamond")
+    mesh = b.add_mesh(p, f, n, face_materials=b.material(mtl))
+    b.add_mesh_instance(mesh, gem, transform_from_data(scale=(0.5, 0.5, 0.5), translate=(0.0, 0.0, -0.7)))
+    b.add_camera((-5.0, 0.0, 0.0), (0.0, 0.0, 0.0), 27.8, focal_distance=5.0, aperture_diameter=0.02)
+    return b
+
+
+def white_furnace(material="ggx_glass_rough"):
+    """data/scenes/white_furnace.toml: camera inside a non-absorbing sphere in a constant environment."""
+    b = SceneBuilder()
+    add_library_curves(b, ["simple_sky_blue"])
+    b.set_environment_constant(b.curve("simple_sky_blue"), 1.0)
+    b.env_sampling_probability = 1.0
+    m = add_library_material(b, material)
+    b.add_sphere(1.0, (0.0, 0.0, 0.0), m)
+    b.add_camera((0.5, 0.0, 0.0), (0.0, 0.0, 0.0), 70.4, focal_distance=0.5, aperture_diameter=0.001)
+    return b
+
+
+def mixed_primitives():
+    """A small scene that exercises every primitive kind, transforms, metals and a dual-sided light
+    (parity-test coverage for Instance/Aggregate dispatch; not a reference scene)."""
+    b = SceneBuilder()
+    add_library_curves(b, ["simple_sky_blue"])
+    b.set_environment_constant(b.curve("simple_sky_blue"), 0.3)
+    b.env_sampling_probability = 0.25
+    light = add_library_material(b, "diffuse_light_flat_x5")
+    white = add_library_material(b, "lambertian_white")
+    red = add_library_material(b, "lambertian_red")
+    gold = add_library_material(b, "ggx_gold")
+    glass = add_library_material(b, "ggx_glass_rough")
+    b.add_rect((6, 6), (0.0, 0.0, -1.0), "Z", True, white)
+    b.add_rect((1.0, 1.0), (0.0, 0.0, 2.5), "Z", True, light)
+    b.add_disk(0.7, (0.0, 0.0, 0.0), True, light,
+               transform_from_data(rotate=[((0, 1, 0), 70.0)], translate=(2.0, 1.5, 1.0)))
+    b.add_sphere(0.6, (0.0, -1.2, -0.4), gold)
+    b.add_sphere(0.5, (0.0, 0.0, 0.0), glass, transform_from_data(scale=(1.0, 1.4, 0.8), translate=(0.3, 1.1, -0.3)))
+    b.add_rect((2.0, 3.0), (0.0, 2.5, 0.5), "Y", True, red)
+    p, f, n, mtl = _npz_mesh("gem")
+    mesh = b.add_mesh(p, f, n, face_materials=api.material_id(api.TAG_MATERIAL, 0))
+    b.add_mesh_instance(mesh, glass, transform_from_data(scale=(0.5, 0.5, 0.5), rotate=[((0, 0, 1), 30.0), ((1, 0, 0), 15.0)],
+                                                         translate=(-0.8, 0.0, -0.5)))
+    b.add_camera((-5.0, 0.3, 0.8), (0.0, 0.0, 0.0), 35.0, focal_distance=5.0, aperture_diameter=0.05)
+    return b
+
+
+SCENES = {"cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
+          "mixed_primitives": mixed_primitives}
