@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the PT hot path on the BASELINE.json headline workload (C2: Cornell box 1024x1024,
+max_bounces = 8, PT + NEE, L = 2), one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the wavefront pipeline over this rank's film shard at `--spp-per-step` x N samples per pixel
+(weak scaling: tiles are dealt round-robin to ranks, every rank renders 1/N of the pixels at N times the samples, so
+per-GPU work is fixed).  Scene upload, BVH build and buffer allocation happen before the timed region (the window of
+src/renderer/tiled.rs:294 -> 536); the film stays in HBM.  After the last step the rank films are summed into rank 0
+with one RCCL reduce (disjoint shards, so the sum is a gather) inside the timed region.
+
+Prints ONE JSON line on rank 0 with `roofline` (HIP-event time of the dominant kernel, measured inside the timed
+region by the engine) and `cpu_baseline` (the oracle on the host cores, bounded sample).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+STAGES = ["generate", "extend", "shade", "shadow", "accumulate"]
+
+
+def algorithmic_bytes(stage, light_samples):
+    """HBM bytes one work item of a stage must move (each field read once by its consumer / written once by its
+    producer; DESIGN.md 'Algorithmic bytes').  4-byte fields."""
+    path, hit = 16 * 4, 11 * 4
+    if stage == "generate":
+        return path + 4 + 4                       # write path state + zero energy, read pixel id
+    if stage == "extend":
+        return 6 * 4 + hit                        # read ray (o, d), write hit record
+    if stage == "shade":
+        return path + hit + 4 + path + (3 + 7 * light_samples) * 4   # read state + hit + pixel id, write next state + light-sample item
+    if stage == "shadow":
+        return (3 + 7 * light_samples) * 4 + 8   # read item, read-modify-write the slot energy
+    return 16 * 2                                 # accumulate: film pixel read-modify-write (energy reads are per sample, added below)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=30, help="samples per pixel per step and per GPU")
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--max-bounces", type=int, default=8)
+    ap.add_argument("--light-samples", type=int, default=2)
+    ap.add_argument("--scene", default="cornell_box")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+
+    pkg = importlib.import_module("rust-pathtracer_amd")
+    engine = pkg.load()
+    builder = pkg.scene.SCENES[args.scene]()
+    scene = engine.create_scene(builder)
+
+    W, H, L = args.width, args.height, args.light_samples
+    S = args.spp_per_step * n_gpus                  # weak scaling: N x the samples on 1/N of the pixels
+    total_spp = S * (args.steps + args.warmup)
+    assert total_spp <= 65535 * 16
+    film_step = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    film_total = torch.zeros_like(film_step)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k):
+        rd = pkg.api.render_desc(W, H, total_spp, args.max_bounces, min_bounces=1, light_samples=L, seed=1,
+                                 shard=(rank, n_gpus) if n_gpus > 1 else (0, 0), first_sample=k * S, sample_count=S)
+        prof = scene.render_device(rd, film_step.data_ptr(), stream)
+        film_total.add_(film_step)
+        return prof
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    t0 = time.perf_counter()
+    profs = [step(args.warmup + k) for k in range(args.steps)]
+    if world > 1:
+        dist.reduce(film_total, dst=0, op=dist.ReduceOp.SUM)   # RCCL over xGMI: the only exchange step
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # whole-job units: every rank rendered (pixels / N) x (S = spp_per_step x N) samples per step
+    shard_pixels = sum(p.stage_items[4] for p in profs) / max(1, len(profs))
+    samples_rank = sum(p.camera_rays for p in profs)
+    counts = torch.tensor([samples_rank] + [sum(p.stage_items[i] for p in profs) for i in range(5)] +
+                          [sum(p.bounce_rays for p in profs), sum(p.shadow_rays for p in profs)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    total_samples = float(counts[0].item())
+    value = total_samples / elapsed / 1e6
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (rank 0's own launches, HIP events inside the timed region)
+        ksec = [sum(p.kernel_seconds[i] for p in profs) for i in range(5)]
+        klaunch = [sum(p.kernel_launches[i] for p in profs) for i in range(5)]
+        kitems = [sum(p.stage_items[i] for p in profs) for i in range(5)]
+        dom = max(range(5), key=lambda i: ksec[i])
+        per_item = [algorithmic_bytes(s, L) for s in STAGES]
+        kbytes = [per_item[i] * kitems[i] for i in range(5)]
+        kbytes[4] += 4 * sum(p.camera_rays for p in profs)          # accumulate also reads one energy per sample
+        kernels = {}
+        for i, s in enumerate(STAGES):
+            if klaunch[i]:
+                kernels[s] = {"launches": klaunch[i], "avg_us": 1e6 * ksec[i] / klaunch[i], "items_per_launch": kitems[i] / klaunch[i],
+                              "bytes_per_item": per_item[i], "achieved_GBs": (kbytes[i] / ksec[i] / 1e9) if ksec[i] > 0 else None}
+        achieved = kbytes[dom] / ksec[dom] / 1e9 if ksec[dom] > 0 else 0.0
+        cam = sum(p.camera_rays for p in profs)
+        segs = kitems[1]
+        d_bar = segs / cam if cam else 0.0
+        roofline = {"bound": "hbm", "kernel": "k_" + STAGES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_us": 1e6 * ksec[dom] / klaunch[dom], "algorithmic_bytes_per_launch": kbytes[dom] / klaunch[dom],
+                    "device_time_share": ksec[dom] / sum(ksec) if sum(ksec) > 0 else None,
+                    "whole_pipeline": {"bytes_per_sample": sum(kbytes) / cam if cam else None, "segments_per_sample": d_bar,
+                                       "achieved_GBs": sum(kbytes) / elapsed / 1e9, "frac": sum(kbytes) / elapsed / 1e9 / HBM_PEAK_GBS},
+                    "kernels": kernels,
+                    "note": "latency/VALU-bound by construction: the scene (%d B) is LDS-resident, HBM only carries the queues" % engine.lib.pt_debug_scene_info(scene.handle, 0)}
+
+        # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
+        cpu = None
+        if args.cpu_seconds > 0:
+            import oracle_loader
+            oracle = oracle_loader.load(pkg)
+            oscene = oracle.create_scene(builder)
+            cores = os.cpu_count() or 1
+            probe = pkg.api.render_desc(W, H, 1, args.max_bounces, min_bounces=1, light_samples=L, seed=1, shard=(0, 256))
+            t = time.perf_counter(); _, pp = oscene.render(probe); dt = time.perf_counter() - t
+            rate = pp.camera_rays / dt
+            budget = rate * args.cpu_seconds
+            shard_count = max(1, int((W * H) / max(budget, 1.0)) + 1) if budget < W * H else 1
+            spp = max(1, int(budget / (W * H))) if shard_count == 1 else 1
+            rdc = pkg.api.render_desc(W, H, spp, args.max_bounces, min_bounces=1, light_samples=L, seed=1, shard=(0, shard_count) if shard_count > 1 else (0, 0))
+            t = time.perf_counter(); _, pc = oscene.render(rdc); dt = time.perf_counter() - t
+            cpu = {"value": pc.camera_rays / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+                   "sample": "oracle (C++ restatement of the reference PT path, std::thread over 32x32 tiles) on %d host threads: "
+                             "tiles t %% %d == 0 of the %dx%d film at %d spp = %d samples in %.1f s; Rust reference not buildable here"
+                             % (cores, shard_count, W, H, spp, pc.camera_rays, dt),
+                   "rays_per_sample": (pc.bounce_rays + pc.shadow_rays) / max(1, pc.camera_rays)}
+
+        out = {
+            "metric": "Msamples/s (paths x spp / s), Cornell box %dx%d, max_bounces=%d" % (W, H, args.max_bounces),
+            "value": value, "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: Cornell box (authored mesh + reference light/camera), %dx%d, PT+NEE, max_bounces=%d, min_bounces=1, "
+                                   "light_samples=%d, wavelengths 380-750 nm" % (W, H, args.max_bounces, L),
+                       "scene": args.scene, "spp_per_step_per_gpu": args.spp_per_step, "spp_per_step": S, "samples_per_step": total_samples / args.steps,
+                       "parallelism": "film tiles 32x32 round-robin over %d GPU(s), one RCCL reduce of the XYZ film" % n_gpus,
+                       "device": engine.device_info()},
+            "rays_per_s": {"segments": float(counts[2].item()) / elapsed, "shadow": float(counts[7].item()) / elapsed,
+                           "total_Mrays": (float(counts[2].item()) + float(counts[7].item())) / elapsed / 1e6},
+            "segments_per_sample": float(counts[2].item()) / total_samples,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -208,6 +208,8 @@ typedef struct pt_profile {      /* Profile (src/profile.rs:2-8) + timing */
     double seconds;              /* render loop only: the window of src/renderer/tiled.rs:294 -> :536 */
     double kernel_seconds[8];    /* HIP-event time per stage: generate, extend, shade, shadow, accumulate, 3 spare */
     uint64_t kernel_launches[8];
+    uint64_t stage_items[8];     /* work items per stage summed over launches: paths generated, segments extended,
+                                    vertices shaded, light-sample items traced, pixels accumulated */
 } pt_profile;
 
 typedef struct pt_hit {          /* HitRecord (src/hittable.rs:7-16) */

@@ -31,7 +31,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__) || defined(__CUDACC__)
-#define PT_HD __host__ __device__ __forceinline__
+#define PT_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define PT_HD static inline
 #endif

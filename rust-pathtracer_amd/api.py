@@ -101,12 +101,12 @@ class RenderDesc(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("bounce_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("light_rays", C.c_uint64),
                 ("camera_rays", C.c_uint64), ("env_hits", C.c_uint64), ("seconds", C.c_double),
-                ("kernel_seconds", C.c_double * 8), ("kernel_launches", C.c_uint64 * 8)]
+                ("kernel_seconds", C.c_double * 8), ("kernel_launches", C.c_uint64 * 8), ("stage_items", C.c_uint64 * 8)]
 
     def as_dict(self):
         return {"bounce_rays": self.bounce_rays, "shadow_rays": self.shadow_rays, "light_rays": self.light_rays,
                 "camera_rays": self.camera_rays, "env_hits": self.env_hits, "seconds": self.seconds,
-                "kernel_seconds": list(self.kernel_seconds), "kernel_launches": list(self.kernel_launches)}
+                "kernel_seconds": list(self.kernel_seconds), "kernel_launches": list(self.kernel_launches), "stage_items": list(self.stage_items)}
 
 
 class Hit(C.Structure):

@@ -1,0 +1,90 @@
+// pt_blob.h — layout of the flattened scene ("blob") the HIP kernels read.
+//
+// The whole scene except bulk texture texels is one array of 32-bit words, 16-byte aligned sections,
+// addressed by word offsets from a header.  One layout, two homes: HBM, and — when it fits — a copy
+// staged into LDS by every workgroup (Cornell: ~7 KB, brilliant-cut gem scene: ~45 KB), so BVH nodes,
+// primitives, material records and spectral curve tables are read with ds_read instead of going to L2.
+//
+// Geometry keeps the reference's two-level structure (top-level BVH over Instances, per-mesh BVH over
+// triangles, rays transformed into instance space; src/accelerator/mod.rs:86-178, src/geometry/mesh.rs:314-360,
+// src/geometry/instance.rs:75-133) because hit distances, points and normals computed in instance space
+// differ in the last bits from a world-space bake, and path decisions must match the oracle bit for bit.
+#ifndef PT_BLOB_H
+#define PT_BLOB_H
+#include <stdint.h>
+
+#define PT_BLOB_MAGIC 0x50544231u /* "PTB1" */
+#define PT_NODE_INNER 0xffffffffu
+
+// A BVH node: two float4.  a = (min.xyz, bits(exit)), b = (max.xyz, bits(shape or PT_NODE_INNER)).
+// Pre-order array with skip links (src/accelerator/lbvh.rs:16-45): an inner node that is hit continues at
+// index + 1, otherwise (and after a leaf) at `exit`.  The reference's flat array has a "navigator" node in
+// front of every leaf carrying the same box the leaf test recomputes; both are merged into the leaf here.
+#define PT_NODE_WORDS 8
+
+// Triangle: three float4: (p0.xyz, bits(material)), (p1.xyz, 0), (p2.xyz, 0); optional normals: three float4.
+#define PT_TRI_WORDS 12
+
+// Mesh record (8 words): node_off (float4 units... all offsets are WORD offsets), node_count, tri_off, normal_off
+// (0 = none), face_count, pad x3
+#define PT_MESH_WORDS 8
+#define PT_MESH_NODE_OFF 0
+#define PT_MESH_NODE_COUNT 1
+#define PT_MESH_TRI_OFF 2
+#define PT_MESH_NORMAL_OFF 3
+#define PT_MESH_FACE_COUNT 4
+
+// Instance record (40 words).
+#define PT_INST_WORDS 40
+#define PT_INST_KIND 0
+#define PT_INST_FLAGS 1      /* bit0 has_transform, bit1 two_sided, bits 2-3 axis */
+#define PT_INST_MATERIAL 2   /* packed MaterialId or PT_MATERIAL_NONE */
+#define PT_INST_MESH 3       /* word offset of the mesh record */
+#define PT_INST_ORIGIN 4     /* 3 floats */
+#define PT_INST_RADIUS 7
+#define PT_INST_SIZE 8       /* 2 floats */
+#define PT_INST_FORWARD 16   /* 12 floats: rows 0..2 of the 4x4 */
+#define PT_INST_REVERSE 28   /* 12 floats */
+
+// Material record (12 words).
+#define PT_MAT_WORDS 12
+#define PT_MAT_KIND 0
+#define PT_MAT_TEXSTACK 1    /* word offset of texstack record */
+#define PT_MAT_ALPHA 2
+#define PT_MAT_ETA 3         /* word offsets of curve records */
+#define PT_MAT_ETA_O 4
+#define PT_MAT_KAPPA 5
+#define PT_MAT_EMIT 6
+#define PT_MAT_BOUNCE 7
+#define PT_MAT_SHARPNESS 8   /* already 1 + |s| */
+#define PT_MAT_SIDEDNESS 9
+#define PT_MAT_METALLIC 10
+
+// Curve record (8 words): kind, mode, p0, p1, data_off (word offset), data_count, pad, pad
+#define PT_CURVE_WORDS 8
+// Texstack record: layer_count, then per layer 8 words: kind, curve0..3 (word offsets), width, height, texel offset (floats, into texture memory)
+#define PT_LAYER_WORDS 8
+
+// Header (64 words)
+#define PT_HDR_WORDS 64
+#define PT_HDR_MAGIC 0
+#define PT_HDR_TOTAL_WORDS 1
+#define PT_HDR_TOP_NODE_OFF 2
+#define PT_HDR_TOP_NODE_COUNT 3
+#define PT_HDR_INSTANCE_OFF 4
+#define PT_HDR_INSTANCE_COUNT 5
+#define PT_HDR_MATERIAL_OFF 6
+#define PT_HDR_MATERIAL_COUNT 7
+#define PT_HDR_LIGHT_OFF 8        /* u32 instance ids */
+#define PT_HDR_LIGHT_COUNT 9
+#define PT_HDR_ENV_KIND 10
+#define PT_HDR_ENV_STRENGTH 11
+#define PT_HDR_ENV_CURVE 12       /* word offset */
+#define PT_HDR_ENV_ANGULAR 13
+#define PT_HDR_ENV_SUN_DIR 14     /* 3 floats */
+#define PT_HDR_ENV_PROB 17        /* get_env_sampling_probability() */
+#define PT_HDR_WORLD_RADIUS 18
+#define PT_HDR_CURVE_OFF 19
+#define PT_HDR_CURVE_COUNT 20
+
+#endif

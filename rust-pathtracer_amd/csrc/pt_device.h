@@ -1,0 +1,757 @@
+// pt_device.h — per-lane device logic of the HIP path tracer (gfx950).
+//
+// Everything a single lane computes: scene-blob accessors, ray/primitive tests with the reference's
+// interval rules, the two-level skip-link BVH walk, spectral curve evaluation, the four materials,
+// light sampling and the thin-lens camera.  The kernels in pt_kernels.hip are thin: they stage the
+// blob into LDS, move SoA state between HBM and registers, call these functions, and compact queues.
+//
+// All functions are __host__ __device__ so tests can run the same lane logic on the CPU
+// (tests/host_emulation) before it is trusted on the GPU; the shipped library only uses the device side.
+//
+// Arithmetic rules (include/pt_numerics.h): no contraction, IEEE division and sqrt, transcendental
+// functions only from pt_numerics.h, expressions written in the operation order documented in
+// DESIGN.md "numeric contract" so that path decisions match the CPU oracle bit for bit.
+//
+// Reference citations are relative to /root/reference (gillett-hernandez/rust-pathtracer @ 2024_08_07).
+#ifndef PT_DEVICE_H
+#define PT_DEVICE_H
+
+#include "../../include/pt_api.h"
+#include "../../include/pt_numerics.h"
+#include "pt_blob.h"
+
+namespace ptd {
+
+struct F3 { float x, y, z; };
+struct alignas(16) F4 { float x, y, z, w; };
+
+PT_HD F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_HD F3 add(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_HD F3 sub(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_HD F3 neg(F3 a) { return f3(-a.x, -a.y, -a.z); }
+PT_HD F3 mul(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+PT_HD F3 divs(F3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+PT_HD float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_HD F3 cross(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+PT_HD float norm(F3 a) { return pt_sqrt(dot(a, a)); }
+PT_HD F3 normalize(F3 a) { return divs(a, norm(a)); }
+
+// ---------------------------------------------------------------- blob access
+struct SceneView {
+    const uint32_t* w;  // blob words: LDS copy or HBM
+    const float* tex;   // texture texels, HBM
+};
+PT_HD uint32_t bu(const SceneView& s, uint32_t off) { return s.w[off]; }
+PT_HD float bf(const SceneView& s, uint32_t off) { return pt_u2f(s.w[off]); }
+PT_HD F4 bf4(const SceneView& s, uint32_t off) { return *reinterpret_cast<const F4*>(s.w + off); }
+PT_HD F3 bf3(const SceneView& s, uint32_t off) { return f3(bf(s, off), bf(s, off + 1), bf(s, off + 2)); }
+
+// TangentFrame::from_normal (math crate): Duff et al. 2017.
+struct Frame { F3 t, b, n; };
+PT_HD Frame frame_from_normal(F3 n) {
+    float sign = (pt_f2u(n.z) & 0x80000000u) ? -1.0f : 1.0f;
+    float a = -1.0f / (sign + n.z);
+    float b = n.x * n.y * a;
+    Frame f;
+    f.t = f3(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
+    f.b = f3(b, sign + n.y * n.y * a, -n.y);
+    f.n = n;
+    return f;
+}
+PT_HD F3 to_world(const Frame& f, F3 v) { return add(add(mul(f.t, v.x), mul(f.b, v.y)), mul(f.n, v.z)); }
+PT_HD F3 to_local(const Frame& f, F3 v) { return f3(dot(f.t, v), dot(f.b, v), dot(f.n, v)); }
+
+// rows 0..2 of a 4x4 at word offset `m`
+PT_HD F3 xf_point(const SceneView& s, uint32_t m, F3 p) {
+    return f3(bf(s, m + 0) * p.x + bf(s, m + 1) * p.y + bf(s, m + 2) * p.z + bf(s, m + 3),
+              bf(s, m + 4) * p.x + bf(s, m + 5) * p.y + bf(s, m + 6) * p.z + bf(s, m + 7),
+              bf(s, m + 8) * p.x + bf(s, m + 9) * p.y + bf(s, m + 10) * p.z + bf(s, m + 11));
+}
+PT_HD F3 xf_vec(const SceneView& s, uint32_t m, F3 v) {
+    return f3(bf(s, m + 0) * v.x + bf(s, m + 1) * v.y + bf(s, m + 2) * v.z,
+              bf(s, m + 4) * v.x + bf(s, m + 5) * v.y + bf(s, m + 6) * v.z,
+              bf(s, m + 8) * v.x + bf(s, m + 9) * v.y + bf(s, m + 10) * v.z);
+}
+PT_HD F3 xf_vec_transposed(const SceneView& s, uint32_t m, F3 v) {
+    return f3(bf(s, m + 0) * v.x + bf(s, m + 4) * v.y + bf(s, m + 8) * v.z,
+              bf(s, m + 1) * v.x + bf(s, m + 5) * v.y + bf(s, m + 9) * v.z,
+              bf(s, m + 2) * v.x + bf(s, m + 6) * v.y + bf(s, m + 10) * v.z);
+}
+
+// ---------------------------------------------------------------- spectral curves (math::curves::Curve::evaluate)
+PT_HD float gaussianf32(float x, float alpha, float mu, float s1, float s2) {
+    float t = (x - mu) / (x < mu ? s1 : s2);
+    return alpha * pt_exp(-(t * t) / 2.0f);
+}
+PT_HD float blackbody(float temperature, float lambda_nm) {
+    float l = lambda_nm * 1e-9f;
+    float l2 = l * l;
+    float l5 = l2 * l2 * l;
+    return (1.0f / l5) * 1.1910429723971884140794892e-29f /
+           (pt_exp(1.438777085924334052222404423195819240925e-2f / (l * temperature)) - 1.0f);
+}
+PT_HD float interp(uint32_t mode, float t, float left, float right) {
+    if (mode == PT_INTERP_LINEAR) return (1.0f - t) * left + t * right;
+    if (mode == PT_INTERP_NEAREST) return t < 0.5f ? left : right;
+    float t2 = 2.0f * t;
+    float omt = 1.0f - t;
+    float h00 = (1.0f + t2) * omt * omt;
+    float h01 = t * t * (3.0f - t2);
+    return h00 * left + h01 * right;
+}
+PT_HD float curve_eval(const SceneView& s, uint32_t c, float lambda) {
+    uint32_t kind = bu(s, c), mode = bu(s, c + 1);
+    float p0 = bf(s, c + 2), p1 = bf(s, c + 3);
+    uint32_t d = bu(s, c + 4), n = bu(s, c + 5);
+    switch (kind) {
+        case PT_CURVE_LINEAR: {
+            if (lambda < p0 || lambda > p1) return 0.0f;
+            float step = (p1 - p0) / (float)n;
+            float fi = (lambda - p0) / step;
+            uint32_t index = (fi >= 0.0f) ? (uint32_t)fi : 0u;
+            if (index >= n) index = n - 1;
+            float left = bf(s, d + index);
+            if (index + 1 >= n) return left;
+            float right = bf(s, d + index + 1);
+            float t = (lambda - (p0 + (float)index * step)) / step;
+            return interp(mode, t, left, right);
+        }
+        case PT_CURVE_TABULATED: {
+            uint32_t lo = 0, hi = n;
+            while (lo < hi) {
+                uint32_t mid = lo + (hi - lo) / 2;
+                if (bf(s, d + 2 * mid) < lambda) lo = mid + 1; else hi = mid;
+            }
+            if (lo == n) return bf(s, d + 2 * (n - 1) + 1);
+            if (lo == 0) return bf(s, d + 1);
+            float lx = bf(s, d + 2 * (lo - 1)), ly = bf(s, d + 2 * (lo - 1) + 1);
+            float rx = bf(s, d + 2 * lo), ry = bf(s, d + 2 * lo + 1);
+            float t = (lambda - lx) / (rx - lx);
+            return interp(mode, t, ly, ry);
+        }
+        case PT_CURVE_CAUCHY: return p0 + p1 / (lambda * lambda);
+        case PT_CURVE_EXPONENTIAL: {
+            float val = 0.0f;
+            for (uint32_t i = 0; i < n; ++i)
+                val += gaussianf32(lambda, bf(s, d + 4 * i + 3), bf(s, d + 4 * i), bf(s, d + 4 * i + 1), bf(s, d + 4 * i + 2));
+            return val;
+        }
+        case PT_CURVE_INV_EXPONENTIAL: {
+            float val = 1.0f;
+            for (uint32_t i = 0; i < n; ++i)
+                val -= gaussianf32(lambda, bf(s, d + 4 * i + 3), bf(s, d + 4 * i), bf(s, d + 4 * i + 1), bf(s, d + 4 * i + 2));
+            return pt_max(val, 0.0f);
+        }
+        case PT_CURVE_BLACKBODY: {
+            if (p1 == 0.0f) return blackbody(p0, lambda);
+            return p1 * blackbody(p0, lambda) / blackbody(p0, 2.8977721e-3f / (p0 * 1e-9f));
+        }
+        case PT_CURVE_CONST: return pt_max(p0, 0.0f);
+        default: return 0.0f;
+    }
+}
+
+// TexStack::eval_at (src/texture.rs:258-265), nearest texel (src/vec2d.rs:34-42)
+PT_HD float texstack_eval(const SceneView& s, uint32_t ts, float lambda, float u, float v) {
+    uint32_t layers = bu(s, ts);
+    float energy = 0.0f;
+    for (uint32_t i = 0; i < layers; ++i) {
+        uint32_t l = ts + 1 + i * PT_LAYER_WORDS;
+        uint32_t kind = bu(s, l), w = bu(s, l + 5), h = bu(s, l + 6), toff = bu(s, l + 7);
+        float cu = pt_clamp(u, 0.0f, 1.0f - PT_F32_EPSILON), cv = pt_clamp(v, 0.0f, 1.0f - PT_F32_EPSILON);
+        uint32_t x = (uint32_t)(cu * (float)w), y = (uint32_t)(cv * (float)h);
+        uint32_t idx = y * w + x;
+        if (kind == PT_TEXTURE1) {
+            energy += curve_eval(s, bu(s, l + 1), lambda) * s.tex[toff + idx];
+        } else {
+            const float* t = s.tex + toff + 4u * idx;
+            float e0 = curve_eval(s, bu(s, l + 1), lambda) * t[0], e1 = curve_eval(s, bu(s, l + 2), lambda) * t[1];
+            float e2 = curve_eval(s, bu(s, l + 3), lambda) * t[2], e3 = curve_eval(s, bu(s, l + 4), lambda) * t[3];
+            energy += (e0 + e1) + (e2 + e3);
+        }
+    }
+    return energy;
+}
+
+// ---------------------------------------------------------------- intersection
+struct Hit {
+    float t; F3 p, n; float u, v; uint32_t material, instance; bool valid;
+};
+
+// AABB::hit (src/aabb.rs:37-65) for the (t0, t1) = (0, inf) every caller on this path passes: slab test clipped
+// against t >= 0 by the w lane (d.w = 0 -> tmin 0, tmax inf).  The second rejection test of the reference is
+// implied by the first for these bounds.
+PT_HD bool aabb_hit(F4 a, F4 b, F3 o, F3 d) {
+    float n0, x0, n1, x1, n2, x2;
+    if (d.x == 0.0f) { n0 = 0.0f; x0 = PT_INF; } else { float p = (a.x - o.x) / d.x, q = (b.x - o.x) / d.x; n0 = __builtin_fminf(p, q); x0 = __builtin_fmaxf(p, q); }
+    if (d.y == 0.0f) { n1 = 0.0f; x1 = PT_INF; } else { float p = (a.y - o.y) / d.y, q = (b.y - o.y) / d.y; n1 = __builtin_fminf(p, q); x1 = __builtin_fmaxf(p, q); }
+    if (d.z == 0.0f) { n2 = 0.0f; x2 = PT_INF; } else { float p = (a.z - o.z) / d.z, q = (b.z - o.z) / d.z; n2 = __builtin_fminf(p, q); x2 = __builtin_fmaxf(p, q); }
+    float tmin_max = __builtin_fmaxf(__builtin_fmaxf(n0, n1), __builtin_fmaxf(n2, 0.0f));
+    float tmax_min = __builtin_fminf(__builtin_fminf(x0, x1), x2);
+    return !(tmin_max > tmax_min);
+}
+
+// MeshTriangleRef::hit (src/geometry/mesh.rs:67-198), split: the interval test here, the HitRecord later for
+// the triangle that survives as closest.
+struct TriHit { float t, b0, b1, b2; };
+PT_HD F3 tri_shuffle(F3 v, uint32_t m) {
+    if (m == 0) return f3(v.y, v.z, v.x);
+    if (m == 1) return f3(v.z, v.x, v.y);
+    return v;
+}
+PT_HD bool triangle_test(F3 p0, F3 p1, F3 p2, F3 o, F3 dir, float t0, float t1, TriHit* out) {
+    F3 p0t = sub(p0, o), p1t = sub(p1, o), p2t = sub(p2, o);
+    float ax = pt_abs(dir.x), ay = pt_abs(dir.y), az = pt_abs(dir.z);
+    float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), __builtin_fmaxf(az, 0.0f));
+    uint32_t kz = 0;
+    if (ax >= mx) kz = 0;
+    if (ay >= mx) kz = 1;
+    if (az >= mx) kz = 2;
+    if (0.0f >= mx) kz = 3;
+    F3 d = tri_shuffle(dir, kz);
+    p0t = tri_shuffle(p0t, kz); p1t = tri_shuffle(p1t, kz); p2t = tri_shuffle(p2t, kz);
+    float sx = -d.x / d.z, sy = -d.y / d.z, sz = 1.0f / d.z;
+    p0t.x += sx * p0t.z; p1t.x += sx * p1t.z; p2t.x += sx * p2t.z;
+    p0t.y += sy * p0t.z; p1t.y += sy * p1t.z; p2t.y += sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+        double a = (double)p2t.x * (double)p1t.y, b = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(b - a);
+        a = (double)p0t.x * (double)p2t.y; b = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(b - a);
+        a = (double)p1t.x * (double)p0t.y; b = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(b - a);
+    }
+    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0.0f) return false;
+    p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
+    float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if ((det < 0.0f && (t_scaled >= t0 * det || t_scaled < t1 * det)) ||
+        (det > 0.0f && (t_scaled <= t0 * det || t_scaled > t1 * det)))
+        return false;
+    float inv_det = 1.0f / det;
+    out->b0 = e0 * inv_det; out->b1 = e1 * inv_det; out->b2 = e2 * inv_det;
+    out->t = t_scaled * inv_det;
+    return true;
+}
+
+PT_HD F3 rect_shuffle(F3 v, uint32_t axis) {
+    if (axis == PT_AXIS_X) return f3(v.z, v.y, v.x);
+    if (axis == PT_AXIS_Y) return f3(v.x, v.z, v.y);
+    return v;
+}
+PT_HD F3 axis_vec(uint32_t axis) { return axis == PT_AXIS_X ? f3(1, 0, 0) : (axis == PT_AXIS_Y ? f3(0, 1, 0) : f3(0, 0, 1)); }
+
+// Mesh::hit (src/geometry/mesh.rs:314-360): skip-link walk over the per-mesh BVH, triangles tested in
+// traversal order against the running closest distance.
+PT_HD bool mesh_hit(const SceneView& s, uint32_t mesh, F3 o, F3 d, float t1, Hit* out) {
+    uint32_t node_off = bu(s, mesh + PT_MESH_NODE_OFF), node_count = bu(s, mesh + PT_MESH_NODE_COUNT);
+    uint32_t tri_off = bu(s, mesh + PT_MESH_TRI_OFF), normal_off = bu(s, mesh + PT_MESH_NORMAL_OFF);
+    float closest = t1; bool found = false; uint32_t best = 0; TriHit bh; bh.t = 0; bh.b0 = bh.b1 = bh.b2 = 0;
+    uint32_t i = 0;
+    while (i < node_count) {
+        F4 a = bf4(s, node_off + i * PT_NODE_WORDS), b = bf4(s, node_off + i * PT_NODE_WORDS + 4);
+        uint32_t exit_i = pt_f2u(a.w), shape = pt_f2u(b.w);
+        bool box = aabb_hit(a, b, o, d);
+        if (shape == PT_NODE_INNER) { i = box ? i + 1 : exit_i; continue; }
+        if (box) {
+            uint32_t t = tri_off + shape * PT_TRI_WORDS;
+            F4 q0 = bf4(s, t), q1 = bf4(s, t + 4), q2 = bf4(s, t + 8);
+            TriHit th;
+            if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), o, d, 0.0f, closest, &th)) {
+                closest = th.t; found = true; best = shape; bh = th;
+            }
+        }
+        i = exit_i;
+    }
+    if (!found) return false;
+    uint32_t t = tri_off + best * PT_TRI_WORDS;
+    F4 q0 = bf4(s, t), q1 = bf4(s, t + 4), q2 = bf4(s, t + 8);
+    F3 p0 = f3(q0.x, q0.y, q0.z), p1 = f3(q1.x, q1.y, q1.z), p2 = f3(q2.x, q2.y, q2.z);
+    F3 n = normalize(cross(sub(p0, p2), sub(p1, p2)));
+    if (normal_off != 0) {
+        uint32_t nn = normal_off + best * PT_TRI_WORDS;
+        F4 m0 = bf4(s, nn), m1 = bf4(s, nn + 4), m2 = bf4(s, nn + 8);
+        n = add(add(mul(f3(m0.x, m0.y, m0.z), bh.b0), mul(f3(m1.x, m1.y, m1.z), bh.b1)), mul(f3(m2.x, m2.y, m2.z), bh.b2));
+    }
+    out->t = bh.t;
+    out->p = add(add(mul(p0, bh.b0), mul(p1, bh.b1)), mul(p2, bh.b2));
+    out->u = 0.0f; out->v = 0.0f;
+    out->n = normalize(n);
+    out->material = pt_f2u(q0.w);
+    out->valid = true;
+    return true;
+}
+
+// Aggregate::hit for rect / sphere / disk (src/geometry/rect.rs:69-112, sphere.rs:34-87, disk.rs:31-62); tmax = inf on this path.
+PT_HD bool analytic_hit(const SceneView& s, uint32_t inst, uint32_t kind, F3 o, F3 d, float t1, Hit* out) {
+    uint32_t flags = bu(s, inst + PT_INST_FLAGS);
+    bool two_sided = (flags & 2u) != 0;
+    F3 origin = bf3(s, inst + PT_INST_ORIGIN);
+    const uint32_t mat0 = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0);
+    if (kind == PT_SHAPE_RECT) {
+        uint32_t axis = (flags >> 2) & 3u;
+        float s0 = bf(s, inst + PT_INST_SIZE), s1 = bf(s, inst + PT_INST_SIZE + 1);
+        F3 to = rect_shuffle(sub(o, origin), axis), td = rect_shuffle(d, axis);
+        if (td.z == 0.0f) return false;
+        float t = (-to.z) / td.z;
+        if (t <= 0.0f || t > t1 || t >= PT_INF) return false;
+        float xh = to.x + t * td.x, yh = to.y + t * td.y;
+        float hx = s0 / 2.0f, hy = s1 / 2.0f;
+        if (xh < -hx || xh > hx || yh < -hy || yh > hy) return false;
+        F3 n = axis_vec(axis);
+        if (two_sided && dot(d, n) > 0.0f) n = neg(n);
+        out->t = t; out->p = add(o, mul(d, t)); out->u = (xh + hx) / s0; out->v = (yh + hy) / s1;
+        out->n = normalize(n); out->material = mat0; out->valid = true;
+        return true;
+    }
+    if (kind == PT_SHAPE_SPHERE) {
+        float radius = bf(s, inst + PT_INST_RADIUS);
+        F3 oc = sub(o, origin);
+        float a = dot(d, d), b = dot(oc, d), c = dot(oc, oc) - radius * radius;
+        float disc = b * b - a * c;
+        if (!(disc > 0.0f)) return false;
+        float ds = pt_sqrt(disc);
+        float t = (-b - ds) / a;
+        if (!(t < t1 && t > 0.0f && t < PT_INF)) {
+            t = (-b + ds) / a;
+            if (!(t < t1 && t > 0.0f && t < PT_INF)) return false;
+        }
+        F3 p = add(o, mul(d, t));
+        out->t = t; out->p = p; out->u = 0.0f; out->v = 0.0f;
+        out->n = normalize(divs(sub(p, origin), radius)); out->material = mat0; out->valid = true;
+        return true;
+    }
+    // disk
+    float radius = bf(s, inst + PT_INST_RADIUS);
+    F3 to = sub(o, origin);
+    if (d.z == 0.0f) return false;
+    float t = (-to.z) / d.z;
+    if (t <= 0.0f || t > t1 || t >= PT_INF) return false;
+    float xh = to.x + t * d.x, yh = to.y + t * d.y;
+    if (xh * xh + yh * yh > radius * radius) return false;
+    F3 n = f3(0, 0, 1);
+    if (dot(d, n) > 0.0f && two_sided) n = neg(n);
+    out->t = t; out->p = add(o, mul(d, t)); out->u = 0.0f; out->v = 0.0f;
+    out->n = normalize(n); out->material = mat0; out->valid = true;
+    return true;
+}
+
+// Instance::hit (src/geometry/instance.rs:75-133)
+PT_HD bool instance_hit(const SceneView& s, uint32_t inst, uint32_t instance_id, F3 o, F3 d, float t1, Hit* out) {
+    uint32_t kind = bu(s, inst + PT_INST_KIND), flags = bu(s, inst + PT_INST_FLAGS);
+    bool xf = (flags & 1u) != 0;
+    F3 lo = o, ld = d;
+    if (xf) { lo = xf_point(s, inst + PT_INST_REVERSE, o); ld = xf_vec(s, inst + PT_INST_REVERSE, d); }
+    Hit h;
+    bool ok = (kind == PT_SHAPE_MESH) ? mesh_hit(s, bu(s, inst + PT_INST_MESH), lo, ld, t1, &h)
+                                      : analytic_hit(s, inst, kind, lo, ld, t1, &h);
+    if (!ok) return false;
+    if (xf) {
+        h.n = normalize(xf_vec_transposed(s, inst + PT_INST_REVERSE, h.n));
+        h.p = xf_point(s, inst + PT_INST_FORWARD, h.p);
+    }
+    h.instance = instance_id;
+    uint32_t m = bu(s, inst + PT_INST_MATERIAL);
+    if (m != PT_MATERIAL_NONE) h.material = m;
+    *out = h;
+    return true;
+}
+
+// World::hit(r, 0, inf) -> Accelerator::hit (src/accelerator/mod.rs:106-176) fused with FlatBVH::traverse
+// (src/accelerator/lbvh.rs:172-213): instances are tested in traversal order as their leaves are reached,
+// which is the order the reference's candidate list is processed in (its sort keys are all 0).
+PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out) {
+    uint32_t node_off = bu(s, PT_HDR_TOP_NODE_OFF), node_count = bu(s, PT_HDR_TOP_NODE_COUNT);
+    uint32_t inst_off = bu(s, PT_HDR_INSTANCE_OFF);
+    float closest = PT_INF; bool found = false;
+    uint32_t i = 0;
+    while (i < node_count) {
+        F4 a = bf4(s, node_off + i * PT_NODE_WORDS), b = bf4(s, node_off + i * PT_NODE_WORDS + 4);
+        uint32_t exit_i = pt_f2u(a.w), shape = pt_f2u(b.w);
+        bool box = aabb_hit(a, b, o, d);
+        if (shape == PT_NODE_INNER) { i = box ? i + 1 : exit_i; continue; }
+        if (box) {
+            Hit h;
+            if (instance_hit(s, inst_off + shape * PT_INST_WORDS, shape, o, d, closest, &h)) { closest = h.t; *out = h; found = true; }
+        }
+        i = exit_i;
+    }
+    if (!found) out->valid = false;
+    return found;
+}
+
+// ---------------------------------------------------------------- sampling helpers (math crate)
+PT_HD F3 random_cosine_direction(float u, float v) {
+    float z = pt_sqrt(1.0f - v);
+    float phi = 2.0f * PT_PI * u;
+    float sn, cs; pt_sincos(phi, &sn, &cs);
+    float r = pt_sqrt(v);
+    return f3(cs * r, sn * r, z);
+}
+PT_HD F3 random_on_unit_sphere(float x, float y) {
+    float phi = x * 2.0f * PT_PI;
+    float z = y * 2.0f - 1.0f;
+    float r = pt_sqrt(1.0f - z * z);
+    float sn, cs; pt_sincos(phi, &sn, &cs);
+    return f3(r * cs, r * sn, z);
+}
+PT_HD F3 random_in_unit_disk(float x, float y) {
+    float u = x * PT_PI * 2.0f;
+    float v = pt_sqrt(y);
+    float sn, cs; pt_sincos(u, &sn, &cs);
+    return f3(cs * v, sn * v, 0.0f);
+}
+// Sample1D::choose
+PT_HD bool choose_first(float* x, float split) {
+    if (*x < split) { *x = *x / split; return true; }
+    *x = (*x - split) / (1.0f - split);
+    return false;
+}
+PT_HD F3 uv_to_direction(float u, float v) {
+    float theta = (u - 0.5f) * 2.0f * PT_PI;
+    float phi = v * PT_PI;
+    float st, ct, sp, cp;
+    pt_sincos(theta, &st, &ct);
+    pt_sincos(phi, &sp, &cp);
+    return f3(sp * ct, sp * st, cp);
+}
+PT_HD void direction_to_uv(F3 d, float* u, float* v) {
+    float theta = pt_atan2(d.y, d.x);
+    float phi = pt_acos(d.z);
+    *u = theta / 2.0f / PT_PI + 0.5f;
+    *v = phi / PT_PI;
+}
+
+// ---------------------------------------------------------------- GGX (src/materials/ggx.rs:3-180)
+PT_HD F3 reflect(F3 wi, F3 n) { F3 w = neg(wi); return normalize(sub(w, mul(n, 2.0f * dot(w, n)))); }
+PT_HD bool refract(F3 wi, F3 n, float eta, F3* out) {
+    float cos_i = dot(wi, n);
+    float sin2_i = pt_max(1.0f - cos_i * cos_i, 0.0f);
+    float sin2_t = eta * eta * sin2_i;
+    if (sin2_t >= 1.0f) return false;
+    float cos_t = pt_sqrt(1.0f - sin2_t);
+    *out = normalize(add(mul(neg(wi), eta), mul(n, eta * cos_i - cos_t)));
+    return true;
+}
+PT_HD float fresnel_dielectric(float eta_i, float eta_t, float cos_i) {
+    cos_i = pt_clamp(cos_i, -1.0f, 1.0f);
+    if (cos_i < 0.0f) { cos_i = -cos_i; float t = eta_i; eta_i = eta_t; eta_t = t; }
+    float sin_t = eta_i / eta_t * pt_sqrt(pt_max(0.0f, 1.0f - cos_i * cos_i));
+    float cos_t = pt_sqrt(pt_max(0.0f, 1.0f - sin_t * sin_t));
+    float ei_ct = eta_i * cos_t, et_ci = eta_t * cos_i, ei_ci = eta_i * cos_i, et_ct = eta_t * cos_t;
+    float r_par = (et_ci - ei_ct) / (et_ci + ei_ct);
+    float r_perp = (ei_ci - et_ct) / (ei_ci + et_ct);
+    return (r_par * r_par + r_perp * r_perp) / 2.0f;
+}
+PT_HD float fresnel_conductor(float eta_i, float eta_t, float k_t, float c) {
+    c = pt_clamp(c, -1.0f, 1.0f);
+    if (c < 0.0f) { c = -c; float t = eta_i; eta_i = eta_t; eta_t = t; }
+    float eta = eta_t / eta_i, etak = k_t / eta_i;
+    float c2 = c * c, s2 = 1.0f - c2;
+    float eta2 = eta * eta, etak2 = etak * etak;
+    float t0 = eta2 - etak2 - s2;
+    float a2plusb2 = pt_sqrt(t0 * t0 + eta2 * etak2 * 4.0f);
+    float t1 = a2plusb2 + c2;
+    float a = pt_sqrt((a2plusb2 + t0) * 0.5f);
+    float t2 = a * c * 2.0f;
+    float rs = (t1 - t2) / (t1 + t2);
+    float t3 = a2plusb2 * c2 + s2 * s2;
+    float t4 = t2 * s2;
+    float rp = rs * (t3 - t4) / (t3 + t4);
+    return (rs + rp) / 2.0f;
+}
+PT_HD float ggx_d(float alpha, F3 wm) {
+    float sx = wm.x / alpha, sy = wm.y / alpha;
+    float t = wm.z * wm.z + sx * sx + sy * sy;
+    float a2 = alpha * alpha, t2 = t * t;
+    return 1.0f / (PT_PI * (a2 * t2));
+}
+PT_HD float ggx_lambda(float alpha, F3 w) {
+    if (w.z == 0.0f) return 0.0f;
+    float a2 = alpha * alpha;
+    float c = 1.0f + (a2 * (w.x * w.x) + a2 * (w.y * w.y)) / (w.z * w.z);
+    return pt_sqrt(c) * 0.5f - 0.5f;
+}
+PT_HD float ggx_g(float alpha, F3 wi, F3 wo) { return 1.0f / (1.0f + ggx_lambda(alpha, wi) + ggx_lambda(alpha, wo)); }
+PT_HD float ggx_vnpdf(float alpha, F3 wi, F3 wh) {
+    float inv_gl = 1.0f + ggx_lambda(alpha, wi);
+    return (ggx_d(alpha, wh) * pt_abs(dot(wi, wh))) / (inv_gl * pt_abs(wi.z));
+}
+PT_HD float ggx_vnpdf_no_d(float alpha, F3 wi, F3 wh) {
+    return pt_abs(dot(wi, wh) / ((1.0f + ggx_lambda(alpha, wi)) * wi.z));
+}
+PT_HD F3 sample_vndf(float alpha, F3 wi, float x, float y) {
+    F3 v = normalize(f3(alpha * wi.x, alpha * wi.y, wi.z));
+    F3 t1 = (v.z < 0.9999f) ? normalize(cross(v, f3(0, 0, 1))) : f3(1, 0, 0);
+    F3 t2 = cross(t1, v);
+    float a = 1.0f / (1.0f + v.z);
+    float r = pt_sqrt(x);
+    float phi = (y < a) ? (y / a * PT_PI) : (PT_PI + (y - a) / (1.0f - a) * PT_PI);
+    float sp, cp; pt_sincos(phi, &sp, &cp);
+    float p1 = r * cp;
+    float p2 = r * sp * ((y < a) ? 1.0f : v.z);
+    float value = 1.0f - p1 * p1 - p2 * p2;
+    F3 n = add(add(mul(t1, p1), mul(t2, p2)), mul(v, pt_sqrt(pt_max(value, 0.0f))));
+    return normalize(f3(alpha * n.x, alpha * n.y, pt_max(n.z, 0.0f)));
+}
+PT_HD F3 sample_wh(float alpha, F3 wi, float x, float y) {
+    bool flip = wi.z < 0.0f;
+    F3 wh = sample_vndf(alpha, flip ? neg(wi) : wi, x, y);
+    return flip ? neg(wh) : wh;
+}
+PT_HD float ggx_reflectance(bool metallic, float eo, float ei, float k, float c) {
+    return metallic ? fresnel_conductor(eo, ei, k, c) : fresnel_dielectric(eo, ei, c);
+}
+PT_HD float ggx_reflectance_probability(bool metallic, float eo, float ei, float k, float c) {
+    return metallic ? 1.0f : pt_clamp(fresnel_dielectric(eo, ei, c), 0.0f, 1.0f);
+}
+PT_HD float ggx_eta_rel(float eo, float ei, F3 wi) { return (wi.z < 0.0f) ? eo / ei : ei / eo; }
+// transmission lobe, TransportMode::Importance (ggx.rs:310-376 and 476-551)
+PT_HD void ggx_transmission(float alpha, bool metallic, float eo, float ei, float kappa, F3 wi, F3 wo, F3 wh, float g,
+                            float* transmission, float* transmission_pdf) {
+    float eta_rel = ggx_eta_rel(eo, ei, wi);
+    float ggxg = ggx_g(alpha, wi, wo);
+    float partial = ggx_vnpdf_no_d(alpha, wi, wh);
+    float ndotv = dot(wi, wh), ndotl = dot(wo, wh);
+    float sqrt_denom = ndotv + eta_rel * ndotl;
+    float eta_rel2 = eta_rel * eta_rel;
+    float dwh_dwo1 = ndotl / (sqrt_denom * sqrt_denom);
+    float dwh_dwo2 = eta_rel2 * dwh_dwo1;
+    dwh_dwo1 = dwh_dwo2;  // Importance mode
+    float ggxd = ggx_d(alpha, wh);
+    float weight = ggxd * ggxg * ndotv * dwh_dwo1 / g;
+    *transmission_pdf = pt_abs(ggxd * partial * dwh_dwo2);
+    float inv_reflectance = 1.0f - ggx_reflectance(metallic, eo, ei, kappa, ndotv);
+    *transmission = metallic ? 0.0f : inv_reflectance * pt_abs(weight);
+}
+
+// ---------------------------------------------------------------- Material<f32,f32>
+// Material::bsdf (lambertian.rs:16-33, diffuse_light.rs:29-45, sharp_light.rs:43-60, ggx.rs:256-400)
+PT_HD void material_bsdf(const SceneView& s, uint32_t m, float lambda, float u, float v, F3 wi, F3 wo, float* f_out, float* pdf_out) {
+    uint32_t kind = bu(s, m + PT_MAT_KIND);
+    if (kind != PT_MATERIAL_GGX) {
+        if (wo.z * wi.z > 0.0f) {
+            float refl = (kind == PT_MATERIAL_LAMBERTIAN) ? pt_min(texstack_eval(s, bu(s, m + PT_MAT_TEXSTACK), lambda, u, v), 1.0f)
+                                                          : pt_clamp(curve_eval(s, bu(s, m + PT_MAT_BOUNCE), lambda), 0.0f, 1.0f);
+            *f_out = refl / PT_PI; *pdf_out = pt_abs(wo.z) / PT_PI;
+        } else { *f_out = 0.0f; *pdf_out = 0.0f; }
+        return;
+    }
+    float alpha = bf(s, m + PT_MAT_ALPHA);
+    bool metallic = bu(s, m + PT_MAT_METALLIC) != 0;
+    wi = normalize(wi);
+    bool same_hemisphere = wi.z * wo.z > 0.0f;
+    float g = pt_abs(wi.z * wo.z);
+    if (g == 0.0f) { *f_out = 0.0f; *pdf_out = 0.0f; return; }
+    float cos_i = wi.z;
+    float glossy = 0.0f, transmission = 0.0f, glossy_pdf = 0.0f, transmission_pdf = 0.0f;
+    float ei = curve_eval(s, bu(s, m + PT_MAT_ETA), lambda), eo = curve_eval(s, bu(s, m + PT_MAT_ETA_O), lambda);
+    float kappa = metallic ? curve_eval(s, bu(s, m + PT_MAT_KAPPA), lambda) : 0.0f;
+    if (same_hemisphere) {
+        F3 wh = normalize(add(wo, wi));
+        if (wh.z < 0.0f) wh = neg(wh);
+        float ndotv = dot(wi, wh);
+        float refl = ggx_reflectance(metallic, eo, ei, kappa, ndotv);
+        float ggxd = ggx_d(alpha, wh), ggxg = ggx_g(alpha, wi, wo);
+        glossy = refl * (0.25f / g) * ggxd * ggxg;
+        glossy_pdf = (pt_abs(ndotv) == 0.0f) ? 0.0f : ggx_vnpdf(alpha, wi, wh) * 0.25f / pt_abs(ndotv);
+    } else if (!metallic) {
+        float eta_rel = ggx_eta_rel(eo, ei, wi);
+        F3 wh = normalize(add(wi, mul(wo, eta_rel)));
+        if (wh.z < 0.0f) wh = neg(wh);
+        ggx_transmission(alpha, metallic, eo, ei, kappa, wi, wo, wh, g, &transmission, &transmission_pdf);
+    }
+    float rp = ggx_reflectance_probability(metallic, eo, ei, kappa, cos_i);
+    *f_out = glossy + transmission;
+    *pdf_out = rp * glossy_pdf + (1.0f - rp) * transmission_pdf;
+}
+
+// Material::generate_and_evaluate (lambertian.rs:50-66, diffuse_light.rs:60-76, sharp_light.rs:183-198, ggx.rs:401-590)
+PT_HD void material_sample(const SceneView& s, uint32_t m, float lambda, float u, float v, float sx, float sy, F3 wi,
+                           float* f_out, F3* wo_out, float* pdf_out) {
+    uint32_t kind = bu(s, m + PT_MAT_KIND);
+    if (kind != PT_MATERIAL_GGX) {
+        F3 d = mul(random_cosine_direction(sx, sy), pt_signum(wi.z));
+        float refl = (kind == PT_MATERIAL_LAMBERTIAN) ? pt_min(texstack_eval(s, bu(s, m + PT_MAT_TEXSTACK), lambda, u, v), 1.0f)
+                                                      : pt_clamp(curve_eval(s, bu(s, m + PT_MAT_BOUNCE), lambda), 0.0f, 1.0f);
+        *f_out = refl / PT_PI; *wo_out = d; *pdf_out = pt_abs(d.z) / PT_PI;
+        return;
+    }
+    float alpha = bf(s, m + PT_MAT_ALPHA);
+    bool metallic = bu(s, m + PT_MAT_METALLIC) != 0;
+    float ei = curve_eval(s, bu(s, m + PT_MAT_ETA), lambda), eo = curve_eval(s, bu(s, m + PT_MAT_ETA_O), lambda);
+    float kappa = metallic ? curve_eval(s, bu(s, m + PT_MAT_KAPPA), lambda) : 0.0f;
+    F3 wh = normalize(sample_wh(alpha, wi, sx, sy));
+    float refl_prob = ggx_reflectance_probability(metallic, eo, ei, kappa, dot(wh, wi));
+    bool did_reflect = false;
+    F3 wo;
+    if (sx <= refl_prob) {
+        did_reflect = true; wo = reflect(wi, wh);
+    } else {
+        float eta_rel = 1.0f / ggx_eta_rel(eo, ei, wi);
+        if (!refract(wi, wh, eta_rel, &wo)) { did_reflect = true; wo = reflect(wi, wh); }
+    }
+    float g = pt_abs(wi.z * wo.z);
+    if (g == 0.0f) { *f_out = 0.0f; *wo_out = wo; *pdf_out = 0.0f; return; }
+    float cos_i;
+    float glossy = 0.0f, transmission = 0.0f, glossy_pdf = 0.0f, transmission_pdf = 0.0f;
+    if (did_reflect) {
+        cos_i = dot(wi, wh);
+        float refl = ggx_reflectance(metallic, eo, ei, kappa, cos_i);
+        float ggxd = ggx_d(alpha, wh), ggxg = ggx_g(alpha, wi, wo);
+        glossy = refl * (0.25f / g) * ggxd * ggxg;
+        glossy_pdf = (pt_abs(cos_i) == 0.0f) ? 0.0f : ggx_vnpdf(alpha, wi, wh) * 0.25f / pt_abs(cos_i);
+    } else {
+        if (wh.z < 0.0f) wh = neg(wh);
+        cos_i = dot(wi, wh);
+        ggx_transmission(alpha, metallic, eo, ei, kappa, wi, wo, wh, g, &transmission, &transmission_pdf);
+    }
+    float rp = ggx_reflectance_probability(metallic, eo, ei, kappa, cos_i);
+    *f_out = glossy + transmission;
+    *wo_out = wo;
+    *pdf_out = rp * glossy_pdf + (1.0f - rp) * transmission_pdf;
+}
+
+// Material::emission (diffuse_light.rs:123-133, sharp_light.rs:138-150, 202-204)
+PT_HD float material_emission(const SceneView& s, uint32_t m, float lambda, F3 wi) {
+    uint32_t kind = bu(s, m + PT_MAT_KIND);
+    if (kind != PT_MATERIAL_DIFFUSE_LIGHT && kind != PT_MATERIAL_SHARP_LIGHT) return 0.0f;
+    uint32_t sided = bu(s, m + PT_MAT_SIDEDNESS);
+    float cosine = wi.z;
+    bool on = (cosine > 0.0f && sided == PT_SIDED_FORWARD) || (cosine < 0.0f && sided == PT_SIDED_REVERSE) || sided == PT_SIDED_DUAL;
+    if (!on) return 0.0f;
+    float e = curve_eval(s, bu(s, m + PT_MAT_EMIT), lambda);
+    if (kind == PT_MATERIAL_DIFFUSE_LIGHT) return e / PT_PI;
+    float sharpness = bf(s, m + PT_MAT_SHARPNESS);
+    float inner = (sharpness + 1.0f) * pt_pow(pt_abs(wi.z), sharpness) / 2.0f / PT_PI;
+    return e * inner;
+}
+PT_HD uint32_t material_record(const SceneView& s, uint32_t material_id) {
+    return bu(s, PT_HDR_MATERIAL_OFF) + PT_MATERIAL_INDEX(material_id) * PT_MAT_WORDS;
+}
+
+// ---------------------------------------------------------------- light sampling (Hittable::sample / psa_pdf)
+// rect.rs:113-173, sphere.rs:88-152, disk.rs:63-104, instance.rs:134-170
+PT_HD void light_sample(const SceneView& s, uint32_t inst, float sx, float sy, F3 from, F3* dir, float* pdf) {
+    uint32_t kind = bu(s, inst + PT_INST_KIND), flags = bu(s, inst + PT_INST_FLAGS);
+    bool xf = (flags & 1u) != 0, two_sided = (flags & 2u) != 0;
+    if (xf) from = xf_point(s, inst + PT_INST_REVERSE, from);
+    F3 origin = bf3(s, inst + PT_INST_ORIGIN);
+    F3 point, normal; float area_pdf;
+    if (kind == PT_SHAPE_RECT) {
+        uint32_t axis = (flags >> 2) & 3u;
+        float s0 = bf(s, inst + PT_INST_SIZE), s1 = bf(s, inst + PT_INST_SIZE + 1);
+        float x = sx;
+        normal = axis_vec(axis);
+        if (two_sided) { float c = choose_first(&x, 0.5f) ? -1.0f : 1.0f; normal = mul(normal, c); }
+        point = add(origin, rect_shuffle(f3((x - 0.5f) * s0, (sy - 0.5f) * s1, 0.0f), axis));
+        area_pdf = 1.0f / (s0 * s1);
+    } else if (kind == PT_SHAPE_SPHERE) {
+        float radius = bf(s, inst + PT_INST_RADIUS);
+        normal = random_on_unit_sphere(sx, sy);
+        point = add(origin, mul(normal, radius));
+        area_pdf = 1.0f / (radius * radius * 4.0f * PT_PI);
+    } else {
+        float radius = bf(s, inst + PT_INST_RADIUS);
+        float x = sx;
+        normal = f3(0, 0, 1);
+        if (two_sided) { float c = choose_first(&x, 0.5f) ? -1.0f : 1.0f; normal = mul(normal, c); }
+        point = add(origin, mul(random_in_unit_disk(x, sy), radius));
+        area_pdf = 1.0f / (PT_PI * radius * radius);
+    }
+    F3 direction = sub(point, from);
+    float p;
+    if (kind == PT_SHAPE_SPHERE) p = area_pdf * dot(direction, direction) / pt_abs(dot(normal, normalize(direction)));
+    else { float cos_i = dot(normal, normalize(direction)); p = area_pdf * dot(direction, direction) / pt_abs(cos_i); }
+    if (!pt_isfinite(p)) p = 0.0f;
+    F3 dn = normalize(direction);
+    if (xf) dn = normalize(xf_vec(s, inst + PT_INST_FORWARD, dn));
+    *dir = dn; *pdf = p;
+}
+PT_HD float light_psa_pdf(const SceneView& s, uint32_t inst, float cos_o, float cos_i, F3 from, F3 to) {
+    uint32_t kind = bu(s, inst + PT_INST_KIND), flags = bu(s, inst + PT_INST_FLAGS);
+    if (flags & 1u) { from = xf_point(s, inst + PT_INST_FORWARD, from); to = xf_point(s, inst + PT_INST_FORWARD, to); }
+    F3 dd = sub(to, from);
+    float d2 = dot(dd, dd);
+    if (kind == PT_SHAPE_RECT) { float s0 = bf(s, inst + PT_INST_SIZE), s1 = bf(s, inst + PT_INST_SIZE + 1); return (1.0f / (s0 * s1)) * d2 / pt_abs(cos_i) / pt_abs(cos_o); }
+    float radius = bf(s, inst + PT_INST_RADIUS);
+    if (kind == PT_SHAPE_SPHERE) return (1.0f / (radius * radius * 4.0f * PT_PI)) * d2 / pt_abs(cos_i * cos_o);
+    if (kind == PT_SHAPE_DISK) return d2 / ((pt_abs(cos_o) * pt_abs(cos_i) + 0.00001f) * (PT_PI * radius * radius));
+    return 0.0f;
+}
+
+// ---------------------------------------------------------------- environment (src/world/environment.rs)
+PT_HD float env_emission(const SceneView& s, float u, float v, float lambda) {
+    uint32_t kind = bu(s, PT_HDR_ENV_KIND);
+    float strength = bf(s, PT_HDR_ENV_STRENGTH);
+    if (kind == PT_ENV_CONSTANT) return curve_eval(s, bu(s, PT_HDR_ENV_CURVE), lambda) * strength;
+    if (kind == PT_ENV_SUN) {
+        F3 dir = uv_to_direction(u, v);
+        F3 sd = bf3(s, PT_HDR_ENV_SUN_DIR);
+        float c = dot(sd, dir), sn = pt_sqrt(1.0f - c * c);
+        if (pt_abs(sn) < pt_sin(bf(s, PT_HDR_ENV_ANGULAR) / 2.0f) && c > 0.0f) return curve_eval(s, bu(s, PT_HDR_ENV_CURVE), lambda) * strength;
+        return 0.0f;
+    }
+    return 0.0f;
+}
+PT_HD float env_pdf_for(const SceneView& s, float u, float v) {
+    if (bu(s, PT_HDR_ENV_KIND) == PT_ENV_SUN) {
+        F3 dir = uv_to_direction(u, v);
+        F3 sd = bf3(s, PT_HDR_ENV_SUN_DIR);
+        float ad = bf(s, PT_HDR_ENV_ANGULAR);
+        float c = dot(sd, dir), sn = pt_sqrt(1.0f - c * c);
+        if (pt_abs(sn) < pt_sin(ad / 2.0f) && c > 0.0f) return 1.0f / (2.0f * PT_PI * (1.0f - pt_cos(ad)));
+        return 0.0f;
+    }
+    return 1.0f / (4.0f * PT_PI);
+}
+PT_HD void env_sample_uv(const SceneView& s, float sx, float sy, float* u, float* v, float* pdf) {
+    if (bu(s, PT_HDR_ENV_KIND) == PT_ENV_SUN) {
+        float ad = bf(s, PT_HDR_ENV_ANGULAR);
+        F3 local_wo = add(f3(0, 0, 1), mul(random_in_unit_disk(sx, sy), pt_sin(ad / 2.0f)));
+        Frame fr = frame_from_normal(bf3(s, PT_HDR_ENV_SUN_DIR));
+        F3 dir = to_world(fr, local_wo);
+        direction_to_uv(normalize(dir), u, v);
+        *pdf = 1.0f / (2.0f * PT_PI * (1.0f - pt_cos(ad)));
+        return;
+    }
+    *u = sx; *v = sy; *pdf = 1.0f / (4.0f * PT_PI);
+}
+
+// ---------------------------------------------------------------- camera (src/camera/projective_camera.rs:101-120)
+struct CameraParams { F3 origin, u, v, lower_left, horizontal, vertical; float aperture_diameter; };
+
+PT_HD void camera_ray(const CameraParams& c, uint64_t seed, uint32_t pixel, uint32_t sample, float fu, float fv, F3* o, F3* d) {
+    float ax = 0.0f, ay = 0.0f;
+    for (uint32_t blk = 0; blk < PT_APERTURE_BLOCKS; ++blk) {
+        pt_f32x4 r = pt_draw4(seed, pixel, sample, PT_DIM_APERTURE0 + blk);
+        float x = r.x * 2.0f - 1.0f, y = r.y * 2.0f - 1.0f;
+        if (x * x + y * y <= 1.0f) { ax = x; ay = y; break; }
+        x = r.z * 2.0f - 1.0f; y = r.w * 2.0f - 1.0f;
+        if (x * x + y * y <= 1.0f) { ax = x; ay = y; break; }
+    }
+    F3 rd = mul(f3(ax, ay, 0.0f), c.aperture_diameter);
+    F3 offset = add(mul(c.u, rd.x), mul(c.v, rd.y));
+    F3 ro = add(c.origin, offset);
+    F3 pop = add(add(c.lower_left, mul(c.horizontal, fu)), mul(c.vertical, fv));
+    *o = ro; *d = normalize(sub(pop, ro));
+}
+
+// CIE fit (math::misc::{x_bar,y_bar,z_bar}), f64 as in the reference
+PT_HD double gaussian64(double x, double alpha, double mu, double s1, double s2) {
+    double t = (x - mu) / (x < mu ? s1 : s2);
+    return alpha * pt_exp64(-(t * t) / 2.0);
+}
+PT_HD void xyz_bar(float angstrom, float* xb, float* yb, float* zb) {
+    double a = (double)angstrom;
+    *xb = (float)(gaussian64(a, 1.056, 5998.0, 379.0, 310.0) + gaussian64(a, 0.362, 4420.0, 160.0, 267.0) + gaussian64(a, -0.065, 5011.0, 204.0, 262.0));
+    *yb = (float)(gaussian64(a, 0.821, 5688.0, 469.0, 405.0) + gaussian64(a, 0.286, 5309.0, 163.0, 311.0));
+    *zb = (float)(gaussian64(a, 1.217, 4370.0, 118.0, 360.0) + gaussian64(a, 0.681, 4590.0, 260.0, 138.0));
+}
+
+}  // namespace ptd
+#endif

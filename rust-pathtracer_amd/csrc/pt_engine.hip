@@ -1,0 +1,585 @@
+// pt_engine.hip — the HIP engine behind include/pt_api.h (gfx950 / MI355X only).
+//
+// Wavefront path tracer: per bounce one launch each of extend -> shade -> shadow over dense SoA queues in HBM
+// (pt_stages.h), persistent grids that stage the scene blob into LDS once per workgroup, wave64 ballot +
+// prefix compaction of surviving paths and of light-sample work items, per-slot energy accumulation without
+// float atomics, and an accumulate kernel that owns one film pixel per lane so film sums keep the reference's
+// order.  No CPU fallback: every entry point fails with PT_ERR_NO_DEVICE when HIP has no device.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_api.h"
+#include "pt_plan.h"
+#include "pt_scene_host.h"
+#include "pt_stages.h"
+
+using namespace ptd;
+
+namespace {
+
+thread_local std::string g_error;
+pt_status fail(pt_status st, const std::string& msg) { g_error = msg; return st; }
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : (e_ == hipErrorNoDevice ? PT_ERR_NO_DEVICE : PT_ERR_DEVICE), \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                                    \
+    } while (0)
+
+constexpr int kBlock = 256;
+constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // stage the blob in LDS when it fits (keeps >= 2 workgroups per CU)
+
+enum { CTR_BOUNCE_RAYS, CTR_SHADOW_RAYS, CTR_ENV_HITS, CTR_SEGMENTS, CTR_SHADOW_ITEMS, CTR_COUNT };
+enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_ACCUMULATE, ST_COUNT };
+
+// ------------------------------------------------------------------------------------------------ kernels
+// Every kernel is a persistent grid: blocks stage the scene blob into LDS (when USE_LDS), then walk the queue
+// with a grid stride.  Queue lengths live in device memory (`counts`), so no host round trip between bounces.
+template <bool USE_LDS>
+__device__ __forceinline__ SceneView stage_scene(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* tex, uint32_t* lds) {
+    SceneView s;
+    s.tex = tex;
+    if (USE_LDS) {
+        const uint4* src = reinterpret_cast<const uint4*>(blob);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (uint32_t i = threadIdx.x; i < blob_words / 4; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        s.w = lds;
+    } else {
+        s.w = blob;
+    }
+    return s;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// wave64 compaction: lanes with `flag` get consecutive positions in the queue whose length is *counter.
+__device__ __forceinline__ uint32_t wave_append(bool flag, uint32_t* counter) {
+    unsigned long long mask = __ballot(flag);
+    uint32_t total = (uint32_t)__popcll(mask);
+    uint32_t base = 0;
+    uint32_t lane = lane_id();
+    if (total) {
+        int leader = __ffsll((long long)mask) - 1;
+        if ((int)lane == leader) base = atomicAdd(counter, total);
+        base = __shfl(base, leader);
+    }
+    uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    return base + prefix;
+}
+__device__ __forceinline__ void wave_count(bool flag, unsigned long long* counter) {
+    unsigned long long mask = __ballot(flag);
+    if (mask && lane_id() == (uint32_t)(__ffsll((long long)mask) - 1)) atomicAdd(counter, (unsigned long long)__popcll(mask));
+}
+__device__ __forceinline__ void wave_sum(uint32_t v, unsigned long long* counter) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane_id() == 0 && v) atomicAdd(counter, (unsigned long long)v);
+}
+
+__global__ void __launch_bounds__(kBlock) k_generate(RenderParams rp, const uint32_t* __restrict__ pixels, Queue paths, float* __restrict__ energy,
+                                                    uint32_t n, uint32_t* __restrict__ counts) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t pixel = pixels[i % rp.chunk_pixels];
+        PathVertex p = stage_generate(rp, i, pixel);
+        store_path(paths, i, p);
+        energy[i] = 0.0f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = n;
+}
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(kBlock) k_extend(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                  Queue paths, Queue hits, const uint32_t* __restrict__ count) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    uint32_t n = *count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        F3 o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
+        F3 d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
+        Hit h;
+        world_hit(s, o, d, &h);
+        store_hit(hits, i, h);
+    }
+}
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(kBlock) k_shade(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                 RenderParams rp, uint32_t bounce, const uint32_t* __restrict__ pixels,
+                                                 Queue paths_in, Queue hits, Queue paths_out, Queue shadow, float* __restrict__ energy,
+                                                 const uint32_t* __restrict__ count_in, uint32_t* __restrict__ count_out,
+                                                 uint32_t* __restrict__ shadow_count, unsigned long long* __restrict__ counters) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    uint32_t n = *count_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[CTR_SEGMENTS], (unsigned long long)n);
+    uint32_t rounds = (n + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+    for (uint32_t r = 0; r < rounds; ++r) {  // whole waves stay in the loop so ballots see every lane
+        uint32_t i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        bool active = i < n;
+        ShadeOut out;
+        ShadowRay rays[PT_MAX_LIGHT_SAMPLES];
+        out.survives = false; out.has_item = false; out.vertex_pushed = false; out.env_hit = false; out.shadow_count = 0; out.add_energy = false;
+        PathVertex pv;
+        if (active) {
+            pv = load_path(paths_in, i);
+            Hit hit = load_hit(hits, i);
+            uint32_t pixel = pixels[pv.slot % rp.chunk_pixels];
+            out = stage_shade(s, rp, bounce, pv, hit, pixel, rays);
+            if (out.add_energy) energy[pv.slot] += out.energy_add;
+        }
+        uint32_t pos = wave_append(out.survives, count_out);
+        if (out.survives) store_path(paths_out, pos, out.next);
+        uint32_t ipos = wave_append(out.has_item, shadow_count);
+        if (out.has_item) {
+            qsu(shadow, SH_SLOT, ipos, pv.slot); qsf(shadow, SH_LAMBDA, ipos, pv.lambda); qsu(shadow, SH_FLAGS, ipos, out.env_mask);
+            for (uint32_t l = 0; l < rp.light_samples; ++l) {
+                uint32_t f0 = SH_HEAD + l * SR_FIELDS;
+                qsf(shadow, f0 + SR_FACTOR, ipos, rays[l].factor);
+                if (rays[l].factor != 0.0f) {
+                    qsf(shadow, f0 + SR_OX, ipos, rays[l].o.x); qsf(shadow, f0 + SR_OY, ipos, rays[l].o.y); qsf(shadow, f0 + SR_OZ, ipos, rays[l].o.z);
+                    qsf(shadow, f0 + SR_DX, ipos, rays[l].d.x); qsf(shadow, f0 + SR_DY, ipos, rays[l].d.y); qsf(shadow, f0 + SR_DZ, ipos, rays[l].d.z);
+                }
+            }
+        }
+        wave_count(out.vertex_pushed, &counters[CTR_BOUNCE_RAYS]);
+        wave_count(out.env_hit, &counters[CTR_ENV_HITS]);
+        wave_sum(out.shadow_count, &counters[CTR_SHADOW_RAYS]);
+    }
+}
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(kBlock) k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                  uint32_t light_samples, Queue shadow, float* __restrict__ energy,
+                                                  const uint32_t* __restrict__ count, unsigned long long* __restrict__ counters) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    uint32_t n = *count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[CTR_SHADOW_ITEMS], (unsigned long long)n);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t slot = qu(shadow, SH_SLOT, i), flags = qu(shadow, SH_FLAGS, i);
+        float lambda = qf(shadow, SH_LAMBDA, i);
+        float lc = 0.0f;
+        for (uint32_t l = 0; l < light_samples; ++l) {
+            uint32_t f0 = SH_HEAD + l * SR_FIELDS;
+            ShadowRay ray;
+            ray.factor = qf(shadow, f0 + SR_FACTOR, i);
+            if (ray.factor == 0.0f) continue;
+            ray.o = f3(qf(shadow, f0 + SR_OX, i), qf(shadow, f0 + SR_OY, i), qf(shadow, f0 + SR_OZ, i));
+            ray.d = f3(qf(shadow, f0 + SR_DX, i), qf(shadow, f0 + SR_DY, i), qf(shadow, f0 + SR_DZ, i));
+            lc += ((flags >> l) & 1u) ? stage_shadow_env(s, ray) : stage_shadow_light(s, lambda, ray);
+        }
+        energy[slot] += lc / (float)light_samples;  // pt.rs:596
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_accumulate(RenderParams rp, const uint32_t* __restrict__ pixels, const float* __restrict__ energy,
+                                                      float* __restrict__ film) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < rp.chunk_pixels; p += gridDim.x * blockDim.x) {
+        uint32_t pixel = pixels[p];
+        float4* px = reinterpret_cast<float4*>(film) + pixel;
+        float4 v = *px;
+        float f[4] = {v.x, v.y, v.z, v.w};
+        stage_accumulate_pixel(rp, energy, p, pixel, f);
+        *px = make_float4(f[0], f[1], f[2], f[3]);
+    }
+}
+
+// ---- probes (parity tests of single stages)
+template <bool USE_LDS>
+__global__ void __launch_bounds__(kBlock) k_probe_intersect(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                           uint32_t n, const float* __restrict__ o, const float* __restrict__ d, pt_hit* __restrict__ out) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Hit h;
+        bool ok = world_hit(s, f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), &h);
+        pt_hit r;
+        memset(&r, 0, sizeof(r));
+        if (ok) {
+            r.valid = 1; r.t = h.t; r.point[0] = h.p.x; r.point[1] = h.p.y; r.point[2] = h.p.z;
+            r.normal[0] = h.n.x; r.normal[1] = h.n.y; r.normal[2] = h.n.z; r.uv[0] = h.u; r.uv[1] = h.v;
+            r.material = h.material; r.instance = h.instance;
+        }
+        out[i] = r;
+    }
+}
+// mode 0: generate_and_evaluate(lambda, wi, s2) -> f, wo, pdf ; 1: bsdf(lambda, wi, wo) -> f, pdf ; 2: emission(lambda, wi) ; 3: curve(lambda)
+__global__ void __launch_bounds__(kBlock) k_probe_material(const uint32_t* __restrict__ blob, const float* __restrict__ tex, int mode, uint32_t record, uint32_t n,
+                                                          const float* __restrict__ lambda, const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ f, float* __restrict__ wo, float* __restrict__ pdf) {
+    SceneView s; s.w = blob; s.tex = tex;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (mode == 0) {
+            F3 w; material_sample(s, record, lambda[i], 0.5f, 0.5f, b[2 * i], b[2 * i + 1], f3(a[3 * i], a[3 * i + 1], a[3 * i + 2]), &f[i], &w, &pdf[i]);
+            wo[3 * i] = w.x; wo[3 * i + 1] = w.y; wo[3 * i + 2] = w.z;
+        } else if (mode == 1) {
+            material_bsdf(s, record, lambda[i], 0.5f, 0.5f, f3(a[3 * i], a[3 * i + 1], a[3 * i + 2]), f3(b[3 * i], b[3 * i + 1], b[3 * i + 2]), &f[i], &pdf[i]);
+        } else if (mode == 2) {
+            f[i] = material_emission(s, record, lambda[i], f3(a[3 * i], a[3 * i + 1], a[3 * i + 2]));
+        } else {
+            f[i] = curve_eval(s, record, lambda[i]);
+        }
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_probe_numerics(int which, uint32_t n, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float r;
+        switch (which) {
+            case 0: r = pt_sin(x[i]); break;
+            case 1: r = pt_cos(x[i]); break;
+            case 2: r = pt_exp(x[i]); break;
+            case 3: r = pt_pow(x[i], y[i]); break;
+            case 4: r = pt_acos(x[i]); break;
+            case 5: r = pt_atan2(x[i], y[i]); break;
+            case 6: r = (float)pt_exp64((double)x[i]); break;
+            case 7: r = (float)pt_log64((double)x[i]); break;
+            case 8: r = x[i] / y[i]; break;
+            case 9: r = pt_sqrt(x[i]); break;
+            case 10: r = x[i] * y[i] + x[i]; break;  // must NOT be contracted to an fma
+            default: r = 0.0f;
+        }
+        out[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct DeviceBuffers {
+    uint32_t capacity = 0, light_samples = 0;
+    uint32_t *paths_a = nullptr, *paths_b = nullptr, *hits = nullptr, *shadow = nullptr, *pixels = nullptr, *counts = nullptr;
+    float* energy = nullptr;
+    unsigned long long* counters = nullptr;
+    size_t pixel_capacity = 0;
+    void release() {
+        hipFree(paths_a); hipFree(paths_b); hipFree(hits); hipFree(shadow); hipFree(pixels); hipFree(counts); hipFree(energy); hipFree(counters);
+        *this = DeviceBuffers();
+    }
+};
+
+}  // namespace
+
+struct pt_scene {
+    pth::HostScene host;
+    uint32_t* d_blob = nullptr;
+    float* d_tex = nullptr;
+    uint32_t blob_words = 0;
+    bool use_lds = false;
+    int device = 0, num_cus = 0;
+    DeviceBuffers buf;
+    std::vector<hipEvent_t> events;  // pairs (start, stop), grown on demand
+};
+
+namespace {
+
+std::string g_device_info;
+
+pt_status ensure_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available: the product path has no CPU fallback");
+    return PT_OK;
+}
+
+uint32_t shadow_fields(uint32_t light_samples) { return SH_HEAD + light_samples * SR_FIELDS; }
+
+pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples, size_t n_pixels) {
+    DeviceBuffers& b = sc->buf;
+    if (b.capacity < capacity || b.light_samples < light_samples) {
+        hipFree(b.paths_a); hipFree(b.paths_b); hipFree(b.hits); hipFree(b.shadow); hipFree(b.energy);
+        b.paths_a = b.paths_b = b.hits = b.shadow = nullptr; b.energy = nullptr; b.capacity = 0;
+        uint32_t ls = light_samples > b.light_samples ? light_samples : b.light_samples;
+        HIP_TRY(hipMalloc(&b.paths_a, sizeof(uint32_t) * (size_t)PS_FIELDS * capacity));
+        HIP_TRY(hipMalloc(&b.paths_b, sizeof(uint32_t) * (size_t)PS_FIELDS * capacity));
+        HIP_TRY(hipMalloc(&b.hits, sizeof(uint32_t) * (size_t)HS_FIELDS * capacity));
+        HIP_TRY(hipMalloc(&b.shadow, sizeof(uint32_t) * (size_t)shadow_fields(ls ? ls : 1) * capacity));
+        HIP_TRY(hipMalloc(&b.energy, sizeof(float) * (size_t)capacity));
+        b.capacity = capacity; b.light_samples = ls;
+    }
+    if (b.pixel_capacity < n_pixels) {
+        hipFree(b.pixels); b.pixels = nullptr;
+        HIP_TRY(hipMalloc(&b.pixels, sizeof(uint32_t) * n_pixels));
+        b.pixel_capacity = n_pixels;
+    }
+    if (!b.counts) HIP_TRY(hipMalloc(&b.counts, sizeof(uint32_t) * 2 * 72));
+    if (!b.counters) HIP_TRY(hipMalloc(&b.counters, sizeof(unsigned long long) * CTR_COUNT));
+    return PT_OK;
+}
+
+template <typename K, typename... Args>
+void launch(K kernel, bool use_lds, int grid, uint32_t blob_bytes, hipStream_t stream, Args... args) {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), use_lds ? blob_bytes : 0, stream, args...);
+}
+
+uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return (uint32_t)strtoul(v, nullptr, 10);
+}
+
+pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hipStream_t stream, pt_profile* profile) {
+    if (!sc || !rdp || !d_film) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    pt_render_desc rd;
+    std::string err;
+    if (!pth::normalize_render_desc(*rdp, (uint32_t)sc->host.cameras.size(), &rd, &err)) return fail(PT_ERR_INVALID_ARGUMENT, err);
+    HIP_TRY(hipSetDevice(sc->device));
+
+    std::vector<uint32_t> pixels = pth::shard_pixels(rd.width, rd.height, rd.tile_width, rd.tile_height, rd.shard_index, rd.shard_count);
+    uint32_t capacity = env_u32("PT_AMD_BATCH", 1u << 22);
+    if (capacity < 1024) capacity = 1024;
+    uint64_t want = (uint64_t)pixels.size() * rd.sample_count;
+    if (want < capacity) capacity = (uint32_t)(want ? want : 1);
+    pt_status st = ensure_buffers(sc, capacity, rd.light_samples, pixels.size() ? pixels.size() : 1);
+    if (st != PT_OK) return st;
+    DeviceBuffers& b = sc->buf;
+    if (!pixels.empty()) HIP_TRY(hipMemcpyAsync(b.pixels, pixels.data(), sizeof(uint32_t) * pixels.size(), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd.width * rd.height, stream));
+    HIP_TRY(hipMemsetAsync(b.counters, 0, sizeof(unsigned long long) * CTR_COUNT, stream));
+
+    RenderParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.seed = rd.seed; rp.width = rd.width; rp.height = rd.height;
+    rp.min_bounces = rd.min_bounces; rp.max_bounces = rd.max_bounces; rp.light_samples = rd.light_samples; rp.only_direct = rd.only_direct;
+    rp.wavelength_lo = rd.wavelength_lo; rp.wavelength_span = rd.wavelength_hi - rd.wavelength_lo;
+    rp.spp = rd.spp; rp.range_end = rd.first_sample + rd.sample_count;
+    rp.normalize = (rd.first_sample == 0 && rd.sample_count == rd.spp) ? 1u : 0u;
+    rp.camera = pth::camera_params(sc->host.cameras[rd.camera_index], (float)rd.width / (float)rd.height);
+
+    const uint32_t blob_bytes = sc->blob_words * 4;
+    const bool lds = sc->use_lds;
+    const int grid = sc->num_cus * (int)env_u32("PT_AMD_BLOCKS_PER_CU", 8);
+    const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
+    const bool timing = env_u32("PT_AMD_STAGE_TIMING", 1) != 0;
+    double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0};
+    uint64_t stage_launches[ST_COUNT] = {0, 0, 0, 0, 0};
+    Queue qa{b.paths_a, b.capacity}, qb{b.paths_b, b.capacity}, qh{b.hits, b.capacity}, qs{b.shadow, b.capacity};
+    uint32_t* live = b.counts;          // live[bounce]
+    uint32_t* nshadow = b.counts + 72;  // nshadow[bounce]
+
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipStreamSynchronize(stream));
+    t0 = std::chrono::steady_clock::now();
+    // HIP events around every launch, recorded on the launch stream and read back after the final sync, so the
+    // per-stage device time is measured inside the timed region without stalling it.
+    std::vector<int> event_stage;
+    auto timed = [&](int stage, auto&& fn) {
+        size_t k = event_stage.size();
+        if (timing) {
+            while (sc->events.size() < 2 * (k + 1)) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; sc->events.push_back(e); }
+            if (sc->events.size() >= 2 * (k + 1)) hipEventRecord(sc->events[2 * k], stream);
+        }
+        fn();
+        if (timing && sc->events.size() >= 2 * (k + 1)) { hipEventRecord(sc->events[2 * k + 1], stream); event_stage.push_back(stage); }
+        stage_launches[stage]++;
+    };
+
+    std::vector<pth::Pass> passes = pth::plan_passes((uint32_t)pixels.size(), rd.first_sample, rd.sample_count, b.capacity);
+    uint64_t camera_rays = 0, accumulated_pixels = 0;
+    for (const pth::Pass& pass : passes) {
+        accumulated_pixels += pass.pixel_count;
+        rp.chunk_pixels = pass.pixel_count; rp.first_sample = pass.first_sample; rp.pass_samples = pass.sample_count;
+        uint32_t n = pass.pixel_count * pass.sample_count;
+        camera_rays += n;
+        const uint32_t* d_px = b.pixels + pass.pixel_begin;
+        HIP_TRY(hipMemsetAsync(b.counts, 0, sizeof(uint32_t) * 2 * 72, stream));
+        timed(ST_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, qa, b.energy, n, live); });
+        for (uint32_t bounce = 0; bounce < bounce_limit; ++bounce) {
+            Queue qin = (bounce & 1) ? qb : qa, qout = (bounce & 1) ? qa : qb;
+            timed(ST_EXTEND, [&] {
+                if (lds) launch(k_extend<true>, true, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, live + bounce);
+                else launch(k_extend<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, live + bounce);
+            });
+            timed(ST_SHADE, [&] {
+                if (lds) launch(k_shade<true>, true, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rp, bounce, d_px, qin, qh, qout, qs, b.energy,
+                                live + bounce, live + bounce + 1, nshadow + bounce, b.counters);
+                else launch(k_shade<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rp, bounce, d_px, qin, qh, qout, qs, b.energy,
+                            live + bounce, live + bounce + 1, nshadow + bounce, b.counters);
+            });
+            if (rd.light_samples > 0)
+                timed(ST_SHADOW, [&] {
+                    if (lds) launch(k_shadow<true>, true, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, nshadow + bounce, b.counters);
+                    else launch(k_shadow<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, nshadow + bounce, b.counters);
+                });
+        }
+        timed(ST_ACCUMULATE, [&] { hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, b.energy, d_film); });
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    auto t1 = std::chrono::steady_clock::now();
+    for (size_t k = 0; k < event_stage.size(); ++k) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, sc->events[2 * k], sc->events[2 * k + 1]) == hipSuccess) stage_ms[event_stage[k]] += ms;
+    }
+    if (profile) {
+        memset(profile, 0, sizeof(*profile));
+        unsigned long long c[CTR_COUNT];
+        HIP_TRY(hipMemcpy(c, b.counters, sizeof(c), hipMemcpyDeviceToHost));
+        profile->camera_rays = camera_rays;
+        profile->bounce_rays = c[CTR_BOUNCE_RAYS] + camera_rays;  // vertices.len() counts the camera vertex (utils.rs:375)
+        profile->shadow_rays = c[CTR_SHADOW_RAYS];
+        profile->env_hits = c[CTR_ENV_HITS];
+        profile->seconds = std::chrono::duration<double>(t1 - t0).count();
+        for (int i = 0; i < ST_COUNT; ++i) { profile->kernel_seconds[i] = stage_ms[i] * 1e-3; profile->kernel_launches[i] = stage_launches[i]; }
+        profile->stage_items[ST_GENERATE] = camera_rays; profile->stage_items[ST_EXTEND] = c[CTR_SEGMENTS]; profile->stage_items[ST_SHADE] = c[CTR_SEGMENTS];
+        profile->stage_items[ST_SHADOW] = c[CTR_SHADOW_ITEMS]; profile->stage_items[ST_ACCUMULATE] = accumulated_pixels;
+    }
+    return PT_OK;
+}
+
+pt_status probe_material(pt_scene* sc, int mode, uint32_t record, size_t n, const float* lambda, const float* a, size_t a_w, const float* b, size_t b_w,
+                         float* f, float* wo, float* pdf) {
+    HIP_TRY(hipSetDevice(sc->device));
+    float *dl = nullptr, *da = nullptr, *db = nullptr, *df = nullptr, *dwo = nullptr, *dp = nullptr;
+    size_t m = n ? n : 1;
+    HIP_TRY(hipMalloc(&dl, 4 * m)); HIP_TRY(hipMalloc(&da, 4 * m * 3)); HIP_TRY(hipMalloc(&db, 4 * m * 3));
+    HIP_TRY(hipMalloc(&df, 4 * m)); HIP_TRY(hipMalloc(&dwo, 4 * m * 3)); HIP_TRY(hipMalloc(&dp, 4 * m));
+    HIP_TRY(hipMemcpy(dl, lambda, 4 * n, hipMemcpyHostToDevice));
+    if (a) HIP_TRY(hipMemcpy(da, a, 4 * n * a_w, hipMemcpyHostToDevice));
+    if (b) HIP_TRY(hipMemcpy(db, b, 4 * n * b_w, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_material, dim3(256), dim3(kBlock), 0, 0, sc->d_blob, sc->d_tex, mode, record, (uint32_t)n, dl, da, db, df, dwo, dp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (f) HIP_TRY(hipMemcpy(f, df, 4 * n, hipMemcpyDeviceToHost));
+    if (wo) HIP_TRY(hipMemcpy(wo, dwo, 4 * n * 3, hipMemcpyDeviceToHost));
+    if (pdf) HIP_TRY(hipMemcpy(pdf, dp, 4 * n, hipMemcpyDeviceToHost));
+    hipFree(dl); hipFree(da); hipFree(db); hipFree(df); hipFree(dwo); hipFree(dp);
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pt_last_error(void) { return g_error.c_str(); }
+
+const char* pt_device_info(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { g_device_info = "no HIP device"; return g_device_info.c_str(); }
+    int dev = 0; hipGetDevice(&dev);
+    hipDeviceProp_t p; hipGetDeviceProperties(&p, dev);
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s %s %d CUs, %.1f GB, LDS/block %zu KB", p.name, p.gcnArchName, p.multiProcessorCount,
+             (double)p.totalGlobalMem / 1e9, p.sharedMemPerBlock / 1024);
+    g_device_info = buf;
+    return g_device_info.c_str();
+}
+
+pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
+    if (!desc || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    pt_status st = ensure_device();
+    if (st != PT_OK) return st;
+    pt_scene* sc = new pt_scene();
+    std::string err;
+    if (!pth::build_host_scene(*desc, &sc->host, &err)) { delete sc; return fail(PT_ERR_INVALID_ARGUMENT, err); }
+    hipError_t e = hipGetDevice(&sc->device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, sc->device);
+    if (e != hipSuccess) { delete sc; return fail(PT_ERR_NO_DEVICE, hipGetErrorString(e)); }
+    sc->num_cus = prop.multiProcessorCount;
+    sc->blob_words = (uint32_t)sc->host.blob.size();
+    sc->use_lds = sc->blob_words * 4 <= kLdsBlobLimitBytes && env_u32("PT_AMD_NO_LDS", 0) == 0;
+    e = hipMalloc(&sc->d_blob, sizeof(uint32_t) * sc->host.blob.size());
+    if (e == hipSuccess) e = hipMalloc(&sc->d_tex, sizeof(float) * sc->host.tex.size());
+    if (e == hipSuccess) e = hipMemcpy(sc->d_blob, sc->host.blob.data(), sizeof(uint32_t) * sc->host.blob.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(sc->d_tex, sc->host.tex.data(), sizeof(float) * sc->host.tex.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { pt_scene_destroy(sc); return fail(e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE, hipGetErrorString(e)); }
+    if (sc->use_lds) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_intersect<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+    }
+    *out = sc;
+    return PT_OK;
+}
+
+void pt_scene_destroy(pt_scene* sc) {
+    if (!sc) return;
+    hipSetDevice(sc->device);
+    sc->buf.release();
+    hipFree(sc->d_blob); hipFree(sc->d_tex);
+    for (auto& e : sc->events) hipEventDestroy(e);
+    delete sc;
+}
+
+pt_status pt_render_device(pt_scene* sc, const pt_render_desc* rd, void* film_device, void* hip_stream, pt_profile* profile) {
+    return render_impl(sc, rd, static_cast<float*>(film_device), static_cast<hipStream_t>(hip_stream), profile);
+}
+
+pt_status pt_render(pt_scene* sc, const pt_render_desc* rd, float* film, pt_profile* profile) {
+    if (!sc || !rd || !film) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    if (rd->width == 0 || rd->height == 0) return fail(PT_ERR_INVALID_ARGUMENT, "width and height must be positive");
+    HIP_TRY(hipSetDevice(sc->device));
+    float* d_film = nullptr;
+    size_t bytes = sizeof(float) * 4 * (size_t)rd->width * rd->height;
+    HIP_TRY(hipMalloc(&d_film, bytes));
+    pt_status st = render_impl(sc, rd, d_film, nullptr, profile);
+    if (st == PT_OK) {
+        hipError_t e = hipMemcpy(film, d_film, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = fail(PT_ERR_DEVICE, hipGetErrorString(e));
+    }
+    hipFree(d_film);
+    return st;
+}
+
+pt_status pt_intersect(pt_scene* sc, size_t n, const float* origins, const float* directions, pt_hit* hits) {
+    if (!sc || !origins || !directions || !hits) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(sc->device));
+    float *dor = nullptr, *dd = nullptr; pt_hit* dh = nullptr;
+    HIP_TRY(hipMalloc(&dor, 12 * n)); HIP_TRY(hipMalloc(&dd, 12 * n)); HIP_TRY(hipMalloc(&dh, sizeof(pt_hit) * n));
+    HIP_TRY(hipMemcpy(dor, origins, 12 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dd, directions, 12 * n, hipMemcpyHostToDevice));
+    int grid = sc->num_cus * 4;
+    if (sc->use_lds) launch(k_probe_intersect<true>, true, grid, sc->blob_words * 4, (hipStream_t)0, sc->d_blob, sc->blob_words, sc->d_tex, (uint32_t)n, dor, dd, dh);
+    else launch(k_probe_intersect<false>, false, grid, sc->blob_words * 4, (hipStream_t)0, sc->d_blob, sc->blob_words, sc->d_tex, (uint32_t)n, dor, dd, dh);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(hits, dh, sizeof(pt_hit) * n, hipMemcpyDeviceToHost));
+    hipFree(dor); hipFree(dd); hipFree(dh);
+    return PT_OK;
+}
+
+pt_status pt_bsdf_sample(pt_scene* sc, uint32_t material, size_t n, const float* lambda, const float* wi, const float* s2, float* f, float* wo, float* pdf) {
+    if (!sc || material >= sc->host.material_count) return fail(PT_ERR_INVALID_ARGUMENT, "bad material");
+    return probe_material(sc, 0, sc->host.blob[PT_HDR_MATERIAL_OFF] + material * PT_MAT_WORDS, n, lambda, wi, 3, s2, 2, f, wo, pdf);
+}
+pt_status pt_bsdf_eval(pt_scene* sc, uint32_t material, size_t n, const float* lambda, const float* wi, const float* wo, float* f, float* pdf) {
+    if (!sc || material >= sc->host.material_count) return fail(PT_ERR_INVALID_ARGUMENT, "bad material");
+    return probe_material(sc, 1, sc->host.blob[PT_HDR_MATERIAL_OFF] + material * PT_MAT_WORDS, n, lambda, wi, 3, wo, 3, f, nullptr, pdf);
+}
+pt_status pt_emission(pt_scene* sc, uint32_t material, size_t n, const float* lambda, const float* wi, float* emission) {
+    if (!sc || material >= sc->host.material_count) return fail(PT_ERR_INVALID_ARGUMENT, "bad material");
+    return probe_material(sc, 2, sc->host.blob[PT_HDR_MATERIAL_OFF] + material * PT_MAT_WORDS, n, lambda, wi, 3, nullptr, 0, emission, nullptr, nullptr);
+}
+pt_status pt_curve_eval(pt_scene* sc, uint32_t curve, size_t n, const float* lambda, float* value) {
+    if (!sc || curve >= sc->host.curve_count) return fail(PT_ERR_INVALID_ARGUMENT, "bad curve");
+    return probe_material(sc, 3, sc->host.curve_offsets[curve], n, lambda, nullptr, 0, nullptr, 0, value, nullptr, nullptr);
+}
+
+// Not part of pt_api.h: numeric-contract probe used by the GPU parity tests (device arithmetic vs x86).
+pt_status pt_debug_numerics(int which, size_t n, const float* x, const float* y, float* out) {
+    pt_status st = ensure_device();
+    if (st != PT_OK) return st;
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&dx, 4 * n)); HIP_TRY(hipMalloc(&dy, 4 * n)); HIP_TRY(hipMalloc(&dout, 4 * n));
+    HIP_TRY(hipMemcpy(dx, x, 4 * n, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dy, y, 4 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_numerics, dim3(256), dim3(kBlock), 0, 0, which, (uint32_t)n, dx, dy, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, 4 * n, hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(dy); hipFree(dout);
+    return PT_OK;
+}
+
+// Not part of pt_api.h: size of the scene blob and whether kernels read it from LDS (reported by bench.py).
+uint32_t pt_debug_scene_info(pt_scene* sc, int what) {
+    switch (what) { case 0: return sc->blob_words * 4; case 1: return sc->use_lds ? 1u : 0u; case 2: return sc->host.light_count; case 3: return (uint32_t)sc->num_cus; default: return 0; }
+}
+
+}  // extern "C"

@@ -1,0 +1,358 @@
+// pt_scene_host.cpp — host side of pt_scene_create: validates a pt_scene_desc, builds the two BVH levels and
+// packs everything into the word blob of pt_blob.h.  Runs once per scene, outside the timed render loop
+// (the reference's equivalent work is construct_world + Mesh::init + Accelerator::new,
+// src/parsing/mod.rs:145-563, src/geometry/mesh.rs:283-305, src/accelerator/mod.rs:31-43).
+#include "pt_scene_host.h"
+#include "pt_device.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace pth {
+
+namespace {
+
+struct Box { float mn[3], mx[3]; };
+
+Box box_empty() { Box b; for (int i = 0; i < 3; ++i) { b.mn[i] = INFINITY; b.mx[i] = -INFINITY; } return b; }
+void box_grow(Box& b, const float* p) { for (int i = 0; i < 3; ++i) { b.mn[i] = std::fmin(b.mn[i], p[i]); b.mx[i] = std::fmax(b.mx[i], p[i]); } }
+void box_expand(Box& b, const Box& o) { for (int i = 0; i < 3; ++i) { b.mn[i] = std::fmin(b.mn[i], o.mn[i]); b.mx[i] = std::fmax(b.mx[i], o.mx[i]); } }
+Box box_of_corners(const float* a, const float* b) {  // AABB::new, src/aabb.rs:16-21
+    Box r; for (int i = 0; i < 3; ++i) { r.mn[i] = std::fmin(a[i], b[i]); r.mx[i] = std::fmax(a[i], b[i]); } return r;
+}
+void box_center(const Box& b, float* c) { for (int i = 0; i < 3; ++i) c[i] = b.mn[i] + (b.mx[i] - b.mn[i]) / 2.0f; }
+float box_area(const Box& b) {  // src/aabb.rs:97-100
+    float sx = b.mx[0] - b.mn[0], sy = b.mx[1] - b.mn[1], sz = b.mx[2] - b.mn[2];
+    return 2.0f * (sx * sy + sx * sz + sy * sz);
+}
+
+uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+// Skip-link BVH in pre-order, SAH with 6 buckets on the widest centroid axis, median split when the centroids
+// coincide, one shape per leaf: the reference's build (src/accelerator/bvh.rs:299-457) emitted directly in
+// the flattened order of src/accelerator/lbvh.rs:47-163, with each leaf merged into its navigator node.
+struct BvhBuilder {
+    const std::vector<Box>& shapes;
+    std::vector<uint32_t>& out;  // PT_NODE_WORDS per node
+    uint32_t base;               // first node's index (0)
+    explicit BvhBuilder(const std::vector<Box>& s, std::vector<uint32_t>& o) : shapes(s), out(o), base(0) {}
+
+    uint32_t node_count() const { return (uint32_t)(out.size() / PT_NODE_WORDS); }
+
+    void split(const std::vector<uint32_t>& idx, std::vector<uint32_t>& li, Box& lb, std::vector<uint32_t>& ri, Box& rb) {
+        Box bounds = box_empty(), cbounds = box_empty();
+        for (uint32_t i : idx) { float c[3]; box_center(shapes[i], c); box_expand(bounds, shapes[i]); box_grow(cbounds, c); }
+        float size[3] = {cbounds.mx[0] - cbounds.mn[0], cbounds.mx[1] - cbounds.mn[1], cbounds.mx[2] - cbounds.mn[2]};
+        float widest = std::fmax(std::fmax(size[0], size[1]), std::fmax(size[2], 0.0f));
+        int axis = 0;
+        for (int a = 0; a < 3; ++a) if (size[a] >= widest) axis = a;  // largest lane index among ties (bvh.rs:348-353)
+        float extent = (0.0f >= widest) ? 0.0f : cbounds.mx[axis] - cbounds.mn[axis];
+        if (extent < 0.00001f) {
+            size_t half = idx.size() / 2;
+            li.assign(idx.begin(), idx.begin() + half); ri.assign(idx.begin() + half, idx.end());
+            lb = box_empty(); for (uint32_t i : li) box_expand(lb, shapes[i]);
+            rb = box_empty(); for (uint32_t i : ri) box_expand(rb, shapes[i]);
+            return;
+        }
+        const int NB = 6;
+        size_t count[NB] = {0, 0, 0, 0, 0, 0}; Box bb[NB]; std::vector<uint32_t> members[NB];
+        for (int b = 0; b < NB; ++b) bb[b] = box_empty();
+        for (uint32_t i : idx) {
+            float c[3]; box_center(shapes[i], c);
+            float rel = (c[axis] - cbounds.mn[axis]) / extent;
+            float fb = rel * ((float)NB - 0.01f);
+            int b = fb >= 0.0f ? (int)fb : 0; if (b > NB - 1) b = NB - 1;
+            count[b]++; box_expand(bb[b], shapes[i]); members[b].push_back(i);
+        }
+        int best = 0; float best_cost = INFINITY; lb = box_empty(); rb = box_empty();
+        for (int k = 0; k < NB - 1; ++k) {
+            size_t nl = 0, nr = 0; Box l = box_empty(), r = box_empty();
+            for (int j = 0; j <= k; ++j) { nl += count[j]; box_expand(l, bb[j]); }
+            for (int j = k + 1; j < NB; ++j) { nr += count[j]; box_expand(r, bb[j]); }
+            float cost = ((float)nl * box_area(l) + (float)nr * box_area(r)) / box_area(bounds);
+            if (cost < best_cost) { best = k; best_cost = cost; lb = l; rb = r; }
+        }
+        li.clear(); ri.clear();
+        for (int j = 0; j <= best; ++j) li.insert(li.end(), members[j].begin(), members[j].end());
+        for (int j = best + 1; j < NB; ++j) ri.insert(ri.end(), members[j].begin(), members[j].end());
+    }
+
+    void emit(const std::vector<uint32_t>& idx, const Box& box) {
+        size_t at = out.size();
+        out.resize(at + PT_NODE_WORDS, 0);
+        bool leaf = idx.size() == 1;
+        const Box& b = leaf ? shapes[idx[0]] : box;
+        if (!leaf) { std::vector<uint32_t> li, ri; Box lb, rb; split(idx, li, lb, ri, rb); emit(li, lb); emit(ri, rb); }
+        out[at + 0] = fbits(b.mn[0]); out[at + 1] = fbits(b.mn[1]); out[at + 2] = fbits(b.mn[2]); out[at + 3] = node_count();
+        out[at + 4] = fbits(b.mx[0]); out[at + 5] = fbits(b.mx[1]); out[at + 6] = fbits(b.mx[2]); out[at + 7] = leaf ? idx[0] : PT_NODE_INNER;
+    }
+
+    void build() {
+        if (shapes.empty()) return;
+        std::vector<uint32_t> idx(shapes.size());
+        for (size_t i = 0; i < idx.size(); ++i) idx[i] = (uint32_t)i;
+        if (idx.size() == 1) { emit(idx, shapes[0]); return; }
+        std::vector<uint32_t> li, ri; Box lb, rb;
+        split(idx, li, lb, ri, rb);  // the root itself has no node (lbvh.rs:134-140)
+        emit(li, lb); emit(ri, rb);
+    }
+};
+
+void pad16(std::vector<uint32_t>& w) { while (w.size() % 4) w.push_back(0); }
+
+void xf_point(const float* m, const float* p, float* o) {
+    for (int r = 0; r < 3; ++r) o[r] = m[4 * r] * p[0] + m[4 * r + 1] * p[1] + m[4 * r + 2] * p[2] + m[4 * r + 3];
+}
+
+}  // namespace
+
+bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
+    auto fail = [&](const char* m) { *err = m; return false; };
+    if (d.material_count == 0 || !d.materials) return fail("scene needs at least the error material (index 0)");
+    if (d.camera_count == 0 || !d.cameras) return fail("scene has no camera");
+    if (d.environment.kind == PT_ENV_HDR) return fail("HDR environment is not supported by this build yet");
+    if (d.environment.kind != PT_ENV_CONSTANT && d.environment.kind != PT_ENV_SUN) return fail("unknown environment kind");
+    if (d.environment.curve < 0 || (uint32_t)d.environment.curve >= d.curve_count) return fail("environment curve index out of range");
+    auto curve_ok = [&](int32_t c) { return c >= 0 && (uint32_t)c < d.curve_count; };
+    for (uint32_t i = 0; i < d.curve_count; ++i) {
+        const pt_curve& c = d.curves[i];
+        uint32_t per = c.kind == PT_CURVE_TABULATED ? 2 : ((c.kind == PT_CURVE_EXPONENTIAL || c.kind == PT_CURVE_INV_EXPONENTIAL) ? 4 : 1);
+        bool needs_data = c.kind == PT_CURVE_LINEAR || c.kind == PT_CURVE_TABULATED || c.kind == PT_CURVE_EXPONENTIAL || c.kind == PT_CURVE_INV_EXPONENTIAL;
+        if (c.kind < 0 || c.kind > PT_CURVE_CONST) return fail("unknown curve kind");
+        if (needs_data && ((size_t)c.data_offset + (size_t)c.data_count * per > d.curve_data_count)) return fail("curve data out of range");
+        if ((c.kind == PT_CURVE_LINEAR || c.kind == PT_CURVE_TABULATED) && c.data_count == 0) return fail("empty curve table");
+    }
+    for (uint32_t i = 0; i < d.material_count; ++i) {
+        const pt_material& m = d.materials[i];
+        switch (m.kind) {
+            case PT_MATERIAL_LAMBERTIAN: if (m.texstack < 0 || (uint32_t)m.texstack >= d.texstack_count) return fail("lambertian texstack out of range"); break;
+            case PT_MATERIAL_GGX: if (!curve_ok(m.curve_eta) || !curve_ok(m.curve_eta_o) || !curve_ok(m.curve_kappa)) return fail("ggx curve out of range");
+                if (!(m.alpha > 0.0f)) return fail("ggx alpha must be positive"); break;
+            case PT_MATERIAL_DIFFUSE_LIGHT: case PT_MATERIAL_SHARP_LIGHT: if (!curve_ok(m.curve_emit) || !curve_ok(m.curve_bounce)) return fail("light curve out of range"); break;
+            default: return fail("unknown material kind");
+        }
+    }
+    for (uint32_t i = 0; i < d.texstack_count; ++i) {
+        const pt_texstack& t = d.texstacks[i];
+        if (t.first_layer < 0 || t.layer_count < 0 || (uint32_t)(t.first_layer + t.layer_count) > d.layer_count) return fail("texstack layers out of range");
+        for (int l = 0; l < t.layer_count; ++l) {
+            const pt_texture_layer& L = d.layers[t.first_layer + l];
+            if (L.kind != PT_TEXTURE1 && L.kind != PT_TEXTURE4) return fail("unknown texture layer kind");
+            if (L.width <= 0 || L.height <= 0) return fail("empty texture");
+            size_t n = (size_t)L.width * L.height * (L.kind == PT_TEXTURE4 ? 4 : 1);
+            if (L.data_offset + n > d.texture_data_count) return fail("texture data out of range");
+            for (int k = 0; k < (L.kind == PT_TEXTURE4 ? 4 : 1); ++k) if (!curve_ok(L.curves[k])) return fail("texture curve out of range");
+            if (L.data_offset + n > 0xffffffffull) return fail("texture data too large");
+        }
+    }
+    auto material_ok = [&](uint32_t id) { return id == PT_MATERIAL_NONE || PT_MATERIAL_INDEX(id) < d.material_count; };
+
+    std::vector<uint32_t>& w = hs->blob;
+    w.assign(PT_HDR_WORDS, 0);
+    hs->tex.assign(d.texture_data, d.texture_data + d.texture_data_count);
+    if (hs->tex.empty()) hs->tex.push_back(0.0f);
+    hs->cameras.assign(d.cameras, d.cameras + d.camera_count);
+
+    // curves
+    pad16(w);
+    std::vector<uint32_t> curve_off(d.curve_count);
+    for (uint32_t i = 0; i < d.curve_count; ++i) { curve_off[i] = (uint32_t)w.size(); w.resize(w.size() + PT_CURVE_WORDS, 0); }
+    for (uint32_t i = 0; i < d.curve_count; ++i) {
+        const pt_curve& c = d.curves[i];
+        uint32_t per = c.kind == PT_CURVE_TABULATED ? 2 : ((c.kind == PT_CURVE_EXPONENTIAL || c.kind == PT_CURVE_INV_EXPONENTIAL) ? 4 : 1);
+        uint32_t off = (uint32_t)w.size();
+        bool has = c.kind == PT_CURVE_LINEAR || c.kind == PT_CURVE_TABULATED || c.kind == PT_CURVE_EXPONENTIAL || c.kind == PT_CURVE_INV_EXPONENTIAL;
+        if (has) for (uint32_t k = 0; k < c.data_count * per; ++k) w.push_back(fbits(d.curve_data[c.data_offset + k]));
+        uint32_t* r = &w[curve_off[i]];
+        r[0] = (uint32_t)c.kind; r[1] = (uint32_t)c.mode; r[2] = fbits(c.p0); r[3] = fbits(c.p1); r[4] = off; r[5] = has ? c.data_count : 0;
+    }
+    w[PT_HDR_CURVE_OFF] = d.curve_count ? curve_off[0] : 0; w[PT_HDR_CURVE_COUNT] = d.curve_count;
+    hs->curve_offsets = curve_off;
+
+    // texstacks
+    pad16(w);
+    std::vector<uint32_t> ts_off(d.texstack_count);
+    for (uint32_t i = 0; i < d.texstack_count; ++i) {
+        const pt_texstack& t = d.texstacks[i];
+        ts_off[i] = (uint32_t)w.size();
+        w.push_back((uint32_t)t.layer_count);
+        for (int l = 0; l < t.layer_count; ++l) {
+            const pt_texture_layer& L = d.layers[t.first_layer + l];
+            w.push_back((uint32_t)L.kind);
+            for (int k = 0; k < 4; ++k) w.push_back((L.kind == PT_TEXTURE4 || k == 0) ? curve_off[L.curves[k]] : 0);
+            w.push_back((uint32_t)L.width); w.push_back((uint32_t)L.height); w.push_back((uint32_t)L.data_offset);
+        }
+    }
+
+    // materials
+    pad16(w);
+    w[PT_HDR_MATERIAL_OFF] = (uint32_t)w.size(); w[PT_HDR_MATERIAL_COUNT] = d.material_count;
+    for (uint32_t i = 0; i < d.material_count; ++i) {
+        const pt_material& m = d.materials[i];
+        uint32_t r[PT_MAT_WORDS] = {0};
+        r[PT_MAT_KIND] = (uint32_t)m.kind;
+        r[PT_MAT_ALPHA] = fbits(m.alpha);
+        r[PT_MAT_SHARPNESS] = fbits(1.0f + std::fabs(m.sharpness));  // SharpLight::new, sharp_light.rs:26
+        r[PT_MAT_SIDEDNESS] = (uint32_t)m.sidedness;
+        if (m.kind == PT_MATERIAL_LAMBERTIAN) r[PT_MAT_TEXSTACK] = ts_off[m.texstack];
+        if (m.kind == PT_MATERIAL_GGX) {
+            r[PT_MAT_ETA] = curve_off[m.curve_eta]; r[PT_MAT_ETA_O] = curve_off[m.curve_eta_o]; r[PT_MAT_KAPPA] = curve_off[m.curve_kappa];
+            // GGX::new: metallic = kappa.evaluate_integral(BOUNDED_VISIBLE_RANGE, 100, false) > 0 (ggx.rs:205)
+            float sum = 0.0f, step = (750.0f - 380.0f) / 100.0f;
+            ptd::SceneView view{w.data(), hs->tex.data()};
+            for (int k = 0; k < 100; ++k) sum += ptd::curve_eval(view, curve_off[m.curve_kappa], 380.0f + (float)k * step) * step;
+            r[PT_MAT_METALLIC] = sum > 0.0f ? 1u : 0u;
+        }
+        if (m.kind == PT_MATERIAL_DIFFUSE_LIGHT || m.kind == PT_MATERIAL_SHARP_LIGHT) { r[PT_MAT_EMIT] = curve_off[m.curve_emit]; r[PT_MAT_BOUNCE] = curve_off[m.curve_bounce]; }
+        w.insert(w.end(), r, r + PT_MAT_WORDS);
+    }
+
+    // meshes: per-mesh BVH over triangles (Mesh::init, mesh.rs:283-305) + gathered triangle records
+    std::vector<uint32_t> mesh_off(d.mesh_count);
+    std::vector<Box> mesh_box(d.mesh_count);
+    hs->mesh_has_light.assign(d.mesh_count, 0);
+    std::vector<uint32_t> mesh_light_faces(d.mesh_count, 0);
+    for (uint32_t mi = 0; mi < d.mesh_count; ++mi) {
+        const pt_mesh& m = d.meshes[mi];
+        if ((size_t)m.vertex_offset + m.vertex_count > d.vertex_count) return fail("mesh vertices out of range");
+        if ((size_t)m.index_offset + 3 * (size_t)m.face_count > d.index_count) return fail("mesh indices out of range");
+        if (m.normal_offset >= 0 && (size_t)m.normal_offset + m.vertex_count > d.normal_count) return fail("mesh normals out of range");
+        if (m.face_material_offset >= 0 && (size_t)m.face_material_offset + m.face_count > d.face_material_count) return fail("mesh face materials out of range");
+        if (m.face_count == 0) return fail("mesh without faces");
+        const float* V = d.vertices + 3 * (size_t)m.vertex_offset;
+        Box mb = box_empty();
+        for (uint32_t v = 0; v < m.vertex_count; ++v) box_grow(mb, V + 3 * v);  // Mesh::new bounding box over all vertices
+        mesh_box[mi] = mb;
+        std::vector<Box> tb(m.face_count);
+        for (uint32_t f = 0; f < m.face_count; ++f) {
+            const uint32_t* ix = d.indices + m.index_offset + 3 * (size_t)f;
+            for (int k = 0; k < 3; ++k) if (ix[k] >= m.vertex_count) return fail("mesh index out of range");
+            Box b = box_of_corners(V + 3 * ix[0], V + 3 * ix[1]); box_grow(b, V + 3 * ix[2]);  // mesh.rs:57-64
+            tb[f] = b;
+        }
+        pad16(w);
+        uint32_t node_off = (uint32_t)w.size();
+        std::vector<uint32_t> nodes; BvhBuilder bb(tb, nodes); bb.build();
+        w.insert(w.end(), nodes.begin(), nodes.end());
+        uint32_t tri_off = (uint32_t)w.size();
+        for (uint32_t f = 0; f < m.face_count; ++f) {
+            const uint32_t* ix = d.indices + m.index_offset + 3 * (size_t)f;
+            uint32_t mat = m.face_material_offset >= 0 ? d.face_materials[m.face_material_offset + f] : PT_MATERIAL_ID(PT_TAG_MATERIAL, 0);
+            if (!material_ok(mat) || mat == PT_MATERIAL_NONE) return fail("mesh face material out of range");
+            if (PT_MATERIAL_TAG(mat) == PT_TAG_LIGHT) mesh_light_faces[mi]++;
+            for (int k = 0; k < 3; ++k) {
+                const float* p = V + 3 * ix[k];
+                w.push_back(fbits(p[0])); w.push_back(fbits(p[1])); w.push_back(fbits(p[2])); w.push_back(k == 0 ? mat : 0u);
+            }
+        }
+        uint32_t normal_off = 0;
+        if (m.normal_offset >= 0) {
+            const float* N = d.normals + 3 * (size_t)m.normal_offset;
+            normal_off = (uint32_t)w.size();
+            for (uint32_t f = 0; f < m.face_count; ++f) {
+                const uint32_t* ix = d.indices + m.index_offset + 3 * (size_t)f;
+                for (int k = 0; k < 3; ++k) { const float* p = N + 3 * ix[k]; w.push_back(fbits(p[0])); w.push_back(fbits(p[1])); w.push_back(fbits(p[2])); w.push_back(0u); }
+            }
+        }
+        mesh_off[mi] = (uint32_t)w.size();
+        uint32_t rec[PT_MESH_WORDS] = {node_off, (uint32_t)(nodes.size() / PT_NODE_WORDS), tri_off, normal_off, m.face_count, 0, 0, 0};
+        w.insert(w.end(), rec, rec + PT_MESH_WORDS);
+    }
+
+    // instances + their world boxes (Instance::aabb, instance.rs:65-72; Matrix4x4 * AABB, aabb.rs:116-138)
+    pad16(w);
+    w[PT_HDR_INSTANCE_OFF] = (uint32_t)w.size(); w[PT_HDR_INSTANCE_COUNT] = d.instance_count;
+    std::vector<Box> ibox(d.instance_count);
+    std::vector<uint32_t> lights;
+    for (uint32_t i = 0; i < d.instance_count; ++i) {
+        const pt_instance& in = d.instances[i];
+        if (!material_ok(in.material)) return fail("instance material out of range");
+        uint32_t r[PT_INST_WORDS] = {0};
+        r[PT_INST_KIND] = (uint32_t)in.kind;
+        r[PT_INST_FLAGS] = (in.has_transform ? 1u : 0u) | (in.two_sided ? 2u : 0u) | (((uint32_t)in.axis & 3u) << 2);
+        r[PT_INST_MATERIAL] = in.material;
+        for (int k = 0; k < 3; ++k) r[PT_INST_ORIGIN + k] = fbits(in.origin[k]);
+        r[PT_INST_RADIUS] = fbits(in.radius);
+        r[PT_INST_SIZE] = fbits(in.size[0]); r[PT_INST_SIZE + 1] = fbits(in.size[1]);
+        for (int k = 0; k < 12; ++k) { r[PT_INST_FORWARD + k] = fbits(in.forward[k]); r[PT_INST_REVERSE + k] = fbits(in.reverse[k]); }
+        Box b;
+        switch (in.kind) {
+            case PT_SHAPE_RECT: {  // rect.rs:58-66
+                if (!(in.size[0] > 0.0f && in.size[1] > 0.0f) || in.axis < 0 || in.axis > 2) return fail("bad rect");
+                float hx = in.size[0] / 2.0f, hy = in.size[1] / 2.0f, v[3];
+                if (in.axis == PT_AXIS_X) { v[0] = 0.0001f; v[1] = hy; v[2] = hx; }
+                else if (in.axis == PT_AXIS_Y) { v[0] = hx; v[1] = 0.0001f; v[2] = hy; }
+                else { v[0] = hx; v[1] = hy; v[2] = 0.0001f; }
+                float lo[3], hi[3]; for (int k = 0; k < 3; ++k) { lo[k] = in.origin[k] - v[k]; hi[k] = in.origin[k] + v[k]; }
+                b = box_of_corners(lo, hi); break;
+            }
+            case PT_SHAPE_SPHERE: {  // sphere.rs:24-31
+                if (!(in.radius > 0.0f)) return fail("bad sphere");
+                float lo[3], hi[3]; for (int k = 0; k < 3; ++k) { lo[k] = in.origin[k] - in.radius; hi[k] = in.origin[k] + in.radius; }
+                b = box_of_corners(lo, hi); break;
+            }
+            case PT_SHAPE_DISK: {  // disk.rs:23-28 (radius / 2: reference quirk kept)
+                if (!(in.radius > 0.0f)) return fail("bad disk");
+                float v[3] = {in.radius / 2.0f, in.radius / 2.0f, 0.001f}, lo[3], hi[3];
+                for (int k = 0; k < 3; ++k) { lo[k] = in.origin[k] - v[k]; hi[k] = in.origin[k] + v[k]; }
+                b = box_of_corners(lo, hi); break;
+            }
+            case PT_SHAPE_MESH:
+                if (in.mesh < 0 || (uint32_t)in.mesh >= d.mesh_count) return fail("instance mesh out of range");
+                r[PT_INST_MESH] = mesh_off[in.mesh]; b = mesh_box[in.mesh]; break;
+            default: return fail("unknown shape kind");
+        }
+        if (in.has_transform) {
+            Box t = box_empty();
+            for (int c = 0; c < 8; ++c) {
+                float p[3] = {(c & 1) == 0 ? b.mn[0] : b.mx[0], ((c >> 1) & 1) == 0 ? b.mn[1] : b.mx[1], ((c >> 2) & 1) == 0 ? b.mn[2] : b.mx[2]}, q[3];
+                xf_point(in.forward, p, q); box_grow(t, q);
+            }
+            b = t;
+        }
+        ibox[i] = b;
+        w.insert(w.end(), r, r + PT_INST_WORDS);
+        // World::new light list (world/mod.rs:42-66)
+        if (in.kind == PT_SHAPE_MESH) { for (uint32_t k = 0; k < mesh_light_faces[in.mesh]; ++k) lights.push_back(i); }
+        else {
+            uint32_t mid = in.material == PT_MATERIAL_NONE ? PT_MATERIAL_ID(PT_TAG_MATERIAL, 0) : in.material;
+            if (PT_MATERIAL_TAG(mid) == PT_TAG_LIGHT) lights.push_back(i);
+        }
+    }
+    for (uint32_t l : lights) if (d.instances[l].kind == PT_SHAPE_MESH) return fail("mesh lights cannot be sampled (todo!() in the reference, mesh.rs:213-232)");
+
+    // top-level BVH over instances
+    pad16(w);
+    {
+        std::vector<uint32_t> nodes; BvhBuilder bb(ibox, nodes); bb.build();
+        w[PT_HDR_TOP_NODE_OFF] = (uint32_t)w.size(); w[PT_HDR_TOP_NODE_COUNT] = (uint32_t)(nodes.size() / PT_NODE_WORDS);
+        w.insert(w.end(), nodes.begin(), nodes.end());
+    }
+    pad16(w);
+    w[PT_HDR_LIGHT_OFF] = (uint32_t)w.size(); w[PT_HDR_LIGHT_COUNT] = (uint32_t)lights.size();
+    w.insert(w.end(), lights.begin(), lights.end());
+    pad16(w);
+
+    // environment + world radius (World::new, world/mod.rs:69-81)
+    w[PT_HDR_ENV_KIND] = (uint32_t)d.environment.kind;
+    w[PT_HDR_ENV_STRENGTH] = fbits(d.environment.strength);
+    w[PT_HDR_ENV_CURVE] = curve_off[d.environment.curve];
+    w[PT_HDR_ENV_ANGULAR] = fbits(d.environment.angular_diameter);
+    for (int k = 0; k < 3; ++k) w[PT_HDR_ENV_SUN_DIR + k] = fbits(d.environment.sun_direction[k]);
+    float env_p = lights.empty() ? 1.0f : d.env_sampling_probability;
+    w[PT_HDR_ENV_PROB] = fbits(env_p);
+    float radius = 0.0f;
+    if (d.instance_count) {
+        Box wb = ibox[0]; for (uint32_t i = 1; i < d.instance_count; ++i) box_expand(wb, ibox[i]);
+        float sx = wb.mx[0] - wb.mn[0], sy = wb.mx[1] - wb.mn[1], sz = wb.mx[2] - wb.mn[2];
+        radius = std::sqrt(sx * sx + sy * sy + sz * sz) / 2.0f;
+    }
+    w[PT_HDR_WORLD_RADIUS] = fbits(radius);
+    w[PT_HDR_MAGIC] = PT_BLOB_MAGIC; w[PT_HDR_TOTAL_WORDS] = (uint32_t)w.size();
+    hs->light_count = (uint32_t)lights.size();
+    hs->material_count = d.material_count;
+    hs->curve_count = d.curve_count;
+    return true;
+}
+
+}  // namespace pth

@@ -1,0 +1,285 @@
+// pt_stages.h — what one lane does in each stage of the wavefront path tracer.
+//
+// The reference runs one recursive-free but strictly sequential loop per camera sample
+// (PathTracingIntegrator::color, src/integrator/pt.rs:397-615, calling random_walk,
+// src/integrator/utils.rs:152-376).  Here the same work is cut into stages that run as separate kernels
+// over dense SoA queues in HBM:
+//
+//   generate  : jitter, wavelength, thin-lens camera ray                       (tiled.rs:366-380, pt.rs:404-417)
+//   extend    : closest hit of the path segment                                (utils.rs:171 -> World::hit)
+//   shade     : everything the walk and the second pass do at one vertex       (utils.rs:172-329, pt.rs:481-604)
+//               emission + MIS for light / environment vertices, BSDF sample, roulette, next ray,
+//               and the set-up of the light samples (light pick, Hittable::sample, bsdf, weight)
+//   shadow    : closest hit of the light-sample rays + emission at the hit     (pt.rs:171-217, 252-330)
+//   accumulate: energy -> CIE XYZ, summed into the film in the reference's order (pt.rs:614, tiled.rs:366-398)
+//
+// NEE is done at the bounce that creates the vertex instead of in a second pass over a vertex list: every
+// light sample only needs that vertex's hit, wi, material and the throughput *before* the bounce
+// (utils.rs:177-193), and random numbers are addressed by (bounce, light sample), so nothing changes.
+#ifndef PT_STAGES_H
+#define PT_STAGES_H
+
+#include "pt_device.h"
+
+namespace ptd {
+
+// ---- SoA queues.  Field k of item i lives at base[k * capacity + i]: every field is a dense, coalesced stream.
+enum { PS_OX, PS_OY, PS_OZ, PS_DX, PS_DY, PS_DZ, PS_BETA, PS_LAMBDA, PS_SLOT, PS_PREV_PDF, PS_PNX, PS_PNY, PS_PNZ, PS_PPX, PS_PPY, PS_PPZ, PS_FIELDS };
+enum { HS_T, HS_PX, HS_PY, HS_PZ, HS_NX, HS_NY, HS_NZ, HS_U, HS_V, HS_MAT, HS_INST, HS_FIELDS };
+// shadow item: SH_SLOT, SH_LAMBDA, SH_FLAGS (bit l set: sub-ray l is an environment sample), then per light sample l: 7 floats
+enum { SH_SLOT, SH_LAMBDA, SH_FLAGS, SH_HEAD };
+enum { SR_OX, SR_OY, SR_OZ, SR_DX, SR_DY, SR_DZ, SR_FACTOR, SR_FIELDS };
+#define PT_MAX_LIGHT_SAMPLES 8
+
+struct Queue { uint32_t* base; uint32_t capacity; };
+PT_HD float qf(const Queue& q, uint32_t field, uint32_t i) { return pt_u2f(q.base[(size_t)field * q.capacity + i]); }
+PT_HD uint32_t qu(const Queue& q, uint32_t field, uint32_t i) { return q.base[(size_t)field * q.capacity + i]; }
+PT_HD void qsf(const Queue& q, uint32_t field, uint32_t i, float v) { q.base[(size_t)field * q.capacity + i] = pt_f2u(v); }
+PT_HD void qsu(const Queue& q, uint32_t field, uint32_t i, uint32_t v) { q.base[(size_t)field * q.capacity + i] = v; }
+
+struct RenderParams {
+    uint64_t seed;
+    uint32_t width, height;
+    uint32_t min_bounces, max_bounces, light_samples, only_direct;
+    float wavelength_lo, wavelength_span;
+    uint32_t chunk_pixels;      // pixels in this pass (slot = s_local * chunk_pixels + p)
+    uint32_t first_sample;      // absolute sample index of s_local = 0
+    uint32_t pass_samples;      // samples per pixel in this pass
+    uint32_t spp;               // RenderSettings::min_samples
+    uint32_t range_end;         // first_sample + sample_count of the whole call
+    uint32_t normalize;         // divide by spp when the last phase of a whole render is flushed
+    CameraParams camera;
+};
+
+struct PathVertex {  // the register-resident state of one path between stages
+    F3 o, d; float beta, lambda; uint32_t slot; float prev_pdf; F3 prev_n, prev_p;
+};
+PT_HD PathVertex load_path(const Queue& q, uint32_t i) {
+    PathVertex p;
+    p.o = f3(qf(q, PS_OX, i), qf(q, PS_OY, i), qf(q, PS_OZ, i));
+    p.d = f3(qf(q, PS_DX, i), qf(q, PS_DY, i), qf(q, PS_DZ, i));
+    p.beta = qf(q, PS_BETA, i); p.lambda = qf(q, PS_LAMBDA, i); p.slot = qu(q, PS_SLOT, i); p.prev_pdf = qf(q, PS_PREV_PDF, i);
+    p.prev_n = f3(qf(q, PS_PNX, i), qf(q, PS_PNY, i), qf(q, PS_PNZ, i));
+    p.prev_p = f3(qf(q, PS_PPX, i), qf(q, PS_PPY, i), qf(q, PS_PPZ, i));
+    return p;
+}
+PT_HD void store_path(const Queue& q, uint32_t i, const PathVertex& p) {
+    qsf(q, PS_OX, i, p.o.x); qsf(q, PS_OY, i, p.o.y); qsf(q, PS_OZ, i, p.o.z);
+    qsf(q, PS_DX, i, p.d.x); qsf(q, PS_DY, i, p.d.y); qsf(q, PS_DZ, i, p.d.z);
+    qsf(q, PS_BETA, i, p.beta); qsf(q, PS_LAMBDA, i, p.lambda); qsu(q, PS_SLOT, i, p.slot); qsf(q, PS_PREV_PDF, i, p.prev_pdf);
+    qsf(q, PS_PNX, i, p.prev_n.x); qsf(q, PS_PNY, i, p.prev_n.y); qsf(q, PS_PNZ, i, p.prev_n.z);
+    qsf(q, PS_PPX, i, p.prev_p.x); qsf(q, PS_PPY, i, p.prev_p.y); qsf(q, PS_PPZ, i, p.prev_p.z);
+}
+PT_HD void store_hit(const Queue& q, uint32_t i, const Hit& h) {
+    qsf(q, HS_T, i, h.valid ? h.t : -1.0f);
+    if (!h.valid) return;
+    qsf(q, HS_PX, i, h.p.x); qsf(q, HS_PY, i, h.p.y); qsf(q, HS_PZ, i, h.p.z);
+    qsf(q, HS_NX, i, h.n.x); qsf(q, HS_NY, i, h.n.y); qsf(q, HS_NZ, i, h.n.z);
+    qsf(q, HS_U, i, h.u); qsf(q, HS_V, i, h.v); qsu(q, HS_MAT, i, h.material); qsu(q, HS_INST, i, h.instance);
+}
+PT_HD Hit load_hit(const Queue& q, uint32_t i) {
+    Hit h; h.t = qf(q, HS_T, i); h.valid = h.t >= 0.0f;
+    if (!h.valid) return h;
+    h.p = f3(qf(q, HS_PX, i), qf(q, HS_PY, i), qf(q, HS_PZ, i));
+    h.n = f3(qf(q, HS_NX, i), qf(q, HS_NY, i), qf(q, HS_NZ, i));
+    h.u = qf(q, HS_U, i); h.v = qf(q, HS_V, i); h.material = qu(q, HS_MAT, i); h.instance = qu(q, HS_INST, i);
+    return h;
+}
+
+// ------------------------------------------------------------------------------------------------ generate
+PT_HD PathVertex stage_generate(const RenderParams& rp, uint32_t slot, uint32_t pixel) {
+    uint32_t s_local = slot / rp.chunk_pixels;
+    uint32_t sample = rp.first_sample + s_local;
+    uint32_t x = pixel % rp.width, y = pixel / rp.width;
+    pt_f32x4 fs = pt_draw4(rp.seed, pixel, sample, PT_DIM_FILM);
+    float cu = ((float)x + fs.x) / (float)rp.width, cv = ((float)y + fs.y) / (float)rp.height;  // box filter, tiled.rs:372-375
+    PathVertex p;
+    p.lambda = rp.wavelength_lo + fs.z * rp.wavelength_span;                                     // pt.rs:406
+    float fu = pt_clamp(cu, 0.0f, 1.0f - PT_F32_EPSILON), fv = pt_clamp(cv, 0.0f, 1.0f - PT_F32_EPSILON);  // pt.rs:411-414
+    camera_ray(rp.camera, rp.seed, pixel, sample, fu, fv, &p.o, &p.d);
+    p.beta = 1.0f; p.slot = slot;
+    p.prev_pdf = 100.0f; p.prev_n = p.d; p.prev_p = p.o;  // the camera vertex (pt.rs:430-446)
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------ shade
+struct ShadowRay { F3 o, d; float factor; };
+struct ShadeOut {
+    bool survives;          // path continues with `next`
+    PathVertex next;
+    float energy_add;       // light / environment vertex contribution
+    bool add_energy;
+    bool vertex_pushed;     // counts towards Profile::bounce_rays
+    bool env_hit;
+    uint32_t shadow_count;  // valid sub-rays (Profile::shadow_rays)
+    uint32_t env_mask;      // bit l: sub-ray l is an environment sample
+    bool has_item;
+};
+
+// One vertex of random_walk (utils.rs:170-373) + the matching iteration of color()'s second pass (pt.rs:481-604).
+// `rays` must hold PT_MAX_LIGHT_SAMPLES entries; entries with factor == 0 are not traced.
+PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t bounce, const PathVertex& pv, const Hit& hit,
+                           uint32_t pixel, ShadowRay* rays) {
+    ShadeOut out;
+    out.survives = false; out.energy_add = 0.0f; out.add_energy = false; out.vertex_pushed = false; out.env_hit = false;
+    out.shadow_count = 0; out.env_mask = 0; out.has_item = false;
+    uint32_t sample = rp.first_sample + pv.slot / rp.chunk_pixels;
+    bool prev_is_camera = bounce == 0;
+    float lambda = pv.lambda;
+    if (!hit.valid) {
+        // environment vertex (utils.rs:344-372) and its MIS-weighted emission (pt.rs:487-511)
+        F3 wo = pv.d;
+        float u = 0.0f, v = 0.0f;
+        if (bu(s, PT_HDR_ENV_KIND) != PT_ENV_CONSTANT) direction_to_uv(wo, &u, &v);
+        float emission = env_emission(s, u, v, lambda);
+        float cos_i = pt_abs(dot(pv.prev_n, wo));
+        float nee_psa_pdf = env_pdf_for(s, u, v) / pt_abs(cos_i);
+        float bsdf_psa_pdf = pv.prev_pdf / pt_abs(cos_i);
+        float weight = (bsdf_psa_pdf * bsdf_psa_pdf) / (bsdf_psa_pdf * bsdf_psa_pdf + nee_psa_pdf * nee_psa_pdf);
+        out.energy_add = weight * pv.beta * emission; out.add_energy = true;
+        out.vertex_pushed = true; out.env_hit = true;
+        return out;
+    }
+    Frame frame = frame_from_normal(hit.n);
+    F3 wi = normalize(to_local(frame, neg(pv.d)));
+    uint32_t m = material_record(s, hit.material);
+    bool is_light = PT_MATERIAL_TAG(hit.material) == PT_TAG_LIGHT;
+    pt_f32x4 r = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples));
+    float f, pdf; F3 wo;
+    material_sample(s, m, lambda, hit.u, hit.v, r.x, r.y, wi, &f, &wo, &pdf);
+    float cos_o = pt_abs(wo.z);
+    if (pt_isnan(pdf)) return out;  // utils.rs:261-263: the vertex is never pushed
+    float rr = (bounce >= rp.min_bounces) ? pt_min(f / pdf, 1.0f) : 1.0f;
+    float pdf_forward = pdf * (rr / cos_o);
+    out.vertex_pushed = true;
+
+    if (is_light) {
+        // pt.rs:512-561
+        float emission = material_emission(s, m, lambda, wi);
+        if (emission > 0.0f) {
+            if (rp.light_samples == 0 || prev_is_camera) { out.energy_add = pv.beta * emission; out.add_energy = true; }
+            else if (!rp.only_direct) {
+                F3 nee_dir = normalize(sub(hit.p, pv.prev_p));
+                uint32_t inst = bu(s, PT_HDR_INSTANCE_OFF) + hit.instance * PT_INST_WORDS;
+                float pdfh = light_psa_pdf(s, inst, dot(pv.prev_n, nee_dir), dot(hit.n, nee_dir), pv.prev_p, hit.p);
+                float a = pv.prev_pdf;
+                float weight = (a * a) / (a * a + pdfh * pdfh);
+                out.energy_add = weight * pv.beta * emission; out.add_energy = true;
+            }
+        }
+    } else if (rp.light_samples > 0) {
+        // pt.rs:562-604 -> estimate_direct_illumination_with_loop (pt.rs:333-393)
+        uint32_t n_lights = bu(s, PT_HDR_LIGHT_COUNT);
+        float env_p = bf(s, PT_HDR_ENV_PROB);
+        if (!(n_lights == 0 && env_p == 0.0f)) {
+            F3 hn = normalize(hit.n);  // HitRecord::from(vertex) renormalises (utils.rs:117-134)
+            Frame fr2 = frame_from_normal(hn);
+            F3 wi2 = to_local(fr2, normalize(sub(pv.prev_p, hit.p)));
+            for (uint32_t l = 0; l < rp.light_samples; ++l) {
+                rays[l].factor = 0.0f;
+                pt_f32x4 q = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples) + 1u + l);
+                float x = q.x;
+                bool sample_world = choose_first(&x, env_p);
+                if (sample_world) {
+                    // estimate_direct_illumination_from_world, pt.rs:224-331
+                    float eu, ev, light_pdf;
+                    env_sample_uv(s, q.y, q.z, &eu, &ev, &light_pdf);
+                    F3 direction = uv_to_direction(eu, ev);
+                    F3 local_wo = to_local(fr2, direction);
+                    if (local_wo.z <= 0.0f) continue;
+                    float refl, spdf;
+                    material_bsdf(s, m, lambda, hit.u, hit.v, wi2, local_wo, &refl, &spdf);
+                    float emission = env_emission(s, eu, ev, lambda);
+                    float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + spdf);
+                    rays[l].o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(direction.z)));
+                    rays[l].d = direction;
+                    rays[l].factor = pv.beta * weight * refl * emission * pt_abs(local_wo.z) * (1.0f / light_pdf);
+                    out.env_mask |= 1u << l;
+                    out.shadow_count += 1;
+                    // a contribution of exactly 0 adds 0 whether or not the ray is occluded; keep it traceable
+                    if (rays[l].factor == 0.0f) { out.env_mask &= ~(1u << l); }
+                } else {
+                    // estimate_direct_illumination, pt.rs:146-218
+                    if (n_lights == 0) continue;
+                    float fi = pt_clamp((float)n_lights * x, 0.0f, (float)n_lights - 1.0f);
+                    uint32_t light_id = bu(s, bu(s, PT_HDR_LIGHT_OFF) + (uint32_t)fi);
+                    float pick_pdf = 1.0f / (float)n_lights;
+                    F3 ldir; float light_pdf;
+                    light_sample(s, bu(s, PT_HDR_INSTANCE_OFF) + light_id * PT_INST_WORDS, q.y, q.z, hit.p, &ldir, &light_pdf);
+                    light_pdf = light_pdf * pick_pdf;
+                    if (light_pdf == 0.0f) continue;
+                    F3 bsdf_wo = to_local(fr2, ldir);
+                    float refl, bpdf;
+                    material_bsdf(s, m, lambda, hit.u, hit.v, wi2, bsdf_wo, &refl, &bpdf);
+                    float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + bpdf);
+                    rays[l].o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(bsdf_wo.z)));
+                    rays[l].d = ldir;
+                    // pt.rs:196-202: reflectance * throughput * cos_i * cos_o * emission * weight / light_pdf; cos_i and the
+                    // emission are only known at the shadow hit and are multiplied in there.
+                    rays[l].factor = refl * pv.beta * pt_abs(bsdf_wo.z) * weight / light_pdf;
+                    out.shadow_count += 1;
+                }
+            }
+            out.has_item = true;
+        }
+    }
+
+    // continue the walk (utils.rs:301-329)
+    float beta = pv.beta * (f / pdf_forward);
+    if (pdf_forward == 0.0f) beta = 0.0f;
+    if (beta == 0.0f) return out;
+    if (r.z > rr) return out;
+    if (bounce + 1 >= (rp.only_direct ? 1u : rp.max_bounces)) return out;  // `for bounce in 0..bounce_limit`
+    out.survives = true;
+    out.next.o = add(hit.p, mul(mul(hit.n, 0.001f), pt_signum(wo.z)));
+    out.next.d = normalize(to_world(frame, wo));
+    out.next.beta = beta; out.next.lambda = lambda; out.next.slot = pv.slot;
+    out.next.prev_pdf = pdf_forward; out.next.prev_n = hit.n; out.next.prev_p = hit.p;
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------ shadow
+// The light-sample ray of pt.rs:171-217: nearest hit must be *a* light; emission is evaluated at that hit.
+PT_HD float stage_shadow_light(const SceneView& s, float lambda, const ShadowRay& ray) {
+    Hit sh;
+    if (!world_hit(s, ray.o, ray.d, &sh)) return 0.0f;
+    if (PT_MATERIAL_TAG(sh.material) != PT_TAG_LIGHT) return 0.0f;
+    Frame lf = frame_from_normal(sh.n);
+    F3 lwi = to_local(lf, neg(ray.d));
+    float emission = material_emission(s, material_record(s, sh.material), lambda, lwi);
+    return ray.factor * pt_abs(lwi.z) * emission;
+}
+// The environment-sample ray of pt.rs:252-330: contributes only if nothing is hit.
+PT_HD float stage_shadow_env(const SceneView& s, const ShadowRay& ray) {
+    Hit sh;
+    if (world_hit(s, ray.o, ray.d, &sh)) return 0.0f;
+    return ray.factor;
+}
+
+// ------------------------------------------------------------------------------------------------ accumulate
+// XYZColor::from(SingleWavelength) (math crate; pt.rs:614) and the film sums of tiled.rs:366-398.
+PT_HD void stage_accumulate_pixel(const RenderParams& rp, const float* energy, uint32_t p, uint32_t pixel, float* film_px) {
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+    float f0 = film_px[0], f1 = film_px[1], f2 = film_px[2];
+    for (uint32_t s_local = 0; s_local < rp.pass_samples; ++s_local) {
+        uint32_t sample = rp.first_sample + s_local;
+        float e = energy[(size_t)s_local * rp.chunk_pixels + p];
+        pt_f32x4 fs = pt_draw4(rp.seed, pixel, sample, PT_DIM_FILM);
+        float lambda = rp.wavelength_lo + fs.z * rp.wavelength_span;
+        float xb, yb, zb;
+        xyz_bar(lambda * 10.0f, &xb, &yb, &zb);
+        t0 += e * xb; t1 += e * yb; t2 += e * zb;
+        if ((sample + 1) % 10 == 0 || sample + 1 == rp.spp || sample + 1 == rp.range_end) {  // phases of 10, tiled.rs:347-361
+            f0 += t0; f1 += t1; f2 += t2;
+            t0 = t1 = t2 = 0.0f;
+        }
+    }
+    if (rp.normalize && rp.first_sample + rp.pass_samples == rp.range_end) {
+        float n = (float)rp.spp;
+        f0 /= n; f1 /= n; f2 /= n;
+    }
+    film_px[0] = f0; film_px[1] = f1; film_px[2] = f2; film_px[3] = 0.0f;
+}
+
+}  // namespace ptd
+#endif

@@ -1,0 +1,151 @@
+// ptemu.cpp — TEST HARNESS: runs the HIP engine's per-lane stage functions (csrc/pt_stages.h, pt_device.h)
+// and its host-side scene flattening / pass planning on the CPU, one "lane" at a time, with sequential queue
+// compaction in place of the wave64 ballot.  It exists so that the wavefront logic can be compared with the
+// oracle bit for bit in the GPU-less build container (tests/test_emulation.py); it is not part of the product
+// (nothing in rust-pathtracer_amd/ builds, links or loads it) and exports the boundary with the prefix ptemu_.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../rust-pathtracer_amd/csrc/pt_plan.h"
+#include "../../rust-pathtracer_amd/csrc/pt_scene_host.h"
+#include "../../rust-pathtracer_amd/csrc/pt_stages.h"
+
+using namespace ptd;
+
+static thread_local std::string g_error;
+struct pt_scene { pth::HostScene host; };
+
+extern "C" {
+
+const char* ptemu_last_error(void) { return g_error.c_str(); }
+
+pt_status ptemu_scene_create(const pt_scene_desc* d, pt_scene** out) {
+    pt_scene* sc = new pt_scene();
+    if (!pth::build_host_scene(*d, &sc->host, &g_error)) { delete sc; return PT_ERR_INVALID_ARGUMENT; }
+    *out = sc;
+    return PT_OK;
+}
+void ptemu_scene_destroy(pt_scene* sc) { delete sc; }
+
+pt_status ptemu_render(pt_scene* sc, const pt_render_desc* rdp, float* film, pt_profile* profile) {
+    pt_render_desc rd;
+    if (!pth::normalize_render_desc(*rdp, (uint32_t)sc->host.cameras.size(), &rd, &g_error)) return PT_ERR_INVALID_ARGUMENT;
+    SceneView s{sc->host.blob.data(), sc->host.tex.data()};
+    std::vector<uint32_t> pixels = pth::shard_pixels(rd.width, rd.height, rd.tile_width, rd.tile_height, rd.shard_index, rd.shard_count);
+    std::memset(film, 0, sizeof(float) * 4 * (size_t)rd.width * rd.height);
+    uint32_t capacity = 1u << 16;  // small on purpose: exercises pixel chunking and phase-aligned sample passes
+    const char* cap_env = getenv("PTEMU_BATCH");
+    if (cap_env) capacity = (uint32_t)strtoul(cap_env, nullptr, 10);
+    RenderParams rp;
+    std::memset(&rp, 0, sizeof(rp));
+    rp.seed = rd.seed; rp.width = rd.width; rp.height = rd.height;
+    rp.min_bounces = rd.min_bounces; rp.max_bounces = rd.max_bounces; rp.light_samples = rd.light_samples; rp.only_direct = rd.only_direct;
+    rp.wavelength_lo = rd.wavelength_lo; rp.wavelength_span = rd.wavelength_hi - rd.wavelength_lo;
+    rp.spp = rd.spp; rp.range_end = rd.first_sample + rd.sample_count;
+    rp.normalize = (rd.first_sample == 0 && rd.sample_count == rd.spp) ? 1u : 0u;
+    rp.camera = pth::camera_params(sc->host.cameras[rd.camera_index], (float)rd.width / (float)rd.height);
+    std::vector<uint32_t> pa((size_t)PS_FIELDS * capacity), pb((size_t)PS_FIELDS * capacity), ph((size_t)HS_FIELDS * capacity),
+        psh((size_t)(SH_HEAD + PT_MAX_LIGHT_SAMPLES * SR_FIELDS) * capacity);
+    std::vector<float> energy(capacity);
+    Queue qa{pa.data(), capacity}, qb{pb.data(), capacity}, qh{ph.data(), capacity}, qs{psh.data(), capacity};
+    uint64_t bounce_rays = 0, shadow_rays = 0, env_hits = 0, camera_rays = 0;
+    uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
+    for (const pth::Pass& pass : pth::plan_passes((uint32_t)pixels.size(), rd.first_sample, rd.sample_count, capacity)) {
+        rp.chunk_pixels = pass.pixel_count; rp.first_sample = pass.first_sample; rp.pass_samples = pass.sample_count;
+        const uint32_t* px = pixels.data() + pass.pixel_begin;
+        uint32_t n = pass.pixel_count * pass.sample_count;
+        camera_rays += n;
+        for (uint32_t i = 0; i < n; ++i) { store_path(qa, i, stage_generate(rp, i, px[i % rp.chunk_pixels])); energy[i] = 0.0f; }
+        uint32_t live = n;
+        for (uint32_t bounce = 0; bounce < bounce_limit; ++bounce) {
+            Queue qin = (bounce & 1) ? qb : qa, qout = (bounce & 1) ? qa : qb;
+            for (uint32_t i = 0; i < live; ++i) {
+                Hit h;
+                world_hit(s, f3(qf(qin, PS_OX, i), qf(qin, PS_OY, i), qf(qin, PS_OZ, i)), f3(qf(qin, PS_DX, i), qf(qin, PS_DY, i), qf(qin, PS_DZ, i)), &h);
+                store_hit(qh, i, h);
+            }
+            uint32_t next = 0, items = 0;
+            for (uint32_t i = 0; i < live; ++i) {
+                PathVertex pv = load_path(qin, i);
+                Hit hit = load_hit(qh, i);
+                ShadowRay rays[PT_MAX_LIGHT_SAMPLES];
+                ShadeOut out = stage_shade(s, rp, bounce, pv, hit, px[pv.slot % rp.chunk_pixels], rays);
+                if (out.add_energy) energy[pv.slot] += out.energy_add;
+                if (out.survives) store_path(qout, next++, out.next);
+                if (out.has_item) {
+                    uint32_t ipos = items++;
+                    qsu(qs, SH_SLOT, ipos, pv.slot); qsf(qs, SH_LAMBDA, ipos, pv.lambda); qsu(qs, SH_FLAGS, ipos, out.env_mask);
+                    for (uint32_t l = 0; l < rp.light_samples; ++l) {
+                        uint32_t f0 = SH_HEAD + l * SR_FIELDS;
+                        qsf(qs, f0 + SR_FACTOR, ipos, rays[l].factor);
+                        if (rays[l].factor != 0.0f) {
+                            qsf(qs, f0 + SR_OX, ipos, rays[l].o.x); qsf(qs, f0 + SR_OY, ipos, rays[l].o.y); qsf(qs, f0 + SR_OZ, ipos, rays[l].o.z);
+                            qsf(qs, f0 + SR_DX, ipos, rays[l].d.x); qsf(qs, f0 + SR_DY, ipos, rays[l].d.y); qsf(qs, f0 + SR_DZ, ipos, rays[l].d.z);
+                        }
+                    }
+                }
+                bounce_rays += out.vertex_pushed; env_hits += out.env_hit; shadow_rays += out.shadow_count;
+            }
+            for (uint32_t i = 0; i < items; ++i) {
+                uint32_t slot = qu(qs, SH_SLOT, i), flags = qu(qs, SH_FLAGS, i);
+                float lambda = qf(qs, SH_LAMBDA, i), lc = 0.0f;
+                for (uint32_t l = 0; l < rp.light_samples; ++l) {
+                    uint32_t f0 = SH_HEAD + l * SR_FIELDS;
+                    ShadowRay ray; ray.factor = qf(qs, f0 + SR_FACTOR, i);
+                    if (ray.factor == 0.0f) continue;
+                    ray.o = f3(qf(qs, f0 + SR_OX, i), qf(qs, f0 + SR_OY, i), qf(qs, f0 + SR_OZ, i));
+                    ray.d = f3(qf(qs, f0 + SR_DX, i), qf(qs, f0 + SR_DY, i), qf(qs, f0 + SR_DZ, i));
+                    lc += ((flags >> l) & 1u) ? stage_shadow_env(s, ray) : stage_shadow_light(s, lambda, ray);
+                }
+                energy[slot] += lc / (float)rp.light_samples;
+            }
+            live = next;
+        }
+        for (uint32_t p = 0; p < rp.chunk_pixels; ++p) stage_accumulate_pixel(rp, energy.data(), p, px[p], film + 4 * (size_t)px[p]);
+    }
+    if (profile) {
+        std::memset(profile, 0, sizeof(*profile));
+        profile->camera_rays = camera_rays; profile->bounce_rays = bounce_rays + camera_rays; profile->shadow_rays = shadow_rays; profile->env_hits = env_hits;
+    }
+    return PT_OK;
+}
+
+pt_status ptemu_intersect(pt_scene* sc, size_t n, const float* o, const float* d, pt_hit* hits) {
+    SceneView s{sc->host.blob.data(), sc->host.tex.data()};
+    for (size_t i = 0; i < n; ++i) {
+        Hit h; pt_hit r; std::memset(&r, 0, sizeof(r));
+        if (world_hit(s, f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), &h)) {
+            r.valid = 1; r.t = h.t; r.point[0] = h.p.x; r.point[1] = h.p.y; r.point[2] = h.p.z; r.normal[0] = h.n.x; r.normal[1] = h.n.y; r.normal[2] = h.n.z;
+            r.uv[0] = h.u; r.uv[1] = h.v; r.material = h.material; r.instance = h.instance;
+        }
+        hits[i] = r;
+    }
+    return PT_OK;
+}
+static uint32_t mat_rec(pt_scene* sc, uint32_t m) { return sc->host.blob[PT_HDR_MATERIAL_OFF] + m * PT_MAT_WORDS; }
+pt_status ptemu_bsdf_sample(pt_scene* sc, uint32_t m, size_t n, const float* lambda, const float* wi, const float* s2, float* f, float* wo, float* pdf) {
+    SceneView s{sc->host.blob.data(), sc->host.tex.data()};
+    for (size_t i = 0; i < n; ++i) {
+        F3 w; material_sample(s, mat_rec(sc, m), lambda[i], 0.5f, 0.5f, s2[2 * i], s2[2 * i + 1], f3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), &f[i], &w, &pdf[i]);
+        wo[3 * i] = w.x; wo[3 * i + 1] = w.y; wo[3 * i + 2] = w.z;
+    }
+    return PT_OK;
+}
+pt_status ptemu_bsdf_eval(pt_scene* sc, uint32_t m, size_t n, const float* lambda, const float* wi, const float* wo, float* f, float* pdf) {
+    SceneView s{sc->host.blob.data(), sc->host.tex.data()};
+    for (size_t i = 0; i < n; ++i)
+        material_bsdf(s, mat_rec(sc, m), lambda[i], 0.5f, 0.5f, f3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), f3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), &f[i], &pdf[i]);
+    return PT_OK;
+}
+pt_status ptemu_emission(pt_scene* sc, uint32_t m, size_t n, const float* lambda, const float* wi, float* e) {
+    SceneView s{sc->host.blob.data(), sc->host.tex.data()};
+    for (size_t i = 0; i < n; ++i) e[i] = material_emission(s, mat_rec(sc, m), lambda[i], f3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]));
+    return PT_OK;
+}
+pt_status ptemu_curve_eval(pt_scene* sc, uint32_t c, size_t n, const float* lambda, float* v) {
+    SceneView s{sc->host.blob.data(), sc->host.tex.data()};
+    for (size_t i = 0; i < n; ++i) v[i] = curve_eval(s, sc->host.curve_offsets[c], lambda[i]);
+    return PT_OK;
+}
+}

@@ -1,0 +1,122 @@
+"""Parity checks of one implementation of the boundary against the CPU oracle.  Used twice: on the CPU with the
+emulated lane logic of the HIP engine (tests/test_emulation.py) and on the GPU with the real engine through the
+C ABI (tests/test_gpu_parity.py).
+
+Bars (BASELINE.json north_star): every discrete decision identical -> ray counters equal and closest hits / BSDF
+samples bit-exact; film within 1e-4 L-inf absolute AND 2e-5 relative to the oracle (floating point: the engine
+multiplies the light-sample factors in a different order than pt.rs:196-202)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+from make_golden import GOLDEN_RENDERS, golden_rays, material_inputs  # noqa: E402
+from util import film_metrics  # noqa: E402
+
+FILM_LINF = 1e-4     # north_star: XYZ film L-inf < 1e-4 vs the CPU reference at matched seeds
+FILM_REL = 2e-5
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def pkg():
+    return importlib.import_module("rust-pathtracer_amd")
+
+
+def assert_hits_equal(a, b):
+    assert np.array_equal(a["valid"], b["valid"])
+    v = a["valid"] == 1
+    for field in ("t", "point", "normal", "uv", "material", "instance"):
+        x, y = a[field][v], b[field][v]
+        same = (x.view(np.uint32) == y.view(np.uint32)) if x.dtype == np.float32 else (x == y)
+        assert same.all(), (field, int((~same).sum()), x[~same.reshape(x.shape)][:4] if x.ndim == 1 else None)
+
+
+def check_film(film, ref, prof=None, ref_prof=None):
+    assert np.isfinite(film).all() == np.isfinite(ref).all()
+    m = film_metrics(film, ref)
+    assert m["linf"] < FILM_LINF, m
+    assert m["relative"] < FILM_REL, m
+    if prof is not None:
+        got = (prof.camera_rays, prof.bounce_rays, prof.shadow_rays, prof.env_hits)
+        want = (ref_prof.camera_rays, ref_prof.bounce_rays, ref_prof.shadow_rays, ref_prof.env_hits) if hasattr(ref_prof, "camera_rays") else tuple(int(x) for x in ref_prof)
+        assert got == want, (got, want)
+    return m
+
+
+def intersect_parity(impl, oracle, scene_name, n=4096, seed=21):
+    b = pkg().scene.SCENES[scene_name]()
+    o, d = golden_rays(scene_name, n, seed)
+    assert_hits_equal(impl.create_scene(b).intersect(o, d), oracle.create_scene(b).intersect(o, d))
+
+
+def material_parity(impl, oracle, scene_name, n=2048, seed=9):
+    b = pkg().scene.SCENES[scene_name]()
+    si, so = impl.create_scene(b), oracle.create_scene(b)
+    lam, wi, s2, wo = material_inputs(n, seed)
+    for name, mid in b.material_ids.items():
+        idx = mid & 0xFFFF
+        for x, y in zip(si.bsdf_sample(idx, lam, wi, s2), so.bsdf_sample(idx, lam, wi, s2)):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), name
+        for x, y in zip(si.bsdf_eval(idx, lam, wi, wo), so.bsdf_eval(idx, lam, wi, wo)):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), name
+        assert np.array_equal(si.emission(idx, lam, wi).view(np.uint32), so.emission(idx, lam, wi).view(np.uint32)), name
+    for c in range(len(b.curves)):
+        lam2 = np.linspace(360, 800, 881).astype(np.float32)
+        assert np.array_equal(si.curve_eval(c, lam2).view(np.uint32), so.curve_eval(c, lam2).view(np.uint32)), c
+
+
+def render_parity(impl, oracle, scene_name, width, height, spp, max_bounces, **kw):
+    b = pkg().scene.SCENES[scene_name]()
+    rd = pkg().api.render_desc(width, height, spp, max_bounces, **kw)
+    film, prof = impl.create_scene(b).render(rd)
+    ref, rprof = oracle.create_scene(b).render(rd)
+    return check_film(film, ref, prof, rprof)
+
+
+def golden_render(impl, name):
+    scene, w, h, spp, mb, ls, seed = GOLDEN_RENDERS[name]
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    film, prof = impl.create_scene(pkg().scene.SCENES[scene]()).render(pkg().api.render_desc(w, h, spp, mb, light_samples=ls, seed=seed))
+    return film, prof, z["film"], z["counters"]
+
+
+def golden_hits(impl, scene_name):
+    z = np.load(os.path.join(GOLDEN, "hits_%s.npz" % scene_name))
+    o, d = golden_rays(scene_name, 4096, 11)
+    return impl.create_scene(pkg().scene.SCENES[scene_name]()).intersect(o, d), z["hits"]
+
+
+def golden_materials(impl, scene_name):
+    z = np.load(os.path.join(GOLDEN, "materials_%s.npz" % scene_name))
+    b = pkg().scene.SCENES[scene_name]()
+    sc = impl.create_scene(b)
+    lam, wi, s2, wo = material_inputs(1024, 5)
+    for mname, mid in b.material_ids.items():
+        idx = mid & 0xFFFF
+        f, wo_s, pdf = sc.bsdf_sample(idx, lam, wi, s2)
+        f2, pdf2 = sc.bsdf_eval(idx, lam, wi, wo)
+        e = sc.emission(idx, lam, wi)
+        got = np.concatenate([f[:, None], wo_s, pdf[:, None], f2[:, None], pdf2[:, None], e[:, None]], axis=1).astype(np.float32)
+        assert np.array_equal(got.view(np.uint32), z[mname].view(np.uint32)), mname
+
+
+def shards_and_ranges(impl, scene_name="cornell_box"):
+    """Size-independent properties: film shards are disjoint and sum to the whole film bit for bit; sample
+    ranges aligned to the 10-sample phases compose bit for bit."""
+    api = pkg().api
+    sc = impl.create_scene(pkg().scene.SCENES[scene_name]())
+    whole, pw = sc.render(api.render_desc(70, 50, 3, 3, tile=(16, 16)))
+    acc = np.zeros_like(whole)
+    rays = 0
+    for k in range(3):
+        part, pp = sc.render(api.render_desc(70, 50, 3, 3, tile=(16, 16), shard=(k, 3)))
+        assert ((part != 0) & (acc != 0)).sum() == 0
+        acc += part
+        rays += pp.bounce_rays
+    assert np.array_equal(acc, whole) and rays == pw.bounce_rays
+    full, _ = sc.render(api.render_desc(32, 32, 20, 4))
+    a, _ = sc.render(api.render_desc(32, 32, 20, 4, first_sample=0, sample_count=10))
+    c, _ = sc.render(api.render_desc(32, 32, 20, 4, first_sample=10, sample_count=10))
+    assert np.array_equal((a + c) / np.float32(20), full)

@@ -1,0 +1,60 @@
+"""CPU: the product library exists, loads, and exports exactly the entry points include/pt_api.h declares.
+No compute calls are made here (no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "pt_api.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pt_[a-z_0-9]+)\s*\(", text)) - {"pt_status"})
+
+
+def test_header_declares_the_boundary():
+    names = declared_functions()
+    for required in ("pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device", "pt_intersect", "pt_bsdf_sample",
+                     "pt_bsdf_eval", "pt_emission", "pt_curve_eval", "pt_last_error", "pt_device_info"):
+        assert required in names
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    if not os.path.exists(pkg.LIBRARY_PATH):
+        pytest.fail("HIP engine not built: run python -c 'import __graft_entry__ as g; g.build()'")
+    lib = C.CDLL(pkg.LIBRARY_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    assert sorted("pt_" + f for f in pkg.api.API_FUNCTIONS) == declared_functions()
+
+
+def test_oracle_exports_the_same_boundary(pkg, oracle):
+    for name in declared_functions():
+        if name in ("pt_render_device", "pt_device_info"):
+            continue
+        assert hasattr(oracle.lib, "ptref_" + name[3:]), name
+
+
+def test_struct_layouts_match_the_header(pkg):
+    """ctypes mirrors vs the C compiler's view of include/pt_api.h."""
+    import subprocess
+    import tempfile
+    src = r'''
+#include <stdio.h>
+#include "pt_api.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pt_curve), sizeof(pt_texture_layer), sizeof(pt_texstack),
+         sizeof(pt_material), sizeof(pt_mesh), sizeof(pt_instance), sizeof(pt_environment), sizeof(pt_camera), sizeof(pt_scene_desc),
+         sizeof(pt_render_desc), sizeof(pt_profile), sizeof(pt_hit));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
+    a = pkg.api
+    mine = [C.sizeof(t) for t in (a.Curve, a.TextureLayer, a.TexStack, a.Material, a.Mesh, a.Instance, a.Environment, a.Camera,
+                                  a.SceneDesc, a.RenderDesc, a.Profile, a.Hit)]
+    assert mine == sizes

@@ -1,0 +1,71 @@
+"""CPU: the HIP engine's lane logic + host planning (emulated sequentially, tests/host_emulation/ptemu.cpp)
+against the oracle.  This is what proves the wavefront decomposition before the GPU is involved."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import parity_suite as ps
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "host_emulation")
+CSRC = os.path.join(HERE, "..", "rust-pathtracer_amd", "csrc")
+
+
+@pytest.fixture(scope="session")
+def emu(pkg):
+    lib = os.path.join(EMU_DIR, "libptemu.so")
+    srcs = [os.path.join(EMU_DIR, "ptemu.cpp"), os.path.join(CSRC, "pt_scene_host.cpp"), os.path.join(CSRC, "pt_plan.cpp")]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("pt_device.h", "pt_stages.h", "pt_blob.h", "pt_plan.h", "pt_scene_host.h")] + \
+        [os.path.join(HERE, "..", "include", h) for h in ("pt_api.h", "pt_numerics.h")]
+    if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+                               "-Wno-unused-function", "-o", lib] + srcs)
+    return pkg.api.Library(lib, "ptemu_", optional=("render_device", "device_info"))
+
+
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives", "white_furnace"])
+def test_closest_hits_bit_exact(emu, oracle, scene):
+    ps.intersect_parity(emu, oracle, scene)
+
+
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives"])
+def test_materials_bit_exact(emu, oracle, scene):
+    ps.material_parity(emu, oracle, scene)
+
+
+@pytest.mark.parametrize("scene,w,h,spp,mb,kw", [
+    ("cornell_box", 48, 40, 13, 4, {}),                       # C1 shape at reduced size; spp not a multiple of 10
+    ("cornell_box", 33, 21, 4, 8, {"tile": (16, 16)}),        # remnant tiles (tiled.rs:236-277)
+    ("cornell_box", 24, 24, 5, 6, {"only_direct": True}),
+    ("cornell_box", 24, 24, 5, 6, {"light_samples": 0}),
+    ("cornell_box", 24, 24, 5, 3, {"min_bounces": 4}),        # roulette never active
+    ("cornell_gem", 40, 24, 6, 12, {}),                       # C3 shape: dispersive GGX + transformed mesh
+    ("mixed_primitives", 32, 32, 8, 6, {"light_samples": 3, "seed": 5}),
+    ("white_furnace", 16, 16, 12, 8, {"light_samples": 6}),
+])
+def test_film_parity(emu, oracle, scene, w, h, spp, mb, kw):
+    ps.render_parity(emu, oracle, scene, w, h, spp, mb, **kw)
+
+
+def test_pass_planning_is_invisible(emu, oracle, monkeypatch):
+    """Chunking pixels and samples into passes (tiny batch capacity) changes nothing."""
+    monkeypatch.setenv("PTEMU_BATCH", "1024")
+    m = ps.render_parity(emu, oracle, "cornell_box", 40, 36, 27, 4)
+    monkeypatch.setenv("PTEMU_BATCH", "100000")
+    ps.render_parity(emu, oracle, "cornell_box", 40, 36, 27, 4)
+
+
+def test_shards_and_sample_ranges(emu):
+    ps.shards_and_ranges(emu)
+
+
+def test_golden_vectors(emu):
+    for name in ps.GOLDEN_RENDERS:
+        film, prof, ref, counters = ps.golden_render(emu, name)
+        ps.check_film(film, ref, prof, counters)
+    for scene in ("cornell_box", "mixed_primitives", "cornell_gem"):
+        got, want = ps.golden_hits(emu, scene)
+        ps.assert_hits_equal(got, want)
+        ps.golden_materials(emu, scene)

@@ -1,0 +1,134 @@
+"""GPU: the HIP engine, called through the C ABI (libptamd.so), against the CPU oracle and the golden vectors.
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import parity_suite as ps
+from util import fptr, numerics
+
+pytestmark = pytest.mark.gpu
+
+
+def test_engine_is_the_hip_library(engine, pkg):
+    assert engine.path == pkg.LIBRARY_PATH and engine.prefix == "pt_"
+    info = engine.device_info()
+    assert "gfx950" in info, info
+
+
+def test_device_arithmetic_matches_x86(engine, oracle):
+    """The numeric contract on the device: elementary functions, IEEE divide / sqrt, no fma contraction."""
+    rng = np.random.default_rng(0)
+    n = 1 << 16
+    fn = engine.lib.pt_debug_numerics
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+
+    def dev(which, x, y):
+        out = np.zeros_like(x)
+        engine.check(fn(which, x.size, fptr(x), fptr(y), fptr(out)))
+        return out
+    cases = {0: (-7, 7), 1: (-7, 7), 2: (-100, 89), 4: (-1, 1), 6: (-40, 40), 7: (1e-6, 1e6)}
+    for which, (lo, hi) in cases.items():
+        x = rng.uniform(lo, hi, n).astype(np.float32); y = np.zeros_like(x)
+        assert np.array_equal(dev(which, x, y).view(np.uint32), numerics(oracle, which, x, y).view(np.uint32)), which
+    x = rng.uniform(0, 1, n).astype(np.float32); y = rng.uniform(1, 500, n).astype(np.float32)
+    assert np.array_equal(dev(3, x, y).view(np.uint32), numerics(oracle, 3, x, y).view(np.uint32))
+    x = rng.uniform(-1, 1, n).astype(np.float32); y = rng.uniform(-1, 1, n).astype(np.float32)
+    assert np.array_equal(dev(5, x, y).view(np.uint32), numerics(oracle, 5, x, y).view(np.uint32))
+    x = (rng.standard_normal(n) * 10.0 ** rng.uniform(-20, 20, n)).astype(np.float32)
+    y = (rng.standard_normal(n) * 10.0 ** rng.uniform(-20, 20, n)).astype(np.float32)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(dev(8, x, y).view(np.uint32), (x / y).view(np.uint32))            # IEEE division, denormals kept
+        assert np.array_equal(dev(9, np.abs(x), y).view(np.uint32), np.sqrt(np.abs(x)).view(np.uint32))
+        assert np.array_equal(dev(10, x, y).view(np.uint32), ((x * y).astype(np.float32) + x).view(np.uint32))  # not fused
+
+
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives", "white_furnace"])
+def test_closest_hits_bit_exact(engine, oracle, scene):
+    ps.intersect_parity(engine, oracle, scene, n=1 << 16)
+
+
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives"])
+def test_materials_bit_exact(engine, oracle, scene):
+    ps.material_parity(engine, oracle, scene, n=1 << 14)
+
+
+@pytest.mark.parametrize("scene,w,h,spp,mb,kw", [
+    ("cornell_box", 256, 256, 16, 4, {}),                     # C1 of BASELINE.json at full size
+    ("cornell_box", 33, 21, 4, 8, {"tile": (16, 16)}),
+    ("cornell_box", 64, 64, 5, 8, {"only_direct": True}),
+    ("cornell_box", 64, 64, 5, 8, {"light_samples": 0}),
+    ("cornell_box", 64, 64, 13, 3, {"min_bounces": 4}),
+    ("cornell_gem", 96, 54, 8, 12, {}),                       # C3 shape at reduced size
+    ("mixed_primitives", 64, 64, 8, 6, {"light_samples": 3, "seed": 5}),
+    ("white_furnace", 32, 32, 12, 8, {"light_samples": 6}),
+])
+def test_film_parity(engine, oracle, scene, w, h, spp, mb, kw):
+    ps.render_parity(engine, oracle, scene, w, h, spp, mb, **kw)
+
+
+def test_golden_vectors(engine):
+    for name in ps.GOLDEN_RENDERS:
+        film, prof, ref, counters = ps.golden_render(engine, name)
+        ps.check_film(film, ref, prof, counters)
+    for scene in ("cornell_box", "mixed_primitives", "cornell_gem"):
+        got, want = ps.golden_hits(engine, scene)
+        ps.assert_hits_equal(got, want)
+        ps.golden_materials(engine, scene)
+
+
+def test_shards_and_sample_ranges(engine):
+    ps.shards_and_ranges(engine)
+
+
+def test_batching_and_lds_staging_are_invisible(engine, pkg, monkeypatch):
+    """Same film bit for bit whatever the pass size, and whether the scene blob is read from LDS or HBM."""
+    b = pkg.scene.cornell_box()
+    rd = pkg.api.render_desc(96, 80, 23, 5)
+    base, pbase = engine.create_scene(b).render(rd)
+    monkeypatch.setenv("PT_AMD_BATCH", "20000")
+    small, psmall = engine.create_scene(b).render(rd)
+    assert np.array_equal(base, small) and pbase.bounce_rays == psmall.bounce_rays and pbase.shadow_rays == psmall.shadow_rays
+    monkeypatch.delenv("PT_AMD_BATCH")
+    monkeypatch.setenv("PT_AMD_NO_LDS", "1")
+    nolds, _ = engine.create_scene(b).render(rd)
+    assert np.array_equal(base, nolds)
+    again, _ = engine.create_scene(b).render(rd)
+    assert np.array_equal(nolds, again)
+
+
+def test_full_size_cornell_properties(engine, oracle, pkg):
+    """BASELINE.json C2 geometry (1024x1024, max_bounces 8, L = 2) at 2 spp: too big for the oracle film in seconds,
+    so check size-independent properties: shards partition the film exactly, counters add up, the film is finite and
+    non-negative, and a 64x64 box-downsample agrees statistically with the oracle's 64x64 render."""
+    b = pkg.scene.cornell_box()
+    sc = engine.create_scene(b)
+    rd = pkg.api.render_desc(1024, 1024, 2, 8)
+    whole, pw = sc.render(rd)
+    assert np.isfinite(whole).all() and whole.min() >= 0 and (whole[..., 3] == 0).all()
+    assert pw.camera_rays == 1024 * 1024 * 2
+    acc = np.zeros_like(whole); rays = 0
+    for k in range(4):
+        part, pp = sc.render(pkg.api.render_desc(1024, 1024, 2, 8, shard=(k, 4)))
+        acc += part; rays += pp.bounce_rays + pp.shadow_rays
+    assert np.array_equal(acc, whole) and rays == pw.bounce_rays + pw.shadow_rays
+    ref, _ = oracle.create_scene(b).render(pkg.api.render_desc(64, 64, 64, 8, seed=3))
+    down = whole[..., 1].reshape(64, 16, 64, 16).mean(axis=(1, 3))
+    rel = abs(down.mean() - ref[..., 1].mean()) / ref[..., 1].mean()
+    assert rel < 0.05, rel
+
+
+def test_error_behaviour(engine, pkg):
+    b = pkg.scene.cornell_box()
+    sc = engine.create_scene(b)
+    for bad in (dict(camera_index=3), dict(shard=(2, 2)), dict(hero_wavelengths=4), dict(light_samples=9)):
+        with pytest.raises(pkg.api.PtError) as e:
+            sc.render(pkg.api.render_desc(8, 8, 1, 2, **bad))
+        assert e.value.status == 1 and str(e.value)
+    bad_scene = pkg.scene.SceneBuilder()
+    bad_scene.add_camera((0, 0, 0), (1, 0, 0), 40.0)
+    with pytest.raises(pkg.api.PtError):
+        engine.create_scene(bad_scene)   # environment curve missing
