@@ -86,5 +86,9 @@
 #define PT_HDR_WORLD_RADIUS 18
 #define PT_HDR_CURVE_OFF 19
 #define PT_HDR_CURVE_COUNT 20
+#define PT_HDR_FLAGS 21
+#define PT_FLAG_EXACT_SLAB 2u    /* diagnostics (PT_AMD_EXACT_SLAB=1): always take the six-division slab test */
+#define PT_FLAG_NO_CULL 4u       /* diagnostics (PT_AMD_NO_CULL=1): never cull by the closest hit */
+#define PT_FLAG_NO_TOP_CULL 1u   /* a Disk instance exists: its reference box (radius/2, disk.rs:24-28) does not contain it */
 
 #endif

@@ -20,6 +20,17 @@
 #include "../../include/pt_numerics.h"
 #include "pt_blob.h"
 
+// Optional instrumentation for host-side experiments (tools/traversal_stats.cpp); compiled out everywhere else.
+#ifndef PT_STAT
+#define PT_STAT(counter)
+#endif
+#ifndef PT_STAT_EVENT
+#define PT_STAT_EVENT(code)
+#endif
+#ifndef PT_STAT_RAY
+#define PT_STAT_RAY(o, d)
+#endif
+
 namespace ptd {
 
 struct F3 { float x, y, z; };
@@ -180,27 +191,93 @@ struct Hit {
 
 // AABB::hit (src/aabb.rs:37-65) for the (t0, t1) = (0, inf) every caller on this path passes: slab test clipped
 // against t >= 0 by the w lane (d.w = 0 -> tmin 0, tmax inf).  The second rejection test of the reference is
-// implied by the first for these bounds.
-PT_HD bool aabb_hit(F4 a, F4 b, F3 o, F3 d) {
+// implied by the first for these bounds.  Exact form: six IEEE divisions.
+PT_HD bool aabb_hit_exact(F4 a, F4 b, F3 o, F3 d, float* entry) {
     float n0, x0, n1, x1, n2, x2;
     if (d.x == 0.0f) { n0 = 0.0f; x0 = PT_INF; } else { float p = (a.x - o.x) / d.x, q = (b.x - o.x) / d.x; n0 = __builtin_fminf(p, q); x0 = __builtin_fmaxf(p, q); }
     if (d.y == 0.0f) { n1 = 0.0f; x1 = PT_INF; } else { float p = (a.y - o.y) / d.y, q = (b.y - o.y) / d.y; n1 = __builtin_fminf(p, q); x1 = __builtin_fmaxf(p, q); }
     if (d.z == 0.0f) { n2 = 0.0f; x2 = PT_INF; } else { float p = (a.z - o.z) / d.z, q = (b.z - o.z) / d.z; n2 = __builtin_fminf(p, q); x2 = __builtin_fmaxf(p, q); }
     float tmin_max = __builtin_fmaxf(__builtin_fmaxf(n0, n1), __builtin_fmaxf(n2, 0.0f));
     float tmax_min = __builtin_fminf(__builtin_fminf(x0, x1), x2);
+    *entry = tmin_max;
     return !(tmin_max > tmax_min);
 }
 
-// MeshTriangleRef::hit (src/geometry/mesh.rs:67-198), split: the interval test here, the HitRecord later for
-// the triangle that survives as closest.
+// ---- filtered slab test ---------------------------------------------------------------------------------------
+// The exact test costs ~100 VALU instructions per node (each IEEE f32 division is ~11).  Its *decision* can almost
+// always be certified from approximate quotients: with r ~ 1/d (v_rcp_f32, <= 1 ulp) the products (c - o) * r are within
+// 3e-7 relative of the correctly rounded quotients, so a comparison of two of them that is decided by more than
+// PT_SLAB_EPS relative is decided the same way by the exact values.  Only comparisons too close to call fall back to
+// the divisions.  hit <=> for every axis j: max(0, entry_i for i != j) <= exit_j (the i == j pairs hold by
+// construction), which keeps zero-thickness boxes — every axis-aligned wall of the Cornell box — on the fast path.
+// The returned decision is therefore always the exact one; `entry` may be the approximate entry distance.
+#define PT_SLAB_EPS 4e-6f
+#define PT_SLAB_TINY 1e-30f
+PT_HD float fast_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+// p ~ (c - o) / d is evaluated as fma(c, r, -o*r): one instruction per slab plane.  Its absolute error is bounded by
+// 2e-7 * (2 |o r| + |p|); the margin below uses PT_SLAB_EPS (4e-6) * (max_i |o_i r_i| + |entry| + |exit|), 10x that.
+PT_HD float approx_fma(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaf(a, b, c);
+#else
+    return a * b + c;  // any approximation within the margin will do on the host
+#endif
+}
+struct RayPrep { F3 o, d, r, nor; float base; bool fast; };
+PT_HD RayPrep ray_prepare(F3 o, F3 d) {
+    RayPrep p; p.o = o; p.d = d;
+    float ax = pt_abs(d.x), ay = pt_abs(d.y), az = pt_abs(d.z);
+    p.r = f3(d.x == 0.0f ? 0.0f : fast_rcp(d.x), d.y == 0.0f ? 0.0f : fast_rcp(d.y), d.z == 0.0f ? 0.0f : fast_rcp(d.z));
+    p.nor = f3(-(o.x * p.r.x), -(o.y * p.r.y), -(o.z * p.r.z));
+    float k = __builtin_fmaxf(__builtin_fmaxf(pt_abs(p.nor.x), pt_abs(p.nor.y)), pt_abs(p.nor.z));
+    p.base = PT_SLAB_EPS * k + PT_SLAB_TINY;
+    // reciprocals must be finite and the products must not overflow: |d| in (1e-18, 1e18) or exactly 0, finite origin
+    bool okx = (ax == 0.0f) || (ax > 1e-18f && ax < 1e18f), oky = (ay == 0.0f) || (ay > 1e-18f && ay < 1e18f), okz = (az == 0.0f) || (az > 1e-18f && az < 1e18f);
+    bool oko = pt_abs(o.x) < 1e18f && pt_abs(o.y) < 1e18f && pt_abs(o.z) < 1e18f;
+    p.fast = okx && oky && okz && oko;
+    return p;
+}
+PT_HD bool aabb_hit(F4 a, F4 b, const RayPrep& rp, float* entry) {
+    PT_STAT(box_tests);
+    if (rp.fast) {
+        float n0, x0, n1, x1, n2, x2;
+        bool z0 = rp.d.x == 0.0f, z1 = rp.d.y == 0.0f, z2 = rp.d.z == 0.0f;
+        if (z0) { n0 = 0.0f; x0 = PT_INF; } else { float p = approx_fma(a.x, rp.r.x, rp.nor.x), q = approx_fma(b.x, rp.r.x, rp.nor.x); n0 = __builtin_fminf(p, q); x0 = __builtin_fmaxf(p, q); }
+        if (z1) { n1 = 0.0f; x1 = PT_INF; } else { float p = approx_fma(a.y, rp.r.y, rp.nor.y), q = approx_fma(b.y, rp.r.y, rp.nor.y); n1 = __builtin_fminf(p, q); x1 = __builtin_fmaxf(p, q); }
+        if (z2) { n2 = 0.0f; x2 = PT_INF; } else { float p = approx_fma(a.z, rp.r.z, rp.nor.z), q = approx_fma(b.z, rp.r.z, rp.nor.z); n2 = __builtin_fminf(p, q); x2 = __builtin_fmaxf(p, q); }
+        float m0 = __builtin_fmaxf(__builtin_fmaxf(n1, n2), 0.0f), m1 = __builtin_fmaxf(__builtin_fmaxf(n0, n2), 0.0f), m2 = __builtin_fmaxf(__builtin_fmaxf(n0, n1), 0.0f);
+        float e0 = approx_fma(PT_SLAB_EPS, m0 + pt_abs(x0), rp.base), e1 = approx_fma(PT_SLAB_EPS, m1 + pt_abs(x1), rp.base), e2 = approx_fma(PT_SLAB_EPS, m2 + pt_abs(x2), rp.base);
+        bool miss = (!z0 && m0 > x0 + e0) || (!z1 && m1 > x1 + e1) || (!z2 && m2 > x2 + e2);
+        if (miss) return false;
+        bool hit = (z0 || m0 < x0 - e0) && (z1 || m1 < x1 - e1) && (z2 || m2 < x2 - e2);
+        if (hit) { *entry = __builtin_fmaxf(m0, n0); return true; }
+    }
+    PT_STAT(box_exact);
+    return aabb_hit_exact(a, b, rp.o, rp.d, entry);
+}
+// Conservative cull: a node whose (approximate or exact) entry distance exceeds the closest hit so far by more than
+// 1e-5 relative cannot contain a primitive hit with t <= closest (primitive t and slab entry agree to ~1e-6 relative;
+// primitives lie inside their boxes, except the reference's half-size Disk box for which culling is switched off).
+PT_HD bool beyond(float entry, float closest, float base) { return entry > closest * 1.00001f + base; }
+
+// MeshTriangleRef::hit (src/geometry/mesh.rs:67-198), split: the per-ray part (axis permutation and shear constants,
+// mesh.rs:79-99) is computed once per mesh visit, the interval test per triangle, the HitRecord only for the triangle
+// that survives as closest.
 struct TriHit { float t, b0, b1, b2; };
 PT_HD F3 tri_shuffle(F3 v, uint32_t m) {
     if (m == 0) return f3(v.y, v.z, v.x);
     if (m == 1) return f3(v.z, v.x, v.y);
     return v;
 }
-PT_HD bool triangle_test(F3 p0, F3 p1, F3 p2, F3 o, F3 dir, float t0, float t1, TriHit* out) {
-    F3 p0t = sub(p0, o), p1t = sub(p1, o), p2t = sub(p2, o);
+struct TriRay { F3 o; uint32_t kz; float sx, sy, sz; };
+PT_HD TriRay tri_ray_prepare(F3 o, F3 dir) {
+    TriRay r; r.o = o;
     float ax = pt_abs(dir.x), ay = pt_abs(dir.y), az = pt_abs(dir.z);
     float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), __builtin_fmaxf(az, 0.0f));
     uint32_t kz = 0;
@@ -209,8 +286,13 @@ PT_HD bool triangle_test(F3 p0, F3 p1, F3 p2, F3 o, F3 dir, float t0, float t1, 
     if (az >= mx) kz = 2;
     if (0.0f >= mx) kz = 3;
     F3 d = tri_shuffle(dir, kz);
-    p0t = tri_shuffle(p0t, kz); p1t = tri_shuffle(p1t, kz); p2t = tri_shuffle(p2t, kz);
-    float sx = -d.x / d.z, sy = -d.y / d.z, sz = 1.0f / d.z;
+    r.kz = kz; r.sx = -d.x / d.z; r.sy = -d.y / d.z; r.sz = 1.0f / d.z;
+    return r;
+}
+PT_HD bool triangle_test(F3 p0, F3 p1, F3 p2, const TriRay& r, float t0, float t1, TriHit* out) {
+    PT_STAT(tri_tests);
+    F3 p0t = tri_shuffle(sub(p0, r.o), r.kz), p1t = tri_shuffle(sub(p1, r.o), r.kz), p2t = tri_shuffle(sub(p2, r.o), r.kz);
+    float sx = r.sx, sy = r.sy, sz = r.sz;
     p0t.x += sx * p0t.z; p1t.x += sx * p1t.z; p2t.x += sx * p2t.z;
     p0t.y += sy * p0t.z; p1t.y += sy * p1t.z; p2t.y += sy * p2t.z;
     float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
@@ -244,47 +326,6 @@ PT_HD F3 rect_shuffle(F3 v, uint32_t axis) {
     return v;
 }
 PT_HD F3 axis_vec(uint32_t axis) { return axis == PT_AXIS_X ? f3(1, 0, 0) : (axis == PT_AXIS_Y ? f3(0, 1, 0) : f3(0, 0, 1)); }
-
-// Mesh::hit (src/geometry/mesh.rs:314-360): skip-link walk over the per-mesh BVH, triangles tested in
-// traversal order against the running closest distance.
-PT_HD bool mesh_hit(const SceneView& s, uint32_t mesh, F3 o, F3 d, float t1, Hit* out) {
-    uint32_t node_off = bu(s, mesh + PT_MESH_NODE_OFF), node_count = bu(s, mesh + PT_MESH_NODE_COUNT);
-    uint32_t tri_off = bu(s, mesh + PT_MESH_TRI_OFF), normal_off = bu(s, mesh + PT_MESH_NORMAL_OFF);
-    float closest = t1; bool found = false; uint32_t best = 0; TriHit bh; bh.t = 0; bh.b0 = bh.b1 = bh.b2 = 0;
-    uint32_t i = 0;
-    while (i < node_count) {
-        F4 a = bf4(s, node_off + i * PT_NODE_WORDS), b = bf4(s, node_off + i * PT_NODE_WORDS + 4);
-        uint32_t exit_i = pt_f2u(a.w), shape = pt_f2u(b.w);
-        bool box = aabb_hit(a, b, o, d);
-        if (shape == PT_NODE_INNER) { i = box ? i + 1 : exit_i; continue; }
-        if (box) {
-            uint32_t t = tri_off + shape * PT_TRI_WORDS;
-            F4 q0 = bf4(s, t), q1 = bf4(s, t + 4), q2 = bf4(s, t + 8);
-            TriHit th;
-            if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), o, d, 0.0f, closest, &th)) {
-                closest = th.t; found = true; best = shape; bh = th;
-            }
-        }
-        i = exit_i;
-    }
-    if (!found) return false;
-    uint32_t t = tri_off + best * PT_TRI_WORDS;
-    F4 q0 = bf4(s, t), q1 = bf4(s, t + 4), q2 = bf4(s, t + 8);
-    F3 p0 = f3(q0.x, q0.y, q0.z), p1 = f3(q1.x, q1.y, q1.z), p2 = f3(q2.x, q2.y, q2.z);
-    F3 n = normalize(cross(sub(p0, p2), sub(p1, p2)));
-    if (normal_off != 0) {
-        uint32_t nn = normal_off + best * PT_TRI_WORDS;
-        F4 m0 = bf4(s, nn), m1 = bf4(s, nn + 4), m2 = bf4(s, nn + 8);
-        n = add(add(mul(f3(m0.x, m0.y, m0.z), bh.b0), mul(f3(m1.x, m1.y, m1.z), bh.b1)), mul(f3(m2.x, m2.y, m2.z), bh.b2));
-    }
-    out->t = bh.t;
-    out->p = add(add(mul(p0, bh.b0), mul(p1, bh.b1)), mul(p2, bh.b2));
-    out->u = 0.0f; out->v = 0.0f;
-    out->n = normalize(n);
-    out->material = pt_f2u(q0.w);
-    out->valid = true;
-    return true;
-}
 
 // Aggregate::hit for rect / sphere / disk (src/geometry/rect.rs:69-112, sphere.rs:34-87, disk.rs:31-62); tmax = inf on this path.
 PT_HD bool analytic_hit(const SceneView& s, uint32_t inst, uint32_t kind, F3 o, F3 d, float t1, Hit* out) {
@@ -340,48 +381,128 @@ PT_HD bool analytic_hit(const SceneView& s, uint32_t inst, uint32_t kind, F3 o, 
     return true;
 }
 
-// Instance::hit (src/geometry/instance.rs:75-133)
-PT_HD bool instance_hit(const SceneView& s, uint32_t inst, uint32_t instance_id, F3 o, F3 d, float t1, Hit* out) {
-    uint32_t kind = bu(s, inst + PT_INST_KIND), flags = bu(s, inst + PT_INST_FLAGS);
-    bool xf = (flags & 1u) != 0;
-    F3 lo = o, ld = d;
-    if (xf) { lo = xf_point(s, inst + PT_INST_REVERSE, o); ld = xf_vec(s, inst + PT_INST_REVERSE, d); }
+// World::hit(r, 0, inf): Accelerator::hit (src/accelerator/mod.rs:106-176) + FlatBVH::traverse (lbvh.rs:172-213) +
+// Instance::hit (instance.rs:75-133) + Mesh::hit (mesh.rs:314-360), as ONE loop.
+//
+// The reference nests two walks (instances, then the triangles of a mesh instance).  Nested loops are poison for a
+// wave64: lanes reach mesh leaves at different outer iterations, so every inner walk runs with a handful of lanes
+// (measured: 6400 VALU instructions per wave-ray for a lane average of 15 box tests).  Here a lane is a small state
+// machine — (level, node index, current ray) — and every loop iteration performs exactly one box test, whether the
+// lane is at the top level or inside a mesh, so the box-test instructions are shared by all lanes.  Each lane still
+// visits its nodes, instances and triangles in exactly the reference's order (ties are broken by that order: rect /
+// disk / triangle accept t <= closest, sphere t < closest), and the HitRecord is built once, after the walk, from
+// (instance, triangle, barycentrics) or by re-running the analytic test — same arithmetic, same bits.
+PT_HD void instance_local_ray(const SceneView& s, uint32_t inst, F3 o, F3 d, F3* lo, F3* ld) {
+    if (bu(s, inst + PT_INST_FLAGS) & 1u) { *lo = xf_point(s, inst + PT_INST_REVERSE, o); *ld = xf_vec(s, inst + PT_INST_REVERSE, d); }
+    else { *lo = o; *ld = d; }
+}
+PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out) {
+    const uint32_t NONE = 0xffffffffu;
+    const uint32_t flags = bu(s, PT_HDR_FLAGS);
+    const uint32_t top_off = bu(s, PT_HDR_TOP_NODE_OFF), top_count = bu(s, PT_HDR_TOP_NODE_COUNT), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
+    const bool exact = (flags & PT_FLAG_EXACT_SLAB) != 0;
+    const bool cull_top = (flags & (PT_FLAG_NO_TOP_CULL | PT_FLAG_NO_CULL)) == 0, cull_mesh = (flags & PT_FLAG_NO_CULL) == 0;
+    RayPrep wr = ray_prepare(o, d);      // world space; reused after every mesh walk and by untransformed instances
+    if (exact) wr.fast = false;
+    const TriRay wtr = tri_ray_prepare(o, d);
+    RayPrep cr = wr;
+    TriRay tr = wtr;
+    uint32_t node_off = top_off, node_count = top_count, i = 0;
+    uint32_t level_inst = NONE, top_resume = 0, tri_off = 0;
+    float closest = PT_INF;
+    uint32_t best_inst = NONE, best_tri = NONE;
+    TriHit bh; bh.t = 0.0f; bh.b0 = bh.b1 = bh.b2 = 0.0f;
+    bool done = false;
+    PT_STAT_EVENT(0);
+    PT_STAT_RAY(o, d);
+    for (;;) {
+        PT_STAT_EVENT(1);
+        // phase 1 — box steps only, until this lane reaches a leaf whose box is hit (or finishes).  All lanes of the wave
+        // share these instructions whatever level they are on.
+        uint32_t pending = NONE;
+        while (!done && pending == NONE) {
+            PT_STAT_EVENT(2);
+            if (i >= node_count) {
+                if (level_inst == NONE) { done = true; break; }
+                // the mesh walk is finished: back to the instance level, in world space
+                cr = wr;
+                node_off = top_off; node_count = top_count; i = top_resume; level_inst = NONE;
+                continue;
+            }
+            F4 a = bf4(s, node_off + i * PT_NODE_WORDS), b = bf4(s, node_off + i * PT_NODE_WORDS + 4);
+            uint32_t exit_i = pt_f2u(a.w), shape = pt_f2u(b.w);
+            float entry;
+            bool box = aabb_hit(a, b, cr, &entry) && !((level_inst != NONE ? cull_mesh : cull_top) && beyond(entry, closest, cr.base));
+            if (shape == PT_NODE_INNER) { i = box ? i + 1 : exit_i; }
+            else { i = exit_i; if (box) pending = shape; }
+        }
+        if (pending == NONE) break;  // done
+        // phase 2 — one leaf per lane: a triangle test inside a mesh, an instance at the top level
+        PT_STAT_EVENT(level_inst != NONE ? 3 : 4);
+        if (level_inst != NONE) {
+            uint32_t t = tri_off + pending * PT_TRI_WORDS;
+            F4 q0 = bf4(s, t), q1 = bf4(s, t + 4), q2 = bf4(s, t + 8);
+            TriHit th;
+            if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, closest, &th)) {
+                closest = th.t; best_inst = level_inst; best_tri = pending; bh = th;
+            }
+        } else {
+            uint32_t inst = inst_off + pending * PT_INST_WORDS;
+            uint32_t kind = bu(s, inst + PT_INST_KIND);
+            F3 lo, ld;
+            instance_local_ray(s, inst, o, d, &lo, &ld);
+            if (kind == PT_SHAPE_MESH) {
+                uint32_t mesh = bu(s, inst + PT_INST_MESH);
+                top_resume = i; level_inst = pending;
+                node_off = bu(s, mesh + PT_MESH_NODE_OFF); node_count = bu(s, mesh + PT_MESH_NODE_COUNT); tri_off = bu(s, mesh + PT_MESH_TRI_OFF);
+                if (bu(s, inst + PT_INST_FLAGS) & 1u) {
+                    cr = ray_prepare(lo, ld);
+                    if (exact) cr.fast = false;
+                    tr = tri_ray_prepare(lo, ld);
+                } else { cr = wr; tr = wtr; }
+                i = 0;
+            } else {
+                Hit h;
+                if (analytic_hit(s, inst, kind, lo, ld, closest, &h)) { closest = h.t; best_inst = pending; best_tri = NONE; }
+            }
+        }
+    }
+    if (best_inst == NONE) { out->valid = false; return false; }
+    // HitRecord of the winner (Instance::hit, instance.rs:89-131)
+    uint32_t inst = inst_off + best_inst * PT_INST_WORDS;
+    F3 lo, ld;
+    instance_local_ray(s, inst, o, d, &lo, &ld);
     Hit h;
-    bool ok = (kind == PT_SHAPE_MESH) ? mesh_hit(s, bu(s, inst + PT_INST_MESH), lo, ld, t1, &h)
-                                      : analytic_hit(s, inst, kind, lo, ld, t1, &h);
-    if (!ok) return false;
-    if (xf) {
+    if (best_tri != NONE) {
+        uint32_t mesh = bu(s, inst + PT_INST_MESH);
+        uint32_t t = bu(s, mesh + PT_MESH_TRI_OFF) + best_tri * PT_TRI_WORDS, normal_off = bu(s, mesh + PT_MESH_NORMAL_OFF);
+        F4 q0 = bf4(s, t), q1 = bf4(s, t + 4), q2 = bf4(s, t + 8);
+        F3 p0 = f3(q0.x, q0.y, q0.z), p1 = f3(q1.x, q1.y, q1.z), p2 = f3(q2.x, q2.y, q2.z);
+        F3 n = normalize(cross(sub(p0, p2), sub(p1, p2)));
+        if (normal_off != 0) {
+            uint32_t nn = normal_off + best_tri * PT_TRI_WORDS;
+            F4 m0 = bf4(s, nn), m1 = bf4(s, nn + 4), m2 = bf4(s, nn + 8);
+            n = add(add(mul(f3(m0.x, m0.y, m0.z), bh.b0), mul(f3(m1.x, m1.y, m1.z), bh.b1)), mul(f3(m2.x, m2.y, m2.z), bh.b2));
+        }
+        h.t = bh.t;
+        h.p = add(add(mul(p0, bh.b0), mul(p1, bh.b1)), mul(p2, bh.b2));
+        h.u = 0.0f; h.v = 0.0f;
+        h.n = normalize(n);
+        h.material = pt_f2u(q0.w);
+    } else {
+        // the accepted root of an analytic primitive does not depend on the upper bound it was tested against
+        analytic_hit(s, inst, bu(s, inst + PT_INST_KIND), lo, ld, PT_INF, &h);
+    }
+    if (bu(s, inst + PT_INST_FLAGS) & 1u) {
         h.n = normalize(xf_vec_transposed(s, inst + PT_INST_REVERSE, h.n));
         h.p = xf_point(s, inst + PT_INST_FORWARD, h.p);
     }
-    h.instance = instance_id;
+    h.instance = best_inst;
     uint32_t m = bu(s, inst + PT_INST_MATERIAL);
     if (m != PT_MATERIAL_NONE) h.material = m;
+    h.valid = true;
     *out = h;
     return true;
-}
-
-// World::hit(r, 0, inf) -> Accelerator::hit (src/accelerator/mod.rs:106-176) fused with FlatBVH::traverse
-// (src/accelerator/lbvh.rs:172-213): instances are tested in traversal order as their leaves are reached,
-// which is the order the reference's candidate list is processed in (its sort keys are all 0).
-PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out) {
-    uint32_t node_off = bu(s, PT_HDR_TOP_NODE_OFF), node_count = bu(s, PT_HDR_TOP_NODE_COUNT);
-    uint32_t inst_off = bu(s, PT_HDR_INSTANCE_OFF);
-    float closest = PT_INF; bool found = false;
-    uint32_t i = 0;
-    while (i < node_count) {
-        F4 a = bf4(s, node_off + i * PT_NODE_WORDS), b = bf4(s, node_off + i * PT_NODE_WORDS + 4);
-        uint32_t exit_i = pt_f2u(a.w), shape = pt_f2u(b.w);
-        bool box = aabb_hit(a, b, o, d);
-        if (shape == PT_NODE_INNER) { i = box ? i + 1 : exit_i; continue; }
-        if (box) {
-            Hit h;
-            if (instance_hit(s, inst_off + shape * PT_INST_WORDS, shape, o, d, closest, &h)) { closest = h.t; *out = h; found = true; }
-        }
-        i = exit_i;
-    }
-    if (!found) out->valid = false;
-    return found;
 }
 
 // ---------------------------------------------------------------- sampling helpers (math crate)
@@ -530,27 +651,38 @@ PT_HD void ggx_transmission(float alpha, bool metallic, float eo, float ei, floa
 }
 
 // ---------------------------------------------------------------- Material<f32,f32>
+// The spectral inputs of a material at one vertex (same lambda, same uv for the BSDF sample and every light-sample
+// evaluation): evaluated once.  The reference re-evaluates its curves in every call (lambertian.rs:25,62; ggx.rs:279-285,
+// 409-417); the values are identical, so this changes nothing but the instruction count.
+struct MatEval { uint32_t kind; bool metallic; float alpha; float refl; float ei, eo, kappa; };
+PT_HD MatEval material_prepare(const SceneView& s, uint32_t m, float lambda, float u, float v) {
+    MatEval e;
+    e.kind = bu(s, m + PT_MAT_KIND); e.metallic = false; e.alpha = 0.0f; e.refl = 0.0f; e.ei = e.eo = e.kappa = 0.0f;
+    if (e.kind == PT_MATERIAL_LAMBERTIAN) e.refl = pt_min(texstack_eval(s, bu(s, m + PT_MAT_TEXSTACK), lambda, u, v), 1.0f);
+    else if (e.kind != PT_MATERIAL_GGX) e.refl = pt_clamp(curve_eval(s, bu(s, m + PT_MAT_BOUNCE), lambda), 0.0f, 1.0f);
+    else {
+        e.alpha = bf(s, m + PT_MAT_ALPHA);
+        e.metallic = bu(s, m + PT_MAT_METALLIC) != 0;
+        e.ei = curve_eval(s, bu(s, m + PT_MAT_ETA), lambda); e.eo = curve_eval(s, bu(s, m + PT_MAT_ETA_O), lambda);
+        e.kappa = e.metallic ? curve_eval(s, bu(s, m + PT_MAT_KAPPA), lambda) : 0.0f;
+    }
+    return e;
+}
+
 // Material::bsdf (lambertian.rs:16-33, diffuse_light.rs:29-45, sharp_light.rs:43-60, ggx.rs:256-400)
-PT_HD void material_bsdf(const SceneView& s, uint32_t m, float lambda, float u, float v, F3 wi, F3 wo, float* f_out, float* pdf_out) {
-    uint32_t kind = bu(s, m + PT_MAT_KIND);
-    if (kind != PT_MATERIAL_GGX) {
-        if (wo.z * wi.z > 0.0f) {
-            float refl = (kind == PT_MATERIAL_LAMBERTIAN) ? pt_min(texstack_eval(s, bu(s, m + PT_MAT_TEXSTACK), lambda, u, v), 1.0f)
-                                                          : pt_clamp(curve_eval(s, bu(s, m + PT_MAT_BOUNCE), lambda), 0.0f, 1.0f);
-            *f_out = refl / PT_PI; *pdf_out = pt_abs(wo.z) / PT_PI;
-        } else { *f_out = 0.0f; *pdf_out = 0.0f; }
+PT_HD void material_bsdf_p(const MatEval& e, F3 wi, F3 wo, float* f_out, float* pdf_out) {
+    if (e.kind != PT_MATERIAL_GGX) {
+        if (wo.z * wi.z > 0.0f) { *f_out = e.refl / PT_PI; *pdf_out = pt_abs(wo.z) / PT_PI; }
+        else { *f_out = 0.0f; *pdf_out = 0.0f; }
         return;
     }
-    float alpha = bf(s, m + PT_MAT_ALPHA);
-    bool metallic = bu(s, m + PT_MAT_METALLIC) != 0;
+    float alpha = e.alpha; bool metallic = e.metallic; float ei = e.ei, eo = e.eo, kappa = e.kappa;
     wi = normalize(wi);
     bool same_hemisphere = wi.z * wo.z > 0.0f;
     float g = pt_abs(wi.z * wo.z);
     if (g == 0.0f) { *f_out = 0.0f; *pdf_out = 0.0f; return; }
     float cos_i = wi.z;
     float glossy = 0.0f, transmission = 0.0f, glossy_pdf = 0.0f, transmission_pdf = 0.0f;
-    float ei = curve_eval(s, bu(s, m + PT_MAT_ETA), lambda), eo = curve_eval(s, bu(s, m + PT_MAT_ETA_O), lambda);
-    float kappa = metallic ? curve_eval(s, bu(s, m + PT_MAT_KAPPA), lambda) : 0.0f;
     if (same_hemisphere) {
         F3 wh = normalize(add(wo, wi));
         if (wh.z < 0.0f) wh = neg(wh);
@@ -571,20 +703,13 @@ PT_HD void material_bsdf(const SceneView& s, uint32_t m, float lambda, float u, 
 }
 
 // Material::generate_and_evaluate (lambertian.rs:50-66, diffuse_light.rs:60-76, sharp_light.rs:183-198, ggx.rs:401-590)
-PT_HD void material_sample(const SceneView& s, uint32_t m, float lambda, float u, float v, float sx, float sy, F3 wi,
-                           float* f_out, F3* wo_out, float* pdf_out) {
-    uint32_t kind = bu(s, m + PT_MAT_KIND);
-    if (kind != PT_MATERIAL_GGX) {
+PT_HD void material_sample_p(const MatEval& e, float sx, float sy, F3 wi, float* f_out, F3* wo_out, float* pdf_out) {
+    if (e.kind != PT_MATERIAL_GGX) {
         F3 d = mul(random_cosine_direction(sx, sy), pt_signum(wi.z));
-        float refl = (kind == PT_MATERIAL_LAMBERTIAN) ? pt_min(texstack_eval(s, bu(s, m + PT_MAT_TEXSTACK), lambda, u, v), 1.0f)
-                                                      : pt_clamp(curve_eval(s, bu(s, m + PT_MAT_BOUNCE), lambda), 0.0f, 1.0f);
-        *f_out = refl / PT_PI; *wo_out = d; *pdf_out = pt_abs(d.z) / PT_PI;
+        *f_out = e.refl / PT_PI; *wo_out = d; *pdf_out = pt_abs(d.z) / PT_PI;
         return;
     }
-    float alpha = bf(s, m + PT_MAT_ALPHA);
-    bool metallic = bu(s, m + PT_MAT_METALLIC) != 0;
-    float ei = curve_eval(s, bu(s, m + PT_MAT_ETA), lambda), eo = curve_eval(s, bu(s, m + PT_MAT_ETA_O), lambda);
-    float kappa = metallic ? curve_eval(s, bu(s, m + PT_MAT_KAPPA), lambda) : 0.0f;
+    float alpha = e.alpha; bool metallic = e.metallic; float ei = e.ei, eo = e.eo, kappa = e.kappa;
     F3 wh = normalize(sample_wh(alpha, wi, sx, sy));
     float refl_prob = ggx_reflectance_probability(metallic, eo, ei, kappa, dot(wh, wi));
     bool did_reflect = false;
@@ -614,6 +739,15 @@ PT_HD void material_sample(const SceneView& s, uint32_t m, float lambda, float u
     *f_out = glossy + transmission;
     *wo_out = wo;
     *pdf_out = rp * glossy_pdf + (1.0f - rp) * transmission_pdf;
+}
+PT_HD void material_bsdf(const SceneView& s, uint32_t m, float lambda, float u, float v, F3 wi, F3 wo, float* f_out, float* pdf_out) {
+    MatEval e = material_prepare(s, m, lambda, u, v);
+    material_bsdf_p(e, wi, wo, f_out, pdf_out);
+}
+PT_HD void material_sample(const SceneView& s, uint32_t m, float lambda, float u, float v, float sx, float sy, F3 wi,
+                           float* f_out, F3* wo_out, float* pdf_out) {
+    MatEval e = material_prepare(s, m, lambda, u, v);
+    material_sample_p(e, sx, sy, wi, f_out, wo_out, pdf_out);
 }
 
 // Material::emission (diffuse_light.rs:123-133, sharp_light.rs:138-150, 202-204)

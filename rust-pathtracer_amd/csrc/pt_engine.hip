@@ -36,7 +36,6 @@ pt_status fail(pt_status st, const std::string& msg) { g_error = msg; return st;
 constexpr int kBlock = 256;
 constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // stage the blob in LDS when it fits (keeps >= 2 workgroups per CU)
 
-enum { CTR_BOUNCE_RAYS, CTR_SHADOW_RAYS, CTR_ENV_HITS, CTR_SEGMENTS, CTR_SHADOW_ITEMS, CTR_COUNT };
 enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_ACCUMULATE, ST_COUNT };
 
 // ------------------------------------------------------------------------------------------------ kernels
@@ -60,47 +59,73 @@ __device__ __forceinline__ SceneView stage_scene(const uint32_t* __restrict__ bl
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
-// wave64 compaction: lanes with `flag` get consecutive positions in the queue whose length is *counter.
-__device__ __forceinline__ uint32_t wave_append(bool flag, uint32_t* counter) {
+// ---- segmented queues -------------------------------------------------------------------------------------------
+// Every queue is cut into gridDim.x segments of `seg_cap` items; workgroup b owns segment b in every kernel of a pass:
+// it reads items [b*seg_cap, b*seg_cap + count_in[b]) and appends its survivors, compacted, to the same segment of the
+// output queue.  Compaction is a wave64 ballot + an LDS exchange of the four wave totals — no global atomics at all
+// (a single hot queue head saturates at ~88 returning atomics/us on MI355X, which was the whole cost of the first
+// version of k_shade), and each workgroup's writes are one contiguous, 256-byte aligned run per field.
+// Survival is statistically uniform over segments, so the static ownership keeps the load balanced.
+struct BlockAppend {
+    uint32_t running;  // items appended so far by this workgroup (uniform across its threads)
+};
+__device__ __forceinline__ uint32_t block_append(bool flag, BlockAppend& st, uint32_t* lds_counts /* [2][4] */, uint32_t round) {
     unsigned long long mask = __ballot(flag);
-    uint32_t total = (uint32_t)__popcll(mask);
-    uint32_t base = 0;
-    uint32_t lane = lane_id();
-    if (total) {
-        int leader = __ffsll((long long)mask) - 1;
-        if ((int)lane == leader) base = atomicAdd(counter, total);
-        base = __shfl(base, leader);
-    }
-    uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    return base + prefix;
+    uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    uint32_t* c = lds_counts + (round & 1u) * 4u;
+    if (lane == 0) c[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+    uint32_t before = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u);
+    uint32_t pos = st.running + before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    st.running += c0 + c1 + c2 + c3;
+    return pos;
 }
-__device__ __forceinline__ void wave_count(bool flag, unsigned long long* counter) {
-    unsigned long long mask = __ballot(flag);
-    if (mask && lane_id() == (uint32_t)(__ffsll((long long)mask) - 1)) atomicAdd(counter, (unsigned long long)__popcll(mask));
+// two independent appends sharing one barrier
+__device__ __forceinline__ void block_append2(bool f0, bool f1, BlockAppend& s0, BlockAppend& s1, uint32_t* lds_counts /* [2][8] */, uint32_t round,
+                                              uint32_t* pos0, uint32_t* pos1) {
+    unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+    uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    uint32_t* c = lds_counts + (round & 1u) * 8u;
+    if (lane == 0) { c[wave] = (uint32_t)__popcll(m0); c[4 + wave] = (uint32_t)__popcll(m1); }
+    __syncthreads();
+    uint32_t a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3], b0 = c[4], b1 = c[5], b2 = c[6], b3 = c[7];
+    unsigned long long lt = (1ull << lane) - 1ull;
+    *pos0 = s0.running + (wave > 0 ? a0 : 0u) + (wave > 1 ? a1 : 0u) + (wave > 2 ? a2 : 0u) + (uint32_t)__popcll(m0 & lt);
+    *pos1 = s1.running + (wave > 0 ? b0 : 0u) + (wave > 1 ? b1 : 0u) + (wave > 2 ? b2 : 0u) + (uint32_t)__popcll(m1 & lt);
+    s0.running += a0 + a1 + a2 + a3;
+    s1.running += b0 + b1 + b2 + b3;
 }
-__device__ __forceinline__ void wave_sum(uint32_t v, unsigned long long* counter) {
+__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if (lane_id() == 0 && v) atomicAdd(counter, (unsigned long long)v);
+    return v;  // valid in lane 0
 }
 
+// Per-workgroup statistics (Profile counters), owned by the workgroup: plain read-modify-write, summed on the host.
+enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_FIELDS };
+
 __global__ void __launch_bounds__(kBlock) k_generate(RenderParams rp, const uint32_t* __restrict__ pixels, Queue paths, float* __restrict__ energy,
-                                                    uint32_t n, uint32_t* __restrict__ counts) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        uint32_t pixel = pixels[i % rp.chunk_pixels];
-        PathVertex p = stage_generate(rp, i, pixel);
-        store_path(paths, i, p);
-        energy[i] = 0.0f;
+                                                    uint32_t n, uint32_t seg_cap, uint32_t* __restrict__ count_out) {
+    uint32_t base = blockIdx.x * seg_cap;
+    uint32_t cnt = base < n ? (n - base < seg_cap ? n - base : seg_cap) : 0u;
+    for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x) {
+        uint32_t slot = base + j;
+        uint32_t pixel = pixels[slot % rp.chunk_pixels];
+        PathVertex p = stage_generate(rp, slot, pixel);
+        store_path(paths, slot, p);
+        energy[slot] = 0.0f;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = n;
+    if (threadIdx.x == 0) count_out[blockIdx.x] = cnt;
 }
 
 template <bool USE_LDS>
 __global__ void __launch_bounds__(kBlock) k_extend(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
-                                                  Queue paths, Queue hits, const uint32_t* __restrict__ count) {
+                                                  Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
     extern __shared__ __align__(16) uint32_t lds[];
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
-    uint32_t n = *count;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+        uint32_t i = base + j;
         F3 o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
         F3 d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
         Hit h;
@@ -113,56 +138,77 @@ template <bool USE_LDS>
 __global__ void __launch_bounds__(kBlock) k_shade(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                  RenderParams rp, uint32_t bounce, const uint32_t* __restrict__ pixels,
                                                  Queue paths_in, Queue hits, Queue paths_out, Queue shadow, float* __restrict__ energy,
-                                                 const uint32_t* __restrict__ count_in, uint32_t* __restrict__ count_out,
-                                                 uint32_t* __restrict__ shadow_count, unsigned long long* __restrict__ counters) {
+                                                 uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ count_out,
+                                                 uint32_t* __restrict__ shadow_count, unsigned long long* __restrict__ block_stats) {
     extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ uint32_t lds_counts[16];
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
-    uint32_t n = *count_in;
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[CTR_SEGMENTS], (unsigned long long)n);
-    uint32_t rounds = (n + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
-    for (uint32_t r = 0; r < rounds; ++r) {  // whole waves stay in the loop so ballots see every lane
-        uint32_t i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-        bool active = i < n;
-        ShadeOut out;
-        ShadowRay rays[PT_MAX_LIGHT_SAMPLES];
-        out.survives = false; out.has_item = false; out.vertex_pushed = false; out.env_hit = false; out.shadow_count = 0; out.add_energy = false;
-        PathVertex pv;
+    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    BlockAppend ap_path{0}, ap_item{0};
+    uint32_t st_vertices = 0, st_shadow = 0, st_env = 0;
+    const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
+    for (uint32_t r = 0; r < rounds; ++r) {  // whole workgroups stay in the loop: the appends contain barriers
+        uint32_t j = r * blockDim.x + threadIdx.x;
+        bool active = j < n;
+        uint32_t i = base + j;
+        PathVertex pv; Hit hit; hit.valid = false;
+        bool wants_item = false;
         if (active) {
             pv = load_path(paths_in, i);
-            Hit hit = load_hit(hits, i);
+            hit = load_hit(hits, i);
+            wants_item = shade_wants_item(s, rp, hit);
+        }
+        // reserve the light-sample item first, so its rays stream straight from registers to the queue
+        uint32_t ipos = base + block_append(wants_item, ap_item, lds_counts, r);
+        ShadeOut out;
+        out.survives = false; out.has_item = false; out.vertex_pushed = false; out.env_hit = false; out.shadow_count = 0; out.add_energy = false; out.env_mask = 0;
+        if (active) {
             uint32_t pixel = pixels[pv.slot % rp.chunk_pixels];
-            out = stage_shade(s, rp, bounce, pv, hit, pixel, rays);
+            const uint32_t L = rp.light_samples;
+            out = stage_shade(s, rp, bounce, pv, hit, pixel, [&](uint32_t l, const ShadowRay& ray) {
+                uint32_t f0 = SH_HEAD + l * SR_FIELDS;
+                qsf(shadow, f0 + SR_FACTOR, ipos, ray.factor);
+                if (ray.factor != 0.0f) {
+                    qsf(shadow, f0 + SR_OX, ipos, ray.o.x); qsf(shadow, f0 + SR_OY, ipos, ray.o.y); qsf(shadow, f0 + SR_OZ, ipos, ray.o.z);
+                    qsf(shadow, f0 + SR_DX, ipos, ray.d.x); qsf(shadow, f0 + SR_DY, ipos, ray.d.y); qsf(shadow, f0 + SR_DZ, ipos, ray.d.z);
+                }
+            });
+            if (wants_item) {
+                qsu(shadow, SH_SLOT, ipos, pv.slot); qsf(shadow, SH_LAMBDA, ipos, pv.lambda); qsu(shadow, SH_FLAGS, ipos, out.env_mask);
+                if (!out.has_item)  // vertex dropped (NaN pdf, utils.rs:261-263): the reserved item traces nothing
+                    for (uint32_t l = 0; l < L; ++l) qsf(shadow, SH_HEAD + l * SR_FIELDS + SR_FACTOR, ipos, 0.0f);
+            }
             if (out.add_energy) energy[pv.slot] += out.energy_add;
         }
-        uint32_t pos = wave_append(out.survives, count_out);
+        uint32_t pos = base + block_append(out.survives, ap_path, lds_counts + 8, r);
         if (out.survives) store_path(paths_out, pos, out.next);
-        uint32_t ipos = wave_append(out.has_item, shadow_count);
-        if (out.has_item) {
-            qsu(shadow, SH_SLOT, ipos, pv.slot); qsf(shadow, SH_LAMBDA, ipos, pv.lambda); qsu(shadow, SH_FLAGS, ipos, out.env_mask);
-            for (uint32_t l = 0; l < rp.light_samples; ++l) {
-                uint32_t f0 = SH_HEAD + l * SR_FIELDS;
-                qsf(shadow, f0 + SR_FACTOR, ipos, rays[l].factor);
-                if (rays[l].factor != 0.0f) {
-                    qsf(shadow, f0 + SR_OX, ipos, rays[l].o.x); qsf(shadow, f0 + SR_OY, ipos, rays[l].o.y); qsf(shadow, f0 + SR_OZ, ipos, rays[l].o.z);
-                    qsf(shadow, f0 + SR_DX, ipos, rays[l].d.x); qsf(shadow, f0 + SR_DY, ipos, rays[l].d.y); qsf(shadow, f0 + SR_DZ, ipos, rays[l].d.z);
-                }
-            }
-        }
-        wave_count(out.vertex_pushed, &counters[CTR_BOUNCE_RAYS]);
-        wave_count(out.env_hit, &counters[CTR_ENV_HITS]);
-        wave_sum(out.shadow_count, &counters[CTR_SHADOW_RAYS]);
+        st_vertices += out.vertex_pushed ? 1u : 0u; st_env += out.env_hit ? 1u : 0u; st_shadow += out.shadow_count;
+    }
+    if (threadIdx.x == 0) { count_out[blockIdx.x] = ap_path.running; shadow_count[blockIdx.x] = ap_item.running; }
+    // workgroup totals -> this workgroup's statistics record
+    st_vertices = wave_reduce_add(st_vertices); st_shadow = wave_reduce_add(st_shadow); st_env = wave_reduce_add(st_env);
+    __syncthreads();
+    if (lane_id() == 0) { uint32_t w = threadIdx.x >> 6; lds_counts[w] = st_vertices; lds_counts[4 + w] = st_shadow; lds_counts[8 + w] = st_env; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* bs = block_stats + (size_t)blockIdx.x * BS_FIELDS;
+        bs[BS_VERTICES] += lds_counts[0] + lds_counts[1] + lds_counts[2] + lds_counts[3];
+        bs[BS_SHADOW_RAYS] += lds_counts[4] + lds_counts[5] + lds_counts[6] + lds_counts[7];
+        bs[BS_ENV_HITS] += lds_counts[8] + lds_counts[9] + lds_counts[10] + lds_counts[11];
+        bs[BS_SEGMENTS] += n;
+        bs[BS_ITEMS] += ap_item.running;
     }
 }
 
 template <bool USE_LDS>
 __global__ void __launch_bounds__(kBlock) k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                   uint32_t light_samples, Queue shadow, float* __restrict__ energy,
-                                                  const uint32_t* __restrict__ count, unsigned long long* __restrict__ counters) {
+                                                  uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
     extern __shared__ __align__(16) uint32_t lds[];
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
-    uint32_t n = *count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[CTR_SHADOW_ITEMS], (unsigned long long)n);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+        uint32_t i = base + j;
         uint32_t slot = qu(shadow, SH_SLOT, i), flags = qu(shadow, SH_FLAGS, i);
         float lambda = qf(shadow, SH_LAMBDA, i);
         float lc = 0.0f;
@@ -254,10 +300,11 @@ struct DeviceBuffers {
     uint32_t capacity = 0, light_samples = 0;
     uint32_t *paths_a = nullptr, *paths_b = nullptr, *hits = nullptr, *shadow = nullptr, *pixels = nullptr, *counts = nullptr;
     float* energy = nullptr;
-    unsigned long long* counters = nullptr;
+    unsigned long long* block_stats = nullptr;
     size_t pixel_capacity = 0;
+    int grid = 0;  // segments per queue == workgroups per launch
     void release() {
-        hipFree(paths_a); hipFree(paths_b); hipFree(hits); hipFree(shadow); hipFree(pixels); hipFree(counts); hipFree(energy); hipFree(counters);
+        hipFree(paths_a); hipFree(paths_b); hipFree(hits); hipFree(shadow); hipFree(pixels); hipFree(counts); hipFree(energy); hipFree(block_stats);
         *this = DeviceBuffers();
     }
 };
@@ -288,26 +335,34 @@ pt_status ensure_device() {
 
 uint32_t shadow_fields(uint32_t light_samples) { return SH_HEAD + light_samples * SR_FIELDS; }
 
-pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples, size_t n_pixels) {
+// Segment capacity for n items over `grid` segments, rounded up to 64 items so that every segment starts on a
+// 256-byte boundary in every field.
+uint32_t segment_capacity(uint32_t n, int grid) {
+    uint32_t c = (n + (uint32_t)grid - 1) / (uint32_t)grid;
+    return (c + 63u) & ~63u;
+}
+
+pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples, size_t n_pixels, int grid) {
     DeviceBuffers& b = sc->buf;
-    if (b.capacity < capacity || b.light_samples < light_samples) {
-        hipFree(b.paths_a); hipFree(b.paths_b); hipFree(b.hits); hipFree(b.shadow); hipFree(b.energy);
-        b.paths_a = b.paths_b = b.hits = b.shadow = nullptr; b.energy = nullptr; b.capacity = 0;
+    uint32_t total = segment_capacity(capacity, grid) * (uint32_t)grid;
+    if (b.capacity < total || b.light_samples < light_samples || b.grid != grid) {
+        hipFree(b.paths_a); hipFree(b.paths_b); hipFree(b.hits); hipFree(b.shadow); hipFree(b.energy); hipFree(b.counts); hipFree(b.block_stats);
+        b.paths_a = b.paths_b = b.hits = b.shadow = b.counts = nullptr; b.energy = nullptr; b.block_stats = nullptr; b.capacity = 0;
         uint32_t ls = light_samples > b.light_samples ? light_samples : b.light_samples;
-        HIP_TRY(hipMalloc(&b.paths_a, sizeof(uint32_t) * (size_t)PS_FIELDS * capacity));
-        HIP_TRY(hipMalloc(&b.paths_b, sizeof(uint32_t) * (size_t)PS_FIELDS * capacity));
-        HIP_TRY(hipMalloc(&b.hits, sizeof(uint32_t) * (size_t)HS_FIELDS * capacity));
-        HIP_TRY(hipMalloc(&b.shadow, sizeof(uint32_t) * (size_t)shadow_fields(ls ? ls : 1) * capacity));
-        HIP_TRY(hipMalloc(&b.energy, sizeof(float) * (size_t)capacity));
-        b.capacity = capacity; b.light_samples = ls;
+        HIP_TRY(hipMalloc(&b.paths_a, sizeof(uint32_t) * (size_t)PS_FIELDS * total));
+        HIP_TRY(hipMalloc(&b.paths_b, sizeof(uint32_t) * (size_t)PS_FIELDS * total));
+        HIP_TRY(hipMalloc(&b.hits, sizeof(uint32_t) * (size_t)HS_FIELDS * total));
+        HIP_TRY(hipMalloc(&b.shadow, sizeof(uint32_t) * (size_t)shadow_fields(ls ? ls : 1) * total));
+        HIP_TRY(hipMalloc(&b.energy, sizeof(float) * (size_t)total));
+        HIP_TRY(hipMalloc(&b.counts, sizeof(uint32_t) * 3 * (size_t)grid));
+        HIP_TRY(hipMalloc(&b.block_stats, sizeof(unsigned long long) * BS_FIELDS * (size_t)grid));
+        b.capacity = total; b.light_samples = ls; b.grid = grid;
     }
     if (b.pixel_capacity < n_pixels) {
         hipFree(b.pixels); b.pixels = nullptr;
         HIP_TRY(hipMalloc(&b.pixels, sizeof(uint32_t) * n_pixels));
         b.pixel_capacity = n_pixels;
     }
-    if (!b.counts) HIP_TRY(hipMalloc(&b.counts, sizeof(uint32_t) * 2 * 72));
-    if (!b.counters) HIP_TRY(hipMalloc(&b.counters, sizeof(unsigned long long) * CTR_COUNT));
     return PT_OK;
 }
 
@@ -334,12 +389,13 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     if (capacity < 1024) capacity = 1024;
     uint64_t want = (uint64_t)pixels.size() * rd.sample_count;
     if (want < capacity) capacity = (uint32_t)(want ? want : 1);
-    pt_status st = ensure_buffers(sc, capacity, rd.light_samples, pixels.size() ? pixels.size() : 1);
+    const int grid = sc->num_cus * (int)env_u32("PT_AMD_BLOCKS_PER_CU", 8);
+    pt_status st = ensure_buffers(sc, capacity, rd.light_samples, pixels.size() ? pixels.size() : 1, grid);
     if (st != PT_OK) return st;
     DeviceBuffers& b = sc->buf;
     if (!pixels.empty()) HIP_TRY(hipMemcpyAsync(b.pixels, pixels.data(), sizeof(uint32_t) * pixels.size(), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd.width * rd.height, stream));
-    HIP_TRY(hipMemsetAsync(b.counters, 0, sizeof(unsigned long long) * CTR_COUNT, stream));
+    HIP_TRY(hipMemsetAsync(b.block_stats, 0, sizeof(unsigned long long) * BS_FIELDS * (size_t)grid, stream));
 
     RenderParams rp;
     memset(&rp, 0, sizeof(rp));
@@ -352,14 +408,13 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
 
     const uint32_t blob_bytes = sc->blob_words * 4;
     const bool lds = sc->use_lds;
-    const int grid = sc->num_cus * (int)env_u32("PT_AMD_BLOCKS_PER_CU", 8);
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
     const bool timing = env_u32("PT_AMD_STAGE_TIMING", 1) != 0;
     double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0};
     uint64_t stage_launches[ST_COUNT] = {0, 0, 0, 0, 0};
     Queue qa{b.paths_a, b.capacity}, qb{b.paths_b, b.capacity}, qh{b.hits, b.capacity}, qs{b.shadow, b.capacity};
-    uint32_t* live = b.counts;          // live[bounce]
-    uint32_t* nshadow = b.counts + 72;  // nshadow[bounce]
+    uint32_t* live[2] = {b.counts, b.counts + grid};  // per-segment live-path counts, ping-pong with the path queues
+    uint32_t* nshadow = b.counts + 2 * grid;          // per-segment light-sample item counts
 
     auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipStreamSynchronize(stream));
@@ -378,32 +433,34 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
         stage_launches[stage]++;
     };
 
-    std::vector<pth::Pass> passes = pth::plan_passes((uint32_t)pixels.size(), rd.first_sample, rd.sample_count, b.capacity);
+    // the planner's capacity is in items; segments round up, so plan with what surely fits
+    std::vector<pth::Pass> passes = pth::plan_passes((uint32_t)pixels.size(), rd.first_sample, rd.sample_count, capacity);
     uint64_t camera_rays = 0, accumulated_pixels = 0;
     for (const pth::Pass& pass : passes) {
         accumulated_pixels += pass.pixel_count;
         rp.chunk_pixels = pass.pixel_count; rp.first_sample = pass.first_sample; rp.pass_samples = pass.sample_count;
         uint32_t n = pass.pixel_count * pass.sample_count;
+        uint32_t seg_cap = segment_capacity(n, grid);
         camera_rays += n;
         const uint32_t* d_px = b.pixels + pass.pixel_begin;
-        HIP_TRY(hipMemsetAsync(b.counts, 0, sizeof(uint32_t) * 2 * 72, stream));
-        timed(ST_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, qa, b.energy, n, live); });
+        timed(ST_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, qa, b.energy, n, seg_cap, live[0]); });
         for (uint32_t bounce = 0; bounce < bounce_limit; ++bounce) {
             Queue qin = (bounce & 1) ? qb : qa, qout = (bounce & 1) ? qa : qb;
+            uint32_t *cin = live[bounce & 1], *cout = live[(bounce + 1) & 1];
             timed(ST_EXTEND, [&] {
-                if (lds) launch(k_extend<true>, true, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, live + bounce);
-                else launch(k_extend<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, live + bounce);
+                if (lds) launch(k_extend<true>, true, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin);
+                else launch(k_extend<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin);
             });
             timed(ST_SHADE, [&] {
                 if (lds) launch(k_shade<true>, true, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rp, bounce, d_px, qin, qh, qout, qs, b.energy,
-                                live + bounce, live + bounce + 1, nshadow + bounce, b.counters);
+                                seg_cap, cin, cout, nshadow, b.block_stats);
                 else launch(k_shade<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rp, bounce, d_px, qin, qh, qout, qs, b.energy,
-                            live + bounce, live + bounce + 1, nshadow + bounce, b.counters);
+                            seg_cap, cin, cout, nshadow, b.block_stats);
             });
             if (rd.light_samples > 0)
                 timed(ST_SHADOW, [&] {
-                    if (lds) launch(k_shadow<true>, true, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, nshadow + bounce, b.counters);
-                    else launch(k_shadow<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, nshadow + bounce, b.counters);
+                    if (lds) launch(k_shadow<true>, true, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, seg_cap, nshadow);
+                    else launch(k_shadow<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, seg_cap, nshadow);
                 });
         }
         timed(ST_ACCUMULATE, [&] { hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, b.energy, d_film); });
@@ -417,16 +474,18 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     }
     if (profile) {
         memset(profile, 0, sizeof(*profile));
-        unsigned long long c[CTR_COUNT];
-        HIP_TRY(hipMemcpy(c, b.counters, sizeof(c), hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> bs((size_t)grid * BS_FIELDS);
+        HIP_TRY(hipMemcpy(bs.data(), b.block_stats, sizeof(unsigned long long) * bs.size(), hipMemcpyDeviceToHost));
+        unsigned long long c[BS_FIELDS] = {0, 0, 0, 0, 0};
+        for (int g = 0; g < grid; ++g) for (int k = 0; k < BS_FIELDS; ++k) c[k] += bs[(size_t)g * BS_FIELDS + k];
         profile->camera_rays = camera_rays;
-        profile->bounce_rays = c[CTR_BOUNCE_RAYS] + camera_rays;  // vertices.len() counts the camera vertex (utils.rs:375)
-        profile->shadow_rays = c[CTR_SHADOW_RAYS];
-        profile->env_hits = c[CTR_ENV_HITS];
+        profile->bounce_rays = c[BS_VERTICES] + camera_rays;  // vertices.len() counts the camera vertex (utils.rs:375)
+        profile->shadow_rays = c[BS_SHADOW_RAYS];
+        profile->env_hits = c[BS_ENV_HITS];
         profile->seconds = std::chrono::duration<double>(t1 - t0).count();
         for (int i = 0; i < ST_COUNT; ++i) { profile->kernel_seconds[i] = stage_ms[i] * 1e-3; profile->kernel_launches[i] = stage_launches[i]; }
-        profile->stage_items[ST_GENERATE] = camera_rays; profile->stage_items[ST_EXTEND] = c[CTR_SEGMENTS]; profile->stage_items[ST_SHADE] = c[CTR_SEGMENTS];
-        profile->stage_items[ST_SHADOW] = c[CTR_SHADOW_ITEMS]; profile->stage_items[ST_ACCUMULATE] = accumulated_pixels;
+        profile->stage_items[ST_GENERATE] = camera_rays; profile->stage_items[ST_EXTEND] = c[BS_SEGMENTS]; profile->stage_items[ST_SHADE] = c[BS_SEGMENTS];
+        profile->stage_items[ST_SHADOW] = c[BS_ITEMS]; profile->stage_items[ST_ACCUMULATE] = accumulated_pixels;
     }
     return PT_OK;
 }
@@ -481,6 +540,8 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, sc->device);
     if (e != hipSuccess) { delete sc; return fail(PT_ERR_NO_DEVICE, hipGetErrorString(e)); }
     sc->num_cus = prop.multiProcessorCount;
+    if (env_u32("PT_AMD_EXACT_SLAB", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_EXACT_SLAB;
+    if (env_u32("PT_AMD_NO_CULL", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_CULL;
     sc->blob_words = (uint32_t)sc->host.blob.size();
     sc->use_lds = sc->blob_words * 4 <= kLdsBlobLimitBytes && env_u32("PT_AMD_NO_LDS", 0) == 0;
     e = hipMalloc(&sc->d_blob, sizeof(uint32_t) * sc->host.blob.size());

@@ -348,6 +348,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
         radius = std::sqrt(sx * sx + sy * sy + sz * sz) / 2.0f;
     }
     w[PT_HDR_WORLD_RADIUS] = fbits(radius);
+    { uint32_t flags = 0; for (uint32_t i = 0; i < d.instance_count; ++i) if (d.instances[i].kind == PT_SHAPE_DISK) flags |= PT_FLAG_NO_TOP_CULL; w[PT_HDR_FLAGS] = flags; }
     w[PT_HDR_MAGIC] = PT_BLOB_MAGIC; w[PT_HDR_TOTAL_WORDS] = (uint32_t)w.size();
     hs->light_count = (uint32_t)lights.size();
     hs->material_count = d.material_count;

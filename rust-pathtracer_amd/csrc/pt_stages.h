@@ -116,10 +116,19 @@ struct ShadeOut {
     bool has_item;
 };
 
+// Whether a hit vertex gets a light-sample work item (known before shading, so the kernel can reserve the queue
+// position first and stream the rays straight to HBM): non-light material, L > 0, something to sample (pt.rs:346-348, 584).
+PT_HD bool shade_wants_item(const SceneView& s, const RenderParams& rp, const Hit& hit) {
+    if (!hit.valid || rp.light_samples == 0) return false;
+    if (PT_MATERIAL_TAG(hit.material) == PT_TAG_LIGHT) return false;
+    return !(bu(s, PT_HDR_LIGHT_COUNT) == 0 && bf(s, PT_HDR_ENV_PROB) == 0.0f);
+}
+
 // One vertex of random_walk (utils.rs:170-373) + the matching iteration of color()'s second pass (pt.rs:481-604).
-// `rays` must hold PT_MAX_LIGHT_SAMPLES entries; entries with factor == 0 are not traced.
+// `sink(l, ray)` receives every light-sample ray (factor == 0: nothing to trace) when the vertex has an item.
+template <typename RaySink>
 PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t bounce, const PathVertex& pv, const Hit& hit,
-                           uint32_t pixel, ShadowRay* rays) {
+                           uint32_t pixel, RaySink&& sink) {
     ShadeOut out;
     out.survives = false; out.energy_add = 0.0f; out.add_energy = false; out.vertex_pushed = false; out.env_hit = false;
     out.shadow_count = 0; out.env_mask = 0; out.has_item = false;
@@ -146,7 +155,8 @@ PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t 
     bool is_light = PT_MATERIAL_TAG(hit.material) == PT_TAG_LIGHT;
     pt_f32x4 r = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples));
     float f, pdf; F3 wo;
-    material_sample(s, m, lambda, hit.u, hit.v, r.x, r.y, wi, &f, &wo, &pdf);
+    MatEval me = material_prepare(s, m, lambda, hit.u, hit.v);
+    material_sample_p(me, r.x, r.y, wi, &f, &wo, &pdf);
     float cos_o = pt_abs(wo.z);
     if (pt_isnan(pdf)) return out;  // utils.rs:261-263: the vertex is never pushed
     float rr = (bounce >= rp.min_bounces) ? pt_min(f / pdf, 1.0f) : 1.0f;
@@ -176,7 +186,7 @@ PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t 
             Frame fr2 = frame_from_normal(hn);
             F3 wi2 = to_local(fr2, normalize(sub(pv.prev_p, hit.p)));
             for (uint32_t l = 0; l < rp.light_samples; ++l) {
-                rays[l].factor = 0.0f;
+                ShadowRay ray; ray.factor = 0.0f; ray.o = f3(0, 0, 0); ray.d = f3(0, 0, 0);
                 pt_f32x4 q = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples) + 1u + l);
                 float x = q.x;
                 bool sample_world = choose_first(&x, env_p);
@@ -186,39 +196,40 @@ PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t 
                     env_sample_uv(s, q.y, q.z, &eu, &ev, &light_pdf);
                     F3 direction = uv_to_direction(eu, ev);
                     F3 local_wo = to_local(fr2, direction);
-                    if (local_wo.z <= 0.0f) continue;
-                    float refl, spdf;
-                    material_bsdf(s, m, lambda, hit.u, hit.v, wi2, local_wo, &refl, &spdf);
-                    float emission = env_emission(s, eu, ev, lambda);
-                    float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + spdf);
-                    rays[l].o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(direction.z)));
-                    rays[l].d = direction;
-                    rays[l].factor = pv.beta * weight * refl * emission * pt_abs(local_wo.z) * (1.0f / light_pdf);
-                    out.env_mask |= 1u << l;
-                    out.shadow_count += 1;
-                    // a contribution of exactly 0 adds 0 whether or not the ray is occluded; keep it traceable
-                    if (rays[l].factor == 0.0f) { out.env_mask &= ~(1u << l); }
-                } else {
+                    if (local_wo.z > 0.0f) {
+                        float refl, spdf;
+                        material_bsdf_p(me, wi2, local_wo, &refl, &spdf);
+                        float emission = env_emission(s, eu, ev, lambda);
+                        float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + spdf);
+                        ray.o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(direction.z)));
+                        ray.d = direction;
+                        ray.factor = pv.beta * weight * refl * emission * pt_abs(local_wo.z) * (1.0f / light_pdf);
+                        out.shadow_count += 1;
+                        // a contribution of exactly 0 adds 0 whether or not the ray is occluded: not traced
+                        if (ray.factor != 0.0f) out.env_mask |= 1u << l;
+                    }
+                } else if (n_lights != 0) {
                     // estimate_direct_illumination, pt.rs:146-218
-                    if (n_lights == 0) continue;
                     float fi = pt_clamp((float)n_lights * x, 0.0f, (float)n_lights - 1.0f);
                     uint32_t light_id = bu(s, bu(s, PT_HDR_LIGHT_OFF) + (uint32_t)fi);
                     float pick_pdf = 1.0f / (float)n_lights;
                     F3 ldir; float light_pdf;
                     light_sample(s, bu(s, PT_HDR_INSTANCE_OFF) + light_id * PT_INST_WORDS, q.y, q.z, hit.p, &ldir, &light_pdf);
                     light_pdf = light_pdf * pick_pdf;
-                    if (light_pdf == 0.0f) continue;
-                    F3 bsdf_wo = to_local(fr2, ldir);
-                    float refl, bpdf;
-                    material_bsdf(s, m, lambda, hit.u, hit.v, wi2, bsdf_wo, &refl, &bpdf);
-                    float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + bpdf);
-                    rays[l].o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(bsdf_wo.z)));
-                    rays[l].d = ldir;
-                    // pt.rs:196-202: reflectance * throughput * cos_i * cos_o * emission * weight / light_pdf; cos_i and the
-                    // emission are only known at the shadow hit and are multiplied in there.
-                    rays[l].factor = refl * pv.beta * pt_abs(bsdf_wo.z) * weight / light_pdf;
-                    out.shadow_count += 1;
+                    if (light_pdf != 0.0f) {
+                        F3 bsdf_wo = to_local(fr2, ldir);
+                        float refl, bpdf;
+                        material_bsdf_p(me, wi2, bsdf_wo, &refl, &bpdf);
+                        float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + bpdf);
+                        ray.o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(bsdf_wo.z)));
+                        ray.d = ldir;
+                        // pt.rs:196-202: reflectance * throughput * cos_i * cos_o * emission * weight / light_pdf; cos_i and the
+                        // emission are only known at the shadow hit and are multiplied in there.
+                        ray.factor = refl * pv.beta * pt_abs(bsdf_wo.z) * weight / light_pdf;
+                        out.shadow_count += 1;
+                    }
                 }
+                sink(l, ray);
             }
             out.has_item = true;
         }

@@ -69,22 +69,23 @@ pt_status ptemu_render(pt_scene* sc, const pt_render_desc* rdp, float* film, pt_
             for (uint32_t i = 0; i < live; ++i) {
                 PathVertex pv = load_path(qin, i);
                 Hit hit = load_hit(qh, i);
-                ShadowRay rays[PT_MAX_LIGHT_SAMPLES];
-                ShadeOut out = stage_shade(s, rp, bounce, pv, hit, px[pv.slot % rp.chunk_pixels], rays);
+                bool wants = shade_wants_item(s, rp, hit);
+                uint32_t ipos = items;
+                ShadeOut out = stage_shade(s, rp, bounce, pv, hit, px[pv.slot % rp.chunk_pixels], [&](uint32_t l, const ShadowRay& ray) {
+                    uint32_t f0 = SH_HEAD + l * SR_FIELDS;
+                    qsf(qs, f0 + SR_FACTOR, ipos, ray.factor);
+                    if (ray.factor != 0.0f) {
+                        qsf(qs, f0 + SR_OX, ipos, ray.o.x); qsf(qs, f0 + SR_OY, ipos, ray.o.y); qsf(qs, f0 + SR_OZ, ipos, ray.o.z);
+                        qsf(qs, f0 + SR_DX, ipos, ray.d.x); qsf(qs, f0 + SR_DY, ipos, ray.d.y); qsf(qs, f0 + SR_DZ, ipos, ray.d.z);
+                    }
+                });
+                if (wants) {
+                    items++;
+                    qsu(qs, SH_SLOT, ipos, pv.slot); qsf(qs, SH_LAMBDA, ipos, pv.lambda); qsu(qs, SH_FLAGS, ipos, out.env_mask);
+                    if (!out.has_item) for (uint32_t l = 0; l < rp.light_samples; ++l) qsf(qs, SH_HEAD + l * SR_FIELDS + SR_FACTOR, ipos, 0.0f);
+                }
                 if (out.add_energy) energy[pv.slot] += out.energy_add;
                 if (out.survives) store_path(qout, next++, out.next);
-                if (out.has_item) {
-                    uint32_t ipos = items++;
-                    qsu(qs, SH_SLOT, ipos, pv.slot); qsf(qs, SH_LAMBDA, ipos, pv.lambda); qsu(qs, SH_FLAGS, ipos, out.env_mask);
-                    for (uint32_t l = 0; l < rp.light_samples; ++l) {
-                        uint32_t f0 = SH_HEAD + l * SR_FIELDS;
-                        qsf(qs, f0 + SR_FACTOR, ipos, rays[l].factor);
-                        if (rays[l].factor != 0.0f) {
-                            qsf(qs, f0 + SR_OX, ipos, rays[l].o.x); qsf(qs, f0 + SR_OY, ipos, rays[l].o.y); qsf(qs, f0 + SR_OZ, ipos, rays[l].o.z);
-                            qsf(qs, f0 + SR_DX, ipos, rays[l].d.x); qsf(qs, f0 + SR_DY, ipos, rays[l].d.y); qsf(qs, f0 + SR_DZ, ipos, rays[l].d.z);
-                        }
-                    }
-                }
                 bounce_rays += out.vertex_pushed; env_hits += out.env_hit; shadow_rays += out.shadow_count;
             }
             for (uint32_t i = 0; i < items; ++i) {

@@ -100,6 +100,26 @@ def test_batching_and_lds_staging_are_invisible(engine, pkg, monkeypatch):
     assert np.array_equal(nolds, again)
 
 
+def test_filtered_slab_test_and_culling_change_nothing(engine, pkg, monkeypatch):
+    """The fast paths of the BVH walk (reciprocal-filtered slab test, culling by the closest hit) must give the films and
+    hits of the plain six-division walk bit for bit."""
+    import parity_suite
+    rd = pkg.api.render_desc(128, 96, 11, 8)
+    for scene in ("cornell_box", "cornell_gem", "mixed_primitives"):
+        b = pkg.scene.SCENES[scene]()
+        o, d = parity_suite.golden_rays(scene, 1 << 16, 77)
+        fast = engine.create_scene(b)
+        film_fast, prof_fast = fast.render(rd)
+        hits_fast = fast.intersect(o, d)
+        monkeypatch.setenv("PT_AMD_EXACT_SLAB", "1"); monkeypatch.setenv("PT_AMD_NO_CULL", "1")
+        plain = engine.create_scene(b)
+        monkeypatch.delenv("PT_AMD_EXACT_SLAB"); monkeypatch.delenv("PT_AMD_NO_CULL")
+        film_plain, prof_plain = plain.render(rd)
+        assert np.array_equal(film_fast, film_plain), scene
+        assert (prof_fast.bounce_rays, prof_fast.shadow_rays) == (prof_plain.bounce_rays, prof_plain.shadow_rays)
+        parity_suite.assert_hits_equal(hits_fast, plain.intersect(o, d))
+
+
 def test_full_size_cornell_properties(engine, oracle, pkg):
     """BASELINE.json C2 geometry (1024x1024, max_bounces 8, L = 2) at 2 spp: too big for the oracle film in seconds,
     so check size-independent properties: shards partition the film exactly, counters add up, the film is finite and
