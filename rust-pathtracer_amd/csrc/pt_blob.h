@@ -87,8 +87,10 @@
 #define PT_HDR_CURVE_OFF 19
 #define PT_HDR_CURVE_COUNT 20
 #define PT_HDR_FLAGS 21
+#define PT_HDR_LIGHT_NODE_OFF 22  /* per light: word offset of its top-level leaf node (its box gates the instance test) */
 #define PT_FLAG_EXACT_SLAB 2u    /* diagnostics (PT_AMD_EXACT_SLAB=1): always take the six-division slab test */
 #define PT_FLAG_NO_CULL 4u       /* diagnostics (PT_AMD_NO_CULL=1): never cull by the closest hit */
+#define PT_FLAG_NO_SHADOW_BOUND 8u /* a mesh instance can produce a Light-tagged hit: the light pre-pass of shadow rays is off */
 #define PT_FLAG_NO_TOP_CULL 1u   /* a Disk instance exists: its reference box (radius/2, disk.rs:24-28) does not contain it */
 
 #endif

@@ -396,7 +396,7 @@ PT_HD void instance_local_ray(const SceneView& s, uint32_t inst, F3 o, F3 d, F3*
     if (bu(s, inst + PT_INST_FLAGS) & 1u) { *lo = xf_point(s, inst + PT_INST_REVERSE, o); *ld = xf_vec(s, inst + PT_INST_REVERSE, d); }
     else { *lo = o; *ld = d; }
 }
-PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out) {
+PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_INF, bool stop_on_nonlight = false) {
     const uint32_t NONE = 0xffffffffu;
     const uint32_t flags = bu(s, PT_HDR_FLAGS);
     const uint32_t top_off = bu(s, PT_HDR_TOP_NODE_OFF), top_count = bu(s, PT_HDR_TOP_NODE_COUNT), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
@@ -409,7 +409,9 @@ PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out) {
     TriRay tr = wtr;
     uint32_t node_off = top_off, node_count = top_count, i = 0;
     uint32_t level_inst = NONE, top_resume = 0, tri_off = 0;
-    float closest = PT_INF;
+    // `bound`: the caller knows that no hit beyond it can matter (shadow rays: the nearest light hit, see
+    // stage_shadow_light); `limit` = min(closest, bound) drives the culling, `closest` keeps the reference's meaning.
+    float closest = PT_INF, limit = bound;
     uint32_t best_inst = NONE, best_tri = NONE;
     TriHit bh; bh.t = 0.0f; bh.b0 = bh.b1 = bh.b2 = 0.0f;
     bool done = false;
@@ -432,7 +434,7 @@ PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out) {
             F4 a = bf4(s, node_off + i * PT_NODE_WORDS), b = bf4(s, node_off + i * PT_NODE_WORDS + 4);
             uint32_t exit_i = pt_f2u(a.w), shape = pt_f2u(b.w);
             float entry;
-            bool box = aabb_hit(a, b, cr, &entry) && !((level_inst != NONE ? cull_mesh : cull_top) && beyond(entry, closest, cr.base));
+            bool box = aabb_hit(a, b, cr, &entry) && !((level_inst != NONE ? cull_mesh : cull_top) && beyond(entry, limit, cr.base));
             if (shape == PT_NODE_INNER) { i = box ? i + 1 : exit_i; }
             else { i = exit_i; if (box) pending = shape; }
         }
@@ -445,6 +447,12 @@ PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out) {
             TriHit th;
             if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, closest, &th)) {
                 closest = th.t; best_inst = level_inst; best_tri = pending; bh = th;
+                limit = __builtin_fminf(closest, bound);
+                if (stop_on_nonlight && closest < bound) {
+                    uint32_t im = bu(s, inst_off + level_inst * PT_INST_WORDS + PT_INST_MATERIAL);
+                    uint32_t mat = im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w);
+                    if (PT_MATERIAL_TAG(mat) != PT_TAG_LIGHT) done = true;  // something opaque in front of every light
+                }
             }
         } else {
             uint32_t inst = inst_off + pending * PT_INST_WORDS;
@@ -463,7 +471,14 @@ PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out) {
                 i = 0;
             } else {
                 Hit h;
-                if (analytic_hit(s, inst, kind, lo, ld, closest, &h)) { closest = h.t; best_inst = pending; best_tri = NONE; }
+                if (analytic_hit(s, inst, kind, lo, ld, closest, &h)) {
+                    closest = h.t; best_inst = pending; best_tri = NONE;
+                    limit = __builtin_fminf(closest, bound);
+                    if (stop_on_nonlight && closest < bound) {
+                        uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+                        if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : h.material) != PT_TAG_LIGHT) done = true;
+                    }
+                }
             }
         }
     }
@@ -503,6 +518,28 @@ PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out) {
     h.valid = true;
     *out = h;
     return true;
+}
+
+// Nearest hit among the light instances that the reference's walk would test for this ray (an instance is tested iff
+// its own leaf box passes AABB::hit; ancestor boxes contain it, and the slab test is monotone under rounding, so they
+// pass too).  Returns +inf if no light is hit.  Same arithmetic as the walk, so the distance is the one the walk finds.
+PT_HD float nearest_light_hit(const SceneView& s, F3 o, F3 d) {
+    const uint32_t n = bu(s, PT_HDR_LIGHT_COUNT), lo_ = bu(s, PT_HDR_LIGHT_OFF), ln = bu(s, PT_HDR_LIGHT_NODE_OFF), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
+    RayPrep wr = ray_prepare(o, d);
+    if (bu(s, PT_HDR_FLAGS) & PT_FLAG_EXACT_SLAB) wr.fast = false;
+    float best = PT_INF;
+    for (uint32_t k = 0; k < n; ++k) {
+        uint32_t node = bu(s, ln + k);
+        F4 a = bf4(s, node), b = bf4(s, node + 4);
+        float entry;
+        if (!aabb_hit(a, b, wr, &entry)) continue;
+        uint32_t inst = inst_off + bu(s, lo_ + k) * PT_INST_WORDS;
+        F3 l0, l1;
+        instance_local_ray(s, inst, o, d, &l0, &l1);
+        Hit h;
+        if (analytic_hit(s, inst, bu(s, inst + PT_INST_KIND), l0, l1, PT_INF, &h)) best = __builtin_fminf(best, h.t);
+    }
+    return best;
 }
 
 // ---------------------------------------------------------------- sampling helpers (math crate)

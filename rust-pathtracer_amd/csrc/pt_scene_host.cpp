@@ -35,7 +35,8 @@ struct BvhBuilder {
     const std::vector<Box>& shapes;
     std::vector<uint32_t>& out;  // PT_NODE_WORDS per node
     uint32_t base;               // first node's index (0)
-    explicit BvhBuilder(const std::vector<Box>& s, std::vector<uint32_t>& o) : shapes(s), out(o), base(0) {}
+    std::vector<uint32_t> leaf_of_shape;  // node index of each shape's leaf
+    explicit BvhBuilder(const std::vector<Box>& s, std::vector<uint32_t>& o) : shapes(s), out(o), base(0), leaf_of_shape(s.size(), 0) {}
 
     uint32_t node_count() const { return (uint32_t)(out.size() / PT_NODE_WORDS); }
 
@@ -85,6 +86,7 @@ struct BvhBuilder {
         if (!leaf) { std::vector<uint32_t> li, ri; Box lb, rb; split(idx, li, lb, ri, rb); emit(li, lb); emit(ri, rb); }
         out[at + 0] = fbits(b.mn[0]); out[at + 1] = fbits(b.mn[1]); out[at + 2] = fbits(b.mn[2]); out[at + 3] = node_count();
         out[at + 4] = fbits(b.mx[0]); out[at + 5] = fbits(b.mx[1]); out[at + 6] = fbits(b.mx[2]); out[at + 7] = leaf ? idx[0] : PT_NODE_INNER;
+        if (leaf) leaf_of_shape[idx[0]] = (uint32_t)(at / PT_NODE_WORDS);
     }
 
     void build() {
@@ -326,11 +328,15 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
     {
         std::vector<uint32_t> nodes; BvhBuilder bb(ibox, nodes); bb.build();
         w[PT_HDR_TOP_NODE_OFF] = (uint32_t)w.size(); w[PT_HDR_TOP_NODE_COUNT] = (uint32_t)(nodes.size() / PT_NODE_WORDS);
+        uint32_t top = (uint32_t)w.size();
         w.insert(w.end(), nodes.begin(), nodes.end());
+        pad16(w);
+        w[PT_HDR_LIGHT_OFF] = (uint32_t)w.size(); w[PT_HDR_LIGHT_COUNT] = (uint32_t)lights.size();
+        w.insert(w.end(), lights.begin(), lights.end());
+        pad16(w);
+        w[PT_HDR_LIGHT_NODE_OFF] = (uint32_t)w.size();
+        for (uint32_t l : lights) w.push_back(top + bb.leaf_of_shape[l] * PT_NODE_WORDS);
     }
-    pad16(w);
-    w[PT_HDR_LIGHT_OFF] = (uint32_t)w.size(); w[PT_HDR_LIGHT_COUNT] = (uint32_t)lights.size();
-    w.insert(w.end(), lights.begin(), lights.end());
     pad16(w);
 
     // environment + world radius (World::new, world/mod.rs:69-81)
@@ -348,7 +354,17 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
         radius = std::sqrt(sx * sx + sy * sy + sz * sz) / 2.0f;
     }
     w[PT_HDR_WORLD_RADIUS] = fbits(radius);
-    { uint32_t flags = 0; for (uint32_t i = 0; i < d.instance_count; ++i) if (d.instances[i].kind == PT_SHAPE_DISK) flags |= PT_FLAG_NO_TOP_CULL; w[PT_HDR_FLAGS] = flags; }
+    {
+        uint32_t flags = 0;
+        for (uint32_t i = 0; i < d.instance_count; ++i) {
+            const pt_instance& in = d.instances[i];
+            if (in.kind == PT_SHAPE_DISK) flags |= PT_FLAG_NO_TOP_CULL;
+            // a mesh whose hits can carry a Light tag is not in the light list (world/mod.rs:45-54 only looks at analytic
+            // instances' own ids and mesh face ids, and mesh face lights are rejected above) but would pass pt.rs:178
+            if (in.kind == PT_SHAPE_MESH && in.material != PT_MATERIAL_NONE && PT_MATERIAL_TAG(in.material) == PT_TAG_LIGHT) flags |= PT_FLAG_NO_SHADOW_BOUND;
+        }
+        w[PT_HDR_FLAGS] = flags;
+    }
     w[PT_HDR_MAGIC] = PT_BLOB_MAGIC; w[PT_HDR_TOTAL_WORDS] = (uint32_t)w.size();
     hs->light_count = (uint32_t)lights.size();
     hs->material_count = d.material_count;

@@ -251,9 +251,18 @@ PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t 
 
 // ------------------------------------------------------------------------------------------------ shadow
 // The light-sample ray of pt.rs:171-217: nearest hit must be *a* light; emission is evaluated at that hit.
+// Only a light that is the closest hit contributes, so the walk is bounded by the nearest light hit (nothing beyond it
+// can be the closest hit) and may stop at the first accepted non-light hit in front of it.  If no light is hit at all
+// the ray contributes nothing and is not walked.  The result is the reference's in every case.
 PT_HD float stage_shadow_light(const SceneView& s, float lambda, const ShadowRay& ray) {
     Hit sh;
-    if (!world_hit(s, ray.o, ray.d, &sh)) return 0.0f;
+    if (bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_CULL)) {
+        if (!world_hit(s, ray.o, ray.d, &sh)) return 0.0f;
+    } else {
+        float t_light = nearest_light_hit(s, ray.o, ray.d);
+        if (!(t_light < PT_INF)) return 0.0f;
+        if (!world_hit(s, ray.o, ray.d, &sh, t_light, true)) return 0.0f;
+    }
     if (PT_MATERIAL_TAG(sh.material) != PT_TAG_LIGHT) return 0.0f;
     Frame lf = frame_from_normal(sh.n);
     F3 lwi = to_local(lf, neg(ray.d));
