@@ -62,9 +62,9 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    pkg = importlib.import_module("rust-pathtracer_amd")
+    sharding = pkg.sharding
+    rank, local_rank, world = sharding.rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -73,13 +73,12 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world
 
-    pkg = importlib.import_module("rust-pathtracer_amd")
     engine = pkg.load()
     builder = pkg.scene.SCENES[args.scene]()
     scene = engine.create_scene(builder)
 
     W, H, L = args.width, args.height, args.light_samples
-    S = args.spp_per_step * n_gpus                  # weak scaling: N x the samples on 1/N of the pixels
+    S = sharding.weak_scaling_samples(args.spp_per_step, n_gpus)   # weak scaling: N x the samples on 1/N of the pixels
     total_spp = S * (args.steps + args.warmup)
     assert total_spp <= 65535 * 16
     film_step = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
@@ -88,7 +87,7 @@ def main():
 
     def step(k):
         rd = pkg.api.render_desc(W, H, total_spp, args.max_bounces, min_bounces=1, light_samples=L, seed=1,
-                                 shard=(rank, n_gpus) if n_gpus > 1 else (0, 0), first_sample=k * S, sample_count=S)
+                                 shard=sharding.shard(rank, n_gpus), first_sample=k * S, sample_count=S)
         prof = scene.render_device(rd, film_step.data_ptr(), stream)
         film_total.add_(film_step)
         return prof
@@ -104,23 +103,16 @@ def main():
     sync()
     t0 = time.perf_counter()
     profs = [step(args.warmup + k) for k in range(args.steps)]
-    if world > 1:
-        dist.reduce(film_total, dst=0, op=dist.ReduceOp.SUM)   # RCCL over xGMI: the only exchange step
+    sharding.reduce_film(film_total, dst=0)                      # RCCL over xGMI: the only exchange step
     sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, "cuda")
 
     # whole-job units: every rank rendered (pixels / N) x (S = spp_per_step x N) samples per step
     shard_pixels = sum(p.stage_items[4] for p in profs) / max(1, len(profs))
     samples_rank = sum(p.camera_rays for p in profs)
-    counts = torch.tensor([samples_rank] + [sum(p.stage_items[i] for p in profs) for i in range(5)] +
-                          [sum(p.bounce_rays for p in profs), sum(p.shadow_rays for p in profs)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    total_samples = float(counts[0].item())
+    counts = sharding.sum_over_ranks([samples_rank] + [sum(p.stage_items[i] for p in profs) for i in range(5)] +
+                                     [sum(p.bounce_rays for p in profs), sum(p.shadow_rays for p in profs)], "cuda")
+    total_samples = counts[0]
     value = total_samples / elapsed / 1e6
 
     if rank == 0:
@@ -181,9 +173,9 @@ def main():
                        "scene": args.scene, "spp_per_step_per_gpu": args.spp_per_step, "spp_per_step": S, "samples_per_step": total_samples / args.steps,
                        "parallelism": "film tiles 32x32 round-robin over %d GPU(s), one RCCL reduce of the XYZ film" % n_gpus,
                        "device": engine.device_info()},
-            "rays_per_s": {"segments": float(counts[2].item()) / elapsed, "shadow": float(counts[7].item()) / elapsed,
-                           "total_Mrays": (float(counts[2].item()) + float(counts[7].item())) / elapsed / 1e6},
-            "segments_per_sample": float(counts[2].item()) / total_samples,
+            "rays_per_s": {"segments": counts[2] / elapsed, "shadow": counts[7] / elapsed,
+                           "total_Mrays": (counts[2] + counts[7]) / elapsed / 1e6},
+            "segments_per_sample": counts[2] / total_samples,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

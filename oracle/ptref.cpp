@@ -557,6 +557,11 @@ struct Scene {
     std::vector<pt_camera> cameras;
     pt_environment env; float env_sampling_probability;
     float radius; V3 center;
+    // ImportanceMap::Baked (src/world/importance_map.rs:33-40): per row a pdf and a cumulative mass function over the
+    // columns, and the marginal over rows; all Curve::Linear{bounds (0,1), mode Nearest}.
+    uint32_t imap_rows = 0, imap_cols = 0;
+    std::vector<float> row_pdf, row_cmf, marginal_pdf, marginal_cmf;
+    M4 env_forward, env_reverse;
 };
 
 inline V3 origin_of(const pt_instance& d) { return v3(d.origin[0], d.origin[1], d.origin[2]); }
@@ -976,7 +981,37 @@ float material_emission(const Scene& s, uint32_t mat_index, float lambda, V3 wi)
 }
 
 // ============================================================== environment
-// EnvironmentMap::emission environment.rs:56-98; pdf_for :198-258; sample_env_uv :303-353.
+// EnvironmentMap::emission environment.rs:56-98; pdf_for :198-258; sample_env_uv :303-353;
+// ImportanceMap::bake_raw importance_map.rs:78-253, sample_uv :325-357.
+//
+// Curve::Linear{signal, bounds (0,1), Nearest}.evaluate(x) as restated in curve_eval: bin = floor(x n), the value of
+// the bin or of the next one when the fractional part is >= 0.5.
+inline float linear01_nearest(const float* signal, uint32_t n, float x) {
+    if (x < 0.0f || x > 1.0f) return 0.0f;
+    float step = 1.0f / (float)n;
+    float fi = x / step;
+    uint32_t index = (uint32_t)fi;
+    if (index >= n) index = n - 1;
+    float left = signal[index];
+    if (index + 1 >= n) return left;
+    float t = (x - (float)index * step) / step;
+    return t < 0.5f ? left : signal[index + 1];
+}
+// CurveWithCDF::sample_power_and_pdf for a (pdf, cmf) pair over [0,1) (math crate; restated): inverse transform on the
+// cumulative mass function — first bin whose cumulative mass reaches x, position inside the bin by linear
+// interpolation — and the "pdf" is the pdf curve evaluated at the sampled coordinate (a mass per bin, not a density:
+// that is what importance_map.rs stores, and environment.rs:236-247,341-349 multiplies it as is).
+inline void sample_cmf(const float* pdf, const float* cmf, uint32_t n, float x, float* coord, float* p) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { uint32_t mid = lo + (hi - lo) / 2; if (cmf[mid] < x) lo = mid + 1; else hi = mid; }
+    uint32_t k = lo < n ? lo : n - 1;
+    float below = k == 0 ? 0.0f : cmf[k - 1];
+    float width = cmf[k] - below;
+    float t = width > 0.0f ? (x - below) / width : 0.0f;
+    float c = ((float)k + t) / (float)n;
+    c = pt_clamp(c, 0.0f, 1.0f - PT_F32_EPSILON);
+    *coord = c; *p = linear01_nearest(pdf, n, c);
+}
 float env_emission(const Scene& s, float u, float v, float lambda) {
     const pt_environment& e = s.env;
     switch (e.kind) {
@@ -988,7 +1023,12 @@ float env_emission(const Scene& s, float u, float v, float lambda) {
             if (std::fabs(sn) < pt_sin(e.angular_diameter / 2.0f) && c > 0.0f) return curve_at(s, e.curve, lambda) * e.strength;
             return 0.0f;
         }
-        default: return 0.0f;  // HDR: not restated yet (C4)
+        default: {  // HDR, environment.rs:84-96
+            V3 direction = uv_to_direction(u, v);
+            V3 nd = mul_vec(s.env_reverse, direction);  // rotation.to_local
+            float u2, v2; direction_to_uv(nd, &u2, &v2);
+            return texstack_eval(s, e.texstack, lambda, u2, v2) * e.strength;
+        }
     }
 }
 float env_pdf_for(const Scene& s, float u, float v) {
@@ -1000,6 +1040,16 @@ float env_pdf_for(const Scene& s, float u, float v) {
         if (std::fabs(sn) < pt_sin(e.angular_diameter / 2.0f) && c > 0.0f)
             return 1.0f / (2.0f * PT_PI * (1.0f - pt_cos(e.angular_diameter)));
         return 0.0f;
+    }
+    if (e.kind == PT_ENV_HDR && s.imap_rows > 0) {  // environment.rs:221-253
+        V3 direction = uv_to_direction(u, v);
+        V3 nd = mul_vec(s.env_reverse, direction);
+        float u2, v2; direction_to_uv(nd, &u2, &v2);
+        uint32_t row = (uint32_t)(pt_clamp(u2, 0.0f, 1.0f - PT_F32_EPSILON) * (float)s.imap_rows);
+        return linear01_nearest(s.marginal_pdf.data(), s.imap_rows, u2) *
+                   linear01_nearest(s.row_pdf.data() + (size_t)row * s.imap_cols, s.imap_cols, v2) *
+                   (2.0f * PT_PI * PT_PI * pt_sin(PT_PI * v2) + 0.001f) +
+               0.001f;
     }
     return 1.0f / (4.0f * PT_PI);
 }
@@ -1014,7 +1064,52 @@ void env_sample_uv(const Scene& s, float sx, float sy, float* u, float* v, float
         *pdf = 1.0f / (2.0f * PT_PI * (1.0f - pt_cos(e.angular_diameter)));
         return;
     }
+    if (e.kind == PT_ENV_HDR && s.imap_rows > 0) {  // environment.rs:331-350 + importance_map.rs:325-357
+        float mu, row_pdf, mv, column_pdf;
+        sample_cmf(s.marginal_pdf.data(), s.marginal_cmf.data(), s.imap_rows, sy, &mu, &row_pdf);
+        uint32_t row = (uint32_t)(mu * (float)s.imap_rows);
+        sample_cmf(s.row_pdf.data() + (size_t)row * s.imap_cols, s.row_cmf.data() + (size_t)row * s.imap_cols, s.imap_cols, sx, &mv, &column_pdf);
+        V3 local_wo = uv_to_direction(mu, mv);
+        V3 new_wo = mul_vec(s.env_forward, local_wo);  // rotation.to_world
+        float u2, v2; direction_to_uv(new_wo, &u2, &v2);
+        *u = u2; *v = v2;
+        *pdf = row_pdf * column_pdf * (2.0f * PT_PI * PT_PI * pt_sin(PT_PI * v2) + 0.001f) + 0.001f;
+        return;
+    }
     *u = sx; *v = sy; *pdf = 1.0f / (4.0f * PT_PI);  // Constant (and unbaked HDR): uv = raw sample, pdf 1/4pi
+}
+// ImportanceMap::bake_raw with BOUNDED_VISIBLE_RANGE (parsing/environment.rs:126-151): texel luminance = integral of
+// luminance_curve * texel spectrum, 100 left-Riemann samples (Curve::evaluate_integral, math crate, restated).
+void bake_importance_map(Scene& s) {
+    const pt_environment& e = s.env;
+    uint32_t V = (uint32_t)e.importance_height, H = (uint32_t)e.importance_width;  // vertical_resolution rows, horizontal_resolution columns
+    s.imap_rows = V; s.imap_cols = H;
+    s.row_pdf.assign((size_t)V * H, 0.0f); s.row_cmf.assign((size_t)V * H, 0.0f);
+    s.marginal_pdf.assign(V, 0.0f); s.marginal_cmf.assign(V, 0.0f);
+    const int N = 100;
+    float lum[N], lam[N];
+    float step = (750.0f - 380.0f) / (float)N;
+    for (int i = 0; i < N; ++i) {
+        lam[i] = 380.0f + (float)i * step;
+        lum[i] = e.importance_luminance_curve >= 0 ? curve_at(s, e.importance_luminance_curve, lam[i]) : y_bar(lam[i] * 10.0f);
+    }
+    float total = 0.0f;
+    for (uint32_t row = 0; row < V; ++row) {
+        float row_luminance = 0.0f;
+        float* pdf = s.row_pdf.data() + (size_t)row * H; float* cmf = s.row_cmf.data() + (size_t)row * H;
+        for (uint32_t col = 0; col < H; ++col) {
+            float u = (float)row / (float)V, v = (float)col / (float)H;
+            float texel = 0.0f;
+            for (int i = 0; i < N; ++i) texel += lum[i] * texstack_eval(s, e.texstack, lam[i], u, v) * step;
+            row_luminance += texel;
+            pdf[col] = texel; cmf[col] = row_luminance;
+        }
+        for (uint32_t col = 0; col < H; ++col) { pdf[col] /= row_luminance; cmf[col] /= row_luminance; }
+        total += row_luminance;
+        s.marginal_pdf[row] = row_luminance;
+    }
+    float run = 0.0f;
+    for (uint32_t row = 0; row < V; ++row) { s.marginal_pdf[row] /= total; run += s.marginal_pdf[row]; s.marginal_cmf[row] = run; }
 }
 
 // =================================================================== camera
@@ -1316,7 +1411,6 @@ bool validate_render(const Scene& s, const pt_render_desc& rd) {
     if (rd.width == 0 || rd.height == 0 || rd.spp == 0) { g_error = "width, height and spp must be positive"; return false; }
     if (rd.camera_index >= s.cameras.size()) { g_error = "camera_index out of range"; return false; }
     if (rd.hero_wavelengths > 1) { g_error = "hero wavelengths: no live reference implementation to restate (SURVEY F6)"; return false; }
-    if (s.env.kind == PT_ENV_HDR) { g_error = "HDR environment not restated in the oracle yet"; return false; }
     if (rd.shard_count > 0 && rd.shard_index >= rd.shard_count) { g_error = "shard_index >= shard_count"; return false; }
     return true;
 }
@@ -1404,6 +1498,9 @@ pt_status ptref_scene_create(const pt_scene_desc* d, pt_scene** out) {
         s.center = wa.min + span / 2.0f; s.radius = norm(span) / 2.0f;
     } else { s.center = v3(0, 0, 0); s.radius = 0.0f; }
     if (s.lights.empty()) s.env_sampling_probability = 1.0f;  // world/mod.rs:78-81
+    std::memcpy(s.env_forward.m, s.env.rotation_forward, sizeof(s.env_forward.m));
+    std::memcpy(s.env_reverse.m, s.env.rotation_reverse, sizeof(s.env_reverse.m));
+    if (s.env.kind == PT_ENV_HDR && s.env.importance_width > 0 && s.env.importance_height > 0 && s.env.strength > 0.0f) bake_importance_map(s);
     *out = ps;
     return PT_OK;
 }

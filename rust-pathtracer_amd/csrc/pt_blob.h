@@ -87,7 +87,16 @@
 #define PT_HDR_CURVE_OFF 19
 #define PT_HDR_CURVE_COUNT 20
 #define PT_HDR_FLAGS 21
-#define PT_HDR_LIGHT_NODE_OFF 22  /* per light: word offset of its top-level leaf node (its box gates the instance test) */
+#define PT_HDR_LIGHT_NODE_OFF 22
+#define PT_HDR_ENV_TEXSTACK 23     /* HDR: word offset of the texstack record */
+#define PT_HDR_IMAP_ROWS 24        /* HDR importance map (0 = unbaked): rows, columns, float offsets into texture memory */
+#define PT_HDR_IMAP_COLS 25
+#define PT_HDR_IMAP_ROW_PDF 26
+#define PT_HDR_IMAP_ROW_CMF 27
+#define PT_HDR_IMAP_MARG_PDF 28
+#define PT_HDR_IMAP_MARG_CMF 29
+#define PT_HDR_ENV_FORWARD 32      /* 12 floats: rows 0..2 of the rotation */
+#define PT_HDR_ENV_REVERSE 44      /* 12 floats */  /* per light: word offset of its top-level leaf node (its box gates the instance test) */
 #define PT_FLAG_EXACT_SLAB 2u    /* diagnostics (PT_AMD_EXACT_SLAB=1): always take the six-division slab test */
 #define PT_FLAG_NO_CULL 4u       /* diagnostics (PT_AMD_NO_CULL=1): never cull by the closest hit */
 #define PT_FLAG_NO_SHADOW_BOUND 8u /* a mesh instance can produce a Light-tagged hit: the light pre-pass of shadow rays is off */

@@ -856,6 +856,30 @@ PT_HD float light_psa_pdf(const SceneView& s, uint32_t inst, float cos_o, float 
 }
 
 // ---------------------------------------------------------------- environment (src/world/environment.rs)
+// Curve::Linear{bounds (0,1), Nearest}.evaluate over a table in texture memory
+PT_HD float linear01_nearest(const float* signal, uint32_t n, float x) {
+    if (x < 0.0f || x > 1.0f) return 0.0f;
+    float step = 1.0f / (float)n;
+    float fi = x / step;
+    uint32_t index = (uint32_t)fi;
+    if (index >= n) index = n - 1;
+    float left = signal[index];
+    if (index + 1 >= n) return left;
+    float t = (x - (float)index * step) / step;
+    return t < 0.5f ? left : signal[index + 1];
+}
+// CurveWithCDF::sample_power_and_pdf on a (pdf, cmf) table pair (math crate, restated)
+PT_HD void sample_cmf(const float* pdf, const float* cmf, uint32_t n, float x, float* coord, float* p) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { uint32_t mid = lo + (hi - lo) / 2; if (cmf[mid] < x) lo = mid + 1; else hi = mid; }
+    uint32_t k = lo < n ? lo : n - 1;
+    float below = k == 0 ? 0.0f : cmf[k - 1];
+    float width = cmf[k] - below;
+    float t = width > 0.0f ? (x - below) / width : 0.0f;
+    float c = ((float)k + t) / (float)n;
+    c = pt_clamp(c, 0.0f, 1.0f - PT_F32_EPSILON);
+    *coord = c; *p = linear01_nearest(pdf, n, c);
+}
 PT_HD float env_emission(const SceneView& s, float u, float v, float lambda) {
     uint32_t kind = bu(s, PT_HDR_ENV_KIND);
     float strength = bf(s, PT_HDR_ENV_STRENGTH);
@@ -867,10 +891,14 @@ PT_HD float env_emission(const SceneView& s, float u, float v, float lambda) {
         if (pt_abs(sn) < pt_sin(bf(s, PT_HDR_ENV_ANGULAR) / 2.0f) && c > 0.0f) return curve_eval(s, bu(s, PT_HDR_ENV_CURVE), lambda) * strength;
         return 0.0f;
     }
-    return 0.0f;
+    // HDR (environment.rs:84-96): direction -> rotation.to_local -> equirect uv -> TexStack
+    F3 nd = xf_vec(s, PT_HDR_ENV_REVERSE, uv_to_direction(u, v));
+    float u2, v2; direction_to_uv(nd, &u2, &v2);
+    return texstack_eval(s, bu(s, PT_HDR_ENV_TEXSTACK), lambda, u2, v2) * strength;
 }
 PT_HD float env_pdf_for(const SceneView& s, float u, float v) {
-    if (bu(s, PT_HDR_ENV_KIND) == PT_ENV_SUN) {
+    uint32_t kind = bu(s, PT_HDR_ENV_KIND);
+    if (kind == PT_ENV_SUN) {
         F3 dir = uv_to_direction(u, v);
         F3 sd = bf3(s, PT_HDR_ENV_SUN_DIR);
         float ad = bf(s, PT_HDR_ENV_ANGULAR);
@@ -878,16 +906,41 @@ PT_HD float env_pdf_for(const SceneView& s, float u, float v) {
         if (pt_abs(sn) < pt_sin(ad / 2.0f) && c > 0.0f) return 1.0f / (2.0f * PT_PI * (1.0f - pt_cos(ad)));
         return 0.0f;
     }
+    uint32_t rows = bu(s, PT_HDR_IMAP_ROWS);
+    if (kind == PT_ENV_HDR && rows > 0) {  // environment.rs:221-253
+        uint32_t cols = bu(s, PT_HDR_IMAP_COLS);
+        F3 nd = xf_vec(s, PT_HDR_ENV_REVERSE, uv_to_direction(u, v));
+        float u2, v2; direction_to_uv(nd, &u2, &v2);
+        uint32_t row = (uint32_t)(pt_clamp(u2, 0.0f, 1.0f - PT_F32_EPSILON) * (float)rows);
+        return linear01_nearest(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), rows, u2) *
+                   linear01_nearest(s.tex + bu(s, PT_HDR_IMAP_ROW_PDF) + (size_t)row * cols, cols, v2) *
+                   (2.0f * PT_PI * PT_PI * pt_sin(PT_PI * v2) + 0.001f) +
+               0.001f;
+    }
     return 1.0f / (4.0f * PT_PI);
 }
 PT_HD void env_sample_uv(const SceneView& s, float sx, float sy, float* u, float* v, float* pdf) {
-    if (bu(s, PT_HDR_ENV_KIND) == PT_ENV_SUN) {
+    uint32_t kind = bu(s, PT_HDR_ENV_KIND);
+    if (kind == PT_ENV_SUN) {
         float ad = bf(s, PT_HDR_ENV_ANGULAR);
         F3 local_wo = add(f3(0, 0, 1), mul(random_in_unit_disk(sx, sy), pt_sin(ad / 2.0f)));
         Frame fr = frame_from_normal(bf3(s, PT_HDR_ENV_SUN_DIR));
         F3 dir = to_world(fr, local_wo);
         direction_to_uv(normalize(dir), u, v);
         *pdf = 1.0f / (2.0f * PT_PI * (1.0f - pt_cos(ad)));
+        return;
+    }
+    uint32_t rows = bu(s, PT_HDR_IMAP_ROWS);
+    if (kind == PT_ENV_HDR && rows > 0) {  // environment.rs:331-350 + importance_map.rs:325-357
+        uint32_t cols = bu(s, PT_HDR_IMAP_COLS);
+        float mu, row_pdf, mv, column_pdf;
+        sample_cmf(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), s.tex + bu(s, PT_HDR_IMAP_MARG_CMF), rows, sy, &mu, &row_pdf);
+        uint32_t row = (uint32_t)(mu * (float)rows);
+        sample_cmf(s.tex + bu(s, PT_HDR_IMAP_ROW_PDF) + (size_t)row * cols, s.tex + bu(s, PT_HDR_IMAP_ROW_CMF) + (size_t)row * cols, cols, sx, &mv, &column_pdf);
+        F3 new_wo = xf_vec(s, PT_HDR_ENV_FORWARD, uv_to_direction(mu, mv));
+        float u2, v2; direction_to_uv(new_wo, &u2, &v2);
+        *u = u2; *v = v2;
+        *pdf = row_pdf * column_pdf * (2.0f * PT_PI * PT_PI * pt_sin(PT_PI * v2) + 0.001f) + 0.001f;
         return;
     }
     *u = sx; *v = sy; *pdf = 1.0f / (4.0f * PT_PI);

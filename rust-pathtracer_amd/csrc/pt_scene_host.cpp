@@ -112,9 +112,12 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
     auto fail = [&](const char* m) { *err = m; return false; };
     if (d.material_count == 0 || !d.materials) return fail("scene needs at least the error material (index 0)");
     if (d.camera_count == 0 || !d.cameras) return fail("scene has no camera");
-    if (d.environment.kind == PT_ENV_HDR) return fail("HDR environment is not supported by this build yet");
-    if (d.environment.kind != PT_ENV_CONSTANT && d.environment.kind != PT_ENV_SUN) return fail("unknown environment kind");
-    if (d.environment.curve < 0 || (uint32_t)d.environment.curve >= d.curve_count) return fail("environment curve index out of range");
+    if (d.environment.kind != PT_ENV_CONSTANT && d.environment.kind != PT_ENV_SUN && d.environment.kind != PT_ENV_HDR) return fail("unknown environment kind");
+    if (d.environment.kind == PT_ENV_HDR) {
+        if (d.environment.texstack < 0 || (uint32_t)d.environment.texstack >= d.texstack_count) return fail("environment texstack out of range");
+        if (d.environment.importance_width < 0 || d.environment.importance_height < 0 || d.environment.importance_width > 16384 || d.environment.importance_height > 16384) return fail("bad importance map size");
+        if (d.environment.importance_luminance_curve >= (int32_t)d.curve_count) return fail("importance luminance curve out of range");
+    } else if (d.environment.curve < 0 || (uint32_t)d.environment.curve >= d.curve_count) return fail("environment curve index out of range");
     auto curve_ok = [&](int32_t c) { return c >= 0 && (uint32_t)c < d.curve_count; };
     for (uint32_t i = 0; i < d.curve_count; ++i) {
         const pt_curve& c = d.curves[i];
@@ -342,7 +345,51 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
     // environment + world radius (World::new, world/mod.rs:69-81)
     w[PT_HDR_ENV_KIND] = (uint32_t)d.environment.kind;
     w[PT_HDR_ENV_STRENGTH] = fbits(d.environment.strength);
-    w[PT_HDR_ENV_CURVE] = curve_off[d.environment.curve];
+    w[PT_HDR_ENV_CURVE] = d.environment.kind == PT_ENV_HDR ? 0u : curve_off[d.environment.curve];
+    if (d.environment.kind == PT_ENV_HDR) {
+        const pt_environment& e = d.environment;
+        w[PT_HDR_ENV_TEXSTACK] = ts_off[e.texstack];
+        for (int k = 0; k < 12; ++k) { w[PT_HDR_ENV_FORWARD + k] = fbits(e.rotation_forward[k]); w[PT_HDR_ENV_REVERSE + k] = fbits(e.rotation_reverse[k]); }
+        if (e.importance_width > 0 && e.importance_height > 0 && e.strength > 0.0f) {
+            // ImportanceMap::bake_raw (src/world/importance_map.rs:78-253) over BOUNDED_VISIBLE_RANGE (parsing/environment.rs:140):
+            // texel luminance = sum of 100 left-Riemann samples of luminance(lambda) * texel spectrum(lambda); per-row pdf and
+            // cumulative mass over the columns, marginal over the rows.  Tables go to texture memory (HBM).
+            const uint32_t V = (uint32_t)e.importance_height, H = (uint32_t)e.importance_width;
+            const int N = 100;
+            float lum[N], lam[N];
+            const float step = (750.0f - 380.0f) / (float)N;
+            ptd::SceneView view{w.data(), hs->tex.data()};
+            for (int i = 0; i < N; ++i) {
+                lam[i] = 380.0f + (float)i * step;
+                if (e.importance_luminance_curve >= 0) lum[i] = ptd::curve_eval(view, curve_off[e.importance_luminance_curve], lam[i]);
+                else { float xb, yb, zb; ptd::xyz_bar(lam[i] * 10.0f, &xb, &yb, &zb); lum[i] = yb; }
+            }
+            std::vector<float> row_pdf((size_t)V * H), row_cmf((size_t)V * H), mpdf(V), mcmf(V);
+            float total = 0.0f;
+            for (uint32_t row = 0; row < V; ++row) {
+                float row_luminance = 0.0f;
+                float* pdf = row_pdf.data() + (size_t)row * H; float* cmf = row_cmf.data() + (size_t)row * H;
+                for (uint32_t col = 0; col < H; ++col) {
+                    float u = (float)row / (float)V, v = (float)col / (float)H;
+                    float texel = 0.0f;
+                    for (int i = 0; i < N; ++i) texel += lum[i] * ptd::texstack_eval(view, ts_off[e.texstack], lam[i], u, v) * step;
+                    row_luminance += texel;
+                    pdf[col] = texel; cmf[col] = row_luminance;
+                }
+                for (uint32_t col = 0; col < H; ++col) { pdf[col] /= row_luminance; cmf[col] /= row_luminance; }
+                total += row_luminance;
+                mpdf[row] = row_luminance;
+            }
+            float run = 0.0f;
+            for (uint32_t row = 0; row < V; ++row) { mpdf[row] /= total; run += mpdf[row]; mcmf[row] = run; }
+            if (hs->tex.size() + 2 * row_pdf.size() + 2 * (size_t)V > 0xffffffffull) return fail("importance map too large");
+            w[PT_HDR_IMAP_ROWS] = V; w[PT_HDR_IMAP_COLS] = H;
+            w[PT_HDR_IMAP_ROW_PDF] = (uint32_t)hs->tex.size(); hs->tex.insert(hs->tex.end(), row_pdf.begin(), row_pdf.end());
+            w[PT_HDR_IMAP_ROW_CMF] = (uint32_t)hs->tex.size(); hs->tex.insert(hs->tex.end(), row_cmf.begin(), row_cmf.end());
+            w[PT_HDR_IMAP_MARG_PDF] = (uint32_t)hs->tex.size(); hs->tex.insert(hs->tex.end(), mpdf.begin(), mpdf.end());
+            w[PT_HDR_IMAP_MARG_CMF] = (uint32_t)hs->tex.size(); hs->tex.insert(hs->tex.end(), mcmf.begin(), mcmf.end());
+        }
+    }
     w[PT_HDR_ENV_ANGULAR] = fbits(d.environment.angular_diameter);
     for (int k = 0; k < 3; ++k) w[PT_HDR_ENV_SUN_DIR + k] = fbits(d.environment.sun_direction[k]);
     float env_p = lights.empty() ? 1.0f : d.env_sampling_probability;

@@ -253,6 +253,19 @@ class SceneBuilder:
         d = np.asarray(sun_direction, np.float64); d = d / np.linalg.norm(d)
         self.environment.sun_direction = (C.c_float * 3)(*d.tolist())
 
+    def set_environment_hdr(self, texstack, strength, rotate=None, importance=(0, 0), luminance_curve=-1):
+        """EnvironmentData::HDRI (src/parsing/environment.rs:93-180): texture stack, rotation list [(axis, degrees)],
+        importance map (width, height)."""
+        self.environment.kind = api.ENV_HDR
+        self.environment.curve = -1
+        self.environment.texstack = texstack
+        self.environment.strength = strength
+        fwd = transform_from_data(rotate=rotate) if rotate else np.eye(4)
+        self.environment.rotation_forward = (C.c_float * 16)(*fwd.astype(np.float32).reshape(-1).tolist())
+        self.environment.rotation_reverse = (C.c_float * 16)(*np.linalg.inv(fwd).astype(np.float32).reshape(-1).tolist())
+        self.environment.importance_width, self.environment.importance_height = importance
+        self.environment.importance_luminance_curve = luminance_curve
+
     # ---- flatten
     def desc(self):
         keep = {}
@@ -494,5 +507,55 @@ def mixed_primitives():
     return b
 
 
-SCENES = {"cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
+def synthetic_hdri(width=1024, height=512):
+    """Deterministic stand-in for the absent data/hdri/*.hdr: a sky gradient, a warm ground and one
+    Gaussian "sun", linear RGB + alpha 0, float32, generated from a closed formula (no RNG).  Texel (x, y) is looked up
+    with uv = (x / width, y / height); u is the azimuth, v the polar angle from +Z (math::uv_to_direction)."""
+    u = (np.arange(width, dtype=np.float64) + 0.5) / width
+    v = (np.arange(height, dtype=np.float64) + 0.5) / height
+    uu, vv = np.meshgrid(u, v)
+    up = np.cos(np.pi * vv)                                  # +1 zenith, -1 nadir
+    sky = np.clip(up, 0, 1)[..., None] * np.array([0.25, 0.45, 1.0]) + (1 - np.clip(up, 0, 1))[..., None] * np.array([0.9, 0.85, 0.8])
+    ground = np.array([0.22, 0.18, 0.12]) * (0.4 + 0.6 * np.clip(-up, 0, 1))[..., None]
+    rgb = np.where((up > 0)[..., None], 0.6 * sky, ground)
+    su, sv = 0.65, 0.27                                      # sun position
+    d2 = (np.minimum(np.abs(uu - su), 1 - np.abs(uu - su)) * 2 * np.sin(np.pi * vv)) ** 2 + (vv - sv) ** 2
+    sun = 60.0 * np.exp(-d2 / (2 * 0.012 ** 2))
+    rgb = rgb + sun[..., None] * np.array([1.0, 0.92, 0.8])
+    out = np.zeros((height, width, 4), np.float32)
+    out[..., :3] = rgb
+    return out
+
+
+def hdri_test(mesh="monkey", hdri_size=(1024, 512), importance=(1024, 1024), env_sampling_probability=0.9):
+    """data/scenes/hdri_test.toml (C4): unit lambertian sphere + one mesh from data/meshes, synthetic HDRI environment with a
+    baked importance map."""
+    b = SceneBuilder()
+    add_library_curves(b, ["srgb_r", "srgb_g", "srgb_b", "flat_zero"])
+    tex = synthetic_hdri(*hdri_size)
+    ts = b.texstack_texture4("synthetic_hdri", [b.curve("srgb_r"), b.curve("srgb_g"), b.curve("srgb_b"), b.curve("flat_zero")], tex)
+    b.set_environment_hdr(ts, 1.0, importance=importance)
+    b.env_sampling_probability = env_sampling_probability
+    white = add_library_material(b, "lambertian_white")
+    b.add_sphere(1.0, (0.0, 0.0, 0.0), white)
+    if mesh:
+        gold = add_library_material(b, "ggx_gold")
+        p, f, n, mtl = _npz_mesh(mesh)
+        m = b.add_mesh(p, f, n, face_materials=api.material_id(api.TAG_MATERIAL, 0))
+        b.add_mesh_instance(m, gold, transform_from_data(scale=(0.6, 0.6, 0.6), rotate=[((0, 0, 1), -60.0)], translate=(-0.6, 1.6, -0.2)))
+    b.add_camera((-5.0, 0.3, 0.4), (0.0, 0.4, -0.3), 24.0, focal_distance=5.0, aperture_diameter=0.001)
+    return b
+
+
+def hdri_small():
+    """C4 at test size: gem mesh, 64x32 HDRI, 32x32 importance map."""
+    return hdri_test(mesh="gem", hdri_size=(64, 32), importance=(32, 32))
+
+
+def hdri_c4_small():
+    """The C4 scene (monkey mesh, 4188 triangles) with a small HDRI / importance map, for parity tests."""
+    return hdri_test(mesh="monkey", hdri_size=(128, 64), importance=(64, 64))
+
+
+SCENES = {"hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
           "mixed_primitives": mixed_primitives}

@@ -25,7 +25,7 @@ def emu(pkg):
     return pkg.api.Library(lib, "ptemu_", optional=("render_device", "device_info"))
 
 
-@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives", "white_furnace"])
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives", "white_furnace", "hdri_small"])
 def test_closest_hits_bit_exact(emu, oracle, scene):
     ps.intersect_parity(emu, oracle, scene)
 
@@ -44,6 +44,7 @@ def test_materials_bit_exact(emu, oracle, scene):
     ("cornell_gem", 40, 24, 6, 12, {}),                       # C3 shape: dispersive GGX + transformed mesh
     ("mixed_primitives", 32, 32, 8, 6, {"light_samples": 3, "seed": 5}),
     ("white_furnace", 16, 16, 12, 8, {"light_samples": 6}),
+    ("hdri_small", 32, 32, 8, 4, {"light_samples": 6}),       # C4 shape: HDR environment, importance map, env NEE + MIS
 ])
 def test_film_parity(emu, oracle, scene, w, h, spp, mb, kw):
     ps.render_parity(emu, oracle, scene, w, h, spp, mb, **kw)

@@ -19,10 +19,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def golden_rays(scene_name, n, seed):
     """Deterministic ray set aimed at the scene (shared by the generator and the tests)."""
     rng = np.random.default_rng(seed)
-    if scene_name == "cornell_box":
+    if scene_name.startswith("hdri"):
+        o = np.tile(np.array([[-5.0, 0.3, 0.4]], np.float32), (n, 1)) + rng.normal(0, 0.05, (n, 3)).astype(np.float32)
+        t = rng.normal(0, 1.0, (n, 3)) + np.array([0.0, 0.6, -0.1])
+    elif scene_name == "cornell_box":
         o = np.tile(np.array([[-0.8, 0.278, 0.273]], np.float32), (n, 1)) + rng.normal(0, 0.01, (n, 3)).astype(np.float32)
         t = np.stack([rng.uniform(0.0, 0.56, n), rng.uniform(-0.05, 0.6, n), rng.uniform(-0.05, 0.6, n)], axis=1)
-    else:
+    elif not scene_name.startswith("hdri"):
         o = np.tile(np.array([[-5.0, 0.3, 0.8]], np.float32), (n, 1)) + rng.normal(0, 0.05, (n, 3)).astype(np.float32)
         t = rng.normal(0, 1.2, (n, 3))
     d = t - o
@@ -53,6 +56,7 @@ GOLDEN_RENDERS = {
     "gem_48x32_6spp": ("cornell_gem", 48, 32, 6, 12, 2, 1),
     "mixed_40x40_12spp": ("mixed_primitives", 40, 40, 12, 6, 3, 7),
     "furnace_24x24_16spp": ("white_furnace", 24, 24, 16, 8, 6, 3),
+    "hdri_32x32_8spp": ("hdri_small", 32, 32, 8, 4, 6, 2),
 }
 
 
