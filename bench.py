@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=30, help="samples per pixel per step and per GPU")
+    ap.add_argument("--spp-per-step", type=int, default=60, help="samples per pixel per step and per GPU")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--max-bounces", type=int, default=8)
@@ -133,8 +133,22 @@ def main():
         cam = sum(p.camera_rays for p in profs)
         segs = kitems[1]
         d_bar = segs / cam if cam else 0.0
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this same command
+        # (profiles/<tag>_summary.json, tools/profile_gpu.sh): (2 x FETCH_SIZE + WRITE_SIZE) KiB — FETCH_SIZE reads 1/2 of a
+        # coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact (calibrated on k_generate's 68 B/item).
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), key=os.path.getmtime)
+            if cands and args.scene == "cornell_box" and (W, H, args.spp_per_step, n_gpus) == (1024, 1024, 60, 1):
+                summ = json.load(open(cands[-1]))
+                kname = "k_" + STAGES[dom]
+                traffic = (2.0 * summ["FETCH_SIZE"][kname]["avg_per_launch"] + summ["WRITE_SIZE"][kname]["avg_per_launch"]) * 1024.0
+                traffic_src = os.path.basename(cands[-1])
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": "k_" + STAGES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_us": 1e6 * ksec[dom] / klaunch[dom], "algorithmic_bytes_per_launch": kbytes[dom] / klaunch[dom],
                     "device_time_share": ksec[dom] / sum(ksec) if sum(ksec) > 0 else None,
                     "whole_pipeline": {"bytes_per_sample": sum(kbytes) / cam if cam else None, "segments_per_sample": d_bar,
@@ -149,7 +163,7 @@ def main():
             oracle = oracle_loader.load(pkg)
             oscene = oracle.create_scene(builder)
             cores = os.cpu_count() or 1
-            probe = pkg.api.render_desc(W, H, 1, args.max_bounces, min_bounces=1, light_samples=L, seed=1, shard=(0, 256))
+            probe = pkg.api.render_desc(W, H, 1, args.max_bounces, min_bounces=1, light_samples=L, seed=1, shard=(0, 4))
             t = time.perf_counter(); _, pp = oscene.render(probe); dt = time.perf_counter() - t
             rate = pp.camera_rays / dt
             budget = rate * args.cpu_seconds
