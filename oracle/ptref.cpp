@@ -1359,6 +1359,153 @@ void color(const RenderCtx& ctx, const Sampler& smp, float cam_u, float cam_v, p
     *lambda_out = lambda; *energy_out = energy;
 }
 
+
+// ============================================================ hero wavelengths
+// BASELINE config C5.  The reference parses `hwss` and drops it (src/parsing/config.rs:51,95) and its only 4-wavelength
+// code is the commented-out sketch `random_walk_hero` (src/integrator/utils.rs:377-602); MaterialEnum is instantiated for
+// (f32, f32) only (src/materials/mod.rs:275-294).  There is nothing live to restate, so the variant is DEFINED here as the
+// live single-wavelength algorithm above carrying three passenger wavelengths, following the sketch where it is explicit:
+//   * lambda_k = lo + frac(u + k/4) * span, k = 0..3; lambda_0 (the hero) is the wavelength the single-wavelength render
+//     of the same seed would use;
+//   * every decision — BSDF sample, roulette probability min(1, f_0/pdf_0), light choice, MIS weights, termination — is
+//     taken with the hero's values (sketch: utils.rs:478-492), so the path geometry equals the single-wavelength path;
+//   * passengers carry their own throughput: beta_k *= f_k / pdf_forward_hero (sketch utils.rs:493: multi_f * cos /
+//     (rr * hero_pdf)), their own emission / light-sample products, and are NOT spectrally MIS-weighted (the sketch has no
+//     such weight): unbiased for non-dispersive scenes such as the Cornell box;
+//   * the sample's colour is the mean of the four XYZ contributions.
+const int NL = 4;
+struct HeroVertex { SurfaceVertex v; float throughput[NL]; };
+
+void material_f4(const Scene& s, uint32_t mat_index, const float* lambda, float u, float v, V3 wi, V3 wo, float* f) {
+    for (int k = 0; k < NL; ++k) { float pdf; material_bsdf(s, mat_index, lambda[k], u, v, wi, wo, &f[k], &pdf); }
+}
+
+void color_hero(const RenderCtx& ctx, const Sampler& smp, float cam_u, float cam_v, pt_profile& profile, float* lambda_out, float* energy_out) {
+    const Scene& s = *ctx.scene;
+    profile.camera_rays += 1;
+    pt_f32x4 film = smp.film();
+    float span = ctx.rd.wavelength_hi - ctx.rd.wavelength_lo;
+    float lambda[NL], energy[NL] = {0, 0, 0, 0};
+    for (int k = 0; k < NL; ++k) {
+        float x = film.z + (float)k * 0.25f;
+        x = x - pt_floor(x);
+        lambda[k] = ctx.rd.wavelength_lo + x * span;
+    }
+    float fu = pt_clamp(cam_u, 0.0f, 1.0f - PT_F32_EPSILON), fv = pt_clamp(cam_v, 0.0f, 1.0f - PT_F32_EPSILON);
+    Ray ray = camera_get_ray(ctx.camera, smp, fu, fv);
+    uint32_t max_bounces = ctx.rd.only_direct ? 1u : ctx.rd.max_bounces;
+    // camera vertex
+    V3 prev_point = ray.origin, prev_normal = ray.direction; float prev_pdf_forward = 100.0f; bool prev_is_camera = true;
+    float beta[NL] = {1, 1, 1, 1};
+    size_t vertices = 1;
+    for (uint32_t bounce = 0; bounce < max_bounces; ++bounce) {
+        HitRecord hit;
+        if (!world_hit(s, ray, 0.0f, ray.tmax, &hit)) {
+            V3 wo = ray.direction;
+            float u = 0.0f, v = 0.0f;
+            if (s.env.kind != PT_ENV_CONSTANT) direction_to_uv(wo, &u, &v);
+            float cos_i = std::fabs(dot(prev_normal, wo));
+            float nee_psa_pdf = env_pdf_for(s, u, v) / std::fabs(cos_i);
+            float bsdf_psa_pdf = prev_pdf_forward / std::fabs(cos_i);
+            float weight = power_heuristic(bsdf_psa_pdf, nee_psa_pdf);
+            profile.env_hits += 1;
+            for (int k = 0; k < NL; ++k) energy[k] += weight * beta[k] * env_emission(s, u, v, lambda[k]);
+            vertices += 1;
+            break;
+        }
+        Frame frame = frame_from_normal(hit.normal);
+        V3 wi = normalized(to_local(frame, -ray.direction));
+        uint32_t m = PT_MATERIAL_INDEX(hit.material);
+        bool is_light = PT_MATERIAL_TAG(hit.material) == PT_TAG_LIGHT;
+        pt_f32x4 r = smp.bounce(bounce);
+        float f0, pdf; V3 wo;
+        material_generate_and_evaluate(s, m, lambda[0], hit.u, hit.v, r.x, r.y, wi, &f0, &wo, &pdf);
+        float cos_o = std::fabs(wo.z);
+        if (pt_isnan(pdf)) break;
+        float rr = (bounce >= ctx.rd.min_bounces) ? pt_min(f0 / pdf, 1.0f) : 1.0f;
+        float pdf_forward = pdf * (rr / cos_o);
+        vertices += 1;
+        if (is_light) {
+            float e0 = material_emission(s, m, lambda[0], wi);
+            if (e0 > 0.0f) {
+                float weight = -1.0f;
+                if (ctx.rd.light_samples == 0 || prev_is_camera) weight = 1.0f;
+                else if (!ctx.rd.only_direct) {
+                    V3 nee_direction = normalized(hit.point - prev_point);
+                    float hp = instance_psa_pdf(s.instances[hit.instance_id], dot(prev_normal, nee_direction), dot(hit.normal, nee_direction), prev_point, hit.point);
+                    weight = power_heuristic(prev_pdf_forward, hp);
+                }
+                if (weight >= 0.0f || weight != weight)
+                    for (int k = 0; k < NL; ++k) {
+                        float ek = k == 0 ? e0 : material_emission(s, m, lambda[k], wi);
+                        energy[k] += (ctx.rd.light_samples == 0 || prev_is_camera) ? beta[k] * ek : weight * beta[k] * ek;
+                    }
+            }
+        } else if (ctx.rd.light_samples > 0) {
+            float env_p = get_env_sampling_probability(s);
+            if (!(s.lights.empty() && env_p == 0.0f)) {
+                HitRecord h2 = hit; h2.normal = normalized(hit.normal);
+                Frame fr2 = frame_from_normal(h2.normal);
+                V3 wi2 = to_local(fr2, normalized(prev_point - hit.point));
+                float lc[NL] = {0, 0, 0, 0};
+                for (uint32_t l = 0; l < ctx.rd.light_samples; ++l) {
+                    pt_f32x4 q = smp.nee(bounce, l);
+                    float x = q.x;
+                    bool sample_world = choose(x, env_p, true, false);
+                    if (sample_world) {
+                        float eu, ev, light_pdf;
+                        env_sample_uv(s, q.y, q.z, &eu, &ev, &light_pdf);
+                        V3 direction = uv_to_direction(eu, ev);
+                        V3 local_wo = to_local(fr2, direction);
+                        if (local_wo.z <= 0.0f) continue;
+                        float refl0, spdf; material_bsdf(s, m, lambda[0], hit.u, hit.v, wi2, local_wo, &refl0, &spdf);
+                        profile.shadow_rays += 1;
+                        HitRecord sh;
+                        Ray sr = ray_new(h2.point + h2.normal * 0.001f * pt_signum(direction.z), direction);
+                        if (world_hit(s, sr, 0.0f, PT_INF, &sh)) continue;
+                        float weight = ctx.rd.only_direct ? 1.0f : power_heuristic_generic(light_pdf, spdf);
+                        float refl[NL]; material_f4(s, m, lambda, hit.u, hit.v, wi2, local_wo, refl);
+                        for (int k = 0; k < NL; ++k)
+                            lc[k] += beta[k] * weight * refl[k] * env_emission(s, eu, ev, lambda[k]) * std::fabs(local_wo.z) * (1.0f / light_pdf);
+                    } else {
+                        uint32_t light_id; float pick_pdf;
+                        if (!pick_random_light(s, x, &light_id, &pick_pdf)) continue;
+                        V3 ldir; float light_pdf;
+                        instance_sample(s.instances[light_id], q.y, q.z, hit.point, &ldir, &light_pdf);
+                        light_pdf = light_pdf * pick_pdf;
+                        if (light_pdf == 0.0f) continue;
+                        V3 bsdf_wo = to_local(fr2, ldir);
+                        float refl0, bpdf; material_bsdf(s, m, lambda[0], hit.u, hit.v, wi2, bsdf_wo, &refl0, &bpdf);
+                        float weight = ctx.rd.only_direct ? 1.0f : power_heuristic_generic(light_pdf, bpdf);
+                        profile.shadow_rays += 1;
+                        HitRecord sh;
+                        Ray sr = ray_new(h2.point + h2.normal * 0.001f * pt_signum(bsdf_wo.z), ldir);
+                        if (!world_hit(s, sr, 0.0f, PT_INF, &sh)) continue;
+                        if (PT_MATERIAL_TAG(sh.material) != PT_TAG_LIGHT) continue;
+                        Frame lf = frame_from_normal(sh.normal);
+                        V3 lwi = to_local(lf, -ldir);
+                        float cos_i = std::fabs(lwi.z), cos_o2 = std::fabs(bsdf_wo.z);
+                        float refl[NL]; material_f4(s, m, lambda, hit.u, hit.v, wi2, bsdf_wo, refl);
+                        for (int k = 0; k < NL; ++k)
+                            lc[k] += refl[k] * beta[k] * cos_i * cos_o2 * material_emission(s, PT_MATERIAL_INDEX(sh.material), lambda[k], lwi) * weight / light_pdf;
+                    }
+                }
+                for (int k = 0; k < NL; ++k) energy[k] += lc[k] / (float)ctx.rd.light_samples;
+            }
+        }
+        // continue the walk: passengers use the hero's pdf
+        float fk[NL]; fk[0] = f0;
+        for (int k = 1; k < NL; ++k) { float pk; material_bsdf(s, m, lambda[k], hit.u, hit.v, wi, wo, &fk[k], &pk); }
+        for (int k = 0; k < NL; ++k) { beta[k] *= fk[k] / pdf_forward; if (pdf_forward == 0.0f) beta[k] = 0.0f; }
+        if (beta[0] == 0.0f) break;
+        if (r.z > rr) break;
+        ray = ray_new(hit.point + hit.normal * 0.001f * pt_signum(wo.z), normalized(to_world(frame, wo)));
+        prev_point = hit.point; prev_normal = hit.normal; prev_pdf_forward = pdf_forward; prev_is_camera = false;
+    }
+    profile.bounce_rays += vertices;
+    for (int k = 0; k < NL; ++k) { lambda_out[k] = lambda[k]; energy_out[k] = energy[k]; }
+}
+
 // ================================================================= renderer
 struct TileRect { uint32_t x0, x1, y0, y1; };
 // TiledRenderer::generate_tiles, src/renderer/tiled.rs:190-277
@@ -1392,10 +1539,17 @@ void render_tile(const RenderCtx& ctx, const TileRect& tile, float* film, pt_pro
                 Sampler smp{rd.seed, y * rd.width + x, sidx, rd.light_samples};
                 pt_f32x4 fs = smp.film();
                 float cu = ((float)x + fs.x) / (float)rd.width, cv = ((float)y + fs.y) / (float)rd.height;
+                if (rd.hero_wavelengths == 4) {
+                    float lam4[NL], e4[NL], c[3] = {0, 0, 0};
+                    color_hero(ctx, smp, cu, cv, profile, lam4, e4);
+                    for (int k = 0; k < NL; ++k) { float ang = lam4[k] * 10.0f; c[0] += e4[k] * x_bar(ang); c[1] += e4[k] * y_bar(ang); c[2] += e4[k] * z_bar(ang); }
+                    temp[0] += c[0] / 4.0f; temp[1] += c[1] / 4.0f; temp[2] += c[2] / 4.0f;
+                } else {
                 float lambda, energy;
                 color(ctx, smp, cu, cv, profile, &lambda, &energy);
                 float ang = lambda * 10.0f;  // XYZColor::from(SingleWavelength), math crate
                 temp[0] += energy * x_bar(ang); temp[1] += energy * y_bar(ang); temp[2] += energy * z_bar(ang);
+                }
                 // phases of 10 samples: temp_color summed per phase, then added to the pixel (tiled.rs:347-391)
                 if ((sidx + 1) % 10 == 0 || sidx + 1 == rd.spp || sidx + 1 == first + count) {
                     px[0] += temp[0]; px[1] += temp[1]; px[2] += temp[2];
@@ -1410,7 +1564,7 @@ void render_tile(const RenderCtx& ctx, const TileRect& tile, float* film, pt_pro
 bool validate_render(const Scene& s, const pt_render_desc& rd) {
     if (rd.width == 0 || rd.height == 0 || rd.spp == 0) { g_error = "width, height and spp must be positive"; return false; }
     if (rd.camera_index >= s.cameras.size()) { g_error = "camera_index out of range"; return false; }
-    if (rd.hero_wavelengths > 1) { g_error = "hero wavelengths: no live reference implementation to restate (SURVEY F6)"; return false; }
+    if (rd.hero_wavelengths != 1 && rd.hero_wavelengths != 4) { g_error = "hero_wavelengths must be 1 or 4"; return false; }
     if (rd.shard_count > 0 && rd.shard_index >= rd.shard_count) { g_error = "shard_index >= shard_count"; return false; }
     return true;
 }

@@ -104,6 +104,7 @@ __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
 // Per-workgroup statistics (Profile counters), owned by the workgroup: plain read-modify-write, summed on the host.
 enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_FIELDS };
 
+template <int NL>
 __global__ void __launch_bounds__(kBlock) k_generate(RenderParams rp, const uint32_t* __restrict__ pixels, Queue paths, float* __restrict__ energy,
                                                     uint32_t n, uint32_t seg_cap, uint32_t* __restrict__ count_out) {
     uint32_t base = blockIdx.x * seg_cap;
@@ -111,9 +112,9 @@ __global__ void __launch_bounds__(kBlock) k_generate(RenderParams rp, const uint
     for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x) {
         uint32_t slot = base + j;
         uint32_t pixel = pixels[slot % rp.chunk_pixels];
-        PathVertex p = stage_generate(rp, slot, pixel);
-        store_path(paths, slot, p);
-        energy[slot] = 0.0f;
+        PathVertexT<NL> p = stage_generate<NL>(rp, slot, pixel);
+        store_path<NL>(paths, slot, p);
+        for (int k = 0; k < NL; ++k) energy[(size_t)k * rp.energy_stride + slot] = 0.0f;
     }
     if (threadIdx.x == 0) count_out[blockIdx.x] = cnt;
 }
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(kBlock) k_extend(const uint32_t* __restrict__ 
     }
 }
 
-template <bool USE_LDS>
+template <bool USE_LDS, int NL>
 __global__ void __launch_bounds__(kBlock) k_shade(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                  RenderParams rp, uint32_t bounce, const uint32_t* __restrict__ pixels,
                                                  Queue paths_in, Queue hits, Queue paths_out, Queue shadow, float* __restrict__ energy,
@@ -151,37 +152,31 @@ __global__ void __launch_bounds__(kBlock) k_shade(const uint32_t* __restrict__ b
         uint32_t j = r * blockDim.x + threadIdx.x;
         bool active = j < n;
         uint32_t i = base + j;
-        PathVertex pv; Hit hit; hit.valid = false;
+        PathVertexT<NL> pv; Hit hit; hit.valid = false;
         bool wants_item = false;
         if (active) {
-            pv = load_path(paths_in, i);
+            pv = load_path<NL>(paths_in, i);
             hit = load_hit(hits, i);
             wants_item = shade_wants_item(s, rp, hit);
         }
         // reserve the light-sample item first, so its rays stream straight from registers to the queue
         uint32_t ipos = base + block_append(wants_item, ap_item, lds_counts, r);
-        ShadeOut out;
+        ShadeOutT<NL> out;
         out.survives = false; out.has_item = false; out.vertex_pushed = false; out.env_hit = false; out.shadow_count = 0; out.add_energy = false; out.env_mask = 0;
         if (active) {
             uint32_t pixel = pixels[pv.slot % rp.chunk_pixels];
-            const uint32_t L = rp.light_samples;
-            out = stage_shade(s, rp, bounce, pv, hit, pixel, [&](uint32_t l, const ShadowRay& ray) {
-                uint32_t f0 = SH_HEAD + l * SR_FIELDS;
-                qsf(shadow, f0 + SR_FACTOR, ipos, ray.factor);
-                if (ray.factor != 0.0f) {
-                    qsf(shadow, f0 + SR_OX, ipos, ray.o.x); qsf(shadow, f0 + SR_OY, ipos, ray.o.y); qsf(shadow, f0 + SR_OZ, ipos, ray.o.z);
-                    qsf(shadow, f0 + SR_DX, ipos, ray.d.x); qsf(shadow, f0 + SR_DY, ipos, ray.d.y); qsf(shadow, f0 + SR_DZ, ipos, ray.d.z);
-                }
-            });
+            out = stage_shade<NL>(s, rp, bounce, pv, hit, pixel, [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(shadow, ipos, l, ray); });
             if (wants_item) {
-                qsu(shadow, SH_SLOT, ipos, pv.slot); qsf(shadow, SH_LAMBDA, ipos, pv.lambda); qsu(shadow, SH_FLAGS, ipos, out.env_mask);
-                if (!out.has_item)  // vertex dropped (NaN pdf, utils.rs:261-263): the reserved item traces nothing
-                    for (uint32_t l = 0; l < L; ++l) qsf(shadow, SH_HEAD + l * SR_FIELDS + SR_FACTOR, ipos, 0.0f);
+                float lam[NL]; lam[0] = pv.lambda;
+                if (NL > 1) hero_lambdas<NL>(rp, pt_draw4(rp.seed, pixel, rp.first_sample + pv.slot / rp.chunk_pixels, PT_DIM_FILM).z, lam);
+                qsu(shadow, Layout<NL>::sh_slot, ipos, pv.slot); qsu(shadow, Layout<NL>::sh_flags, ipos, out.env_mask);
+                for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_lambda + k, ipos, lam[k]);
+                if (!out.has_item) clear_shadow_item<NL>(shadow, ipos, rp.light_samples);  // vertex dropped (NaN pdf, utils.rs:261-263)
             }
-            if (out.add_energy) energy[pv.slot] += out.energy_add;
+            if (out.add_energy) for (int k = 0; k < NL; ++k) energy[(size_t)k * rp.energy_stride + pv.slot] += out.energy_add[k];
         }
         uint32_t pos = base + block_append(out.survives, ap_path, lds_counts + 8, r);
-        if (out.survives) store_path(paths_out, pos, out.next);
+        if (out.survives) store_path<NL>(paths_out, pos, out.next);
         st_vertices += out.vertex_pushed ? 1u : 0u; st_env += out.env_hit ? 1u : 0u; st_shadow += out.shadow_count;
     }
     if (threadIdx.x == 0) { count_out[blockIdx.x] = ap_path.running; shadow_count[blockIdx.x] = ap_item.running; }
@@ -200,31 +195,19 @@ __global__ void __launch_bounds__(kBlock) k_shade(const uint32_t* __restrict__ b
     }
 }
 
-template <bool USE_LDS>
+template <bool USE_LDS, int NL>
 __global__ void __launch_bounds__(kBlock) k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
-                                                  uint32_t light_samples, Queue shadow, float* __restrict__ energy,
+                                                  uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                   uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
     extern __shared__ __align__(16) uint32_t lds[];
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
     uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
     for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
-        uint32_t i = base + j;
-        uint32_t slot = qu(shadow, SH_SLOT, i), flags = qu(shadow, SH_FLAGS, i);
-        float lambda = qf(shadow, SH_LAMBDA, i);
-        float lc = 0.0f;
-        for (uint32_t l = 0; l < light_samples; ++l) {
-            uint32_t f0 = SH_HEAD + l * SR_FIELDS;
-            ShadowRay ray;
-            ray.factor = qf(shadow, f0 + SR_FACTOR, i);
-            if (ray.factor == 0.0f) continue;
-            ray.o = f3(qf(shadow, f0 + SR_OX, i), qf(shadow, f0 + SR_OY, i), qf(shadow, f0 + SR_OZ, i));
-            ray.d = f3(qf(shadow, f0 + SR_DX, i), qf(shadow, f0 + SR_DY, i), qf(shadow, f0 + SR_DZ, i));
-            lc += ((flags >> l) & 1u) ? stage_shadow_env(s, ray) : stage_shadow_light(s, lambda, ray);
-        }
-        energy[slot] += lc / (float)light_samples;  // pt.rs:596
+        stage_shadow_item<NL>(s, light_samples, shadow, base + j, energy, energy_stride);
     }
 }
 
+template <int NL>
 __global__ void __launch_bounds__(kBlock) k_accumulate(RenderParams rp, const uint32_t* __restrict__ pixels, const float* __restrict__ energy,
                                                       float* __restrict__ film) {
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < rp.chunk_pixels; p += gridDim.x * blockDim.x) {
@@ -232,7 +215,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(RenderParams rp, const ui
         float4* px = reinterpret_cast<float4*>(film) + pixel;
         float4 v = *px;
         float f[4] = {v.x, v.y, v.z, v.w};
-        stage_accumulate_pixel(rp, energy, p, pixel, f);
+        stage_accumulate_pixel<NL>(rp, energy, p, pixel, f);
         *px = make_float4(f[0], f[1], f[2], f[3]);
     }
 }
@@ -297,7 +280,7 @@ __global__ void __launch_bounds__(kBlock) k_probe_numerics(int which, uint32_t n
 
 // ------------------------------------------------------------------------------------------------ host side
 struct DeviceBuffers {
-    uint32_t capacity = 0, light_samples = 0;
+    uint32_t capacity = 0, light_samples = 0, nl = 0;
     uint32_t *paths_a = nullptr, *paths_b = nullptr, *hits = nullptr, *shadow = nullptr, *pixels = nullptr, *counts = nullptr;
     float* energy = nullptr;
     unsigned long long* block_stats = nullptr;
@@ -333,7 +316,6 @@ pt_status ensure_device() {
     return PT_OK;
 }
 
-uint32_t shadow_fields(uint32_t light_samples) { return SH_HEAD + light_samples * SR_FIELDS; }
 
 // Segment capacity for n items over `grid` segments, rounded up to 64 items so that every segment starts on a
 // 256-byte boundary in every field.
@@ -342,18 +324,22 @@ uint32_t segment_capacity(uint32_t n, int grid) {
     return (c + 63u) & ~63u;
 }
 
-pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples, size_t n_pixels, int grid) {
+pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples, size_t n_pixels, int grid, uint32_t nl) {
     DeviceBuffers& b = sc->buf;
     uint32_t total = segment_capacity(capacity, grid) * (uint32_t)grid;
-    if (b.capacity < total || b.light_samples < light_samples || b.grid != grid) {
+    if (b.capacity < total || b.light_samples < light_samples || b.grid != grid || b.nl < nl) {
         hipFree(b.paths_a); hipFree(b.paths_b); hipFree(b.hits); hipFree(b.shadow); hipFree(b.energy); hipFree(b.counts); hipFree(b.block_stats);
         b.paths_a = b.paths_b = b.hits = b.shadow = b.counts = nullptr; b.energy = nullptr; b.block_stats = nullptr; b.capacity = 0;
         uint32_t ls = light_samples > b.light_samples ? light_samples : b.light_samples;
-        HIP_TRY(hipMalloc(&b.paths_a, sizeof(uint32_t) * (size_t)PS_FIELDS * total));
-        HIP_TRY(hipMalloc(&b.paths_b, sizeof(uint32_t) * (size_t)PS_FIELDS * total));
+        uint32_t nlmax = nl > b.nl ? nl : b.nl;
+        size_t path_fields = nlmax == 4 ? Layout<4>::path_fields : Layout<1>::path_fields;
+        size_t sh_fields = nlmax == 4 ? Layout<4>::shadow_fields(ls ? ls : 1) : Layout<1>::shadow_fields(ls ? ls : 1);
+        HIP_TRY(hipMalloc(&b.paths_a, sizeof(uint32_t) * path_fields * total));
+        HIP_TRY(hipMalloc(&b.paths_b, sizeof(uint32_t) * path_fields * total));
         HIP_TRY(hipMalloc(&b.hits, sizeof(uint32_t) * (size_t)HS_FIELDS * total));
-        HIP_TRY(hipMalloc(&b.shadow, sizeof(uint32_t) * (size_t)shadow_fields(ls ? ls : 1) * total));
-        HIP_TRY(hipMalloc(&b.energy, sizeof(float) * (size_t)total));
+        HIP_TRY(hipMalloc(&b.shadow, sizeof(uint32_t) * sh_fields * total));
+        HIP_TRY(hipMalloc(&b.energy, sizeof(float) * (size_t)nlmax * total));
+        b.nl = nlmax;
         HIP_TRY(hipMalloc(&b.counts, sizeof(uint32_t) * 3 * (size_t)grid));
         HIP_TRY(hipMalloc(&b.block_stats, sizeof(unsigned long long) * BS_FIELDS * (size_t)grid));
         b.capacity = total; b.light_samples = ls; b.grid = grid;
@@ -390,7 +376,9 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     uint64_t want = (uint64_t)pixels.size() * rd.sample_count;
     if (want < capacity) capacity = (uint32_t)(want ? want : 1);
     const int grid = sc->num_cus * (int)env_u32("PT_AMD_BLOCKS_PER_CU", 32);  // queue segments = workgroups per launch
-    pt_status st = ensure_buffers(sc, capacity, rd.light_samples, pixels.size() ? pixels.size() : 1, grid);
+    const bool hero = rd.hero_wavelengths == 4;
+    if (hero && capacity > (1u << 24)) capacity = 1u << 24;  // 4-wavelength queues are ~1.5x wider
+    pt_status st = ensure_buffers(sc, capacity, rd.light_samples, pixels.size() ? pixels.size() : 1, grid, hero ? 4u : 1u);
     if (st != PT_OK) return st;
     DeviceBuffers& b = sc->buf;
     if (!pixels.empty()) HIP_TRY(hipMemcpyAsync(b.pixels, pixels.data(), sizeof(uint32_t) * pixels.size(), hipMemcpyHostToDevice, stream));
@@ -405,6 +393,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     rp.spp = rd.spp; rp.range_end = rd.first_sample + rd.sample_count;
     rp.normalize = (rd.first_sample == 0 && rd.sample_count == rd.spp) ? 1u : 0u;
     rp.camera = pth::camera_params(sc->host.cameras[rd.camera_index], (float)rd.width / (float)rd.height);
+    rp.energy_stride = b.capacity;
 
     const uint32_t blob_bytes = sc->blob_words * 4;
     const bool lds = sc->use_lds;
@@ -443,7 +432,10 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
         uint32_t seg_cap = segment_capacity(n, grid);
         camera_rays += n;
         const uint32_t* d_px = b.pixels + pass.pixel_begin;
-        timed(ST_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, qa, b.energy, n, seg_cap, live[0]); });
+        timed(ST_GENERATE, [&] {
+            if (hero) hipLaunchKernelGGL(k_generate<4>, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, qa, b.energy, n, seg_cap, live[0]);
+            else hipLaunchKernelGGL(k_generate<1>, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, qa, b.energy, n, seg_cap, live[0]);
+        });
         for (uint32_t bounce = 0; bounce < bounce_limit; ++bounce) {
             Queue qin = (bounce & 1) ? qb : qa, qout = (bounce & 1) ? qa : qb;
             uint32_t *cin = live[bounce & 1], *cout = live[(bounce + 1) & 1];
@@ -452,18 +444,25 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
                 else launch(k_extend<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin);
             });
             timed(ST_SHADE, [&] {
-                if (lds) launch(k_shade<true>, true, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rp, bounce, d_px, qin, qh, qout, qs, b.energy,
-                                seg_cap, cin, cout, nshadow, b.block_stats);
-                else launch(k_shade<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rp, bounce, d_px, qin, qh, qout, qs, b.energy,
-                            seg_cap, cin, cout, nshadow, b.block_stats);
+#define PT_LAUNCH_SHADE(LDSF, NLV) launch(k_shade<LDSF, NLV>, LDSF, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rp, bounce, d_px, qin, qh, qout, qs, \
+                                         b.energy, seg_cap, cin, cout, nshadow, b.block_stats)
+                if (lds) { if (hero) PT_LAUNCH_SHADE(true, 4); else PT_LAUNCH_SHADE(true, 1); }
+                else { if (hero) PT_LAUNCH_SHADE(false, 4); else PT_LAUNCH_SHADE(false, 1); }
+#undef PT_LAUNCH_SHADE
             });
             if (rd.light_samples > 0)
                 timed(ST_SHADOW, [&] {
-                    if (lds) launch(k_shadow<true>, true, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, seg_cap, nshadow);
-                    else launch(k_shadow<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, seg_cap, nshadow);
+#define PT_LAUNCH_SHADOW(LDSF, NLV) launch(k_shadow<LDSF, NLV>, LDSF, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, \
+                                          b.capacity, seg_cap, nshadow)
+                    if (lds) { if (hero) PT_LAUNCH_SHADOW(true, 4); else PT_LAUNCH_SHADOW(true, 1); }
+                    else { if (hero) PT_LAUNCH_SHADOW(false, 4); else PT_LAUNCH_SHADOW(false, 1); }
+#undef PT_LAUNCH_SHADOW
                 });
         }
-        timed(ST_ACCUMULATE, [&] { hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, b.energy, d_film); });
+        timed(ST_ACCUMULATE, [&] {
+            if (hero) hipLaunchKernelGGL(k_accumulate<4>, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, b.energy, d_film);
+            else hipLaunchKernelGGL(k_accumulate<1>, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, b.energy, d_film);
+        });
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
@@ -551,8 +550,10 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     if (e != hipSuccess) { pt_scene_destroy(sc); return fail(e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE, hipGetErrorString(e)); }
     if (sc->use_lds) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_intersect<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
     }
     *out = sc;

@@ -85,7 +85,7 @@ bool normalize_render_desc(const pt_render_desc& in, uint32_t camera_count, pt_r
     if (rd.camera_index >= camera_count) { *error = "camera_index out of range"; return false; }
     if (rd.shard_count > 0 && rd.shard_index >= rd.shard_count) { *error = "shard_index >= shard_count"; return false; }
     if (rd.light_samples > PT_MAX_LIGHT_SAMPLES) { *error = "light_samples > 8 is not supported"; return false; }
-    if (rd.hero_wavelengths != 1) { *error = "hero wavelengths are not implemented yet (no live reference implementation, SURVEY F6)"; return false; }
+    if (rd.hero_wavelengths != 1 && rd.hero_wavelengths != 4) { *error = "hero_wavelengths must be 1 or 4"; return false; }
     if (rd.first_sample + rd.sample_count > rd.spp) { *error = "sample range exceeds spp"; return false; }
     if (!(rd.wavelength_hi >= rd.wavelength_lo)) { *error = "bad wavelength bounds"; return false; }
     if (rd.max_bounces > 64) { *error = "max_bounces > 64"; return false; }

@@ -24,12 +24,18 @@
 namespace ptd {
 
 // ---- SoA queues.  Field k of item i lives at base[k * capacity + i]: every field is a dense, coalesced stream.
+// NL = wavelengths carried per path: 1 (the reference's live integrator) or 4 (hero-wavelength variant, BASELINE C5:
+// lambda_0 drives every decision, three passengers carry their own throughput; definition in oracle/ptref.cpp).
 enum { PS_OX, PS_OY, PS_OZ, PS_DX, PS_DY, PS_DZ, PS_BETA, PS_LAMBDA, PS_SLOT, PS_PREV_PDF, PS_PNX, PS_PNY, PS_PNZ, PS_PPX, PS_PPY, PS_PPZ, PS_FIELDS };
 enum { HS_T, HS_PX, HS_PY, HS_PZ, HS_NX, HS_NY, HS_NZ, HS_U, HS_V, HS_MAT, HS_INST, HS_FIELDS };
-// shadow item: SH_SLOT, SH_LAMBDA, SH_FLAGS (bit l set: sub-ray l is an environment sample), then per light sample l: 7 floats
-enum { SH_SLOT, SH_LAMBDA, SH_FLAGS, SH_HEAD };
-enum { SR_OX, SR_OY, SR_OZ, SR_DX, SR_DY, SR_DZ, SR_FACTOR, SR_FIELDS };
+enum { SR_OX, SR_OY, SR_OZ, SR_DX, SR_DY, SR_DZ, SR_FACTOR };
 #define PT_MAX_LIGHT_SAMPLES 8
+template <int NL> struct Layout {
+    static constexpr uint32_t path_fields = PS_FIELDS + (NL - 1);  // passenger throughputs at PS_FIELDS + k - 1
+    // light-sample item: slot, lambda[NL], flags (bit l: sub-ray l is an environment sample), then per light sample 6 + NL floats
+    static constexpr uint32_t sh_slot = 0, sh_lambda = 1, sh_flags = 1 + NL, sh_head = 2 + NL, sr_fields = 6 + NL;
+    static constexpr uint32_t shadow_fields(uint32_t light_samples) { return sh_head + light_samples * sr_fields; }
+};
 
 struct Queue { uint32_t* base; uint32_t capacity; };
 PT_HD float qf(const Queue& q, uint32_t field, uint32_t i) { return pt_u2f(q.base[(size_t)field * q.capacity + i]); }
@@ -48,25 +54,42 @@ struct RenderParams {
     uint32_t spp;               // RenderSettings::min_samples
     uint32_t range_end;         // first_sample + sample_count of the whole call
     uint32_t normalize;         // divide by spp when the last phase of a whole render is flushed
+    uint32_t energy_stride;     // energy of wavelength k of slot i at energy[k * energy_stride + i]
     CameraParams camera;
 };
 
-struct PathVertex {  // the register-resident state of one path between stages
-    F3 o, d; float beta, lambda; uint32_t slot; float prev_pdf; F3 prev_n, prev_p;
+// lambda_k = lo + frac(u + k/4) * span; lambda_0 is the single-wavelength render's wavelength (pt.rs:406)
+template <int NL>
+PT_HD void hero_lambdas(const RenderParams& rp, float u, float* lambda) {
+    lambda[0] = rp.wavelength_lo + u * rp.wavelength_span;
+    for (int k = 1; k < NL; ++k) {
+        float x = u + (float)k * 0.25f;
+        x = x - pt_floor(x);
+        lambda[k] = rp.wavelength_lo + x * rp.wavelength_span;
+    }
+}
+
+template <int NL>
+struct PathVertexT {  // the register-resident state of one path between stages
+    F3 o, d; float beta[NL]; float lambda; uint32_t slot; float prev_pdf; F3 prev_n, prev_p;
 };
-PT_HD PathVertex load_path(const Queue& q, uint32_t i) {
-    PathVertex p;
+template <int NL>
+PT_HD PathVertexT<NL> load_path(const Queue& q, uint32_t i) {
+    PathVertexT<NL> p;
     p.o = f3(qf(q, PS_OX, i), qf(q, PS_OY, i), qf(q, PS_OZ, i));
     p.d = f3(qf(q, PS_DX, i), qf(q, PS_DY, i), qf(q, PS_DZ, i));
-    p.beta = qf(q, PS_BETA, i); p.lambda = qf(q, PS_LAMBDA, i); p.slot = qu(q, PS_SLOT, i); p.prev_pdf = qf(q, PS_PREV_PDF, i);
+    p.beta[0] = qf(q, PS_BETA, i); p.lambda = qf(q, PS_LAMBDA, i); p.slot = qu(q, PS_SLOT, i); p.prev_pdf = qf(q, PS_PREV_PDF, i);
+    for (int k = 1; k < NL; ++k) p.beta[k] = qf(q, PS_FIELDS + k - 1, i);
     p.prev_n = f3(qf(q, PS_PNX, i), qf(q, PS_PNY, i), qf(q, PS_PNZ, i));
     p.prev_p = f3(qf(q, PS_PPX, i), qf(q, PS_PPY, i), qf(q, PS_PPZ, i));
     return p;
 }
-PT_HD void store_path(const Queue& q, uint32_t i, const PathVertex& p) {
+template <int NL>
+PT_HD void store_path(const Queue& q, uint32_t i, const PathVertexT<NL>& p) {
     qsf(q, PS_OX, i, p.o.x); qsf(q, PS_OY, i, p.o.y); qsf(q, PS_OZ, i, p.o.z);
     qsf(q, PS_DX, i, p.d.x); qsf(q, PS_DY, i, p.d.y); qsf(q, PS_DZ, i, p.d.z);
-    qsf(q, PS_BETA, i, p.beta); qsf(q, PS_LAMBDA, i, p.lambda); qsu(q, PS_SLOT, i, p.slot); qsf(q, PS_PREV_PDF, i, p.prev_pdf);
+    qsf(q, PS_BETA, i, p.beta[0]); qsf(q, PS_LAMBDA, i, p.lambda); qsu(q, PS_SLOT, i, p.slot); qsf(q, PS_PREV_PDF, i, p.prev_pdf);
+    for (int k = 1; k < NL; ++k) qsf(q, PS_FIELDS + k - 1, i, p.beta[k]);
     qsf(q, PS_PNX, i, p.prev_n.x); qsf(q, PS_PNY, i, p.prev_n.y); qsf(q, PS_PNZ, i, p.prev_n.z);
     qsf(q, PS_PPX, i, p.prev_p.x); qsf(q, PS_PPY, i, p.prev_p.y); qsf(q, PS_PPZ, i, p.prev_p.z);
 }
@@ -87,27 +110,31 @@ PT_HD Hit load_hit(const Queue& q, uint32_t i) {
 }
 
 // ------------------------------------------------------------------------------------------------ generate
-PT_HD PathVertex stage_generate(const RenderParams& rp, uint32_t slot, uint32_t pixel) {
+template <int NL>
+PT_HD PathVertexT<NL> stage_generate(const RenderParams& rp, uint32_t slot, uint32_t pixel) {
     uint32_t s_local = slot / rp.chunk_pixels;
     uint32_t sample = rp.first_sample + s_local;
     uint32_t x = pixel % rp.width, y = pixel / rp.width;
     pt_f32x4 fs = pt_draw4(rp.seed, pixel, sample, PT_DIM_FILM);
     float cu = ((float)x + fs.x) / (float)rp.width, cv = ((float)y + fs.y) / (float)rp.height;  // box filter, tiled.rs:372-375
-    PathVertex p;
+    PathVertexT<NL> p;
     p.lambda = rp.wavelength_lo + fs.z * rp.wavelength_span;                                     // pt.rs:406
     float fu = pt_clamp(cu, 0.0f, 1.0f - PT_F32_EPSILON), fv = pt_clamp(cv, 0.0f, 1.0f - PT_F32_EPSILON);  // pt.rs:411-414
     camera_ray(rp.camera, rp.seed, pixel, sample, fu, fv, &p.o, &p.d);
-    p.beta = 1.0f; p.slot = slot;
+    for (int k = 0; k < NL; ++k) p.beta[k] = 1.0f;
+    p.slot = slot;
     p.prev_pdf = 100.0f; p.prev_n = p.d; p.prev_p = p.o;  // the camera vertex (pt.rs:430-446)
     return p;
 }
 
 // ------------------------------------------------------------------------------------------------ shade
-struct ShadowRay { F3 o, d; float factor; };
-struct ShadeOut {
+template <int NL> struct ShadowRayT { F3 o, d; float factor[NL]; };
+template <int NL> PT_HD bool ray_is_live(const ShadowRayT<NL>& r) { bool live = false; for (int k = 0; k < NL; ++k) live = live || (r.factor[k] != 0.0f); return live; }
+template <int NL>
+struct ShadeOutT {
     bool survives;          // path continues with `next`
-    PathVertex next;
-    float energy_add;       // light / environment vertex contribution
+    PathVertexT<NL> next;
+    float energy_add[NL];   // light / environment vertex contribution
     bool add_energy;
     bool vertex_pushed;     // counts towards Profile::bounce_rays
     bool env_hit;
@@ -125,27 +152,31 @@ PT_HD bool shade_wants_item(const SceneView& s, const RenderParams& rp, const Hi
 }
 
 // One vertex of random_walk (utils.rs:170-373) + the matching iteration of color()'s second pass (pt.rs:481-604).
-// `sink(l, ray)` receives every light-sample ray (factor == 0: nothing to trace) when the vertex has an item.
-template <typename RaySink>
-PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t bounce, const PathVertex& pv, const Hit& hit,
-                           uint32_t pixel, RaySink&& sink) {
-    ShadeOut out;
-    out.survives = false; out.energy_add = 0.0f; out.add_energy = false; out.vertex_pushed = false; out.env_hit = false;
+// `sink(l, ray)` receives every light-sample ray (all factors 0: nothing to trace) when the vertex has an item.
+template <int NL, typename RaySink>
+PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint32_t bounce, const PathVertexT<NL>& pv, const Hit& hit,
+                                uint32_t pixel, RaySink&& sink) {
+    ShadeOutT<NL> out;
+    out.survives = false; out.add_energy = false; out.vertex_pushed = false; out.env_hit = false;
     out.shadow_count = 0; out.env_mask = 0; out.has_item = false;
+    for (int k = 0; k < NL; ++k) out.energy_add[k] = 0.0f;
     uint32_t sample = rp.first_sample + pv.slot / rp.chunk_pixels;
     bool prev_is_camera = bounce == 0;
-    float lambda = pv.lambda;
+    float lam[NL];
+    lam[0] = pv.lambda;
+    if (NL > 1) hero_lambdas<NL>(rp, pt_draw4(rp.seed, pixel, sample, PT_DIM_FILM).z, lam);
+    const float lambda = lam[0];
     if (!hit.valid) {
         // environment vertex (utils.rs:344-372) and its MIS-weighted emission (pt.rs:487-511)
         F3 wo = pv.d;
         float u = 0.0f, v = 0.0f;
         if (bu(s, PT_HDR_ENV_KIND) != PT_ENV_CONSTANT) direction_to_uv(wo, &u, &v);
-        float emission = env_emission(s, u, v, lambda);
         float cos_i = pt_abs(dot(pv.prev_n, wo));
         float nee_psa_pdf = env_pdf_for(s, u, v) / pt_abs(cos_i);
         float bsdf_psa_pdf = pv.prev_pdf / pt_abs(cos_i);
         float weight = (bsdf_psa_pdf * bsdf_psa_pdf) / (bsdf_psa_pdf * bsdf_psa_pdf + nee_psa_pdf * nee_psa_pdf);
-        out.energy_add = weight * pv.beta * emission; out.add_energy = true;
+        for (int k = 0; k < NL; ++k) out.energy_add[k] = weight * pv.beta[k] * env_emission(s, u, v, lam[k]);
+        out.add_energy = true;
         out.vertex_pushed = true; out.env_hit = true;
         return out;
     }
@@ -155,8 +186,9 @@ PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t 
     bool is_light = PT_MATERIAL_TAG(hit.material) == PT_TAG_LIGHT;
     pt_f32x4 r = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples));
     float f, pdf; F3 wo;
-    MatEval me = material_prepare(s, m, lambda, hit.u, hit.v);
-    material_sample_p(me, r.x, r.y, wi, &f, &wo, &pdf);
+    MatEval me[NL];
+    for (int k = 0; k < NL; ++k) me[k] = material_prepare(s, m, lam[k], hit.u, hit.v);
+    material_sample_p(me[0], r.x, r.y, wi, &f, &wo, &pdf);
     float cos_o = pt_abs(wo.z);
     if (pt_isnan(pdf)) return out;  // utils.rs:261-263: the vertex is never pushed
     float rr = (bounce >= rp.min_bounces) ? pt_min(f / pdf, 1.0f) : 1.0f;
@@ -167,14 +199,19 @@ PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t 
         // pt.rs:512-561
         float emission = material_emission(s, m, lambda, wi);
         if (emission > 0.0f) {
-            if (rp.light_samples == 0 || prev_is_camera) { out.energy_add = pv.beta * emission; out.add_energy = true; }
-            else if (!rp.only_direct) {
+            if (rp.light_samples == 0 || prev_is_camera) {
+                out.energy_add[0] = pv.beta[0] * emission;
+                for (int k = 1; k < NL; ++k) out.energy_add[k] = pv.beta[k] * material_emission(s, m, lam[k], wi);
+                out.add_energy = true;
+            } else if (!rp.only_direct) {
                 F3 nee_dir = normalize(sub(hit.p, pv.prev_p));
                 uint32_t inst = bu(s, PT_HDR_INSTANCE_OFF) + hit.instance * PT_INST_WORDS;
                 float pdfh = light_psa_pdf(s, inst, dot(pv.prev_n, nee_dir), dot(hit.n, nee_dir), pv.prev_p, hit.p);
                 float a = pv.prev_pdf;
                 float weight = (a * a) / (a * a + pdfh * pdfh);
-                out.energy_add = weight * pv.beta * emission; out.add_energy = true;
+                out.energy_add[0] = weight * pv.beta[0] * emission;
+                for (int k = 1; k < NL; ++k) out.energy_add[k] = weight * pv.beta[k] * material_emission(s, m, lam[k], wi);
+                out.add_energy = true;
             }
         }
     } else if (rp.light_samples > 0) {
@@ -186,7 +223,8 @@ PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t 
             Frame fr2 = frame_from_normal(hn);
             F3 wi2 = to_local(fr2, normalize(sub(pv.prev_p, hit.p)));
             for (uint32_t l = 0; l < rp.light_samples; ++l) {
-                ShadowRay ray; ray.factor = 0.0f; ray.o = f3(0, 0, 0); ray.d = f3(0, 0, 0);
+                ShadowRayT<NL> ray; ray.o = f3(0, 0, 0); ray.d = f3(0, 0, 0);
+                for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
                 pt_f32x4 q = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples) + 1u + l);
                 float x = q.x;
                 bool sample_world = choose_first(&x, env_p);
@@ -198,15 +236,18 @@ PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t 
                     F3 local_wo = to_local(fr2, direction);
                     if (local_wo.z > 0.0f) {
                         float refl, spdf;
-                        material_bsdf_p(me, wi2, local_wo, &refl, &spdf);
-                        float emission = env_emission(s, eu, ev, lambda);
+                        material_bsdf_p(me[0], wi2, local_wo, &refl, &spdf);
                         float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + spdf);
                         ray.o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(direction.z)));
                         ray.d = direction;
-                        ray.factor = pv.beta * weight * refl * emission * pt_abs(local_wo.z) * (1.0f / light_pdf);
+                        ray.factor[0] = pv.beta[0] * weight * refl * env_emission(s, eu, ev, lambda) * pt_abs(local_wo.z) * (1.0f / light_pdf);
+                        for (int k = 1; k < NL; ++k) {
+                            float rk, pk; material_bsdf_p(me[k], wi2, local_wo, &rk, &pk);
+                            ray.factor[k] = pv.beta[k] * weight * rk * env_emission(s, eu, ev, lam[k]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
+                        }
                         out.shadow_count += 1;
                         // a contribution of exactly 0 adds 0 whether or not the ray is occluded: not traced
-                        if (ray.factor != 0.0f) out.env_mask |= 1u << l;
+                        if (ray_is_live<NL>(ray)) out.env_mask |= 1u << l;
                     }
                 } else if (n_lights != 0) {
                     // estimate_direct_illumination, pt.rs:146-218
@@ -219,13 +260,17 @@ PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t 
                     if (light_pdf != 0.0f) {
                         F3 bsdf_wo = to_local(fr2, ldir);
                         float refl, bpdf;
-                        material_bsdf_p(me, wi2, bsdf_wo, &refl, &bpdf);
+                        material_bsdf_p(me[0], wi2, bsdf_wo, &refl, &bpdf);
                         float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + bpdf);
                         ray.o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(bsdf_wo.z)));
                         ray.d = ldir;
                         // pt.rs:196-202: reflectance * throughput * cos_i * cos_o * emission * weight / light_pdf; cos_i and the
                         // emission are only known at the shadow hit and are multiplied in there.
-                        ray.factor = refl * pv.beta * pt_abs(bsdf_wo.z) * weight / light_pdf;
+                        ray.factor[0] = refl * pv.beta[0] * pt_abs(bsdf_wo.z) * weight / light_pdf;
+                        for (int k = 1; k < NL; ++k) {
+                            float rk, pk; material_bsdf_p(me[k], wi2, bsdf_wo, &rk, &pk);
+                            ray.factor[k] = rk * pv.beta[k] * pt_abs(bsdf_wo.z) * weight / light_pdf;
+                        }
                         out.shadow_count += 1;
                     }
                 }
@@ -235,18 +280,46 @@ PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t 
         }
     }
 
-    // continue the walk (utils.rs:301-329)
-    float beta = pv.beta * (f / pdf_forward);
-    if (pdf_forward == 0.0f) beta = 0.0f;
-    if (beta == 0.0f) return out;
+    // continue the walk (utils.rs:301-329); passengers are divided by the hero's pdf (sketch utils.rs:493)
+    float beta[NL];
+    beta[0] = pv.beta[0] * (f / pdf_forward);
+    for (int k = 1; k < NL; ++k) { float fk, pk; material_bsdf_p(me[k], wi, wo, &fk, &pk); beta[k] = pv.beta[k] * (fk / pdf_forward); }
+    if (pdf_forward == 0.0f) for (int k = 0; k < NL; ++k) beta[k] = 0.0f;
+    if (beta[0] == 0.0f) return out;
     if (r.z > rr) return out;
     if (bounce + 1 >= (rp.only_direct ? 1u : rp.max_bounces)) return out;  // `for bounce in 0..bounce_limit`
     out.survives = true;
     out.next.o = add(hit.p, mul(mul(hit.n, 0.001f), pt_signum(wo.z)));
     out.next.d = normalize(to_world(frame, wo));
-    out.next.beta = beta; out.next.lambda = lambda; out.next.slot = pv.slot;
+    for (int k = 0; k < NL; ++k) out.next.beta[k] = beta[k];
+    out.next.lambda = lambda; out.next.slot = pv.slot;
     out.next.prev_pdf = pdf_forward; out.next.prev_n = hit.n; out.next.prev_p = hit.p;
     return out;
+}
+
+// queue I/O of one light-sample ray
+template <int NL>
+PT_HD void store_shadow_ray(const Queue& q, uint32_t item, uint32_t l, const ShadowRayT<NL>& ray) {
+    uint32_t f0 = Layout<NL>::sh_head + l * Layout<NL>::sr_fields;
+    for (int k = 0; k < NL; ++k) qsf(q, f0 + SR_FACTOR + k, item, ray.factor[k]);
+    if (ray_is_live<NL>(ray)) {
+        qsf(q, f0 + SR_OX, item, ray.o.x); qsf(q, f0 + SR_OY, item, ray.o.y); qsf(q, f0 + SR_OZ, item, ray.o.z);
+        qsf(q, f0 + SR_DX, item, ray.d.x); qsf(q, f0 + SR_DY, item, ray.d.y); qsf(q, f0 + SR_DZ, item, ray.d.z);
+    }
+}
+template <int NL>
+PT_HD bool load_shadow_ray(const Queue& q, uint32_t item, uint32_t l, ShadowRayT<NL>* ray) {
+    uint32_t f0 = Layout<NL>::sh_head + l * Layout<NL>::sr_fields;
+    for (int k = 0; k < NL; ++k) ray->factor[k] = qf(q, f0 + SR_FACTOR + k, item);
+    if (!ray_is_live<NL>(*ray)) return false;
+    ray->o = f3(qf(q, f0 + SR_OX, item), qf(q, f0 + SR_OY, item), qf(q, f0 + SR_OZ, item));
+    ray->d = f3(qf(q, f0 + SR_DX, item), qf(q, f0 + SR_DY, item), qf(q, f0 + SR_DZ, item));
+    return true;
+}
+template <int NL>
+PT_HD void clear_shadow_item(const Queue& q, uint32_t item, uint32_t light_samples) {
+    for (uint32_t l = 0; l < light_samples; ++l)
+        for (int k = 0; k < NL; ++k) qsf(q, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------ shadow
@@ -254,41 +327,74 @@ PT_HD ShadeOut stage_shade(const SceneView& s, const RenderParams& rp, uint32_t 
 // Only a light that is the closest hit contributes, so the walk is bounded by the nearest light hit (nothing beyond it
 // can be the closest hit) and may stop at the first accepted non-light hit in front of it.  If no light is hit at all
 // the ray contributes nothing and is not walked.  The result is the reference's in every case.
-PT_HD float stage_shadow_light(const SceneView& s, float lambda, const ShadowRay& ray) {
+template <int NL>
+PT_HD void stage_shadow_light(const SceneView& s, const float* lambda, const ShadowRayT<NL>& ray, float* contribution) {
+    for (int k = 0; k < NL; ++k) contribution[k] = 0.0f;
     Hit sh;
     if (bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_CULL)) {
-        if (!world_hit(s, ray.o, ray.d, &sh)) return 0.0f;
+        if (!world_hit(s, ray.o, ray.d, &sh)) return;
     } else {
         float t_light = nearest_light_hit(s, ray.o, ray.d);
-        if (!(t_light < PT_INF)) return 0.0f;
-        if (!world_hit(s, ray.o, ray.d, &sh, t_light, true)) return 0.0f;
+        if (!(t_light < PT_INF)) return;
+        if (!world_hit(s, ray.o, ray.d, &sh, t_light, true)) return;
     }
-    if (PT_MATERIAL_TAG(sh.material) != PT_TAG_LIGHT) return 0.0f;
+    if (PT_MATERIAL_TAG(sh.material) != PT_TAG_LIGHT) return;
     Frame lf = frame_from_normal(sh.n);
     F3 lwi = to_local(lf, neg(ray.d));
-    float emission = material_emission(s, material_record(s, sh.material), lambda, lwi);
-    return ray.factor * pt_abs(lwi.z) * emission;
+    uint32_t lm = material_record(s, sh.material);
+    for (int k = 0; k < NL; ++k) contribution[k] = ray.factor[k] * pt_abs(lwi.z) * material_emission(s, lm, lambda[k], lwi);
 }
 // The environment-sample ray of pt.rs:252-330: contributes only if nothing is hit.
-PT_HD float stage_shadow_env(const SceneView& s, const ShadowRay& ray) {
+template <int NL>
+PT_HD void stage_shadow_env(const SceneView& s, const ShadowRayT<NL>& ray, float* contribution) {
     Hit sh;
-    if (world_hit(s, ray.o, ray.d, &sh)) return 0.0f;
-    return ray.factor;
+    bool blocked = world_hit(s, ray.o, ray.d, &sh);
+    for (int k = 0; k < NL; ++k) contribution[k] = blocked ? 0.0f : ray.factor[k];
+}
+// One light-sample item: L rays, summed in order, divided by L (pt.rs:349-392, 596)
+template <int NL>
+PT_HD void stage_shadow_item(const SceneView& s, uint32_t light_samples, const Queue& shadow, uint32_t item, float* energy, uint32_t energy_stride) {
+    uint32_t slot = qu(shadow, Layout<NL>::sh_slot, item), flags = qu(shadow, Layout<NL>::sh_flags, item);
+    float lambda[NL], lc[NL];
+    for (int k = 0; k < NL; ++k) { lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item); lc[k] = 0.0f; }
+    for (uint32_t l = 0; l < light_samples; ++l) {
+        ShadowRayT<NL> ray;
+        if (!load_shadow_ray<NL>(shadow, item, l, &ray)) continue;
+        float c[NL];
+        if ((flags >> l) & 1u) stage_shadow_env<NL>(s, ray, c); else stage_shadow_light<NL>(s, lambda, ray, c);
+        for (int k = 0; k < NL; ++k) lc[k] += c[k];
+    }
+    for (int k = 0; k < NL; ++k) energy[(size_t)k * energy_stride + slot] += lc[k] / (float)light_samples;
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
-// XYZColor::from(SingleWavelength) (math crate; pt.rs:614) and the film sums of tiled.rs:366-398.
+// XYZColor::from(SingleWavelength) (math crate; pt.rs:614) and the film sums of tiled.rs:366-398.  With hero wavelengths
+// the sample's colour is the mean of the four wavelengths' XYZ.
+template <int NL>
 PT_HD void stage_accumulate_pixel(const RenderParams& rp, const float* energy, uint32_t p, uint32_t pixel, float* film_px) {
     float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
     float f0 = film_px[0], f1 = film_px[1], f2 = film_px[2];
     for (uint32_t s_local = 0; s_local < rp.pass_samples; ++s_local) {
         uint32_t sample = rp.first_sample + s_local;
-        float e = energy[(size_t)s_local * rp.chunk_pixels + p];
+        size_t slot = (size_t)s_local * rp.chunk_pixels + p;
         pt_f32x4 fs = pt_draw4(rp.seed, pixel, sample, PT_DIM_FILM);
-        float lambda = rp.wavelength_lo + fs.z * rp.wavelength_span;
-        float xb, yb, zb;
-        xyz_bar(lambda * 10.0f, &xb, &yb, &zb);
-        t0 += e * xb; t1 += e * yb; t2 += e * zb;
+        float lam[NL];
+        hero_lambdas<NL>(rp, fs.z, lam);
+        if (NL == 1) {
+            float e = energy[slot];
+            float xb, yb, zb;
+            xyz_bar(lam[0] * 10.0f, &xb, &yb, &zb);
+            t0 += e * xb; t1 += e * yb; t2 += e * zb;
+        } else {
+            float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+            for (int k = 0; k < NL; ++k) {
+                float e = energy[(size_t)k * rp.energy_stride + slot];
+                float xb, yb, zb;
+                xyz_bar(lam[k] * 10.0f, &xb, &yb, &zb);
+                c0 += e * xb; c1 += e * yb; c2 += e * zb;
+            }
+            t0 += c0 / 4.0f; t1 += c1 / 4.0f; t2 += c2 / 4.0f;
+        }
         if ((sample + 1) % 10 == 0 || sample + 1 == rp.spp || sample + 1 == rp.range_end) {  // phases of 10, tiled.rs:347-361
             f0 += t0; f1 += t1; f2 += t2;
             t0 = t1 = t2 = 0.0f;

@@ -28,9 +28,9 @@ pt_status ptemu_scene_create(const pt_scene_desc* d, pt_scene** out) {
 }
 void ptemu_scene_destroy(pt_scene* sc) { delete sc; }
 
-pt_status ptemu_render(pt_scene* sc, const pt_render_desc* rdp, float* film, pt_profile* profile) {
-    pt_render_desc rd;
-    if (!pth::normalize_render_desc(*rdp, (uint32_t)sc->host.cameras.size(), &rd, &g_error)) return PT_ERR_INVALID_ARGUMENT;
+}  // extern "C"
+template <int NL>
+static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, pt_profile* profile) {
     SceneView s{sc->host.blob.data(), sc->host.tex.data()};
     std::vector<uint32_t> pixels = pth::shard_pixels(rd.width, rd.height, rd.tile_width, rd.tile_height, rd.shard_index, rd.shard_count);
     std::memset(film, 0, sizeof(float) * 4 * (size_t)rd.width * rd.height);
@@ -44,10 +44,12 @@ pt_status ptemu_render(pt_scene* sc, const pt_render_desc* rdp, float* film, pt_
     rp.wavelength_lo = rd.wavelength_lo; rp.wavelength_span = rd.wavelength_hi - rd.wavelength_lo;
     rp.spp = rd.spp; rp.range_end = rd.first_sample + rd.sample_count;
     rp.normalize = (rd.first_sample == 0 && rd.sample_count == rd.spp) ? 1u : 0u;
+    rp.energy_stride = capacity;
     rp.camera = pth::camera_params(sc->host.cameras[rd.camera_index], (float)rd.width / (float)rd.height);
-    std::vector<uint32_t> pa((size_t)PS_FIELDS * capacity), pb((size_t)PS_FIELDS * capacity), ph((size_t)HS_FIELDS * capacity),
-        psh((size_t)(SH_HEAD + PT_MAX_LIGHT_SAMPLES * SR_FIELDS) * capacity);
-    std::vector<float> energy(capacity);
+    typedef Layout<NL> LY;
+    std::vector<uint32_t> pa((size_t)LY::path_fields * capacity), pb((size_t)LY::path_fields * capacity), ph((size_t)HS_FIELDS * capacity),
+        psh((size_t)LY::shadow_fields(PT_MAX_LIGHT_SAMPLES) * capacity);
+    std::vector<float> energy((size_t)NL * capacity);
     Queue qa{pa.data(), capacity}, qb{pb.data(), capacity}, qh{ph.data(), capacity}, qs{psh.data(), capacity};
     uint64_t bounce_rays = 0, shadow_rays = 0, env_hits = 0, camera_rays = 0;
     uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
@@ -56,7 +58,7 @@ pt_status ptemu_render(pt_scene* sc, const pt_render_desc* rdp, float* film, pt_
         const uint32_t* px = pixels.data() + pass.pixel_begin;
         uint32_t n = pass.pixel_count * pass.sample_count;
         camera_rays += n;
-        for (uint32_t i = 0; i < n; ++i) { store_path(qa, i, stage_generate(rp, i, px[i % rp.chunk_pixels])); energy[i] = 0.0f; }
+        for (uint32_t i = 0; i < n; ++i) { store_path<NL>(qa, i, stage_generate<NL>(rp, i, px[i % rp.chunk_pixels])); for (int k = 0; k < NL; ++k) energy[(size_t)k * capacity + i] = 0.0f; }
         uint32_t live = n;
         for (uint32_t bounce = 0; bounce < bounce_limit; ++bounce) {
             Queue qin = (bounce & 1) ? qb : qa, qout = (bounce & 1) ? qa : qb;
@@ -67,49 +69,41 @@ pt_status ptemu_render(pt_scene* sc, const pt_render_desc* rdp, float* film, pt_
             }
             uint32_t next = 0, items = 0;
             for (uint32_t i = 0; i < live; ++i) {
-                PathVertex pv = load_path(qin, i);
+                PathVertexT<NL> pv = load_path<NL>(qin, i);
                 Hit hit = load_hit(qh, i);
                 bool wants = shade_wants_item(s, rp, hit);
                 uint32_t ipos = items;
-                ShadeOut out = stage_shade(s, rp, bounce, pv, hit, px[pv.slot % rp.chunk_pixels], [&](uint32_t l, const ShadowRay& ray) {
-                    uint32_t f0 = SH_HEAD + l * SR_FIELDS;
-                    qsf(qs, f0 + SR_FACTOR, ipos, ray.factor);
-                    if (ray.factor != 0.0f) {
-                        qsf(qs, f0 + SR_OX, ipos, ray.o.x); qsf(qs, f0 + SR_OY, ipos, ray.o.y); qsf(qs, f0 + SR_OZ, ipos, ray.o.z);
-                        qsf(qs, f0 + SR_DX, ipos, ray.d.x); qsf(qs, f0 + SR_DY, ipos, ray.d.y); qsf(qs, f0 + SR_DZ, ipos, ray.d.z);
-                    }
-                });
+                ShadeOutT<NL> out = stage_shade<NL>(s, rp, bounce, pv, hit, px[pv.slot % rp.chunk_pixels],
+                                                    [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(qs, ipos, l, ray); });
                 if (wants) {
                     items++;
-                    qsu(qs, SH_SLOT, ipos, pv.slot); qsf(qs, SH_LAMBDA, ipos, pv.lambda); qsu(qs, SH_FLAGS, ipos, out.env_mask);
-                    if (!out.has_item) for (uint32_t l = 0; l < rp.light_samples; ++l) qsf(qs, SH_HEAD + l * SR_FIELDS + SR_FACTOR, ipos, 0.0f);
+                    float lam[NL]; lam[0] = pv.lambda;
+                    if (NL > 1) hero_lambdas<NL>(rp, pt_draw4(rp.seed, px[pv.slot % rp.chunk_pixels], rp.first_sample + pv.slot / rp.chunk_pixels, PT_DIM_FILM).z, lam);
+                    qsu(qs, LY::sh_slot, ipos, pv.slot); qsu(qs, LY::sh_flags, ipos, out.env_mask);
+                    for (int k = 0; k < NL; ++k) qsf(qs, LY::sh_lambda + k, ipos, lam[k]);
+                    if (!out.has_item) clear_shadow_item<NL>(qs, ipos, rp.light_samples);
                 }
-                if (out.add_energy) energy[pv.slot] += out.energy_add;
-                if (out.survives) store_path(qout, next++, out.next);
+                if (out.add_energy) for (int k = 0; k < NL; ++k) energy[(size_t)k * capacity + pv.slot] += out.energy_add[k];
+                if (out.survives) store_path<NL>(qout, next++, out.next);
                 bounce_rays += out.vertex_pushed; env_hits += out.env_hit; shadow_rays += out.shadow_count;
             }
-            for (uint32_t i = 0; i < items; ++i) {
-                uint32_t slot = qu(qs, SH_SLOT, i), flags = qu(qs, SH_FLAGS, i);
-                float lambda = qf(qs, SH_LAMBDA, i), lc = 0.0f;
-                for (uint32_t l = 0; l < rp.light_samples; ++l) {
-                    uint32_t f0 = SH_HEAD + l * SR_FIELDS;
-                    ShadowRay ray; ray.factor = qf(qs, f0 + SR_FACTOR, i);
-                    if (ray.factor == 0.0f) continue;
-                    ray.o = f3(qf(qs, f0 + SR_OX, i), qf(qs, f0 + SR_OY, i), qf(qs, f0 + SR_OZ, i));
-                    ray.d = f3(qf(qs, f0 + SR_DX, i), qf(qs, f0 + SR_DY, i), qf(qs, f0 + SR_DZ, i));
-                    lc += ((flags >> l) & 1u) ? stage_shadow_env(s, ray) : stage_shadow_light(s, lambda, ray);
-                }
-                energy[slot] += lc / (float)rp.light_samples;
-            }
+            for (uint32_t i = 0; i < items; ++i) stage_shadow_item<NL>(s, rp.light_samples, qs, i, energy.data(), capacity);
             live = next;
         }
-        for (uint32_t p = 0; p < rp.chunk_pixels; ++p) stage_accumulate_pixel(rp, energy.data(), p, px[p], film + 4 * (size_t)px[p]);
+        for (uint32_t p = 0; p < rp.chunk_pixels; ++p) stage_accumulate_pixel<NL>(rp, energy.data(), p, px[p], film + 4 * (size_t)px[p]);
     }
     if (profile) {
         std::memset(profile, 0, sizeof(*profile));
         profile->camera_rays = camera_rays; profile->bounce_rays = bounce_rays + camera_rays; profile->shadow_rays = shadow_rays; profile->env_hits = env_hits;
     }
     return PT_OK;
+}
+
+extern "C" {
+pt_status ptemu_render(pt_scene* sc, const pt_render_desc* rdp, float* film, pt_profile* profile) {
+    pt_render_desc rd;
+    if (!pth::normalize_render_desc(*rdp, (uint32_t)sc->host.cameras.size(), &rd, &g_error)) return PT_ERR_INVALID_ARGUMENT;
+    return rd.hero_wavelengths == 4 ? render_t<4>(sc, rd, film, profile) : render_t<1>(sc, rd, film, profile);
 }
 
 pt_status ptemu_intersect(pt_scene* sc, size_t n, const float* o, const float* d, pt_hit* hits) {

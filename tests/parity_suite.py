@@ -76,9 +76,12 @@ def render_parity(impl, oracle, scene_name, width, height, spp, max_bounces, **k
 
 
 def golden_render(impl, name):
-    scene, w, h, spp, mb, ls, seed = GOLDEN_RENDERS[name]
+    cfg = GOLDEN_RENDERS[name]
+    scene, w, h, spp, mb, ls, seed = cfg[:7]
+    hero = cfg[7] if len(cfg) > 7 else 1
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
-    film, prof = impl.create_scene(pkg().scene.SCENES[scene]()).render(pkg().api.render_desc(w, h, spp, mb, light_samples=ls, seed=seed))
+    film, prof = impl.create_scene(pkg().scene.SCENES[scene]()).render(
+        pkg().api.render_desc(w, h, spp, mb, light_samples=ls, seed=seed, hero_wavelengths=hero))
     return film, prof, z["film"], z["counters"]
 
 

@@ -66,6 +66,9 @@ def test_materials_bit_exact(engine, oracle, scene):
     ("mixed_primitives", 64, 64, 8, 6, {"light_samples": 3, "seed": 5}),
     ("white_furnace", 32, 32, 12, 8, {"light_samples": 6}),
     ("hdri_small", 64, 64, 8, 4, {"light_samples": 6}),
+    ("cornell_box", 128, 128, 12, 8, {"hero_wavelengths": 4}),      # C5 shape: four wavelengths per path
+    ("cornell_gem", 64, 48, 6, 12, {"hero_wavelengths": 4}),
+    ("hdri_small", 48, 48, 6, 4, {"hero_wavelengths": 4, "light_samples": 3}),
     ("hdri_c4_small", 96, 96, 6, 4, {"light_samples": 6}),   # C4 scene (monkey mesh: blob too big for LDS -> HBM/L2 path)
 ])
 def test_film_parity(engine, oracle, scene, w, h, spp, mb, kw):
@@ -146,7 +149,7 @@ def test_full_size_cornell_properties(engine, oracle, pkg):
 def test_error_behaviour(engine, pkg):
     b = pkg.scene.cornell_box()
     sc = engine.create_scene(b)
-    for bad in (dict(camera_index=3), dict(shard=(2, 2)), dict(hero_wavelengths=4), dict(light_samples=9)):
+    for bad in (dict(camera_index=3), dict(shard=(2, 2)), dict(hero_wavelengths=3), dict(light_samples=9)):
         with pytest.raises(pkg.api.PtError) as e:
             sc.render(pkg.api.render_desc(8, 8, 1, 2, **bad))
         assert e.value.status == 1 and str(e.value)

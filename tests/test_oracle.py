@@ -361,3 +361,19 @@ def test_white_furnace(pkg, oracle):
     level = (env * xyz[:, 1]).mean()
     ratio = y.mean() / level
     assert 0.5 < ratio < 3.0, ratio
+
+
+def test_hero_wavelengths_follow_the_single_wavelength_path(pkg, oracle):
+    """C5 as defined in oracle/ptref.cpp: the hero wavelength takes every decision, so ray counters equal the
+    single-wavelength render of the same seed, and the film agrees statistically (same expectation)."""
+    sc = oracle.create_scene(pkg.scene.cornell_box())
+    a, pa = sc.render(pkg.api.render_desc(32, 32, 64, 6))
+    b, pb = sc.render(pkg.api.render_desc(32, 32, 64, 6, hero_wavelengths=4))
+    assert (pa.bounce_rays, pa.shadow_rays, pa.env_hits) == (pb.bounce_rays, pb.shadow_rays, pb.env_hits)
+    assert np.isfinite(b).all() and b[..., :3].min() >= 0
+    assert abs(a[..., 1].mean() - b[..., 1].mean()) / a[..., 1].mean() < 0.05
+    # colour noise drops: per-pixel chroma variance of the hero render is lower
+    def chroma_var(f):
+        s = f[..., :3].sum(axis=2) + 1e-9
+        return np.var(f[..., 0] / s) + np.var(f[..., 2] / s)
+    assert chroma_var(b) < chroma_var(a)

@@ -51,12 +51,13 @@ def material_inputs(n, seed):
 
 
 GOLDEN_RENDERS = {
-    # name: (scene, width, height, spp, max_bounces, light_samples, seed)
+    # name: (scene, width, height, spp, max_bounces, light_samples, seed[, hero_wavelengths])
     "cornell_64x64_4spp": ("cornell_box", 64, 64, 4, 4, 2, 1),
     "gem_48x32_6spp": ("cornell_gem", 48, 32, 6, 12, 2, 1),
     "mixed_40x40_12spp": ("mixed_primitives", 40, 40, 12, 6, 3, 7),
     "furnace_24x24_16spp": ("white_furnace", 24, 24, 16, 8, 6, 3),
     "hdri_32x32_8spp": ("hdri_small", 32, 32, 8, 4, 6, 2),
+    "cornell_hero_48x48_6spp": ("cornell_box", 48, 48, 6, 8, 2, 4, 4),
 }
 
 
@@ -66,9 +67,11 @@ def main():
     ora = oracle_loader.load(pkg)
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
-    for name, (scene, w, h, spp, mb, ls, seed) in GOLDEN_RENDERS.items():
+    for name, cfg in GOLDEN_RENDERS.items():
+        scene, w, h, spp, mb, ls, seed = cfg[:7]
+        hero = cfg[7] if len(cfg) > 7 else 1
         sc = ora.create_scene(pkg.scene.SCENES[scene]())
-        film, prof = sc.render(pkg.api.render_desc(w, h, spp, mb, light_samples=ls, seed=seed))
+        film, prof = sc.render(pkg.api.render_desc(w, h, spp, mb, light_samples=ls, seed=seed, hero_wavelengths=hero))
         np.savez_compressed(os.path.join(out, name + ".npz"), film=film,
                             counters=np.array([prof.camera_rays, prof.bounce_rays, prof.shadow_rays, prof.env_hits], np.uint64))
         print(name, film[..., :3].mean(axis=(0, 1)), prof.bounce_rays, prof.shadow_rays, prof.env_hits)
