@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--max-bounces", type=int, default=8)
     ap.add_argument("--light-samples", type=int, default=2)
     ap.add_argument("--scene", default="cornell_box")
+    ap.add_argument("--min-bounces", type=int, default=1)
+    ap.add_argument("--hero", type=int, default=1, help="wavelengths per path: 1, or 4 for the hero-wavelength variant (C5)")
+    ap.add_argument("--workload", default=None, help="label for config.workload (default: derived from the arguments)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -86,8 +89,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(k):
-        rd = pkg.api.render_desc(W, H, total_spp, args.max_bounces, min_bounces=1, light_samples=L, seed=1,
-                                 shard=sharding.shard(rank, n_gpus), first_sample=k * S, sample_count=S)
+        rd = pkg.api.render_desc(W, H, total_spp, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1,
+                                 shard=sharding.shard(rank, n_gpus), first_sample=k * S, sample_count=S, hero_wavelengths=args.hero)
         prof = scene.render_device(rd, film_step.data_ptr(), stream)
         film_total.add_(film_step)
         return prof
@@ -163,13 +166,13 @@ def main():
             oracle = oracle_loader.load(pkg)
             oscene = oracle.create_scene(builder)
             cores = os.cpu_count() or 1
-            probe = pkg.api.render_desc(W, H, 1, args.max_bounces, min_bounces=1, light_samples=L, seed=1, shard=(0, 4))
+            probe = pkg.api.render_desc(W, H, 1, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, shard=(0, 4), hero_wavelengths=args.hero)
             t = time.perf_counter(); _, pp = oscene.render(probe); dt = time.perf_counter() - t
             rate = pp.camera_rays / dt
             budget = rate * args.cpu_seconds
             shard_count = max(1, int((W * H) / max(budget, 1.0)) + 1) if budget < W * H else 1
             spp = max(1, int(budget / (W * H))) if shard_count == 1 else 1
-            rdc = pkg.api.render_desc(W, H, spp, args.max_bounces, min_bounces=1, light_samples=L, seed=1, shard=(0, shard_count) if shard_count > 1 else (0, 0))
+            rdc = pkg.api.render_desc(W, H, spp, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, shard=(0, shard_count) if shard_count > 1 else (0, 0), hero_wavelengths=args.hero)
             t = time.perf_counter(); _, pc = oscene.render(rdc); dt = time.perf_counter() - t
             cpu = {"value": pc.camera_rays / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
                    "sample": "oracle (C++ restatement of the reference PT path, std::thread over 32x32 tiles) on %d host threads: "
@@ -182,8 +185,10 @@ def main():
             "value": value, "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: Cornell box (authored mesh + reference light/camera), %dx%d, PT+NEE, max_bounces=%d, min_bounces=1, "
-                                   "light_samples=%d, wavelengths 380-750 nm" % (W, H, args.max_bounces, L),
+            "config": {"workload": args.workload or ("C2: Cornell box (authored mesh + reference light/camera), %dx%d, PT+NEE, max_bounces=%d, min_bounces=1, "
+                                                     "light_samples=%d, wavelengths 380-750 nm" % (W, H, args.max_bounces, L) if (args.scene, args.hero) == ("cornell_box", 1)
+                                                     else "%s %dx%d, PT+NEE, max_bounces=%d, min_bounces=%d, light_samples=%d, %d wavelength(s) per path" %
+                                                     (args.scene, W, H, args.max_bounces, args.min_bounces, L, args.hero)),
                        "scene": args.scene, "spp_per_step_per_gpu": args.spp_per_step, "spp_per_step": S, "samples_per_step": total_samples / args.steps,
                        "parallelism": "film tiles 32x32 round-robin over %d GPU(s), one RCCL reduce of the XYZ film" % n_gpus,
                        "device": engine.device_info()},

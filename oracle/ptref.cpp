@@ -1093,6 +1093,14 @@ void bake_importance_map(Scene& s) {
         lam[i] = 380.0f + (float)i * step;
         lum[i] = e.importance_luminance_curve >= 0 ? curve_at(s, e.importance_luminance_curve, lam[i]) : y_bar(lam[i] * 10.0f);
     }
+    // curve values at the 100 wavelengths, per layer and channel (TexStack::eval_at evaluates them per texel; same values)
+    const pt_texstack& ts = s.texstacks[e.texstack];
+    std::vector<float> cv((size_t)ts.layer_count * 4 * N, 0.0f);
+    for (int li = 0; li < ts.layer_count; ++li) {
+        const pt_texture_layer& l = s.layers[ts.first_layer + li];
+        for (int c = 0; c < (l.kind == PT_TEXTURE4 ? 4 : 1); ++c)
+            for (int i = 0; i < N; ++i) cv[((size_t)li * 4 + c) * N + i] = curve_at(s, l.curves[c], lam[i]);
+    }
     float total = 0.0f;
     for (uint32_t row = 0; row < V; ++row) {
         float row_luminance = 0.0f;
@@ -1100,7 +1108,18 @@ void bake_importance_map(Scene& s) {
         for (uint32_t col = 0; col < H; ++col) {
             float u = (float)row / (float)V, v = (float)col / (float)H;
             float texel = 0.0f;
-            for (int i = 0; i < N; ++i) texel += lum[i] * texstack_eval(s, e.texstack, lam[i], u, v) * step;
+            for (int i = 0; i < N; ++i) {
+                float energy = 0.0f;  // texstack_eval(s, e.texstack, lam[i], u, v) with the cached curve values
+                for (int li = 0; li < ts.layer_count; ++li) {
+                    const pt_texture_layer& l = s.layers[ts.first_layer + li];
+                    const float* data = s.texture_data.data() + l.data_offset;
+                    size_t idx = texel_index(l.width, l.height, u, v);
+                    const float* c = &cv[(size_t)li * 4 * N];
+                    if (l.kind == PT_TEXTURE1) energy += c[i] * data[idx];
+                    else { const float* t = data + 4 * idx; energy += (c[i] * t[0] + c[N + i] * t[1]) + (c[2 * N + i] * t[2] + c[3 * N + i] * t[3]); }
+                }
+                texel += lum[i] * energy * step;
+            }
             row_luminance += texel;
             pdf[col] = texel; cmf[col] = row_luminance;
         }

@@ -365,14 +365,35 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                 else { float xb, yb, zb; ptd::xyz_bar(lam[i] * 10.0f, &xb, &yb, &zb); lum[i] = yb; }
             }
             std::vector<float> row_pdf((size_t)V * H), row_cmf((size_t)V * H), mpdf(V), mcmf(V);
+            // the spectral curves of the environment texture at the 100 wavelengths, evaluated once per channel instead of once
+            // per texel (TexStack::eval_at re-evaluates them; same values)
+            const pt_texstack& ets = d.texstacks[e.texstack];
+            std::vector<float> cv((size_t)ets.layer_count * 4 * N, 0.0f);
+            for (int li = 0; li < ets.layer_count; ++li) {
+                const pt_texture_layer& L = d.layers[ets.first_layer + li];
+                for (int c = 0; c < (L.kind == PT_TEXTURE4 ? 4 : 1); ++c)
+                    for (int i = 0; i < N; ++i) cv[((size_t)li * 4 + c) * N + i] = ptd::curve_eval(view, curve_off[L.curves[c]], lam[i]);
+            }
             float total = 0.0f;
             for (uint32_t row = 0; row < V; ++row) {
                 float row_luminance = 0.0f;
                 float* pdf = row_pdf.data() + (size_t)row * H; float* cmf = row_cmf.data() + (size_t)row * H;
                 for (uint32_t col = 0; col < H; ++col) {
                     float u = (float)row / (float)V, v = (float)col / (float)H;
+                    float cu = pt_clamp(u, 0.0f, 1.0f - PT_F32_EPSILON), cvv = pt_clamp(v, 0.0f, 1.0f - PT_F32_EPSILON);
                     float texel = 0.0f;
-                    for (int i = 0; i < N; ++i) texel += lum[i] * ptd::texstack_eval(view, ts_off[e.texstack], lam[i], u, v) * step;
+                    for (int i = 0; i < N; ++i) {
+                        float energy = 0.0f;
+                        for (int li = 0; li < ets.layer_count; ++li) {
+                            const pt_texture_layer& L = d.layers[ets.first_layer + li];
+                            const float* data = d.texture_data + L.data_offset;
+                            size_t idx = (size_t)(cvv * (float)L.height) * (size_t)L.width + (size_t)(cu * (float)L.width);
+                            const float* c = &cv[(size_t)li * 4 * N];
+                            if (L.kind == PT_TEXTURE1) energy += c[i] * data[idx];
+                            else { const float* t = data + 4 * idx; energy += (c[i] * t[0] + c[N + i] * t[1]) + (c[2 * N + i] * t[2] + c[3 * N + i] * t[3]); }
+                        }
+                        texel += lum[i] * energy * step;
+                    }
                     row_luminance += texel;
                     pdf[col] = texel; cmf[col] = row_luminance;
                 }
