@@ -246,6 +246,27 @@ pt_status pt_emission(pt_scene* scene, uint32_t material, size_t n, const float*
                       float* emission);
 pt_status pt_curve_eval(pt_scene* scene, uint32_t curve, size_t n, const float* lambda, float* value);
 
+/* ---- film output stage: output_film (src/renderer/mod.rs:24-80) = tonemap + colour space + files ---- */
+enum { PT_TONEMAP_CLAMP = 0, PT_TONEMAP_REINHARD0 = 1, PT_TONEMAP_REINHARD1 = 2 };      /* src/parsing/tonemap.rs:8-31 */
+enum { PT_COLORSPACE_SRGB = 0, PT_COLORSPACE_REC709 = 1, PT_COLORSPACE_REC2020 = 2 };   /* ColorSpaceSettings, src/parsing/config.rs */
+typedef struct pt_output_desc {
+    uint32_t width, height;
+    int32_t tonemap;          /* PT_TONEMAP_* */
+    int32_t luminance_only;   /* Reinhard0/1: false selects the per-channel x3 variants (src/parsing/tonemap.rs:80-104) */
+    float exposure;           /* Clamp: stops (2^exposure), default 0 */
+    float key_value;          /* Reinhard */
+    float white_point;        /* Reinhard1 max_white */
+    int32_t colorspace;       /* PT_COLORSPACE_* */
+    float factor;             /* output_film's factor * premultiply (src/renderer/mod.rs:24-26) */
+} pt_output_desc;
+/* film_xyzw: host, width*height*4 f32.  rgba8: width*height*4 bytes = what write_to_files puts in the PNG (tonemapped,
+ * converted to the colour space's primaries, OETF-encoded, ceil(255 v) clamped; src/tonemap/mod.rs:316-333).
+ * linear_rgb (may be NULL): width*height*3 f32 = the EXR payload (factor * film in linear RGB of those primaries, :232-251). */
+pt_status pt_output_film(const pt_output_desc* desc, const float* film_xyzw, uint8_t* rgba8, float* linear_rgb);
+/* PNG (8-bit RGBA with gAMA and cHRM chunks, mod.rs:291-314) and OpenEXR (float RGB scanlines + chromaticities, :253-279). */
+pt_status pt_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8, int32_t colorspace);
+pt_status pt_write_exr(const char* path, uint32_t width, uint32_t height, const float* linear_rgb, int32_t colorspace);
+
 /* Library / device identification, e.g. "gfx950 ... 256 CUs". */
 const char* pt_device_info(void);
 

@@ -1763,6 +1763,72 @@ pt_status ptref_curve_eval(pt_scene* ps, uint32_t curve, size_t n, const float* 
     return PT_OK;
 }
 
+// ---- film output stage: restatement of Tonemapper::{initialize,map} + colour conversion + OETF + quantisation
+// src/tonemap/clamp.rs:24-102, reinhard0.rs:24-196, reinhard1.rs:26-231, mod.rs:19-37,147-205,316-333.  Sequential sums as
+// in the reference (f64 for the luminance-only tonemappers, f32 lanes for the x3 variants); ln / exp / powf from libm.
+pt_status ptref_output_film(const pt_output_desc* d, const float* film, uint8_t* rgba8, float* linear_rgb) {
+    if (!d || !film || !rgba8 || d->width == 0 || d->height == 0 || !(d->factor > 0.0f)) { g_error = "bad argument"; return PT_ERR_INVALID_ARGUMENT; }
+    const size_t n = (size_t)d->width * d->height;
+    const float MAUVE[3] = {0.5199467f, 51.48687f, 1.0180528f};
+    float lw[3] = {1, 1, 1};
+    if (d->tonemap != PT_TONEMAP_CLAMP) {
+        if (d->luminance_only) {
+            double sum = 0.0;
+            for (size_t i = 0; i < n; ++i) {
+                float lum = film[4 * i + 1];
+                if (lum != lum) continue;
+                sum += d->tonemap == PT_TONEMAP_REINHARD0 ? std::log(0.001 + (double)lum) : std::log((double)(0.001f + lum));
+            }
+            lw[0] = lw[1] = lw[2] = (float)std::exp(sum / (double)n) / d->factor;
+        } else {
+            float sum[3] = {0, 0, 0};
+            for (size_t i = 0; i < n; ++i) {
+                if (film[4 * i + 1] != film[4 * i + 1]) continue;
+                for (int k = 0; k < 3; ++k) sum[k] += std::log(0.001f + film[4 * i + k]);
+            }
+            for (int k = 0; k < 3; ++k) lw[k] = std::exp(sum[k] / (float)n) / d->factor;
+        }
+    }
+    auto to_rgb = [&](const float* c, float* o) {
+        const float m709[9] = {3.24096994f, -1.53738318f, -0.49861076f, -0.96924364f, 1.8759675f, 0.04155506f, 0.05563008f, -0.20397696f, 1.05697151f};
+        const float m2020[9] = {1.4628067f, -0.1840623f, -0.2743606f, -0.5217933f, 1.4472381f, 0.0677227f, 0.0349342f, -0.0968930f, 1.2884099f};
+        const float* m = d->colorspace == PT_COLORSPACE_REC2020 ? m2020 : m709;
+        for (int r = 0; r < 3; ++r) o[r] = m[3 * r] * c[0] + m[3 * r + 1] * c[1] + m[3 * r + 2] * c[2];
+    };
+    auto oetf = [&](float v) {
+        if (d->colorspace == PT_COLORSPACE_SRGB) return v < 0.0031308f ? (323.0f / 25.0f) * v : (211.0f / 200.0f) * std::pow(v, 5.0f / 12.0f) - (11.0f / 200.0f);
+        return v < 0.01805397f ? 4.5f * v : 1.0992968f * std::pow(v, 0.45f) - 0.09929682f;
+    };
+    auto finite3 = [](const float* c) { return std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]); };
+    float exposure_mult = std::pow(2.0f, d->exposure), mul = 1.0f / (d->white_point * d->white_point);
+    for (size_t i = 0; i < n; ++i) {
+        float c[3] = {film[4 * i], film[4 * i + 1], film[4 * i + 2]}, o[3];
+        if (d->tonemap == PT_TONEMAP_CLAMP) {
+            for (int k = 0; k < 3; ++k) c[k] *= d->factor;
+            if (!finite3(c)) for (int k = 0; k < 3; ++k) c[k] = MAUVE[k];
+            if (d->luminance_only) {
+                float lum = c[1], new_lum = pt_clamp(lum * exposure_mult, 0.0f, 1.0f), sf = new_lum / lum;
+                for (int k = 0; k < 3; ++k) o[k] = sf * c[k];
+            } else for (int k = 0; k < 3; ++k) o[k] = std::fmax(std::fmin(c[k] * exposure_mult, 1.0f), 0.0f);
+        } else if (d->luminance_only) {
+            float l = d->key_value * c[1] / lw[1];
+            float sf = d->tonemap == PT_TONEMAP_REINHARD0 ? l / (1.0f + l) : l * (mul * l + 1.0f) / (1.0f + l);
+            if (!finite3(c)) for (int k = 0; k < 3; ++k) c[k] = MAUVE[k];
+            for (int k = 0; k < 3; ++k) o[k] = sf * c[k];
+        } else {
+            float sf[3];
+            for (int k = 0; k < 3; ++k) { float l = d->key_value * c[k] / lw[k]; sf[k] = d->tonemap == PT_TONEMAP_REINHARD0 ? l / (1.0f + l) : l * (mul * l + 1.0f) / (1.0f + l); }
+            if (d->tonemap == PT_TONEMAP_REINHARD0) { if (!finite3(c)) for (int k = 0; k < 3; ++k) c[k] = MAUVE[k]; for (int k = 0; k < 3; ++k) o[k] = sf[k] * c[k]; }
+            else { for (int k = 0; k < 3; ++k) o[k] = sf[k] * c[k]; if (!finite3(o)) for (int k = 0; k < 3; ++k) o[k] = MAUVE[k]; }
+        }
+        float rgb[3]; to_rgb(o, rgb);
+        for (int k = 0; k < 3; ++k) { float v = std::ceil(oetf(rgb[k]) * 255.0f); rgba8[4 * i + k] = (uint8_t)(v != v ? 0.0f : pt_clamp(v, 0.0f, 255.0f)); }
+        rgba8[4 * i + 3] = 255;
+        if (linear_rgb) { float fc[3] = {d->factor * film[4 * i], d->factor * film[4 * i + 1], d->factor * film[4 * i + 2]}; to_rgb(fc, linear_rgb + 3 * i); }
+    }
+    return PT_OK;
+}
+
 // Extra oracle-only probes used by tests.
 void ptref_generate_tiles(uint32_t w, uint32_t h, uint32_t tw, uint32_t th, uint32_t* out_xyxy, uint32_t* count) {
     std::vector<TileRect> t = generate_tiles(w, h, tw, th);

@@ -109,6 +109,16 @@ class Profile(C.Structure):
                 "kernel_seconds": list(self.kernel_seconds), "kernel_launches": list(self.kernel_launches), "stage_items": list(self.stage_items)}
 
 
+class OutputDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("tonemap", C.c_int32), ("luminance_only", C.c_int32),
+                ("exposure", C.c_float), ("key_value", C.c_float), ("white_point", C.c_float), ("colorspace", C.c_int32),
+                ("factor", C.c_float)]
+
+
+TONEMAP_CLAMP, TONEMAP_REINHARD0, TONEMAP_REINHARD1 = range(3)
+COLORSPACE_SRGB, COLORSPACE_REC709, COLORSPACE_REC2020 = range(3)
+
+
 class Hit(C.Structure):
     _fields_ = [("t", C.c_float), ("point", C.c_float * 3), ("normal", C.c_float * 3), ("uv", C.c_float * 2),
                 ("material", C.c_uint32), ("instance", C.c_uint32), ("valid", C.c_int32)]
@@ -120,7 +130,7 @@ assert HIT_DTYPE.itemsize == C.sizeof(Hit)
 
 # every entry point include/pt_api.h declares (without prefix)
 API_FUNCTIONS = ["scene_create", "scene_destroy", "last_error", "render", "render_device", "intersect",
-                 "bsdf_sample", "bsdf_eval", "emission", "curve_eval", "device_info"]
+                 "bsdf_sample", "bsdf_eval", "emission", "curve_eval", "device_info", "output_film", "write_png", "write_exr"]
 
 
 class PtError(RuntimeError):
@@ -173,6 +183,9 @@ class Library:
         self._emission = bind("emission", C.c_int32, [vp, u32, sz, fpp, fpp, fpp])
         self._curve_eval = bind("curve_eval", C.c_int32, [vp, u32, sz, fpp, fpp])
         self._device_info = bind("device_info", C.c_char_p, [], required=False)
+        self._output_film = bind("output_film", C.c_int32, [C.POINTER(OutputDesc), fpp, C.POINTER(C.c_uint8), fpp], required=False)
+        self._write_png = bind("write_png", C.c_int32, [C.c_char_p, u32, u32, C.POINTER(C.c_uint8), C.c_int32], required=False)
+        self._write_exr = bind("write_exr", C.c_int32, [C.c_char_p, u32, u32, fpp, C.c_int32], required=False)
 
     def last_error(self):
         m = self._last_error()
@@ -187,6 +200,25 @@ class Library:
 
     def create_scene(self, builder):
         return Scene(self, builder)
+
+    def output_film(self, film, tonemap=TONEMAP_CLAMP, luminance_only=True, exposure=0.0, key_value=0.18, white_point=1.0,
+                    colorspace=COLORSPACE_SRGB, factor=1.0, want_linear=True):
+        """output_film (src/renderer/mod.rs:24-80) without the file writes: (rgba8 [H,W,4] u8, linear_rgb [H,W,3] f32)."""
+        film = np.ascontiguousarray(film, dtype=np.float32)
+        h, w = film.shape[:2]
+        d = OutputDesc(w, h, tonemap, int(bool(luminance_only)), exposure, key_value, white_point, colorspace, factor)
+        rgba = np.zeros((h, w, 4), np.uint8)
+        lin = np.zeros((h, w, 3), np.float32) if want_linear else None
+        self.check(self._output_film(C.byref(d), _fp(film), rgba.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(lin) if want_linear else None))
+        return rgba, lin
+
+    def write_png(self, path, rgba8, colorspace=COLORSPACE_SRGB):
+        rgba8 = np.ascontiguousarray(rgba8, np.uint8)
+        self.check(self._write_png(path.encode(), rgba8.shape[1], rgba8.shape[0], rgba8.ctypes.data_as(C.POINTER(C.c_uint8)), colorspace))
+
+    def write_exr(self, path, linear_rgb, colorspace=COLORSPACE_SRGB):
+        linear_rgb = np.ascontiguousarray(linear_rgb, np.float32)
+        self.check(self._write_exr(path.encode(), linear_rgb.shape[1], linear_rgb.shape[0], _fp(linear_rgb), colorspace))
 
 
 class Scene:

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/pt_api.h"
+#include "pt_error.h"
 #include "pt_plan.h"
 #include "pt_scene_host.h"
 #include "pt_stages.h"
@@ -24,6 +25,9 @@ namespace {
 
 thread_local std::string g_error;
 pt_status fail(pt_status st, const std::string& msg) { g_error = msg; return st; }
+}  // namespace
+void pt_set_error(const std::string& message) { g_error = message; }
+namespace {
 
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
