@@ -78,9 +78,26 @@ def main():
             acc[short(r.get("Kernel_Name", ""))].append(float(r["Counter_Value"]))
         summary[name] = {k: {"launches": len(v), "avg_per_launch": sum(v) / len(v), "total": sum(v)} for k, v in acc.items()}
     sq = defaultdict(lambda: defaultdict(float))
-    for r in counter_rows(os.path.join(out_dir, "pmc_sq")):
-        sq[short(r.get("Kernel_Name", ""))][r.get("Counter_Name")] += float(r["Counter_Value"])
+    for sub in ("pmc_sq", "pmc_sq2"):
+        for r in counter_rows(os.path.join(out_dir, sub)):
+            sq[short(r.get("Kernel_Name", ""))][r.get("Counter_Name")] += float(r["Counter_Value"])
     summary["SQ"] = {k: dict(v) for k, v in sq.items()}
+    # derived: lanes active per VALU instruction (SIMT efficiency) and VALU busy share of the wave lifetime
+    derived = {}
+    for k, v in sq.items():
+        if not k.startswith("k_"):
+            continue
+        dv = {}
+        if v.get("SQ_ACTIVE_INST_VALU") and v.get("SQ_THREAD_CYCLES_VALU"):
+            dv["valu_lane_utilization"] = v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"])
+        if v.get("SQ_WAVE_CYCLES") and v.get("SQ_ACTIVE_INST_VALU"):
+            dv["valu_active_share_of_wave_cycles"] = v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
+        if v.get("SQ_WAVE_CYCLES") and v.get("SQ_WAIT_INST_ANY"):
+            dv["issue_wait_share_of_wave_cycles"] = v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"]
+        if v.get("SQ_INSTS_VALU") and v.get("SQ_WAVES"):
+            dv["valu_instructions_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
+        derived[k] = dv
+    summary["derived"] = derived
     with open(os.path.join(prof, "%s_summary.json" % tag), "w") as fh:
         json.dump(summary, fh, indent=1, sort_keys=True)
     print(json.dumps(summary, indent=1, sort_keys=True)[:6000])
