@@ -185,6 +185,7 @@ class Library:
         self._device_info = bind("device_info", C.c_char_p, [], required=False)
         self._output_film = bind("output_film", C.c_int32, [C.POINTER(OutputDesc), fpp, C.POINTER(C.c_uint8), fpp], required=False)
         self._write_png = bind("write_png", C.c_int32, [C.c_char_p, u32, u32, C.POINTER(C.c_uint8), C.c_int32], required=False)
+        self._debug_scene_info = bind("debug_scene_info", u32, [vp, C.c_int32], required=False)
         self._write_exr = bind("write_exr", C.c_int32, [C.c_char_p, u32, u32, fpp, C.c_int32], required=False)
 
     def last_error(self):
@@ -243,6 +244,10 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+    def uses_leaf_sweep(self):
+        """True when closest-hit queries on this scene take the leaf sweep (<= 64 leaves) instead of the BVH walk."""
+        return bool(self.library._debug_scene_info(self.handle, 4))
 
     def render(self, rd):
         film = np.zeros((rd.height, rd.width, 4), dtype=np.float32)

@@ -95,11 +95,29 @@
 #define PT_HDR_IMAP_ROW_CMF 27
 #define PT_HDR_IMAP_MARG_PDF 28
 #define PT_HDR_IMAP_MARG_CMF 29
+#define PT_HDR_SWEEP_OFF 30        /* leaf sweep table (0 = none): scenes with <= 64 leaves, see world_hit_sweep */
+#define PT_HDR_SWEEP_COUNT 31      /* instances in top-level pre-order */
 #define PT_HDR_ENV_FORWARD 32      /* 12 floats: rows 0..2 of the rotation */
 #define PT_HDR_ENV_REVERSE 44      /* 12 floats */  /* per light: word offset of its top-level leaf node (its box gates the instance test) */
 #define PT_FLAG_EXACT_SLAB 2u    /* diagnostics (PT_AMD_EXACT_SLAB=1): always take the six-division slab test */
 #define PT_FLAG_NO_CULL 4u       /* diagnostics (PT_AMD_NO_CULL=1): never cull by the closest hit */
 #define PT_FLAG_NO_SHADOW_BOUND 8u /* a mesh instance can produce a Light-tagged hit: the light pre-pass of shadow rays is off */
+#define PT_FLAG_NO_SWEEP 16u      /* diagnostics (PT_AMD_NO_SWEEP=1): always walk the BVHs */
 #define PT_FLAG_NO_TOP_CULL 1u   /* a Disk instance exists: its reference box (radius/2, disk.rs:24-28) does not contain it */
+
+// Leaf sweep table (world_hit_sweep).  One mask bit per top-level leaf (instance) and per triangle leaf, numbered in
+// traversal pre-order: instance j gets bit `first`, its triangle leaves first+1 .. first+count.
+// Per instance, in the pre-order of the top-level BVH's leaves (12 words):
+//   [0] instance record offset, [1] instance id, [2] kind | flat << 8 | has_transform << 9, [3] first mask bit,
+//   [4..6] box min, [7] triangle-leaf list offset, [8..10] box max, [11] triangle-leaf count
+// Triangle leaf (8 words, in the pre-order of the mesh BVH's leaves): [0..2] box min, [3] triangle word offset, [4..6] box max, [7] flat
+// Bit table (PT_HDR_SWEEP_BITS_OFF): per mask bit 4 words: instance record offset, triangle word offset (0: the instance
+// itself), box word offset (min at +0, max at +4), kind | flat << 8 | has_transform << 9 | instance id << 16
+#define PT_SWEEP_INST_WORDS 12
+#define PT_SWEEP_TRI_WORDS 8
+#define PT_SWEEP_BIT_WORDS 4
+#define PT_SWEEP_MAX_BITS 64
+#define PT_HDR_SWEEP_BITS_OFF 56
+#define PT_HDR_SWEEP_MESH_MASK 57  /* 2 words: the bits that stand for mesh instances (no primitive of their own) */
 
 #endif

@@ -266,6 +266,30 @@ PT_HD bool aabb_hit(F4 a, F4 b, const RayPrep& rp, float* entry) {
 // primitives lie inside their boxes, except the reference's half-size Disk box for which culling is switched off).
 PT_HD bool beyond(float entry, float closest, float base) { return entry > closest * 1.00001f + base; }
 
+// Three-way form of the filtered test for the leaf sweep: 1 = hit, 0 = miss, 2 = too close to call (the caller settles it
+// with aabb_hit_exact).  Requires rp.fast and no zero direction component.  `flat` (a box of zero thickness, known per leaf
+// on the host) selects the per-axis form above; other boxes use the plain comparison of max entry and min exit, whose
+// approximation error is covered by the same margin.
+PT_HD int aabb_classify(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry) {
+    PT_STAT(box_tests);
+    float p0 = approx_fma(a.x, rp.r.x, rp.nor.x), q0 = approx_fma(b.x, rp.r.x, rp.nor.x);
+    float p1 = approx_fma(a.y, rp.r.y, rp.nor.y), q1 = approx_fma(b.y, rp.r.y, rp.nor.y);
+    float p2 = approx_fma(a.z, rp.r.z, rp.nor.z), q2 = approx_fma(b.z, rp.r.z, rp.nor.z);
+    float n0 = __builtin_fminf(p0, q0), x0 = __builtin_fmaxf(p0, q0), n1 = __builtin_fminf(p1, q1), x1 = __builtin_fmaxf(p1, q1);
+    float n2 = __builtin_fminf(p2, q2), x2 = __builtin_fmaxf(p2, q2);
+    if (!flat) {
+        float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(n0, n1), n2), 0.0f), hi = __builtin_fminf(__builtin_fminf(x0, x1), x2);
+        float e = approx_fma(PT_SLAB_EPS, lo + pt_abs(hi), rp.base), gap = lo - hi;
+        *entry = lo;
+        return gap > e ? 0 : (gap < -e ? 1 : 2);
+    }
+    float m0 = __builtin_fmaxf(__builtin_fmaxf(n1, n2), 0.0f), m1 = __builtin_fmaxf(__builtin_fmaxf(n0, n2), 0.0f), m2 = __builtin_fmaxf(__builtin_fmaxf(n0, n1), 0.0f);
+    float e0 = approx_fma(PT_SLAB_EPS, m0 + pt_abs(x0), rp.base), e1 = approx_fma(PT_SLAB_EPS, m1 + pt_abs(x1), rp.base), e2 = approx_fma(PT_SLAB_EPS, m2 + pt_abs(x2), rp.base);
+    *entry = __builtin_fmaxf(m0, n0);
+    if (m0 > x0 + e0 || m1 > x1 + e1 || m2 > x2 + e2) return 0;
+    return (m0 < x0 - e0 && m1 < x1 - e1 && m2 < x2 - e2) ? 1 : 2;
+}
+
 // MeshTriangleRef::hit (src/geometry/mesh.rs:67-198), split: the per-ray part (axis permutation and shear constants,
 // mesh.rs:79-99) is computed once per mesh visit, the interval test per triangle, the HitRecord only for the triangle
 // that survives as closest.
@@ -396,7 +420,169 @@ PT_HD void instance_local_ray(const SceneView& s, uint32_t inst, F3 o, F3 d, F3*
     if (bu(s, inst + PT_INST_FLAGS) & 1u) { *lo = xf_point(s, inst + PT_INST_REVERSE, o); *ld = xf_vec(s, inst + PT_INST_REVERSE, d); }
     else { *lo = o; *ld = d; }
 }
-PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_INF, bool stop_on_nonlight = false) {
+// HitRecord of the winning primitive (Instance::hit, instance.rs:89-131; mesh.rs:160-197): `triw` is the word offset of the
+// winning triangle, or 0 for an analytic instance, whose test is re-run (the accepted root does not depend on the upper
+// bound it was tested against).
+PT_HD void hit_record(const SceneView& s, F3 o, F3 d, uint32_t best_inst, uint32_t triw, const TriHit& bh, Hit* out) {
+    uint32_t inst = bu(s, PT_HDR_INSTANCE_OFF) + best_inst * PT_INST_WORDS;
+    F3 lo, ld;
+    instance_local_ray(s, inst, o, d, &lo, &ld);
+    Hit h;
+    if (triw != 0u) {
+        uint32_t mesh = bu(s, inst + PT_INST_MESH);
+        uint32_t normal_off = bu(s, mesh + PT_MESH_NORMAL_OFF);
+        F4 q0 = bf4(s, triw), q1 = bf4(s, triw + 4), q2 = bf4(s, triw + 8);
+        F3 p0 = f3(q0.x, q0.y, q0.z), p1 = f3(q1.x, q1.y, q1.z), p2 = f3(q2.x, q2.y, q2.z);
+        F3 n = normalize(cross(sub(p0, p2), sub(p1, p2)));
+        if (normal_off != 0) {
+            uint32_t nn = normal_off + (triw - bu(s, mesh + PT_MESH_TRI_OFF));
+            F4 m0 = bf4(s, nn), m1 = bf4(s, nn + 4), m2 = bf4(s, nn + 8);
+            n = add(add(mul(f3(m0.x, m0.y, m0.z), bh.b0), mul(f3(m1.x, m1.y, m1.z), bh.b1)), mul(f3(m2.x, m2.y, m2.z), bh.b2));
+        }
+        h.t = bh.t;
+        h.p = add(add(mul(p0, bh.b0), mul(p1, bh.b1)), mul(p2, bh.b2));
+        h.u = 0.0f; h.v = 0.0f;
+        h.n = normalize(n);
+        h.material = pt_f2u(q0.w);
+    } else {
+        analytic_hit(s, inst, bu(s, inst + PT_INST_KIND), lo, ld, PT_INF, &h);
+    }
+    if (bu(s, inst + PT_INST_FLAGS) & 1u) {
+        h.n = normalize(xf_vec_transposed(s, inst + PT_INST_REVERSE, h.n));
+        h.p = xf_point(s, inst + PT_INST_FORWARD, h.p);
+    }
+    h.instance = best_inst;
+    uint32_t m = bu(s, inst + PT_INST_MATERIAL);
+    if (m != PT_MATERIAL_NONE) h.material = m;
+    h.valid = true;
+    *out = h;
+}
+
+// ---- leaf sweep: World::hit for scenes of at most 64 leaves ------------------------------------------------------------
+// The reference's walk tests exactly the leaves whose own box passes AABB::hit (a triangle leaf: its box and its
+// instance's box) — ancestor boxes contain them and the slab test is monotone under rounding, so they pass too — in
+// pre-order, against the running closest hit.  For a scene this small the tree walk is therefore replaced by
+//   1. a sweep over ALL leaf boxes with wave-uniform addresses and no divergence (every lane of the wave executes the
+//      same box test on the same box), collecting per lane a 64-bit mask of hit leaves and a mask of undecided ones,
+//   2. the exact six-division test for the undecided bits only,
+//   3. the primitive tests of the lane's hit leaves in bit order = pre-order.
+// Same leaves, same order, same arithmetic as world_hit: same bits.  The tree walk keeps 32 % of the VALU lanes busy
+// (profiles/r1c); here step 1, the bulk of the work, keeps all of them busy.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
+#define PT_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* a value every lane of the wave holds */
+#else
+#define PT_WAVE_ANY(x) (x)
+#define PT_UNIFORM(x) (x)
+#endif
+PT_HD uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
+PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, bool stop_on_nonlight) {
+    const uint32_t NONE = 0xffffffffu;
+    const uint32_t flags = bu(s, PT_HDR_FLAGS), sweep = bu(s, PT_HDR_SWEEP_OFF), count = bu(s, PT_HDR_SWEEP_COUNT), bits_off = bu(s, PT_HDR_SWEEP_BITS_OFF);
+    const bool exact = (flags & PT_FLAG_EXACT_SLAB) != 0;
+    const bool cull_top = (flags & (PT_FLAG_NO_TOP_CULL | PT_FLAG_NO_CULL)) == 0, cull_mesh = (flags & PT_FLAG_NO_CULL) == 0;
+    const RayPrep wr = ray_prepare(o, d);
+    const bool quick = wr.fast && !exact && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f;
+    const bool bounded = bound < PT_INF;
+    // the masks are built as 32-bit halves: the bit index is wave-uniform, so the half is chosen by a scalar branch and a
+    // leaf costs one select + one or per mask
+    uint32_t hit_lo = 0, hit_hi = 0, unc_lo = 0, unc_hi = 0;
+    PT_STAT_EVENT(0);
+    PT_STAT_RAY(o, d);
+    // 1 — the sweep.  `bound` culls leaves that start beyond the distance the caller cares about (shadow rays).
+    for (uint32_t j = 0; j < count; ++j) {
+        const uint32_t e = PT_UNIFORM(sweep + j * PT_SWEEP_INST_WORDS);
+        const F4 h0 = bf4(s, e), a = bf4(s, e + 4), b = bf4(s, e + 8);
+        const uint32_t kf = PT_UNIFORM(pt_f2u(h0.z)), bit = PT_UNIFORM(pt_f2u(h0.w));
+        float entry = 0.0f;
+        int c = quick ? aabb_classify(a, b, wr, (kf & 0x100u) != 0, &entry) : 2;
+        if (bounded && c == 1 && cull_top && beyond(entry, bound, wr.base)) c = 0;
+        {
+            const uint32_t m = 1u << (bit & 31u);
+            if (bit < 32u) { hit_lo |= c == 1 ? m : 0u; unc_lo |= c == 2 ? m : 0u; } else { hit_hi |= c == 1 ? m : 0u; unc_hi |= c == 2 ? m : 0u; }
+        }
+        if ((kf & 0xffu) == PT_SHAPE_MESH && PT_WAVE_ANY(c != 0)) {
+            const uint32_t tl = PT_UNIFORM(pt_f2u(a.w)), tc = PT_UNIFORM(pt_f2u(b.w));
+            RayPrep lr = wr; bool lquick = quick;
+            if (kf & 0x200u) {
+                F3 lo, ld;
+                instance_local_ray(s, pt_f2u(h0.x), o, d, &lo, &ld);
+                lr = ray_prepare(lo, ld);
+                lquick = lr.fast && !exact && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f;
+            }
+            for (uint32_t t = 0; t < tc; ++t) {
+                const F4 ta = bf4(s, tl + t * PT_SWEEP_TRI_WORDS), tb = bf4(s, tl + t * PT_SWEEP_TRI_WORDS + 4);
+                int ct = lquick ? aabb_classify(ta, tb, lr, PT_UNIFORM(pt_f2u(tb.w)) != 0u, &entry) : 2;
+                if (bounded && ct == 1 && cull_mesh && beyond(entry, bound, lr.base)) ct = 0;
+                if (c == 0) ct = 0;
+                const uint32_t tbit = bit + 1 + t, m = 1u << (tbit & 31u);
+                if (tbit < 32u) { hit_lo |= ct == 1 ? m : 0u; unc_lo |= ct == 2 ? m : 0u; } else { hit_hi |= ct == 1 ? m : 0u; unc_hi |= ct == 2 ? m : 0u; }
+            }
+        }
+    }
+    uint64_t hit = (uint64_t)hit_lo | (uint64_t)hit_hi << 32, unc = (uint64_t)unc_lo | (uint64_t)unc_hi << 32;
+    // 2 — settle the undecided boxes, ascending, so that an instance box is settled before its triangles'
+    while (unc != 0) {
+        const uint32_t k = ctz64(unc);
+        unc &= unc - 1;
+        const F4 be = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS);
+        const uint32_t inst = pt_f2u(be.x), triw = pt_f2u(be.y), box = pt_f2u(be.z), kf = pt_f2u(be.w);
+        F3 ro = o, rd = d;
+        if (triw != 0u) instance_local_ray(s, inst, o, d, &ro, &rd);
+        float entry;
+        PT_STAT(box_exact);
+        bool h = aabb_hit_exact(bf4(s, box), bf4(s, box + 4), ro, rd, &entry);
+        if (bounded && h && (triw != 0u ? cull_mesh : cull_top) && beyond(entry, bound, 0.0f)) h = false;
+        if (h) hit |= 1ull << k;
+        else if (triw == 0u && (kf & 0xffu) == PT_SHAPE_MESH) {
+            const uint32_t tc = pt_f2u(bf4(s, box + 4).w);  // triangle-leaf count rides in the instance entry's max.w
+            const uint64_t range = (tc + 1 >= 64 ? ~0ull : ((1ull << (tc + 1)) - 1)) << k;
+            hit &= ~range; unc &= ~range;
+        }
+    }
+    hit &= ~((uint64_t)bu(s, PT_HDR_SWEEP_MESH_MASK) | (uint64_t)bu(s, PT_HDR_SWEEP_MESH_MASK + 1) << 32);
+    // 3 — primitive tests in pre-order (ties are broken by that order, as in world_hit)
+    const TriRay wtr = tri_ray_prepare(o, d);
+    float closest = PT_INF;
+    uint32_t best_inst = NONE, best_triw = 0;
+    TriHit bh; bh.t = 0.0f; bh.b0 = bh.b1 = bh.b2 = 0.0f;
+    while (hit != 0) {
+        const uint32_t k = ctz64(hit);
+        hit &= hit - 1;
+        const F4 be = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS);
+        const uint32_t inst = pt_f2u(be.x), triw = pt_f2u(be.y), kf = pt_f2u(be.w);
+        PT_STAT_EVENT(triw != 0u ? 3 : 4);
+        if (triw != 0u) {
+            const F4 q0 = bf4(s, triw), q1 = bf4(s, triw + 4), q2 = bf4(s, triw + 8);
+            TriRay tr = wtr;
+            if (kf & 0x200u) { F3 lo, ld; instance_local_ray(s, inst, o, d, &lo, &ld); tr = tri_ray_prepare(lo, ld); }
+            TriHit th;
+            if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, closest, &th)) {
+                closest = th.t; best_inst = kf >> 16; best_triw = triw; bh = th;
+                if (stop_on_nonlight && closest < bound) {
+                    uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+                    if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) hit = 0;  // something opaque in front of every light
+                }
+            }
+        } else {
+            F3 lo, ld;
+            instance_local_ray(s, inst, o, d, &lo, &ld);
+            Hit h;
+            if (analytic_hit(s, inst, kf & 0xffu, lo, ld, closest, &h)) {
+                closest = h.t; best_inst = kf >> 16; best_triw = 0;
+                if (stop_on_nonlight && closest < bound) {
+                    uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+                    if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : h.material) != PT_TAG_LIGHT) hit = 0;
+                }
+            }
+        }
+    }
+    if (best_inst == NONE) { out->valid = false; return false; }
+    hit_record(s, o, d, best_inst, best_triw, bh, out);
+    return true;
+}
+
+PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound, bool stop_on_nonlight) {
     const uint32_t NONE = 0xffffffffu;
     const uint32_t flags = bu(s, PT_HDR_FLAGS);
     const uint32_t top_off = bu(s, PT_HDR_TOP_NODE_OFF), top_count = bu(s, PT_HDR_TOP_NODE_COUNT), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
@@ -483,41 +669,21 @@ PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_
         }
     }
     if (best_inst == NONE) { out->valid = false; return false; }
-    // HitRecord of the winner (Instance::hit, instance.rs:89-131)
-    uint32_t inst = inst_off + best_inst * PT_INST_WORDS;
-    F3 lo, ld;
-    instance_local_ray(s, inst, o, d, &lo, &ld);
-    Hit h;
-    if (best_tri != NONE) {
-        uint32_t mesh = bu(s, inst + PT_INST_MESH);
-        uint32_t t = bu(s, mesh + PT_MESH_TRI_OFF) + best_tri * PT_TRI_WORDS, normal_off = bu(s, mesh + PT_MESH_NORMAL_OFF);
-        F4 q0 = bf4(s, t), q1 = bf4(s, t + 4), q2 = bf4(s, t + 8);
-        F3 p0 = f3(q0.x, q0.y, q0.z), p1 = f3(q1.x, q1.y, q1.z), p2 = f3(q2.x, q2.y, q2.z);
-        F3 n = normalize(cross(sub(p0, p2), sub(p1, p2)));
-        if (normal_off != 0) {
-            uint32_t nn = normal_off + best_tri * PT_TRI_WORDS;
-            F4 m0 = bf4(s, nn), m1 = bf4(s, nn + 4), m2 = bf4(s, nn + 8);
-            n = add(add(mul(f3(m0.x, m0.y, m0.z), bh.b0), mul(f3(m1.x, m1.y, m1.z), bh.b1)), mul(f3(m2.x, m2.y, m2.z), bh.b2));
-        }
-        h.t = bh.t;
-        h.p = add(add(mul(p0, bh.b0), mul(p1, bh.b1)), mul(p2, bh.b2));
-        h.u = 0.0f; h.v = 0.0f;
-        h.n = normalize(n);
-        h.material = pt_f2u(q0.w);
-    } else {
-        // the accepted root of an analytic primitive does not depend on the upper bound it was tested against
-        analytic_hit(s, inst, bu(s, inst + PT_INST_KIND), lo, ld, PT_INF, &h);
-    }
-    if (bu(s, inst + PT_INST_FLAGS) & 1u) {
-        h.n = normalize(xf_vec_transposed(s, inst + PT_INST_REVERSE, h.n));
-        h.p = xf_point(s, inst + PT_INST_FORWARD, h.p);
-    }
-    h.instance = best_inst;
-    uint32_t m = bu(s, inst + PT_INST_MATERIAL);
-    if (m != PT_MATERIAL_NONE) h.material = m;
-    h.valid = true;
-    *out = h;
+    uint32_t mesh = bu(s, inst_off + best_inst * PT_INST_WORDS + PT_INST_MESH);
+    hit_record(s, o, d, best_inst, best_tri != NONE ? bu(s, mesh + PT_MESH_TRI_OFF) + best_tri * PT_TRI_WORDS : 0u, bh, out);
     return true;
+}
+
+// TRAV: PT_TRAV_ANY picks the form at run time (host emulation, probes); the render kernels are instantiated once per form
+// so that each keeps its own register budget.
+#define PT_TRAV_ANY 0
+#define PT_TRAV_WALK 1
+#define PT_TRAV_SWEEP 2
+PT_HD bool scene_uses_sweep(const SceneView& s) { return bu(s, PT_HDR_SWEEP_OFF) != 0u && !(bu(s, PT_HDR_FLAGS) & PT_FLAG_NO_SWEEP); }
+template <int TRAV = PT_TRAV_ANY>
+PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_INF, bool stop_on_nonlight = false) {
+    if (TRAV == PT_TRAV_SWEEP || (TRAV == PT_TRAV_ANY && scene_uses_sweep(s))) return world_hit_sweep(s, o, d, out, bound, stop_on_nonlight);
+    return world_hit_walk(s, o, d, out, bound, stop_on_nonlight);
 }
 
 // Nearest hit among the light instances that the reference's walk would test for this ray (an instance is tested iff

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(RenderParams rp, const uint
     if (threadIdx.x == 0) count_out[blockIdx.x] = cnt;
 }
 
-template <bool USE_LDS>
+template <bool USE_LDS, int TRAV>
 __global__ void __launch_bounds__(kBlock) k_extend(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                   Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(kBlock) k_extend(const uint32_t* __restrict__ 
         F3 o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
         F3 d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
         Hit h;
-        world_hit(s, o, d, &h);
+        world_hit<TRAV>(s, o, d, &h);
         store_hit(hits, i, h);
     }
 }
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(const uint32_t* __restrict__ b
     }
 }
 
-template <bool USE_LDS, int NL>
+template <bool USE_LDS, int NL, int TRAV>
 __global__ void __launch_bounds__(kBlock) k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                   uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                   uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(const uint32_t* __restrict__ 
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
     uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
     for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
-        stage_shadow_item<NL>(s, light_samples, shadow, base + j, energy, energy_stride);
+        stage_shadow_item<NL, TRAV>(s, light_samples, shadow, base + j, energy, energy_stride);
     }
 }
 
@@ -401,6 +401,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
 
     const uint32_t blob_bytes = sc->blob_words * 4;
     const bool lds = sc->use_lds;
+    const bool sweep = sc->host.blob[PT_HDR_SWEEP_OFF] != 0 && !(sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP);
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
     const bool timing = env_u32("PT_AMD_STAGE_TIMING", 1) != 0;
     double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0};
@@ -444,8 +445,11 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
             Queue qin = (bounce & 1) ? qb : qa, qout = (bounce & 1) ? qa : qb;
             uint32_t *cin = live[bounce & 1], *cout = live[(bounce + 1) & 1];
             timed(ST_EXTEND, [&] {
-                if (lds) launch(k_extend<true>, true, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin);
-                else launch(k_extend<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin);
+#define PT_LAUNCH_EXTEND(LDSF, TRAVV) launch(k_extend<LDSF, TRAVV>, LDSF, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin)
+                if (!lds) PT_LAUNCH_EXTEND(false, PT_TRAV_ANY);
+                else if (sweep) PT_LAUNCH_EXTEND(true, PT_TRAV_SWEEP);
+                else PT_LAUNCH_EXTEND(true, PT_TRAV_WALK);
+#undef PT_LAUNCH_EXTEND
             });
             timed(ST_SHADE, [&] {
 #define PT_LAUNCH_SHADE(LDSF, NLV) launch(k_shade<LDSF, NLV>, LDSF, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rp, bounce, d_px, qin, qh, qout, qs, \
@@ -456,10 +460,11 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
             });
             if (rd.light_samples > 0)
                 timed(ST_SHADOW, [&] {
-#define PT_LAUNCH_SHADOW(LDSF, NLV) launch(k_shadow<LDSF, NLV>, LDSF, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, \
+#define PT_LAUNCH_SHADOW(LDSF, NLV, TRAVV) launch(k_shadow<LDSF, NLV, TRAVV>, LDSF, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, \
                                           b.capacity, seg_cap, nshadow)
-                    if (lds) { if (hero) PT_LAUNCH_SHADOW(true, 4); else PT_LAUNCH_SHADOW(true, 1); }
-                    else { if (hero) PT_LAUNCH_SHADOW(false, 4); else PT_LAUNCH_SHADOW(false, 1); }
+                    if (!lds) { if (hero) PT_LAUNCH_SHADOW(false, 4, PT_TRAV_ANY); else PT_LAUNCH_SHADOW(false, 1, PT_TRAV_ANY); }
+                    else if (sweep) { if (hero) PT_LAUNCH_SHADOW(true, 4, PT_TRAV_SWEEP); else PT_LAUNCH_SHADOW(true, 1, PT_TRAV_SWEEP); }
+                    else { if (hero) PT_LAUNCH_SHADOW(true, 4, PT_TRAV_WALK); else PT_LAUNCH_SHADOW(true, 1, PT_TRAV_WALK); }
 #undef PT_LAUNCH_SHADOW
                 });
         }
@@ -545,6 +550,7 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     sc->num_cus = prop.multiProcessorCount;
     if (env_u32("PT_AMD_EXACT_SLAB", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_EXACT_SLAB;
     if (env_u32("PT_AMD_NO_CULL", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_CULL;
+    if (env_u32("PT_AMD_NO_SWEEP", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_SWEEP;
     sc->blob_words = (uint32_t)sc->host.blob.size();
     sc->use_lds = sc->blob_words * 4 <= kLdsBlobLimitBytes && env_u32("PT_AMD_NO_LDS", 0) == 0;
     e = hipMalloc(&sc->d_blob, sizeof(uint32_t) * sc->host.blob.size());
@@ -553,11 +559,14 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     if (e == hipSuccess) e = hipMemcpy(sc->d_tex, sc->host.tex.data(), sizeof(float) * sc->host.tex.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { pt_scene_destroy(sc); return fail(e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE, hipGetErrorString(e)); }
     if (sc->use_lds) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend<true, PT_TRAV_WALK>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend<true, PT_TRAV_SWEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 1, PT_TRAV_WALK>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 1, PT_TRAV_SWEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 4, PT_TRAV_WALK>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 4, PT_TRAV_SWEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_intersect<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
     }
     *out = sc;
@@ -645,7 +654,8 @@ pt_status pt_debug_numerics(int which, size_t n, const float* x, const float* y,
 
 // Not part of pt_api.h: size of the scene blob and whether kernels read it from LDS (reported by bench.py).
 uint32_t pt_debug_scene_info(pt_scene* sc, int what) {
-    switch (what) { case 0: return sc->blob_words * 4; case 1: return sc->use_lds ? 1u : 0u; case 2: return sc->host.light_count; case 3: return (uint32_t)sc->num_cus; default: return 0; }
+    switch (what) { case 0: return sc->blob_words * 4; case 1: return sc->use_lds ? 1u : 0u; case 2: return sc->host.light_count; case 3: return (uint32_t)sc->num_cus;
+                    case 4: return sc->host.blob[PT_HDR_SWEEP_OFF] != 0 && !(sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP) ? 1u : 0u; default: return 0; }
 }
 
 }  // extern "C"

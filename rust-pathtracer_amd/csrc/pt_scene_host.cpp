@@ -213,7 +213,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
     }
 
     // meshes: per-mesh BVH over triangles (Mesh::init, mesh.rs:283-305) + gathered triangle records
-    std::vector<uint32_t> mesh_off(d.mesh_count);
+    std::vector<uint32_t> mesh_off(d.mesh_count), mesh_node_off(d.mesh_count), mesh_node_count(d.mesh_count);
     std::vector<Box> mesh_box(d.mesh_count);
     hs->mesh_has_light.assign(d.mesh_count, 0);
     std::vector<uint32_t> mesh_light_faces(d.mesh_count, 0);
@@ -239,6 +239,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
         uint32_t node_off = (uint32_t)w.size();
         std::vector<uint32_t> nodes; BvhBuilder bb(tb, nodes); bb.build();
         w.insert(w.end(), nodes.begin(), nodes.end());
+        mesh_node_off[mi] = node_off; mesh_node_count[mi] = (uint32_t)(nodes.size() / PT_NODE_WORDS);
         uint32_t tri_off = (uint32_t)w.size();
         for (uint32_t f = 0; f < m.face_count; ++f) {
             const uint32_t* ix = d.indices + m.index_offset + 3 * (size_t)f;
@@ -339,6 +340,56 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
         pad16(w);
         w[PT_HDR_LIGHT_NODE_OFF] = (uint32_t)w.size();
         for (uint32_t l : lights) w.push_back(top + bb.leaf_of_shape[l] * PT_NODE_WORDS);
+        // ---- leaf sweep table (world_hit_sweep): every leaf box of both levels, in traversal pre-order, when 64 mask bits suffice
+        size_t sweep_bits = 0;
+        for (uint32_t i = 0; i < d.instance_count; ++i) sweep_bits += d.instances[i].kind == PT_SHAPE_MESH ? 1 + (size_t)d.meshes[d.instances[i].mesh].face_count : 1;
+        if (d.instance_count > 0 && sweep_bits <= PT_SWEEP_MAX_BITS) {
+            auto is_flat = [](const uint32_t* node) { return node[0] == node[4] || node[1] == node[5] || node[2] == node[6]; };
+            pad16(w);
+            std::vector<uint32_t> order;  // top-level leaf nodes in pre-order
+            for (size_t k = 0; k < nodes.size() / PT_NODE_WORDS; ++k) if (nodes[k * PT_NODE_WORDS + 7] != PT_NODE_INNER) order.push_back((uint32_t)k);
+            uint32_t sweep_off = (uint32_t)w.size();
+            w.resize(w.size() + order.size() * PT_SWEEP_INST_WORDS, 0);
+            std::vector<uint32_t> bits;
+            uint32_t bit = 0;
+            uint64_t mesh_mask = 0;
+            for (size_t j = 0; j < order.size(); ++j) {
+                const uint32_t* nd = &nodes[order[j] * PT_NODE_WORDS];
+                uint32_t inst = nd[7];
+                const pt_instance& in = d.instances[inst];
+                uint32_t e = sweep_off + (uint32_t)j * PT_SWEEP_INST_WORDS;
+                uint32_t rec_off = w[PT_HDR_INSTANCE_OFF] + inst * PT_INST_WORDS;
+                uint32_t kf = (uint32_t)in.kind | (is_flat(nd) ? 1u << 8 : 0u) | (in.has_transform ? 1u << 9 : 0u);
+                uint32_t tri_list = 0, tri_count = 0, first_bit = bit++;
+                uint32_t own[PT_SWEEP_BIT_WORDS] = {rec_off, 0u, e + 4, kf | inst << 16};
+                bits.insert(bits.end(), own, own + PT_SWEEP_BIT_WORDS);
+                if (in.kind == PT_SHAPE_MESH) {
+                    mesh_mask |= 1ull << first_bit;
+                    pad16(w);
+                    tri_list = (uint32_t)w.size();
+                    uint32_t tri_base = w[mesh_off[in.mesh] + PT_MESH_TRI_OFF];
+                    for (uint32_t k = 0; k < mesh_node_count[in.mesh]; ++k) {
+                        uint32_t mn[PT_NODE_WORDS];
+                        for (int q = 0; q < PT_NODE_WORDS; ++q) mn[q] = w[mesh_node_off[in.mesh] + k * PT_NODE_WORDS + q];
+                        if (mn[7] == PT_NODE_INNER) continue;
+                        uint32_t triw = tri_base + mn[7] * PT_TRI_WORDS, flat = is_flat(mn) ? 1u : 0u;
+                        uint32_t rec[PT_SWEEP_TRI_WORDS] = {mn[0], mn[1], mn[2], triw, mn[4], mn[5], mn[6], flat};
+                        uint32_t tb[PT_SWEEP_BIT_WORDS] = {rec_off, triw, (uint32_t)w.size(), (kf & ~0x100u) | flat << 8 | inst << 16};
+                        w.insert(w.end(), rec, rec + PT_SWEEP_TRI_WORDS);
+                        bits.insert(bits.end(), tb, tb + PT_SWEEP_BIT_WORDS);
+                        ++tri_count; ++bit;
+                    }
+                }
+                uint32_t* r = &w[e];
+                r[0] = rec_off; r[1] = inst; r[2] = kf; r[3] = first_bit;
+                r[4] = nd[0]; r[5] = nd[1]; r[6] = nd[2]; r[7] = tri_list; r[8] = nd[4]; r[9] = nd[5]; r[10] = nd[6]; r[11] = tri_count;
+            }
+            pad16(w);
+            w[PT_HDR_SWEEP_BITS_OFF] = (uint32_t)w.size();
+            w.insert(w.end(), bits.begin(), bits.end());
+            w[PT_HDR_SWEEP_MESH_MASK] = (uint32_t)mesh_mask; w[PT_HDR_SWEEP_MESH_MASK + 1] = (uint32_t)(mesh_mask >> 32);
+            w[PT_HDR_SWEEP_OFF] = sweep_off; w[PT_HDR_SWEEP_COUNT] = (uint32_t)order.size();
+        }
     }
     pad16(w);
 

@@ -327,16 +327,16 @@ PT_HD void clear_shadow_item(const Queue& q, uint32_t item, uint32_t light_sampl
 // Only a light that is the closest hit contributes, so the walk is bounded by the nearest light hit (nothing beyond it
 // can be the closest hit) and may stop at the first accepted non-light hit in front of it.  If no light is hit at all
 // the ray contributes nothing and is not walked.  The result is the reference's in every case.
-template <int NL>
+template <int NL, int TRAV = PT_TRAV_ANY>
 PT_HD void stage_shadow_light(const SceneView& s, const float* lambda, const ShadowRayT<NL>& ray, float* contribution) {
     for (int k = 0; k < NL; ++k) contribution[k] = 0.0f;
     Hit sh;
     if (bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_CULL)) {
-        if (!world_hit(s, ray.o, ray.d, &sh)) return;
+        if (!world_hit<TRAV>(s, ray.o, ray.d, &sh)) return;
     } else {
         float t_light = nearest_light_hit(s, ray.o, ray.d);
         if (!(t_light < PT_INF)) return;
-        if (!world_hit(s, ray.o, ray.d, &sh, t_light, true)) return;
+        if (!world_hit<TRAV>(s, ray.o, ray.d, &sh, t_light, true)) return;
     }
     if (PT_MATERIAL_TAG(sh.material) != PT_TAG_LIGHT) return;
     Frame lf = frame_from_normal(sh.n);
@@ -345,14 +345,14 @@ PT_HD void stage_shadow_light(const SceneView& s, const float* lambda, const Sha
     for (int k = 0; k < NL; ++k) contribution[k] = ray.factor[k] * pt_abs(lwi.z) * material_emission(s, lm, lambda[k], lwi);
 }
 // The environment-sample ray of pt.rs:252-330: contributes only if nothing is hit.
-template <int NL>
+template <int NL, int TRAV = PT_TRAV_ANY>
 PT_HD void stage_shadow_env(const SceneView& s, const ShadowRayT<NL>& ray, float* contribution) {
     Hit sh;
-    bool blocked = world_hit(s, ray.o, ray.d, &sh);
+    bool blocked = world_hit<TRAV>(s, ray.o, ray.d, &sh);
     for (int k = 0; k < NL; ++k) contribution[k] = blocked ? 0.0f : ray.factor[k];
 }
 // One light-sample item: L rays, summed in order, divided by L (pt.rs:349-392, 596)
-template <int NL>
+template <int NL, int TRAV = PT_TRAV_ANY>
 PT_HD void stage_shadow_item(const SceneView& s, uint32_t light_samples, const Queue& shadow, uint32_t item, float* energy, uint32_t energy_stride) {
     uint32_t slot = qu(shadow, Layout<NL>::sh_slot, item), flags = qu(shadow, Layout<NL>::sh_flags, item);
     float lambda[NL], lc[NL];
@@ -361,7 +361,7 @@ PT_HD void stage_shadow_item(const SceneView& s, uint32_t light_samples, const Q
         ShadowRayT<NL> ray;
         if (!load_shadow_ray<NL>(shadow, item, l, &ray)) continue;
         float c[NL];
-        if ((flags >> l) & 1u) stage_shadow_env<NL>(s, ray, c); else stage_shadow_light<NL>(s, lambda, ray, c);
+        if ((flags >> l) & 1u) stage_shadow_env<NL, TRAV>(s, ray, c); else stage_shadow_light<NL, TRAV>(s, lambda, ray, c);
         for (int k = 0; k < NL; ++k) lc[k] += c[k];
     }
     for (int k = 0; k < NL; ++k) energy[(size_t)k * energy_stride + slot] += lc[k] / (float)light_samples;

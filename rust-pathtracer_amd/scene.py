@@ -507,6 +507,47 @@ def mixed_primitives():
     return b
 
 
+def _octahedron():
+    """Unit octahedron with per-vertex normals (8 faces)."""
+    p = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+    f = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]], np.uint32)
+    return p, f, p.copy()
+
+
+def mixed_small():
+    """mixed_primitives at leaf-sweep size (<= 64 leaves in total, csrc/pt_device.h world_hit_sweep): every primitive kind,
+    transformed and untransformed meshes, vertex normals, axis-aligned and slanted triangles (not a reference scene)."""
+    b = SceneBuilder()
+    add_library_curves(b, ["simple_sky_blue"])
+    b.set_environment_constant(b.curve("simple_sky_blue"), 0.3)
+    b.env_sampling_probability = 0.25
+    light = add_library_material(b, "diffuse_light_flat_x5")
+    white = add_library_material(b, "lambertian_white")
+    red = add_library_material(b, "lambertian_red")
+    gold = add_library_material(b, "ggx_gold")
+    glass = add_library_material(b, "ggx_glass_rough")
+    b.add_rect((6, 6), (0.0, 0.0, -1.0), "Z", True, white)
+    b.add_rect((1.0, 1.0), (0.0, 0.0, 2.5), "Z", True, light)
+    b.add_disk(0.7, (0.0, 0.0, 0.0), True, light,
+               transform_from_data(rotate=[((0, 1, 0), 70.0)], translate=(2.0, 1.5, 1.0)))
+    b.add_sphere(0.6, (0.0, -1.2, -0.4), gold)
+    b.add_sphere(0.5, (0.0, 0.0, 0.0), glass, transform_from_data(scale=(1.0, 1.4, 0.8), translate=(0.3, 1.1, -0.3)))
+    b.add_rect((2.0, 3.0), (0.0, 2.5, 0.5), "Y", True, red)
+    p, f, n = _octahedron()
+    octa = b.add_mesh(p, f, n, face_materials=api.material_id(api.TAG_MATERIAL, 0))
+    b.add_mesh_instance(octa, glass, transform_from_data(scale=(0.5, 0.6, 0.7), rotate=[((0, 0, 1), 30.0), ((1, 0, 0), 15.0)],
+                                                         translate=(-0.8, 0.0, -0.3)))
+    b.add_mesh_instance(octa, gold, transform_from_data(scale=(0.3, 0.3, 0.3), translate=(0.2, -0.2, 0.9)))
+    # an untransformed mesh with faces in the coordinate planes (zero-thickness leaf boxes) and per-face materials
+    q = np.array([[1.0, -2.0, -1.0], [2.0, -2.0, -1.0], [2.0, -1.0, -1.0], [1.0, -1.0, -1.0], [1.0, -2.0, 0.2], [2.0, -2.0, 0.2]], np.float32)
+    g = np.array([[0, 1, 4], [1, 5, 4], [0, 4, 3], [1, 2, 5], [3, 4, 5], [3, 5, 2]], np.uint32)
+    fm = np.array([red, white, red, white, gold, gold], np.uint32)
+    wedge = b.add_mesh(q, g, None, face_materials=fm)
+    b.add_mesh_instance(wedge)
+    b.add_camera((-5.0, 0.3, 0.8), (0.0, 0.0, 0.0), 35.0, focal_distance=5.0, aperture_diameter=0.05)
+    return b
+
+
 def synthetic_hdri(width=1024, height=512):
     """Deterministic stand-in for the absent data/hdri/*.hdr: a sky gradient, a warm ground and one
     Gaussian "sun", linear RGB + alpha 0, float32, generated from a closed formula (no RNG).  Texel (x, y) is looked up
@@ -558,4 +599,4 @@ def hdri_c4_small():
 
 
 SCENES = {"hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
-          "mixed_primitives": mixed_primitives}
+          "mixed_primitives": mixed_primitives, "mixed_small": mixed_small}

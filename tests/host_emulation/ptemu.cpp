@@ -23,10 +23,17 @@ const char* ptemu_last_error(void) { return g_error.c_str(); }
 pt_status ptemu_scene_create(const pt_scene_desc* d, pt_scene** out) {
     pt_scene* sc = new pt_scene();
     if (!pth::build_host_scene(*d, &sc->host, &g_error)) { delete sc; return PT_ERR_INVALID_ARGUMENT; }
+    // the engine's diagnostic switches (pt_engine.hip: PT_AMD_EXACT_SLAB / NO_CULL / NO_SWEEP), as one flag word
+    const char* f = getenv("PTEMU_FLAGS");
+    if (f) sc->host.blob[PT_HDR_FLAGS] |= (uint32_t)strtoul(f, nullptr, 0);
     *out = sc;
     return PT_OK;
 }
 void ptemu_scene_destroy(pt_scene* sc) { delete sc; }
+uint32_t ptemu_debug_scene_info(pt_scene* sc, int what) {
+    if (what == 4) return sc->host.blob[PT_HDR_SWEEP_OFF] != 0 && !(sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP) ? 1u : 0u;
+    return 0;
+}
 
 }  // extern "C"
 template <int NL>

@@ -25,7 +25,7 @@ def emu(pkg):
     return pkg.api.Library(lib, "ptemu_", optional=("render_device", "device_info"))
 
 
-@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives", "white_furnace", "hdri_small"])
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives", "mixed_small", "white_furnace", "hdri_small"])
 def test_closest_hits_bit_exact(emu, oracle, scene):
     ps.intersect_parity(emu, oracle, scene)
 
@@ -43,9 +43,11 @@ def test_materials_bit_exact(emu, oracle, scene):
     ("cornell_box", 24, 24, 5, 3, {"min_bounces": 4}),        # roulette never active
     ("cornell_gem", 40, 24, 6, 12, {}),                       # C3 shape: dispersive GGX + transformed mesh
     ("mixed_primitives", 32, 32, 8, 6, {"light_samples": 3, "seed": 5}),
+    ("mixed_small", 32, 32, 8, 6, {"light_samples": 3, "seed": 6}),
     ("white_furnace", 16, 16, 12, 8, {"light_samples": 6}),
     ("cornell_box", 40, 36, 11, 6, {"hero_wavelengths": 4}),  # C5 shape: hero wavelength + 3 passengers
     ("mixed_primitives", 32, 32, 6, 6, {"hero_wavelengths": 4, "light_samples": 3}),
+    ("mixed_small", 32, 32, 6, 6, {"hero_wavelengths": 4, "light_samples": 2}),
     ("hdri_small", 32, 32, 8, 4, {"light_samples": 6}),       # C4 shape: HDR environment, importance map, env NEE + MIS
 ])
 def test_film_parity(emu, oracle, scene, w, h, spp, mb, kw):
@@ -72,3 +74,25 @@ def test_golden_vectors(emu):
         got, want = ps.golden_hits(emu, scene)
         ps.assert_hits_equal(got, want)
         ps.golden_materials(emu, scene)
+
+
+@pytest.mark.parametrize("scene", ["cornell_box", "mixed_small", "white_furnace"])
+def test_leaf_sweep_equals_bvh_walk(emu, pkg, monkeypatch, scene):
+    """Scenes of <= 64 leaves take world_hit_sweep; the BVH walk (flag 16), the exact slab test (2) and no culling (4)
+    must give the same bits: hits, films and ray counters."""
+    b = pkg.scene.SCENES[scene]()
+    o, d = ps.golden_rays(scene, 4096, 33)
+    # axis-parallel directions take the undecided path for every box
+    d[:64] = np.eye(3, dtype=np.float32)[np.arange(64) % 3] * np.where(np.arange(64) % 2, -1.0, 1.0)[:, None].astype(np.float32)
+    rd = pkg.api.render_desc(24, 24, 4, 5, light_samples=2)
+    results = []
+    for flags in ("0", "16", "2", "18", "4"):
+        monkeypatch.setenv("PTEMU_FLAGS", flags)
+        sc = emu.create_scene(b)
+        assert sc.uses_leaf_sweep() == (flags not in ("16", "18"))
+        film, prof = sc.render(rd)
+        results.append((sc.intersect(o, d), film, (prof.camera_rays, prof.bounce_rays, prof.shadow_rays, prof.env_hits)))
+    for hits, film, counts in results[1:]:
+        ps.assert_hits_equal(hits, results[0][0])
+        assert np.array_equal(film.view(np.uint32), results[0][1].view(np.uint32))
+        assert counts == results[0][2]

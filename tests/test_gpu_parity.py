@@ -46,7 +46,7 @@ def test_device_arithmetic_matches_x86(engine, oracle):
         assert np.array_equal(dev(10, x, y).view(np.uint32), ((x * y).astype(np.float32) + x).view(np.uint32))  # not fused
 
 
-@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives", "white_furnace", "hdri_small", "hdri_c4_small"])
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives", "mixed_small", "white_furnace", "hdri_small", "hdri_c4_small"])
 def test_closest_hits_bit_exact(engine, oracle, scene):
     ps.intersect_parity(engine, oracle, scene, n=1 << 16)
 
@@ -64,6 +64,7 @@ def test_materials_bit_exact(engine, oracle, scene):
     ("cornell_box", 64, 64, 13, 3, {"min_bounces": 4}),
     ("cornell_gem", 96, 54, 8, 12, {}),                       # C3 shape at reduced size
     ("mixed_primitives", 64, 64, 8, 6, {"light_samples": 3, "seed": 5}),
+    ("mixed_small", 64, 64, 8, 6, {"light_samples": 3, "seed": 6}),
     ("white_furnace", 32, 32, 12, 8, {"light_samples": 6}),
     ("hdri_small", 64, 64, 8, 4, {"light_samples": 6}),
     ("cornell_box", 128, 128, 12, 8, {"hero_wavelengths": 4}),      # C5 shape: four wavelengths per path

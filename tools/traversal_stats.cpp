@@ -21,6 +21,7 @@ static inline void pt_event(int code) {
 static std::vector<float> g_raydata;
 #define PT_STAT_RAY(o, d) do { g_raydata.push_back((o).x); g_raydata.push_back((o).y); g_raydata.push_back((o).z); g_raydata.push_back((d).x); g_raydata.push_back((d).y); g_raydata.push_back((d).z); } while (0)
 #include "../tests/host_emulation/ptemu.cpp"
+extern "C" void ptemu_set_flags(pt_scene* sc, unsigned flags) { sc->host.blob[PT_HDR_FLAGS] |= flags; }
 extern "C" size_t ptemu_trace_dump(int* out, size_t cap) {
     // flat: per ray: n_rounds, then (steps, leaf) pairs
     size_t k = 0;
