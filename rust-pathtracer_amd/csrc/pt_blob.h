@@ -110,12 +110,16 @@
 // Per instance, in the pre-order of the top-level BVH's leaves (12 words):
 //   [0] instance record offset, [1] instance id, [2] kind | flat << 8 | has_transform << 9, [3] first mask bit,
 //   [4..6] box min, [7] triangle-leaf list offset, [8..10] box max, [11] triangle-leaf count
-// Triangle leaf (8 words, in the pre-order of the mesh BVH's leaves): [0..2] box min, [3] triangle word offset, [4..6] box max, [7] flat
-// Bit table (PT_HDR_SWEEP_BITS_OFF): per mask bit 4 words: instance record offset, triangle word offset (0: the instance
-// itself), box word offset (min at +0, max at +4), kind | flat << 8 | has_transform << 9 | instance id << 16
+// Triangle leaf (8 words, in the pre-order of the mesh BVH's leaves): [0..2] box min, [3] triangle word offset, [4..6] box max,
+//   [7] flat | alias << 1: alias 0 = own box test; alias b + 1 = the box is bit-identical to that of mask bit b, which is tested
+//   against the same ray (the untransformed instance's own box, or an earlier triangle leaf of the instance — the two
+//   triangles of every planar quad share a box), so b's decision is copied instead of recomputed.
+// Bit table (PT_HDR_SWEEP_BITS_OFF): per mask bit 8 words: instance record offset, triangle word offset (0: the instance
+// itself), box word offset (min at +0, max at +4), kind | flat << 8 | has_transform << 9 | instance id << 16,
+// followers (2 words: the later bits that alias this one, directly or through a chain), 2 pad
 #define PT_SWEEP_INST_WORDS 12
 #define PT_SWEEP_TRI_WORDS 8
-#define PT_SWEEP_BIT_WORDS 4
+#define PT_SWEEP_BIT_WORDS 8
 #define PT_SWEEP_MAX_BITS 64
 #define PT_HDR_SWEEP_BITS_OFF 56
 #define PT_HDR_SWEEP_MESH_MASK 57  /* 2 words: the bits that stand for mesh instances (no primitive of their own) */

@@ -512,11 +512,20 @@ PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound
             }
             for (uint32_t t = 0; t < tc; ++t) {
                 const F4 ta = bf4(s, tl + t * PT_SWEEP_TRI_WORDS), tb = bf4(s, tl + t * PT_SWEEP_TRI_WORDS + 4);
-                int ct = lquick ? aabb_classify(ta, tb, lr, PT_UNIFORM(pt_f2u(tb.w)) != 0u, &entry) : 2;
-                if (bounded && ct == 1 && cull_mesh && beyond(entry, bound, lr.base)) ct = 0;
-                if (c == 0) ct = 0;
-                const uint32_t tbit = bit + 1 + t, m = 1u << (tbit & 31u);
-                if (tbit < 32u) { hit_lo |= ct == 1 ? m : 0u; unc_lo |= ct == 2 ? m : 0u; } else { hit_hi |= ct == 1 ? m : 0u; unc_hi |= ct == 2 ? m : 0u; }
+                const uint32_t tw = PT_UNIFORM(pt_f2u(tb.w)), tbit = bit + 1 + t, sh = tbit & 31u;
+                uint32_t th, tu;  // this leaf's hit / undecided bit, in place
+                if (tw >> 1) {
+                    // same box, same ray as an earlier bit: copy its decision (already gated by the instance's)
+                    const uint32_t sb = (tw >> 1) - 1u;
+                    th = (((sb < 32u ? hit_lo : hit_hi) >> (sb & 31u)) & 1u) << sh;
+                    tu = (((sb < 32u ? unc_lo : unc_hi) >> (sb & 31u)) & 1u) << sh;
+                } else {
+                    int ct = lquick ? aabb_classify(ta, tb, lr, (tw & 1u) != 0u, &entry) : 2;
+                    if (bounded && ct == 1 && cull_mesh && beyond(entry, bound, lr.base)) ct = 0;
+                    if (c == 0) ct = 0;
+                    th = ct == 1 ? 1u << sh : 0u; tu = ct == 2 ? 1u << sh : 0u;
+                }
+                if (tbit < 32u) { hit_lo |= th; unc_lo |= tu; } else { hit_hi |= th; unc_hi |= tu; }
             }
         }
     }
@@ -525,15 +534,17 @@ PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound
     while (unc != 0) {
         const uint32_t k = ctz64(unc);
         unc &= unc - 1;
-        const F4 be = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS);
+        const F4 be = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS), bg = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS + 4);
         const uint32_t inst = pt_f2u(be.x), triw = pt_f2u(be.y), box = pt_f2u(be.z), kf = pt_f2u(be.w);
+        const uint64_t followers = (uint64_t)pt_f2u(bg.x) | (uint64_t)pt_f2u(bg.y) << 32;  // copies of this decision
         F3 ro = o, rd = d;
         if (triw != 0u) instance_local_ray(s, inst, o, d, &ro, &rd);
         float entry;
         PT_STAT(box_exact);
         bool h = aabb_hit_exact(bf4(s, box), bf4(s, box + 4), ro, rd, &entry);
         if (bounded && h && (triw != 0u ? cull_mesh : cull_top) && beyond(entry, bound, 0.0f)) h = false;
-        if (h) hit |= 1ull << k;
+        unc &= ~followers;
+        if (h) hit |= 1ull << k | followers;
         else if (triw == 0u && (kf & 0xffu) == PT_SHAPE_MESH) {
             const uint32_t tc = pt_f2u(bf4(s, box + 4).w);  // triangle-leaf count rides in the instance entry's max.w
             const uint64_t range = (tc + 1 >= 64 ? ~0ull : ((1ull << (tc + 1)) - 1)) << k;

@@ -38,6 +38,23 @@ namespace {
     } while (0)
 
 constexpr int kBlock = 256;
+// Register budgets: the number of waves per SIMD the compiler must leave room for (1 = no constraint), per kernel form.
+// Measured on MI355X (tools/occupancy_sweep.sh): the traversal kernels are VALU-issue bound and gain from a
+// 5th wave; k_shade is a large body (196 VGPRs unconstrained = 2 waves) that gains from a 3rd wave and loses with a 4th.
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 3
+#endif
+#ifndef PT_SHADE4_WAVES
+#define PT_SHADE4_WAVES 2
+#endif
+#ifndef PT_SWEEP_WAVES
+#define PT_SWEEP_WAVES 5
+#endif
+#ifndef PT_WALK_WAVES
+#define PT_WALK_WAVES 1
+#endif
+#define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(NL == 1 ? PT_SHADE_WAVES : PT_SHADE4_WAVES)))
+#define PT_TRAV_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? PT_SWEEP_WAVES : PT_WALK_WAVES)))
 constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // stage the blob in LDS when it fits (keeps >= 2 workgroups per CU)
 
 enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_ACCUMULATE, ST_COUNT };
@@ -124,7 +141,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(RenderParams rp, const uint
 }
 
 template <bool USE_LDS, int TRAV>
-__global__ void __launch_bounds__(kBlock) k_extend(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+__global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_extend(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                   Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
     extern __shared__ __align__(16) uint32_t lds[];
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
@@ -140,7 +157,7 @@ __global__ void __launch_bounds__(kBlock) k_extend(const uint32_t* __restrict__ 
 }
 
 template <bool USE_LDS, int NL>
-__global__ void __launch_bounds__(kBlock) k_shade(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+__global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                  RenderParams rp, uint32_t bounce, const uint32_t* __restrict__ pixels,
                                                  Queue paths_in, Queue hits, Queue paths_out, Queue shadow, float* __restrict__ energy,
                                                  uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ count_out,
@@ -200,7 +217,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(const uint32_t* __restrict__ b
 }
 
 template <bool USE_LDS, int NL, int TRAV>
-__global__ void __launch_bounds__(kBlock) k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+__global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                   uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                   uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
     extern __shared__ __align__(16) uint32_t lds[];

@@ -5,6 +5,7 @@
 #include "pt_scene_host.h"
 #include "pt_device.h"
 
+#include <array>
 #include <cmath>
 #include <cstring>
 
@@ -351,6 +352,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             uint32_t sweep_off = (uint32_t)w.size();
             w.resize(w.size() + order.size() * PT_SWEEP_INST_WORDS, 0);
             std::vector<uint32_t> bits;
+            std::vector<int> root_of;  // per bit: the bit whose box test it copies (itself if none)
             uint32_t bit = 0;
             uint64_t mesh_mask = 0;
             for (size_t j = 0; j < order.size(); ++j) {
@@ -361,20 +363,29 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                 uint32_t rec_off = w[PT_HDR_INSTANCE_OFF] + inst * PT_INST_WORDS;
                 uint32_t kf = (uint32_t)in.kind | (is_flat(nd) ? 1u << 8 : 0u) | (in.has_transform ? 1u << 9 : 0u);
                 uint32_t tri_list = 0, tri_count = 0, first_bit = bit++;
-                uint32_t own[PT_SWEEP_BIT_WORDS] = {rec_off, 0u, e + 4, kf | inst << 16};
+                uint32_t own[PT_SWEEP_BIT_WORDS] = {rec_off, 0u, e + 4, kf | inst << 16, 0u, 0u, 0u, 0u};
                 bits.insert(bits.end(), own, own + PT_SWEEP_BIT_WORDS);
+                root_of.push_back((int)first_bit);
                 if (in.kind == PT_SHAPE_MESH) {
                     mesh_mask |= 1ull << first_bit;
                     pad16(w);
                     tri_list = (uint32_t)w.size();
                     uint32_t tri_base = w[mesh_off[in.mesh] + PT_MESH_TRI_OFF];
+                    std::vector<std::array<uint32_t, 6>> seen;  // boxes of this instance's bits, index = bit - first_bit
+                    seen.push_back({nd[0], nd[1], nd[2], nd[4], nd[5], nd[6]});
                     for (uint32_t k = 0; k < mesh_node_count[in.mesh]; ++k) {
                         uint32_t mn[PT_NODE_WORDS];
                         for (int q = 0; q < PT_NODE_WORDS; ++q) mn[q] = w[mesh_node_off[in.mesh] + k * PT_NODE_WORDS + q];
                         if (mn[7] == PT_NODE_INNER) continue;
+                        std::array<uint32_t, 6> box = {mn[0], mn[1], mn[2], mn[4], mn[5], mn[6]};
+                        // the instance's own box is tested against the world ray: only an untransformed instance may share it
+                        uint32_t alias = 0;
+                        for (size_t q = in.has_transform ? 1 : 0; q < seen.size() && !alias; ++q) if (seen[q] == box) alias = first_bit + (uint32_t)q + 1;
+                        seen.push_back(box);
+                        root_of.push_back(alias ? root_of[alias - 1] : (int)bit);
                         uint32_t triw = tri_base + mn[7] * PT_TRI_WORDS, flat = is_flat(mn) ? 1u : 0u;
-                        uint32_t rec[PT_SWEEP_TRI_WORDS] = {mn[0], mn[1], mn[2], triw, mn[4], mn[5], mn[6], flat};
-                        uint32_t tb[PT_SWEEP_BIT_WORDS] = {rec_off, triw, (uint32_t)w.size(), (kf & ~0x100u) | flat << 8 | inst << 16};
+                        uint32_t rec[PT_SWEEP_TRI_WORDS] = {mn[0], mn[1], mn[2], triw, mn[4], mn[5], mn[6], flat | (alias ? (uint32_t)root_of[alias - 1] + 1 : 0u) << 1};
+                        uint32_t tb[PT_SWEEP_BIT_WORDS] = {rec_off, triw, (uint32_t)w.size(), (kf & ~0x100u) | flat << 8 | inst << 16, 0u, 0u, 0u, 0u};
                         w.insert(w.end(), rec, rec + PT_SWEEP_TRI_WORDS);
                         bits.insert(bits.end(), tb, tb + PT_SWEEP_BIT_WORDS);
                         ++tri_count; ++bit;
@@ -384,6 +395,11 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                 r[0] = rec_off; r[1] = inst; r[2] = kf; r[3] = first_bit;
                 r[4] = nd[0]; r[5] = nd[1]; r[6] = nd[2]; r[7] = tri_list; r[8] = nd[4]; r[9] = nd[5]; r[10] = nd[6]; r[11] = tri_count;
             }
+            for (size_t k = 0; k < root_of.size(); ++k)
+                if (root_of[k] != (int)k) {
+                    uint64_t m = 1ull << k;
+                    bits[(size_t)root_of[k] * PT_SWEEP_BIT_WORDS + 4] |= (uint32_t)m; bits[(size_t)root_of[k] * PT_SWEEP_BIT_WORDS + 5] |= (uint32_t)(m >> 32);
+                }
             pad16(w);
             w[PT_HDR_SWEEP_BITS_OFF] = (uint32_t)w.size();
             w.insert(w.end(), bits.begin(), bits.end());

@@ -31,7 +31,17 @@ pt_status ptemu_scene_create(const pt_scene_desc* d, pt_scene** out) {
 }
 void ptemu_scene_destroy(pt_scene* sc) { delete sc; }
 uint32_t ptemu_debug_scene_info(pt_scene* sc, int what) {
-    if (what == 4) return sc->host.blob[PT_HDR_SWEEP_OFF] != 0 && !(sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP) ? 1u : 0u;
+    const std::vector<uint32_t>& w = sc->host.blob;
+    if (what == 4) return w[PT_HDR_SWEEP_OFF] != 0 && !(w[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP) ? 1u : 0u;
+    if ((what == 5 || what == 6) && w[PT_HDR_SWEEP_OFF] != 0) {  // 5: mask bits in use, 6: bits whose box test is a copy
+        uint32_t bits = 0, copies = 0;
+        for (uint32_t j = 0; j < w[PT_HDR_SWEEP_COUNT]; ++j) {
+            const uint32_t* e = &w[w[PT_HDR_SWEEP_OFF] + j * PT_SWEEP_INST_WORDS];
+            bits += 1 + e[11];
+            for (uint32_t t = 0; t < e[11]; ++t) copies += (w[e[7] + t * PT_SWEEP_TRI_WORDS + 7] >> 1) != 0;
+        }
+        return what == 5 ? bits : copies;
+    }
     return 0;
 }
 
