@@ -267,6 +267,24 @@ pt_status pt_output_film(const pt_output_desc* desc, const float* film_xyzw, uin
 pt_status pt_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8, int32_t colorspace);
 pt_status pt_write_exr(const char* path, uint32_t width, uint32_t height, const float* linear_rgb, int32_t colorspace);
 
+/* ---- film comparison: the three modes of src/bin/compare_exr.rs:39-52,70-170 on raw float4 images (XYZ films
+ * or linear RGB), plus the per-channel statistics the parity tests quote. ---- */
+enum { PT_COMPARE_ABSOLUTE = 0, PT_COMPARE_RMSE = 1, PT_COMPARE_RELATIVE = 2 };
+typedef struct pt_compare_stats {
+    double linf[4];        /* max |image - truth| per channel */
+    double mean_abs[4];    /* mean |image - truth| per channel */
+    double rmse;           /* sqrt(mean over pixels and channels of (image - truth)^2) */
+    float pixel_min, pixel_max; /* range of the per-pixel value: RMSE mode = the "minmax" the reference prints (compare_exr.rs:108-110),
+                                   other modes = largest channel of the output pixel */
+    uint64_t nonfinite;    /* pixels with a NaN/inf channel in either input */
+} pt_compare_stats;
+/* image, truth, out: host, width*height*4 f32.  out (may be NULL):
+ *   ABSOLUTE  |image - truth| per channel (compare_exr.rs:74-82)
+ *   RMSE      per pixel sqrt(sum of squared channel differences / 4), mapped through the viridis gradient over [min, max]
+ *             (compare_exr.rs:93-127); alpha = 1
+ *   RELATIVE  |image - truth| / truth per channel, non-finite -> 0 (compare_exr.rs:150-161) */
+pt_status pt_compare_films(uint32_t width, uint32_t height, const float* image, const float* truth, int32_t mode, float* out, pt_compare_stats* stats);
+
 /* Library / device identification, e.g. "gfx950 ... 256 CUs". */
 const char* pt_device_info(void);
 

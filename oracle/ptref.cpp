@@ -1862,4 +1862,64 @@ uint32_t ptref_scene_info(pt_scene* ps, int what) {
     switch (what) { case 0: return (uint32_t)ps->s.lights.size(); case 1: return (uint32_t)ps->s.bvh.size(); default: return 0; }
 }
 
+// ---- film comparison: src/bin/compare_exr.rs:70-170, pixel by pixel in image order ------------------------
+// colorgrad::viridis() (crate not in the tree): uniform B-spline through the preset's nine key colours.
+static void viridis_at(double t, float* rgb) {
+    static const int key[9][3] = {{0x44, 0x01, 0x54}, {0x48, 0x27, 0x77}, {0x3f, 0x4a, 0x8a}, {0x31, 0x67, 0x8e}, {0x26, 0x83, 0x8f},
+                                  {0x1f, 0x9d, 0x8a}, {0x6c, 0xce, 0x5a}, {0xb6, 0xde, 0x2b}, {0xfe, 0xe8, 0x25}};
+    if (!(t >= 0.0)) t = 0.0;
+    if (t > 1.0) t = 1.0;
+    int i = t >= 1.0 ? 7 : (int)(t * 8.0);
+    double t1 = (t - (double)i / 8.0) * 8.0, t2 = t1 * t1, t3 = t2 * t1;
+    for (int c = 0; c < 3; ++c) {
+        double v1 = key[i][c] / 255.0, v2 = key[i + 1][c] / 255.0;
+        double v0 = i > 0 ? key[i - 1][c] / 255.0 : 2.0 * v1 - v2, v3 = i < 7 ? key[i + 2][c] / 255.0 : 2.0 * v2 - v1;
+        double v = ((1.0 - 3.0 * t1 + 3.0 * t2 - t3) * v0 + (4.0 - 6.0 * t2 + 3.0 * t3) * v1 + (1.0 + 3.0 * t1 + 3.0 * t2 - 3.0 * t3) * v2 + t3 * v3) / 6.0;
+        rgb[c] = (float)std::min(1.0, std::max(0.0, v));
+    }
+}
+pt_status ptref_compare_films(uint32_t width, uint32_t height, const float* image, const float* truth, int32_t mode, float* out, pt_compare_stats* stats) {
+    if (!image || !truth || width == 0 || height == 0 || mode < 0 || mode > 2) return PT_ERR_INVALID_ARGUMENT;
+    const size_t n = (size_t)width * height;
+    pt_compare_stats st; memset(&st, 0, sizeof(st));
+    double sum_abs[4] = {0, 0, 0, 0}, sum_sq = 0.0, lo = INFINITY, hi = -INFINITY;
+    size_t good = 0;
+    std::vector<float> value(n);
+    for (size_t i = 0; i < n; ++i) {
+        const float *a = image + 4 * i, *b = truth + 4 * i;
+        float d[4], o[4];
+        bool bad = false;
+        for (int c = 0; c < 4; ++c) { d[c] = a[c] - b[c]; bad = bad || !std::isfinite(a[c]) || !std::isfinite(b[c]); }
+        if (mode == PT_COMPARE_RMSE) {               // compare_exr.rs:93-104 (a f32x4 reduce_sum: pairwise)
+            float r = pt_sqrt(((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) / 4.0f);
+            o[0] = o[1] = o[2] = r; o[3] = 0.0f; value[i] = r;
+        } else if (mode == PT_COMPARE_RELATIVE) {    // :150-161
+            for (int c = 0; c < 4; ++c) { float r = pt_abs(d[c]) / b[c]; o[c] = std::isfinite(r) ? r : 0.0f; }
+            value[i] = std::max(std::max(o[0], o[1]), std::max(o[2], o[3]));
+        } else {                                     // :74-82
+            for (int c = 0; c < 4; ++c) o[c] = pt_abs(d[c]);
+            value[i] = std::max(std::max(o[0], o[1]), std::max(o[2], o[3]));
+        }
+        if (out) for (int c = 0; c < 4; ++c) out[4 * i + c] = o[c];
+        if (bad) { st.nonfinite++; continue; }
+        ++good;
+        for (int c = 0; c < 4; ++c) {
+            double ad = (double)pt_abs(d[c]);
+            st.linf[c] = std::max(st.linf[c], ad); sum_abs[c] += ad; sum_sq += (double)d[c] * (double)d[c];
+        }
+        lo = std::min(lo, (double)value[i]); hi = std::max(hi, (double)value[i]);
+    }
+    for (int c = 0; c < 4; ++c) st.mean_abs[c] = good ? sum_abs[c] / (double)good : 0.0;
+    st.rmse = good ? std::sqrt(sum_sq / (4.0 * (double)good)) : 0.0;
+    st.pixel_min = good ? (float)lo : 0.0f; st.pixel_max = good ? (float)hi : 0.0f;
+    if (out && mode == PT_COMPARE_RMSE)              // :106-127
+        for (size_t i = 0; i < n; ++i) {
+            float rgb[3];
+            viridis_at((double)((value[i] - st.pixel_min) / (st.pixel_max - st.pixel_min)), rgb);
+            out[4 * i] = rgb[0]; out[4 * i + 1] = rgb[1]; out[4 * i + 2] = rgb[2]; out[4 * i + 3] = 1.0f;
+        }
+    if (stats) *stats = st;
+    return PT_OK;
+}
+
 }  // extern "C"

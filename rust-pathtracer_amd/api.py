@@ -117,6 +117,16 @@ class OutputDesc(C.Structure):
 
 TONEMAP_CLAMP, TONEMAP_REINHARD0, TONEMAP_REINHARD1 = range(3)
 COLORSPACE_SRGB, COLORSPACE_REC709, COLORSPACE_REC2020 = range(3)
+COMPARE_ABSOLUTE, COMPARE_RMSE, COMPARE_RELATIVE = range(3)
+
+
+class CompareStats(C.Structure):
+    _fields_ = [("linf", C.c_double * 4), ("mean_abs", C.c_double * 4), ("rmse", C.c_double), ("pixel_min", C.c_float),
+                ("pixel_max", C.c_float), ("nonfinite", C.c_uint64)]
+
+    def as_dict(self):
+        return {"linf": list(self.linf), "mean_abs": list(self.mean_abs), "rmse": self.rmse, "pixel_min": self.pixel_min,
+                "pixel_max": self.pixel_max, "nonfinite": int(self.nonfinite)}
 
 
 class Hit(C.Structure):
@@ -130,7 +140,7 @@ assert HIT_DTYPE.itemsize == C.sizeof(Hit)
 
 # every entry point include/pt_api.h declares (without prefix)
 API_FUNCTIONS = ["scene_create", "scene_destroy", "last_error", "render", "render_device", "intersect",
-                 "bsdf_sample", "bsdf_eval", "emission", "curve_eval", "device_info", "output_film", "write_png", "write_exr"]
+                 "bsdf_sample", "bsdf_eval", "emission", "curve_eval", "device_info", "output_film", "write_png", "write_exr", "compare_films"]
 
 
 class PtError(RuntimeError):
@@ -185,6 +195,7 @@ class Library:
         self._device_info = bind("device_info", C.c_char_p, [], required=False)
         self._output_film = bind("output_film", C.c_int32, [C.POINTER(OutputDesc), fpp, C.POINTER(C.c_uint8), fpp], required=False)
         self._write_png = bind("write_png", C.c_int32, [C.c_char_p, u32, u32, C.POINTER(C.c_uint8), C.c_int32], required=False)
+        self._compare_films = bind("compare_films", C.c_int32, [u32, u32, fpp, fpp, C.c_int32, fpp, C.POINTER(CompareStats)], required=False)
         self._debug_scene_info = bind("debug_scene_info", u32, [vp, C.c_int32], required=False)
         self._write_exr = bind("write_exr", C.c_int32, [C.c_char_p, u32, u32, fpp, C.c_int32], required=False)
 
@@ -212,6 +223,18 @@ class Library:
         lin = np.zeros((h, w, 3), np.float32) if want_linear else None
         self.check(self._output_film(C.byref(d), _fp(film), rgba.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(lin) if want_linear else None))
         return rgba, lin
+
+    def compare_films(self, image, truth, mode=COMPARE_ABSOLUTE, want_image=True):
+        """compare_exr (src/bin/compare_exr.rs:70-170) on raw [H,W,4] f32 images: (difference image or None, CompareStats)."""
+        image = np.ascontiguousarray(image, dtype=np.float32)
+        truth = np.ascontiguousarray(truth, dtype=np.float32)
+        if image.shape != truth.shape or image.ndim != 3 or image.shape[2] != 4:
+            raise ValueError("image dimensions must match ([H, W, 4] each)")  # the reference asserts (compare_exr.rs:66-69)
+        h, w = image.shape[:2]
+        out = np.zeros((h, w, 4), np.float32) if want_image else None
+        st = CompareStats()
+        self.check(self._compare_films(w, h, _fp(image), _fp(truth), mode, _fp(out) if want_image else None, C.byref(st)))
+        return out, st
 
     def write_png(self, path, rgba8, colorspace=COLORSPACE_SRGB):
         rgba8 = np.ascontiguousarray(rgba8, np.uint8)

@@ -46,9 +46,9 @@ def test_struct_layouts_match_the_header(pkg):
 #include <stdio.h>
 #include "pt_api.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pt_curve), sizeof(pt_texture_layer), sizeof(pt_texstack),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pt_curve), sizeof(pt_texture_layer), sizeof(pt_texstack),
          sizeof(pt_material), sizeof(pt_mesh), sizeof(pt_instance), sizeof(pt_environment), sizeof(pt_camera), sizeof(pt_scene_desc),
-         sizeof(pt_render_desc), sizeof(pt_profile), sizeof(pt_hit), sizeof(pt_output_desc));
+         sizeof(pt_render_desc), sizeof(pt_profile), sizeof(pt_hit), sizeof(pt_output_desc), sizeof(pt_compare_stats));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
@@ -56,5 +56,5 @@ int main(void) {
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
     a = pkg.api
     mine = [C.sizeof(t) for t in (a.Curve, a.TextureLayer, a.TexStack, a.Material, a.Mesh, a.Instance, a.Environment, a.Camera,
-                                  a.SceneDesc, a.RenderDesc, a.Profile, a.Hit, a.OutputDesc)]
+                                  a.SceneDesc, a.RenderDesc, a.Profile, a.Hit, a.OutputDesc, a.CompareStats)]
     assert mine == sizes
