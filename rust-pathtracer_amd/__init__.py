@@ -9,7 +9,7 @@ Import with ``importlib.import_module("rust-pathtracer_amd")`` (the name has a h
 """
 import os
 
-from . import api, scene, sharding  # noqa: F401
+from . import api, scene, scene_file, sharding  # noqa: F401
 
 PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PACKAGE_DIR)

@@ -251,7 +251,8 @@ class Scene:
     def __init__(self, library, builder):
         self.library = library
         self.builder = builder
-        desc, keep = builder.desc()
+        # a SceneBuilder (scene.py) or a SceneFile (scene_file.py, the C++ TOML front end)
+        desc, keep = builder.desc_and_keepalive() if hasattr(builder, "desc_and_keepalive") else builder.desc()
         self._keep = keep
         handle = C.c_void_p()
         library.check(library._scene_create(C.byref(desc), C.byref(handle)))

@@ -27,20 +27,38 @@ def _spectra():
 
 
 # ---- Transform3 (math crate): from_stack(scale, rotate, translate) = T * R * S -------------------
+# Inputs are f32 (Transform3Data holds f32 fields, src/parsing/instance.rs:17-31); the composition runs in f64 with a
+# fixed operation order, the same as csrc/host/scene_file.cpp, so both front ends produce the same matrices bit for bit.
+def _f32(v):
+    return [float(np.float32(x)) for x in v]
+
+
+def _mat4_mul(a, b):
+    r = np.zeros((4, 4))
+    for i in range(4):
+        for j in range(4):
+            s = 0.0
+            for k in range(4):
+                s += float(a[i][k]) * float(b[k][j])
+            r[i, j] = s
+    return r
+
+
 def transform_from_scale(s):
-    m = np.eye(4); m[0, 0], m[1, 1], m[2, 2] = s
+    m = np.eye(4); m[0, 0], m[1, 1], m[2, 2] = _f32(s)
     return m
 
 
 def transform_from_translation(t):
-    m = np.eye(4); m[:3, 3] = t
+    m = np.eye(4); m[:3, 3] = _f32(t)
     return m
 
 
 def transform_from_axis_angle(axis, angle_rad):
-    a = np.asarray(axis, dtype=np.float64); a = a / np.linalg.norm(a)
+    x, y, z = _f32(axis)
+    n = math.sqrt(x * x + y * y + z * z)
+    x, y, z = x / n, y / n, z / n
     c, s = math.cos(angle_rad), math.sin(angle_rad)
-    x, y, z = a
     r = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s],
                   [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s],
                   [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]])
@@ -53,16 +71,45 @@ def transform_from_data(scale=None, rotate=None, translate=None):
     [(axis, degrees), ...] are applied in list order."""
     m = np.eye(4)
     if scale is not None:
-        m = transform_from_scale(scale) @ m
+        m = _mat4_mul(transform_from_scale(scale), m)
     if rotate:
         base = None
         for axis, deg in rotate:
-            t = transform_from_axis_angle(axis, math.pi * deg / 180.0)
-            base = t if base is None else t @ base
-        m = base @ m
+            t = transform_from_axis_angle(axis, math.pi * float(np.float32(deg)) / 180.0)
+            base = t if base is None else _mat4_mul(t, base)
+        m = _mat4_mul(base, m)
     if translate is not None:
-        m = transform_from_translation(translate) @ m
+        m = _mat4_mul(transform_from_translation(translate), m)
     return m
+
+
+def transform_inverse(m):
+    """Transform3::reverse: Gauss-Jordan with partial pivoting in f64, operation for operation the same as `inverse` in
+    csrc/host/scene_file.cpp so that both front ends hand the engine the same bits."""
+    a = [[float(m[i][j]) for j in range(4)] for i in range(4)]
+    inv = [[1.0 if i == j else 0.0 for j in range(4)] for i in range(4)]
+    for col in range(4):
+        piv = col
+        for r in range(col + 1, 4):
+            if abs(a[r][col]) > abs(a[piv][col]):
+                piv = r
+        if a[piv][col] == 0.0:
+            raise ValueError("singular transform")
+        if piv != col:
+            a[piv], a[col] = a[col], a[piv]
+            inv[piv], inv[col] = inv[col], inv[piv]
+        p = a[col][col]
+        for j in range(4):
+            a[col][j] /= p
+            inv[col][j] /= p
+        for r in range(4):
+            if r == col:
+                continue
+            f = a[r][col]
+            for j in range(4):
+                a[r][j] -= f * a[col][j]
+                inv[r][j] -= f * inv[col][j]
+    return np.array(inv, dtype=np.float64)
 
 
 class SceneBuilder:
@@ -209,7 +256,7 @@ class SceneBuilder:
         fwd = _IDENTITY if transform is None else np.asarray(transform, np.float64)
         inst.has_transform = 0 if transform is None else 1
         inst.forward = (C.c_float * 16)(*fwd.astype(np.float32).reshape(-1).tolist())
-        inst.reverse = (C.c_float * 16)(*np.linalg.inv(fwd).astype(np.float32).reshape(-1).tolist())
+        inst.reverse = (C.c_float * 16)(*transform_inverse(fwd).astype(np.float32).reshape(-1).tolist())
         self.instances.append(inst)
         return inst
 
@@ -250,8 +297,9 @@ class SceneBuilder:
         self.environment.curve = curve
         self.environment.strength = strength
         self.environment.angular_diameter = angular_diameter
-        d = np.asarray(sun_direction, np.float64); d = d / np.linalg.norm(d)
-        self.environment.sun_direction = (C.c_float * 3)(*d.tolist())
+        d = np.asarray(sun_direction, np.float32)  # Vec3::normalized in f32 (src/parsing/environment.rs:91)
+        n = np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2], dtype=np.float32)
+        self.environment.sun_direction = (C.c_float * 3)(*(d / n).tolist())
 
     def set_environment_hdr(self, texstack, strength, rotate=None, importance=(0, 0), luminance_curve=-1):
         """EnvironmentData::HDRI (src/parsing/environment.rs:93-180): texture stack, rotation list [(axis, degrees)],
@@ -262,7 +310,7 @@ class SceneBuilder:
         self.environment.strength = strength
         fwd = transform_from_data(rotate=rotate) if rotate else np.eye(4)
         self.environment.rotation_forward = (C.c_float * 16)(*fwd.astype(np.float32).reshape(-1).tolist())
-        self.environment.rotation_reverse = (C.c_float * 16)(*np.linalg.inv(fwd).astype(np.float32).reshape(-1).tolist())
+        self.environment.rotation_reverse = (C.c_float * 16)(*transform_inverse(fwd).astype(np.float32).reshape(-1).tolist())
         self.environment.importance_width, self.environment.importance_height = importance
         self.environment.importance_luminance_curve = luminance_curve
 
@@ -548,6 +596,20 @@ def mixed_small():
     return b
 
 
+def sun_test():
+    """data/scenes/sun_test.toml of this repository: Sun environment with a literal blackbody colour, a metal sphere on a
+    ground rect (not a reference scene; covers EnvironmentData::Sun and camera defaults)."""
+    b = SceneBuilder()
+    sun = b.curve_blackbody(None, 5800.0, 1.0)
+    b.set_environment_sun(sun, 2.0, 0.1, (0.3, -0.2, 1.0))
+    white = add_library_material(b, "lambertian_white")
+    copper = add_library_material(b, "ggx_copper")
+    b.add_rect((8, 8), (0.0, 0.0, -1.0), "Z", True, white)
+    b.add_sphere(0.8, (0.0, 0.0, -0.2), copper)
+    b.add_camera((-5.0, 0.0, 1.0), (0.0, 0.0, 0.0), 30.0)
+    return b
+
+
 def synthetic_hdri(width=1024, height=512):
     """Deterministic stand-in for the absent data/hdri/*.hdr: a sky gradient, a warm ground and one
     Gaussian "sun", linear RGB + alpha 0, float32, generated from a closed formula (no RNG).  Texel (x, y) is looked up
@@ -599,4 +661,4 @@ def hdri_c4_small():
 
 
 SCENES = {"hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
-          "mixed_primitives": mixed_primitives, "mixed_small": mixed_small}
+          "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test}

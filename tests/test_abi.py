@@ -58,3 +58,40 @@ int main(void) {
     mine = [C.sizeof(t) for t in (a.Curve, a.TextureLayer, a.TexStack, a.Material, a.Mesh, a.Instance, a.Environment, a.Camera,
                                   a.SceneDesc, a.RenderDesc, a.Profile, a.Hit, a.OutputDesc, a.CompareStats)]
     assert mine == sizes
+
+
+def test_scene_file_library_exports_every_declared_symbol(pkg):
+    """include/pt_scene_file.h (the TOML front end, libptscene.so)."""
+    text = open(os.path.join(ROOT, "include", "pt_scene_file.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(pt_[a-z_0-9]+)\s*\(", text)))
+    assert len(names) >= 18 and "pt_scene_file_load" in names and "pt_config_render_desc" in names
+    lib = C.CDLL(pkg.scene_file.LIBRARY_PATH)
+    for name in names:
+        assert hasattr(lib, name), name
+    # the ctypes mirror of pt_render_settings against the C compiler's view
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write('#include <stdio.h>\n#include "pt_scene_file.h"\nint main(void) { printf("%zu\\n", sizeof(pt_render_settings)); return 0; }')
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
+        assert int(subprocess.check_output([os.path.join(d, "t")])) == C.sizeof(pkg.scene_file.RenderSettings)
+
+
+def test_command_line_renderer_dry_run(pkg):
+    """ptcli (src/bin/main.rs): parses config + scene and stops before rendering with --dry-run; fails loudly without a GPU
+    otherwise (no CPU fallback)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.LIBRARY_PATH), "ptcli")
+    if not os.path.exists(exe):
+        pytest.fail("ptcli not built: run python -c 'import __graft_entry__ as g; g.build()'")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run([exe, "--root", pkg.PACKAGE_DIR, "--config", "data/config_two_passes.toml", "--dry-run", "--stdout-log-level", "info", "--output-dir", os.path.join(d, "out")],
+                           capture_output=True, text=True, cwd=d)
+        assert r.returncode == 0, r.stderr
+        assert "7 instances" in r.stdout and "constructing renderer" in r.stdout and "render done" not in r.stdout
+        r = subprocess.run([exe, "--root", pkg.PACKAGE_DIR, "--config", "data/no_such_config.toml"], capture_output=True, text=True, cwd=d)
+        assert r.returncode == 1 and "couldn't read config.toml" in r.stderr
+        r = subprocess.run([exe, "--bogus"], capture_output=True, text=True, cwd=d)
+        assert r.returncode == 2

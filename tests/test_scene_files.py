@@ -1,0 +1,311 @@
+"""TOML front end: csrc/host/scene_file.cpp (libptscene.so) against the Python SceneBuilder.
+Both assemble the same scenes from the same tables (tools/make_scene_files.py writes the files); the oracle must render
+bit-identical films from either, and the flat arrays must agree field by field.  CPU only."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import parity_suite as ps
+
+
+@pytest.fixture(scope="module")
+def sfmod(pkg):
+    return pkg.scene_file
+
+
+def data(sf, *parts):
+    return os.path.join(sf.DATA_ROOT, "data", *parts)
+
+
+def test_config_fields(sfmod, pkg):
+    a = pkg.api
+    cfg = sfmod.Config(data(sfmod, "config_gem_c3.toml"))
+    assert cfg.scene_file == "data/scenes/cornell_box_diamond_gem.toml"
+    assert cfg.renderer == (sfmod.library().pt_config_renderer(cfg.handle, None, None), (32, 32)) and cfg.renderer[0] == 1
+    assert len(cfg) == 1
+    s = cfg.render_settings(0)
+    assert (s.filename, s.width, s.height, s.min_samples, s.min_bounces, s.max_bounces) == (b"beauty", 1920, 1080, 4096, 1, 12)
+    assert (s.integrator, s.light_samples, s.medium_aware, s.hwss, s.threads, s.max_samples) == (0, 2, 0, 0, -1, -1)
+    assert (s.russian_roulette, s.only_direct, s.camera_id) == (1, 0, b"main")
+    assert s.has_wavelength_bounds == 1 and (s.wavelength_lo, s.wavelength_hi) == (380.0, 750.0)
+    assert s.has_premultiply == 1 and s.premultiply == 2.0
+    assert (s.tonemap, s.has_exposure, s.exposure, s.luminance_only, s.colorspace) == (a.TONEMAP_CLAMP, 1, -1.0, 0, a.COLORSPACE_SRGB)
+    rd = cfg.render_desc(0, seed=7)
+    assert (rd.width, rd.height, rd.spp, rd.min_bounces, rd.max_bounces, rd.light_samples, rd.only_direct) == (1920, 1080, 4096, 1, 12, 2, 0)
+    assert (rd.tile_width, rd.tile_height, rd.camera_index, rd.seed, rd.hero_wavelengths) == (32, 32, 0, 7, 1)
+    od = cfg.output_desc(0, 1.0)
+    assert (od.width, od.height, od.tonemap, od.exposure, od.factor) == (1920, 1080, a.TONEMAP_CLAMP, -1.0, 2.0)  # factor *= premultiply
+
+
+def test_config_defaults_and_second_pass(sfmod, pkg):
+    cfg = sfmod.Config(data(sfmod, "config_two_passes.toml"))
+    assert len(cfg) == 2
+    s = cfg.render_settings(1)
+    assert (s.filename, s.min_bounces, s.max_bounces, s.hwss, s.only_direct, s.russian_roulette, s.threads) == (b"direct_only", -1, 3, 1, 1, -1, 2)
+    assert s.has_wavelength_bounds == 0 and s.has_premultiply == 0 and s.silenced == 0 and cfg.render_settings(0).silenced == 1
+    rd = cfg.render_desc(1)
+    # defaults of src/integrator/mod.rs:59-105: min_bounces 4, bounds [380, 750]; hwss selects the hero-wavelength variant
+    assert (rd.min_bounces, rd.wavelength_lo, rd.wavelength_hi, rd.hero_wavelengths, rd.only_direct) == (4, 380.0, 750.0, 4, 1)
+    assert cfg.output_desc(1).key_value == np.float32(0.2)
+
+
+def _write(tmp_path, name, text):
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+def test_config_errors(sfmod, tmp_path):
+    good = open(data(sfmod, "config_cornell_c1.toml")).read()
+    with pytest.raises(sfmod.SceneFileError, match="unknown field `bogus`"):      # serde deny_unknown_fields
+        sfmod.Config(_write(tmp_path, "a.toml", good.replace("hwss = false", "hwss = false\nbogus = 1")))
+    with pytest.raises(sfmod.SceneFileError, match="missing field `hwss`"):
+        sfmod.Config(_write(tmp_path, "b.toml", good.replace("hwss = false\n", "")))
+    with pytest.raises(sfmod.SceneFileError, match="unknown variant `Reinhard9`"):
+        sfmod.Config(_write(tmp_path, "c.toml", good.replace('"Reinhard1"', '"Reinhard9"')))
+    with pytest.raises(sfmod.SceneFileError, match="TOML line"):
+        sfmod.Config(_write(tmp_path, "d.toml", good + "\n[renderer]\n"))
+    with pytest.raises(sfmod.SceneFileError, match="failed to load file"):
+        sfmod.Config(str(tmp_path / "missing.toml"))
+    lt = good.replace('type = "PT"\nlight_samples = 2\nmedium_aware = false', 'type = "LT"\ncamera_samples = 4')
+    cfg = sfmod.Config(_write(tmp_path, "e.toml", lt))
+    with pytest.raises(sfmod.SceneFileError) as e:
+        cfg.render_desc(0)
+    assert e.value.status == 4  # PT_ERR_UNSUPPORTED: only the PT integrator is on this path
+    nomax = sfmod.Config(_write(tmp_path, "f.toml", good.replace("max_bounces = 4\n", "")))
+    with pytest.raises(sfmod.SceneFileError, match="max_bounces is required"):
+        nomax.render_desc(0)
+
+
+def arrays(d):
+    """The flat arrays of a pt_scene_desc as numpy copies."""
+    def arr(ptr, n, dtype):
+        return np.ctypeslib.as_array(ptr, shape=(max(int(n), 1),))[:int(n)].astype(dtype).copy() if n else np.zeros(0, dtype)
+    return {"vertices": arr(d.vertices, d.vertex_count * 3, np.float32), "indices": arr(d.indices, d.index_count, np.uint32),
+            "normals": arr(d.normals, d.normal_count * 3, np.float32), "texture_data": arr(d.texture_data, d.texture_data_count, np.float32),
+            "curve_data": arr(d.curve_data, d.curve_data_count, np.float32)}
+
+
+def curve_of(d, i, cd):
+    c = d.curves[i]
+    per = 2 if c.kind == 1 else 4 if c.kind in (3, 4) else 1
+    return (c.kind, c.mode, c.p0, c.p1, tuple(cd[c.data_offset:c.data_offset + per * c.data_count].tolist()))
+
+
+SCENE_FILES = {"cornell_box": "cornell_box.toml", "cornell_gem": "cornell_box_diamond_gem.toml", "white_furnace": "white_furnace.toml",
+               "mixed_primitives": "mixed_primitives.toml", "hdri_small": "hdri_small.toml", "sun_test": "sun_test.toml"}
+
+
+@pytest.mark.parametrize("name", sorted(SCENE_FILES))
+def test_scene_file_matches_builder(sfmod, pkg, name):
+    sf = sfmod.SceneFile(data(sfmod, "scenes", SCENE_FILES[name]))
+    b = pkg.scene.SCENES[name]()
+    bd, keep = b.desc()
+    fd = sf.desc
+    fa, ba = arrays(fd), arrays(bd)
+    # geometry: identical arrays, instance by instance
+    for k in ("vertices", "indices", "normals"):
+        assert np.array_equal(fa[k].view(np.uint32), ba[k].view(np.uint32)), k
+    assert fd.instance_count == bd.instance_count and fd.mesh_count == bd.mesh_count
+    names = {v: k for k, v in b.material_ids.items()}
+    for i in range(bd.instance_count):
+        x, y = fd.instances[i], bd.instances[i]
+        for field in ("kind", "has_transform", "radius", "axis", "two_sided"):
+            assert getattr(x, field) == getattr(y, field), (i, field)
+        assert x.kind != 3 or x.mesh == y.mesh, i
+        for field in ("origin", "size", "forward", "reverse"):
+            assert list(getattr(x, field)) == list(getattr(y, field)), (i, field)
+        # materials are numbered in library order by one front end and in call order by the other: compare by name
+        assert (x.material == 0xFFFFFFFF) == (y.material == 0xFFFFFFFF)
+        if y.material != 0xFFFFFFFF:
+            assert x.material == sf.material(names[y.material]), (i, names[y.material])
+    for i in range(bd.mesh_count):
+        x, y = fd.meshes[i], bd.meshes[i]
+        assert (x.vertex_offset, x.vertex_count, x.index_offset, x.face_count, x.normal_offset >= 0) == (y.vertex_offset, y.vertex_count, y.index_offset, y.face_count, y.normal_offset >= 0)
+    # materials and their curves, by name
+    for mname, mid in b.material_ids.items():
+        fid = sf.material(mname)
+        assert fid >= 0 and (fid >> 16) == (mid >> 16), mname
+        x, y = fd.materials[fid & 0xFFFF], bd.materials[mid & 0xFFFF]
+        assert (x.kind, x.alpha, x.sharpness, x.sidedness) == (y.kind, y.alpha, y.sharpness, y.sidedness), mname
+        for field in ("curve_eta", "curve_eta_o", "curve_kappa", "curve_emit", "curve_bounce"):
+            assert (getattr(x, field) < 0) == (getattr(y, field) < 0), (mname, field)
+            if getattr(y, field) >= 0:
+                assert curve_of(fd, getattr(x, field), fa["curve_data"]) == curve_of(bd, getattr(y, field), ba["curve_data"]), (mname, field)
+        if y.texstack >= 0:
+            lx, ly = fd.layers[fd.texstacks[x.texstack].first_layer], bd.layers[bd.texstacks[y.texstack].first_layer]
+            assert (lx.kind, lx.width, lx.height) == (ly.kind, ly.width, ly.height)
+            assert curve_of(fd, lx.curves[0], fa["curve_data"]) == curve_of(bd, ly.curves[0], ba["curve_data"])
+            assert fa["texture_data"][lx.data_offset] == ba["texture_data"][ly.data_offset] == 1.0
+    # camera, environment
+    for field in ("look_from", "look_at", "v_up"):
+        assert list(getattr(fd.cameras[0], field)) == list(getattr(bd.cameras[0], field)), field
+    assert (fd.cameras[0].vfov, fd.cameras[0].focal_distance, fd.cameras[0].aperture_diameter) == (bd.cameras[0].vfov, bd.cameras[0].focal_distance, bd.cameras[0].aperture_diameter)
+    ex, ey = fd.environment, bd.environment
+    assert (ex.kind, ex.strength, ex.angular_diameter, ex.importance_width, ex.importance_height) == (ey.kind, ey.strength, ey.angular_diameter, ey.importance_width, ey.importance_height)
+    assert list(ex.sun_direction) == list(ey.sun_direction)
+    if ey.kind == 2:
+        assert list(ex.rotation_forward) == list(ey.rotation_forward) and list(ex.rotation_reverse) == list(ey.rotation_reverse)
+    assert fd.env_sampling_probability == bd.env_sampling_probability
+    if ey.curve >= 0:
+        assert curve_of(fd, ex.curve, fa["curve_data"]) == curve_of(bd, ey.curve, ba["curve_data"])
+    if ey.texstack >= 0:
+        lx, ly = fd.layers[fd.texstacks[ex.texstack].first_layer], bd.layers[bd.texstacks[ey.texstack].first_layer]
+        n = lx.width * lx.height * 4
+        assert (lx.kind, lx.width, lx.height) == (ly.kind, ly.width, ly.height) == (4, 64, 32)
+        assert np.array_equal(fa["texture_data"][lx.data_offset:lx.data_offset + n].view(np.uint32), ba["texture_data"][ly.data_offset:ly.data_offset + n].view(np.uint32))
+        for k in range(4):
+            assert curve_of(fd, lx.curves[k], fa["curve_data"]) == curve_of(bd, ly.curves[k], ba["curve_data"])
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "mixed_primitives", "hdri_small", "sun_test"])
+def test_oracle_renders_the_same_film_from_either_front_end(sfmod, pkg, oracle, name):
+    sf = sfmod.SceneFile(data(sfmod, "scenes", SCENE_FILES[name]))
+    rd = pkg.api.render_desc(40, 32, 6, 5, light_samples=2, seed=3)
+    film_f, prof_f = oracle.create_scene(sf).render(rd)
+    film_b, prof_b = oracle.create_scene(pkg.scene.SCENES[name]()).render(rd)
+    assert np.array_equal(film_f.view(np.uint32), film_b.view(np.uint32))
+    assert (prof_f.bounce_rays, prof_f.shadow_rays, prof_f.env_hits) == (prof_b.bounce_rays, prof_b.shadow_rays, prof_b.env_hits)
+    assert film_f[..., :3].sum() > 0
+
+
+def test_scan_loads_only_what_is_used(sfmod):
+    """construct_world parses only the curves / textures / materials / meshes the scene uses (src/parsing/mod.rs:145-262):
+    the libraries hold an entry with a missing file and a material with a missing curve, neither is touched."""
+    sf = sfmod.SceneFile(data(sfmod, "scenes", "cornell_box.toml"))
+    assert sf.curve("unused_missing_file") == -1 and sf.material("unused_broken") == -1 and sf.material("ggx_gold") == -1
+    assert sf.material("error") == (1 << 16) and sf.curve("cornell_white") >= 0 and sf.texture("lambertian_red") >= 0
+    assert sf.desc.material_count == 5 and sf.desc.instance_count == 8 and sf.warnings == []
+
+
+def test_cameras_follow_the_render_settings(sfmod):
+    cfg = sfmod.Config(data(sfmod, "config_two_passes.toml"))
+    sf = sfmod.SceneFile(data(sfmod, "scenes", "mixed_primitives.toml"), cfg)
+    assert sf.desc.camera_count == 2 and sf.camera("main") == 0      # one camera per render-settings entry (cameras.rs:191-203)
+    hs = sfmod.SceneFile(data(sfmod, "scenes", "hdri_small.toml"))
+    assert hs.desc.camera_count == 1 and any("PanoramaCamera" in w for w in hs.warnings)   # the unused panorama camera is skipped
+
+
+def test_scene_errors(sfmod, tmp_path):
+    base = open(data(sfmod, "scenes", "mixed_primitives.toml")).read()
+    def load(text):
+        return sfmod.SceneFile(_write(tmp_path, "s.toml", text))
+    with pytest.raises(sfmod.SceneFileError, match="unknown field `colour`"):
+        load(base.replace('color = "simple_sky_blue"', 'color = "simple_sky_blue"\ncolour = 1'))
+    with pytest.raises(sfmod.SceneFileError, match="unknown variant `Cube`"):
+        load(base.replace('type = "Disk"', 'type = "Cube"'))
+    with pytest.raises(sfmod.SceneFileError, match="radius must be positive"):
+        load(base.replace("radius = 0.7", "radius = 0.0"))
+    with pytest.raises(sfmod.SceneFileError, match="not found in the meshes library"):
+        load(base.replace('name = "gem"', 'name = "no_such_mesh"'))
+    with pytest.raises(sfmod.SceneFileError, match="missing field `two_sided`"):
+        load(base.replace("radius = 0.7\norigin = [0.0, 0.0, 0.0]\ntwo_sided = true", "radius = 0.7\norigin = [0.0, 0.0, 0.0]"))
+    # an unknown material name falls back to the error material with a warning (instance.rs:88-98); an unknown curve in
+    # the environment falls back to mauve (environment.rs:70-75)
+    sf = load(base.replace('material_name = "ggx_gold"', 'material_name = "unobtainium"').replace('color = "simple_sky_blue"', 'color = "nope"'))
+    assert any("unobtainium" in w for w in sf.warnings) and any("error color" in w for w in sf.warnings)
+    assert sf.desc.instances[3].material == (1 << 16)
+    pano = base.replace('type = "SimpleCamera"', 'type = "PanoramaCamera"')
+    with pytest.raises(sfmod.SceneFileError, match="no usable camera"):
+        load(pano)
+
+
+def test_image_readers(sfmod, tmp_path):
+    """Texture4 (PNG RGBA, palette PNG, BMP), Texture1 (luma of an RGB PNG) and HDR (RGBE with run-length scanlines) through
+    a literal texture library."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(5)
+    def png(path, w, h, ctype, rows, extra=b""):
+        def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+        raw = b"".join(b"\0" + r for r in rows)
+        open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) + extra + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+        return chunk
+    rgba = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    png(tmp_path / "rgba.png", 7, 5, 6, [rgba[y].tobytes() for y in range(5)])
+    rgb = rng.integers(0, 256, (4, 3, 3), dtype=np.uint8)
+    png(tmp_path / "rgb.png", 3, 4, 2, [rgb[y].tobytes() for y in range(4)])
+    bmp_px = rng.integers(0, 256, (3, 5, 3), dtype=np.uint8)
+    stride = (5 * 3 + 3) // 4 * 4
+    body = b"".join(bmp_px[y, :, ::-1].tobytes() + b"\0" * (stride - 15) for y in range(2, -1, -1))
+    open(tmp_path / "t.bmp", "wb").write(b"BM" + struct.pack("<IHHI", 54 + len(body), 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 5, 3, 1, 24, 0, len(body), 2835, 2835, 0, 0) + body)
+    w, h = 16, 3
+    rgbe = rng.integers(0, 256, (h, w, 4), dtype=np.uint8); rgbe[..., 3] = rng.integers(120, 136, (h, w)); rgbe[0, 0, 3] = 0
+    rgbe[1, 4:12, 0] = 77  # a run
+    def rle(channel):
+        out, i = b"", 0
+        while i < len(channel):
+            j = i
+            while j < len(channel) and channel[j] == channel[i] and j - i < 127: j += 1
+            if j - i >= 3: out += bytes([128 + j - i, channel[i]]); i = j
+            else:
+                k = i
+                while k < len(channel) and k - i < 128 and not (k + 2 < len(channel) and channel[k] == channel[k + 1] == channel[k + 2]): k += 1
+                k = max(k, i + 1)
+                out += bytes([k - i]) + bytes(channel[i:k].tolist()); i = k
+        return out
+    hdr = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w)
+    for y in range(h):
+        hdr += bytes([2, 2, w >> 8, w & 255]) + b"".join(rle(rgbe[y, :, c]) for c in range(4))
+    open(tmp_path / "t.hdr", "wb").write(hdr)
+    lib = 'curves = { one = { type = "Flat", strength = 1.0 } }\nmaterials = {}\nmeshes = {}\n'
+    tex = "[textures]\n" + "\n".join('%s = [{ type = "%s", filename = "%s", %s }]' % (n, t, tmp_path / f, c) for n, t, f, c in (
+        ("rgba", "Texture4", "rgba.png", 'curves = ["one", "one", "one", "one"]'), ("bmp", "Texture4", "t.bmp", 'curves = ["one", "one", "one", "one"]'),
+        ("luma", "Texture1", "rgb.png", 'curve = "one"'), ("hdr", "HDR", "t.hdr", 'alpha_fill = 0.25, curves = ["one", "one", "one", "one"]')))
+    for name, expect in (("rgba", rgba.astype(np.float32) / np.float32(255)),
+                         ("bmp", np.concatenate([bmp_px, np.full((3, 5, 1), 255, np.uint8)], axis=2).astype(np.float32) / np.float32(255)),
+                         ("luma", ((2126 * rgb[..., 0].astype(np.uint32) + 7152 * rgb[..., 1].astype(np.uint32) + 722 * rgb[..., 2].astype(np.uint32)) // 10000).astype(np.float32) / np.float32(255)),
+                         ("hdr", None)):
+        scene = lib + 'env_sampling_probability = 1.0\ninstances = []\n[environment]\ntype = "HDRI"\ntexture_name = "%s"\nstrength = 1.0\n[[cameras]]\ntype = "SimpleCamera"\nname = "c"\nlook_from = [0.0, 0.0, 0.0]\nlook_at = [1.0, 0.0, 0.0]\nvfov = 30.0\n' % name + tex
+        sf = sfmod.SceneFile(_write(tmp_path, "tex_%s.toml" % name, scene))
+        d = sf.desc
+        layer = d.layers[d.texstacks[d.environment.texstack].first_layer]
+        n = layer.width * layer.height * (1 if layer.kind == 1 else 4)
+        got = np.ctypeslib.as_array(d.texture_data, shape=(d.texture_data_count,))[layer.data_offset:layer.data_offset + n]
+        if expect is None:
+            scale = np.where(rgbe[..., 3] == 0, 0.0, np.ldexp(1.0, rgbe[..., 3].astype(np.int32) - 136)).astype(np.float32)
+            expect = np.concatenate([rgbe[..., :3].astype(np.float32) * scale[..., None], np.full((h, w, 1), 0.25, np.float32)], axis=2)
+        assert (layer.height, layer.width) == expect.shape[:2], name
+        assert np.array_equal(got.reshape(expect.shape), expect.astype(np.float32)), name
+
+
+@pytest.mark.gpu
+def test_command_line_render_matches_the_library(sfmod, pkg, engine, tmp_path):
+    """ptcli end to end on the GPU: config + scene TOML -> film, EXR, PNG; the raw film equals the one rendered through
+    the Python front end with the same settings, bit for bit."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.LIBRARY_PATH), "ptcli")
+    out = tmp_path / "out"
+    r = subprocess.run([exe, "--root", pkg.PACKAGE_DIR, "--config", "data/config_two_passes.toml", "--output-dir", str(out), "--seed", "5", "--write-film"],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "render done" in r.stdout and r.stdout.count("Msamples/s") == 2
+    cfg = sfmod.Config(data(sfmod, "config_two_passes.toml"))
+    scene = engine.create_scene(pkg.scene.mixed_primitives())
+    for i, name in enumerate(("beauty", "direct_only")):
+        film = np.load(out / (name + ".npy"))
+        rd = cfg.render_desc(i, seed=5)
+        ref, _ = scene.render(rd)
+        assert film.shape == ref.shape and np.array_equal(film.view(np.uint32), ref.view(np.uint32)), name
+        assert (out / (name + ".exr")).stat().st_size > rd.width * rd.height * 12 and (out / (name + ".png")).read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
+    # the EXR holds factor * film in linear Rec.709 (first pass: Rec709 colour space, no premultiply)
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("compare_films", os.path.join(sys_path, "compare_films.py"))
+    cf = importlib.util.module_from_spec(spec); spec.loader.exec_module(cf)
+    exr = cf.read_exr(str(out / "beauty.exr"))
+    _, lin = engine.output_film(np.load(out / "beauty.npy"), tonemap=pkg.api.TONEMAP_CLAMP, colorspace=pkg.api.COLORSPACE_REC709)
+    assert np.array_equal(exr[..., :3], lin)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_gem", "hdri_small"])
+def test_engine_renders_the_same_film_from_either_front_end(sfmod, pkg, engine, name):
+    sf = sfmod.SceneFile(data(sfmod, "scenes", SCENE_FILES[name]))
+    rd = pkg.api.render_desc(96, 64, 8, 6, light_samples=2, seed=11)
+    film_f, prof_f = engine.create_scene(sf).render(rd)
+    film_b, prof_b = engine.create_scene(pkg.scene.SCENES[name]()).render(rd)
+    assert np.array_equal(film_f.view(np.uint32), film_b.view(np.uint32))
+    assert (prof_f.bounce_rays, prof_f.shadow_rays, prof_f.env_hits) == (prof_b.bounce_rays, prof_b.shadow_rays, prof_b.env_hits)
