@@ -250,14 +250,75 @@ def test_image_readers(sfmod, tmp_path):
     for y in range(h):
         hdr += bytes([2, 2, w >> 8, w & 255]) + b"".join(rle(rgbe[y, :, c]) for c in range(4))
     open(tmp_path / "t.hdr", "wb").write(hdr)
+    # OpenEXR: ZIP (16-line blocks, half + float channels, no alpha -> alpha 1), ZIPS, RLE and a tiled uncompressed file
+    def exr(path, img, compression, half=(), tiled=None, channels="ABGR"):
+        hh, ww, _ = img.shape
+        def attr(name, typ, d): return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(d)) + d
+        names = sorted(channels)
+        ch = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", 1 if n in half else 2, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+        box = struct.pack("<4i", 0, 0, ww - 1, hh - 1)
+        head = struct.pack("<II", 20000630, 2 | (0x200 if tiled else 0)) + attr("channels", "chlist", ch) + attr("compression", "compression", bytes([compression])) + \
+            attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + \
+            attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + \
+            attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + (attr("tiles", "tiledesc", struct.pack("<IIB", tiled[0], tiled[1], 0)) if tiled else b"") + b"\0"
+        slot = {"R": 0, "G": 1, "B": 2, "A": 3}
+        def block(x0, y0, bw, bh):
+            raw = b""
+            for y in range(y0, y0 + bh):
+                for n in names:
+                    row = img[y, x0:x0 + bw, slot[n]]
+                    raw += row.astype(np.float16).tobytes() if n in half else row.astype(np.float32).tobytes()
+            if compression == 0:
+                return raw
+            a = np.frombuffer(raw, np.uint8)
+            inter = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+            pred = inter.copy(); pred[1:] = (inter[1:] - inter[:-1] + 128 + 256) % 256
+            pred = pred.astype(np.uint8).tobytes()
+            if compression == 1:
+                out, i = b"", 0
+                while i < len(pred):
+                    j = i
+                    while j < len(pred) and pred[j] == pred[i] and j - i < 127: j += 1
+                    if j - i >= 3: out += struct.pack("b", j - i - 1) + pred[i:i + 1]; i = j
+                    else:
+                        k = min(len(pred), i + 100)
+                        out += struct.pack("b", -(k - i)) + pred[i:k]; i = k
+                comp = out
+            else:
+                comp = zlib.compress(pred)
+            return comp if len(comp) < len(raw) else raw
+        blocks = []
+        if tiled:
+            for ty in range((hh + tiled[1] - 1) // tiled[1]):
+                for tx in range((ww + tiled[0] - 1) // tiled[0]):
+                    bw, bh = min(tiled[0], ww - tx * tiled[0]), min(tiled[1], hh - ty * tiled[1])
+                    d = block(tx * tiled[0], ty * tiled[1], bw, bh)
+                    blocks.append(struct.pack("<4iI", tx, ty, 0, 0, len(d)) + d)
+        else:
+            lines = 16 if compression == 3 else 1
+            for y0 in range(0, hh, lines):
+                d = block(0, y0, ww, min(lines, hh - y0))
+                blocks.append(struct.pack("<iI", y0, len(d)) + d)
+        pos, table = len(head) + 8 * len(blocks), b""
+        for b in blocks:
+            table += struct.pack("<Q", pos); pos += len(b)
+        open(path, "wb").write(head + table + b"".join(blocks))
+    img = np.zeros((37, 21, 4), np.float32)
+    yy, xx = np.mgrid[0:37, 0:21]
+    img[..., 0] = xx * 0.25; img[..., 1] = yy * 0.5 + 0.125; img[..., 2] = (xx + yy) % 5; img[..., 3] = 0.5
+    exr_cases = {"exr_zip": dict(compression=3, half=("G",), channels="BGR"), "exr_zips": dict(compression=2), "exr_rle": dict(compression=1, half=("R", "A")),
+                 "exr_tiled": dict(compression=0, tiled=(8, 16))}
+    for n, kw in exr_cases.items():
+        exr(tmp_path / (n + ".exr"), img, **kw)
     lib = 'curves = { one = { type = "Flat", strength = 1.0 } }\nmaterials = {}\nmeshes = {}\n'
     tex = "[textures]\n" + "\n".join('%s = [{ type = "%s", filename = "%s", %s }]' % (n, t, tmp_path / f, c) for n, t, f, c in (
         ("rgba", "Texture4", "rgba.png", 'curves = ["one", "one", "one", "one"]'), ("bmp", "Texture4", "t.bmp", 'curves = ["one", "one", "one", "one"]'),
-        ("luma", "Texture1", "rgb.png", 'curve = "one"'), ("hdr", "HDR", "t.hdr", 'alpha_fill = 0.25, curves = ["one", "one", "one", "one"]')))
+        ("luma", "Texture1", "rgb.png", 'curve = "one"'), ("hdr", "HDR", "t.hdr", 'alpha_fill = 0.25, curves = ["one", "one", "one", "one"]')) +
+        tuple((n, "EXR", n + ".exr", 'curves = ["one", "one", "one", "one"]') for n in exr_cases))
     for name, expect in (("rgba", rgba.astype(np.float32) / np.float32(255)),
                          ("bmp", np.concatenate([bmp_px, np.full((3, 5, 1), 255, np.uint8)], axis=2).astype(np.float32) / np.float32(255)),
                          ("luma", ((2126 * rgb[..., 0].astype(np.uint32) + 7152 * rgb[..., 1].astype(np.uint32) + 722 * rgb[..., 2].astype(np.uint32)) // 10000).astype(np.float32) / np.float32(255)),
-                         ("hdr", None)):
+                         ("hdr", None)) + tuple((n, np.where(np.arange(4) == 3, np.float32(1.0), img) if n == "exr_zip" else img) for n in exr_cases):
         scene = lib + 'env_sampling_probability = 1.0\ninstances = []\n[environment]\ntype = "HDRI"\ntexture_name = "%s"\nstrength = 1.0\n[[cameras]]\ntype = "SimpleCamera"\nname = "c"\nlook_from = [0.0, 0.0, 0.0]\nlook_at = [1.0, 0.0, 0.0]\nvfov = 30.0\n' % name + tex
         sf = sfmod.SceneFile(_write(tmp_path, "tex_%s.toml" % name, scene))
         d = sf.desc
