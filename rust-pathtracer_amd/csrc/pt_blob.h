@@ -102,6 +102,7 @@
 #define PT_FLAG_EXACT_SLAB 2u    /* diagnostics (PT_AMD_EXACT_SLAB=1): always take the six-division slab test */
 #define PT_FLAG_NO_CULL 4u       /* diagnostics (PT_AMD_NO_CULL=1): never cull by the closest hit */
 #define PT_FLAG_NO_SHADOW_BOUND 8u /* a mesh instance can produce a Light-tagged hit: the light pre-pass of shadow rays is off */
+#define PT_FLAG_SWEEP_WALKS 32u   /* the sweep table holds mesh instances whose BVH is walked (hybrid form) */
 #define PT_FLAG_NO_SWEEP 16u      /* diagnostics (PT_AMD_NO_SWEEP=1): always walk the BVHs */
 #define PT_FLAG_NO_TOP_CULL 1u   /* a Disk instance exists: its reference box (radius/2, disk.rs:24-28) does not contain it */
 
@@ -117,6 +118,7 @@
 // Bit table (PT_HDR_SWEEP_BITS_OFF): per mask bit 8 words: instance record offset, triangle word offset (0: the instance
 // itself), box word offset (min at +0, max at +4), kind | flat << 8 | has_transform << 9 | instance id << 16,
 // followers (2 words: the later bits that alias this one, directly or through a chain), 2 pad
+#define PT_SWEEP_WALKED 0x400u     /* kind/flags word: a mesh instance whose triangles are not in the table; its BVH is walked */
 #define PT_SWEEP_INST_WORDS 12
 #define PT_SWEEP_TRI_WORDS 8
 #define PT_SWEEP_BIT_WORDS 8

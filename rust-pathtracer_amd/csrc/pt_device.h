@@ -476,8 +476,8 @@ PT_HD void hit_record(const SceneView& s, F3 o, F3 d, uint32_t best_inst, uint32
 #define PT_UNIFORM(x) (x)
 #endif
 PT_HD uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
-PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, bool stop_on_nonlight) {
-    const uint32_t NONE = 0xffffffffu;
+// Phases 1 and 2: the mask of leaves whose own box the ray hits (walked mesh instances keep their instance bit).
+PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
     const uint32_t flags = bu(s, PT_HDR_FLAGS), sweep = bu(s, PT_HDR_SWEEP_OFF), count = bu(s, PT_HDR_SWEEP_COUNT), bits_off = bu(s, PT_HDR_SWEEP_BITS_OFF);
     const bool exact = (flags & PT_FLAG_EXACT_SLAB) != 0;
     const bool cull_top = (flags & (PT_FLAG_NO_TOP_CULL | PT_FLAG_NO_CULL)) == 0, cull_mesh = (flags & PT_FLAG_NO_CULL) == 0;
@@ -501,7 +501,7 @@ PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound
             const uint32_t m = 1u << (bit & 31u);
             if (bit < 32u) { hit_lo |= c == 1 ? m : 0u; unc_lo |= c == 2 ? m : 0u; } else { hit_hi |= c == 1 ? m : 0u; unc_hi |= c == 2 ? m : 0u; }
         }
-        if ((kf & 0xffu) == PT_SHAPE_MESH && PT_WAVE_ANY(c != 0)) {
+        if ((kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH && PT_WAVE_ANY(c != 0)) {
             const uint32_t tl = PT_UNIFORM(pt_f2u(a.w)), tc = PT_UNIFORM(pt_f2u(b.w));
             RayPrep lr = wr; bool lquick = quick;
             if (kf & 0x200u) {
@@ -545,52 +545,125 @@ PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound
         if (bounded && h && (triw != 0u ? cull_mesh : cull_top) && beyond(entry, bound, 0.0f)) h = false;
         unc &= ~followers;
         if (h) hit |= 1ull << k | followers;
-        else if (triw == 0u && (kf & 0xffu) == PT_SHAPE_MESH) {
+        else if (triw == 0u && (kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH) {
             const uint32_t tc = pt_f2u(bf4(s, box + 4).w);  // triangle-leaf count rides in the instance entry's max.w
             const uint64_t range = (tc + 1 >= 64 ? ~0ull : ((1ull << (tc + 1)) - 1)) << k;
             hit &= ~range; unc &= ~range;
         }
     }
     hit &= ~((uint64_t)bu(s, PT_HDR_SWEEP_MESH_MASK) | (uint64_t)bu(s, PT_HDR_SWEEP_MESH_MASK + 1) << 32);
-    // 3 — primitive tests in pre-order (ties are broken by that order, as in world_hit)
-    const TriRay wtr = tri_ray_prepare(o, d);
-    float closest = PT_INF;
-    uint32_t best_inst = NONE, best_triw = 0;
-    TriHit bh; bh.t = 0.0f; bh.b0 = bh.b1 = bh.b2 = 0.0f;
-    while (hit != 0) {
-        const uint32_t k = ctz64(hit);
-        hit &= hit - 1;
+    return hit;
+}
+
+// The running state of phase 3 — it can be parked (a lane that reaches a walked mesh) and resumed later.
+struct SweepState { uint64_t hit; float closest; uint32_t best_inst, best_triw; TriHit bh; };
+PT_HD void sweep_state_init(SweepState& st, uint64_t hit) {
+    st.hit = hit; st.closest = PT_INF; st.best_inst = 0xffffffffu; st.best_triw = 0u; st.bh.t = 0.0f; st.bh.b0 = st.bh.b1 = st.bh.b2 = 0.0f;
+}
+// Mesh::hit (src/geometry/mesh.rs:314-360) for one instance, against the running closest hit: the mesh half of
+// world_hit_walk on its own (same while-while loop, same filtered box test, same culling).
+PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, F3 d, float bound, bool stop_on_nonlight, SweepState& st) {
+    const uint32_t NONE = 0xffffffffu;
+    const uint32_t flags = bu(s, PT_HDR_FLAGS);
+    const bool cull = (flags & PT_FLAG_NO_CULL) == 0;
+    F3 lo, ld;
+    instance_local_ray(s, inst, o, d, &lo, &ld);
+    RayPrep cr = ray_prepare(lo, ld);
+    if (flags & PT_FLAG_EXACT_SLAB) cr.fast = false;
+    const TriRay tr = tri_ray_prepare(lo, ld);
+    const uint32_t mesh = bu(s, inst + PT_INST_MESH);
+    const uint32_t node_off = bu(s, mesh + PT_MESH_NODE_OFF), node_count = bu(s, mesh + PT_MESH_NODE_COUNT), tri_off = bu(s, mesh + PT_MESH_TRI_OFF);
+    float limit = __builtin_fminf(st.closest, bound);
+    uint32_t i = 0;
+    for (;;) {
+        uint32_t pending = NONE;
+        while (i < node_count && pending == NONE) {
+            F4 a = bf4(s, node_off + i * PT_NODE_WORDS), b = bf4(s, node_off + i * PT_NODE_WORDS + 4);
+            uint32_t exit_i = pt_f2u(a.w), shape = pt_f2u(b.w);
+            float entry;
+            bool box = aabb_hit(a, b, cr, &entry) && !(cull && beyond(entry, limit, cr.base));
+            if (shape == PT_NODE_INNER) i = box ? i + 1 : exit_i;
+            else { i = exit_i; if (box) pending = shape; }
+        }
+        if (pending == NONE) break;
+        uint32_t t = tri_off + pending * PT_TRI_WORDS;
+        F4 q0 = bf4(s, t), q1 = bf4(s, t + 4), q2 = bf4(s, t + 8);
+        TriHit th;
+        if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
+            st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th;
+            limit = __builtin_fminf(st.closest, bound);
+            if (stop_on_nonlight && st.closest < bound) {
+                uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+                if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) { st.hit = 0; break; }  // something opaque in front of every light
+            }
+        }
+    }
+}
+// Phase 3: the primitive tests of the set bits in pre-order (ties are broken by that order, as in world_hit_walk).  With
+// `park_at_walked` the loop returns true when the next bit is a walked mesh instance, leaving the bit set: the caller
+// parks the state and resumes with sweep_resume; otherwise walked meshes are walked in line.
+PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bound, bool stop_on_nonlight, SweepState& st, bool park_at_walked) {
+    const uint32_t bits_off = bu(s, PT_HDR_SWEEP_BITS_OFF);
+    while (st.hit != 0) {
+        const uint32_t k = ctz64(st.hit);
         const F4 be = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS);
         const uint32_t inst = pt_f2u(be.x), triw = pt_f2u(be.y), kf = pt_f2u(be.w);
+        if (kf & PT_SWEEP_WALKED) {
+            if (park_at_walked) return true;
+            st.hit &= st.hit - 1;
+            mesh_walk(s, inst, kf >> 16, o, d, bound, stop_on_nonlight, st);
+            continue;
+        }
+        st.hit &= st.hit - 1;
         PT_STAT_EVENT(triw != 0u ? 3 : 4);
         if (triw != 0u) {
             const F4 q0 = bf4(s, triw), q1 = bf4(s, triw + 4), q2 = bf4(s, triw + 8);
             TriRay tr = wtr;
             if (kf & 0x200u) { F3 lo, ld; instance_local_ray(s, inst, o, d, &lo, &ld); tr = tri_ray_prepare(lo, ld); }
             TriHit th;
-            if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, closest, &th)) {
-                closest = th.t; best_inst = kf >> 16; best_triw = triw; bh = th;
-                if (stop_on_nonlight && closest < bound) {
+            if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
+                st.closest = th.t; st.best_inst = kf >> 16; st.best_triw = triw; st.bh = th;
+                if (stop_on_nonlight && st.closest < bound) {
                     uint32_t im = bu(s, inst + PT_INST_MATERIAL);
-                    if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) hit = 0;  // something opaque in front of every light
+                    if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) st.hit = 0;  // something opaque in front of every light
                 }
             }
         } else {
             F3 lo, ld;
             instance_local_ray(s, inst, o, d, &lo, &ld);
             Hit h;
-            if (analytic_hit(s, inst, kf & 0xffu, lo, ld, closest, &h)) {
-                closest = h.t; best_inst = kf >> 16; best_triw = 0;
-                if (stop_on_nonlight && closest < bound) {
+            if (analytic_hit(s, inst, kf & 0xffu, lo, ld, st.closest, &h)) {
+                st.closest = h.t; st.best_inst = kf >> 16; st.best_triw = 0;
+                if (stop_on_nonlight && st.closest < bound) {
                     uint32_t im = bu(s, inst + PT_INST_MATERIAL);
-                    if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : h.material) != PT_TAG_LIGHT) hit = 0;
+                    if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : h.material) != PT_TAG_LIGHT) st.hit = 0;
                 }
             }
         }
     }
-    if (best_inst == NONE) { out->valid = false; return false; }
-    hit_record(s, o, d, best_inst, best_triw, bh, out);
+    return false;
+}
+// A parked lane: walk the mesh of its lowest set bit, then carry on with phase 3 (it may park again at another walked mesh).
+PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, bool stop_on_nonlight, SweepState& st) {
+    const uint32_t k = ctz64(st.hit);
+    const F4 be = bf4(s, bu(s, PT_HDR_SWEEP_BITS_OFF) + k * PT_SWEEP_BIT_WORDS);
+    st.hit &= st.hit - 1;
+    mesh_walk(s, pt_f2u(be.x), pt_f2u(be.w) >> 16, o, d, bound, stop_on_nonlight, st);
+    if (st.hit == 0) return false;
+    const TriRay wtr = tri_ray_prepare(o, d);
+    return sweep_run(s, o, d, wtr, bound, stop_on_nonlight, st, true);
+}
+PT_HD bool sweep_finish(const SceneView& s, F3 o, F3 d, const SweepState& st, Hit* out) {
+    if (st.best_inst == 0xffffffffu) { out->valid = false; return false; }
+    hit_record(s, o, d, st.best_inst, st.best_triw, st.bh, out);
     return true;
+}
+PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, bool stop_on_nonlight) {
+    SweepState st;
+    sweep_state_init(st, sweep_masks(s, o, d, bound));
+    const TriRay wtr = tri_ray_prepare(o, d);
+    sweep_run(s, o, d, wtr, bound, stop_on_nonlight, st, false);
+    return sweep_finish(s, o, d, st, out);
 }
 
 PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound, bool stop_on_nonlight) {

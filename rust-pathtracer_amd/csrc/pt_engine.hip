@@ -53,6 +53,10 @@ constexpr int kBlock = 256;
 #ifndef PT_WALK_WAVES
 #define PT_WALK_WAVES 1
 #endif
+#ifndef PT_PARK_WAVES
+#define PT_PARK_WAVES 1
+#endif
+#define PT_PARK_OCC __attribute__((amdgpu_waves_per_eu(PT_PARK_WAVES)))
 #define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(NL == 1 ? PT_SHADE_WAVES : PT_SHADE4_WAVES)))
 #define PT_TRAV_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? PT_SWEEP_WAVES : PT_WALK_WAVES)))
 constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // stage the blob in LDS when it fits (keeps >= 2 workgroups per CU)
@@ -228,6 +232,148 @@ __global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_shadow(const uint32_t* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------ parked traversal
+// Scenes whose sweep table holds walked meshes (PT_FLAG_SWEEP_WALKS: a few analytic shapes and small meshes around one or
+// more big meshes — the gem in the Cornell room, the monkey under the HDRI).  Most rays never enter a big mesh's box, and
+// the ones that do are scattered over the waves, so walking the mesh in line would leave a wave waiting for a handful of
+// lanes.  Instead a lane that reaches a walked-mesh bit *parks* its sweep state in the workgroup's scratch region, and
+// whenever 256 rays are parked (and at the end) the workgroup resumes them together: full waves, every lane in a mesh
+// walk.  Nothing about a ray's own sequence of tests changes (same leaves, same order, same running closest hit).
+constexpr uint32_t kParkCap = 512, kParkFields = 16;
+enum { PK_ITEM, PK_HIT_LO, PK_HIT_HI, PK_CLOSEST, PK_BEST_INST, PK_BEST_TRIW, PK_T, PK_B0, PK_B1, PK_B2, PK_RAY, PK_BOUND, PK_KIND };
+__device__ __forceinline__ void park_store(uint32_t* pk, uint32_t e, uint32_t item, const SweepState& st, uint32_t ray, float bound, uint32_t kind) {
+    pk[PK_ITEM * kParkCap + e] = item; pk[PK_HIT_LO * kParkCap + e] = (uint32_t)st.hit; pk[PK_HIT_HI * kParkCap + e] = (uint32_t)(st.hit >> 32);
+    pk[PK_CLOSEST * kParkCap + e] = pt_f2u(st.closest); pk[PK_BEST_INST * kParkCap + e] = st.best_inst; pk[PK_BEST_TRIW * kParkCap + e] = st.best_triw;
+    pk[PK_T * kParkCap + e] = pt_f2u(st.bh.t); pk[PK_B0 * kParkCap + e] = pt_f2u(st.bh.b0); pk[PK_B1 * kParkCap + e] = pt_f2u(st.bh.b1); pk[PK_B2 * kParkCap + e] = pt_f2u(st.bh.b2);
+    pk[PK_RAY * kParkCap + e] = ray; pk[PK_BOUND * kParkCap + e] = pt_f2u(bound); pk[PK_KIND * kParkCap + e] = kind;
+}
+__device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32_t* item, SweepState* st, uint32_t* ray, float* bound, uint32_t* kind) {
+    *item = pk[PK_ITEM * kParkCap + e]; st->hit = (uint64_t)pk[PK_HIT_LO * kParkCap + e] | (uint64_t)pk[PK_HIT_HI * kParkCap + e] << 32;
+    st->closest = pt_u2f(pk[PK_CLOSEST * kParkCap + e]); st->best_inst = pk[PK_BEST_INST * kParkCap + e]; st->best_triw = pk[PK_BEST_TRIW * kParkCap + e];
+    st->bh.t = pt_u2f(pk[PK_T * kParkCap + e]); st->bh.b0 = pt_u2f(pk[PK_B0 * kParkCap + e]); st->bh.b1 = pt_u2f(pk[PK_B1 * kParkCap + e]); st->bh.b2 = pt_u2f(pk[PK_B2 * kParkCap + e]);
+    *ray = pk[PK_RAY * kParkCap + e]; *bound = pt_u2f(pk[PK_BOUND * kParkCap + e]); *kind = pk[PK_KIND * kParkCap + e];
+}
+// The resume loop shared by both kernels: `resume(entry state)` runs for up to 256 parked rays at a time.
+template <typename Resume>
+__device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, bool last, Resume&& resume) {
+    for (;;) {
+        const uint32_t cnt = *park_count;  // uniform: read between barriers
+        if (!(cnt >= kBlock || (last && cnt > 0))) break;
+        const uint32_t take = cnt < (uint32_t)kBlock ? cnt : (uint32_t)kBlock, first = cnt - take;
+        const bool mine = threadIdx.x < take;
+        uint32_t item = 0, ray = 0, kind = 0; float bound = PT_INF; SweepState st;
+        if (mine) park_load(pk, first + threadIdx.x, &item, &st, &ray, &bound, &kind);
+        __syncthreads();                   // every entry has been read
+        if (threadIdx.x == 0) *park_count = first;
+        __syncthreads();
+        if (mine) resume(item, st, ray, bound, kind);
+        __syncthreads();
+    }
+}
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                                     Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
+                                                                     uint32_t* __restrict__ park_all) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ uint32_t park_count;
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap;
+    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
+    if (threadIdx.x == 0) park_count = 0;
+    __syncthreads();
+    auto ray_of = [&](uint32_t i, F3* o, F3* d) {
+        *o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
+        *d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
+    };
+    auto settle = [&](uint32_t j, F3 o, F3 d, const SweepState& st, bool parked) {
+        if (parked) park_store(pk, atomicAdd(&park_count, 1u), j, st, 0u, PT_INF, 0u);
+        else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, base + j, h); }
+    };
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t j = r * blockDim.x + threadIdx.x;
+        if (j < n) {
+            F3 o, d;
+            ray_of(base + j, &o, &d);
+            SweepState st;
+            sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
+            const TriRay wtr = tri_ray_prepare(o, d);
+            settle(j, o, d, st, sweep_run(s, o, d, wtr, PT_INF, false, st, true));
+        }
+        __syncthreads();
+        park_drain(pk, &park_count, r + 1 == rounds, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t) {
+            F3 o, d;
+            ray_of(base + j2, &o, &d);
+            settle(j2, o, d, st, sweep_resume(s, o, d, PT_INF, false, st));
+        });
+    }
+}
+
+template <bool USE_LDS, int NL>
+__global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                                     uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
+                                                                     uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ park_all) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ uint32_t park_count;
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap;
+    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
+    if (threadIdx.x == 0) park_count = 0;
+    __syncthreads();
+    // a finished ray leaves its contribution where its factor was; the item's rays are summed in order at the end
+    auto settle = [&](uint32_t j, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked) {
+        if (parked) { park_store(pk, atomicAdd(&park_count, 1u), j, st, l, bound, env ? 1u : 0u); return; }
+        const uint32_t item = base + j;
+        float lambda[NL], c[NL];
+        for (int k = 0; k < NL; ++k) lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item);
+        Hit sh;
+        bool hit = sweep_finish(s, ray.o, ray.d, st, &sh);
+        shadow_ray_contribution<NL>(s, lambda, ray, env, hit, sh, c);
+        for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
+    };
+    // one ray of every item per step, so that a step parks at most one ray per lane (the scratch region holds 512)
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t j = r * blockDim.x + threadIdx.x;
+        const uint32_t item = base + j, flags = j < n ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
+        for (uint32_t l = 0; l < light_samples; ++l) {
+            ShadowRayT<NL> ray;
+            if (j < n && load_shadow_ray<NL>(shadow, item, l, &ray)) {
+                const bool env = ((flags >> l) & 1u) != 0;
+                float bound = PT_INF; bool stop = false;
+                if (!env && !shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) {
+                    for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
+                } else {
+                    SweepState st;
+                    sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
+                    const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
+                    settle(j, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true));
+                }
+            }
+            __syncthreads();
+            park_drain(pk, &park_count, r + 1 == rounds && l + 1 == light_samples, [&](uint32_t j2, SweepState& st, uint32_t l2, float bound, uint32_t kind) {
+                ShadowRayT<NL> pr;
+                load_shadow_ray<NL>(shadow, base + j2, l2, &pr);
+                const bool env = kind != 0u;
+                // a light ray searches with the early stop whenever it has a finite bound (shadow_light_bound)
+                settle(j2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, !env && bound < PT_INF, st));
+            });
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = 0; r < rounds; ++r) {  // pt.rs:349-392, 596: the item's rays summed in order, divided by L
+        const uint32_t j = r * blockDim.x + threadIdx.x;
+        if (j >= n) continue;
+        const uint32_t item = base + j, slot = qu(shadow, Layout<NL>::sh_slot, item);
+        float lc[NL];
+        for (int k = 0; k < NL; ++k) lc[k] = 0.0f;
+        for (uint32_t l = 0; l < light_samples; ++l)
+            for (int k = 0; k < NL; ++k) lc[k] += qf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item);
+        for (int k = 0; k < NL; ++k) energy[(size_t)k * energy_stride + slot] += lc[k] / (float)light_samples;
+    }
+}
+
 template <int NL>
 __global__ void __launch_bounds__(kBlock) k_accumulate(RenderParams rp, const uint32_t* __restrict__ pixels, const float* __restrict__ energy,
                                                       float* __restrict__ film) {
@@ -302,13 +448,13 @@ __global__ void __launch_bounds__(kBlock) k_probe_numerics(int which, uint32_t n
 // ------------------------------------------------------------------------------------------------ host side
 struct DeviceBuffers {
     uint32_t capacity = 0, light_samples = 0, nl = 0;
-    uint32_t *paths_a = nullptr, *paths_b = nullptr, *hits = nullptr, *shadow = nullptr, *pixels = nullptr, *counts = nullptr;
+    uint32_t *paths_a = nullptr, *paths_b = nullptr, *hits = nullptr, *shadow = nullptr, *pixels = nullptr, *counts = nullptr, *park = nullptr;
     float* energy = nullptr;
     unsigned long long* block_stats = nullptr;
     size_t pixel_capacity = 0;
     int grid = 0;  // segments per queue == workgroups per launch
     void release() {
-        hipFree(paths_a); hipFree(paths_b); hipFree(hits); hipFree(shadow); hipFree(pixels); hipFree(counts); hipFree(energy); hipFree(block_stats);
+        hipFree(paths_a); hipFree(paths_b); hipFree(hits); hipFree(shadow); hipFree(pixels); hipFree(counts); hipFree(energy); hipFree(block_stats); hipFree(park);
         *this = DeviceBuffers();
     }
 };
@@ -349,8 +495,8 @@ pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples
     DeviceBuffers& b = sc->buf;
     uint32_t total = segment_capacity(capacity, grid) * (uint32_t)grid;
     if (b.capacity < total || b.light_samples < light_samples || b.grid != grid || b.nl < nl) {
-        hipFree(b.paths_a); hipFree(b.paths_b); hipFree(b.hits); hipFree(b.shadow); hipFree(b.energy); hipFree(b.counts); hipFree(b.block_stats);
-        b.paths_a = b.paths_b = b.hits = b.shadow = b.counts = nullptr; b.energy = nullptr; b.block_stats = nullptr; b.capacity = 0;
+        hipFree(b.paths_a); hipFree(b.paths_b); hipFree(b.hits); hipFree(b.shadow); hipFree(b.energy); hipFree(b.counts); hipFree(b.block_stats); hipFree(b.park);
+        b.paths_a = b.paths_b = b.hits = b.shadow = b.counts = b.park = nullptr; b.energy = nullptr; b.block_stats = nullptr; b.capacity = 0;
         uint32_t ls = light_samples > b.light_samples ? light_samples : b.light_samples;
         uint32_t nlmax = nl > b.nl ? nl : b.nl;
         size_t path_fields = nlmax == 4 ? Layout<4>::path_fields : Layout<1>::path_fields;
@@ -363,6 +509,7 @@ pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples
         b.nl = nlmax;
         HIP_TRY(hipMalloc(&b.counts, sizeof(uint32_t) * 3 * (size_t)grid));
         HIP_TRY(hipMalloc(&b.block_stats, sizeof(unsigned long long) * BS_FIELDS * (size_t)grid));
+        if (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) HIP_TRY(hipMalloc(&b.park, sizeof(uint32_t) * kParkFields * kParkCap * (size_t)grid));
         b.capacity = total; b.light_samples = ls; b.grid = grid;
     }
     if (b.pixel_capacity < n_pixels) {
@@ -419,6 +566,8 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     const uint32_t blob_bytes = sc->blob_words * 4;
     const bool lds = sc->use_lds;
     const bool sweep = sc->host.blob[PT_HDR_SWEEP_OFF] != 0 && !(sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP);
+    // the sweep table holds walked meshes: rays that reach one are parked and resumed in full waves (PT_AMD_NO_PARK=1: in line)
+    const bool parked = sweep && (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) && b.park != nullptr && !env_u32("PT_AMD_NO_PARK", 0);
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
     const bool timing = env_u32("PT_AMD_STAGE_TIMING", 1) != 0;
     double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0};
@@ -463,7 +612,11 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
             uint32_t *cin = live[bounce & 1], *cout = live[(bounce + 1) & 1];
             timed(ST_EXTEND, [&] {
 #define PT_LAUNCH_EXTEND(LDSF, TRAVV) launch(k_extend<LDSF, TRAVV>, LDSF, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin)
-                if (!lds) PT_LAUNCH_EXTEND(false, PT_TRAV_ANY);
+                if (parked) {
+                    if (lds) launch(k_extend_parked<true>, true, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin, b.park);
+                    else launch(k_extend_parked<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin, b.park);
+                }
+                else if (!lds) PT_LAUNCH_EXTEND(false, PT_TRAV_ANY);
                 else if (sweep) PT_LAUNCH_EXTEND(true, PT_TRAV_SWEEP);
                 else PT_LAUNCH_EXTEND(true, PT_TRAV_WALK);
 #undef PT_LAUNCH_EXTEND
@@ -479,7 +632,14 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
                 timed(ST_SHADOW, [&] {
 #define PT_LAUNCH_SHADOW(LDSF, NLV, TRAVV) launch(k_shadow<LDSF, NLV, TRAVV>, LDSF, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, \
                                           b.capacity, seg_cap, nshadow)
-                    if (!lds) { if (hero) PT_LAUNCH_SHADOW(false, 4, PT_TRAV_ANY); else PT_LAUNCH_SHADOW(false, 1, PT_TRAV_ANY); }
+#define PT_LAUNCH_SHADOW_PARKED(LDSF, NLV) launch(k_shadow_parked<LDSF, NLV>, LDSF, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, \
+                                                 b.energy, b.capacity, seg_cap, nshadow, b.park)
+                    if (parked) {
+                        if (lds) { if (hero) PT_LAUNCH_SHADOW_PARKED(true, 4); else PT_LAUNCH_SHADOW_PARKED(true, 1); }
+                        else { if (hero) PT_LAUNCH_SHADOW_PARKED(false, 4); else PT_LAUNCH_SHADOW_PARKED(false, 1); }
+                    }
+#undef PT_LAUNCH_SHADOW_PARKED
+                    else if (!lds) { if (hero) PT_LAUNCH_SHADOW(false, 4, PT_TRAV_ANY); else PT_LAUNCH_SHADOW(false, 1, PT_TRAV_ANY); }
                     else if (sweep) { if (hero) PT_LAUNCH_SHADOW(true, 4, PT_TRAV_SWEEP); else PT_LAUNCH_SHADOW(true, 1, PT_TRAV_SWEEP); }
                     else { if (hero) PT_LAUNCH_SHADOW(true, 4, PT_TRAV_WALK); else PT_LAUNCH_SHADOW(true, 1, PT_TRAV_WALK); }
 #undef PT_LAUNCH_SHADOW
@@ -585,6 +745,9 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 4, PT_TRAV_WALK>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 4, PT_TRAV_SWEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_intersect<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend_parked<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow_parked<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow_parked<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
     }
     *out = sc;
     return PT_OK;

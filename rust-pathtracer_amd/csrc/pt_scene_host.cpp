@@ -5,6 +5,7 @@
 #include "pt_scene_host.h"
 #include "pt_device.h"
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstring>
@@ -341,10 +342,22 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
         pad16(w);
         w[PT_HDR_LIGHT_NODE_OFF] = (uint32_t)w.size();
         for (uint32_t l : lights) w.push_back(top + bb.leaf_of_shape[l] * PT_NODE_WORDS);
-        // ---- leaf sweep table (world_hit_sweep): every leaf box of both levels, in traversal pre-order, when 64 mask bits suffice
-        size_t sweep_bits = 0;
-        for (uint32_t i = 0; i < d.instance_count; ++i) sweep_bits += d.instances[i].kind == PT_SHAPE_MESH ? 1 + (size_t)d.meshes[d.instances[i].mesh].face_count : 1;
-        if (d.instance_count > 0 && sweep_bits <= PT_SWEEP_MAX_BITS) {
+        // ---- leaf sweep table (world_hit_sweep): the leaf boxes of both levels in traversal pre-order, as far as 64 mask bits
+        // go.  Every instance takes a bit; the triangle leaves of mesh instances are taken in ("inlined") smallest mesh first
+        // while they fit; the remaining mesh instances keep only their own bit and their BVH is walked when that bit is hit.
+        std::vector<char> walked(d.instance_count, 0);
+        size_t sweep_bits = d.instance_count;
+        {
+            std::vector<uint32_t> mesh_instances;
+            for (uint32_t i = 0; i < d.instance_count; ++i) if (d.instances[i].kind == PT_SHAPE_MESH) mesh_instances.push_back(i);
+            std::stable_sort(mesh_instances.begin(), mesh_instances.end(), [&](uint32_t a, uint32_t b) {
+                return d.meshes[d.instances[a].mesh].face_count < d.meshes[d.instances[b].mesh].face_count; });
+            for (uint32_t i : mesh_instances) {
+                size_t faces = d.meshes[d.instances[i].mesh].face_count;
+                if (sweep_bits + faces <= PT_SWEEP_MAX_BITS) sweep_bits += faces; else walked[i] = 1;
+            }
+        }
+        if (d.instance_count > 0 && d.instance_count <= PT_SWEEP_MAX_BITS) {
             auto is_flat = [](const uint32_t* node) { return node[0] == node[4] || node[1] == node[5] || node[2] == node[6]; };
             pad16(w);
             std::vector<uint32_t> order;  // top-level leaf nodes in pre-order
@@ -355,18 +368,20 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             std::vector<int> root_of;  // per bit: the bit whose box test it copies (itself if none)
             uint32_t bit = 0;
             uint64_t mesh_mask = 0;
+            bool any_walked = false;
             for (size_t j = 0; j < order.size(); ++j) {
                 const uint32_t* nd = &nodes[order[j] * PT_NODE_WORDS];
                 uint32_t inst = nd[7];
                 const pt_instance& in = d.instances[inst];
                 uint32_t e = sweep_off + (uint32_t)j * PT_SWEEP_INST_WORDS;
                 uint32_t rec_off = w[PT_HDR_INSTANCE_OFF] + inst * PT_INST_WORDS;
-                uint32_t kf = (uint32_t)in.kind | (is_flat(nd) ? 1u << 8 : 0u) | (in.has_transform ? 1u << 9 : 0u);
+                uint32_t kf = (uint32_t)in.kind | (is_flat(nd) ? 1u << 8 : 0u) | (in.has_transform ? 1u << 9 : 0u) | (walked[inst] ? PT_SWEEP_WALKED : 0u);
                 uint32_t tri_list = 0, tri_count = 0, first_bit = bit++;
                 uint32_t own[PT_SWEEP_BIT_WORDS] = {rec_off, 0u, e + 4, kf | inst << 16, 0u, 0u, 0u, 0u};
                 bits.insert(bits.end(), own, own + PT_SWEEP_BIT_WORDS);
                 root_of.push_back((int)first_bit);
-                if (in.kind == PT_SHAPE_MESH) {
+                if (in.kind == PT_SHAPE_MESH && walked[inst]) any_walked = true;
+                if (in.kind == PT_SHAPE_MESH && !walked[inst]) {
                     mesh_mask |= 1ull << first_bit;
                     pad16(w);
                     tri_list = (uint32_t)w.size();
@@ -405,6 +420,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             w.insert(w.end(), bits.begin(), bits.end());
             w[PT_HDR_SWEEP_MESH_MASK] = (uint32_t)mesh_mask; w[PT_HDR_SWEEP_MESH_MASK + 1] = (uint32_t)(mesh_mask >> 32);
             w[PT_HDR_SWEEP_OFF] = sweep_off; w[PT_HDR_SWEEP_COUNT] = (uint32_t)order.size();
+            if (any_walked) w[PT_HDR_FLAGS] |= PT_FLAG_SWEEP_WALKS;
         }
     }
     pad16(w);
@@ -490,7 +506,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
     }
     w[PT_HDR_WORLD_RADIUS] = fbits(radius);
     {
-        uint32_t flags = 0;
+        uint32_t flags = w[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS;
         for (uint32_t i = 0; i < d.instance_count; ++i) {
             const pt_instance& in = d.instances[i];
             if (in.kind == PT_SHAPE_DISK) flags |= PT_FLAG_NO_TOP_CULL;

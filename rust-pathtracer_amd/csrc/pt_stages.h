@@ -327,29 +327,41 @@ PT_HD void clear_shadow_item(const Queue& q, uint32_t item, uint32_t light_sampl
 // Only a light that is the closest hit contributes, so the walk is bounded by the nearest light hit (nothing beyond it
 // can be the closest hit) and may stop at the first accepted non-light hit in front of it.  If no light is hit at all
 // the ray contributes nothing and is not walked.  The result is the reference's in every case.
-template <int NL, int TRAV = PT_TRAV_ANY>
-PT_HD void stage_shadow_light(const SceneView& s, const float* lambda, const ShadowRayT<NL>& ray, float* contribution) {
+// What a traced light-sample ray adds, given its closest hit: a light ray contributes only if that hit is a light, with
+// the emission evaluated there (pt.rs:177-217); an environment ray only if nothing was hit (pt.rs:300-330).
+template <int NL>
+PT_HD void shadow_ray_contribution(const SceneView& s, const float* lambda, const ShadowRayT<NL>& ray, bool env, bool hit, const Hit& sh, float* contribution) {
     for (int k = 0; k < NL; ++k) contribution[k] = 0.0f;
-    Hit sh;
-    if (bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_CULL)) {
-        if (!world_hit<TRAV>(s, ray.o, ray.d, &sh)) return;
-    } else {
-        float t_light = nearest_light_hit(s, ray.o, ray.d);
-        if (!(t_light < PT_INF)) return;
-        if (!world_hit<TRAV>(s, ray.o, ray.d, &sh, t_light, true)) return;
-    }
-    if (PT_MATERIAL_TAG(sh.material) != PT_TAG_LIGHT) return;
+    if (env) { if (!hit) for (int k = 0; k < NL; ++k) contribution[k] = ray.factor[k]; return; }
+    if (!hit || PT_MATERIAL_TAG(sh.material) != PT_TAG_LIGHT) return;
     Frame lf = frame_from_normal(sh.n);
     F3 lwi = to_local(lf, neg(ray.d));
     uint32_t lm = material_record(s, sh.material);
     for (int k = 0; k < NL; ++k) contribution[k] = ray.factor[k] * pt_abs(lwi.z) * material_emission(s, lm, lambda[k], lwi);
+}
+// The bound of a light ray's search: the nearest light hit (+inf: no light on the ray, nothing to trace), or "unbounded"
+// when the scene forbids the shortcut.  Returns false when the ray cannot contribute.
+PT_HD bool shadow_light_bound(const SceneView& s, F3 o, F3 d, float* bound, bool* stop_on_nonlight) {
+    if (bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_CULL)) { *bound = PT_INF; *stop_on_nonlight = false; return true; }
+    float t_light = nearest_light_hit(s, o, d);
+    *bound = t_light; *stop_on_nonlight = true;
+    return t_light < PT_INF;
+}
+template <int NL, int TRAV = PT_TRAV_ANY>
+PT_HD void stage_shadow_light(const SceneView& s, const float* lambda, const ShadowRayT<NL>& ray, float* contribution) {
+    for (int k = 0; k < NL; ++k) contribution[k] = 0.0f;
+    float bound; bool stop;
+    if (!shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) return;
+    Hit sh;
+    bool hit = world_hit<TRAV>(s, ray.o, ray.d, &sh, bound, stop);
+    shadow_ray_contribution<NL>(s, lambda, ray, false, hit, sh, contribution);
 }
 // The environment-sample ray of pt.rs:252-330: contributes only if nothing is hit.
 template <int NL, int TRAV = PT_TRAV_ANY>
 PT_HD void stage_shadow_env(const SceneView& s, const ShadowRayT<NL>& ray, float* contribution) {
     Hit sh;
     bool blocked = world_hit<TRAV>(s, ray.o, ray.d, &sh);
-    for (int k = 0; k < NL; ++k) contribution[k] = blocked ? 0.0f : ray.factor[k];
+    shadow_ray_contribution<NL>(s, nullptr, ray, true, blocked, sh, contribution);
 }
 // One light-sample item: L rays, summed in order, divided by L (pt.rs:349-392, 596)
 template <int NL, int TRAV = PT_TRAV_ANY>

@@ -76,10 +76,11 @@ def test_golden_vectors(emu):
         ps.golden_materials(emu, scene)
 
 
-@pytest.mark.parametrize("scene", ["cornell_box", "mixed_small", "white_furnace"])
+@pytest.mark.parametrize("scene", ["cornell_box", "mixed_small", "white_furnace", "cornell_gem", "mixed_primitives", "hdri_small"])
 def test_leaf_sweep_equals_bvh_walk(emu, pkg, monkeypatch, scene):
-    """Scenes of <= 64 leaves take world_hit_sweep; the BVH walk (flag 16), the exact slab test (2) and no culling (4)
-    must give the same bits: hits, films and ray counters."""
+    """Scenes of <= 64 instances take world_hit_sweep (with the triangle leaves of small meshes in the table and the BVHs of
+    big meshes walked from it); the pure BVH walk (flag 16), the exact slab test (2) and no culling (4) must give the same
+    bits: hits, films and ray counters."""
     b = pkg.scene.SCENES[scene]()
     o, d = ps.golden_rays(scene, 4096, 33)
     # axis-parallel directions take the undecided path for every box
