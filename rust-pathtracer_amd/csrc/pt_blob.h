@@ -33,6 +33,9 @@
 #define PT_MESH_TRI_OFF 2
 #define PT_MESH_NORMAL_OFF 3
 #define PT_MESH_FACE_COUNT 4
+#define PT_MESH_LEAF_OFF 5     /* leaf list for mesh_sweep (0 = none): per leaf in pre-order 8 words = min.xyz, triangle word offset, max.xyz, flat */
+#define PT_MESH_LEAF_COUNT 6
+#define PT_MESH_SWEEP_MAX 512  /* meshes of at most this many triangles get a leaf list */
 
 // Instance record (40 words).
 #define PT_INST_WORDS 40
@@ -103,6 +106,7 @@
 #define PT_FLAG_NO_CULL 4u       /* diagnostics (PT_AMD_NO_CULL=1): never cull by the closest hit */
 #define PT_FLAG_NO_SHADOW_BOUND 8u /* a mesh instance can produce a Light-tagged hit: the light pre-pass of shadow rays is off */
 #define PT_FLAG_SWEEP_WALKS 32u   /* the sweep table holds mesh instances whose BVH is walked (hybrid form) */
+#define PT_FLAG_NO_MESH_SWEEP 64u  /* diagnostics (PT_AMD_NO_MESH_SWEEP=1): walk every mesh BVH */
 #define PT_FLAG_NO_SWEEP 16u      /* diagnostics (PT_AMD_NO_SWEEP=1): always walk the BVHs */
 #define PT_FLAG_NO_TOP_CULL 1u   /* a Disk instance exists: its reference box (radius/2, disk.rs:24-28) does not contain it */
 

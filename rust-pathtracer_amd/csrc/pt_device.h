@@ -555,6 +555,10 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
     return hit;
 }
 
+// When a search may end early: never (closest hit wanted), at the first opaque hit in front of every light (light rays, with
+// the nearest light hit as bound), or at any accepted hit (environment rays: only "is anything in the way" matters).
+enum { PT_STOP_NONE = 0, PT_STOP_NONLIGHT = 1, PT_STOP_ANY = 2 };
+
 // The running state of phase 3 — it can be parked (a lane that reaches a walked mesh) and resumed later.
 struct SweepState { uint64_t hit; float closest; uint32_t best_inst, best_triw; TriHit bh; };
 PT_HD void sweep_state_init(SweepState& st, uint64_t hit) {
@@ -562,7 +566,7 @@ PT_HD void sweep_state_init(SweepState& st, uint64_t hit) {
 }
 // Mesh::hit (src/geometry/mesh.rs:314-360) for one instance, against the running closest hit: the mesh half of
 // world_hit_walk on its own (same while-while loop, same filtered box test, same culling).
-PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, F3 d, float bound, bool stop_on_nonlight, SweepState& st) {
+PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, F3 d, float bound, int stop, SweepState& st) {
     const uint32_t NONE = 0xffffffffu;
     const uint32_t flags = bu(s, PT_HDR_FLAGS);
     const bool cull = (flags & PT_FLAG_NO_CULL) == 0;
@@ -574,6 +578,53 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
     const uint32_t mesh = bu(s, inst + PT_INST_MESH);
     const uint32_t node_off = bu(s, mesh + PT_MESH_NODE_OFF), node_count = bu(s, mesh + PT_MESH_NODE_COUNT), tri_off = bu(s, mesh + PT_MESH_TRI_OFF);
     float limit = __builtin_fminf(st.closest, bound);
+    const uint32_t leaf_off = bu(s, mesh + PT_MESH_LEAF_OFF);
+    // (bounded searches — light rays, which also stop at the first opaque hit — prune so much of the tree that the walk wins)
+    if (leaf_off != 0u && !(bound < PT_INF) && !(flags & (PT_FLAG_NO_SWEEP | PT_FLAG_NO_MESH_SWEEP))) {
+        // mesh sweep: the leaf-box sweep of world_hit_sweep applied to this mesh, 64 leaves (in pre-order) at a time, each
+        // chunk culled by the closest hit the chunks before it left — the same leaves in the same order as the walk below
+        const uint32_t leaf_count = PT_UNIFORM(bu(s, mesh + PT_MESH_LEAF_COUNT));
+        const bool quick = cr.fast && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f;
+        for (uint32_t first = 0; first < leaf_count; first += 64u) {
+            const uint32_t chunk = leaf_count - first < 64u ? leaf_count - first : 64u;
+            uint32_t hit_lo = 0, hit_hi = 0, unc_lo = 0, unc_hi = 0;
+            for (uint32_t t = 0; t < chunk; ++t) {
+                const uint32_t e = PT_UNIFORM(leaf_off + (first + t) * 8u);
+                const F4 ta = bf4(s, e), tb = bf4(s, e + 4);
+                float entry = 0.0f;
+                int ct = quick ? aabb_classify(ta, tb, cr, PT_UNIFORM(pt_f2u(tb.w)) != 0u, &entry) : 2;
+                if (ct == 1 && cull && beyond(entry, limit, cr.base)) ct = 0;
+                const uint32_t m = 1u << (t & 31u);
+                if (t < 32u) { hit_lo |= ct == 1 ? m : 0u; unc_lo |= ct == 2 ? m : 0u; } else { hit_hi |= ct == 1 ? m : 0u; unc_hi |= ct == 2 ? m : 0u; }
+            }
+            uint64_t hit = (uint64_t)hit_lo | (uint64_t)hit_hi << 32, unc = (uint64_t)unc_lo | (uint64_t)unc_hi << 32;
+            while (unc != 0) {
+                const uint32_t k = ctz64(unc);
+                unc &= unc - 1;
+                const uint32_t e = leaf_off + (first + k) * 8u;
+                float entry;
+                PT_STAT(box_exact);
+                if (aabb_hit_exact(bf4(s, e), bf4(s, e + 4), lo, ld, &entry)) hit |= 1ull << k;
+            }
+            while (hit != 0) {
+                const uint32_t k = ctz64(hit);
+                hit &= hit - 1;
+                const uint32_t t = bu(s, leaf_off + (first + k) * 8u + 3u);
+                F4 q0 = bf4(s, t), q1 = bf4(s, t + 4), q2 = bf4(s, t + 8);
+                TriHit th;
+                if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
+                    st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th;
+                    limit = __builtin_fminf(st.closest, bound);
+                    if (stop == PT_STOP_ANY) { st.hit = 0; return; }
+                    if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
+                        uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+                        if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) { st.hit = 0; return; }
+                    }
+                }
+            }
+        }
+        return;
+    }
     uint32_t i = 0;
     for (;;) {
         uint32_t pending = NONE;
@@ -592,7 +643,8 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
         if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
             st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th;
             limit = __builtin_fminf(st.closest, bound);
-            if (stop_on_nonlight && st.closest < bound) {
+            if (stop == PT_STOP_ANY) { st.hit = 0; break; }
+            if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
                 uint32_t im = bu(s, inst + PT_INST_MATERIAL);
                 if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) { st.hit = 0; break; }  // something opaque in front of every light
             }
@@ -602,7 +654,7 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
 // Phase 3: the primitive tests of the set bits in pre-order (ties are broken by that order, as in world_hit_walk).  With
 // `park_at_walked` the loop returns true when the next bit is a walked mesh instance, leaving the bit set: the caller
 // parks the state and resumes with sweep_resume; otherwise walked meshes are walked in line.
-PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bound, bool stop_on_nonlight, SweepState& st, bool park_at_walked) {
+PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bound, int stop, SweepState& st, bool park_at_walked) {
     const uint32_t bits_off = bu(s, PT_HDR_SWEEP_BITS_OFF);
     while (st.hit != 0) {
         const uint32_t k = ctz64(st.hit);
@@ -611,7 +663,7 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
         if (kf & PT_SWEEP_WALKED) {
             if (park_at_walked) return true;
             st.hit &= st.hit - 1;
-            mesh_walk(s, inst, kf >> 16, o, d, bound, stop_on_nonlight, st);
+            mesh_walk(s, inst, kf >> 16, o, d, bound, stop, st);
             continue;
         }
         st.hit &= st.hit - 1;
@@ -623,7 +675,8 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
             TriHit th;
             if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
                 st.closest = th.t; st.best_inst = kf >> 16; st.best_triw = triw; st.bh = th;
-                if (stop_on_nonlight && st.closest < bound) {
+                if (stop == PT_STOP_ANY) st.hit = 0;
+                else if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
                     uint32_t im = bu(s, inst + PT_INST_MATERIAL);
                     if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) st.hit = 0;  // something opaque in front of every light
                 }
@@ -634,7 +687,8 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
             Hit h;
             if (analytic_hit(s, inst, kf & 0xffu, lo, ld, st.closest, &h)) {
                 st.closest = h.t; st.best_inst = kf >> 16; st.best_triw = 0;
-                if (stop_on_nonlight && st.closest < bound) {
+                if (stop == PT_STOP_ANY) st.hit = 0;
+                else if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
                     uint32_t im = bu(s, inst + PT_INST_MATERIAL);
                     if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : h.material) != PT_TAG_LIGHT) st.hit = 0;
                 }
@@ -644,29 +698,29 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
     return false;
 }
 // A parked lane: walk the mesh of its lowest set bit, then carry on with phase 3 (it may park again at another walked mesh).
-PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, bool stop_on_nonlight, SweepState& st) {
+PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st) {
     const uint32_t k = ctz64(st.hit);
     const F4 be = bf4(s, bu(s, PT_HDR_SWEEP_BITS_OFF) + k * PT_SWEEP_BIT_WORDS);
     st.hit &= st.hit - 1;
-    mesh_walk(s, pt_f2u(be.x), pt_f2u(be.w) >> 16, o, d, bound, stop_on_nonlight, st);
+    mesh_walk(s, pt_f2u(be.x), pt_f2u(be.w) >> 16, o, d, bound, stop, st);
     if (st.hit == 0) return false;
     const TriRay wtr = tri_ray_prepare(o, d);
-    return sweep_run(s, o, d, wtr, bound, stop_on_nonlight, st, true);
+    return sweep_run(s, o, d, wtr, bound, stop, st, true);
 }
 PT_HD bool sweep_finish(const SceneView& s, F3 o, F3 d, const SweepState& st, Hit* out) {
     if (st.best_inst == 0xffffffffu) { out->valid = false; return false; }
     hit_record(s, o, d, st.best_inst, st.best_triw, st.bh, out);
     return true;
 }
-PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, bool stop_on_nonlight) {
+PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, int stop) {
     SweepState st;
     sweep_state_init(st, sweep_masks(s, o, d, bound));
     const TriRay wtr = tri_ray_prepare(o, d);
-    sweep_run(s, o, d, wtr, bound, stop_on_nonlight, st, false);
+    sweep_run(s, o, d, wtr, bound, stop, st, false);
     return sweep_finish(s, o, d, st, out);
 }
 
-PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound, bool stop_on_nonlight) {
+PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound, int stop) {
     const uint32_t NONE = 0xffffffffu;
     const uint32_t flags = bu(s, PT_HDR_FLAGS);
     const uint32_t top_off = bu(s, PT_HDR_TOP_NODE_OFF), top_count = bu(s, PT_HDR_TOP_NODE_COUNT), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
@@ -718,7 +772,8 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
             if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, closest, &th)) {
                 closest = th.t; best_inst = level_inst; best_tri = pending; bh = th;
                 limit = __builtin_fminf(closest, bound);
-                if (stop_on_nonlight && closest < bound) {
+                if (stop == PT_STOP_ANY) done = true;
+                else if (stop == PT_STOP_NONLIGHT && closest < bound) {
                     uint32_t im = bu(s, inst_off + level_inst * PT_INST_WORDS + PT_INST_MATERIAL);
                     uint32_t mat = im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w);
                     if (PT_MATERIAL_TAG(mat) != PT_TAG_LIGHT) done = true;  // something opaque in front of every light
@@ -744,7 +799,8 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
                 if (analytic_hit(s, inst, kind, lo, ld, closest, &h)) {
                     closest = h.t; best_inst = pending; best_tri = NONE;
                     limit = __builtin_fminf(closest, bound);
-                    if (stop_on_nonlight && closest < bound) {
+                    if (stop == PT_STOP_ANY) done = true;
+                    else if (stop == PT_STOP_NONLIGHT && closest < bound) {
                         uint32_t im = bu(s, inst + PT_INST_MATERIAL);
                         if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : h.material) != PT_TAG_LIGHT) done = true;
                     }
@@ -765,9 +821,9 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
 #define PT_TRAV_SWEEP 2
 PT_HD bool scene_uses_sweep(const SceneView& s) { return bu(s, PT_HDR_SWEEP_OFF) != 0u && !(bu(s, PT_HDR_FLAGS) & PT_FLAG_NO_SWEEP); }
 template <int TRAV = PT_TRAV_ANY>
-PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_INF, bool stop_on_nonlight = false) {
-    if (TRAV == PT_TRAV_SWEEP || (TRAV == PT_TRAV_ANY && scene_uses_sweep(s))) return world_hit_sweep(s, o, d, out, bound, stop_on_nonlight);
-    return world_hit_walk(s, o, d, out, bound, stop_on_nonlight);
+PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_INF, int stop = PT_STOP_NONE) {
+    if (TRAV == PT_TRAV_SWEEP || (TRAV == PT_TRAV_ANY && scene_uses_sweep(s))) return world_hit_sweep(s, o, d, out, bound, stop);
+    return world_hit_walk(s, o, d, out, bound, stop);
 }
 
 // Nearest hit among the light instances that the reference's walk would test for this ray (an instance is tested iff

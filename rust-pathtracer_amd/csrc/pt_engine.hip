@@ -299,13 +299,13 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_extend_parked(const uint
             SweepState st;
             sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
             const TriRay wtr = tri_ray_prepare(o, d);
-            settle(j, o, d, st, sweep_run(s, o, d, wtr, PT_INF, false, st, true));
+            settle(j, o, d, st, sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true));
         }
         __syncthreads();
         park_drain(pk, &park_count, r + 1 == rounds, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t) {
             F3 o, d;
             ray_of(base + j2, &o, &d);
-            settle(j2, o, d, st, sweep_resume(s, o, d, PT_INF, false, st));
+            settle(j2, o, d, st, sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st));
         });
     }
 }
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
             ShadowRayT<NL> ray;
             if (j < n && load_shadow_ray<NL>(shadow, item, l, &ray)) {
                 const bool env = ((flags >> l) & 1u) != 0;
-                float bound = PT_INF; bool stop = false;
+                float bound = PT_INF; int stop = shadow_env_stop(s);
                 if (!env && !shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) {
                     for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
                 } else {
@@ -357,7 +357,8 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
                 load_shadow_ray<NL>(shadow, base + j2, l2, &pr);
                 const bool env = kind != 0u;
                 // a light ray searches with the early stop whenever it has a finite bound (shadow_light_bound)
-                settle(j2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, !env && bound < PT_INF, st));
+                const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
+                settle(j2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, stop2, st));
             });
         }
     }
@@ -728,6 +729,7 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     if (env_u32("PT_AMD_EXACT_SLAB", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_EXACT_SLAB;
     if (env_u32("PT_AMD_NO_CULL", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_CULL;
     if (env_u32("PT_AMD_NO_SWEEP", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_SWEEP;
+    if (env_u32("PT_AMD_NO_MESH_SWEEP", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_MESH_SWEEP;
     sc->blob_words = (uint32_t)sc->host.blob.size();
     sc->use_lds = sc->blob_words * 4 <= kLdsBlobLimitBytes && env_u32("PT_AMD_NO_LDS", 0) == 0;
     e = hipMalloc(&sc->d_blob, sizeof(uint32_t) * sc->host.blob.size());

@@ -262,8 +262,23 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                 for (int k = 0; k < 3; ++k) { const float* p = N + 3 * ix[k]; w.push_back(fbits(p[0])); w.push_back(fbits(p[1])); w.push_back(fbits(p[2])); w.push_back(0u); }
             }
         }
+        // leaf list for mesh_sweep: the leaf boxes alone, in pre-order (a dense wave of rays inside a mesh of a few hundred
+        // triangles tests them all, 64 at a time, instead of walking the tree lane by lane)
+        uint32_t leaf_off = 0, leaf_count = 0;
+        if (m.face_count <= PT_MESH_SWEEP_MAX) {
+            pad16(w);
+            leaf_off = (uint32_t)w.size();
+            for (size_t k = 0; k < nodes.size() / PT_NODE_WORDS; ++k) {
+                const uint32_t* nd = &nodes[k * PT_NODE_WORDS];
+                if (nd[7] == PT_NODE_INNER) continue;
+                uint32_t flat = (nd[0] == nd[4] || nd[1] == nd[5] || nd[2] == nd[6]) ? 1u : 0u;
+                uint32_t rec[8] = {nd[0], nd[1], nd[2], tri_off + nd[7] * PT_TRI_WORDS, nd[4], nd[5], nd[6], flat};
+                w.insert(w.end(), rec, rec + 8);
+                ++leaf_count;
+            }
+        }
         mesh_off[mi] = (uint32_t)w.size();
-        uint32_t rec[PT_MESH_WORDS] = {node_off, (uint32_t)(nodes.size() / PT_NODE_WORDS), tri_off, normal_off, m.face_count, 0, 0, 0};
+        uint32_t rec[PT_MESH_WORDS] = {node_off, (uint32_t)(nodes.size() / PT_NODE_WORDS), tri_off, normal_off, m.face_count, leaf_off, leaf_count, 0};
         w.insert(w.end(), rec, rec + PT_MESH_WORDS);
     }
 

@@ -341,16 +341,17 @@ PT_HD void shadow_ray_contribution(const SceneView& s, const float* lambda, cons
 }
 // The bound of a light ray's search: the nearest light hit (+inf: no light on the ray, nothing to trace), or "unbounded"
 // when the scene forbids the shortcut.  Returns false when the ray cannot contribute.
-PT_HD bool shadow_light_bound(const SceneView& s, F3 o, F3 d, float* bound, bool* stop_on_nonlight) {
-    if (bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_CULL)) { *bound = PT_INF; *stop_on_nonlight = false; return true; }
+PT_HD bool shadow_light_bound(const SceneView& s, F3 o, F3 d, float* bound, int* stop) {
+    if (bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_CULL)) { *bound = PT_INF; *stop = PT_STOP_NONE; return true; }
     float t_light = nearest_light_hit(s, o, d);
-    *bound = t_light; *stop_on_nonlight = true;
+    *bound = t_light; *stop = PT_STOP_NONLIGHT;
     return t_light < PT_INF;
 }
+PT_HD int shadow_env_stop(const SceneView& s) { return (bu(s, PT_HDR_FLAGS) & PT_FLAG_NO_CULL) ? PT_STOP_NONE : PT_STOP_ANY; }
 template <int NL, int TRAV = PT_TRAV_ANY>
 PT_HD void stage_shadow_light(const SceneView& s, const float* lambda, const ShadowRayT<NL>& ray, float* contribution) {
     for (int k = 0; k < NL; ++k) contribution[k] = 0.0f;
-    float bound; bool stop;
+    float bound; int stop;
     if (!shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) return;
     Hit sh;
     bool hit = world_hit<TRAV>(s, ray.o, ray.d, &sh, bound, stop);
@@ -360,7 +361,8 @@ PT_HD void stage_shadow_light(const SceneView& s, const float* lambda, const Sha
 template <int NL, int TRAV = PT_TRAV_ANY>
 PT_HD void stage_shadow_env(const SceneView& s, const ShadowRayT<NL>& ray, float* contribution) {
     Hit sh;
-    bool blocked = world_hit<TRAV>(s, ray.o, ray.d, &sh);
+    // any hit blocks the environment: the search ends at the first one (PT_AMD_NO_CULL keeps the full search)
+    bool blocked = world_hit<TRAV>(s, ray.o, ray.d, &sh, PT_INF, shadow_env_stop(s));
     shadow_ray_contribution<NL>(s, nullptr, ray, true, blocked, sh, contribution);
 }
 // One light-sample item: L rays, summed in order, divided by L (pt.rs:349-392, 596)
