@@ -654,13 +654,14 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
 // Phase 3: the primitive tests of the set bits in pre-order (ties are broken by that order, as in world_hit_walk).  With
 // `park_at_walked` the loop returns true when the next bit is a walked mesh instance, leaving the bit set: the caller
 // parks the state and resumes with sweep_resume; otherwise walked meshes are walked in line.
+template <bool WALKS = true>
 PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bound, int stop, SweepState& st, bool park_at_walked) {
     const uint32_t bits_off = bu(s, PT_HDR_SWEEP_BITS_OFF);
     while (st.hit != 0) {
         const uint32_t k = ctz64(st.hit);
         const F4 be = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS);
         const uint32_t inst = pt_f2u(be.x), triw = pt_f2u(be.y), kf = pt_f2u(be.w);
-        if (kf & PT_SWEEP_WALKED) {
+        if (WALKS && (kf & PT_SWEEP_WALKED)) {  // WALKS = false: the table is known to hold no walked mesh (pure sweep kernels)
             if (park_at_walked) return true;
             st.hit &= st.hit - 1;
             mesh_walk(s, inst, kf >> 16, o, d, bound, stop, st);
@@ -705,18 +706,19 @@ PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, S
     mesh_walk(s, pt_f2u(be.x), pt_f2u(be.w) >> 16, o, d, bound, stop, st);
     if (st.hit == 0) return false;
     const TriRay wtr = tri_ray_prepare(o, d);
-    return sweep_run(s, o, d, wtr, bound, stop, st, true);
+    return sweep_run<true>(s, o, d, wtr, bound, stop, st, true);
 }
 PT_HD bool sweep_finish(const SceneView& s, F3 o, F3 d, const SweepState& st, Hit* out) {
     if (st.best_inst == 0xffffffffu) { out->valid = false; return false; }
     hit_record(s, o, d, st.best_inst, st.best_triw, st.bh, out);
     return true;
 }
+template <bool WALKS = true>
 PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, int stop) {
     SweepState st;
     sweep_state_init(st, sweep_masks(s, o, d, bound));
     const TriRay wtr = tri_ray_prepare(o, d);
-    sweep_run(s, o, d, wtr, bound, stop, st, false);
+    sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, false);
     return sweep_finish(s, o, d, st, out);
 }
 
@@ -822,7 +824,8 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
 PT_HD bool scene_uses_sweep(const SceneView& s) { return bu(s, PT_HDR_SWEEP_OFF) != 0u && !(bu(s, PT_HDR_FLAGS) & PT_FLAG_NO_SWEEP); }
 template <int TRAV = PT_TRAV_ANY>
 PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_INF, int stop = PT_STOP_NONE) {
-    if (TRAV == PT_TRAV_SWEEP || (TRAV == PT_TRAV_ANY && scene_uses_sweep(s))) return world_hit_sweep(s, o, d, out, bound, stop);
+    if (TRAV == PT_TRAV_SWEEP) return world_hit_sweep<false>(s, o, d, out, bound, stop);
+    if (TRAV == PT_TRAV_ANY && scene_uses_sweep(s)) return world_hit_sweep<true>(s, o, d, out, bound, stop);
     return world_hit_walk(s, o, d, out, bound, stop);
 }
 

@@ -568,7 +568,8 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     const bool lds = sc->use_lds;
     const bool sweep = sc->host.blob[PT_HDR_SWEEP_OFF] != 0 && !(sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP);
     // the sweep table holds walked meshes: rays that reach one are parked and resumed in full waves (PT_AMD_NO_PARK=1: in line)
-    const bool parked = sweep && (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) && b.park != nullptr && !env_u32("PT_AMD_NO_PARK", 0);
+    const bool walks = (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) != 0;
+    const bool parked = sweep && walks && b.park != nullptr && !env_u32("PT_AMD_NO_PARK", 0);
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
     const bool timing = env_u32("PT_AMD_STAGE_TIMING", 1) != 0;
     double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0};
@@ -618,6 +619,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
                     else launch(k_extend_parked<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin, b.park);
                 }
                 else if (!lds) PT_LAUNCH_EXTEND(false, PT_TRAV_ANY);
+                else if (sweep && walks) PT_LAUNCH_EXTEND(true, PT_TRAV_ANY);   // PT_AMD_NO_PARK: walked meshes in line
                 else if (sweep) PT_LAUNCH_EXTEND(true, PT_TRAV_SWEEP);
                 else PT_LAUNCH_EXTEND(true, PT_TRAV_WALK);
 #undef PT_LAUNCH_EXTEND
@@ -641,6 +643,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
                     }
 #undef PT_LAUNCH_SHADOW_PARKED
                     else if (!lds) { if (hero) PT_LAUNCH_SHADOW(false, 4, PT_TRAV_ANY); else PT_LAUNCH_SHADOW(false, 1, PT_TRAV_ANY); }
+                    else if (sweep && walks) { if (hero) PT_LAUNCH_SHADOW(true, 4, PT_TRAV_ANY); else PT_LAUNCH_SHADOW(true, 1, PT_TRAV_ANY); }
                     else if (sweep) { if (hero) PT_LAUNCH_SHADOW(true, 4, PT_TRAV_SWEEP); else PT_LAUNCH_SHADOW(true, 1, PT_TRAV_SWEEP); }
                     else { if (hero) PT_LAUNCH_SHADOW(true, 4, PT_TRAV_WALK); else PT_LAUNCH_SHADOW(true, 1, PT_TRAV_WALK); }
 #undef PT_LAUNCH_SHADOW
@@ -740,6 +743,9 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     if (sc->use_lds) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend<true, PT_TRAV_WALK>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend<true, PT_TRAV_SWEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend<true, PT_TRAV_ANY>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 1, PT_TRAV_ANY>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 4, PT_TRAV_ANY>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 1, PT_TRAV_WALK>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 1, PT_TRAV_SWEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
