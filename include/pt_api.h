@@ -159,12 +159,16 @@ typedef struct pt_environment {
     int32_t importance_luminance_curve; /* curve used as the luminance weight when baking (y_bar when -1) */
 } pt_environment;
 
-/* ---- camera: ProjectiveCamera (src/camera/projective_camera.rs:27-95, parse defaults src/parsing/cameras.rs:132-148) */
+/* ---- camera: ProjectiveCamera (src/camera/projective_camera.rs:27-95, parse defaults src/parsing/cameras.rs:132-148)
+ * or PanoramaCamera (src/camera/panorama_camera.rs:18-95) */
+enum { PT_CAMERA_PROJECTIVE = 0, PT_CAMERA_PANORAMA = 1 };
 typedef struct pt_camera {
     float look_from[3], look_at[3], v_up[3];
-    float vfov;                   /* degrees */
-    float focal_distance;
-    float aperture_diameter;
+    float vfov;                   /* projective: degrees */
+    float focal_distance;         /* projective */
+    float aperture_diameter;      /* projective */
+    int32_t kind;                 /* PT_CAMERA_* */
+    float fov[2];                 /* panorama: horizontal (0, 360] and vertical (0, 180] field of view in degrees */
 } pt_camera;
 
 typedef struct pt_scene_desc {

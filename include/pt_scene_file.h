@@ -14,7 +14,7 @@
  *   TonemapSettings                               src/parsing/tonemap.rs:5-31
  * The result is a pt_scene_desc (include/pt_api.h) ready for pt_scene_create, and pt_render_desc / pt_output_desc per
  * [[render_settings]] entry.  Like serde's deny_unknown_fields, unknown keys are errors.  Not on this path and rejected
- * with PT_ERR_UNSUPPORTED: mediums, LT integrator, panorama / realistic cameras.
+ * with PT_ERR_UNSUPPORTED: mediums, LT integrator, realistic cameras.
  *
  * File names inside the TOML files are used as written (the reference resolves them against the working directory);
  * when a file is not found there it is looked up under the root given to pt_scene_file_set_root.

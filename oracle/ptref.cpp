@@ -1133,13 +1133,24 @@ void bake_importance_map(Scene& s) {
 
 // =================================================================== camera
 // ProjectiveCamera::new projective_camera.rs:27-95 + with_aspect_ratio :121-133 (applied at parse time, cameras.rs:196-200)
-struct Camera { V3 origin, u, v, w, lower_left_corner, horizontal, vertical; float aperture_diameter; };
+struct Camera { V3 origin, u, v, w, lower_left_corner, horizontal, vertical; float aperture_diameter; int kind; float span_x, span_y; };
 Camera camera_new(const pt_camera& c, float aspect_ratio) {
     Camera cam;
     V3 look_from = v3(c.look_from[0], c.look_from[1], c.look_from[2]);
     V3 look_at = v3(c.look_at[0], c.look_at[1], c.look_at[2]);
     V3 v_up = normalized(v3(c.v_up[0], c.v_up[1], c.v_up[2]));
     V3 direction = normalized(look_at - look_from);
+    cam.kind = c.kind; cam.span_x = cam.span_y = 0.0f;
+    if (c.kind == PT_CAMERA_PANORAMA) {  // PanoramaCamera::new, src/camera/panorama_camera.rs:18-62
+        cam.w = direction;
+        cam.u = normalized(cross(v_up, cam.w));
+        cam.v = normalized(cross(cam.w, cam.u));
+        cam.origin = look_from;
+        cam.span_x = pt_clamp(c.fov[0] * 0.017453292519943295f, 0.0f, 6.283185307179586f);   // to_radians().clamp(0, TAU)
+        cam.span_y = pt_clamp(c.fov[1] * 0.017453292519943295f, 0.0f, 3.141592653589793f);   // clamp(0, PI)
+        cam.lower_left_corner = cam.horizontal = cam.vertical = v3(0, 0, 0); cam.aperture_diameter = 0.0f;
+        return cam;
+    }
     float theta = c.vfov * 0.017453292519943295f;  // f32::to_radians
     float half_height = std::tan(theta / 2.0f);
     float half_width = aspect_ratio * half_height;
@@ -1168,6 +1179,14 @@ struct Sampler {
 
 // ProjectiveCamera::get_ray, projective_camera.rs:101-120.  Circular aperture (rust_optics): rejection from [-1,1]^2.
 Ray camera_get_ray(const Camera& cam, const Sampler& smp, float u, float v) {
+    if (cam.kind == PT_CAMERA_PANORAMA) {  // PanoramaCamera::get_ray, src/camera/panorama_camera.rs:71-95
+        float angle_x = cam.span_x * (u - 0.5f), angle_y = cam.span_y * (0.5f - v);
+        float sin_x, cos_x, sin_y, cos_y;
+        pt_sincos(angle_x, &sin_x, &cos_x); pt_sincos(angle_y, &sin_y, &cos_y);
+        V3 vec = v3(sin_x * cos_y, sin_y, cos_x * cos_y);
+        // transform.to_world(vec) with transform = inverse(frame(u, v, w) o translate(-origin)): the frame's basis
+        return ray_new(cam.origin, cam.u * vec.x + cam.v * vec.y + cam.w * vec.z);
+    }
     float ax = 0.0f, ay = 0.0f; bool ok = false;
     for (uint32_t blk = 0; blk < PT_APERTURE_BLOCKS && !ok; ++blk) {
         pt_f32x4 r = smp.aperture(blk);

@@ -66,7 +66,11 @@ class Environment(C.Structure):
 
 class Camera(C.Structure):
     _fields_ = [("look_from", C.c_float * 3), ("look_at", C.c_float * 3), ("v_up", C.c_float * 3),
-                ("vfov", C.c_float), ("focal_distance", C.c_float), ("aperture_diameter", C.c_float)]
+                ("vfov", C.c_float), ("focal_distance", C.c_float), ("aperture_diameter", C.c_float),
+                ("kind", C.c_int32), ("fov", C.c_float * 2)]
+
+
+CAMERA_PROJECTIVE, CAMERA_PANORAMA = 0, 1
 
 
 class SceneDesc(C.Structure):

@@ -643,15 +643,27 @@ void load_scene(const std::string& path, const pt_config* config, pt_scene_file&
         std::string ctx = "cameras[" + std::to_string(cam_no++) + "]";
         Fields f(cv, ctx);
         std::string type = f.str("type"), name = f.str("name");
+        pt_camera c; memset(&c, 0, sizeof(c));
+        if (type == "PanoramaCamera") {  // PanoramaCameraData, cameras.rs:86-94,150-159
+            c.kind = PT_CAMERA_PANORAMA;
+            f.floats("look_from", c.look_from, 3); f.floats("look_at", c.look_at, 3);
+            float up[3] = {0.0f, 0.0f, 1.0f};
+            f.floats_opt("v_up", up, 3);
+            float n = std::sqrt(up[0] * up[0] + up[1] * up[1] + up[2] * up[2]);
+            for (int k = 0; k < 3; ++k) c.v_up[k] = up[k] / n;
+            f.floats("fov", c.fov, 2);
+            f.done();
+            by_name[name] = c; file_order.push_back(name);
+            continue;
+        }
         if (type != "SimpleCamera") {
-            if (type != "PanoramaCamera" && type != "RealisticCamera") fail(ctx + ": unknown variant `" + type + "`");
+            if (type != "RealisticCamera") fail(ctx + ": unknown variant `" + type + "`");
             bool used = false;
             if (config) for (auto& s : config->settings) used = used || s->camera_id == name;
             if (used) fail(ctx + ": camera type `" + type + "` is not on the PT path", PT_ERR_UNSUPPORTED);
             sf.warn(ctx + ": camera type `" + type + "` is not on the PT path, skipped");
             continue;
         }
-        pt_camera c;
         f.floats("look_from", c.look_from, 3); f.floats("look_at", c.look_at, 3);
         float up[3] = {0.0f, 0.0f, 1.0f};
         f.floats_opt("v_up", up, 3);

@@ -1256,9 +1256,19 @@ PT_HD void env_sample_uv(const SceneView& s, float sx, float sy, float* u, float
 }
 
 // ---------------------------------------------------------------- camera (src/camera/projective_camera.rs:101-120)
-struct CameraParams { F3 origin, u, v, lower_left, horizontal, vertical; float aperture_diameter; };
+struct CameraParams { F3 origin, u, v, lower_left, horizontal, vertical; float aperture_diameter; int kind; float span_x, span_y; F3 w; };
 
 PT_HD void camera_ray(const CameraParams& c, uint64_t seed, uint32_t pixel, uint32_t sample, float fu, float fv, F3* o, F3* d) {
+    if (c.kind == PT_CAMERA_PANORAMA) {
+        // PanoramaCamera::get_ray (src/camera/panorama_camera.rs:71-95): azimuth from the centre line, elevation from the
+        // horizon, no aperture and no sampler draw; the local vector goes to the world through the (u, v, w) frame
+        float ax_ = c.span_x * (fu - 0.5f), ay_ = c.span_y * (0.5f - fv);
+        float sx, cx, sy, cy;
+        pt_sincos(ax_, &sx, &cx); pt_sincos(ay_, &sy, &cy);
+        F3 l = f3(sx * cy, sy, cx * cy);
+        *o = c.origin; *d = add(add(mul(c.u, l.x), mul(c.v, l.y)), mul(c.w, l.z));
+        return;
+    }
     float ax = 0.0f, ay = 0.0f;
     for (uint32_t blk = 0; blk < PT_APERTURE_BLOCKS; ++blk) {
         pt_f32x4 r = pt_draw4(seed, pixel, sample, PT_DIM_APERTURE0 + blk);

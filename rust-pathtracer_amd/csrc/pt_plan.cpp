@@ -59,6 +59,15 @@ ptd::CameraParams camera_params(const pt_camera& c, float aspect_ratio) {
     F3 look_at = f3(c.look_at[0], c.look_at[1], c.look_at[2]);
     F3 v_up = normalize(f3(c.v_up[0], c.v_up[1], c.v_up[2]));          // src/parsing/cameras.rs:139
     F3 direction = normalize(sub(look_at, look_from));
+    cam.kind = c.kind; cam.span_x = cam.span_y = 0.0f; cam.w = f3(0.0f, 0.0f, 0.0f);
+    if (c.kind == PT_CAMERA_PANORAMA) {  // PanoramaCamera::new (src/camera/panorama_camera.rs:18-62)
+        F3 w = direction, u = normalize(cross(v_up, w)), v = normalize(cross(w, u));
+        cam.origin = look_from; cam.u = u; cam.v = v; cam.w = w;
+        cam.span_x = pt_clamp(c.fov[0] * 0.017453292519943295f, 0.0f, 6.283185307179586f);
+        cam.span_y = pt_clamp(c.fov[1] * 0.017453292519943295f, 0.0f, 3.141592653589793f);
+        cam.lower_left = cam.horizontal = cam.vertical = f3(0.0f, 0.0f, 0.0f); cam.aperture_diameter = 0.0f;
+        return cam;
+    }
     float theta = c.vfov * 0.017453292519943295f;                      // f32::to_radians
     float half_height = std::tan(theta / 2.0f);
     float half_width = aspect_ratio * half_height;

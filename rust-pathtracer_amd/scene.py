@@ -287,6 +287,14 @@ class SceneBuilder:
                                        vfov, focal_distance, aperture_diameter))
         return len(self.cameras) - 1
 
+    def add_panorama_camera(self, look_from, look_at, fov, v_up=(0.0, 0.0, 1.0)):
+        """PanoramaCameraData (src/parsing/cameras.rs:86-94): fov = (horizontal, vertical) in degrees."""
+        up = np.asarray(v_up, np.float32)
+        up = up / np.sqrt(up[0] * up[0] + up[1] * up[1] + up[2] * up[2], dtype=np.float32)
+        self.cameras.append(api.Camera((C.c_float * 3)(*look_from), (C.c_float * 3)(*look_at), (C.c_float * 3)(*up.tolist()),
+                                       0.0, 0.0, 0.0, api.CAMERA_PANORAMA, (C.c_float * 2)(*fov)))
+        return len(self.cameras) - 1
+
     def set_environment_constant(self, curve, strength):
         self.environment.kind = api.ENV_CONSTANT
         self.environment.curve = curve
@@ -596,6 +604,14 @@ def mixed_small():
     return b
 
 
+def panorama_test():
+    """The Cornell box seen by a PanoramaCamera from its centre (not a reference scene)."""
+    b = cornell_box()
+    b.cameras.clear()
+    b.add_panorama_camera((0.28, 0.28, 0.27), (1.0, 0.28, 0.27), (360.0, 180.0))
+    return b
+
+
 def sun_test():
     """data/scenes/sun_test.toml of this repository: Sun environment with a literal blackbody colour, a metal sphere on a
     ground rect (not a reference scene; covers EnvironmentData::Sun and camera defaults)."""
@@ -661,4 +677,4 @@ def hdri_c4_small():
 
 
 SCENES = {"hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
-          "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test}
+          "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test, "panorama_test": panorama_test}

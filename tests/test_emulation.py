@@ -44,6 +44,7 @@ def test_materials_bit_exact(emu, oracle, scene):
     ("cornell_gem", 40, 24, 6, 12, {}),                       # C3 shape: dispersive GGX + transformed mesh
     ("mixed_primitives", 32, 32, 8, 6, {"light_samples": 3, "seed": 5}),
     ("mixed_small", 32, 32, 8, 6, {"light_samples": 3, "seed": 6}),
+    ("panorama_test", 48, 24, 6, 5, {}),                      # PanoramaCamera
     ("white_furnace", 16, 16, 12, 8, {"light_samples": 6}),
     ("cornell_box", 40, 36, 11, 6, {"hero_wavelengths": 4}),  # C5 shape: hero wavelength + 3 passengers
     ("mixed_primitives", 32, 32, 6, 6, {"hero_wavelengths": 4, "light_samples": 3}),

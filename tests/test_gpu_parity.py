@@ -65,6 +65,7 @@ def test_materials_bit_exact(engine, oracle, scene):
     ("cornell_gem", 96, 54, 8, 12, {}),                       # C3 shape at reduced size
     ("mixed_primitives", 64, 64, 8, 6, {"light_samples": 3, "seed": 5}),
     ("mixed_small", 64, 64, 8, 6, {"light_samples": 3, "seed": 6}),
+    ("panorama_test", 128, 64, 8, 6, {}),                     # PanoramaCamera
     ("white_furnace", 32, 32, 12, 8, {"light_samples": 6}),
     ("hdri_small", 64, 64, 8, 4, {"light_samples": 6}),
     ("cornell_box", 128, 128, 12, 8, {"hero_wavelengths": 4}),      # C5 shape: four wavelengths per path

@@ -377,3 +377,24 @@ def test_hero_wavelengths_follow_the_single_wavelength_path(pkg, oracle):
         s = f[..., :3].sum(axis=2) + 1e-9
         return np.var(f[..., 0] / s) + np.var(f[..., 2] / s)
     assert chroma_var(b) < chroma_var(a)
+
+
+def test_panorama_camera_directions(pkg, oracle):
+    """PanoramaCamera::get_ray (src/camera/panorama_camera.rs:71-95): film u is the azimuth about the centre line, v the
+    elevation from the horizon (top of the film looks up); no aperture.  Checked through a render of a constant
+    environment split by a ground rect: pixels above the horizon see the environment, pixels below see the (black) ground."""
+    b = pkg.scene.SceneBuilder()
+    pkg.scene.add_library_curves(b, ["flat_one", "flat_zero"])
+    b.set_environment_constant(b.curve("flat_one"), 1.0)
+    b.env_sampling_probability = 0.5
+    black = b.material_lambertian("black", b.texstack_texture1("black", b.curve("flat_zero")))
+    b.add_rect((1000.0, 1000.0), (0.0, 0.0, -1.0), "Z", True, black)
+    b.add_panorama_camera((0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (360.0, 180.0))
+    film, prof = oracle.create_scene(b).render(pkg.api.render_desc(64, 32, 4, 2, light_samples=0))
+    y = film[..., 1]
+    assert (y[:15] > 0).all() and (y[17:] == 0).all()                 # v < 0.5 looks up (angle_y = span_y * (0.5 - v))
+    assert 0.1 < y[:15].mean() < 0.6                                   # spectral noise only (Y of a flat spectrum over random wavelengths)
+    # a narrow field of view looking straight down sees only the ground
+    b.cameras.clear(); b.add_panorama_camera((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (10.0, 10.0), v_up=(1.0, 0.0, 0.0))
+    film, _ = oracle.create_scene(b).render(pkg.api.render_desc(8, 8, 2, 2, light_samples=0))
+    assert (film[..., :3] == 0).all()

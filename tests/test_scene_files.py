@@ -95,7 +95,8 @@ def curve_of(d, i, cd):
 
 
 SCENE_FILES = {"cornell_box": "cornell_box.toml", "cornell_gem": "cornell_box_diamond_gem.toml", "white_furnace": "white_furnace.toml",
-               "mixed_primitives": "mixed_primitives.toml", "hdri_small": "hdri_small.toml", "sun_test": "sun_test.toml"}
+               "mixed_primitives": "mixed_primitives.toml", "hdri_small": "hdri_small.toml", "sun_test": "sun_test.toml",
+               "panorama_test": "panorama_test.toml"}
 
 
 @pytest.mark.parametrize("name", sorted(SCENE_FILES))
@@ -143,6 +144,7 @@ def test_scene_file_matches_builder(sfmod, pkg, name):
     for field in ("look_from", "look_at", "v_up"):
         assert list(getattr(fd.cameras[0], field)) == list(getattr(bd.cameras[0], field)), field
     assert (fd.cameras[0].vfov, fd.cameras[0].focal_distance, fd.cameras[0].aperture_diameter) == (bd.cameras[0].vfov, bd.cameras[0].focal_distance, bd.cameras[0].aperture_diameter)
+    assert (fd.cameras[0].kind, list(fd.cameras[0].fov)) == (bd.cameras[0].kind, list(bd.cameras[0].fov))
     ex, ey = fd.environment, bd.environment
     assert (ex.kind, ex.strength, ex.angular_diameter, ex.importance_width, ex.importance_height) == (ey.kind, ey.strength, ey.angular_diameter, ey.importance_width, ey.importance_height)
     assert list(ex.sun_direction) == list(ey.sun_direction)
@@ -160,7 +162,7 @@ def test_scene_file_matches_builder(sfmod, pkg, name):
             assert curve_of(fd, lx.curves[k], fa["curve_data"]) == curve_of(bd, ly.curves[k], ba["curve_data"])
 
 
-@pytest.mark.parametrize("name", ["cornell_box", "mixed_primitives", "hdri_small", "sun_test"])
+@pytest.mark.parametrize("name", ["cornell_box", "mixed_primitives", "hdri_small", "sun_test", "panorama_test"])
 def test_oracle_renders_the_same_film_from_either_front_end(sfmod, pkg, oracle, name):
     sf = sfmod.SceneFile(data(sfmod, "scenes", SCENE_FILES[name]))
     rd = pkg.api.render_desc(40, 32, 6, 5, light_samples=2, seed=3)
@@ -185,7 +187,7 @@ def test_cameras_follow_the_render_settings(sfmod):
     sf = sfmod.SceneFile(data(sfmod, "scenes", "mixed_primitives.toml"), cfg)
     assert sf.desc.camera_count == 2 and sf.camera("main") == 0      # one camera per render-settings entry (cameras.rs:191-203)
     hs = sfmod.SceneFile(data(sfmod, "scenes", "hdri_small.toml"))
-    assert hs.desc.camera_count == 1 and any("PanoramaCamera" in w for w in hs.warnings)   # the unused panorama camera is skipped
+    assert hs.desc.camera_count == 1 and any("RealisticCamera" in w for w in hs.warnings)   # the unused lens camera is skipped
 
 
 def test_scene_errors(sfmod, tmp_path):
@@ -207,9 +209,9 @@ def test_scene_errors(sfmod, tmp_path):
     sf = load(base.replace('material_name = "ggx_gold"', 'material_name = "unobtainium"').replace('color = "simple_sky_blue"', 'color = "nope"'))
     assert any("unobtainium" in w for w in sf.warnings) and any("error color" in w for w in sf.warnings)
     assert sf.desc.instances[3].material == (1 << 16)
-    pano = base.replace('type = "SimpleCamera"', 'type = "PanoramaCamera"')
+    lens = base.replace('type = "SimpleCamera"', 'type = "RealisticCamera"')
     with pytest.raises(sfmod.SceneFileError, match="no usable camera"):
-        load(pano)
+        load(lens)
 
 
 def test_image_readers(sfmod, tmp_path):

@@ -279,10 +279,18 @@ focal_distance = 5.0
 vfov = 24.0
 
 [[cameras]]
-type = "PanoramaCamera"
-name = "unused panorama"
+type = "RealisticCamera"
+name = "unused lens camera"
+lens_spec = "data/cameras/none.txt"
 look_from = [0.0, 0.0, 0.0]
 look_at = [1.0, 0.0, 0.0]
+''')
+    cornell = open(os.path.join(DATA, "scenes", "cornell_box.toml")).read()
+    write("scenes/panorama_test.toml", cornell[:cornell.index("[[cameras]]")] + '''[[cameras]]
+type = "PanoramaCamera"
+name = "main"
+look_from = [0.28, 0.28, 0.27]
+look_at = [1.0, 0.28, 0.27]
 fov = [360.0, 180.0]
 ''')
     write("scenes/sun_test.toml", libs + '''# no env_sampling_probability: the scene default 0.5 applies
