@@ -1,7 +1,9 @@
 // pt_blob.h — layout of the flattened scene ("blob") the HIP kernels read.
 //
 // The whole scene except bulk texture texels is one array of 32-bit words, 16-byte aligned sections,
-// addressed by word offsets from a header.  One layout, two homes: HBM, and — when it fits — a copy
+// addressed by word offsets from a header.  It has two parts: the core (header, curves, textures stacks, materials, mesh
+// records, instances, top-level BVH, lights, sweep table) and, behind it, the mesh data (per mesh: BVH nodes, triangles,
+// normals, leaf list) whose offsets are relative to the start of that part.  One layout, two homes: HBM, and — when it fits — a copy
 // staged into LDS by every workgroup (Cornell: ~7 KB, brilliant-cut gem scene: ~45 KB), so BVH nodes,
 // primitives, material records and spectral curve tables are read with ds_read instead of going to L2.
 //
@@ -128,6 +130,9 @@
 #define PT_SWEEP_BIT_WORDS 8
 #define PT_SWEEP_MAX_BITS 64
 #define PT_HDR_SWEEP_BITS_OFF 56
+#define PT_HDR_IMAP_MARG_GUIDE 59   /* guide tables for the CDF searches (float offsets into texture memory, u32 bit patterns): */
+#define PT_HDR_IMAP_ROW_GUIDE 60    /* n + 3 entries per table, entry j = first index whose cmf is >= j / n (pt_device.h sample_cmf) */
+#define PT_HDR_CORE_WORDS 61        /* words of the core section; the mesh-data section follows it */
 #define PT_HDR_SWEEP_MESH_MASK 57  /* 2 words: the bits that stand for mesh instances (no primitive of their own) */
 
 #endif

@@ -49,13 +49,16 @@ PT_HD F3 normalize(F3 a) { return divs(a, norm(a)); }
 
 // ---------------------------------------------------------------- blob access
 struct SceneView {
-    const uint32_t* w;  // blob words: LDS copy or HBM
+    const uint32_t* w;  // core section of the blob (everything but mesh data): LDS copy or HBM
     const float* tex;   // texture texels, HBM
+    const uint32_t* m;  // mesh-data section (BVH nodes, triangles, normals, leaf lists; offsets relative to it): LDS copy or HBM
 };
 PT_HD uint32_t bu(const SceneView& s, uint32_t off) { return s.w[off]; }
 PT_HD float bf(const SceneView& s, uint32_t off) { return pt_u2f(s.w[off]); }
 PT_HD F4 bf4(const SceneView& s, uint32_t off) { return *reinterpret_cast<const F4*>(s.w + off); }
 PT_HD F3 bf3(const SceneView& s, uint32_t off) { return f3(bf(s, off), bf(s, off + 1), bf(s, off + 2)); }
+PT_HD uint32_t mu(const SceneView& s, uint32_t off) { return s.m[off]; }
+PT_HD F4 mf4(const SceneView& s, uint32_t off) { return *reinterpret_cast<const F4*>(s.m + off); }
 
 // TangentFrame::from_normal (math crate): Duff et al. 2017.
 struct Frame { F3 t, b, n; };
@@ -431,12 +434,12 @@ PT_HD void hit_record(const SceneView& s, F3 o, F3 d, uint32_t best_inst, uint32
     if (triw != 0u) {
         uint32_t mesh = bu(s, inst + PT_INST_MESH);
         uint32_t normal_off = bu(s, mesh + PT_MESH_NORMAL_OFF);
-        F4 q0 = bf4(s, triw), q1 = bf4(s, triw + 4), q2 = bf4(s, triw + 8);
+        F4 q0 = mf4(s, triw), q1 = mf4(s, triw + 4), q2 = mf4(s, triw + 8);
         F3 p0 = f3(q0.x, q0.y, q0.z), p1 = f3(q1.x, q1.y, q1.z), p2 = f3(q2.x, q2.y, q2.z);
         F3 n = normalize(cross(sub(p0, p2), sub(p1, p2)));
         if (normal_off != 0) {
             uint32_t nn = normal_off + (triw - bu(s, mesh + PT_MESH_TRI_OFF));
-            F4 m0 = bf4(s, nn), m1 = bf4(s, nn + 4), m2 = bf4(s, nn + 8);
+            F4 m0 = mf4(s, nn), m1 = mf4(s, nn + 4), m2 = mf4(s, nn + 8);
             n = add(add(mul(f3(m0.x, m0.y, m0.z), bh.b0), mul(f3(m1.x, m1.y, m1.z), bh.b1)), mul(f3(m2.x, m2.y, m2.z), bh.b2));
         }
         h.t = bh.t;
@@ -590,7 +593,7 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
             uint32_t hit_lo = 0, hit_hi = 0, unc_lo = 0, unc_hi = 0;
             for (uint32_t t = 0; t < chunk; ++t) {
                 const uint32_t e = PT_UNIFORM(leaf_off + (first + t) * 8u);
-                const F4 ta = bf4(s, e), tb = bf4(s, e + 4);
+                const F4 ta = mf4(s, e), tb = mf4(s, e + 4);
                 float entry = 0.0f;
                 int ct = quick ? aabb_classify(ta, tb, cr, PT_UNIFORM(pt_f2u(tb.w)) != 0u, &entry) : 2;
                 if (ct == 1 && cull && beyond(entry, limit, cr.base)) ct = 0;
@@ -604,13 +607,13 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                 const uint32_t e = leaf_off + (first + k) * 8u;
                 float entry;
                 PT_STAT(box_exact);
-                if (aabb_hit_exact(bf4(s, e), bf4(s, e + 4), lo, ld, &entry)) hit |= 1ull << k;
+                if (aabb_hit_exact(mf4(s, e), mf4(s, e + 4), lo, ld, &entry)) hit |= 1ull << k;
             }
             while (hit != 0) {
                 const uint32_t k = ctz64(hit);
                 hit &= hit - 1;
-                const uint32_t t = bu(s, leaf_off + (first + k) * 8u + 3u);
-                F4 q0 = bf4(s, t), q1 = bf4(s, t + 4), q2 = bf4(s, t + 8);
+                const uint32_t t = mu(s, leaf_off + (first + k) * 8u + 3u);
+                F4 q0 = mf4(s, t), q1 = mf4(s, t + 4), q2 = mf4(s, t + 8);
                 TriHit th;
                 if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
                     st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th;
@@ -629,7 +632,7 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
     for (;;) {
         uint32_t pending = NONE;
         while (i < node_count && pending == NONE) {
-            F4 a = bf4(s, node_off + i * PT_NODE_WORDS), b = bf4(s, node_off + i * PT_NODE_WORDS + 4);
+            F4 a = mf4(s, node_off + i * PT_NODE_WORDS), b = mf4(s, node_off + i * PT_NODE_WORDS + 4);
             uint32_t exit_i = pt_f2u(a.w), shape = pt_f2u(b.w);
             float entry;
             bool box = aabb_hit(a, b, cr, &entry) && !(cull && beyond(entry, limit, cr.base));
@@ -638,7 +641,7 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
         }
         if (pending == NONE) break;
         uint32_t t = tri_off + pending * PT_TRI_WORDS;
-        F4 q0 = bf4(s, t), q1 = bf4(s, t + 4), q2 = bf4(s, t + 8);
+        F4 q0 = mf4(s, t), q1 = mf4(s, t + 4), q2 = mf4(s, t + 8);
         TriHit th;
         if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
             st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th;
@@ -670,7 +673,7 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
         st.hit &= st.hit - 1;
         PT_STAT_EVENT(triw != 0u ? 3 : 4);
         if (triw != 0u) {
-            const F4 q0 = bf4(s, triw), q1 = bf4(s, triw + 4), q2 = bf4(s, triw + 8);
+            const F4 q0 = mf4(s, triw), q1 = mf4(s, triw + 4), q2 = mf4(s, triw + 8);
             TriRay tr = wtr;
             if (kf & 0x200u) { F3 lo, ld; instance_local_ray(s, inst, o, d, &lo, &ld); tr = tri_ray_prepare(lo, ld); }
             TriHit th;
@@ -757,7 +760,9 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
                 node_off = top_off; node_count = top_count; i = top_resume; level_inst = NONE;
                 continue;
             }
-            F4 a = bf4(s, node_off + i * PT_NODE_WORDS), b = bf4(s, node_off + i * PT_NODE_WORDS + 4);
+            // the node array is the top level's (core section) or a mesh's (mesh-data section), lane by lane
+            const uint32_t* nb = (level_inst != NONE ? s.m : s.w) + node_off + i * PT_NODE_WORDS;
+            F4 a = *reinterpret_cast<const F4*>(nb), b = *reinterpret_cast<const F4*>(nb + 4);
             uint32_t exit_i = pt_f2u(a.w), shape = pt_f2u(b.w);
             float entry;
             bool box = aabb_hit(a, b, cr, &entry) && !((level_inst != NONE ? cull_mesh : cull_top) && beyond(entry, limit, cr.base));
@@ -769,7 +774,7 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
         PT_STAT_EVENT(level_inst != NONE ? 3 : 4);
         if (level_inst != NONE) {
             uint32_t t = tri_off + pending * PT_TRI_WORDS;
-            F4 q0 = bf4(s, t), q1 = bf4(s, t + 4), q2 = bf4(s, t + 8);
+            F4 q0 = mf4(s, t), q1 = mf4(s, t + 4), q2 = mf4(s, t + 8);
             TriHit th;
             if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, closest, &th)) {
                 closest = th.t; best_inst = level_inst; best_tri = pending; bh = th;
@@ -1178,8 +1183,17 @@ PT_HD float linear01_nearest(const float* signal, uint32_t n, float x) {
     return t < 0.5f ? left : signal[index + 1];
 }
 // CurveWithCDF::sample_power_and_pdf on a (pdf, cmf) table pair (math crate, restated)
-PT_HD void sample_cmf(const float* pdf, const float* cmf, uint32_t n, float x, float* coord, float* p) {
+// `guide` (optional, n + 3 entries of u32 bits: entry j = lower bound of j / n) brackets the search: with
+// j = max(0, floor(x n) - 1), j / n <= x < (j + 3) / n whatever the rounding, so the lower bound of x lies in
+// [guide[j], guide[j + 3]] and the search inside the bracket returns the index the search of the whole table returns.
+PT_HD void sample_cmf(const float* pdf, const float* cmf, uint32_t n, float x, float* coord, float* p, const float* guide = nullptr) {
     uint32_t lo = 0, hi = n;
+    if (guide != nullptr && x >= 0.0f && x <= 1.0f) {
+        float fj = pt_floor(x * (float)n) - 1.0f;
+        uint32_t j = fj > 0.0f ? (uint32_t)fj : 0u;
+        if (j > n - 1u) j = n - 1u;
+        lo = pt_f2u(guide[j]); hi = pt_f2u(guide[j + 3u]);
+    }
     while (lo < hi) { uint32_t mid = lo + (hi - lo) / 2; if (cmf[mid] < x) lo = mid + 1; else hi = mid; }
     uint32_t k = lo < n ? lo : n - 1;
     float below = k == 0 ? 0.0f : cmf[k - 1];
@@ -1243,9 +1257,11 @@ PT_HD void env_sample_uv(const SceneView& s, float sx, float sy, float* u, float
     if (kind == PT_ENV_HDR && rows > 0) {  // environment.rs:331-350 + importance_map.rs:325-357
         uint32_t cols = bu(s, PT_HDR_IMAP_COLS);
         float mu, row_pdf, mv, column_pdf;
-        sample_cmf(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), s.tex + bu(s, PT_HDR_IMAP_MARG_CMF), rows, sy, &mu, &row_pdf);
+        const uint32_t mg = bu(s, PT_HDR_IMAP_MARG_GUIDE), rg = bu(s, PT_HDR_IMAP_ROW_GUIDE);
+        sample_cmf(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), s.tex + bu(s, PT_HDR_IMAP_MARG_CMF), rows, sy, &mu, &row_pdf, mg ? s.tex + mg : nullptr);
         uint32_t row = (uint32_t)(mu * (float)rows);
-        sample_cmf(s.tex + bu(s, PT_HDR_IMAP_ROW_PDF) + (size_t)row * cols, s.tex + bu(s, PT_HDR_IMAP_ROW_CMF) + (size_t)row * cols, cols, sx, &mv, &column_pdf);
+        sample_cmf(s.tex + bu(s, PT_HDR_IMAP_ROW_PDF) + (size_t)row * cols, s.tex + bu(s, PT_HDR_IMAP_ROW_CMF) + (size_t)row * cols, cols, sx, &mv, &column_pdf,
+                   rg ? s.tex + rg + (size_t)row * (cols + 3u) : nullptr);
         F3 new_wo = xf_vec(s, PT_HDR_ENV_FORWARD, uv_to_direction(mu, mv));
         float u2, v2; direction_to_uv(new_wo, &u2, &v2);
         *u = u2; *v = v2;

@@ -66,18 +66,26 @@ enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_ACCUMULATE, ST_COUNT };
 // ------------------------------------------------------------------------------------------------ kernels
 // Every kernel is a persistent grid: blocks stage the scene blob into LDS (when USE_LDS), then walk the queue
 // with a grid stride.  Queue lengths live in device memory (`counts`), so no host round trip between bounces.
-template <bool USE_LDS>
+// USE_LDS: 0 = everything is read from HBM/L2; 1 = the whole blob is copied to LDS; 2 = only the core section is (curves,
+// materials, instances, top-level BVH, sweep table: the words every lane keeps re-reading), the mesh data stays in HBM/L2
+// — scenes whose meshes do not fit the LDS budget but whose core does (C4: 470 KB of monkey, 24 KB of core).
+enum { PT_LDS_NONE = 0, PT_LDS_ALL = 1, PT_LDS_CORE = 2 };
+template <int USE_LDS>
 __device__ __forceinline__ SceneView stage_scene(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* tex, uint32_t* lds) {
     SceneView s;
     s.tex = tex;
-    if (USE_LDS) {
+    const uint32_t core_words = blob[PT_HDR_CORE_WORDS];
+    if (USE_LDS != PT_LDS_NONE) {
+        const uint32_t words = USE_LDS == PT_LDS_ALL ? blob_words : core_words;
         const uint4* src = reinterpret_cast<const uint4*>(blob);
         uint4* dst = reinterpret_cast<uint4*>(lds);
-        for (uint32_t i = threadIdx.x; i < blob_words / 4; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < words / 4; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
         s.w = lds;
+        s.m = USE_LDS == PT_LDS_ALL ? lds + core_words : blob + core_words;
     } else {
         s.w = blob;
+        s.m = blob + core_words;
     }
     return s;
 }
@@ -144,7 +152,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(RenderParams rp, const uint
     if (threadIdx.x == 0) count_out[blockIdx.x] = cnt;
 }
 
-template <bool USE_LDS, int TRAV>
+template <int USE_LDS, int TRAV>
 __global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_extend(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                   Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -160,7 +168,7 @@ __global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_extend(const uint32_t* _
     }
 }
 
-template <bool USE_LDS, int NL>
+template <int USE_LDS, int NL>
 __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                  RenderParams rp, uint32_t bounce, const uint32_t* __restrict__ pixels,
                                                  Queue paths_in, Queue hits, Queue paths_out, Queue shadow, float* __restrict__ energy,
@@ -220,7 +228,7 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
     }
 }
 
-template <bool USE_LDS, int NL, int TRAV>
+template <int USE_LDS, int NL, int TRAV>
 __global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                   uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                   uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
@@ -271,7 +279,7 @@ __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, b
     }
 }
 
-template <bool USE_LDS>
+template <int USE_LDS>
 __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                      Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
                                                                      uint32_t* __restrict__ park_all) {
@@ -310,7 +318,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_extend_parked(const uint
     }
 }
 
-template <bool USE_LDS, int NL>
+template <int USE_LDS, int NL>
 __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                      uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                                      uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ park_all) {
@@ -389,7 +397,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(RenderParams rp, const ui
 }
 
 // ---- probes (parity tests of single stages)
-template <bool USE_LDS>
+template <int USE_LDS>
 __global__ void __launch_bounds__(kBlock) k_probe_intersect(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                            uint32_t n, const float* __restrict__ o, const float* __restrict__ d, pt_hit* __restrict__ out) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -467,7 +475,7 @@ struct pt_scene {
     uint32_t* d_blob = nullptr;
     float* d_tex = nullptr;
     uint32_t blob_words = 0;
-    bool use_lds = false;
+    int lds_mode = 0;  // PT_LDS_*
     int device = 0, num_cus = 0;
     DeviceBuffers buf;
     std::vector<hipEvent_t> events;  // pairs (start, stop), grown on demand
@@ -522,8 +530,8 @@ pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples
 }
 
 template <typename K, typename... Args>
-void launch(K kernel, bool use_lds, int grid, uint32_t blob_bytes, hipStream_t stream, Args... args) {
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), use_lds ? blob_bytes : 0, stream, args...);
+void launch(K kernel, uint32_t lds_bytes, int grid, hipStream_t stream, Args... args) {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, args...);
 }
 
 uint32_t env_u32(const char* name, uint32_t dflt) {
@@ -564,8 +572,8 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     rp.camera = pth::camera_params(sc->host.cameras[rd.camera_index], (float)rd.width / (float)rd.height);
     rp.energy_stride = b.capacity;
 
-    const uint32_t blob_bytes = sc->blob_words * 4;
-    const bool lds = sc->use_lds;
+    const int mode = sc->lds_mode;
+    const uint32_t lds_bytes = mode == PT_LDS_ALL ? sc->blob_words * 4u : (mode == PT_LDS_CORE ? sc->host.blob[PT_HDR_CORE_WORDS] * 4u : 0u);
     const bool sweep = sc->host.blob[PT_HDR_SWEEP_OFF] != 0 && !(sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP);
     // the sweep table holds walked meshes: rays that reach one are parked and resumed in full waves (PT_AMD_NO_PARK=1: in line)
     const bool walks = (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) != 0;
@@ -612,41 +620,41 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
         for (uint32_t bounce = 0; bounce < bounce_limit; ++bounce) {
             Queue qin = (bounce & 1) ? qb : qa, qout = (bounce & 1) ? qa : qb;
             uint32_t *cin = live[bounce & 1], *cout = live[(bounce + 1) & 1];
+            // kernel variant = staging mode (PT_LDS_*) x traversal form x wavelengths per path
+#define PT_ARGS_EXTEND sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin
+#define PT_ARGS_SHADE sc->d_blob, sc->blob_words, sc->d_tex, rp, bounce, d_px, qin, qh, qout, qs, b.energy, seg_cap, cin, cout, nshadow, b.block_stats
+#define PT_ARGS_SHADOW sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, b.capacity, seg_cap, nshadow
+#define PT_BY_MODE(K, ...) do { if (mode == PT_LDS_ALL) launch(K(PT_LDS_ALL), lds_bytes, grid, stream, __VA_ARGS__); \
+                                else if (mode == PT_LDS_CORE) launch(K(PT_LDS_CORE), lds_bytes, grid, stream, __VA_ARGS__); \
+                                else launch(K(PT_LDS_NONE), lds_bytes, grid, stream, __VA_ARGS__); } while (0)
             timed(ST_EXTEND, [&] {
-#define PT_LAUNCH_EXTEND(LDSF, TRAVV) launch(k_extend<LDSF, TRAVV>, LDSF, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin)
-                if (parked) {
-                    if (lds) launch(k_extend_parked<true>, true, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin, b.park);
-                    else launch(k_extend_parked<false>, false, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin, b.park);
-                }
-                else if (!lds) PT_LAUNCH_EXTEND(false, PT_TRAV_ANY);
-                else if (sweep && walks) PT_LAUNCH_EXTEND(true, PT_TRAV_ANY);   // PT_AMD_NO_PARK: walked meshes in line
-                else if (sweep) PT_LAUNCH_EXTEND(true, PT_TRAV_SWEEP);
-                else PT_LAUNCH_EXTEND(true, PT_TRAV_WALK);
-#undef PT_LAUNCH_EXTEND
+#define K_EXT_PARKED(M) k_extend_parked<M>
+#define K_EXT_ANY(M) k_extend<M, PT_TRAV_ANY>
+                if (parked) PT_BY_MODE(K_EXT_PARKED, PT_ARGS_EXTEND, b.park);
+                else if (mode != PT_LDS_ALL || (sweep && walks)) PT_BY_MODE(K_EXT_ANY, PT_ARGS_EXTEND);   // (walked meshes in line: PT_AMD_NO_PARK)
+                else if (sweep) launch(k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>, lds_bytes, grid, stream, PT_ARGS_EXTEND);
+                else launch(k_extend<PT_LDS_ALL, PT_TRAV_WALK>, lds_bytes, grid, stream, PT_ARGS_EXTEND);
             });
             timed(ST_SHADE, [&] {
-#define PT_LAUNCH_SHADE(LDSF, NLV) launch(k_shade<LDSF, NLV>, LDSF, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rp, bounce, d_px, qin, qh, qout, qs, \
-                                         b.energy, seg_cap, cin, cout, nshadow, b.block_stats)
-                if (lds) { if (hero) PT_LAUNCH_SHADE(true, 4); else PT_LAUNCH_SHADE(true, 1); }
-                else { if (hero) PT_LAUNCH_SHADE(false, 4); else PT_LAUNCH_SHADE(false, 1); }
-#undef PT_LAUNCH_SHADE
+#define K_SHADE1(M) k_shade<M, 1>
+#define K_SHADE4(M) k_shade<M, 4>
+                if (hero) PT_BY_MODE(K_SHADE4, PT_ARGS_SHADE); else PT_BY_MODE(K_SHADE1, PT_ARGS_SHADE);
             });
             if (rd.light_samples > 0)
                 timed(ST_SHADOW, [&] {
-#define PT_LAUNCH_SHADOW(LDSF, NLV, TRAVV) launch(k_shadow<LDSF, NLV, TRAVV>, LDSF, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, \
-                                          b.capacity, seg_cap, nshadow)
-#define PT_LAUNCH_SHADOW_PARKED(LDSF, NLV) launch(k_shadow_parked<LDSF, NLV>, LDSF, grid, blob_bytes, stream, sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, \
-                                                 b.energy, b.capacity, seg_cap, nshadow, b.park)
-                    if (parked) {
-                        if (lds) { if (hero) PT_LAUNCH_SHADOW_PARKED(true, 4); else PT_LAUNCH_SHADOW_PARKED(true, 1); }
-                        else { if (hero) PT_LAUNCH_SHADOW_PARKED(false, 4); else PT_LAUNCH_SHADOW_PARKED(false, 1); }
+#define K_SH_PARKED1(M) k_shadow_parked<M, 1>
+#define K_SH_PARKED4(M) k_shadow_parked<M, 4>
+#define K_SH_ANY1(M) k_shadow<M, 1, PT_TRAV_ANY>
+#define K_SH_ANY4(M) k_shadow<M, 4, PT_TRAV_ANY>
+                    if (parked) { if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS_SHADOW, b.park); else PT_BY_MODE(K_SH_PARKED1, PT_ARGS_SHADOW, b.park); }
+                    else if (mode != PT_LDS_ALL || (sweep && walks)) { if (hero) PT_BY_MODE(K_SH_ANY4, PT_ARGS_SHADOW); else PT_BY_MODE(K_SH_ANY1, PT_ARGS_SHADOW); }
+                    else if (sweep) {
+                        if (hero) launch(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
+                        else launch(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
+                    } else {
+                        if (hero) launch(k_shadow<PT_LDS_ALL, 4, PT_TRAV_WALK>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
+                        else launch(k_shadow<PT_LDS_ALL, 1, PT_TRAV_WALK>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
                     }
-#undef PT_LAUNCH_SHADOW_PARKED
-                    else if (!lds) { if (hero) PT_LAUNCH_SHADOW(false, 4, PT_TRAV_ANY); else PT_LAUNCH_SHADOW(false, 1, PT_TRAV_ANY); }
-                    else if (sweep && walks) { if (hero) PT_LAUNCH_SHADOW(true, 4, PT_TRAV_ANY); else PT_LAUNCH_SHADOW(true, 1, PT_TRAV_ANY); }
-                    else if (sweep) { if (hero) PT_LAUNCH_SHADOW(true, 4, PT_TRAV_SWEEP); else PT_LAUNCH_SHADOW(true, 1, PT_TRAV_SWEEP); }
-                    else { if (hero) PT_LAUNCH_SHADOW(true, 4, PT_TRAV_WALK); else PT_LAUNCH_SHADOW(true, 1, PT_TRAV_WALK); }
-#undef PT_LAUNCH_SHADOW
                 });
         }
         timed(ST_ACCUMULATE, [&] {
@@ -734,28 +742,40 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     if (env_u32("PT_AMD_NO_SWEEP", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_SWEEP;
     if (env_u32("PT_AMD_NO_MESH_SWEEP", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_MESH_SWEEP;
     sc->blob_words = (uint32_t)sc->host.blob.size();
-    sc->use_lds = sc->blob_words * 4 <= kLdsBlobLimitBytes && env_u32("PT_AMD_NO_LDS", 0) == 0;
+    const bool no_lds = env_u32("PT_AMD_NO_LDS", 0) != 0;
+    sc->lds_mode = no_lds ? PT_LDS_NONE : (sc->blob_words * 4 <= kLdsBlobLimitBytes ? PT_LDS_ALL
+                 : (sc->host.blob[PT_HDR_CORE_WORDS] * 4 <= kLdsBlobLimitBytes && !env_u32("PT_AMD_NO_CORE_LDS", 0) ? PT_LDS_CORE : PT_LDS_NONE));
     e = hipMalloc(&sc->d_blob, sizeof(uint32_t) * sc->host.blob.size());
-    if (e == hipSuccess) e = hipMalloc(&sc->d_tex, sizeof(float) * sc->host.tex.size());
+    if (e == hipSuccess) e = hipMalloc(&sc->d_tex, sizeof(float) * (sc->host.tex.size() + 4));
     if (e == hipSuccess) e = hipMemcpy(sc->d_blob, sc->host.blob.data(), sizeof(uint32_t) * sc->host.blob.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(sc->d_tex, sc->host.tex.data(), sizeof(float) * sc->host.tex.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { pt_scene_destroy(sc); return fail(e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE, hipGetErrorString(e)); }
-    if (sc->use_lds) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend<true, PT_TRAV_WALK>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend<true, PT_TRAV_SWEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend<true, PT_TRAV_ANY>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 1, PT_TRAV_ANY>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 4, PT_TRAV_ANY>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 1, PT_TRAV_WALK>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 1, PT_TRAV_SWEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 4, PT_TRAV_WALK>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow<true, 4, PT_TRAV_SWEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_intersect<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend_parked<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow_parked<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow_parked<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes);
+    if (sc->lds_mode != PT_LDS_NONE) {
+        auto allow = [](const void* k) { hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes); };
+#define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
+#define K1(M) k_extend<M, PT_TRAV_ANY>
+#define K2(M) k_shadow<M, 1, PT_TRAV_ANY>
+#define K3(M) k_shadow<M, 4, PT_TRAV_ANY>
+#define K4(M) k_shade<M, 1>
+#define K5(M) k_shade<M, 4>
+#define K6(M) k_extend_parked<M>
+#define K7(M) k_shadow_parked<M, 1>
+#define K8(M) k_shadow_parked<M, 4>
+#define K9(M) k_probe_intersect<M>
+        PT_ALLOW_MODES(K1); PT_ALLOW_MODES(K2); PT_ALLOW_MODES(K3); PT_ALLOW_MODES(K4); PT_ALLOW_MODES(K5); PT_ALLOW_MODES(K6); PT_ALLOW_MODES(K7); PT_ALLOW_MODES(K8); PT_ALLOW_MODES(K9);
+#undef K1
+#undef K2
+#undef K3
+#undef K4
+#undef K5
+#undef K6
+#undef K7
+#undef K8
+#undef K9
+#undef PT_ALLOW_MODES
+        allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>));
+        allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP>));
+        allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP>));
     }
     *out = sc;
     return PT_OK;
@@ -799,8 +819,10 @@ pt_status pt_intersect(pt_scene* sc, size_t n, const float* origins, const float
     HIP_TRY(hipMemcpy(dor, origins, 12 * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dd, directions, 12 * n, hipMemcpyHostToDevice));
     int grid = sc->num_cus * 4;
-    if (sc->use_lds) launch(k_probe_intersect<true>, true, grid, sc->blob_words * 4, (hipStream_t)0, sc->d_blob, sc->blob_words, sc->d_tex, (uint32_t)n, dor, dd, dh);
-    else launch(k_probe_intersect<false>, false, grid, sc->blob_words * 4, (hipStream_t)0, sc->d_blob, sc->blob_words, sc->d_tex, (uint32_t)n, dor, dd, dh);
+    const uint32_t lds_bytes = sc->lds_mode == PT_LDS_ALL ? sc->blob_words * 4u : (sc->lds_mode == PT_LDS_CORE ? sc->host.blob[PT_HDR_CORE_WORDS] * 4u : 0u);
+    if (sc->lds_mode == PT_LDS_ALL) launch(k_probe_intersect<PT_LDS_ALL>, lds_bytes, grid, (hipStream_t)0, sc->d_blob, sc->blob_words, sc->d_tex, (uint32_t)n, dor, dd, dh);
+    else if (sc->lds_mode == PT_LDS_CORE) launch(k_probe_intersect<PT_LDS_CORE>, lds_bytes, grid, (hipStream_t)0, sc->d_blob, sc->blob_words, sc->d_tex, (uint32_t)n, dor, dd, dh);
+    else launch(k_probe_intersect<PT_LDS_NONE>, lds_bytes, grid, (hipStream_t)0, sc->d_blob, sc->blob_words, sc->d_tex, (uint32_t)n, dor, dd, dh);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(hits, dh, sizeof(pt_hit) * n, hipMemcpyDeviceToHost));
@@ -842,7 +864,7 @@ pt_status pt_debug_numerics(int which, size_t n, const float* x, const float* y,
 
 // Not part of pt_api.h: size of the scene blob and whether kernels read it from LDS (reported by bench.py).
 uint32_t pt_debug_scene_info(pt_scene* sc, int what) {
-    switch (what) { case 0: return sc->blob_words * 4; case 1: return sc->use_lds ? 1u : 0u; case 2: return sc->host.light_count; case 3: return (uint32_t)sc->num_cus;
+    switch (what) { case 0: return sc->blob_words * 4; case 1: return (uint32_t)sc->lds_mode; case 2: return sc->host.light_count; case 3: return (uint32_t)sc->num_cus;
                     case 4: return sc->host.blob[PT_HDR_SWEEP_OFF] != 0 && !(sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP) ? 1u : 0u; default: return 0; }
 }
 

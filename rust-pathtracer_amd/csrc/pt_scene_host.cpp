@@ -215,6 +215,9 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
     }
 
     // meshes: per-mesh BVH over triangles (Mesh::init, mesh.rs:283-305) + gathered triangle records
+    // mesh data (BVH nodes, triangles, normals, leaf lists) goes into its own section behind the core blob; its offsets
+    // are relative to the section (SceneView::m), so the core alone can be staged in LDS when the whole scene does not fit
+    std::vector<uint32_t> md(4, 0u);
     std::vector<uint32_t> mesh_off(d.mesh_count), mesh_node_off(d.mesh_count), mesh_node_count(d.mesh_count);
     std::vector<Box> mesh_box(d.mesh_count);
     hs->mesh_has_light.assign(d.mesh_count, 0);
@@ -237,12 +240,12 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             Box b = box_of_corners(V + 3 * ix[0], V + 3 * ix[1]); box_grow(b, V + 3 * ix[2]);  // mesh.rs:57-64
             tb[f] = b;
         }
-        pad16(w);
-        uint32_t node_off = (uint32_t)w.size();
+        pad16(md);
+        uint32_t node_off = (uint32_t)md.size();
         std::vector<uint32_t> nodes; BvhBuilder bb(tb, nodes); bb.build();
-        w.insert(w.end(), nodes.begin(), nodes.end());
+        md.insert(md.end(), nodes.begin(), nodes.end());
         mesh_node_off[mi] = node_off; mesh_node_count[mi] = (uint32_t)(nodes.size() / PT_NODE_WORDS);
-        uint32_t tri_off = (uint32_t)w.size();
+        uint32_t tri_off = (uint32_t)md.size();
         for (uint32_t f = 0; f < m.face_count; ++f) {
             const uint32_t* ix = d.indices + m.index_offset + 3 * (size_t)f;
             uint32_t mat = m.face_material_offset >= 0 ? d.face_materials[m.face_material_offset + f] : PT_MATERIAL_ID(PT_TAG_MATERIAL, 0);
@@ -250,30 +253,30 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             if (PT_MATERIAL_TAG(mat) == PT_TAG_LIGHT) mesh_light_faces[mi]++;
             for (int k = 0; k < 3; ++k) {
                 const float* p = V + 3 * ix[k];
-                w.push_back(fbits(p[0])); w.push_back(fbits(p[1])); w.push_back(fbits(p[2])); w.push_back(k == 0 ? mat : 0u);
+                md.push_back(fbits(p[0])); md.push_back(fbits(p[1])); md.push_back(fbits(p[2])); md.push_back(k == 0 ? mat : 0u);
             }
         }
         uint32_t normal_off = 0;
         if (m.normal_offset >= 0) {
             const float* N = d.normals + 3 * (size_t)m.normal_offset;
-            normal_off = (uint32_t)w.size();
+            normal_off = (uint32_t)md.size();
             for (uint32_t f = 0; f < m.face_count; ++f) {
                 const uint32_t* ix = d.indices + m.index_offset + 3 * (size_t)f;
-                for (int k = 0; k < 3; ++k) { const float* p = N + 3 * ix[k]; w.push_back(fbits(p[0])); w.push_back(fbits(p[1])); w.push_back(fbits(p[2])); w.push_back(0u); }
+                for (int k = 0; k < 3; ++k) { const float* p = N + 3 * ix[k]; md.push_back(fbits(p[0])); md.push_back(fbits(p[1])); md.push_back(fbits(p[2])); md.push_back(0u); }
             }
         }
         // leaf list for mesh_sweep: the leaf boxes alone, in pre-order (a dense wave of rays inside a mesh of a few hundred
         // triangles tests them all, 64 at a time, instead of walking the tree lane by lane)
         uint32_t leaf_off = 0, leaf_count = 0;
         if (m.face_count <= PT_MESH_SWEEP_MAX) {
-            pad16(w);
-            leaf_off = (uint32_t)w.size();
+            pad16(md);
+            leaf_off = (uint32_t)md.size();
             for (size_t k = 0; k < nodes.size() / PT_NODE_WORDS; ++k) {
                 const uint32_t* nd = &nodes[k * PT_NODE_WORDS];
                 if (nd[7] == PT_NODE_INNER) continue;
                 uint32_t flat = (nd[0] == nd[4] || nd[1] == nd[5] || nd[2] == nd[6]) ? 1u : 0u;
                 uint32_t rec[8] = {nd[0], nd[1], nd[2], tri_off + nd[7] * PT_TRI_WORDS, nd[4], nd[5], nd[6], flat};
-                w.insert(w.end(), rec, rec + 8);
+                md.insert(md.end(), rec, rec + 8);
                 ++leaf_count;
             }
         }
@@ -405,7 +408,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                     seen.push_back({nd[0], nd[1], nd[2], nd[4], nd[5], nd[6]});
                     for (uint32_t k = 0; k < mesh_node_count[in.mesh]; ++k) {
                         uint32_t mn[PT_NODE_WORDS];
-                        for (int q = 0; q < PT_NODE_WORDS; ++q) mn[q] = w[mesh_node_off[in.mesh] + k * PT_NODE_WORDS + q];
+                        for (int q = 0; q < PT_NODE_WORDS; ++q) mn[q] = md[mesh_node_off[in.mesh] + k * PT_NODE_WORDS + q];
                         if (mn[7] == PT_NODE_INNER) continue;
                         std::array<uint32_t, 6> box = {mn[0], mn[1], mn[2], mn[4], mn[5], mn[6]};
                         // the instance's own box is tested against the world ray: only an untransformed instance may share it
@@ -507,6 +510,20 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             w[PT_HDR_IMAP_ROW_CMF] = (uint32_t)hs->tex.size(); hs->tex.insert(hs->tex.end(), row_cmf.begin(), row_cmf.end());
             w[PT_HDR_IMAP_MARG_PDF] = (uint32_t)hs->tex.size(); hs->tex.insert(hs->tex.end(), mpdf.begin(), mpdf.end());
             w[PT_HDR_IMAP_MARG_CMF] = (uint32_t)hs->tex.size(); hs->tex.insert(hs->tex.end(), mcmf.begin(), mcmf.end());
+            // guide tables: entry j = lower bound of j / n in the cmf, so that a search starts in a bracket of a few entries
+            // instead of at the whole table (ten dependent loads from L2/HBM per search otherwise)
+            auto guide = [&](const float* cmf, uint32_t n) {
+                uint32_t k = 0;
+                for (uint32_t j = 0; j < n + 3; ++j) {
+                    if (j > n) k = n;
+                    else { float t = (float)j / (float)n; while (k < n && cmf[k] < t) ++k; }
+                    float bits; uint32_t kk = k; memcpy(&bits, &kk, 4);
+                    hs->tex.push_back(bits);
+                }
+            };
+            w[PT_HDR_IMAP_MARG_GUIDE] = (uint32_t)hs->tex.size(); guide(mcmf.data(), V);
+            w[PT_HDR_IMAP_ROW_GUIDE] = (uint32_t)hs->tex.size();
+            for (uint32_t r = 0; r < V; ++r) guide(row_cmf.data() + (size_t)r * H, H);
         }
     }
     w[PT_HDR_ENV_ANGULAR] = fbits(d.environment.angular_diameter);
@@ -531,6 +548,10 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
         }
         w[PT_HDR_FLAGS] = flags;
     }
+    pad16(w);
+    w[PT_HDR_CORE_WORDS] = (uint32_t)w.size();
+    w.insert(w.end(), md.begin(), md.end());
+    pad16(w);
     w[PT_HDR_MAGIC] = PT_BLOB_MAGIC; w[PT_HDR_TOTAL_WORDS] = (uint32_t)w.size();
     hs->light_count = (uint32_t)lights.size();
     hs->material_count = d.material_count;

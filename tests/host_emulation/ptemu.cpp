@@ -48,7 +48,7 @@ uint32_t ptemu_debug_scene_info(pt_scene* sc, int what) {
 }  // extern "C"
 template <int NL>
 static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, pt_profile* profile) {
-    SceneView s{sc->host.blob.data(), sc->host.tex.data()};
+    SceneView s{sc->host.blob.data(), sc->host.tex.data(), sc->host.blob.data() + sc->host.blob[PT_HDR_CORE_WORDS]};
     std::vector<uint32_t> pixels = pth::shard_pixels(rd.width, rd.height, rd.tile_width, rd.tile_height, rd.shard_index, rd.shard_count);
     std::memset(film, 0, sizeof(float) * 4 * (size_t)rd.width * rd.height);
     uint32_t capacity = 1u << 16;  // small on purpose: exercises pixel chunking and phase-aligned sample passes
@@ -124,7 +124,7 @@ pt_status ptemu_render(pt_scene* sc, const pt_render_desc* rdp, float* film, pt_
 }
 
 pt_status ptemu_intersect(pt_scene* sc, size_t n, const float* o, const float* d, pt_hit* hits) {
-    SceneView s{sc->host.blob.data(), sc->host.tex.data()};
+    SceneView s{sc->host.blob.data(), sc->host.tex.data(), sc->host.blob.data() + sc->host.blob[PT_HDR_CORE_WORDS]};
     for (size_t i = 0; i < n; ++i) {
         Hit h; pt_hit r; std::memset(&r, 0, sizeof(r));
         if (world_hit(s, f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), &h)) {
@@ -137,7 +137,7 @@ pt_status ptemu_intersect(pt_scene* sc, size_t n, const float* o, const float* d
 }
 static uint32_t mat_rec(pt_scene* sc, uint32_t m) { return sc->host.blob[PT_HDR_MATERIAL_OFF] + m * PT_MAT_WORDS; }
 pt_status ptemu_bsdf_sample(pt_scene* sc, uint32_t m, size_t n, const float* lambda, const float* wi, const float* s2, float* f, float* wo, float* pdf) {
-    SceneView s{sc->host.blob.data(), sc->host.tex.data()};
+    SceneView s{sc->host.blob.data(), sc->host.tex.data(), sc->host.blob.data() + sc->host.blob[PT_HDR_CORE_WORDS]};
     for (size_t i = 0; i < n; ++i) {
         F3 w; material_sample(s, mat_rec(sc, m), lambda[i], 0.5f, 0.5f, s2[2 * i], s2[2 * i + 1], f3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), &f[i], &w, &pdf[i]);
         wo[3 * i] = w.x; wo[3 * i + 1] = w.y; wo[3 * i + 2] = w.z;
@@ -145,18 +145,18 @@ pt_status ptemu_bsdf_sample(pt_scene* sc, uint32_t m, size_t n, const float* lam
     return PT_OK;
 }
 pt_status ptemu_bsdf_eval(pt_scene* sc, uint32_t m, size_t n, const float* lambda, const float* wi, const float* wo, float* f, float* pdf) {
-    SceneView s{sc->host.blob.data(), sc->host.tex.data()};
+    SceneView s{sc->host.blob.data(), sc->host.tex.data(), sc->host.blob.data() + sc->host.blob[PT_HDR_CORE_WORDS]};
     for (size_t i = 0; i < n; ++i)
         material_bsdf(s, mat_rec(sc, m), lambda[i], 0.5f, 0.5f, f3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), f3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), &f[i], &pdf[i]);
     return PT_OK;
 }
 pt_status ptemu_emission(pt_scene* sc, uint32_t m, size_t n, const float* lambda, const float* wi, float* e) {
-    SceneView s{sc->host.blob.data(), sc->host.tex.data()};
+    SceneView s{sc->host.blob.data(), sc->host.tex.data(), sc->host.blob.data() + sc->host.blob[PT_HDR_CORE_WORDS]};
     for (size_t i = 0; i < n; ++i) e[i] = material_emission(s, mat_rec(sc, m), lambda[i], f3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]));
     return PT_OK;
 }
 pt_status ptemu_curve_eval(pt_scene* sc, uint32_t c, size_t n, const float* lambda, float* v) {
-    SceneView s{sc->host.blob.data(), sc->host.tex.data()};
+    SceneView s{sc->host.blob.data(), sc->host.tex.data(), sc->host.blob.data() + sc->host.blob[PT_HDR_CORE_WORDS]};
     for (size_t i = 0; i < n; ++i) v[i] = curve_eval(s, sc->host.curve_offsets[c], lambda[i]);
     return PT_OK;
 }
