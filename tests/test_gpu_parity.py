@@ -127,6 +127,28 @@ def test_filtered_slab_test_and_culling_change_nothing(engine, pkg, monkeypatch)
         parity_suite.assert_hits_equal(hits_fast, plain.intersect(o, d))
 
 
+@pytest.mark.parametrize("scene,L", [("cornell_gem", 2), ("hdri_c4_small", 6), ("mixed_primitives", 3)])
+def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
+    """Hybrid scenes (sweep table + walked meshes): parked rays resumed in full waves, walked meshes in line, mesh sweep
+    off, pure BVH walk, core-only / no LDS staging — all the same film bit for bit.  One workgroup per CU makes the
+    segments long enough for the park queue to fill and drain several times per launch."""
+    b = pkg.scene.SCENES[scene]()
+    rd = pkg.api.render_desc(256, 192, 12, 8, light_samples=L, seed=9)
+    monkeypatch.setenv("PT_AMD_BLOCKS_PER_CU", "1")
+    ref_scene = engine.create_scene(b)
+    assert ref_scene.uses_leaf_sweep()
+    base, pbase = ref_scene.render(rd)
+    for env in ({"PT_AMD_NO_PARK": "1"}, {"PT_AMD_NO_MESH_SWEEP": "1"}, {"PT_AMD_NO_SWEEP": "1"}, {"PT_AMD_NO_LDS": "1"}, {"PT_AMD_NO_CORE_LDS": "1"},
+                {"PT_AMD_BLOCKS_PER_CU": "32"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        film, prof = engine.create_scene(b).render(rd)
+        for k in env:
+            monkeypatch.delenv(k) if k != "PT_AMD_BLOCKS_PER_CU" else monkeypatch.setenv(k, "1")
+        assert np.array_equal(base.view(np.uint32), film.view(np.uint32)), env
+        assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits), env
+
+
 def test_full_size_cornell_properties(engine, oracle, pkg):
     """BASELINE.json C2 geometry (1024x1024, max_bounces 8, L = 2) at 2 spp: too big for the oracle film in seconds,
     so check size-independent properties: shards partition the film exactly, counters add up, the film is finite and
