@@ -1,9 +1,10 @@
 // pt_engine.hip — the HIP engine behind include/pt_api.h (gfx950 / MI355X only).
 //
-// Wavefront path tracer: per bounce one launch each of extend -> shade -> shadow over dense SoA queues in HBM
-// (pt_stages.h), persistent grids that stage the scene blob into LDS once per workgroup, wave64 ballot +
-// prefix compaction of surviving paths and of light-sample work items, per-slot energy accumulation without
-// float atomics, and an accumulate kernel that owns one film pixel per lane so film sums keep the reference's
+// Wavefront path tracer: per bounce one launch each of extend -> shade -> shadow over segmented SoA queues in HBM
+// (pt_stages.h; workgroup b owns segment b of every queue and compacts survivors into its own segment with an LDS prefix
+// sum — no global atomics), persistent grids that stage the scene blob (or its core section) into LDS once per workgroup,
+// three traversal forms (pt_device.h: BVH walk, leaf sweep, sweep + parked mesh walks), per-slot energy accumulation
+// without float atomics, and an accumulate kernel that owns one film pixel per lane so film sums keep the reference's
 // order.  No CPU fallback: every entry point fails with PT_ERR_NO_DEVICE when HIP has no device.
 #include <hip/hip_runtime.h>
 

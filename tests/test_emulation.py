@@ -25,7 +25,7 @@ def emu(pkg):
     return pkg.api.Library(lib, "ptemu_", optional=("render_device", "device_info"))
 
 
-@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives", "mixed_small", "white_furnace", "hdri_small"])
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives", "mixed_small", "white_furnace", "hdri_small", "hdri_c4_small"])
 def test_closest_hits_bit_exact(emu, oracle, scene):
     ps.intersect_parity(emu, oracle, scene)
 
@@ -45,6 +45,7 @@ def test_materials_bit_exact(emu, oracle, scene):
     ("mixed_primitives", 32, 32, 8, 6, {"light_samples": 3, "seed": 5}),
     ("mixed_small", 32, 32, 8, 6, {"light_samples": 3, "seed": 6}),
     ("panorama_test", 48, 24, 6, 5, {}),                      # PanoramaCamera
+    ("hdri_c4_small", 24, 24, 4, 4, {"light_samples": 3}),    # monkey mesh: hot BVH nodes re-laid out breadth first
     ("white_furnace", 16, 16, 12, 8, {"light_samples": 6}),
     ("cornell_box", 40, 36, 11, 6, {"hero_wavelengths": 4}),  # C5 shape: hero wavelength + 3 passengers
     ("mixed_primitives", 32, 32, 6, 6, {"hero_wavelengths": 4, "light_samples": 3}),
