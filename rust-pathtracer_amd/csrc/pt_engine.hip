@@ -55,7 +55,7 @@ constexpr int kBlock = 256;
 #define PT_WALK_WAVES 1
 #endif
 #ifndef PT_PARK_WAVES
-#define PT_PARK_WAVES 1
+#define PT_PARK_WAVES 4
 #endif
 #define PT_PARK_OCC __attribute__((amdgpu_waves_per_eu(PT_PARK_WAVES)))
 #define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(NL == 1 ? PT_SHADE_WAVES : PT_SHADE4_WAVES)))
@@ -246,8 +246,7 @@ __global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_shadow(const uint32_t* _
 // more big meshes — the gem in the Cornell room, the monkey under the HDRI).  Most rays never enter a big mesh's box, and
 // the ones that do are scattered over the waves, so walking the mesh in line would leave a wave waiting for a handful of
 // lanes.  Instead a lane that reaches a walked-mesh bit *parks* its sweep state in the workgroup's scratch region, and
-// whenever 256 rays are parked (and at the end) the workgroup resumes them together: full waves, every lane in a mesh
-// walk.  Nothing about a ray's own sequence of tests changes (same leaves, same order, same running closest hit).
+// whenever a wave has 64 rays parked (and at the end) it resumes them together: a full wave, every lane in a mesh walk.  Nothing about a ray's own sequence of tests changes (same leaves, same order, same running closest hit).
 constexpr uint32_t kParkCap = 512, kParkFields = 16;
 enum { PK_ITEM, PK_HIT_LO, PK_HIT_HI, PK_CLOSEST, PK_BEST_INST, PK_BEST_TRIW, PK_T, PK_B0, PK_B1, PK_B2, PK_RAY, PK_BOUND, PK_KIND };
 __device__ __forceinline__ void park_store(uint32_t* pk, uint32_t e, uint32_t item, const SweepState& st, uint32_t ray, float bound, uint32_t kind) {
@@ -262,21 +261,26 @@ __device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32
     st->bh.t = pt_u2f(pk[PK_T * kParkCap + e]); st->bh.b0 = pt_u2f(pk[PK_B0 * kParkCap + e]); st->bh.b1 = pt_u2f(pk[PK_B1 * kParkCap + e]); st->bh.b2 = pt_u2f(pk[PK_B2 * kParkCap + e]);
     *ray = pk[PK_RAY * kParkCap + e]; *bound = pt_u2f(pk[PK_BOUND * kParkCap + e]); *kind = pk[PK_KIND * kParkCap + e];
 }
-// The resume loop shared by both kernels: `resume(entry state)` runs for up to 256 parked rays at a time.
+// The resume loop shared by both kernels, per WAVE: every wave of the workgroup parks into its own quarter of the scratch
+// region (128 entries: fewer than 64 left over + at most 64 new per step) and resumes 64 parked rays at a time — full
+// waves — with no workgroup barrier anywhere: a wave that is deep in a mesh never holds the other three up.  (The first
+// version parked per workgroup with three barriers per drain; rocprofv3 showed the C4 shadow kernel waiting 68 % of its
+// wave cycles at 12 % VALU issue.)
+constexpr uint32_t kWaveParkCap = kParkCap / (kBlock / 64);
 template <typename Resume>
 __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, bool last, Resume&& resume) {
+    const uint32_t lane = lane_id();
     for (;;) {
-        const uint32_t cnt = *park_count;  // uniform: read between barriers
-        if (!(cnt >= kBlock || (last && cnt > 0))) break;
-        const uint32_t take = cnt < (uint32_t)kBlock ? cnt : (uint32_t)kBlock, first = cnt - take;
-        const bool mine = threadIdx.x < take;
+        __threadfence_block();             // this wave's parked entries are visible to its other lanes
+        const uint32_t cnt = *park_count;  // the same for every lane of the wave
+        if (!(cnt >= 64u || (last && cnt > 0u))) break;
+        const uint32_t take = cnt < 64u ? cnt : 64u, first = cnt - take;
+        const bool mine = lane < take;
         uint32_t item = 0, ray = 0, kind = 0; float bound = PT_INF; SweepState st;
-        if (mine) park_load(pk, first + threadIdx.x, &item, &st, &ray, &bound, &kind);
-        __syncthreads();                   // every entry has been read
-        if (threadIdx.x == 0) *park_count = first;
-        __syncthreads();
+        if (mine) park_load(pk, first + lane, &item, &st, &ray, &bound, &kind);
+        __threadfence_block();             // entries are in registers before any lane parks again into these slots
+        if (lane == 0) *park_count = first;
         if (mine) resume(item, st, ray, bound, kind);
-        __syncthreads();
     }
 }
 
@@ -285,19 +289,20 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_extend_parked(const uint
                                                                      Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
                                                                      uint32_t* __restrict__ park_all) {
     extern __shared__ __align__(16) uint32_t lds[];
-    __shared__ uint32_t park_count;
+    __shared__ uint32_t park_counts[kBlock / 64];
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
-    uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap + wave * kWaveParkCap;  // field f of entry e at pk[f * kParkCap + e]
+    uint32_t* park_count = &park_counts[wave];
     const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
     const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
-    if (threadIdx.x == 0) park_count = 0;
-    __syncthreads();
+    if (lane_id() == 0) *park_count = 0;
     auto ray_of = [&](uint32_t i, F3* o, F3* d) {
         *o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
         *d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
     };
     auto settle = [&](uint32_t j, F3 o, F3 d, const SweepState& st, bool parked) {
-        if (parked) park_store(pk, atomicAdd(&park_count, 1u), j, st, 0u, PT_INF, 0u);
+        if (parked) park_store(pk, atomicAdd(park_count, 1u), j, st, 0u, PT_INF, 0u);
         else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, base + j, h); }
     };
     for (uint32_t r = 0; r < rounds; ++r) {
@@ -310,8 +315,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_extend_parked(const uint
             const TriRay wtr = tri_ray_prepare(o, d);
             settle(j, o, d, st, sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true));
         }
-        __syncthreads();
-        park_drain(pk, &park_count, r + 1 == rounds, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t) {
+        park_drain(pk, park_count, r + 1 == rounds, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t) {
             F3 o, d;
             ray_of(base + j2, &o, &d);
             settle(j2, o, d, st, sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st));
@@ -324,16 +328,18 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
                                                                      uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                                      uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ park_all) {
     extern __shared__ __align__(16) uint32_t lds[];
-    __shared__ uint32_t park_count;
+    __shared__ uint32_t park_counts[kBlock / 64];
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
-    uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap + wave * kWaveParkCap;
+    uint32_t* park_count = &park_counts[wave];
     const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
     const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
-    if (threadIdx.x == 0) park_count = 0;
-    __syncthreads();
-    // a finished ray leaves its contribution where its factor was; the item's rays are summed in order at the end
+    if (lane_id() == 0) *park_count = 0;
+    // a finished ray leaves its contribution where its factor was; the item's rays are summed in order at the end (an item's
+    // rays are parked and resumed by the wave that owns the item, so that sum needs no workgroup barrier either)
     auto settle = [&](uint32_t j, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked) {
-        if (parked) { park_store(pk, atomicAdd(&park_count, 1u), j, st, l, bound, env ? 1u : 0u); return; }
+        if (parked) { park_store(pk, atomicAdd(park_count, 1u), j, st, l, bound, env ? 1u : 0u); return; }
         const uint32_t item = base + j;
         float lambda[NL], c[NL];
         for (int k = 0; k < NL; ++k) lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item);
@@ -342,7 +348,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
         shadow_ray_contribution<NL>(s, lambda, ray, env, hit, sh, c);
         for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
     };
-    // one ray of every item per step, so that a step parks at most one ray per lane (the scratch region holds 512)
+    // one ray of every item per step, so that a step parks at most one ray per lane
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t j = r * blockDim.x + threadIdx.x;
         const uint32_t item = base + j, flags = j < n ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
@@ -360,8 +366,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
                     settle(j, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true));
                 }
             }
-            __syncthreads();
-            park_drain(pk, &park_count, r + 1 == rounds && l + 1 == light_samples, [&](uint32_t j2, SweepState& st, uint32_t l2, float bound, uint32_t kind) {
+            park_drain(pk, park_count, r + 1 == rounds && l + 1 == light_samples, [&](uint32_t j2, SweepState& st, uint32_t l2, float bound, uint32_t kind) {
                 ShadowRayT<NL> pr;
                 load_shadow_ray<NL>(shadow, base + j2, l2, &pr);
                 const bool env = kind != 0u;
@@ -371,7 +376,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
             });
         }
     }
-    __syncthreads();
+    __threadfence_block();
     for (uint32_t r = 0; r < rounds; ++r) {  // pt.rs:349-392, 596: the item's rays summed in order, divided by L
         const uint32_t j = r * blockDim.x + threadIdx.x;
         if (j >= n) continue;
