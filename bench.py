@@ -169,6 +169,11 @@ def main():
             probe = pkg.api.render_desc(W, H, 1, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, shard=(0, 4), hero_wavelengths=args.hero)
             t = time.perf_counter(); _, pp = oscene.render(probe); dt = time.perf_counter() - t
             rate = pp.camera_rays / dt
+            # the short probe overestimates the sustained rate (caches, clocks): calibrate once more on ~2 s of work
+            spp2 = max(1, min(64, int(rate * 2.0 / (W * H))))
+            probe2 = pkg.api.render_desc(W, H, spp2, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, hero_wavelengths=args.hero)
+            t = time.perf_counter(); _, pp = oscene.render(probe2); dt = time.perf_counter() - t
+            rate = pp.camera_rays / dt
             budget = rate * args.cpu_seconds
             shard_count = max(1, int((W * H) / max(budget, 1.0)) + 1) if budget < W * H else 1
             spp = max(1, int(budget / (W * H))) if shard_count == 1 else 1
