@@ -96,40 +96,10 @@ __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 // ---- segmented queues -------------------------------------------------------------------------------------------
 // Every queue is cut into gridDim.x segments of `seg_cap` items; workgroup b owns segment b in every kernel of a pass:
 // it reads items [b*seg_cap, b*seg_cap + count_in[b]) and appends its survivors, compacted, to the same segment of the
-// output queue.  Compaction is a wave64 ballot + an LDS exchange of the four wave totals — no global atomics at all
-// (a single hot queue head saturates at ~88 returning atomics/us on MI355X, which was the whole cost of the first
-// version of k_shade), and each workgroup's writes are one contiguous, 256-byte aligned run per field.
-// Survival is statistically uniform over segments, so the static ownership keeps the load balanced.
-struct BlockAppend {
-    uint32_t running;  // items appended so far by this workgroup (uniform across its threads)
-};
-__device__ __forceinline__ uint32_t block_append(bool flag, BlockAppend& st, uint32_t* lds_counts /* [2][4] */, uint32_t round) {
-    unsigned long long mask = __ballot(flag);
-    uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    uint32_t* c = lds_counts + (round & 1u) * 4u;
-    if (lane == 0) c[wave] = (uint32_t)__popcll(mask);
-    __syncthreads();
-    uint32_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-    uint32_t before = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u);
-    uint32_t pos = st.running + before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    st.running += c0 + c1 + c2 + c3;
-    return pos;
-}
-// two independent appends sharing one barrier
-__device__ __forceinline__ void block_append2(bool f0, bool f1, BlockAppend& s0, BlockAppend& s1, uint32_t* lds_counts /* [2][8] */, uint32_t round,
-                                              uint32_t* pos0, uint32_t* pos1) {
-    unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
-    uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    uint32_t* c = lds_counts + (round & 1u) * 8u;
-    if (lane == 0) { c[wave] = (uint32_t)__popcll(m0); c[4 + wave] = (uint32_t)__popcll(m1); }
-    __syncthreads();
-    uint32_t a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3], b0 = c[4], b1 = c[5], b2 = c[6], b3 = c[7];
-    unsigned long long lt = (1ull << lane) - 1ull;
-    *pos0 = s0.running + (wave > 0 ? a0 : 0u) + (wave > 1 ? a1 : 0u) + (wave > 2 ? a2 : 0u) + (uint32_t)__popcll(m0 & lt);
-    *pos1 = s1.running + (wave > 0 ? b0 : 0u) + (wave > 1 ? b1 : 0u) + (wave > 2 ? b2 : 0u) + (uint32_t)__popcll(m1 & lt);
-    s0.running += a0 + a1 + a2 + a3;
-    s1.running += b0 + b1 + b2 + b3;
-}
+// output queue.  Compaction is a wave64 ballot + one LDS atomic per wave (shared_append) — no global atomics (a single hot
+// queue head saturates at ~88 returning atomics/us on MI355X, which was the whole cost of the first version of k_shade)
+// and no barrier; each wave's writes are one contiguous run per field.  The four waves of a workgroup stride through the
+// shared segment, which balances them; survival is statistically uniform over segments, which balances the workgroups.
 // Append without a barrier: one LDS atomic per wave claims the wave's run in the workgroup's segment.  The order of the
 // waves' runs inside the segment then depends on timing, which no result depends on (every queue item is processed on its
 // own; energy and film sums are keyed by slot and pixel).  Measured on k_shade: -6 % against block_append's barrier.

@@ -181,3 +181,29 @@ def test_error_behaviour(engine, pkg):
     bad_scene.add_camera((0, 0, 0), (1, 0, 0), 40.0)
     with pytest.raises(pkg.api.PtError):
         engine.create_scene(bad_scene)   # environment curve missing
+
+
+def test_bench_line_contract(pkg):
+    """bench.py prints ONE JSON line with the driver's keys, the roofline of the dominant kernel (HIP-event time inside the
+    timed region) and the CPU baseline of the oracle."""
+    import json
+    import subprocess
+    import sys
+    root = pkg.REPO_ROOT
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--width", "128", "--height", "128",
+                        "--spp-per-step", "20", "--cpu-seconds", "0.5"], capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().split("\n") if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Msamples/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 128 * 128 * 20 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-6
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert "traffic" in rf and rf["kernel"].startswith("k_")
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "Msamples/s" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
