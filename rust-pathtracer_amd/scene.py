@@ -604,6 +604,15 @@ def mixed_small():
     return b
 
 
+def empty_env():
+    """No instance at all: a constant environment and a camera (edge case: empty BVH, empty light list)."""
+    b = SceneBuilder()
+    add_library_curves(b, ["flat_one"])
+    b.set_environment_constant(b.curve("flat_one"), 1.0)
+    b.add_camera((0.0, 0.0, 0.0), (1.0, 0.0, 0.0), 40.0)
+    return b
+
+
 def panorama_test():
     """The Cornell box seen by a PanoramaCamera from its centre (not a reference scene)."""
     b = cornell_box()
@@ -677,4 +686,4 @@ def hdri_c4_small():
 
 
 SCENES = {"hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
-          "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test, "panorama_test": panorama_test}
+          "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test, "panorama_test": panorama_test, "empty_env": empty_env}
