@@ -205,6 +205,8 @@ typedef struct pt_render_desc {
     uint32_t hero_wavelengths;   /* 1, or 4 for the hero-wavelength variant */
     uint32_t first_sample;       /* render samples [first_sample, first_sample + sample_count) of the spp; */
     uint32_t sample_count;       /* 0 = all spp. With a partial range the film holds the un-normalised running sum. */
+    uint32_t phase_samples;      /* samples summed before their sum is added to the pixel: 0 = 10 (TiledRenderer, src/renderer/tiled.rs:347-361);
+                                    >= spp = all of them, then one division (NaiveRenderer, src/renderer/naive.rs:82-103) */
 } pt_render_desc;
 
 typedef struct pt_profile {      /* Profile (src/profile.rs:2-8) + timing */

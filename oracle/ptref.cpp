@@ -1568,6 +1568,7 @@ inline void add_profile(pt_profile& a, const pt_profile& b) {
 void render_tile(const RenderCtx& ctx, const TileRect& tile, float* film, pt_profile& profile) {
     const pt_render_desc& rd = ctx.rd;
     uint32_t first = rd.first_sample, count = rd.sample_count ? rd.sample_count : rd.spp;
+    const uint32_t phase = rd.phase_samples ? rd.phase_samples : 10;  // tiled.rs:347-361 (10) or naive.rs:82-103 (all samples)
     bool whole = (first == 0 && count == rd.spp);
     for (uint32_t y = tile.y0; y < tile.y1; ++y) {
         for (uint32_t x = tile.x0; x < tile.x1; ++x) {
@@ -1589,7 +1590,7 @@ void render_tile(const RenderCtx& ctx, const TileRect& tile, float* film, pt_pro
                 temp[0] += energy * x_bar(ang); temp[1] += energy * y_bar(ang); temp[2] += energy * z_bar(ang);
                 }
                 // phases of 10 samples: temp_color summed per phase, then added to the pixel (tiled.rs:347-391)
-                if ((sidx + 1) % 10 == 0 || sidx + 1 == rd.spp || sidx + 1 == first + count) {
+                if ((sidx + 1) % phase == 0 || sidx + 1 == rd.spp || sidx + 1 == first + count) {
                     px[0] += temp[0]; px[1] += temp[1]; px[2] += temp[2];
                     temp[0] = temp[1] = temp[2] = 0.0f;
                 }

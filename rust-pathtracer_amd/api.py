@@ -99,7 +99,7 @@ class RenderDesc(C.Structure):
                 ("wavelength_lo", C.c_float), ("wavelength_hi", C.c_float), ("camera_index", C.c_uint32),
                 ("seed", C.c_uint64), ("tile_width", C.c_uint32), ("tile_height", C.c_uint32),
                 ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("hero_wavelengths", C.c_uint32),
-                ("first_sample", C.c_uint32), ("sample_count", C.c_uint32)]
+                ("first_sample", C.c_uint32), ("sample_count", C.c_uint32), ("phase_samples", C.c_uint32)]
 
 
 class Profile(C.Structure):
@@ -159,10 +159,10 @@ def _fp(a):
 
 def render_desc(width, height, spp, max_bounces, min_bounces=1, light_samples=2, only_direct=False,
                 wavelength=(380.0, 750.0), camera_index=0, seed=1, tile=(32, 32), shard=(0, 0),
-                hero_wavelengths=1, first_sample=0, sample_count=0):
+                hero_wavelengths=1, first_sample=0, sample_count=0, phase_samples=0):
     return RenderDesc(width, height, spp, min_bounces, max_bounces, light_samples, int(bool(only_direct)),
                       wavelength[0], wavelength[1], camera_index, seed, tile[0], tile[1], shard[0], shard[1],
-                      hero_wavelengths, first_sample, sample_count)
+                      hero_wavelengths, first_sample, sample_count, phase_samples)
 
 
 class Library:

@@ -816,7 +816,9 @@ pt_status pt_config_render_desc(const pt_config* c, uint32_t i, uint64_t seed, p
     out->camera_index = 0;  // the PT integrator always asks for camera 0 (src/renderer/tiled.rs:378)
     out->seed = seed;
     if (c->renderer == PT_RENDERER_TILED) { out->tile_width = c->tile_w; out->tile_height = c->tile_h; }
-    else { out->tile_width = s.width; out->tile_height = s.height; }  // NaiveRenderer: the film as one tile
+    else {  // NaiveRenderer (src/renderer/naive.rs:67-103): pixels in row-major order, all samples summed, one division
+        out->tile_width = s.width; out->tile_height = s.height; out->phase_samples = s.min_samples;
+    }
     out->hero_wavelengths = s.hwss ? 4u : 1u;
     return PT_OK;
 }

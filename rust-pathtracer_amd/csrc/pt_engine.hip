@@ -553,6 +553,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     rp.wavelength_lo = rd.wavelength_lo; rp.wavelength_span = rd.wavelength_hi - rd.wavelength_lo;
     rp.spp = rd.spp; rp.range_end = rd.first_sample + rd.sample_count;
     rp.normalize = (rd.first_sample == 0 && rd.sample_count == rd.spp) ? 1u : 0u;
+    rp.phase = rd.phase_samples;
     rp.camera = pth::camera_params(sc->host.cameras[rd.camera_index], (float)rd.width / (float)rd.height);
     rp.energy_stride = b.capacity;
 
@@ -588,7 +589,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     };
 
     // the planner's capacity is in items; segments round up, so plan with what surely fits
-    std::vector<pth::Pass> passes = pth::plan_passes((uint32_t)pixels.size(), rd.first_sample, rd.sample_count, capacity);
+    std::vector<pth::Pass> passes = pth::plan_passes((uint32_t)pixels.size(), rd.first_sample, rd.sample_count, capacity, rd.phase_samples);
     uint64_t camera_rays = 0, accumulated_pixels = 0;
     for (const pth::Pass& pass : passes) {
         accumulated_pixels += pass.pixel_count;

@@ -23,12 +23,14 @@ std::vector<uint32_t> shard_pixels(uint32_t width, uint32_t height, uint32_t tw,
     return px;
 }
 
-std::vector<Pass> plan_passes(uint32_t n_pixels, uint32_t first_sample, uint32_t sample_count, uint32_t capacity) {
+std::vector<Pass> plan_passes(uint32_t n_pixels, uint32_t first_sample, uint32_t sample_count, uint32_t capacity, uint32_t phase_samples) {
     std::vector<Pass> passes;
     if (n_pixels == 0 || sample_count == 0) return passes;
-    // A pass must be able to hold one whole phase (10 samples, or the whole range if shorter) of its pixels,
-    // because the per-phase partial sums of tiled.rs:366-391 live in registers of the accumulate kernel.
-    uint32_t phase = sample_count < 10 ? sample_count : 10;
+    // A pass must be able to hold one whole phase (10 samples — or all of them for the naive renderer —, or the whole range
+    // if shorter) of its pixels, because the per-phase partial sums of tiled.rs:366-391 live in registers of the
+    // accumulate kernel.
+    const uint32_t period = phase_samples ? phase_samples : 10;
+    uint32_t phase = sample_count < period ? sample_count : period;
     uint32_t max_chunk = capacity / phase;
     if (max_chunk == 0) max_chunk = 1;
     uint32_t n_chunks = (n_pixels + max_chunk - 1) / max_chunk;
@@ -42,7 +44,7 @@ std::vector<Pass> plan_passes(uint32_t n_pixels, uint32_t first_sample, uint32_t
             uint32_t take = end - s; if (take > max_s) take = max_s;
             uint32_t stop = s + take;
             if (stop < end) {                                 // end the pass on a phase boundary
-                uint32_t aligned = (stop / 10) * 10;
+                uint32_t aligned = (stop / period) * period;
                 if (aligned > s) stop = aligned;
             }
             passes.push_back(Pass{p0, pc, s, stop - s});
@@ -88,6 +90,7 @@ bool normalize_render_desc(const pt_render_desc& in, uint32_t camera_count, pt_r
     if (rd.tile_width == 0) rd.tile_width = 32;
     if (rd.tile_height == 0) rd.tile_height = 32;
     if (rd.hero_wavelengths == 0) rd.hero_wavelengths = 1;
+    if (rd.phase_samples == 0) rd.phase_samples = 10;
     if (rd.sample_count == 0) { rd.first_sample = 0; rd.sample_count = rd.spp; }
     if (rd.width == 0 || rd.height == 0 || rd.spp == 0) { *error = "width, height and spp must be positive"; return false; }
     if ((uint64_t)rd.width * rd.height > 0xffffffffull) { *error = "film too large"; return false; }

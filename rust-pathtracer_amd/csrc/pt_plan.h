@@ -21,7 +21,7 @@ std::vector<uint32_t> shard_pixels(uint32_t width, uint32_t height, uint32_t til
 struct Pass { uint32_t pixel_begin, pixel_count, first_sample, sample_count; };
 // Passes over (pixel chunk, sample range).  A pass never splits one of the reference's phases of 10 samples
 // (tiled.rs:347-361) unless the requested range itself does, so the film sums keep the reference's order.
-std::vector<Pass> plan_passes(uint32_t n_pixels, uint32_t first_sample, uint32_t sample_count, uint32_t capacity);
+std::vector<Pass> plan_passes(uint32_t n_pixels, uint32_t first_sample, uint32_t sample_count, uint32_t capacity, uint32_t phase_samples = 10);
 
 // ProjectiveCamera::new + with_aspect_ratio (src/camera/projective_camera.rs:27-95, 121-133)
 ptd::CameraParams camera_params(const pt_camera& c, float aspect_ratio);

@@ -55,6 +55,7 @@ struct RenderParams {
     uint32_t range_end;         // first_sample + sample_count of the whole call
     uint32_t normalize;         // divide by spp when the last phase of a whole render is flushed
     uint32_t energy_stride;     // energy of wavelength k of slot i at energy[k * energy_stride + i]
+    uint32_t phase;             // samples per partial sum (10: tiled.rs:347-361; spp: naive.rs:82-103)
     CameraParams camera;
 };
 
@@ -409,7 +410,7 @@ PT_HD void stage_accumulate_pixel(const RenderParams& rp, const float* energy, u
             }
             t0 += c0 / 4.0f; t1 += c1 / 4.0f; t2 += c2 / 4.0f;
         }
-        if ((sample + 1) % 10 == 0 || sample + 1 == rp.spp || sample + 1 == rp.range_end) {  // phases of 10, tiled.rs:347-361
+        if ((sample + 1) % rp.phase == 0 || sample + 1 == rp.spp || sample + 1 == rp.range_end) {  // phases of 10, tiled.rs:347-361 (or of everything, naive.rs:82-103)
             f0 += t0; f1 += t1; f2 += t2;
             t0 = t1 = t2 = 0.0f;
         }

@@ -61,6 +61,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
     rp.wavelength_lo = rd.wavelength_lo; rp.wavelength_span = rd.wavelength_hi - rd.wavelength_lo;
     rp.spp = rd.spp; rp.range_end = rd.first_sample + rd.sample_count;
     rp.normalize = (rd.first_sample == 0 && rd.sample_count == rd.spp) ? 1u : 0u;
+    rp.phase = rd.phase_samples;
     rp.energy_stride = capacity;
     rp.camera = pth::camera_params(sc->host.cameras[rd.camera_index], (float)rd.width / (float)rd.height);
     typedef Layout<NL> LY;
@@ -70,7 +71,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
     Queue qa{pa.data(), capacity}, qb{pb.data(), capacity}, qh{ph.data(), capacity}, qs{psh.data(), capacity};
     uint64_t bounce_rays = 0, shadow_rays = 0, env_hits = 0, camera_rays = 0;
     uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
-    for (const pth::Pass& pass : pth::plan_passes((uint32_t)pixels.size(), rd.first_sample, rd.sample_count, capacity)) {
+    for (const pth::Pass& pass : pth::plan_passes((uint32_t)pixels.size(), rd.first_sample, rd.sample_count, capacity, rd.phase_samples)) {
         rp.chunk_pixels = pass.pixel_count; rp.first_sample = pass.first_sample; rp.pass_samples = pass.sample_count;
         const uint32_t* px = pixels.data() + pass.pixel_begin;
         uint32_t n = pass.pixel_count * pass.sample_count;

@@ -66,6 +66,7 @@ def test_materials_bit_exact(engine, oracle, scene):
     ("mixed_primitives", 64, 64, 8, 6, {"light_samples": 3, "seed": 5}),
     ("mixed_small", 64, 64, 8, 6, {"light_samples": 3, "seed": 6}),
     ("panorama_test", 128, 64, 8, 6, {}),                     # PanoramaCamera
+    ("cornell_box", 96, 64, 23, 4, {"phase_samples": 23, "tile": (96, 64)}),   # NaiveRenderer: one sum over all samples (naive.rs:82-103)
     ("empty_env", 1, 1, 1, 0, {}),                            # edge cases: no instances, 1x1 film, no bounces
     ("empty_env", 5, 3, 2, 4, {"light_samples": 3}),
     ("cornell_box", 3, 2, 1, 1, {"tile": (64, 64)}),          # film smaller than a tile

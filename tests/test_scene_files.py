@@ -51,6 +51,16 @@ def test_config_defaults_and_second_pass(sfmod, pkg):
     assert cfg.output_desc(1).key_value == np.float32(0.2)
 
 
+def test_naive_renderer_settings(sfmod, tmp_path):
+    """renderer.type = "Naive" (src/renderer/naive.rs): the film as one tile, all samples in one sum."""
+    text = open(data(sfmod, "config_cornell_c1.toml")).read().replace('type = "Tiled"\ntile_size = [32, 32]', 'type = "Naive"')
+    p = tmp_path / "naive.toml"; p.write_text(text)
+    cfg = sfmod.Config(str(p))
+    rd = cfg.render_desc(0)
+    assert cfg.renderer[0] == 0 and (rd.tile_width, rd.tile_height, rd.phase_samples) == (256, 256, 16)
+    assert sfmod.Config(data(sfmod, "config_cornell_c1.toml")).render_desc(0).phase_samples == 0
+
+
 def _write(tmp_path, name, text):
     p = tmp_path / name
     p.write_text(text)
