@@ -1,0 +1,92 @@
+"""Seeded random scenes for differential testing (engine / emulation vs oracle): every primitive kind, random transform
+stacks (non-uniform scale, rotation lists), one-sided and two-sided surfaces, lights of both kinds, metals and dielectrics,
+small meshes with and without shading normals, every environment kind.  Not reference scenes: their only purpose is to
+reach corners of the traversal and shading code that the authored scenes do not."""
+import importlib
+
+import numpy as np
+
+
+def random_scene(seed):
+    pkg = importlib.import_module("rust-pathtracer_amd")
+    S, api = pkg.scene, pkg.api
+    rng = np.random.default_rng(seed)
+    b = S.SceneBuilder()
+    env = rng.integers(0, 3)
+    if env == 0:
+        S.add_library_curves(b, ["simple_sky_blue"])
+        b.set_environment_constant(b.curve("simple_sky_blue"), float(rng.uniform(0.0, 1.0)))
+    elif env == 1:
+        sun = b.curve_blackbody(None, float(rng.uniform(3000, 7000)), 1.0)
+        d = rng.normal(size=3); d[2] = abs(d[2]) + 0.2
+        b.set_environment_sun(sun, float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.05, 0.3)), d.tolist())
+    else:
+        S.add_library_curves(b, ["srgb_r", "srgb_g", "srgb_b", "flat_zero"])
+        ts = b.texstack_texture4("hdri", [b.curve(n) for n in ("srgb_r", "srgb_g", "srgb_b", "flat_zero")], S.synthetic_hdri(32, 16))
+        rot = [((0, 0, 1), float(rng.uniform(-180, 180)))] if rng.random() < 0.5 else None
+        imp = (16, 16) if rng.random() < 0.7 else (0, 0)
+        b.set_environment_hdr(ts, float(rng.uniform(0.3, 1.5)), rotate=rot, importance=imp)
+    b.env_sampling_probability = float(rng.choice([0.0, 0.3, 0.5, 1.0])) if env != 0 or rng.random() < 0.8 else 0.5
+    mats = [S.add_library_material(b, n) for n in ("lambertian_white", "lambertian_red", "lambertian_green", "ggx_gold", "ggx_copper", "ggx_glass", "ggx_glass_rough",
+                                                   "ggx_moissanite")]
+    lights = [S.add_library_material(b, n) for n in ("diffuse_light_flat_x5", "diffuse_light_cornell", "sharp_light", "sharp_light_fluorescent")]
+
+    def transform():
+        if rng.random() < 0.4:
+            return None
+        scale = rng.uniform(0.4, 1.6, 3).tolist() if rng.random() < 0.6 else None
+        rot = [(rng.normal(size=3).tolist(), float(rng.uniform(-180, 180))) for _ in range(rng.integers(0, 3))] or None
+        tr = rng.uniform(-1.0, 1.0, 3).tolist() if rng.random() < 0.8 else None
+        if scale is None and rot is None and tr is None:
+            return None
+        return S.transform_from_data(scale, rot, tr)
+
+    def material(light_ok=True):
+        if light_ok and rng.random() < 0.25:
+            return lights[rng.integers(len(lights))]
+        return mats[rng.integers(len(mats))]
+
+    b.add_rect((8, 8), (0.0, 0.0, -1.5), "Z", True, mats[0])  # a floor, so that most paths bounce
+    n_light = 0
+    for _ in range(rng.integers(2, 9)):
+        kind = rng.integers(0, 4)
+        origin = rng.uniform(-1.2, 1.2, 3).tolist()
+        m = material()
+        n_light += (m >> 16) == 1
+        if kind == 0:
+            b.add_rect(tuple(rng.uniform(0.3, 2.0, 2).tolist()), origin, "XYZ"[rng.integers(3)], bool(rng.integers(2)), m, transform())
+        elif kind == 1:
+            b.add_sphere(float(rng.uniform(0.2, 0.8)), origin, m, transform())
+        elif kind == 2:
+            b.add_disk(float(rng.uniform(0.2, 0.9)), origin, bool(rng.integers(2)), m, transform())
+        else:
+            p, f, n = S._octahedron()
+            if rng.random() < 0.5:
+                n = None
+            p = p * rng.uniform(0.3, 0.9, 3).astype(np.float32)
+            fm = np.array([mats[rng.integers(len(mats))] for _ in range(len(f))], np.uint32)   # mesh faces cannot be lights (mesh.rs:213-232)
+            mesh = b.add_mesh(p, f, n, face_materials=fm)
+            b.add_mesh_instance(mesh, material(light_ok=False) if rng.random() < 0.5 else None, transform())
+    if n_light == 0:
+        b.add_rect((1.0, 1.0), (0.0, 0.0, 2.0), "Z", True, lights[0])
+    if rng.random() < 0.3:  # a bigger mesh: the sweep table can no longer inline every triangle (walked mesh, parked rays)
+        p, f, n, _ = S._npz_mesh("gem")
+        mesh = b.add_mesh(p, f, n, face_materials=api.material_id(api.TAG_MATERIAL, mats[0] & 0xFFFF))
+        b.add_mesh_instance(mesh, mats[rng.integers(len(mats))], S.transform_from_data((0.5, 0.5, 0.5), None, rng.uniform(-0.8, 0.8, 3).tolist()))
+    eye = rng.normal(size=3); eye = eye / np.linalg.norm(eye) * rng.uniform(3.0, 6.0); eye[2] = abs(eye[2]) * 0.5
+    if rng.random() < 0.2:
+        b.add_panorama_camera(eye.tolist(), (0.0, 0.0, 0.0), (float(rng.uniform(60, 360)), float(rng.uniform(40, 180))))
+    else:
+        b.add_camera(eye.tolist(), (0.0, 0.0, -0.3), float(rng.uniform(25, 60)), focal_distance=float(np.linalg.norm(eye)), aperture_diameter=float(rng.choice([0.0, 0.01, 0.1])))
+    return b
+
+
+def random_rays(seed, n):
+    rng = np.random.default_rng(seed + 1000)
+    o = rng.normal(0, 1.5, (n, 3)).astype(np.float32)
+    d = rng.normal(0, 1, (n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    # a share of axis-parallel rays and of rays that start on z = -1.5 (the floor plane)
+    d[: n // 16] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, n // 16)] * rng.choice([-1.0, 1.0], (n // 16, 1)).astype(np.float32)
+    o[n // 16: n // 8, 2] = -1.5
+    return o, d

@@ -1,0 +1,43 @@
+"""Differential fuzzing over seeded random scenes (tests/fuzz_scenes.py): closest hits bit for bit and films within the
+parity bars, emulation vs oracle on the CPU and engine vs oracle on the GPU."""
+import numpy as np
+import pytest
+
+import fuzz_scenes
+import parity_suite as ps
+from test_emulation import emu  # noqa: F401  (fixture)
+
+
+def run(impl, oracle, pkg, seed, n_rays, w, h, spp):
+    b = fuzz_scenes.random_scene(seed)
+    o, d = fuzz_scenes.random_rays(seed, n_rays)
+    si, so = impl.create_scene(b), oracle.create_scene(b)
+    ps.assert_hits_equal(si.intersect(o, d), so.intersect(o, d))
+    rd = pkg.api.render_desc(w, h, spp, 6, light_samples=int(1 + seed % 3), seed=seed, hero_wavelengths=4 if seed % 5 == 0 else 1)
+    film, prof = si.render(rd)
+    ref, rprof = so.render(rd)
+    ps.check_film(film, ref, prof, rprof)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_emulation_on_random_scenes(emu, oracle, pkg, seed):  # noqa: F811
+    run(emu, oracle, pkg, seed, 2048, 20, 16, 3)
+
+
+@pytest.mark.parametrize("seed", range(20, 26))
+def test_emulation_bvh_walk_on_random_scenes(emu, oracle, pkg, monkeypatch, seed):  # noqa: F811
+    monkeypatch.setenv("PTEMU_FLAGS", "16")  # PT_FLAG_NO_SWEEP: the two-level BVH walk instead of the sweep table
+    run(emu, oracle, pkg, seed, 2048, 20, 16, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(100, 140))
+def test_engine_on_random_scenes(engine, oracle, pkg, seed):
+    run(engine, oracle, pkg, seed, 1 << 14, 48, 40, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(200, 210))
+def test_engine_bvh_walk_on_random_scenes(engine, oracle, pkg, monkeypatch, seed):
+    monkeypatch.setenv("PT_AMD_NO_SWEEP", "1")
+    run(engine, oracle, pkg, seed, 1 << 14, 48, 40, 4)
