@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=60, help="samples per pixel per step and per GPU")
+    ap.add_argument("--spp-per-step", type=int, default=120, help="samples per pixel per step and per GPU (120 x 1024^2 = one full 128 Mi-slot pass)")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--max-bounces", type=int, default=8)
@@ -142,12 +142,17 @@ def main():
         traffic, traffic_src = None, None
         try:
             import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), key=os.path.getmtime)
-            if cands and args.scene == "cornell_box" and (W, H, args.spp_per_step, n_gpus) == (1024, 1024, 60, 1):
-                summ = json.load(open(cands[-1]))
+            # the newest committed profile (by tag) that was taken on this very workload
+            metric_name = "Msamples/s (paths x spp / s), Cornell box %dx%d, max_bounces=%d" % (W, H, args.max_bounces)
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), reverse=True):
+                summ = json.load(open(path))
+                wl = summ.get("workload")
+                if not wl or (wl["scene"], wl["spp_per_step"], wl["n_gpus"], wl["metric"]) != (args.scene, S, n_gpus, metric_name):
+                    continue
                 kname = "k_" + STAGES[dom]
                 traffic = (2.0 * summ["FETCH_SIZE"][kname]["avg_per_launch"] + summ["WRITE_SIZE"][kname]["avg_per_launch"]) * 1024.0
-                traffic_src = os.path.basename(cands[-1])
+                traffic_src = os.path.basename(path)
+                break
         except Exception:
             traffic = None
         roofline = {"bound": "hbm", "kernel": "k_" + STAGES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

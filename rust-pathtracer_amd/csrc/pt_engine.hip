@@ -532,13 +532,13 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     HIP_TRY(hipSetDevice(sc->device));
 
     std::vector<uint32_t> pixels = pth::shard_pixels(rd.width, rd.height, rd.tile_width, rd.tile_height, rd.shard_index, rd.shard_count);
-    uint32_t capacity = env_u32("PT_AMD_BATCH", 1u << 26);  // path slots per pass (64 Mi ~ 16 GB of queues; measured knee, tools/sweep.sh)
+    uint32_t capacity = env_u32("PT_AMD_BATCH", 1u << 27);  // path slots per pass (128 Mi ~ 32 GB of queues of the 288 GB; tools/sweep.sh)
     if (capacity < 1024) capacity = 1024;
     uint64_t want = (uint64_t)pixels.size() * rd.sample_count;
     if (want < capacity) capacity = (uint32_t)(want ? want : 1);
-    const int grid = sc->num_cus * (int)env_u32("PT_AMD_BLOCKS_PER_CU", 32);  // queue segments = workgroups per launch
+    const int grid = sc->num_cus * (int)env_u32("PT_AMD_BLOCKS_PER_CU", 64);  // queue segments = workgroups per launch
     const bool hero = rd.hero_wavelengths == 4;
-    if (hero && capacity > (1u << 24)) capacity = 1u << 24;  // 4-wavelength queues are ~1.5x wider
+    if (hero && capacity > (1u << 26)) capacity = 1u << 26;  // 4-wavelength queues are ~1.5x wider: 64 Mi slots ~ 24 GB
     pt_status st = ensure_buffers(sc, capacity, rd.light_samples, pixels.size() ? pixels.size() : 1, grid, hero ? 4u : 1u);
     if (st != PT_OK) return st;
     DeviceBuffers& b = sc->buf;

@@ -2,11 +2,11 @@
 # Runs bench.py on the BASELINE.json configurations C2..C5 (C1 is the CPU plumbing case) and stores one JSON line each.
 OUT=${1:-gpurun_out/configs}; mkdir -p $OUT
 python bench.py --steps 4 --warmup 1 --cpu-seconds 10 > $OUT/C2.json 2> $OUT/C2.err
-python bench.py --scene cornell_gem --width 1920 --height 1080 --max-bounces 12 --spp-per-step 30 --steps 3 --warmup 1 --cpu-seconds 10 \
+python bench.py --scene cornell_gem --width 1920 --height 1080 --max-bounces 12 --spp-per-step 60 --steps 3 --warmup 1 --cpu-seconds 10 \
   --workload "C3: cornell_box_diamond_gem (moissanite GGX, brilliant_diamond.obj, env constant 0), 1920x1080, max_bounces=12, L=2" > $OUT/C3.json 2> $OUT/C3.err
-python bench.py --scene hdri_test --max-bounces 4 --light-samples 6 --spp-per-step 30 --steps 3 --warmup 1 --cpu-seconds 10 \
+python bench.py --scene hdri_test --max-bounces 4 --light-samples 6 --spp-per-step 120 --steps 3 --warmup 1 --cpu-seconds 10 \
   --workload "C4: hdri_test sphere + monkey.obj (ggx_gold), synthetic 1024x512 HDRI, 1024x1024 importance map, env_sampling_probability 0.9, 1024x1024, max_bounces=4, L=6" > $OUT/C4.json 2> $OUT/C4.err
-python bench.py --hero 4 --spp-per-step 10 --steps 3 --warmup 1 --cpu-seconds 10 \
+python bench.py --hero 4 --spp-per-step 60 --steps 3 --warmup 1 --cpu-seconds 10 \
   --workload "C5: Cornell box, hero wavelength (4 wavelengths per path), 1024x1024, max_bounces=8, L=2" > $OUT/C5.json 2> $OUT/C5.err
 for c in C2 C3 C4 C5; do python - <<PY
 import json

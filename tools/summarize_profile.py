@@ -42,6 +42,16 @@ def main():
     prof = os.path.join(root, "profiles")
     os.makedirs(prof, exist_ok=True)
     summary = {"tag": tag}
+    # the workload the profiled command ran (bench.py's own JSON line in the trace pass), so that bench.py can tell whether
+    # these per-launch numbers belong to the run it is reporting
+    try:
+        for line in open(os.path.join(out_dir, "bench_trace.log")):
+            if line.startswith("{") and '"metric"' in line:
+                b = json.loads(line)
+                summary["workload"] = {"scene": b["config"]["scene"], "spp_per_step": b["config"]["spp_per_step"], "samples_per_step": b["config"]["samples_per_step"],
+                                       "metric": b["metric"], "n_gpus": b["n_gpus"]}
+    except (OSError, ValueError, KeyError):
+        pass
     # 1. kernel stats
     stats = defaultdict(list)
     meta = {}
