@@ -123,7 +123,9 @@
 //   triangles of every planar quad share a box), so b's decision is copied instead of recomputed.
 // Bit table (PT_HDR_SWEEP_BITS_OFF): per mask bit 8 words: instance record offset, triangle word offset (0: the instance
 // itself), box word offset (min at +0, max at +4), kind | flat << 8 | has_transform << 9 | instance id << 16,
-// followers (2 words: the later bits that alias this one, directly or through a chain), 2 pad
+// followers (2 words: the later bits that alias this one, directly or through a chain), then for a triangle the word
+// distances from its record to its copies permuted for a dominant x axis (y, z, x) and y axis (z, x, y) — the mesh-data
+// section keeps the triangles of every mesh in the table in all three vertex permutations (triangle_test_permuted)
 #define PT_SWEEP_WALKED 0x400u     /* kind/flags word: a mesh instance whose triangles are not in the table; its BVH is walked */
 #define PT_SWEEP_INST_WORDS 12
 #define PT_SWEEP_TRI_WORDS 8

@@ -302,7 +302,7 @@ PT_HD F3 tri_shuffle(F3 v, uint32_t m) {
     if (m == 1) return f3(v.z, v.x, v.y);
     return v;
 }
-struct TriRay { F3 o; uint32_t kz; float sx, sy, sz; };
+struct TriRay { F3 o; uint32_t kz; float sx, sy, sz; F3 os; /* o, permuted like the direction */ };
 PT_HD TriRay tri_ray_prepare(F3 o, F3 dir) {
     TriRay r; r.o = o;
     float ax = pt_abs(dir.x), ay = pt_abs(dir.y), az = pt_abs(dir.z);
@@ -314,11 +314,12 @@ PT_HD TriRay tri_ray_prepare(F3 o, F3 dir) {
     if (0.0f >= mx) kz = 3;
     F3 d = tri_shuffle(dir, kz);
     r.kz = kz; r.sx = -d.x / d.z; r.sy = -d.y / d.z; r.sz = 1.0f / d.z;
+    r.os = tri_shuffle(o, kz);
     return r;
 }
-PT_HD bool triangle_test(F3 p0, F3 p1, F3 p2, const TriRay& r, float t0, float t1, TriHit* out) {
+// the test proper, on vertices already translated to the ray origin and permuted (mesh.rs:101-198)
+PT_HD bool triangle_test_core(F3 p0t, F3 p1t, F3 p2t, const TriRay& r, float t0, float t1, TriHit* out) {
     PT_STAT(tri_tests);
-    F3 p0t = tri_shuffle(sub(p0, r.o), r.kz), p1t = tri_shuffle(sub(p1, r.o), r.kz), p2t = tri_shuffle(sub(p2, r.o), r.kz);
     float sx = r.sx, sy = r.sy, sz = r.sz;
     p0t.x += sx * p0t.z; p1t.x += sx * p1t.z; p2t.x += sx * p2t.z;
     p0t.y += sy * p0t.z; p1t.y += sy * p1t.z; p2t.y += sy * p2t.z;
@@ -345,6 +346,14 @@ PT_HD bool triangle_test(F3 p0, F3 p1, F3 p2, const TriRay& r, float t0, float t
     out->b0 = e0 * inv_det; out->b1 = e1 * inv_det; out->b2 = e2 * inv_det;
     out->t = t_scaled * inv_det;
     return true;
+}
+PT_HD bool triangle_test(F3 p0, F3 p1, F3 p2, const TriRay& r, float t0, float t1, TriHit* out) {
+    return triangle_test_core(tri_shuffle(sub(p0, r.o), r.kz), tri_shuffle(sub(p1, r.o), r.kz), tri_shuffle(sub(p2, r.o), r.kz), r, t0, t1, out);
+}
+// Vertices stored already permuted for the ray's dominant axis (the sweep table's triangles are kept in all three
+// permutations, pt_blob.h): permuting commutes with the subtraction, so the 18 selects per test go away — same bits.
+PT_HD bool triangle_test_permuted(F3 p0s, F3 p1s, F3 p2s, const TriRay& r, float t0, float t1, TriHit* out) {
+    return triangle_test_core(sub(p0s, r.os), sub(p1s, r.os), sub(p2s, r.os), r, t0, t1, out);
 }
 
 PT_HD F3 rect_shuffle(F3 v, uint32_t axis) {
@@ -673,11 +682,14 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
         st.hit &= st.hit - 1;
         PT_STAT_EVENT(triw != 0u ? 3 : 4);
         if (triw != 0u) {
-            const F4 q0 = mf4(s, triw), q1 = mf4(s, triw + 4), q2 = mf4(s, triw + 8);
             TriRay tr = wtr;
             if (kf & 0x200u) { F3 lo, ld; instance_local_ray(s, inst, o, d, &lo, &ld); tr = tri_ray_prepare(lo, ld); }
+            // the copy of the triangle whose vertices are permuted for this ray's dominant axis (kz = 2, 3: the original)
+            const F4 bp = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS + 4);
+            const uint32_t tp = triw + (tr.kz == 0u ? pt_f2u(bp.z) : (tr.kz == 1u ? pt_f2u(bp.w) : 0u));
+            const F4 q0 = mf4(s, tp), q1 = mf4(s, tp + 4), q2 = mf4(s, tp + 8);
             TriHit th;
-            if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
+            if (triangle_test_permuted(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
                 st.closest = th.t; st.best_inst = kf >> 16; st.best_triw = triw; st.bh = th;
                 if (stop == PT_STOP_ANY) st.hit = 0;
                 else if (stop == PT_STOP_NONLIGHT && st.closest < bound) {

@@ -218,6 +218,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
     // mesh data (BVH nodes, triangles, normals, leaf lists) goes into its own section behind the core blob; its offsets
     // are relative to the section (SceneView::m), so the core alone can be staged in LDS when the whole scene does not fit
     std::vector<uint32_t> md(4, 0u);
+    std::vector<uint32_t> mesh_perm0(d.mesh_count, 0), mesh_perm1(d.mesh_count, 0);
     std::vector<uint32_t> mesh_off(d.mesh_count), mesh_node_off(d.mesh_count), mesh_node_count(d.mesh_count);
     std::vector<Box> mesh_box(d.mesh_count);
     hs->mesh_has_light.assign(d.mesh_count, 0);
@@ -263,6 +264,20 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             for (uint32_t f = 0; f < m.face_count; ++f) {
                 const uint32_t* ix = d.indices + m.index_offset + 3 * (size_t)f;
                 for (int k = 0; k < 3; ++k) { const float* p = N + 3 * ix[k]; md.push_back(fbits(p[0])); md.push_back(fbits(p[1])); md.push_back(fbits(p[2])); md.push_back(0u); }
+            }
+        }
+        // permuted copies of the triangles of a mesh small enough to be taken into the sweep table (pt_blob.h)
+        if (m.face_count < PT_SWEEP_MAX_BITS) {
+            for (int variant = 0; variant < 2; ++variant) {
+                (variant == 0 ? mesh_perm0 : mesh_perm1)[mi] = (uint32_t)md.size() - tri_off;
+                for (uint32_t f = 0; f < m.face_count; ++f)
+                    for (int k = 0; k < 3; ++k) {
+                        const size_t at = tri_off + f * PT_TRI_WORDS + 4 * k;
+                        const uint32_t q[4] = {md[at], md[at + 1], md[at + 2], md[at + 3]};  // (copied: push_back reallocates)
+                        if (variant == 0) { md.push_back(q[1]); md.push_back(q[2]); md.push_back(q[0]); }   // (y, z, x)
+                        else { md.push_back(q[2]); md.push_back(q[0]); md.push_back(q[1]); }               // (z, x, y)
+                        md.push_back(q[3]);
+                    }
             }
         }
         // leaf list for mesh_sweep: the leaf boxes alone, in pre-order (a dense wave of rays inside a mesh of a few hundred
@@ -418,7 +433,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                         root_of.push_back(alias ? root_of[alias - 1] : (int)bit);
                         uint32_t triw = tri_base + mn[7] * PT_TRI_WORDS, flat = is_flat(mn) ? 1u : 0u;
                         uint32_t rec[PT_SWEEP_TRI_WORDS] = {mn[0], mn[1], mn[2], triw, mn[4], mn[5], mn[6], flat | (alias ? (uint32_t)root_of[alias - 1] + 1 : 0u) << 1};
-                        uint32_t tb[PT_SWEEP_BIT_WORDS] = {rec_off, triw, (uint32_t)w.size(), (kf & ~0x100u) | flat << 8 | inst << 16, 0u, 0u, 0u, 0u};
+                        uint32_t tb[PT_SWEEP_BIT_WORDS] = {rec_off, triw, (uint32_t)w.size(), (kf & ~0x100u) | flat << 8 | inst << 16, 0u, 0u, mesh_perm0[in.mesh], mesh_perm1[in.mesh]};
                         w.insert(w.end(), rec, rec + PT_SWEEP_TRI_WORDS);
                         bits.insert(bits.end(), tb, tb + PT_SWEEP_BIT_WORDS);
                         ++tri_count; ++bit;
