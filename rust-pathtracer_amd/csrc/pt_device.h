@@ -515,30 +515,33 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
         }
         if ((kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH && PT_WAVE_ANY(c != 0)) {
             const uint32_t tl = PT_UNIFORM(pt_f2u(a.w)), tc = PT_UNIFORM(pt_f2u(b.w));
-            RayPrep lr = wr; bool lquick = quick;
+            // the triangle leaves against the instance's ray: the world ray itself unless the instance is transformed (a branch
+            // on a wave-uniform flag, not a copy of the prepared ray: 20 registers moved per mesh instance otherwise)
+            auto leaves = [&](const RayPrep& lr, bool lquick) {
+                for (uint32_t t = 0; t < tc; ++t) {
+                    const F4 ta = bf4(s, tl + t * PT_SWEEP_TRI_WORDS), tb = bf4(s, tl + t * PT_SWEEP_TRI_WORDS + 4);
+                    const uint32_t tw = PT_UNIFORM(pt_f2u(tb.w)), tbit = bit + 1 + t, sh = tbit & 31u;
+                    uint32_t th, tu;  // this leaf's hit / undecided bit, in place
+                    if (tw >> 1) {
+                        // same box, same ray as an earlier bit: copy its decision (already gated by the instance's)
+                        const uint32_t sb = (tw >> 1) - 1u;
+                        th = (((sb < 32u ? hit_lo : hit_hi) >> (sb & 31u)) & 1u) << sh;
+                        tu = (((sb < 32u ? unc_lo : unc_hi) >> (sb & 31u)) & 1u) << sh;
+                    } else {
+                        int ct = lquick ? aabb_classify(ta, tb, lr, (tw & 1u) != 0u, &entry) : 2;
+                        if (bounded && ct == 1 && cull_mesh && beyond(entry, bound, lr.base)) ct = 0;
+                        if (c == 0) ct = 0;
+                        th = ct == 1 ? 1u << sh : 0u; tu = ct == 2 ? 1u << sh : 0u;
+                    }
+                    if (tbit < 32u) { hit_lo |= th; unc_lo |= tu; } else { hit_hi |= th; unc_hi |= tu; }
+                }
+            };
             if (kf & 0x200u) {
                 F3 lo, ld;
                 instance_local_ray(s, pt_f2u(h0.x), o, d, &lo, &ld);
-                lr = ray_prepare(lo, ld);
-                lquick = lr.fast && !exact && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f;
-            }
-            for (uint32_t t = 0; t < tc; ++t) {
-                const F4 ta = bf4(s, tl + t * PT_SWEEP_TRI_WORDS), tb = bf4(s, tl + t * PT_SWEEP_TRI_WORDS + 4);
-                const uint32_t tw = PT_UNIFORM(pt_f2u(tb.w)), tbit = bit + 1 + t, sh = tbit & 31u;
-                uint32_t th, tu;  // this leaf's hit / undecided bit, in place
-                if (tw >> 1) {
-                    // same box, same ray as an earlier bit: copy its decision (already gated by the instance's)
-                    const uint32_t sb = (tw >> 1) - 1u;
-                    th = (((sb < 32u ? hit_lo : hit_hi) >> (sb & 31u)) & 1u) << sh;
-                    tu = (((sb < 32u ? unc_lo : unc_hi) >> (sb & 31u)) & 1u) << sh;
-                } else {
-                    int ct = lquick ? aabb_classify(ta, tb, lr, (tw & 1u) != 0u, &entry) : 2;
-                    if (bounded && ct == 1 && cull_mesh && beyond(entry, bound, lr.base)) ct = 0;
-                    if (c == 0) ct = 0;
-                    th = ct == 1 ? 1u << sh : 0u; tu = ct == 2 ? 1u << sh : 0u;
-                }
-                if (tbit < 32u) { hit_lo |= th; unc_lo |= tu; } else { hit_hi |= th; unc_hi |= tu; }
-            }
+                const RayPrep lr = ray_prepare(lo, ld);
+                leaves(lr, lr.fast && !exact && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f);
+            } else leaves(wr, quick);
         }
     }
     uint64_t hit = (uint64_t)hit_lo | (uint64_t)hit_hi << 32, unc = (uint64_t)unc_lo | (uint64_t)unc_hi << 32;
@@ -682,14 +685,21 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
         st.hit &= st.hit - 1;
         PT_STAT_EVENT(triw != 0u ? 3 : 4);
         if (triw != 0u) {
-            TriRay tr = wtr;
-            if (kf & 0x200u) { F3 lo, ld; instance_local_ray(s, inst, o, d, &lo, &ld); tr = tri_ray_prepare(lo, ld); }
-            // the copy of the triangle whose vertices are permuted for this ray's dominant axis (kz = 2, 3: the original)
+            // the copy of the triangle whose vertices are permuted for this ray's dominant axis (kz = 2, 3: the original);
+            // the world ray's constants unless the instance is transformed (no copy of the 11-register TriRay)
             const F4 bp = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS + 4);
-            const uint32_t tp = triw + (tr.kz == 0u ? pt_f2u(bp.z) : (tr.kz == 1u ? pt_f2u(bp.w) : 0u));
-            const F4 q0 = mf4(s, tp), q1 = mf4(s, tp + 4), q2 = mf4(s, tp + 8);
             TriHit th;
-            if (triangle_test_permuted(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
+            F4 q0;
+            auto test = [&](const TriRay& tr) {
+                const uint32_t tp = triw + (tr.kz == 0u ? pt_f2u(bp.z) : (tr.kz == 1u ? pt_f2u(bp.w) : 0u));
+                q0 = mf4(s, tp);
+                const F4 q1 = mf4(s, tp + 4), q2 = mf4(s, tp + 8);
+                return triangle_test_permuted(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th);
+            };
+            bool accepted;
+            if (kf & 0x200u) { F3 lo, ld; instance_local_ray(s, inst, o, d, &lo, &ld); const TriRay ltr = tri_ray_prepare(lo, ld); accepted = test(ltr); }
+            else accepted = test(wtr);
+            if (accepted) {
                 st.closest = th.t; st.best_inst = kf >> 16; st.best_triw = triw; st.bh = th;
                 if (stop == PT_STOP_ANY) st.hit = 0;
                 else if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
