@@ -70,10 +70,11 @@ def main():
     rank, local_rank, world = sharding.rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % max(1, torch.cuda.device_count())  # (a launcher that exposes one GPU per process shows it as device 0)
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
     n_gpus = world
 
     engine = pkg.load()
