@@ -382,7 +382,8 @@ PT_HD bool analytic_hit(const SceneView& s, uint32_t inst, uint32_t kind, F3 o, 
         F3 n = axis_vec(axis);
         if (two_sided && dot(d, n) > 0.0f) n = neg(n);
         out->t = t; out->p = add(o, mul(d, t)); out->u = (xh + hx) / s0; out->v = (yh + hy) / s1;
-        out->n = normalize(n); out->material = mat0; out->valid = true;
+        // HitRecord::new normalizes the normal (hittable.rs:30-39); n is +-e_axis: norm = sqrt(1) = 1 and x / 1 = x, bit for bit
+        out->n = n; out->material = mat0; out->valid = true;
         return true;
     }
     if (kind == PT_SHAPE_SPHERE) {
@@ -413,7 +414,7 @@ PT_HD bool analytic_hit(const SceneView& s, uint32_t inst, uint32_t kind, F3 o, 
     F3 n = f3(0, 0, 1);
     if (dot(d, n) > 0.0f && two_sided) n = neg(n);
     out->t = t; out->p = add(o, mul(d, t)); out->u = 0.0f; out->v = 0.0f;
-    out->n = normalize(n); out->material = mat0; out->valid = true;
+    out->n = n; out->material = mat0; out->valid = true;  // (0, 0, +-1): normalizing it changes no bit
     return true;
 }
 
