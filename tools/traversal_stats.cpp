@@ -13,6 +13,7 @@ static inline void pt_event(int code) {
     if (code == 0) { g_rays.emplace_back(); return; }
     auto& r = g_rays.back();
     if (code == 1) { r.push_back(Round{0, 0}); return; }
+    if (r.empty()) r.push_back(Round{0, 0});  // the sweep form has no walk rounds
     if (code == 2) { r.back().steps++; return; }
     r.back().leaf = code;
 }
@@ -46,4 +47,7 @@ extern "C" void ptemu_wave_stats(double* out) {
     double lanes = waves * 64;
     out[0] = (double)n; out[1] = steps / lanes; out[2] = rounds / lanes; out[3] = w_steps / waves; out[4] = w_rounds / waves; out[5] = w_tri / waves; out[6] = w_inst / waves;
     g_rays.clear(); g_stats = Stats{};
+}
+extern "C" void ptemu_counter_stats(unsigned long long* out) {
+    out[0] = g_stats.box_tests; out[1] = g_stats.box_exact; out[2] = g_stats.tri_tests; out[3] = g_stats.instance_tests; out[4] = (unsigned long long)g_rays.size();
 }
