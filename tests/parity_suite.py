@@ -34,7 +34,13 @@ def assert_hits_equal(a, b):
 
 
 def check_film(film, ref, prof=None, ref_prof=None):
-    assert np.isfinite(film).all() == np.isfinite(ref).all()
+    # a non-finite pixel is a result like any other (the reference lets a 0/0 of its NEE weights through to the film, where the
+    # tonemapper paints it mauve): it must sit in the same place on both sides; the bars apply to the finite pixels
+    bad = ~np.isfinite(ref)
+    assert np.array_equal(~np.isfinite(film), bad)
+    assert bad.mean() < 1e-2
+    if bad.any():
+        film, ref = np.where(bad, 0.0, film).astype(np.float32), np.where(bad, 0.0, ref).astype(np.float32)
     m = film_metrics(film, ref)
     assert m["linf"] < FILM_LINF, m
     assert m["relative"] < FILM_REL, m

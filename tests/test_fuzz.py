@@ -31,7 +31,7 @@ def test_emulation_bvh_walk_on_random_scenes(emu, oracle, pkg, monkeypatch, seed
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(100, 140))
+@pytest.mark.parametrize("seed", list(range(100, 140)) + [5427])  # 5427: a NaN pixel (NEE from a point of a light to that light), same on both sides
 def test_engine_on_random_scenes(engine, oracle, pkg, seed):
     run(engine, oracle, pkg, seed, 1 << 14, 48, 40, 4)
 

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Differential soak on the GPU: engine vs oracle over many seeded random scenes (tests/fuzz_scenes.py), hits bit for bit and
+films within the parity bars.  usage: tools/fuzz_soak.py <first seed> <count>"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fuzz_scenes  # noqa: E402
+import oracle_loader  # noqa: E402
+import parity_suite as ps  # noqa: E402
+
+pkg = importlib.import_module("rust-pathtracer_amd")
+engine, oracle = pkg.load(), oracle_loader.load(pkg)
+first, count = int(sys.argv[1]), int(sys.argv[2])
+bad, forms = [], {"sweep": 0, "walked": 0, "walk": 0}
+for seed in range(first, first + count):
+    try:
+        b = fuzz_scenes.random_scene(seed)
+        o, d = fuzz_scenes.random_rays(seed, 1 << 13)
+        se, so = engine.create_scene(b), oracle.create_scene(b)
+        forms["sweep" if se.uses_leaf_sweep() else "walk"] += 1
+        ps.assert_hits_equal(se.intersect(o, d), so.intersect(o, d))
+        rd = pkg.api.render_desc(40, 32, 3, 6, light_samples=int(1 + seed % 3), seed=seed, hero_wavelengths=4 if seed % 5 == 0 else 1)
+        film, prof = se.render(rd)
+        ref, rprof = so.render(rd)
+        ps.check_film(film, ref, prof, rprof)
+    except Exception as e:  # noqa: BLE001
+        bad.append((seed, repr(e)[:300]))
+print("seeds", first, "..", first + count - 1, forms, "failures:", len(bad), bad[:5])
+sys.exit(1 if bad else 0)
