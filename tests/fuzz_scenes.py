@@ -69,6 +69,13 @@ def random_scene(seed):
             b.add_mesh_instance(mesh, material(light_ok=False) if rng.random() < 0.5 else None, transform())
     if n_light == 0:
         b.add_rect((1.0, 1.0), (0.0, 0.0, 2.0), "Z", True, lights[0])
+    if rng.random() < 0.12:  # more than 64 instances: no sweep table, the two-level BVH walk is the default form
+        for _ in range(70):
+            o3 = rng.uniform(-2.5, 2.5, 3).tolist()
+            if rng.random() < 0.7:
+                b.add_sphere(float(rng.uniform(0.05, 0.25)), o3, material(light_ok=False), transform() if rng.random() < 0.2 else None)
+            else:
+                b.add_rect(tuple(rng.uniform(0.1, 0.5, 2).tolist()), o3, "XYZ"[rng.integers(3)], True, material(light_ok=False))
     if rng.random() < 0.3:  # a bigger mesh: the sweep table can no longer inline every triangle (walked mesh, parked rays)
         p, f, n, _ = S._npz_mesh("gem")
         mesh = b.add_mesh(p, f, n, face_materials=api.material_id(api.TAG_MATERIAL, mats[0] & 0xFFFF))
