@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(kBlock) k_probe_intersect(const uint32_t* __re
 __global__ void __launch_bounds__(kBlock) k_probe_material(const uint32_t* __restrict__ blob, const float* __restrict__ tex, int mode, uint32_t record, uint32_t n,
                                                           const float* __restrict__ lambda, const float* __restrict__ a, const float* __restrict__ b,
                                                           float* __restrict__ f, float* __restrict__ wo, float* __restrict__ pdf) {
-    SceneView s; s.w = blob; s.tex = tex;
+    SceneView s; s.w = blob; s.tex = tex; s.m = blob + blob[PT_HDR_CORE_WORDS];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (mode == 0) {
             F3 w; material_sample(s, record, lambda[i], 0.5f, 0.5f, b[2 * i], b[2 * i + 1], f3(a[3 * i], a[3 * i + 1], a[3 * i + 2]), &f[i], &w, &pdf[i]);
