@@ -398,3 +398,33 @@ def test_panorama_camera_directions(pkg, oracle):
     b.cameras.clear(); b.add_panorama_camera((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (10.0, 10.0), v_up=(1.0, 0.0, 0.0))
     film, _ = oracle.create_scene(b).render(pkg.api.render_desc(8, 8, 2, 2, light_samples=0))
     assert (film[..., :3] == 0).all()
+
+
+def test_reference_instance_case(pkg, oracle):
+    """src/geometry/instance.rs test_instance (prints only in the reference): a sphere of radius 2 and a 4x4 Z rect, each
+    under from_stack(scale 3, Rx(1 rad) * Ry(1 rad), no translation), hit by the ray (0, 0, 10) -> -Z.  Expected values from
+    first principles: the scaled sphere has radius 6 (t = 4, normal +Z); the rect's plane passes through the origin (t = 10)
+    with normal +-(Rx Ry) e_z."""
+    S = pkg.scene
+    deg = 180.0 / np.pi
+    tr = S.transform_from_data(scale=(3.0, 3.0, 3.0), rotate=[((0.0, 1.0, 0.0), deg), ((1.0, 0.0, 0.0), deg)])   # list order: Ry first, then Rx
+    rx = np.array([[1, 0, 0], [0, np.cos(1), -np.sin(1)], [0, np.sin(1), np.cos(1)]])
+    ry = np.array([[np.cos(1), 0, np.sin(1)], [0, 1, 0], [-np.sin(1), 0, np.cos(1)]])
+    assert np.allclose(tr[:3, :3], (rx @ ry) * 3.0, atol=1e-6)
+    o = np.array([[0.0, 0.0, 10.0]], np.float32); d = np.array([[0.0, 0.0, -1.0]], np.float32)
+    for shape in ("sphere", "rect"):
+        b = S.SceneBuilder()
+        white = S.add_library_material(b, "lambertian_white")
+        if shape == "sphere":
+            b.add_sphere(2.0, (0.0, 0.0, 0.0), white, tr)
+        else:
+            b.add_rect((4.0, 4.0), (0.0, 0.0, 0.0), "Z", True, white, tr)
+        b.add_camera((0, 0, 10), (0, 0, 0), 30.0)
+        h = oracle.create_scene(b).intersect(o, d)[0]
+        assert h["valid"] == 1
+        if shape == "sphere":
+            assert abs(h["t"] - 4.0) < 1e-4 and np.allclose(h["point"], [0, 0, 6], atol=1e-4) and np.allclose(h["normal"], [0, 0, 1], atol=1e-5)
+        else:
+            n = (rx @ ry) @ np.array([0.0, 0.0, 1.0])
+            assert abs(h["t"] - 10.0) < 1e-4 and np.allclose(h["point"], [0, 0, 0], atol=1e-4)
+            assert np.allclose(np.abs(np.dot(h["normal"], n)), 1.0, atol=1e-5) and np.dot(h["normal"], [0, 0, 1]) > 0   # two-sided: faces the ray
