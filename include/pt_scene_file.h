@@ -87,6 +87,13 @@ int32_t pt_scene_file_camera(const pt_scene_file* scene, const char* camera_id);
 uint32_t pt_scene_file_warning_count(const pt_scene_file* scene);
 const char* pt_scene_file_warning(const pt_scene_file* scene, uint32_t index);
 
+/* The image readers of the texture parser (src/parsing/texture.rs:48-153), for tools: PT_IMAGE_GREY8 = parse_bitmap
+ * (1 channel), PT_IMAGE_RGBA8 = parse_rgba, PT_IMAGE_HDR = parse_hdr (alpha = alpha_fill), PT_IMAGE_EXR = parse_exr (4 channels
+ * each).  `*data` is width * height * channels floats, row-major, top row first; release it with pt_image_free. */
+enum { PT_IMAGE_GREY8 = 0, PT_IMAGE_RGBA8 = 1, PT_IMAGE_HDR = 2, PT_IMAGE_EXR = 3 };
+pt_status pt_image_read(const char* path, int32_t kind, float alpha_fill, uint32_t* width, uint32_t* height, uint32_t* channels, float** data);
+void pt_image_free(float* data);
+
 #ifdef __cplusplus
 }
 #endif

@@ -848,4 +848,19 @@ int32_t pt_scene_file_camera(const pt_scene_file* s, const char* name) { auto it
 uint32_t pt_scene_file_warning_count(const pt_scene_file* s) { return s ? (uint32_t)s->warnings.size() : 0; }
 const char* pt_scene_file_warning(const pt_scene_file* s, uint32_t i) { return (s && i < s->warnings.size()) ? s->warnings[i].c_str() : nullptr; }
 
+pt_status pt_image_read(const char* path, int32_t kind, float alpha_fill, uint32_t* width, uint32_t* height, uint32_t* channels, float** data) {
+    if (!path || !width || !height || !channels || !data) { g_error = "null argument"; return PT_ERR_INVALID_ARGUMENT; }
+    pth::Image img; std::string err;
+    const std::string p = resolve_path(path);
+    bool ok = kind == PT_IMAGE_GREY8 ? pth::read_grey8(p, &img, &err) : kind == PT_IMAGE_RGBA8 ? pth::read_rgba8(p, &img, &err)
+            : kind == PT_IMAGE_HDR ? pth::read_hdr(p, alpha_fill, &img, &err) : kind == PT_IMAGE_EXR ? pth::read_exr(p, &img, &err) : false;
+    if (!ok) { g_error = err.empty() ? "unknown image kind" : err; return PT_ERR_INVALID_ARGUMENT; }
+    float* out = (float*)malloc(sizeof(float) * (img.data.size() ? img.data.size() : 1));
+    if (!out) { g_error = "out of memory"; return PT_ERR_OUT_OF_MEMORY; }
+    memcpy(out, img.data.data(), sizeof(float) * img.data.size());
+    *width = img.width; *height = img.height; *channels = img.channels; *data = out;
+    return PT_OK;
+}
+void pt_image_free(float* data) { free(data); }
+
 }  // extern "C"

@@ -57,6 +57,8 @@ def library():
             getattr(L, "pt_scene_file_" + n).restype = C.c_int32; getattr(L, "pt_scene_file_" + n).argtypes = [vp, C.c_char_p]
         L.pt_scene_file_warning_count.restype = C.c_uint32; L.pt_scene_file_warning_count.argtypes = [vp]
         L.pt_scene_file_warning.restype = C.c_char_p; L.pt_scene_file_warning.argtypes = [vp, C.c_uint32]
+        L.pt_image_read.argtypes = [C.c_char_p, C.c_int32, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_float))]
+        L.pt_image_free.argtypes = [C.POINTER(C.c_float)]
         L.pt_scene_file_set_root(DATA_ROOT.encode())
         _lib = L
     return _lib
@@ -65,6 +67,22 @@ def library():
 def _check(status):
     if status != api.PT_OK:
         raise SceneFileError(status, library().pt_scene_file_last_error().decode())
+
+
+IMAGE_GREY8, IMAGE_RGBA8, IMAGE_HDR, IMAGE_EXR = range(4)
+
+
+def read_image(path, kind, alpha_fill=0.0):
+    """The texture parser's image readers (src/parsing/texture.rs:48-153): float32 [H, W] or [H, W, 4]."""
+    import numpy as np
+    w, h, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    data = C.POINTER(C.c_float)()
+    _check(library().pt_image_read(os.fsencode(path), kind, alpha_fill, C.byref(w), C.byref(h), C.byref(c), C.byref(data)))
+    try:
+        a = np.ctypeslib.as_array(data, shape=(h.value * w.value * c.value,)).copy()
+    finally:
+        library().pt_image_free(data)
+    return a.reshape((h.value, w.value) if c.value == 1 else (h.value, w.value, c.value))
 
 
 class Config:

@@ -344,6 +344,44 @@ def test_image_readers(sfmod, tmp_path):
         assert np.array_equal(got.reshape(expect.shape), expect.astype(np.float32)), name
 
 
+def test_image_reader_entry_point(sfmod, pkg):
+    """pt_image_read: the committed 1x1 PNG and the synthetic EXR environment, and an error for a missing file."""
+    assert np.array_equal(sfmod.read_image(data(sfmod, "textures", "single_pixel.png"), sfmod.IMAGE_GREY8), np.ones((1, 1), np.float32))
+    assert np.array_equal(sfmod.read_image(data(sfmod, "textures", "single_pixel.png"), sfmod.IMAGE_RGBA8), np.ones((1, 1, 4), np.float32))
+    exr = sfmod.read_image(data(sfmod, "hdri", "synthetic_64x32.exr"), sfmod.IMAGE_EXR)
+    assert np.array_equal(exr.view(np.uint32), pkg.scene.synthetic_hdri(64, 32).view(np.uint32))
+    with pytest.raises(sfmod.SceneFileError, match="could not find file"):
+        sfmod.read_image(data(sfmod, "textures", "missing.png"), sfmod.IMAGE_RGBA8)
+
+
+@pytest.mark.gpu
+def test_compare_tool_on_rendered_files(sfmod, pkg, engine, tmp_path):
+    """ptcompare (src/bin/compare_exr.rs) on two EXR files written by ptcli: its statistics are those of pt_compare_films on
+    the images read back, the RMSE mode writes the viridis PNG."""
+    import subprocess
+    exe_dir = os.path.dirname(pkg.LIBRARY_PATH)
+    outs = []
+    for seed in ("3", "4"):
+        out = tmp_path / ("out" + seed)
+        r = subprocess.run([os.path.join(exe_dir, "ptcli"), "--root", pkg.PACKAGE_DIR, "--config", "data/config_two_passes.toml", "--output-dir", str(out), "--seed", seed],
+                           capture_output=True, text=True, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr
+        outs.append(str(out / "beauty.exr"))
+    r = subprocess.run([os.path.join(exe_dir, "ptcompare"), "--compare-file", outs[0], "--ground-truth-file", outs[1], "--output-file", str(tmp_path / "diff.exr")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "saved, exiting" in r.stdout, r.stderr + r.stdout
+    a, b = sfmod.read_image(outs[0], sfmod.IMAGE_EXR), sfmod.read_image(outs[1], sfmod.IMAGE_EXR)
+    diff = sfmod.read_image(str(tmp_path / "diff.exr"), sfmod.IMAGE_EXR)
+    assert np.array_equal(diff[..., :3], np.abs(a - b)[..., :3]) and diff[..., :3].max() > 0
+    _, st = engine.compare_films(a, b, pkg.api.COMPARE_ABSOLUTE, want_image=False)
+    assert ("rmse %g" % st.rmse) in r.stdout
+    r = subprocess.run([os.path.join(exe_dir, "ptcompare"), "--compare-file", outs[0], "--ground-truth-file", outs[1], "--output-file", str(tmp_path / "heat"), "--mode", "rmse"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("minmax: ") and (tmp_path / "heat.png").read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
+    r = subprocess.run([os.path.join(exe_dir, "ptcompare"), "--compare-file", outs[0], "--ground-truth-file", str(tmp_path / "nope.exr"), "--output-file", "x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "failed to parse images" in r.stdout
+
+
 @pytest.mark.gpu
 def test_command_line_render_matches_the_library(sfmod, pkg, engine, tmp_path):
     """ptcli end to end on the GPU: config + scene TOML -> film, EXR, PNG; the raw film equals the one rendered through
