@@ -154,15 +154,18 @@ def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
 
 
 def test_full_size_cornell_properties(engine, oracle, pkg):
-    """BASELINE.json C2 geometry (1024x1024, max_bounces 8, L = 2) at 2 spp: too big for the oracle film in seconds,
-    so check size-independent properties: shards partition the film exactly, counters add up, the film is finite and
-    non-negative, and a 64x64 box-downsample agrees statistically with the oracle's 64x64 render."""
+    """BASELINE.json C2 geometry (1024x1024, max_bounces 8, L = 2) at 2 spp (2 M paths: seconds for the threaded oracle on
+    the GPU box's host): the north-star bar directly — film within 1e-4 L-inf of the oracle at matched seeds, ray counters
+    equal — plus size-independent properties: shards partition the film exactly, counters add up, the film is finite and
+    non-negative, and a 64x64 box-downsample agrees statistically with an independent 64x64 oracle render."""
     b = pkg.scene.cornell_box()
     sc = engine.create_scene(b)
     rd = pkg.api.render_desc(1024, 1024, 2, 8)
     whole, pw = sc.render(rd)
     assert np.isfinite(whole).all() and whole.min() >= 0 and (whole[..., 3] == 0).all()
     assert pw.camera_rays == 1024 * 1024 * 2
+    full_ref, pref = oracle.create_scene(b).render(rd)
+    ps.check_film(whole, full_ref, pw, pref)
     acc = np.zeros_like(whole); rays = 0
     for k in range(4):
         part, pp = sc.render(pkg.api.render_desc(1024, 1024, 2, 8, shard=(k, 4)))
@@ -172,6 +175,18 @@ def test_full_size_cornell_properties(engine, oracle, pkg):
     down = whole[..., 1].reshape(64, 16, 64, 16).mean(axis=(1, 3))
     rel = abs(down.mean() - ref[..., 1].mean()) / ref[..., 1].mean()
     assert rel < 0.05, rel
+
+
+@pytest.mark.parametrize("scene,w,h,mb,kw", [
+    ("cornell_box", 1024, 1024, 8, {"spp": 10}),                      # C2, one whole 10-sample phase
+    ("cornell_gem", 1920, 1080, 12, {}),                              # C3
+    ("hdri_test", 1024, 1024, 4, {"light_samples": 6}),               # C4
+    ("cornell_box", 1024, 1024, 8, {"hero_wavelengths": 4}),          # C5
+])
+def test_full_size_baseline_configs(engine, oracle, scene, w, h, mb, kw):
+    """The other BASELINE.json configurations at their full film size, 1 spp (C2: 10), against the oracle at matched seeds."""
+    kw = dict(kw)
+    ps.render_parity(engine, oracle, scene, w, h, kw.pop("spp", 1), mb, **kw)
 
 
 def test_error_behaviour(engine, pkg):
