@@ -103,3 +103,19 @@ def test_leaf_sweep_equals_bvh_walk(emu, pkg, monkeypatch, scene):
         ps.assert_hits_equal(hits, results[0][0])
         assert np.array_equal(film.view(np.uint32), results[0][1].view(np.uint32))
         assert counts == results[0][2]
+
+
+def test_reference_known_answers_on_the_lane_logic(emu, oracle, pkg):
+    """The reference's own known-answer tests for the path, which tests/test_oracle.py runs on the oracle, on the
+    engine's lane logic; tests/test_gpu_parity.py runs the same list on the GPU."""
+    import test_oracle as kat
+    kat.check_ggx_properties(pkg, emu)
+    kat.test_ggx_sample_matches_eval(pkg, emu)
+    kat.test_sharp_light_pdf_integrates_to_one(pkg, emu)
+    kat.test_lambertian_and_light(pkg, emu)
+    kat.test_curves(pkg, emu)
+    kat.test_world_intersection(pkg, emu)
+    kat.test_intersection_against_brute_force(pkg, emu)
+    kat.test_reference_instance_case(pkg, emu)
+    kat.test_panorama_camera_directions(pkg, emu)
+    kat.test_white_furnace(pkg, emu, cmf=oracle)

@@ -91,6 +91,25 @@ def test_golden_vectors(engine):
         ps.golden_materials(engine, scene)
 
 
+def test_reference_known_answers_on_the_engine(engine, oracle, pkg):
+    """the known-answer tests the reference's own test modules hold for this path (GGX properties, regression
+    seed and fixed pairs of ggx.rs:637-926; the cos^n normalisation of sharp_light.rs:229; the world ray of world/mod.rs:282;
+    the instance case of instance.rs; the white furnace scene) replayed on the HIP engine — the same checks tests/test_oracle.py
+    runs on the oracle, here through the C ABI of the product."""
+    import test_oracle as kat
+    kat.check_ggx_properties(pkg, engine)
+    kat.test_ggx_sample_matches_eval(pkg, engine)
+    kat.test_sharp_light_pdf_integrates_to_one(pkg, engine)
+    kat.test_lambertian_and_light(pkg, engine)
+    kat.test_curves(pkg, engine)
+    kat.test_world_intersection(pkg, engine)
+    kat.test_intersection_against_brute_force(pkg, engine)
+    kat.test_reference_instance_case(pkg, engine)
+    kat.test_panorama_camera_directions(pkg, engine)
+    kat.test_hero_wavelengths_follow_the_single_wavelength_path(pkg, engine)
+    kat.test_white_furnace(pkg, engine, cmf=oracle)
+
+
 def test_shards_and_sample_ranges(engine):
     ps.shards_and_ranges(engine)
 

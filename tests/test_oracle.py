@@ -95,6 +95,7 @@ def test_curves(pkg, oracle):
     bb = b.curve_blackbody("bb", 5000.0, 2.0)
     spike = b.curve_simple_spike("s", 500.0, 100.0, 50.0, 0.55)
     lin = b.curve_linear("l", 390.0, 10.0, [1.0, 2.0, 4.0], mode=pkg.api.INTERP_LINEAR)
+    b.set_environment_constant(flat, 0.0)
     b.add_camera((0, 0, 0), (1, 0, 0), 40.0)
     sc = oracle.create_scene(b)
     lam = np.array([380, 400, 450, 500, 600, 650, 700, 750], np.float32)
@@ -122,6 +123,7 @@ def _ggx_glass_scene(pkg, roughnesses):
     one = b.curve_flat("one", 1.0)
     zero = b.curve_flat("zero", 0.0)
     ids = [pkg.api.MATERIAL_NONE and (b.material_ggx("g%d" % i, float(r), glass, one, zero) & 0xFFFF) for i, r in enumerate(roughnesses)]
+    b.set_environment_constant(zero, 0.0)
     b.add_camera((0, 0, 0), (1, 0, 0), 40.0)
     return b, ids
 
@@ -208,6 +210,7 @@ def test_sharp_light_pdf_integrates_to_one(pkg, oracle):
     b = pkg.scene.SceneBuilder()
     one = b.curve_flat("one", 1.0)
     zero = b.curve_flat("zero", 0.0)
+    b.set_environment_constant(zero, 0.0)
     for sharp in (0.0, 1.5, 40.0, 400.0):
         mid = b.material_sharp_light("s%g" % sharp, one, zero, sharp, pkg.api.SIDED_DUAL) & 0xFFFF
         b.add_camera((0, 0, 0), (1, 0, 0), 40.0)
@@ -340,7 +343,7 @@ def test_sample_ranges_compose(pkg, oracle):
     assert np.array_equal((a + b) / np.float32(20), whole)
 
 
-def test_white_furnace(pkg, oracle):
+def test_white_furnace(pkg, oracle, cmf=None):
     """data/scenes/white_furnace.toml + config_test_whitefurnace.toml: camera inside a non-absorbing rough glass
     sphere in a constant environment -> the film is spatially uniform (up to MC noise)."""
     b = pkg.scene.white_furnace("ggx_glass_rough")
@@ -357,7 +360,7 @@ def test_white_furnace(pkg, oracle):
     xyz = np.zeros((lam.size, 3), np.float32)
     out = (C.c_float * 3)()
     for i, l in enumerate(lam):
-        oracle.lib.ptref_xyz_bar(float(l), out); xyz[i] = out[:]
+        (cmf or oracle).lib.ptref_xyz_bar(float(l), out); xyz[i] = out[:]
     level = (env * xyz[:, 1]).mean()
     ratio = y.mean() / level
     assert 0.5 < ratio < 3.0, ratio
@@ -415,6 +418,8 @@ def test_reference_instance_case(pkg, oracle):
     for shape in ("sphere", "rect"):
         b = S.SceneBuilder()
         white = S.add_library_material(b, "lambertian_white")
+        S.add_library_curves(b, ["flat_zero"])
+        b.set_environment_constant(b.curve("flat_zero"), 0.0)
         if shape == "sphere":
             b.add_sphere(2.0, (0.0, 0.0, 0.0), white, tr)
         else:
