@@ -165,24 +165,33 @@ PT_HD float curve_eval(const SceneView& s, uint32_t c, float lambda) {
     }
 }
 
-// TexStack::eval_at (src/texture.rs:258-265), nearest texel (src/vec2d.rs:34-42)
+// TexStack::eval_at (src/texture.rs:258-265), nearest texel (src/vec2d.rs:34-42).  A layer's curves depend on the wavelength only:
+// LayerCurves holds their values so that a caller evaluating one stack at many (u, v) of one wavelength evaluates them once.
+struct LayerCurves { float c0, c1, c2, c3; };
+PT_HD LayerCurves layer_curves(const SceneView& s, uint32_t l, float lambda) {
+    LayerCurves c;
+    c.c0 = curve_eval(s, bu(s, l + 1), lambda);
+    c.c1 = c.c2 = c.c3 = 0.0f;
+    if (bu(s, l) != PT_TEXTURE1) { c.c1 = curve_eval(s, bu(s, l + 2), lambda); c.c2 = curve_eval(s, bu(s, l + 3), lambda); c.c3 = curve_eval(s, bu(s, l + 4), lambda); }
+    return c;
+}
+PT_HD float layer_eval(const SceneView& s, uint32_t l, const LayerCurves& c, float u, float v) {
+    uint32_t kind = bu(s, l), w = bu(s, l + 5), h = bu(s, l + 6), toff = bu(s, l + 7);
+    float cu = pt_clamp(u, 0.0f, 1.0f - PT_F32_EPSILON), cv = pt_clamp(v, 0.0f, 1.0f - PT_F32_EPSILON);
+    uint32_t x = (uint32_t)(cu * (float)w), y = (uint32_t)(cv * (float)h);
+    uint32_t idx = y * w + x;
+    if (kind == PT_TEXTURE1) return c.c0 * s.tex[toff + idx];
+    const float* t = s.tex + toff + 4u * idx;
+    float e0 = c.c0 * t[0], e1 = c.c1 * t[1];
+    float e2 = c.c2 * t[2], e3 = c.c3 * t[3];
+    return (e0 + e1) + (e2 + e3);
+}
 PT_HD float texstack_eval(const SceneView& s, uint32_t ts, float lambda, float u, float v) {
     uint32_t layers = bu(s, ts);
     float energy = 0.0f;
     for (uint32_t i = 0; i < layers; ++i) {
         uint32_t l = ts + 1 + i * PT_LAYER_WORDS;
-        uint32_t kind = bu(s, l), w = bu(s, l + 5), h = bu(s, l + 6), toff = bu(s, l + 7);
-        float cu = pt_clamp(u, 0.0f, 1.0f - PT_F32_EPSILON), cv = pt_clamp(v, 0.0f, 1.0f - PT_F32_EPSILON);
-        uint32_t x = (uint32_t)(cu * (float)w), y = (uint32_t)(cv * (float)h);
-        uint32_t idx = y * w + x;
-        if (kind == PT_TEXTURE1) {
-            energy += curve_eval(s, bu(s, l + 1), lambda) * s.tex[toff + idx];
-        } else {
-            const float* t = s.tex + toff + 4u * idx;
-            float e0 = curve_eval(s, bu(s, l + 1), lambda) * t[0], e1 = curve_eval(s, bu(s, l + 2), lambda) * t[1];
-            float e2 = curve_eval(s, bu(s, l + 3), lambda) * t[2], e3 = curve_eval(s, bu(s, l + 4), lambda) * t[3];
-            energy += (e0 + e1) + (e2 + e3);
-        }
+        energy += layer_eval(s, l, layer_curves(s, l, lambda), u, v);
     }
     return energy;
 }
@@ -1241,6 +1250,23 @@ PT_HD float env_emission(const SceneView& s, float u, float v, float lambda) {
     F3 nd = xf_vec(s, PT_HDR_ENV_REVERSE, uv_to_direction(u, v));
     float u2, v2; direction_to_uv(nd, &u2, &v2);
     return texstack_eval(s, bu(s, PT_HDR_ENV_TEXSTACK), lambda, u2, v2) * strength;
+}
+// The same for the light samples of one vertex: an HDR environment of one layer (every HDRI of the reference's scene files)
+// evaluates its curves once per vertex and wavelength instead of once per light sample.
+struct EnvCurves { LayerCurves c; bool cached; };
+PT_HD EnvCurves env_curves(const SceneView& s, float lambda) {
+    EnvCurves e; e.cached = false; e.c.c0 = e.c.c1 = e.c.c2 = e.c.c3 = 0.0f;
+    if (bu(s, PT_HDR_ENV_KIND) != PT_ENV_HDR) return e;
+    const uint32_t ts = bu(s, PT_HDR_ENV_TEXSTACK);
+    if (bu(s, ts) != 1u) return e;
+    e.c = layer_curves(s, ts + 1, lambda); e.cached = true;
+    return e;
+}
+PT_HD float env_emission(const SceneView& s, float u, float v, float lambda, const EnvCurves& ec) {
+    if (!ec.cached) return env_emission(s, u, v, lambda);
+    F3 nd = xf_vec(s, PT_HDR_ENV_REVERSE, uv_to_direction(u, v));
+    float u2, v2; direction_to_uv(nd, &u2, &v2);
+    return (0.0f + layer_eval(s, bu(s, PT_HDR_ENV_TEXSTACK) + 1, ec.c, u2, v2)) * bf(s, PT_HDR_ENV_STRENGTH);
 }
 PT_HD float env_pdf_for(const SceneView& s, float u, float v) {
     uint32_t kind = bu(s, PT_HDR_ENV_KIND);

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_extend(const uint32_t* _
     }
 }
 
-template <int USE_LDS, int NL>
+template <int USE_LDS, int NL, bool ENV>
 __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                  RenderParams rp, uint32_t bounce, const uint32_t* __restrict__ pixels,
                                                  Queue paths_in, Queue hits, Queue paths_out, Queue shadow, float* __restrict__ energy,
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
         out.survives = false; out.has_item = false; out.vertex_pushed = false; out.env_hit = false; out.shadow_count = 0; out.add_energy = false; out.env_mask = 0;
         if (active) {
             uint32_t pixel = pixels[pv.slot % rp.chunk_pixels];
-            out = stage_shade<NL>(s, rp, bounce, pv, hit, pixel, [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(shadow, ipos, l, ray); });
+            out = stage_shade<NL, ENV>(s, rp, bounce, pv, hit, pixel, [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(shadow, ipos, l, ray); });
             if (wants_item) {
                 float lam[NL]; lam[0] = pv.lambda;
                 if (NL > 1) hero_lambdas<NL>(rp, pt_draw4(rp.seed, pixel, rp.first_sample + pv.slot / rp.chunk_pixels, PT_DIM_FILM).z, lam);
@@ -563,6 +563,9 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     // the sweep table holds walked meshes: rays that reach one are parked and resumed in full waves (PT_AMD_NO_PARK=1: in line)
     const bool walks = (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) != 0;
     const bool parked = sweep && walks && b.park != nullptr && !env_u32("PT_AMD_NO_PARK", 0);
+    // light samples can pick the environment only if env_sampling_probability > 0: otherwise k_shade is the form without that branch
+    float env_prob; std::memcpy(&env_prob, &sc->host.blob[PT_HDR_ENV_PROB], sizeof env_prob);
+    const bool env_samples = env_prob != 0.0f || env_u32("PT_AMD_ENV_BRANCH", 0);
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
     const bool timing = env_u32("PT_AMD_STAGE_TIMING", 1) != 0;
     double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0};
@@ -621,9 +624,12 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
                 else launch(k_extend<PT_LDS_ALL, PT_TRAV_WALK>, lds_bytes, grid, stream, PT_ARGS_EXTEND);
             });
             timed(ST_SHADE, [&] {
-#define K_SHADE1(M) k_shade<M, 1>
-#define K_SHADE4(M) k_shade<M, 4>
-                if (hero) PT_BY_MODE(K_SHADE4, PT_ARGS_SHADE); else PT_BY_MODE(K_SHADE1, PT_ARGS_SHADE);
+#define K_SHADE1(M) k_shade<M, 1, false>
+#define K_SHADE4(M) k_shade<M, 4, false>
+#define K_SHADE1E(M) k_shade<M, 1, true>
+#define K_SHADE4E(M) k_shade<M, 4, true>
+                if (env_samples) { if (hero) PT_BY_MODE(K_SHADE4E, PT_ARGS_SHADE); else PT_BY_MODE(K_SHADE1E, PT_ARGS_SHADE); }
+                else if (hero) PT_BY_MODE(K_SHADE4, PT_ARGS_SHADE); else PT_BY_MODE(K_SHADE1, PT_ARGS_SHADE);
             });
             if (rd.light_samples > 0)
                 timed(ST_SHADOW, [&] {
@@ -741,18 +747,22 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
 #define K1(M) k_extend<M, PT_TRAV_ANY>
 #define K2(M) k_shadow<M, 1, PT_TRAV_ANY>
 #define K3(M) k_shadow<M, 4, PT_TRAV_ANY>
-#define K4(M) k_shade<M, 1>
-#define K5(M) k_shade<M, 4>
+#define K4(M) k_shade<M, 1, false>
+#define K5(M) k_shade<M, 4, false>
+#define K4E(M) k_shade<M, 1, true>
+#define K5E(M) k_shade<M, 4, true>
 #define K6(M) k_extend_parked<M>
 #define K7(M) k_shadow_parked<M, 1>
 #define K8(M) k_shadow_parked<M, 4>
 #define K9(M) k_probe_intersect<M>
-        PT_ALLOW_MODES(K1); PT_ALLOW_MODES(K2); PT_ALLOW_MODES(K3); PT_ALLOW_MODES(K4); PT_ALLOW_MODES(K5); PT_ALLOW_MODES(K6); PT_ALLOW_MODES(K7); PT_ALLOW_MODES(K8); PT_ALLOW_MODES(K9);
+        PT_ALLOW_MODES(K1); PT_ALLOW_MODES(K2); PT_ALLOW_MODES(K3); PT_ALLOW_MODES(K4); PT_ALLOW_MODES(K5); PT_ALLOW_MODES(K4E); PT_ALLOW_MODES(K5E); PT_ALLOW_MODES(K6); PT_ALLOW_MODES(K7); PT_ALLOW_MODES(K8); PT_ALLOW_MODES(K9);
 #undef K1
 #undef K2
 #undef K3
 #undef K4
 #undef K5
+#undef K4E
+#undef K5E
 #undef K6
 #undef K7
 #undef K8

@@ -154,7 +154,10 @@ PT_HD bool shade_wants_item(const SceneView& s, const RenderParams& rp, const Hi
 
 // One vertex of random_walk (utils.rs:170-373) + the matching iteration of color()'s second pass (pt.rs:481-604).
 // `sink(l, ray)` receives every light-sample ray (all factors 0: nothing to trace) when the vertex has an item.
-template <int NL, typename RaySink>
+// ENV = false: the caller knows env_sampling_probability == 0 (Cornell-type scenes) — light samples never pick the environment, and
+// the whole estimate_direct_illumination_from_world branch is compiled out of the kernel (registers, not results: choose_first with
+// probability 0 leaves the sample as it is).
+template <int NL, bool ENV = true, typename RaySink>
 PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint32_t bounce, const PathVertexT<NL>& pv, const Hit& hit,
                                 uint32_t pixel, RaySink&& sink) {
     ShadeOutT<NL> out;
@@ -223,13 +226,15 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
             F3 hn = normalize(hit.n);  // HitRecord::from(vertex) renormalises (utils.rs:117-134)
             Frame fr2 = frame_from_normal(hn);
             F3 wi2 = to_local(fr2, normalize(sub(pv.prev_p, hit.p)));
+            EnvCurves ec[NL];  // the environment's spectral weights at this vertex' wavelengths, for all its light samples
+            for (int k = 0; k < NL; ++k) ec[k] = (ENV && env_p > 0.0f) ? env_curves(s, lam[k]) : EnvCurves{{0.0f, 0.0f, 0.0f, 0.0f}, false};
             for (uint32_t l = 0; l < rp.light_samples; ++l) {
                 ShadowRayT<NL> ray; ray.o = f3(0, 0, 0); ray.d = f3(0, 0, 0);
                 for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
                 pt_f32x4 q = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples) + 1u + l);
                 float x = q.x;
-                bool sample_world = choose_first(&x, env_p);
-                if (sample_world) {
+                const bool sample_world = choose_first(&x, env_p) && ENV;
+                if (ENV && sample_world) {
                     // estimate_direct_illumination_from_world, pt.rs:224-331
                     float eu, ev, light_pdf;
                     env_sample_uv(s, q.y, q.z, &eu, &ev, &light_pdf);
@@ -241,10 +246,10 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                         float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + spdf);
                         ray.o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(direction.z)));
                         ray.d = direction;
-                        ray.factor[0] = pv.beta[0] * weight * refl * env_emission(s, eu, ev, lambda) * pt_abs(local_wo.z) * (1.0f / light_pdf);
+                        ray.factor[0] = pv.beta[0] * weight * refl * env_emission(s, eu, ev, lambda, ec[0]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
                         for (int k = 1; k < NL; ++k) {
                             float rk, pk; material_bsdf_p(me[k], wi2, local_wo, &rk, &pk);
-                            ray.factor[k] = pv.beta[k] * weight * rk * env_emission(s, eu, ev, lam[k]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
+                            ray.factor[k] = pv.beta[k] * weight * rk * env_emission(s, eu, ev, lam[k], ec[k]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
                         }
                         out.shadow_count += 1;
                         // a contribution of exactly 0 adds 0 whether or not the ray is occluded: not traced

@@ -91,8 +91,11 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
                 Hit hit = load_hit(qh, i);
                 bool wants = shade_wants_item(s, rp, hit);
                 uint32_t ipos = items;
-                ShadeOutT<NL> out = stage_shade<NL>(s, rp, bounce, pv, hit, px[pv.slot % rp.chunk_pixels],
-                                                    [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(qs, ipos, l, ray); });
+                auto sink = [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(qs, ipos, l, ray); };
+                // the kernel form the engine launches: without the environment-sampling branch when env_sampling_probability is 0
+                const bool env_samples = bf(s, PT_HDR_ENV_PROB) != 0.0f || getenv("PTEMU_ENV_BRANCH") != nullptr;
+                ShadeOutT<NL> out = env_samples ? stage_shade<NL, true>(s, rp, bounce, pv, hit, px[pv.slot % rp.chunk_pixels], sink)
+                                                : stage_shade<NL, false>(s, rp, bounce, pv, hit, px[pv.slot % rp.chunk_pixels], sink);
                 if (wants) {
                     items++;
                     float lam[NL]; lam[0] = pv.lambda;
