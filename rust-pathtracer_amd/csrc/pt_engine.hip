@@ -58,7 +58,13 @@ constexpr int kBlock = 256;
 #define PT_PARK_WAVES 4
 #endif
 #define PT_PARK_OCC __attribute__((amdgpu_waves_per_eu(PT_PARK_WAVES)))
-#define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(NL == 1 ? PT_SHADE_WAVES : PT_SHADE4_WAVES)))
+#ifndef PT_SHADE_LEAN_WAVES
+#define PT_SHADE_LEAN_WAVES PT_SHADE_WAVES
+#endif
+#ifndef PT_SHADE4_LEAN_WAVES
+#define PT_SHADE4_LEAN_WAVES 3   // (the form without the environment branch: 6082 us at 3 waves, 7029 at 2, 6759 unconstrained; tools/shade_occupancy.sh)
+#endif
+#define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(NL == 1 ? (ENV ? PT_SHADE_WAVES : PT_SHADE_LEAN_WAVES) : (ENV ? PT_SHADE4_WAVES : PT_SHADE4_LEAN_WAVES))))
 #define PT_TRAV_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? PT_SWEEP_WAVES : PT_WALK_WAVES)))
 constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // stage the blob in LDS when it fits (keeps >= 2 workgroups per CU)
 
