@@ -1038,11 +1038,13 @@ PT_HD void ggx_transmission(float alpha, bool metallic, float eo, float ei, floa
 // evaluation): evaluated once.  The reference re-evaluates its curves in every call (lambertian.rs:25,62; ggx.rs:279-285,
 // 409-417); the values are identical, so this changes nothing but the instruction count.
 struct MatEval { uint32_t kind; bool metallic; float alpha; float refl; float ei, eo, kappa; };
+// GGX = false (here and below): the caller knows the scene holds no GGX material, and the microfacet code is compiled out of its kernel.
+template <bool GGX = true>
 PT_HD MatEval material_prepare(const SceneView& s, uint32_t m, float lambda, float u, float v) {
     MatEval e;
     e.kind = bu(s, m + PT_MAT_KIND); e.metallic = false; e.alpha = 0.0f; e.refl = 0.0f; e.ei = e.eo = e.kappa = 0.0f;
     if (e.kind == PT_MATERIAL_LAMBERTIAN) e.refl = pt_min(texstack_eval(s, bu(s, m + PT_MAT_TEXSTACK), lambda, u, v), 1.0f);
-    else if (e.kind != PT_MATERIAL_GGX) e.refl = pt_clamp(curve_eval(s, bu(s, m + PT_MAT_BOUNCE), lambda), 0.0f, 1.0f);
+    else if (!GGX || e.kind != PT_MATERIAL_GGX) e.refl = pt_clamp(curve_eval(s, bu(s, m + PT_MAT_BOUNCE), lambda), 0.0f, 1.0f);
     else {
         e.alpha = bf(s, m + PT_MAT_ALPHA);
         e.metallic = bu(s, m + PT_MAT_METALLIC) != 0;
@@ -1053,8 +1055,9 @@ PT_HD MatEval material_prepare(const SceneView& s, uint32_t m, float lambda, flo
 }
 
 // Material::bsdf (lambertian.rs:16-33, diffuse_light.rs:29-45, sharp_light.rs:43-60, ggx.rs:256-400)
+template <bool GGX = true>
 PT_HD void material_bsdf_p(const MatEval& e, F3 wi, F3 wo, float* f_out, float* pdf_out) {
-    if (e.kind != PT_MATERIAL_GGX) {
+    if (!GGX || e.kind != PT_MATERIAL_GGX) {
         if (wo.z * wi.z > 0.0f) { *f_out = e.refl / PT_PI; *pdf_out = pt_abs(wo.z) / PT_PI; }
         else { *f_out = 0.0f; *pdf_out = 0.0f; }
         return;
@@ -1086,8 +1089,9 @@ PT_HD void material_bsdf_p(const MatEval& e, F3 wi, F3 wo, float* f_out, float* 
 }
 
 // Material::generate_and_evaluate (lambertian.rs:50-66, diffuse_light.rs:60-76, sharp_light.rs:183-198, ggx.rs:401-590)
+template <bool GGX = true>
 PT_HD void material_sample_p(const MatEval& e, float sx, float sy, F3 wi, float* f_out, F3* wo_out, float* pdf_out) {
-    if (e.kind != PT_MATERIAL_GGX) {
+    if (!GGX || e.kind != PT_MATERIAL_GGX) {
         F3 d = mul(random_cosine_direction(sx, sy), pt_signum(wi.z));
         *f_out = e.refl / PT_PI; *wo_out = d; *pdf_out = pt_abs(d.z) / PT_PI;
         return;

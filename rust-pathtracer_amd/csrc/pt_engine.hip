@@ -64,7 +64,7 @@ constexpr int kBlock = 256;
 #ifndef PT_SHADE4_LEAN_WAVES
 #define PT_SHADE4_LEAN_WAVES 3   // (the form without the environment branch: 6082 us at 3 waves, 7029 at 2, 6759 unconstrained; tools/shade_occupancy.sh)
 #endif
-#define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(NL == 1 ? (ENV ? PT_SHADE_WAVES : PT_SHADE_LEAN_WAVES) : (ENV ? PT_SHADE4_WAVES : PT_SHADE4_LEAN_WAVES))))
+#define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(NL == 1 ? (FORM == 2 ? PT_SHADE_WAVES : PT_SHADE_LEAN_WAVES) : (FORM == 2 ? PT_SHADE4_WAVES : PT_SHADE4_LEAN_WAVES))))
 #define PT_TRAV_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? PT_SWEEP_WAVES : PT_WALK_WAVES)))
 constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // stage the blob in LDS when it fits (keeps >= 2 workgroups per CU)
 
@@ -155,7 +155,11 @@ __global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_extend(const uint32_t* _
     }
 }
 
-template <int USE_LDS, int NL, bool ENV>
+// FORM: what the scene can need at a vertex, so that the rest is compiled out (registers and code size, never results):
+// PT_SHADE_LEAN = no light sample picks the environment (env_sampling_probability = 0) and no GGX material (the Cornell box of C2 / C5),
+// PT_SHADE_NO_ENV = any material, PT_SHADE_FULL = everything.
+enum { PT_SHADE_LEAN = 0, PT_SHADE_NO_ENV = 1, PT_SHADE_FULL = 2 };
+template <int USE_LDS, int NL, int FORM>
 __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                  RenderParams rp, uint32_t bounce, const uint32_t* __restrict__ pixels,
                                                  Queue paths_in, Queue hits, Queue paths_out, Queue shadow, float* __restrict__ energy,
@@ -186,7 +190,7 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
         out.survives = false; out.has_item = false; out.vertex_pushed = false; out.env_hit = false; out.shadow_count = 0; out.add_energy = false; out.env_mask = 0;
         if (active) {
             uint32_t pixel = pixels[pv.slot % rp.chunk_pixels];
-            out = stage_shade<NL, ENV>(s, rp, bounce, pv, hit, pixel, [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(shadow, ipos, l, ray); });
+            out = stage_shade<NL, FORM == PT_SHADE_FULL, FORM != PT_SHADE_LEAN>(s, rp, bounce, pv, hit, pixel, [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(shadow, ipos, l, ray); });
             if (wants_item) {
                 float lam[NL]; lam[0] = pv.lambda;
                 if (NL > 1) hero_lambdas<NL>(rp, pt_draw4(rp.seed, pixel, rp.first_sample + pv.slot / rp.chunk_pixels, PT_DIM_FILM).z, lam);
@@ -571,7 +575,9 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     const bool parked = sweep && walks && b.park != nullptr && !env_u32("PT_AMD_NO_PARK", 0);
     // light samples can pick the environment only if env_sampling_probability > 0: otherwise k_shade is the form without that branch
     float env_prob; std::memcpy(&env_prob, &sc->host.blob[PT_HDR_ENV_PROB], sizeof env_prob);
-    const bool env_samples = env_prob != 0.0f || env_u32("PT_AMD_ENV_BRANCH", 0);
+    bool has_ggx = false;
+    for (uint32_t i = 0; i < sc->host.blob[PT_HDR_MATERIAL_COUNT]; ++i) has_ggx = has_ggx || sc->host.blob[sc->host.blob[PT_HDR_MATERIAL_OFF] + i * PT_MAT_WORDS + PT_MAT_KIND] == PT_MATERIAL_GGX;
+    const int shade_form = (env_prob != 0.0f || env_u32("PT_AMD_SHADE_FORM", 0) == 2) ? PT_SHADE_FULL : (has_ggx || env_u32("PT_AMD_SHADE_FORM", 0) == 1) ? PT_SHADE_NO_ENV : PT_SHADE_LEAN;
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
     const bool timing = env_u32("PT_AMD_STAGE_TIMING", 1) != 0;
     double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0};
@@ -630,12 +636,15 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
                 else launch(k_extend<PT_LDS_ALL, PT_TRAV_WALK>, lds_bytes, grid, stream, PT_ARGS_EXTEND);
             });
             timed(ST_SHADE, [&] {
-#define K_SHADE1(M) k_shade<M, 1, false>
-#define K_SHADE4(M) k_shade<M, 4, false>
-#define K_SHADE1E(M) k_shade<M, 1, true>
-#define K_SHADE4E(M) k_shade<M, 4, true>
-                if (env_samples) { if (hero) PT_BY_MODE(K_SHADE4E, PT_ARGS_SHADE); else PT_BY_MODE(K_SHADE1E, PT_ARGS_SHADE); }
-                else if (hero) PT_BY_MODE(K_SHADE4, PT_ARGS_SHADE); else PT_BY_MODE(K_SHADE1, PT_ARGS_SHADE);
+#define K_SHADE1L(M) k_shade<M, 1, PT_SHADE_LEAN>
+#define K_SHADE4L(M) k_shade<M, 4, PT_SHADE_LEAN>
+#define K_SHADE1N(M) k_shade<M, 1, PT_SHADE_NO_ENV>
+#define K_SHADE4N(M) k_shade<M, 4, PT_SHADE_NO_ENV>
+#define K_SHADE1F(M) k_shade<M, 1, PT_SHADE_FULL>
+#define K_SHADE4F(M) k_shade<M, 4, PT_SHADE_FULL>
+                if (shade_form == PT_SHADE_FULL) { if (hero) PT_BY_MODE(K_SHADE4F, PT_ARGS_SHADE); else PT_BY_MODE(K_SHADE1F, PT_ARGS_SHADE); }
+                else if (shade_form == PT_SHADE_NO_ENV) { if (hero) PT_BY_MODE(K_SHADE4N, PT_ARGS_SHADE); else PT_BY_MODE(K_SHADE1N, PT_ARGS_SHADE); }
+                else if (hero) PT_BY_MODE(K_SHADE4L, PT_ARGS_SHADE); else PT_BY_MODE(K_SHADE1L, PT_ARGS_SHADE);
             });
             if (rd.light_samples > 0)
                 timed(ST_SHADOW, [&] {
@@ -753,15 +762,17 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
 #define K1(M) k_extend<M, PT_TRAV_ANY>
 #define K2(M) k_shadow<M, 1, PT_TRAV_ANY>
 #define K3(M) k_shadow<M, 4, PT_TRAV_ANY>
-#define K4(M) k_shade<M, 1, false>
-#define K5(M) k_shade<M, 4, false>
-#define K4E(M) k_shade<M, 1, true>
-#define K5E(M) k_shade<M, 4, true>
+#define K4(M) k_shade<M, 1, PT_SHADE_LEAN>
+#define K5(M) k_shade<M, 4, PT_SHADE_LEAN>
+#define K4E(M) k_shade<M, 1, PT_SHADE_FULL>
+#define K5E(M) k_shade<M, 4, PT_SHADE_FULL>
+#define K4N(M) k_shade<M, 1, PT_SHADE_NO_ENV>
+#define K5N(M) k_shade<M, 4, PT_SHADE_NO_ENV>
 #define K6(M) k_extend_parked<M>
 #define K7(M) k_shadow_parked<M, 1>
 #define K8(M) k_shadow_parked<M, 4>
 #define K9(M) k_probe_intersect<M>
-        PT_ALLOW_MODES(K1); PT_ALLOW_MODES(K2); PT_ALLOW_MODES(K3); PT_ALLOW_MODES(K4); PT_ALLOW_MODES(K5); PT_ALLOW_MODES(K4E); PT_ALLOW_MODES(K5E); PT_ALLOW_MODES(K6); PT_ALLOW_MODES(K7); PT_ALLOW_MODES(K8); PT_ALLOW_MODES(K9);
+        PT_ALLOW_MODES(K1); PT_ALLOW_MODES(K2); PT_ALLOW_MODES(K3); PT_ALLOW_MODES(K4); PT_ALLOW_MODES(K5); PT_ALLOW_MODES(K4E); PT_ALLOW_MODES(K5E); PT_ALLOW_MODES(K4N); PT_ALLOW_MODES(K5N); PT_ALLOW_MODES(K6); PT_ALLOW_MODES(K7); PT_ALLOW_MODES(K8); PT_ALLOW_MODES(K9);
 #undef K1
 #undef K2
 #undef K3
@@ -769,6 +780,8 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
 #undef K5
 #undef K4E
 #undef K5E
+#undef K4N
+#undef K5N
 #undef K6
 #undef K7
 #undef K8

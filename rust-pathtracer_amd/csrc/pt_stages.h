@@ -157,7 +157,8 @@ PT_HD bool shade_wants_item(const SceneView& s, const RenderParams& rp, const Hi
 // ENV = false: the caller knows env_sampling_probability == 0 (Cornell-type scenes) — light samples never pick the environment, and
 // the whole estimate_direct_illumination_from_world branch is compiled out of the kernel (registers, not results: choose_first with
 // probability 0 leaves the sample as it is).
-template <int NL, bool ENV = true, typename RaySink>
+// GGX = false: the scene holds no GGX material (material_prepare<false> and friends).
+template <int NL, bool ENV = true, bool GGX = true, typename RaySink>
 PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint32_t bounce, const PathVertexT<NL>& pv, const Hit& hit,
                                 uint32_t pixel, RaySink&& sink) {
     ShadeOutT<NL> out;
@@ -191,8 +192,8 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     pt_f32x4 r = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples));
     float f, pdf; F3 wo;
     MatEval me[NL];
-    for (int k = 0; k < NL; ++k) me[k] = material_prepare(s, m, lam[k], hit.u, hit.v);
-    material_sample_p(me[0], r.x, r.y, wi, &f, &wo, &pdf);
+    for (int k = 0; k < NL; ++k) me[k] = material_prepare<GGX>(s, m, lam[k], hit.u, hit.v);
+    material_sample_p<GGX>(me[0], r.x, r.y, wi, &f, &wo, &pdf);
     float cos_o = pt_abs(wo.z);
     if (pt_isnan(pdf)) return out;  // utils.rs:261-263: the vertex is never pushed
     float rr = (bounce >= rp.min_bounces) ? pt_min(f / pdf, 1.0f) : 1.0f;
@@ -242,13 +243,13 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                     F3 local_wo = to_local(fr2, direction);
                     if (local_wo.z > 0.0f) {
                         float refl, spdf;
-                        material_bsdf_p(me[0], wi2, local_wo, &refl, &spdf);
+                        material_bsdf_p<GGX>(me[0], wi2, local_wo, &refl, &spdf);
                         float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + spdf);
                         ray.o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(direction.z)));
                         ray.d = direction;
                         ray.factor[0] = pv.beta[0] * weight * refl * env_emission(s, eu, ev, lambda, ec[0]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
                         for (int k = 1; k < NL; ++k) {
-                            float rk, pk; material_bsdf_p(me[k], wi2, local_wo, &rk, &pk);
+                            float rk, pk; material_bsdf_p<GGX>(me[k], wi2, local_wo, &rk, &pk);
                             ray.factor[k] = pv.beta[k] * weight * rk * env_emission(s, eu, ev, lam[k], ec[k]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
                         }
                         out.shadow_count += 1;
@@ -266,7 +267,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                     if (light_pdf != 0.0f) {
                         F3 bsdf_wo = to_local(fr2, ldir);
                         float refl, bpdf;
-                        material_bsdf_p(me[0], wi2, bsdf_wo, &refl, &bpdf);
+                        material_bsdf_p<GGX>(me[0], wi2, bsdf_wo, &refl, &bpdf);
                         float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + bpdf);
                         ray.o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(bsdf_wo.z)));
                         ray.d = ldir;
@@ -274,7 +275,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                         // emission are only known at the shadow hit and are multiplied in there.
                         ray.factor[0] = refl * pv.beta[0] * pt_abs(bsdf_wo.z) * weight / light_pdf;
                         for (int k = 1; k < NL; ++k) {
-                            float rk, pk; material_bsdf_p(me[k], wi2, bsdf_wo, &rk, &pk);
+                            float rk, pk; material_bsdf_p<GGX>(me[k], wi2, bsdf_wo, &rk, &pk);
                             ray.factor[k] = rk * pv.beta[k] * pt_abs(bsdf_wo.z) * weight / light_pdf;
                         }
                         out.shadow_count += 1;
@@ -289,7 +290,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     // continue the walk (utils.rs:301-329); passengers are divided by the hero's pdf (sketch utils.rs:493)
     float beta[NL];
     beta[0] = pv.beta[0] * (f / pdf_forward);
-    for (int k = 1; k < NL; ++k) { float fk, pk; material_bsdf_p(me[k], wi, wo, &fk, &pk); beta[k] = pv.beta[k] * (fk / pdf_forward); }
+    for (int k = 1; k < NL; ++k) { float fk, pk; material_bsdf_p<GGX>(me[k], wi, wo, &fk, &pk); beta[k] = pv.beta[k] * (fk / pdf_forward); }
     if (pdf_forward == 0.0f) for (int k = 0; k < NL; ++k) beta[k] = 0.0f;
     if (beta[0] == 0.0f) return out;
     if (r.z > rr) return out;

@@ -78,6 +78,10 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
         camera_rays += n;
         for (uint32_t i = 0; i < n; ++i) { store_path<NL>(qa, i, stage_generate<NL>(rp, i, px[i % rp.chunk_pixels])); for (int k = 0; k < NL; ++k) energy[(size_t)k * capacity + i] = 0.0f; }
         uint32_t live = n;
+        bool has_ggx = false;
+        for (uint32_t i = 0; i < bu(s, PT_HDR_MATERIAL_COUNT); ++i) has_ggx = has_ggx || bu(s, bu(s, PT_HDR_MATERIAL_OFF) + i * PT_MAT_WORDS + PT_MAT_KIND) == PT_MATERIAL_GGX;
+        const int forced = getenv("PTEMU_SHADE_FORM") ? atoi(getenv("PTEMU_SHADE_FORM")) : 0;
+        const int shade_form = (bf(s, PT_HDR_ENV_PROB) != 0.0f || forced == 2) ? 2 : (has_ggx || forced == 1) ? 1 : 0;
         for (uint32_t bounce = 0; bounce < bounce_limit; ++bounce) {
             Queue qin = (bounce & 1) ? qb : qa, qout = (bounce & 1) ? qa : qb;
             for (uint32_t i = 0; i < live; ++i) {
@@ -92,10 +96,12 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
                 bool wants = shade_wants_item(s, rp, hit);
                 uint32_t ipos = items;
                 auto sink = [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(qs, ipos, l, ray); };
-                // the kernel form the engine launches: without the environment-sampling branch when env_sampling_probability is 0
-                const bool env_samples = bf(s, PT_HDR_ENV_PROB) != 0.0f || getenv("PTEMU_ENV_BRANCH") != nullptr;
-                ShadeOutT<NL> out = env_samples ? stage_shade<NL, true>(s, rp, bounce, pv, hit, px[pv.slot % rp.chunk_pixels], sink)
-                                                : stage_shade<NL, false>(s, rp, bounce, pv, hit, px[pv.slot % rp.chunk_pixels], sink);
+                // the kernel form the engine launches (PT_SHADE_LEAN / NO_ENV / FULL): without the environment-sampling branch when
+                // env_sampling_probability is 0, without the GGX code when the scene has no GGX material
+                const uint32_t px_i = px[pv.slot % rp.chunk_pixels];
+                ShadeOutT<NL> out = shade_form == 2 ? stage_shade<NL, true, true>(s, rp, bounce, pv, hit, px_i, sink)
+                                  : shade_form == 1 ? stage_shade<NL, false, true>(s, rp, bounce, pv, hit, px_i, sink)
+                                                    : stage_shade<NL, false, false>(s, rp, bounce, pv, hit, px_i, sink);
                 if (wants) {
                     items++;
                     float lam[NL]; lam[0] = pv.lambda;

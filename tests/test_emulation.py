@@ -121,14 +121,16 @@ def test_reference_known_answers_on_the_lane_logic(emu, oracle, pkg):
     kat.test_white_furnace(pkg, emu, cmf=oracle)
 
 
-def test_shade_form_without_environment_sampling_changes_nothing(emu, pkg, monkeypatch):
-    """env_sampling_probability = 0 selects stage_shade<NL, false> (no environment-sampling branch): same bits as the general form."""
+def test_specialised_shade_forms_change_nothing(emu, pkg, monkeypatch):
+    """The shade forms compiled without the environment-sampling branch (env_sampling_probability = 0) and without the GGX code (no
+    GGX material in the scene) give the bits of the general form."""
     for scene, hero in (("cornell_box", 1), ("cornell_gem", 1), ("cornell_box", 4)):
         b = pkg.scene.SCENES[scene]()
         rd = pkg.api.render_desc(24, 20, 5, 6, hero_wavelengths=hero)
         lean, plean = emu.create_scene(b).render(rd)
-        monkeypatch.setenv("PTEMU_ENV_BRANCH", "1")
-        general, pgen = emu.create_scene(b).render(rd)
-        monkeypatch.delenv("PTEMU_ENV_BRANCH")
-        assert np.array_equal(lean.view(np.uint32), general.view(np.uint32)), scene
-        assert (plean.bounce_rays, plean.shadow_rays) == (pgen.bounce_rays, pgen.shadow_rays)
+        for form in ("1", "2"):
+            monkeypatch.setenv("PTEMU_SHADE_FORM", form)
+            general, pgen = emu.create_scene(b).render(rd)
+            monkeypatch.delenv("PTEMU_SHADE_FORM")
+            assert np.array_equal(lean.view(np.uint32), general.view(np.uint32)), (scene, form)
+            assert (plean.bounce_rays, plean.shadow_rays) == (pgen.bounce_rays, pgen.shadow_rays)

@@ -130,18 +130,19 @@ def test_batching_and_lds_staging_are_invisible(engine, pkg, monkeypatch):
     assert np.array_equal(nolds, again)
 
 
-def test_shade_form_without_environment_sampling_changes_nothing(engine, pkg, monkeypatch):
+def test_specialised_shade_forms_change_nothing(engine, pkg, monkeypatch):
     """Scenes with env_sampling_probability = 0 run the k_shade form compiled without the environment-sampling branch;
     forcing the general form must give the same film bit for bit."""
     for scene, hero in (("cornell_box", 1), ("cornell_gem", 1), ("cornell_box", 4)):
         b = pkg.scene.SCENES[scene]()
         rd = pkg.api.render_desc(96, 80, 11, 8, hero_wavelengths=hero)
         lean, plean = engine.create_scene(b).render(rd)
-        monkeypatch.setenv("PT_AMD_ENV_BRANCH", "1")
-        general, pgen = engine.create_scene(b).render(rd)
-        monkeypatch.delenv("PT_AMD_ENV_BRANCH")
-        assert np.array_equal(lean.view(np.uint32), general.view(np.uint32)), scene
-        assert (plean.bounce_rays, plean.shadow_rays) == (pgen.bounce_rays, pgen.shadow_rays)
+        for form in ("1", "2"):
+            monkeypatch.setenv("PT_AMD_SHADE_FORM", form)
+            general, pgen = engine.create_scene(b).render(rd)
+            monkeypatch.delenv("PT_AMD_SHADE_FORM")
+            assert np.array_equal(lean.view(np.uint32), general.view(np.uint32)), (scene, form)
+            assert (plean.bounce_rays, plean.shadow_rays) == (pgen.bounce_rays, pgen.shadow_rays)
 
 
 def test_filtered_slab_test_and_culling_change_nothing(engine, pkg, monkeypatch):
