@@ -58,13 +58,21 @@ constexpr int kBlock = 256;
 #define PT_PARK_WAVES 4
 #endif
 #define PT_PARK_OCC __attribute__((amdgpu_waves_per_eu(PT_PARK_WAVES)))
+// (forms of k_shade, see the kernel: FULL = PT_SHADE_WAVES / PT_SHADE4_WAVES above; measured with tools/shade_occupancy.sh)
+#ifndef PT_SHADE_NO_ENV_WAVES
+#define PT_SHADE_NO_ENV_WAVES 3
+#endif
+#ifndef PT_SHADE4_NO_ENV_WAVES
+#define PT_SHADE4_NO_ENV_WAVES 3   // 6082 us at 3 waves, 7029 at 2, 6759 unconstrained (C5 before the lean form existed)
+#endif
 #ifndef PT_SHADE_LEAN_WAVES
-#define PT_SHADE_LEAN_WAVES PT_SHADE_WAVES
+#define PT_SHADE_LEAN_WAVES 3      // 126 VGPRs without a constraint = 4 waves; 5 waves spill (3892 vs 2866 us)
 #endif
 #ifndef PT_SHADE4_LEAN_WAVES
-#define PT_SHADE4_LEAN_WAVES 3   // (the form without the environment branch: 6082 us at 3 waves, 7029 at 2, 6759 unconstrained; tools/shade_occupancy.sh)
+#define PT_SHADE4_LEAN_WAVES 2     // C5: 3885 us at 2 waves, 4142 at 3-4, 4830 at 5
 #endif
-#define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(NL == 1 ? (FORM == 2 ? PT_SHADE_WAVES : PT_SHADE_LEAN_WAVES) : (FORM == 2 ? PT_SHADE4_WAVES : PT_SHADE4_LEAN_WAVES))))
+#define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(NL == 1 ? (FORM == 2 ? PT_SHADE_WAVES : FORM == 1 ? PT_SHADE_NO_ENV_WAVES : PT_SHADE_LEAN_WAVES) \
+                                                                : (FORM == 2 ? PT_SHADE4_WAVES : FORM == 1 ? PT_SHADE4_NO_ENV_WAVES : PT_SHADE4_LEAN_WAVES))))
 #define PT_TRAV_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? PT_SWEEP_WAVES : PT_WALK_WAVES)))
 constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // stage the blob in LDS when it fits (keeps >= 2 workgroups per CU)
 
@@ -217,7 +225,7 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
     }
 }
 
-template <int USE_LDS, int NL, int TRAV>
+template <int USE_LDS, int NL, int TRAV, bool ENV = true>
 __global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                   uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                   uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
@@ -225,7 +233,7 @@ __global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_shadow(const uint32_t* _
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
     uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
     for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
-        stage_shadow_item<NL, TRAV>(s, light_samples, shadow, base + j, energy, energy_stride);
+        stage_shadow_item<NL, TRAV, ENV>(s, light_samples, shadow, base + j, energy, energy_stride);
     }
 }
 
@@ -654,9 +662,12 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
 #define K_SH_ANY4(M) k_shadow<M, 4, PT_TRAV_ANY>
                     if (parked) { if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS_SHADOW, b.park); else PT_BY_MODE(K_SH_PARKED1, PT_ARGS_SHADOW, b.park); }
                     else if (mode != PT_LDS_ALL || (sweep && walks)) { if (hero) PT_BY_MODE(K_SH_ANY4, PT_ARGS_SHADOW); else PT_BY_MODE(K_SH_ANY1, PT_ARGS_SHADOW); }
-                    else if (sweep) {
-                        if (hero) launch(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
-                        else launch(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
+                    else if (sweep) {   // (shade_form FULL = the scene can produce environment rays)
+                        if (shade_form == PT_SHADE_FULL) {
+                            if (hero) launch(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, true>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
+                            else launch(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, true>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
+                        } else if (hero) launch(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, false>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
+                        else launch(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, false>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
                     } else {
                         if (hero) launch(k_shadow<PT_LDS_ALL, 4, PT_TRAV_WALK>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
                         else launch(k_shadow<PT_LDS_ALL, 1, PT_TRAV_WALK>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
@@ -790,6 +801,7 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
         allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>));
         allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP>));
         allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP>));
+        allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, false>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, false>));
     }
     *out = sc;
     return PT_OK;

@@ -355,34 +355,31 @@ PT_HD bool shadow_light_bound(const SceneView& s, F3 o, F3 d, float* bound, int*
     return t_light < PT_INF;
 }
 PT_HD int shadow_env_stop(const SceneView& s) { return (bu(s, PT_HDR_FLAGS) & PT_FLAG_NO_CULL) ? PT_STOP_NONE : PT_STOP_ANY; }
-template <int NL, int TRAV = PT_TRAV_ANY>
-PT_HD void stage_shadow_light(const SceneView& s, const float* lambda, const ShadowRayT<NL>& ray, float* contribution) {
+// One light-sample ray: a light ray (pt.rs:171-217) or an environment ray (pt.rs:252-330, contributes only if nothing is hit: any hit
+// blocks it, so its search ends at the first one; PT_AMD_NO_CULL keeps the full search).  One search call site for both kinds — a
+// wave whose lanes hold both kinds traces them together.  ENV = false: the caller knows the scene produces no environment rays
+// (env_sampling_probability = 0) and that half is compiled out.
+template <int NL, int TRAV = PT_TRAV_ANY, bool ENV = true>
+PT_HD void stage_shadow_ray(const SceneView& s, const float* lambda, const ShadowRayT<NL>& ray, bool env, float* contribution) {
     for (int k = 0; k < NL; ++k) contribution[k] = 0.0f;
-    float bound; int stop;
-    if (!shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) return;
+    float bound = PT_INF; int stop = PT_STOP_NONE;
+    if (ENV && env) stop = shadow_env_stop(s);
+    else if (!shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) return;
     Hit sh;
     bool hit = world_hit<TRAV>(s, ray.o, ray.d, &sh, bound, stop);
-    shadow_ray_contribution<NL>(s, lambda, ray, false, hit, sh, contribution);
-}
-// The environment-sample ray of pt.rs:252-330: contributes only if nothing is hit.
-template <int NL, int TRAV = PT_TRAV_ANY>
-PT_HD void stage_shadow_env(const SceneView& s, const ShadowRayT<NL>& ray, float* contribution) {
-    Hit sh;
-    // any hit blocks the environment: the search ends at the first one (PT_AMD_NO_CULL keeps the full search)
-    bool blocked = world_hit<TRAV>(s, ray.o, ray.d, &sh, PT_INF, shadow_env_stop(s));
-    shadow_ray_contribution<NL>(s, nullptr, ray, true, blocked, sh, contribution);
+    shadow_ray_contribution<NL>(s, lambda, ray, ENV && env, hit, sh, contribution);
 }
 // One light-sample item: L rays, summed in order, divided by L (pt.rs:349-392, 596)
-template <int NL, int TRAV = PT_TRAV_ANY>
+template <int NL, int TRAV = PT_TRAV_ANY, bool ENV = true>
 PT_HD void stage_shadow_item(const SceneView& s, uint32_t light_samples, const Queue& shadow, uint32_t item, float* energy, uint32_t energy_stride) {
-    uint32_t slot = qu(shadow, Layout<NL>::sh_slot, item), flags = qu(shadow, Layout<NL>::sh_flags, item);
+    uint32_t slot = qu(shadow, Layout<NL>::sh_slot, item), flags = ENV ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
     float lambda[NL], lc[NL];
     for (int k = 0; k < NL; ++k) { lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item); lc[k] = 0.0f; }
     for (uint32_t l = 0; l < light_samples; ++l) {
         ShadowRayT<NL> ray;
         if (!load_shadow_ray<NL>(shadow, item, l, &ray)) continue;
         float c[NL];
-        if ((flags >> l) & 1u) stage_shadow_env<NL, TRAV>(s, ray, c); else stage_shadow_light<NL, TRAV>(s, lambda, ray, c);
+        stage_shadow_ray<NL, TRAV, ENV>(s, lambda, ray, ((flags >> l) & 1u) != 0u, c);
         for (int k = 0; k < NL; ++k) lc[k] += c[k];
     }
     for (int k = 0; k < NL; ++k) energy[(size_t)k * energy_stride + slot] += lc[k] / (float)light_samples;

@@ -114,7 +114,10 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
                 if (out.survives) store_path<NL>(qout, next++, out.next);
                 bounce_rays += out.vertex_pushed; env_hits += out.env_hit; shadow_rays += out.shadow_count;
             }
-            for (uint32_t i = 0; i < items; ++i) stage_shadow_item<NL>(s, rp.light_samples, qs, i, energy.data(), capacity);
+            for (uint32_t i = 0; i < items; ++i) {
+                if (shade_form == 2) stage_shadow_item<NL, PT_TRAV_ANY, true>(s, rp.light_samples, qs, i, energy.data(), capacity);
+                else stage_shadow_item<NL, PT_TRAV_ANY, false>(s, rp.light_samples, qs, i, energy.data(), capacity);
+            }
             live = next;
         }
         for (uint32_t p = 0; p < rp.chunk_pixels; ++p) stage_accumulate_pixel<NL>(rp, energy.data(), p, px[p], film + 4 * (size_t)px[p]);

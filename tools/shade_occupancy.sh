@@ -6,7 +6,7 @@ one() { timeout 200 python bench.py --steps 3 --warmup 1 --cpu-seconds 0 "$@" 2>
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['roofline']['kernels']
 print('   %.1f Ms/s' % d['value'], {n: round(v['avg_us']) for n,v in k.items()})"; }
-for flags in "-DPT_SHADE_LEAN_WAVES=3 -DPT_SHADE4_LEAN_WAVES=2" "-DPT_SHADE_LEAN_WAVES=4 -DPT_SHADE4_LEAN_WAVES=3" "-DPT_SHADE_LEAN_WAVES=2 -DPT_SHADE4_LEAN_WAVES=1"; do
+for flags in "-DPT_SHADE_LEAN_WAVES=5 -DPT_SHADE4_LEAN_WAVES=5" "-DPT_SHADE_LEAN_WAVES=4 -DPT_SHADE4_LEAN_WAVES=4" "-DPT_SHADE_LEAN_WAVES=2 -DPT_SHADE4_LEAN_WAVES=2"; do
   build "$flags"; echo "== $flags"
   one; one --hero 4 --spp-per-step 60
 done
