@@ -114,20 +114,22 @@
 
 // Leaf sweep table (world_hit_sweep).  One mask bit per top-level leaf (instance) and per triangle leaf, numbered in
 // traversal pre-order: instance j gets bit `first`, its triangle leaves first+1 .. first+count.
-// Per instance, in the pre-order of the top-level BVH's leaves (12 words):
-//   [0] instance record offset, [1] instance id, [2] kind | flat << 8 | has_transform << 9, [3] first mask bit,
-//   [4..6] box min, [7] triangle-leaf list offset, [8..10] box max, [11] triangle-leaf count
-// Triangle leaf (8 words, in the pre-order of the mesh BVH's leaves): [0..2] box min, [3] triangle word offset, [4..6] box max,
-//   [7] flat | alias << 1: alias 0 = own box test; alias b + 1 = the box is bit-identical to that of mask bit b, which is tested
-//   against the same ray (the untransformed instance's own box, or an earlier triangle leaf of the instance — the two
-//   triangles of every planar quad share a box), so b's decision is copied instead of recomputed.
+// Per instance, in the pre-order of the top-level BVH's leaves (16 words):
+//   [0] instance record offset, [1] kind | flat << 8 | has_transform << 9 | walked << 10 | first mask bit << 16 | tested triangle leaves << 24,
+//   [2..3] the mask its box test sets, [4..6] box min, [7] triangle-leaf list offset, [8..10] box max, [11] triangle-leaf count (all of them),
+//   [12..13] which of the tested triangle leaves (by list index) have a flat box, [14] instance id
+// Triangle leaf (8 words, in the pre-order of the mesh BVH's leaves; only the leaves that keep a box test of their own): [0..2] box
+//   min, [4..6] box max, [3] and [7] the low and high word of the mask the test sets = the leaf's own bit (the lowest) and the bits
+//   of the later leaves of the instance whose box is bit-identical: they are tested against the same ray, so the decision is theirs
+//   too and they have no record here.  Leaves whose box is the untransformed instance's own box ride in the instance's mask (the
+//   two triangles of every planar quad share a box; the two of an axis-aligned wall share it with their instance).
 // Bit table (PT_HDR_SWEEP_BITS_OFF): per mask bit 8 words: instance record offset, triangle word offset (0: the instance
 // itself), box word offset (min at +0, max at +4), kind | flat << 8 | has_transform << 9 | instance id << 16,
 // followers (2 words: the later bits that alias this one, directly or through a chain), then for a triangle the word
 // distances from its record to its copies permuted for a dominant x axis (y, z, x) and y axis (z, x, y) — the mesh-data
 // section keeps the triangles of every mesh in the table in all three vertex permutations (triangle_test_permuted)
 #define PT_SWEEP_WALKED 0x400u     /* kind/flags word: a mesh instance whose triangles are not in the table; its BVH is walked */
-#define PT_SWEEP_INST_WORDS 12
+#define PT_SWEEP_INST_WORDS 16
 #define PT_SWEEP_TRI_WORDS 8
 #define PT_SWEEP_BIT_WORDS 8
 #define PT_SWEEP_MAX_BITS 64

@@ -506,44 +506,40 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
     const RayPrep wr = ray_prepare(o, d);
     const bool quick = wr.fast && !exact && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f;
     const bool bounded = bound < PT_INF;
-    // the masks are built as 32-bit halves: the bit index is wave-uniform, so the half is chosen by a scalar branch and a
-    // leaf costs one select + one or per mask
+    // the masks are built as 32-bit halves
     uint32_t hit_lo = 0, hit_hi = 0, unc_lo = 0, unc_hi = 0;
     PT_STAT_EVENT(0);
     PT_STAT_RAY(o, d);
     // 1 — the sweep.  `bound` culls leaves that start beyond the distance the caller cares about (shadow rays).
+    // A test sets a whole mask: the leaf's bit and the bits of the later leaves of the instance with the very same box (same box,
+    // same ray, same decision; the host folds them into the mask, pt_blob.h).  The masks are wave-uniform, so the halves that are
+    // empty are skipped by scalar branches.
+    auto mark = [&](int c, uint32_t mlo, uint32_t mhi) {
+        if (mlo != 0u) { hit_lo |= c == 1 ? mlo : 0u; unc_lo |= c == 2 ? mlo : 0u; }
+        if (mhi != 0u) { hit_hi |= c == 1 ? mhi : 0u; unc_hi |= c == 2 ? mhi : 0u; }
+    };
     for (uint32_t j = 0; j < count; ++j) {
         const uint32_t e = PT_UNIFORM(sweep + j * PT_SWEEP_INST_WORDS);
         const F4 h0 = bf4(s, e), a = bf4(s, e + 4), b = bf4(s, e + 8);
-        const uint32_t kf = PT_UNIFORM(pt_f2u(h0.z)), bit = PT_UNIFORM(pt_f2u(h0.w));
+        const uint32_t kf = PT_UNIFORM(pt_f2u(h0.y));
         float entry = 0.0f;
         int c = quick ? aabb_classify(a, b, wr, (kf & 0x100u) != 0, &entry) : 2;
         if (bounded && c == 1 && cull_top && beyond(entry, bound, wr.base)) c = 0;
-        {
-            const uint32_t m = 1u << (bit & 31u);
-            if (bit < 32u) { hit_lo |= c == 1 ? m : 0u; unc_lo |= c == 2 ? m : 0u; } else { hit_hi |= c == 1 ? m : 0u; unc_hi |= c == 2 ? m : 0u; }
-        }
-        if ((kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH && PT_WAVE_ANY(c != 0)) {
-            const uint32_t tl = PT_UNIFORM(pt_f2u(a.w)), tc = PT_UNIFORM(pt_f2u(b.w));
+        mark(c, PT_UNIFORM(pt_f2u(h0.z)), PT_UNIFORM(pt_f2u(h0.w)));
+        if ((kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH && (kf >> 24) != 0u && PT_WAVE_ANY(c != 0)) {
+            const uint32_t tl = PT_UNIFORM(pt_f2u(a.w)), tc = kf >> 24;   // the leaves with a box test of their own
+            const F4 fl = bf4(s, e + 12);
+            const uint32_t flat_lo = PT_UNIFORM(pt_f2u(fl.x)), flat_hi = PT_UNIFORM(pt_f2u(fl.y));
             // the triangle leaves against the instance's ray: the world ray itself unless the instance is transformed (a branch
             // on a wave-uniform flag, not a copy of the prepared ray: 20 registers moved per mesh instance otherwise)
             auto leaves = [&](const RayPrep& lr, bool lquick) {
                 for (uint32_t t = 0; t < tc; ++t) {
                     const F4 ta = bf4(s, tl + t * PT_SWEEP_TRI_WORDS), tb = bf4(s, tl + t * PT_SWEEP_TRI_WORDS + 4);
-                    const uint32_t tw = PT_UNIFORM(pt_f2u(tb.w)), tbit = bit + 1 + t, sh = tbit & 31u;
-                    uint32_t th, tu;  // this leaf's hit / undecided bit, in place
-                    if (tw >> 1) {
-                        // same box, same ray as an earlier bit: copy its decision (already gated by the instance's)
-                        const uint32_t sb = (tw >> 1) - 1u;
-                        th = (((sb < 32u ? hit_lo : hit_hi) >> (sb & 31u)) & 1u) << sh;
-                        tu = (((sb < 32u ? unc_lo : unc_hi) >> (sb & 31u)) & 1u) << sh;
-                    } else {
-                        int ct = lquick ? aabb_classify(ta, tb, lr, (tw & 1u) != 0u, &entry) : 2;
-                        if (bounded && ct == 1 && cull_mesh && beyond(entry, bound, lr.base)) ct = 0;
-                        if (c == 0) ct = 0;
-                        th = ct == 1 ? 1u << sh : 0u; tu = ct == 2 ? 1u << sh : 0u;
-                    }
-                    if (tbit < 32u) { hit_lo |= th; unc_lo |= tu; } else { hit_hi |= th; unc_hi |= tu; }
+                    const bool flat = (((t < 32u ? flat_lo : flat_hi) >> (t & 31u)) & 1u) != 0u;
+                    int ct = lquick ? aabb_classify(ta, tb, lr, flat, &entry) : 2;
+                    if (bounded && ct == 1 && cull_mesh && beyond(entry, bound, lr.base)) ct = 0;
+                    if (c == 0) ct = 0;
+                    mark(ct, PT_UNIFORM(pt_f2u(ta.w)), PT_UNIFORM(pt_f2u(tb.w)));
                 }
             };
             if (kf & 0x200u) {

@@ -414,6 +414,8 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                 bits.insert(bits.end(), own, own + PT_SWEEP_BIT_WORDS);
                 root_of.push_back((int)first_bit);
                 if (in.kind == PT_SHAPE_MESH && walked[inst]) any_walked = true;
+                std::vector<uint32_t> leaders;  // word offsets of the triangle-leaf records that keep their own box test
+                uint64_t flat_leaders = 0;
                 if (in.kind == PT_SHAPE_MESH && !walked[inst]) {
                     mesh_mask |= 1ull << first_bit;
                     pad16(w);
@@ -432,16 +434,34 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                         seen.push_back(box);
                         root_of.push_back(alias ? root_of[alias - 1] : (int)bit);
                         uint32_t triw = tri_base + mn[7] * PT_TRI_WORDS, flat = is_flat(mn) ? 1u : 0u;
-                        uint32_t rec[PT_SWEEP_TRI_WORDS] = {mn[0], mn[1], mn[2], triw, mn[4], mn[5], mn[6], flat | (alias ? (uint32_t)root_of[alias - 1] + 1 : 0u) << 1};
-                        uint32_t tb[PT_SWEEP_BIT_WORDS] = {rec_off, triw, (uint32_t)w.size(), (kf & ~0x100u) | flat << 8 | inst << 16, 0u, 0u, mesh_perm0[in.mesh], mesh_perm1[in.mesh]};
-                        w.insert(w.end(), rec, rec + PT_SWEEP_TRI_WORDS);
+                        uint32_t box_words = e + 4;  // a copy of the instance's own box: settled with it, never looked up
+                        if (!alias) {
+                            if (flat) flat_leaders |= 1ull << leaders.size();
+                            leaders.push_back((uint32_t)w.size());
+                            uint32_t rec[PT_SWEEP_TRI_WORDS] = {mn[0], mn[1], mn[2], 0u, mn[4], mn[5], mn[6], 0u};  // [3], [7]: the mask, below
+                            box_words = (uint32_t)w.size();
+                            w.insert(w.end(), rec, rec + PT_SWEEP_TRI_WORDS);
+                        } else if (root_of.back() != (int)first_bit) box_words = bits[(size_t)root_of.back() * PT_SWEEP_BIT_WORDS + 2];
+                        uint32_t tb[PT_SWEEP_BIT_WORDS] = {rec_off, triw, box_words, (kf & ~0x100u) | flat << 8 | inst << 16, 0u, 0u, mesh_perm0[in.mesh], mesh_perm1[in.mesh]};
                         bits.insert(bits.end(), tb, tb + PT_SWEEP_BIT_WORDS);
                         ++tri_count; ++bit;
                     }
                 }
+                // the mask a box test sets: its own bit and the bits of the later leaves of this instance whose box is the same
+                auto mask_of = [&](uint32_t leader_bit) { uint64_t m = 0; for (uint32_t b2 = first_bit; b2 < bit; ++b2) if (root_of[b2] == (int)leader_bit) m |= 1ull << b2; return m; };
+                {
+                    uint32_t b2 = first_bit + 1;
+                    for (uint32_t off : leaders) {
+                        while (root_of[b2] != (int)b2) ++b2;
+                        uint64_t m = mask_of(b2++);
+                        w[off + 3] = (uint32_t)m; w[off + 7] = (uint32_t)(m >> 32);
+                    }
+                }
+                uint64_t own_mask = mask_of(first_bit);
                 uint32_t* r = &w[e];
-                r[0] = rec_off; r[1] = inst; r[2] = kf; r[3] = first_bit;
+                r[0] = rec_off; r[1] = kf | first_bit << 16 | (uint32_t)leaders.size() << 24; r[2] = (uint32_t)own_mask; r[3] = (uint32_t)(own_mask >> 32);
                 r[4] = nd[0]; r[5] = nd[1]; r[6] = nd[2]; r[7] = tri_list; r[8] = nd[4]; r[9] = nd[5]; r[10] = nd[6]; r[11] = tri_count;
+                r[12] = (uint32_t)flat_leaders; r[13] = (uint32_t)(flat_leaders >> 32); r[14] = inst; r[15] = 0u;
             }
             for (size_t k = 0; k < root_of.size(); ++k)
                 if (root_of[k] != (int)k) {

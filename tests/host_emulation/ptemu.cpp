@@ -38,7 +38,7 @@ uint32_t ptemu_debug_scene_info(pt_scene* sc, int what) {
         for (uint32_t j = 0; j < w[PT_HDR_SWEEP_COUNT]; ++j) {
             const uint32_t* e = &w[w[PT_HDR_SWEEP_OFF] + j * PT_SWEEP_INST_WORDS];
             bits += 1 + e[11];
-            for (uint32_t t = 0; t < e[11]; ++t) copies += (w[e[7] + t * PT_SWEEP_TRI_WORDS + 7] >> 1) != 0;
+            copies += e[11] - (e[1] >> 24);   // triangle leaves without a box test of their own
         }
         return what == 5 ? bits : copies;
     }
