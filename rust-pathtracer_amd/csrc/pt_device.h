@@ -302,6 +302,16 @@ PT_HD int aabb_classify(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry) 
     return (m0 < x0 - e0 && m1 < x1 - e1 && m2 < x2 - e2) ? 1 : 2;
 }
 
+// The box test of a BVH walk step: the three-way classification when the ray allows it (`quick`: rp.fast and no zero direction
+// component; a non-flat node then takes the cheap form), the per-axis filtered test otherwise; the exact test settles what is left.
+PT_HD bool aabb_hit_node(F4 a, F4 b, const RayPrep& rp, bool quick, float* entry) {
+    if (!quick) return aabb_hit(a, b, rp, entry);
+    const int c = aabb_classify(a, b, rp, (pt_f2u(a.w) & PT_NODE_FLAT) != 0u, entry);
+    if (c != 2) return c == 1;
+    PT_STAT(box_exact);
+    return aabb_hit_exact(a, b, rp.o, rp.d, entry);
+}
+
 // MeshTriangleRef::hit (src/geometry/mesh.rs:67-198), split: the per-ray part (axis permutation and shear constants,
 // mesh.rs:79-99) is computed once per mesh visit, the interval test per triangle, the HitRecord only for the triangle
 // that survives as closest.
@@ -647,13 +657,14 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
         return;
     }
     uint32_t i = 0;
+    const bool walk_quick = cr.fast && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f;
     for (;;) {
         uint32_t pending = NONE;
         while (i < node_count && pending == NONE) {
             F4 a = mf4(s, node_off + i * PT_NODE_WORDS), b = mf4(s, node_off + i * PT_NODE_WORDS + 4);
-            uint32_t exit_i = pt_f2u(a.w), shape = pt_f2u(b.w);
+            uint32_t exit_i = PT_NODE_EXIT(pt_f2u(a.w)), shape = pt_f2u(b.w);
             float entry;
-            bool box = aabb_hit(a, b, cr, &entry) && !(cull && beyond(entry, limit, cr.base));
+            bool box = aabb_hit_node(a, b, cr, walk_quick, &entry) && !(cull && beyond(entry, limit, cr.base));
             if (shape == PT_NODE_INNER) i = box ? i + 1 : exit_i;
             else { i = exit_i; if (box) pending = shape; }
         }
@@ -764,6 +775,8 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
     const TriRay wtr = tri_ray_prepare(o, d);
     RayPrep cr = wr;
     TriRay tr = wtr;
+    const bool wr_quick = wr.fast && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f;
+    bool cr_quick = wr_quick;  // (of the ray the current level is walked with)
     uint32_t node_off = top_off, node_count = top_count, i = 0;
     uint32_t level_inst = NONE, top_resume = 0, tri_off = 0;
     // `bound`: the caller knows that no hit beyond it can matter (shadow rays: the nearest light hit, see
@@ -784,16 +797,16 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
             if (i >= node_count) {
                 if (level_inst == NONE) { done = true; break; }
                 // the mesh walk is finished: back to the instance level, in world space
-                cr = wr;
+                cr = wr; cr_quick = wr_quick;
                 node_off = top_off; node_count = top_count; i = top_resume; level_inst = NONE;
                 continue;
             }
             // the node array is the top level's (core section) or a mesh's (mesh-data section), lane by lane
             const uint32_t* nb = (level_inst != NONE ? s.m : s.w) + node_off + i * PT_NODE_WORDS;
             F4 a = *reinterpret_cast<const F4*>(nb), b = *reinterpret_cast<const F4*>(nb + 4);
-            uint32_t exit_i = pt_f2u(a.w), shape = pt_f2u(b.w);
+            uint32_t exit_i = PT_NODE_EXIT(pt_f2u(a.w)), shape = pt_f2u(b.w);
             float entry;
-            bool box = aabb_hit(a, b, cr, &entry) && !((level_inst != NONE ? cull_mesh : cull_top) && beyond(entry, limit, cr.base));
+            bool box = aabb_hit_node(a, b, cr, cr_quick, &entry) && !((level_inst != NONE ? cull_mesh : cull_top) && beyond(entry, limit, cr.base));
             if (shape == PT_NODE_INNER) { i = box ? i + 1 : exit_i; }
             else { i = exit_i; if (box) pending = shape; }
         }
@@ -826,8 +839,9 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
                 if (bu(s, inst + PT_INST_FLAGS) & 1u) {
                     cr = ray_prepare(lo, ld);
                     if (exact) cr.fast = false;
+                    cr_quick = cr.fast && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f;
                     tr = tri_ray_prepare(lo, ld);
-                } else { cr = wr; tr = wtr; }
+                } else { cr = wr; cr_quick = wr_quick; tr = wtr; }
                 i = 0;
             } else {
                 Hit h;

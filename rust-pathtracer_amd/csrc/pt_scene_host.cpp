@@ -86,7 +86,10 @@ struct BvhBuilder {
         bool leaf = idx.size() == 1;
         const Box& b = leaf ? shapes[idx[0]] : box;
         if (!leaf) { std::vector<uint32_t> li, ri; Box lb, rb; split(idx, li, lb, ri, rb); emit(li, lb); emit(ri, rb); }
-        out[at + 0] = fbits(b.mn[0]); out[at + 1] = fbits(b.mn[1]); out[at + 2] = fbits(b.mn[2]); out[at + 3] = node_count();
+        // [3]: the node to continue with when this subtree is done or skipped; bit 31 (PT_NODE_FLAT) marks a box of zero thickness,
+        // which the filtered slab test must take axis by axis (aabb_classify)
+        const bool flat = b.mn[0] == b.mx[0] || b.mn[1] == b.mx[1] || b.mn[2] == b.mx[2];
+        out[at + 0] = fbits(b.mn[0]); out[at + 1] = fbits(b.mn[1]); out[at + 2] = fbits(b.mn[2]); out[at + 3] = node_count() | (flat ? PT_NODE_FLAT : 0u);
         out[at + 4] = fbits(b.mx[0]); out[at + 5] = fbits(b.mx[1]); out[at + 6] = fbits(b.mx[2]); out[at + 7] = leaf ? idx[0] : PT_NODE_INNER;
         if (leaf) leaf_of_shape[idx[0]] = (uint32_t)(at / PT_NODE_WORDS);
     }
