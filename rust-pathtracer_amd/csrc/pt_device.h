@@ -282,6 +282,28 @@ PT_HD bool beyond(float entry, float closest, float base) { return entry > close
 // with aabb_hit_exact).  Requires rp.fast and no zero direction component.  `flat` (a box of zero thickness, known per leaf
 // on the host) selects the per-axis form above; other boxes use the plain comparison of max entry and min exit, whose
 // approximation error is covered by the same margin.
+PT_HD void aabb_classify2(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry, bool* hit, bool* undecided) {
+    PT_STAT(box_tests);
+    float p0 = approx_fma(a.x, rp.r.x, rp.nor.x), q0 = approx_fma(b.x, rp.r.x, rp.nor.x);
+    float p1 = approx_fma(a.y, rp.r.y, rp.nor.y), q1 = approx_fma(b.y, rp.r.y, rp.nor.y);
+    float p2 = approx_fma(a.z, rp.r.z, rp.nor.z), q2 = approx_fma(b.z, rp.r.z, rp.nor.z);
+    float n0 = __builtin_fminf(p0, q0), x0 = __builtin_fmaxf(p0, q0), n1 = __builtin_fminf(p1, q1), x1 = __builtin_fmaxf(p1, q1);
+    float n2 = __builtin_fminf(p2, q2), x2 = __builtin_fmaxf(p2, q2);
+    if (!flat) {
+        float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(n0, n1), n2), 0.0f), hi = __builtin_fminf(__builtin_fminf(x0, x1), x2);
+        float e = approx_fma(PT_SLAB_EPS, lo + pt_abs(hi), rp.base), gap = lo - hi;
+        *entry = lo;
+        *hit = gap < -e; *undecided = !(gap > e) && !(gap < -e);
+        return;
+    }
+    float m0 = __builtin_fmaxf(__builtin_fmaxf(n1, n2), 0.0f), m1 = __builtin_fmaxf(__builtin_fmaxf(n0, n2), 0.0f), m2 = __builtin_fmaxf(__builtin_fmaxf(n0, n1), 0.0f);
+    float e0 = approx_fma(PT_SLAB_EPS, m0 + pt_abs(x0), rp.base), e1 = approx_fma(PT_SLAB_EPS, m1 + pt_abs(x1), rp.base), e2 = approx_fma(PT_SLAB_EPS, m2 + pt_abs(x2), rp.base);
+    *entry = __builtin_fmaxf(m0, n0);
+    const bool miss = m0 > x0 + e0 || m1 > x1 + e1 || m2 > x2 + e2;
+    *hit = !miss && (m0 < x0 - e0 && m1 < x1 - e1 && m2 < x2 - e2);
+    *undecided = !miss && !*hit;
+}
+// (the same as one three-way value, for the per-lane loops — BVH walk steps, mesh sweep — whose compiled form is better with it)
 PT_HD int aabb_classify(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry) {
     PT_STAT(box_tests);
     float p0 = approx_fma(a.x, rp.r.x, rp.nor.x), q0 = approx_fma(b.x, rp.r.x, rp.nor.x);
@@ -301,7 +323,6 @@ PT_HD int aabb_classify(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry) 
     if (m0 > x0 + e0 || m1 > x1 + e1 || m2 > x2 + e2) return 0;
     return (m0 < x0 - e0 && m1 < x1 - e1 && m2 < x2 - e2) ? 1 : 2;
 }
-
 // The box test of a BVH walk step: the three-way classification when the ray allows it (`quick`: rp.fast and no zero direction
 // component; a non-flat node then takes the cheap form), the per-axis filtered test otherwise; the exact test settles what is left.
 PT_HD bool aabb_hit_node(F4 a, F4 b, const RayPrep& rp, bool quick, float* entry) {
@@ -522,21 +543,23 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
     PT_STAT_RAY(o, d);
     // 1 — the sweep.  `bound` culls leaves that start beyond the distance the caller cares about (shadow rays).
     // A test sets a whole mask: the leaf's bit and the bits of the later leaves of the instance with the very same box (same box,
-    // same ray, same decision; the host folds them into the mask, pt_blob.h).  The masks are wave-uniform, so the halves that are
-    // empty are skipped by scalar branches.
-    auto mark = [&](int c, uint32_t mlo, uint32_t mhi) {
-        if (mlo != 0u) { hit_lo |= c == 1 ? mlo : 0u; unc_lo |= c == 2 ? mlo : 0u; }
-        if (mhi != 0u) { hit_hi |= c == 1 ? mhi : 0u; unc_hi |= c == 2 ? mhi : 0u; }
+    // same ray, same decision; the host folds them into the mask, pt_blob.h).  The decision stays a pair of lane predicates (the
+    // compiler keeps them in scalar registers) and every mask word costs one select-and-or.
+    auto mark = [&](bool h, bool u, uint32_t mlo, uint32_t mhi) {
+        const uint32_t sh = h ? ~0u : 0u, su = u ? ~0u : 0u;
+        hit_lo |= sh & mlo; hit_hi |= sh & mhi; unc_lo |= su & mlo; unc_hi |= su & mhi;
     };
     for (uint32_t j = 0; j < count; ++j) {
         const uint32_t e = PT_UNIFORM(sweep + j * PT_SWEEP_INST_WORDS);
         const F4 h0 = bf4(s, e), a = bf4(s, e + 4), b = bf4(s, e + 8);
         const uint32_t kf = PT_UNIFORM(pt_f2u(h0.y));
         float entry = 0.0f;
-        int c = quick ? aabb_classify(a, b, wr, (kf & 0x100u) != 0, &entry) : 2;
-        if (bounded && c == 1 && cull_top && beyond(entry, bound, wr.base)) c = 0;
-        mark(c, PT_UNIFORM(pt_f2u(h0.z)), PT_UNIFORM(pt_f2u(h0.w)));
-        if ((kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH && (kf >> 24) != 0u && PT_WAVE_ANY(c != 0)) {
+        bool ih = false, iu = true;   // (a ray the filter cannot take: every box is undecided)
+        if (quick) aabb_classify2(a, b, wr, (kf & 0x100u) != 0, &entry, &ih, &iu);
+        if (bounded && cull_top && ih && beyond(entry, bound, wr.base)) ih = false;
+        mark(ih, iu, pt_f2u(h0.z), pt_f2u(h0.w));
+        const bool inside = ih || iu;
+        if ((kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH && (kf >> 24) != 0u && PT_WAVE_ANY(inside)) {
             const uint32_t tl = PT_UNIFORM(pt_f2u(a.w)), tc = kf >> 24;   // the leaves with a box test of their own
             const F4 fl = bf4(s, e + 12);
             const uint32_t flat_lo = PT_UNIFORM(pt_f2u(fl.x)), flat_hi = PT_UNIFORM(pt_f2u(fl.y));
@@ -546,10 +569,10 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
                 for (uint32_t t = 0; t < tc; ++t) {
                     const F4 ta = bf4(s, tl + t * PT_SWEEP_TRI_WORDS), tb = bf4(s, tl + t * PT_SWEEP_TRI_WORDS + 4);
                     const bool flat = (((t < 32u ? flat_lo : flat_hi) >> (t & 31u)) & 1u) != 0u;
-                    int ct = lquick ? aabb_classify(ta, tb, lr, flat, &entry) : 2;
-                    if (bounded && ct == 1 && cull_mesh && beyond(entry, bound, lr.base)) ct = 0;
-                    if (c == 0) ct = 0;
-                    mark(ct, PT_UNIFORM(pt_f2u(ta.w)), PT_UNIFORM(pt_f2u(tb.w)));
+                    bool th = false, tu = true;
+                    if (lquick) aabb_classify2(ta, tb, lr, flat, &entry, &th, &tu);
+                    if (bounded && cull_mesh && th && beyond(entry, bound, lr.base)) th = false;
+                    mark(th && inside, tu && inside, pt_f2u(ta.w), pt_f2u(tb.w));
                 }
             };
             if (kf & 0x200u) {
