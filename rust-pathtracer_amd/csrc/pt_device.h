@@ -282,6 +282,15 @@ PT_HD bool beyond(float entry, float closest, float base) { return entry > close
 // with aabb_hit_exact).  Requires rp.fast and no zero direction component.  `flat` (a box of zero thickness, known per leaf
 // on the host) selects the per-axis form above; other boxes use the plain comparison of max entry and min exit, whose
 // approximation error is covered by the same margin.
+// max(a, b, c, 0) and min(a, b, c) of slab distances: two / one instruction on the device (the compiler's own lowering of the fmaxf
+// chain spends two more on quieting signalling NaNs that arithmetic results cannot be)
+#if defined(__HIP_DEVICE_COMPILE__)
+PT_HD float slab_entry(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, 0, %0" : "=&v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+PT_HD float slab_exit(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+#else
+PT_HD float slab_entry(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a, b), c), 0.0f); }
+PT_HD float slab_exit(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+#endif
 PT_HD void aabb_classify2(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry, bool* hit, bool* undecided) {
     PT_STAT(box_tests);
     float p0 = approx_fma(a.x, rp.r.x, rp.nor.x), q0 = approx_fma(b.x, rp.r.x, rp.nor.x);
@@ -290,7 +299,7 @@ PT_HD void aabb_classify2(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry
     float n0 = __builtin_fminf(p0, q0), x0 = __builtin_fmaxf(p0, q0), n1 = __builtin_fminf(p1, q1), x1 = __builtin_fmaxf(p1, q1);
     float n2 = __builtin_fminf(p2, q2), x2 = __builtin_fmaxf(p2, q2);
     if (!flat) {
-        float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(n0, n1), n2), 0.0f), hi = __builtin_fminf(__builtin_fminf(x0, x1), x2);
+        float lo = slab_entry(n0, n1, n2), hi = slab_exit(x0, x1, x2);
         float e = approx_fma(PT_SLAB_EPS, lo + pt_abs(hi), rp.base), gap = lo - hi;
         *entry = lo;
         *hit = gap < -e; *undecided = !(gap > e) && !(gap < -e);
@@ -312,7 +321,7 @@ PT_HD int aabb_classify(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry) 
     float n0 = __builtin_fminf(p0, q0), x0 = __builtin_fmaxf(p0, q0), n1 = __builtin_fminf(p1, q1), x1 = __builtin_fmaxf(p1, q1);
     float n2 = __builtin_fminf(p2, q2), x2 = __builtin_fmaxf(p2, q2);
     if (!flat) {
-        float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(n0, n1), n2), 0.0f), hi = __builtin_fminf(__builtin_fminf(x0, x1), x2);
+        float lo = slab_entry(n0, n1, n2), hi = slab_exit(x0, x1, x2);
         float e = approx_fma(PT_SLAB_EPS, lo + pt_abs(hi), rp.base), gap = lo - hi;
         *entry = lo;
         return gap > e ? 0 : (gap < -e ? 1 : 2);
