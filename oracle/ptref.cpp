@@ -1714,7 +1714,7 @@ pt_status ptref_render_mt(pt_scene* ps, const pt_render_desc* rdp, float* film, 
     std::memset(film, 0, sizeof(float) * 4 * (size_t)rd.width * rd.height);
     std::vector<TileRect> all = generate_tiles(rd.width, rd.height, rd.tile_width, rd.tile_height), tiles;
     for (size_t t = 0; t < all.size(); ++t)
-        if (rd.shard_count == 0 || t % rd.shard_count == rd.shard_index) tiles.push_back(all[t]);
+        if (rd.shard_count == 0 || PT_TILE_SHARD((uint32_t)t, rd.width / rd.tile_width, rd.shard_count) == rd.shard_index) tiles.push_back(all[t]);
     if (threads == 0) threads = std::thread::hardware_concurrency();
     if (threads == 0) threads = 1;
     auto t0 = std::chrono::steady_clock::now();

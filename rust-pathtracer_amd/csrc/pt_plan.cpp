@@ -16,7 +16,7 @@ std::vector<uint32_t> shard_pixels(uint32_t width, uint32_t height, uint32_t tw,
     }
     std::vector<uint32_t> px;
     for (size_t t = 0; t < tiles.size(); ++t) {
-        if (shard_count && t % shard_count != shard_index) continue;
+        if (shard_count && PT_TILE_SHARD((uint32_t)t, fx, shard_count) != shard_index) continue;
         for (uint32_t y = tiles[t].y0; y < tiles[t].y1; ++y)
             for (uint32_t x = tiles[t].x0; x < tiles[t].x1; ++x) px.push_back(y * width + x);
     }

@@ -1,7 +1,7 @@
-"""Multi-GPU film sharding: one process per GPU, film tiles dealt round-robin to ranks, one reduce.
+"""Multi-GPU film sharding: one process per GPU, film tiles dealt along diagonals to ranks, one reduce.
 
 The renderer itself shards inside the C ABI (`pt_render_desc.shard_index / shard_count`: rank r renders the tiles t of
-the reference's tile order with t % N == r and leaves the rest of its full-size film zero).  This module is the few lines
+the reference's tile order with PT_TILE_SHARD(t) == r — (column + row) mod N — and leaves the rest of its full-size film zero).  This module is the few lines
 of `torch.distributed` plumbing around it, shared by bench.py (backend nccl = RCCL over xGMI) and by the CPU tests
 (backend gloo).  Because shards are disjoint and the RNG is keyed by pixel id, the reduced film is bit-identical to the
 single-process film.
