@@ -14,11 +14,23 @@ std::vector<uint32_t> shard_pixels(uint32_t width, uint32_t height, uint32_t tw,
         for (uint32_t x = 0; x < fx; ++x) tiles.push_back(T{x * tw, x * tw + tw, fy * th, fy * th + ry});
         if (rx) tiles.push_back(T{fx * tw, fx * tw + rx, fy * th, fy * th + ry});
     }
+    std::vector<uint32_t> mine;
+    for (size_t t = 0; t < tiles.size(); ++t)
+        if (!shard_count || PT_TILE_SHARD((uint32_t)t, fx, shard_count) == shard_index) mine.push_back((uint32_t)t);
+    // The order of the tiles in the slot space is free (a pixel's samples are keyed by its id, its sums are its own), and it decides
+    // how evenly the work falls on the workgroups, each of which takes a run of consecutive slots = a few consecutive tiles: in film
+    // order those are neighbours and cost alike (a run of bright floor, a run of dark wall); taken with a stride coprime to their
+    // number (about 0.382 of it), every run mixes tiles from all over the film.
+    const size_t n = mine.size();
+    size_t stride = (size_t)((double)n * 0.3819660112501051);
+    auto gcd = [](size_t a, size_t b) { while (b) { size_t t = a % b; a = b; b = t; } return a; };
+    if (stride < 1) stride = 1;
+    while (gcd(stride, n ? n : 1) != 1) ++stride;
     std::vector<uint32_t> px;
-    for (size_t t = 0; t < tiles.size(); ++t) {
-        if (shard_count && PT_TILE_SHARD((uint32_t)t, fx, shard_count) != shard_index) continue;
-        for (uint32_t y = tiles[t].y0; y < tiles[t].y1; ++y)
-            for (uint32_t x = tiles[t].x0; x < tiles[t].x1; ++x) px.push_back(y * width + x);
+    for (size_t i = 0; i < n; ++i) {
+        const T& tile = tiles[mine[(i * stride) % n]];
+        for (uint32_t y = tile.y0; y < tile.y1; ++y)
+            for (uint32_t x = tile.x0; x < tile.x1; ++x) px.push_back(y * width + x);
     }
     return px;
 }
