@@ -58,7 +58,8 @@ constexpr int kBlock = 256;
 #define PT_PARK_WAVES 4
 #endif
 #define PT_PARK_OCC __attribute__((amdgpu_waves_per_eu(PT_PARK_WAVES)))
-// (forms of k_shade, see the kernel: FULL = PT_SHADE_WAVES / PT_SHADE4_WAVES above; measured with tools/shade_occupancy.sh)
+// (forms of k_shade, see the kernel: FULL = PT_SHADE_WAVES / PT_SHADE4_WAVES above; measured with tools/shade_occupancy.sh.  FULL on C4:
+// 11442 us at 3 waves, 14735 at 2, 11869 at 4; NO_ENV on C3: 3564 at 3 or 2, 3902 at 4)
 #ifndef PT_SHADE_NO_ENV_WAVES
 #define PT_SHADE_NO_ENV_WAVES 3
 #endif
