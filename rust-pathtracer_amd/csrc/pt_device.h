@@ -643,7 +643,9 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
     float limit = __builtin_fminf(st.closest, bound);
     const uint32_t leaf_off = bu(s, mesh + PT_MESH_LEAF_OFF);
     // (bounded searches — light rays, which also stop at the first opaque hit — prune so much of the tree that the walk wins)
-    if (leaf_off != 0u && !(bound < PT_INF) && !(flags & (PT_FLAG_NO_SWEEP | PT_FLAG_NO_MESH_SWEEP))) {
+    // The mesh sweep reads its leaf list with wave-uniform addresses: every lane that takes it must be in the same mesh.  A table
+    // with two walked meshes can resume lanes of both in one wave — those waves walk (same result, lane by lane).
+    if (leaf_off != 0u && !(bound < PT_INF) && !(flags & (PT_FLAG_NO_SWEEP | PT_FLAG_NO_MESH_SWEEP)) && !PT_WAVE_ANY(mesh != PT_UNIFORM(mesh))) {
         // mesh sweep: the leaf-box sweep of world_hit_sweep applied to this mesh, 64 leaves (in pre-order) at a time, each
         // chunk culled by the closest hit the chunks before it left — the same leaves in the same order as the walk below
         const uint32_t leaf_count = PT_UNIFORM(bu(s, mesh + PT_MESH_LEAF_COUNT));

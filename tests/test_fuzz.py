@@ -31,7 +31,10 @@ def test_emulation_bvh_walk_on_random_scenes(emu, oracle, pkg, monkeypatch, seed
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(100, 140)) + [5427])  # 5427: a NaN pixel (NEE from a point of a light to that light), same on both sides
+# 5427: a NaN pixel (NEE from a point of a light to that light), same on both sides; 49682: two walked meshes in one sweep table (an
+# octahedron that no longer fits and the gem) — a wave resumes parked rays of both, and the mesh sweep must not assume one mesh per wave;
+# 30295: pixel values of 3700, whose f32 ulp is above the absolute film bar
+@pytest.mark.parametrize("seed", list(range(100, 140)) + [5427, 49682, 30295])
 def test_engine_on_random_scenes(engine, oracle, pkg, seed):
     run(engine, oracle, pkg, seed, 1 << 14, 48, 40, 4)
 
