@@ -80,6 +80,16 @@ def random_scene(seed):
         p, f, n, _ = S._npz_mesh("gem")
         mesh = b.add_mesh(p, f, n, face_materials=api.material_id(api.TAG_MATERIAL, mats[0] & 0xFFFF))
         b.add_mesh_instance(mesh, mats[rng.integers(len(mats))], S.transform_from_data((0.5, 0.5, 0.5), None, rng.uniform(-0.8, 0.8, 3).tolist()))
+    if seed >= 100000:  # (a seed space of its own, so that the scenes of the seeds already in the tests stay what they are)
+        # several different meshes too big for the sweep table together: a wave resumes parked rays of more than one of them
+        rng2 = np.random.default_rng(seed + 7777)
+        p, f, n, _ = S._npz_mesh("gem")
+        for k in range(int(rng2.integers(1, 4))):
+            scale = rng2.uniform(0.3, 0.7, 3)
+            mesh = b.add_mesh((p * scale.astype(np.float32)).astype(np.float32), f, n if k % 2 == 0 else None,
+                              face_materials=api.material_id(api.TAG_MATERIAL, mats[k % len(mats)] & 0xFFFF))
+            b.add_mesh_instance(mesh, mats[int(rng2.integers(len(mats)))] if rng2.random() < 0.5 else None,
+                                S.transform_from_data(None, None, rng2.uniform(-1.0, 1.0, 3).tolist()) if rng2.random() < 0.7 else None)
     eye = rng.normal(size=3); eye = eye / np.linalg.norm(eye) * rng.uniform(3.0, 6.0); eye[2] = abs(eye[2]) * 0.5
     if rng.random() < 0.2:
         b.add_panorama_camera(eye.tolist(), (0.0, 0.0, 0.0), (float(rng.uniform(60, 360)), float(rng.uniform(40, 180))))

@@ -19,7 +19,7 @@ def run(impl, oracle, pkg, seed, n_rays, w, h, spp):
     ps.check_film(film, ref, prof, rprof)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", list(range(12)) + [100000, 100001])
 def test_emulation_on_random_scenes(emu, oracle, pkg, seed):  # noqa: F811
     run(emu, oracle, pkg, seed, 2048, 20, 16, 3)
 
@@ -34,7 +34,7 @@ def test_emulation_bvh_walk_on_random_scenes(emu, oracle, pkg, monkeypatch, seed
 # 5427: a NaN pixel (NEE from a point of a light to that light), same on both sides; 49682: two walked meshes in one sweep table (an
 # octahedron that no longer fits and the gem) — a wave resumes parked rays of both, and the mesh sweep must not assume one mesh per wave;
 # 30295: pixel values of 3700, whose f32 ulp is above the absolute film bar
-@pytest.mark.parametrize("seed", list(range(100, 140)) + [5427, 49682, 30295])
+@pytest.mark.parametrize("seed", list(range(100, 140)) + [5427, 49682, 30295] + list(range(100000, 100008)))   # >= 100000: several walked meshes per scene
 def test_engine_on_random_scenes(engine, oracle, pkg, seed):
     run(engine, oracle, pkg, seed, 1 << 14, 48, 40, 4)
 
