@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Differential soak on the GPU: engine vs oracle over many seeded random scenes (tests/fuzz_scenes.py), hits bit for bit and
-films within the parity bars.  usage: tools/fuzz_soak.py <first seed> <count>"""
+films within the parity bars.  usage: tools/fuzz_soak.py <first seed> <count> [width height spp]  (default 40 32 3; bigger films give the
+workgroups several rounds per segment and fill the park lists many times over)"""
 import importlib
 import os
 import sys
@@ -14,6 +15,7 @@ import parity_suite as ps  # noqa: E402
 pkg = importlib.import_module("rust-pathtracer_amd")
 engine, oracle = pkg.load(), oracle_loader.load(pkg)
 first, count = int(sys.argv[1]), int(sys.argv[2])
+W, H, SPP = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (40, 32, 3)
 bad, forms = [], {"sweep": 0, "walked": 0, "walk": 0}
 for seed in range(first, first + count):
     try:
@@ -22,7 +24,7 @@ for seed in range(first, first + count):
         se, so = engine.create_scene(b), oracle.create_scene(b)
         forms["sweep" if se.uses_leaf_sweep() else "walk"] += 1
         ps.assert_hits_equal(se.intersect(o, d), so.intersect(o, d))
-        rd = pkg.api.render_desc(40, 32, 3, 6, light_samples=int(1 + seed % 3), seed=seed, hero_wavelengths=4 if seed % 5 == 0 else 1)
+        rd = pkg.api.render_desc(W, H, SPP, 6, light_samples=int(1 + seed % 3), seed=seed, hero_wavelengths=4 if seed % 5 == 0 else 1)
         film, prof = se.render(rd)
         ref, rprof = so.render(rd)
         ps.check_film(film, ref, prof, rprof)
