@@ -207,7 +207,7 @@ def main():
                                                      else "%s %dx%d, PT+NEE, max_bounces=%d, min_bounces=%d, light_samples=%d, %d wavelength(s) per path" %
                                                      (args.scene, W, H, args.max_bounces, args.min_bounces, L, args.hero)),
                        "scene": args.scene, "spp_per_step_per_gpu": args.spp_per_step, "spp_per_step": S, "samples_per_step": total_samples / args.steps,
-                       "parallelism": "film tiles 32x32 round-robin over %d GPU(s), one RCCL reduce of the XYZ film" % n_gpus,
+                       "parallelism": "film tiles 32x32 dealt along diagonals over %d GPU(s), one RCCL reduce of the XYZ film" % n_gpus,
                        "device": engine.device_info()},
             "rays_per_s": {"segments": counts[2] / elapsed, "shadow": counts[7] / elapsed,
                            "total_Mrays": (counts[2] + counts[7]) / elapsed / 1e6},
