@@ -6,7 +6,7 @@ max_bounces = 8, PT + NEE, L = 2), one process per GPU.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one pass of the wavefront pipeline over this rank's film shard at `--spp-per-step` x N samples per pixel
-(weak scaling: tiles are dealt round-robin to ranks, every rank renders 1/N of the pixels at N times the samples, so
+(weak scaling: tiles are dealt along diagonals to ranks, every rank renders 1/N of the pixels at N times the samples, so
 per-GPU work is fixed).  Scene upload, BVH build and buffer allocation happen before the timed region (the window of
 src/renderer/tiled.rs:294 -> 536); the film stays in HBM.  After the last step the rank films are summed into rank 0
 with one RCCL reduce (disjoint shards, so the sum is a gather) inside the timed region.

@@ -323,7 +323,7 @@ def test_cornell_render_is_deterministic_and_thread_independent(pkg, oracle):
 
 
 def test_shards_partition_the_film(pkg, oracle):
-    """Film tiles dealt round-robin to shards: the shard films are disjoint and sum to the whole film exactly."""
+    """Film tiles dealt to shards (PT_TILE_SHARD): the shard films are disjoint and sum to the whole film exactly."""
     sc = oracle.create_scene(pkg.scene.cornell_box())
     whole, _ = sc.render(pkg.api.render_desc(70, 50, 3, 3, tile=(16, 16)))
     acc = np.zeros_like(whole)
