@@ -40,6 +40,17 @@ def test_engine_on_random_scenes(engine, oracle, pkg, seed):
 
 
 @pytest.mark.gpu
+def test_grazing_sphere_light_is_not_culled_by_its_own_bound(engine, oracle, pkg):
+    """Fuzz seed 101684 at 512x384x8: a light-sample ray grazes a sphere light; in f32 the hit lies 2.5e-5 of t in front of the
+    sphere's box, and a cull margin below the error of the sphere's quadratic (4.9e-4 of t) dropped the light."""
+    b = fuzz_scenes.random_scene(101684)
+    rd = pkg.api.render_desc(512, 384, 8, 6, light_samples=3, seed=101684)
+    film, prof = engine.create_scene(b).render(rd)
+    ref, rprof = oracle.create_scene(b).render(rd)
+    ps.check_film(film, ref, prof, rprof)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(200, 210))
 def test_engine_bvh_walk_on_random_scenes(engine, oracle, pkg, monkeypatch, seed):
     monkeypatch.setenv("PT_AMD_NO_SWEEP", "1")
