@@ -112,6 +112,7 @@
 #define PT_FLAG_SWEEP_WALKS 32u   /* the sweep table holds mesh instances whose BVH is walked (hybrid form) */
 #define PT_FLAG_NO_MESH_SWEEP 64u  /* diagnostics (PT_AMD_NO_MESH_SWEEP=1): walk every mesh BVH */
 #define PT_FLAG_NO_SWEEP 16u      /* diagnostics (PT_AMD_NO_SWEEP=1): always walk the BVHs */
+#define PT_FLAG_REPLAY 128u       /* diagnostics (host emulation): phase 3 of the sweep as unbounded tests + ordered replay (the pooled form's logic) */
 #define PT_FLAG_NO_TOP_CULL 1u   /* a Disk instance exists: its reference box (radius/2, disk.rs:24-28) does not contain it */
 
 // Leaf sweep table (world_hit_sweep).  One mask bit per top-level leaf (instance) and per triangle leaf, numbered in
@@ -140,5 +141,7 @@
 #define PT_HDR_IMAP_ROW_GUIDE 60    /* n + 3 entries per table, entry j = first index whose cmf is >= j / n (pt_device.h sample_cmf) */
 #define PT_HDR_CORE_WORDS 61        /* words of the core section; the mesh-data section follows it */
 #define PT_HDR_SWEEP_MESH_MASK 57  /* 2 words: the bits that stand for mesh instances (no primitive of their own) */
+#define PT_HDR_SWEEP_OWNER_MASK 62 /* 2 words: the bits whose primitive test needs the ray itself (analytic shapes, triangles of transformed
+                                      instances); the other bits are triangles tested with the world ray's shear constants (pooled phase 3) */
 
 #endif

@@ -371,8 +371,10 @@ PT_HD TriRay tri_ray_prepare(F3 o, F3 dir) {
     r.os = tri_shuffle(o, kz);
     return r;
 }
-// the test proper, on vertices already translated to the ray origin and permuted (mesh.rs:101-198)
-PT_HD bool triangle_test_core(F3 p0t, F3 p1t, F3 p2t, const TriRay& r, float t0, float t1, TriHit* out) {
+// the test proper, on vertices already translated to the ray origin and permuted (mesh.rs:101-198), in two steps: everything that
+// does not depend on the interval (edge functions with the f64 fallback, sign test, determinant, scaled distance) ...
+struct TriEdges { float e0, e1, e2, det, ts; };
+PT_HD bool triangle_edges(F3 p0t, F3 p1t, F3 p2t, const TriRay& r, TriEdges* g) {
     PT_STAT(tri_tests);
     float sx = r.sx, sy = r.sy, sz = r.sz;
     p0t.x += sx * p0t.z; p1t.x += sx * p1t.z; p2t.x += sx * p2t.z;
@@ -392,13 +394,21 @@ PT_HD bool triangle_test_core(F3 p0t, F3 p1t, F3 p2t, const TriRay& r, float t0,
     float det = e0 + e1 + e2;
     if (det == 0.0f) return false;
     p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
-    float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
-    if ((det < 0.0f && (t_scaled >= t0 * det || t_scaled < t1 * det)) ||
-        (det > 0.0f && (t_scaled <= t0 * det || t_scaled > t1 * det)))
-        return false;
-    float inv_det = 1.0f / det;
-    out->b0 = e0 * inv_det; out->b1 = e1 * inv_det; out->b2 = e2 * inv_det;
-    out->t = t_scaled * inv_det;
+    g->e0 = e0; g->e1 = e1; g->e2 = e2; g->det = det;
+    g->ts = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    return true;
+}
+// ... and the interval test in its scaled form (mesh.rs:150-158): true when (ts, det) lies outside (t0, t1]
+PT_HD bool triangle_outside(float ts, float det, float t0, float t1) {
+    return (det < 0.0f && (ts >= t0 * det || ts < t1 * det)) || (det > 0.0f && (ts <= t0 * det || ts > t1 * det));
+}
+PT_HD bool triangle_test_core(F3 p0t, F3 p1t, F3 p2t, const TriRay& r, float t0, float t1, TriHit* out) {
+    TriEdges g;
+    if (!triangle_edges(p0t, p1t, p2t, r, &g)) return false;
+    if (triangle_outside(g.ts, g.det, t0, t1)) return false;
+    float inv_det = 1.0f / g.det;
+    out->b0 = g.e0 * inv_det; out->b1 = g.e1 * inv_det; out->b2 = g.e2 * inv_det;
+    out->t = g.ts * inv_det;
     return true;
 }
 PT_HD bool triangle_test(F3 p0, F3 p1, F3 p2, const TriRay& r, float t0, float t1, TriHit* out) {
@@ -794,11 +804,187 @@ PT_HD bool sweep_finish(const SceneView& s, F3 o, F3 d, const SweepState& st, Hi
     hit_record(s, o, d, st.best_inst, st.best_triw, st.bh, out);
     return true;
 }
+// ---- phase 3 as independent tests + ordered replay ------------------------------------------------------------------
+// The per-lane loop of sweep_run is sequential only through `closest`: a candidate is accepted iff its distance lies in the
+// interval that ends at the closest hit so far (triangle: the scaled comparison of mesh.rs:150-158; rect / disk: t <= closest;
+// sphere: t < closest, the nearer root first).  Everything else a primitive test computes depends on the ray and the primitive
+// alone.  So a candidate can be tested on its own against the unbounded interval — by ANY lane — leaving a record (t, scaled
+// t, determinant), and the acceptance decisions are then replayed per ray in leaf order from the records: the same
+// comparisons on the same numbers, the same closest hit, ties to the earlier leaf.  The wave pools the candidates of its 64 rays
+// and tests them 64 at a time (sweep_run_pooled below): the expensive part runs with full waves, the sequential part is a few
+// instructions per candidate.  No early stop: the replay finds the reference's closest hit, of which the early-stop forms only
+// use "is it a light / is there one" (DESIGN.md section 5).
+struct CandRec { float t, ts, det; uint32_t info; };  // det == 0: never accepted.  info: owner lane | mask bit << 8 | flags
+#define PT_CAND_STRICT 0x10000u                        // sphere: accepted iff t < closest (sphere.rs:34-87); the others iff !(t > closest)
+PT_HD CandRec cand_none() { CandRec r; r.t = 0.0f; r.ts = 0.0f; r.det = 0.0f; r.info = 0u; return r; }
+// a triangle leaf of the table against a ray given by its shear constants (tr.os, tr.kz, tr.sx..sz)
+PT_HD CandRec cand_test_triangle(const SceneView& s, uint32_t bits_off, uint32_t k, const TriRay& tr) {
+    const F4 be = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS), bp = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS + 4);
+    const uint32_t tp = pt_f2u(be.y) + (tr.kz == 0u ? pt_f2u(bp.z) : (tr.kz == 1u ? pt_f2u(bp.w) : 0u));
+    const F4 q0 = mf4(s, tp), q1 = mf4(s, tp + 4), q2 = mf4(s, tp + 8);
+    CandRec r = cand_none();
+    TriEdges g;
+    if (!triangle_edges(sub(f3(q0.x, q0.y, q0.z), tr.os), sub(f3(q1.x, q1.y, q1.z), tr.os), sub(f3(q2.x, q2.y, q2.z), tr.os), tr, &g)) return r;
+    if (triangle_outside(g.ts, g.det, 0.0f, PT_INF)) return r;
+    r.t = g.ts * (1.0f / g.det); r.ts = g.ts; r.det = g.det;
+    return r;
+}
+// a leaf whose test needs the ray itself: an analytic shape, or a triangle of a transformed instance
+PT_HD CandRec cand_test_owner(const SceneView& s, uint32_t bits_off, uint32_t k, F3 o, F3 d) {
+    const F4 be = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS);
+    const uint32_t inst = pt_f2u(be.x), triw = pt_f2u(be.y), kf = pt_f2u(be.w);
+    F3 lo, ld;
+    instance_local_ray(s, inst, o, d, &lo, &ld);
+    if (triw != 0u) return cand_test_triangle(s, bits_off, k, tri_ray_prepare(lo, ld));
+    CandRec r = cand_none();
+    Hit h;
+    PT_STAT_EVENT(4);
+    if (analytic_hit(s, inst, kf & 0xffu, lo, ld, PT_INF, &h)) {
+        r.t = h.t; r.ts = h.t; r.det = 1.0f;   // rect.rs / disk.rs: rejected iff t > t1 -- the scaled comparison with det = 1
+        if ((kf & 0xffu) == PT_SHAPE_SPHERE) r.info = PT_CAND_STRICT;
+    }
+    return r;
+}
+PT_HD bool cand_accepts(const CandRec& r, float closest) {
+    if (r.det == 0.0f) return false;
+    if (r.info & PT_CAND_STRICT) return r.t < closest;
+    return !(r.det < 0.0f ? r.ts < closest * r.det : r.ts > closest * r.det);
+}
+// the winner's place in the running state (barycentrics: the accepted test again, its numbers do not depend on the interval)
+PT_HD void cand_winner(const SceneView& s, uint32_t bits_off, uint32_t k, F3 o, F3 d, const TriRay& wtr, float t, SweepState& st) {
+    const F4 be = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS), bp = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS + 4);
+    const uint32_t inst = pt_f2u(be.x), triw = pt_f2u(be.y), kf = pt_f2u(be.w);
+    st.closest = t; st.best_inst = kf >> 16; st.best_triw = triw;
+    if (triw == 0u) return;
+    TriRay ltr;
+    if (kf & 0x200u) { F3 lo, ld; instance_local_ray(s, inst, o, d, &lo, &ld); ltr = tri_ray_prepare(lo, ld); }
+    const TriRay& tr = (kf & 0x200u) ? ltr : wtr;
+    const uint32_t tp = triw + (tr.kz == 0u ? pt_f2u(bp.z) : (tr.kz == 1u ? pt_f2u(bp.w) : 0u));
+    const F4 q0 = mf4(s, tp), q1 = mf4(s, tp + 4), q2 = mf4(s, tp + 8);
+    triangle_test_permuted(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, PT_INF, &st.bh);
+}
+// One ray on its own (host emulation, PT_FLAG_REPLAY): the records of its set bits, then the replay.
+PT_HD void sweep_run_replay(const SceneView& s, F3 o, F3 d, const TriRay& wtr, SweepState& st) {
+    const uint32_t bits_off = bu(s, PT_HDR_SWEEP_BITS_OFF);
+    const uint64_t owner_mask = (uint64_t)bu(s, PT_HDR_SWEEP_OWNER_MASK) | (uint64_t)bu(s, PT_HDR_SWEEP_OWNER_MASK + 1) << 32;
+    CandRec recs[PT_SWEEP_MAX_BITS];
+    uint32_t n = 0;
+    for (uint64_t m = st.hit; m != 0; m &= m - 1) {
+        const uint32_t k = ctz64(m);
+        CandRec r;
+        if ((owner_mask >> k) & 1ull) r = cand_test_owner(s, bits_off, k, o, d);
+        else { PT_STAT_EVENT(3); r = cand_test_triangle(s, bits_off, k, wtr); }
+        r.info |= k << 8;
+        recs[n++] = r;
+    }
+    st.hit = 0;
+    uint32_t best = 0xffffffffu; float t = PT_INF;
+    for (uint32_t i = 0; i < n; ++i)
+        if (cand_accepts(recs[i], t)) { t = recs[i].t; best = (recs[i].info >> 8) & 63u; }
+    if (best != 0xffffffffu) cand_winner(s, bits_off, best, o, d, wtr, t, st);
+}
+
+#if defined(PT_WAVE_KERNELS)   /* defined by pt_engine.hip, after <hip/hip_runtime.h> */
+// Inclusive prefix sum over the wave (all 64 lanes must be active): row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast15
+// into rows 1 and 3 and row_bcast31 into rows 2 and 3.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+// Per-wave scratch in LDS, in 32-bit words: 64 ray records of 8 words (o permuted, kz, shear constants), PT_POOL_PAIRS candidate
+// records of 4 words, PT_POOL_PAIRS bytes listing the records that are triangle tests.
+#define PT_POOL_PAIRS 192u
+#define PT_POOL_WORDS (64u * 8u + PT_POOL_PAIRS * 4u + PT_POOL_PAIRS / 4u)
+// Phase 3 for the 64 rays of a wave together.  Every lane of the wave must call it (a lane without a ray passes st.hit == 0).
+// Rounds: as many rays, in lane order, as have room for all their candidates in the pool; normally one round.
+// (EXP: measurement variants that leave parts out, tools/phase_costs.sh; 0 in the product)
+template <int EXP = 0>
+__device__ __forceinline__ void sweep_run_pooled(const SceneView& s, uint32_t* ws, F3 o, F3 d, const TriRay& wtr, SweepState& st) {
+    const uint32_t lane = __lane_id();
+    uint4* rays = reinterpret_cast<uint4*>(ws);
+    uint4* pool = rays + 128;
+    uint8_t* pairs = reinterpret_cast<uint8_t*>(pool + PT_POOL_PAIRS);
+    const uint32_t bits_off = bu(s, PT_HDR_SWEEP_BITS_OFF);
+    const uint64_t owner_mask = (uint64_t)bu(s, PT_HDR_SWEEP_OWNER_MASK) | (uint64_t)bu(s, PT_HDR_SWEEP_OWNER_MASK + 1) << 32;
+    rays[2 * lane] = make_uint4(pt_f2u(wtr.os.x), pt_f2u(wtr.os.y), pt_f2u(wtr.os.z), wtr.kz);
+    rays[2 * lane + 1] = make_uint4(pt_f2u(wtr.sx), pt_f2u(wtr.sy), pt_f2u(wtr.sz), 0u);
+    uint64_t pending = st.hit;
+    st.hit = 0;
+    uint32_t best = 0xffffffffu; float closest = PT_INF;
+    while (__builtin_amdgcn_ballot_w64(pending != 0) != 0) {
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(pending), tcnt = (uint32_t)__builtin_popcountll(pending & ~owner_mask);
+        const uint32_t incl = wave_inclusive_scan(cnt | tcnt << 16);
+        const bool in = (incl & 0xffffu) <= PT_POOL_PAIRS;   // a prefix of the lanes (the sums do not decrease), never empty (cnt <= 64)
+        const uint32_t nin = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+        const uint32_t tri_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(nin - 1u)) >> 16;
+        const uint32_t off = (incl & 0xffffu) - cnt;
+        if (in && cnt != 0u && !(EXP & 0x40)) {
+            // the ray's candidates in leaf order: which bit each record stands for, and the list of the pooled ones
+            uint32_t pos = off, tpos = (incl >> 16) - tcnt;
+            for (uint64_t m = pending; m != 0; m &= m - 1, ++pos) {
+                const uint32_t k = ctz64(m);
+                reinterpret_cast<uint32_t*>(pool + pos)[3] = lane | k << 8;
+                if (!((owner_mask >> k) & 1ull)) pairs[tpos++] = (uint8_t)pos;
+            }
+            // the candidates that need the ray itself: tested here, by their owner
+            for (uint64_t m = pending & owner_mask; m != 0; m &= m - 1) {
+                const uint32_t k = ctz64(m);
+                CandRec r = cand_test_owner(s, bits_off, k, o, d);
+                pool[off + (uint32_t)__builtin_popcountll(pending & ((1ull << k) - 1ull))] = make_uint4(pt_f2u(r.t), pt_f2u(r.ts), pt_f2u(r.det), r.info | lane | k << 8);
+            }
+        }
+        __threadfence_block();
+        // the pooled triangle tests, 64 at a time, whoever the ray belongs to
+        for (uint32_t c = 0; c < tri_total && !(EXP & 0x8); c += 64u) {
+            const uint32_t idx = c + lane;
+            if (idx < tri_total) {
+                const uint32_t p = pairs[idx];
+                const uint32_t info = reinterpret_cast<const uint32_t*>(pool + p)[3];
+                const uint4 r0 = rays[2u * (info & 63u)], r1 = rays[2u * (info & 63u) + 1u];
+                TriRay tr;
+                tr.os = f3(pt_u2f(r0.x), pt_u2f(r0.y), pt_u2f(r0.z)); tr.kz = r0.w; tr.sx = pt_u2f(r1.x); tr.sy = pt_u2f(r1.y); tr.sz = pt_u2f(r1.z);
+                tr.o = tr.os;  // (not used by the permuted test)
+                const CandRec r = cand_test_triangle(s, bits_off, (info >> 8) & 63u, tr);
+                pool[p] = make_uint4(pt_f2u(r.t), pt_f2u(r.ts), pt_f2u(r.det), info);
+            }
+        }
+        __threadfence_block();
+        if (in && cnt != 0u) {
+            for (uint32_t i = 0; i < cnt && !(EXP & 0x10); ++i) {
+                const uint4 q = pool[off + i];
+                CandRec r; r.t = pt_u2f(q.x); r.ts = pt_u2f(q.y); r.det = pt_u2f(q.z); r.info = q.w;
+                if (cand_accepts(r, closest)) { closest = r.t; best = (q.w >> 8) & 63u; }
+            }
+            pending = 0;
+        }
+        __threadfence_block();  // the records are consumed before a next round overwrites them
+    }
+    if (EXP & 0x20) { st.closest = closest; st.best_inst = best; return; }
+    if (best != 0xffffffffu) cand_winner(s, bits_off, best, o, d, wtr, closest, st);
+}
+#endif
+
+// Whether the closest hit a sweep found carries a Light-tagged material (the instance's override, else the triangle's own).
+PT_HD bool sweep_best_is_light(const SceneView& s, const SweepState& st) {
+    const uint32_t inst = bu(s, PT_HDR_INSTANCE_OFF) + st.best_inst * PT_INST_WORDS;
+    uint32_t m = bu(s, inst + PT_INST_MATERIAL);
+    if (m == PT_MATERIAL_NONE) m = st.best_triw != 0u ? pt_f2u(mf4(s, st.best_triw).w) : PT_MATERIAL_ID(PT_TAG_MATERIAL, 0);
+    return PT_MATERIAL_TAG(m) == PT_TAG_LIGHT;
+}
 template <bool WALKS = true>
 PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, int stop) {
     SweepState st;
     sweep_state_init(st, sweep_masks(s, o, d, bound));
     const TriRay wtr = tri_ray_prepare(o, d);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if ((bu(s, PT_HDR_FLAGS) & (PT_FLAG_REPLAY | PT_FLAG_SWEEP_WALKS)) == PT_FLAG_REPLAY) { sweep_run_replay(s, o, d, wtr, st); return sweep_finish(s, o, d, st, out); }
+#endif
     sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, false);
     return sweep_finish(s, o, d, st, out);
 }

@@ -14,13 +14,14 @@
 #include <string>
 #include <vector>
 
+#include "pt_kernels.h"   /* first: it switches on the wave-level device code of pt_device.h */
 #include "../../include/pt_api.h"
 #include "pt_error.h"
 #include "pt_plan.h"
 #include "pt_scene_host.h"
-#include "pt_stages.h"
 
 using namespace ptd;
+using namespace ptk;
 
 namespace {
 
@@ -38,386 +39,6 @@ namespace {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                                    \
     } while (0)
 
-constexpr int kBlock = 256;
-// Register budgets: the number of waves per SIMD the compiler must leave room for (1 = no constraint), per kernel form.
-// Measured on MI355X (tools/occupancy_sweep.sh): the traversal kernels are VALU-issue bound and gain from a
-// 5th wave; k_shade is a large body (196 VGPRs unconstrained = 2 waves) that gains from a 3rd wave and loses with a 4th.
-#ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 3
-#endif
-#ifndef PT_SHADE4_WAVES
-#define PT_SHADE4_WAVES 2
-#endif
-#ifndef PT_SWEEP_WAVES
-#define PT_SWEEP_WAVES 5
-#endif
-#ifndef PT_WALK_WAVES
-#define PT_WALK_WAVES 1
-#endif
-#ifndef PT_PARK_WAVES
-#define PT_PARK_WAVES 4
-#endif
-#define PT_PARK_OCC __attribute__((amdgpu_waves_per_eu(PT_PARK_WAVES)))
-// (forms of k_shade, see the kernel: FULL = PT_SHADE_WAVES / PT_SHADE4_WAVES above; measured with tools/shade_occupancy.sh.  FULL on C4:
-// 11442 us at 3 waves, 14735 at 2, 11869 at 4; NO_ENV on C3: 3564 at 3 or 2, 3902 at 4)
-#ifndef PT_SHADE_NO_ENV_WAVES
-#define PT_SHADE_NO_ENV_WAVES 3
-#endif
-#ifndef PT_SHADE4_NO_ENV_WAVES
-#define PT_SHADE4_NO_ENV_WAVES 3   // 6082 us at 3 waves, 7029 at 2, 6759 unconstrained (C5 before the lean form existed)
-#endif
-#ifndef PT_SHADE_LEAN_WAVES
-#define PT_SHADE_LEAN_WAVES 3      // 126 VGPRs without a constraint = 4 waves; 5 waves spill (3892 vs 2866 us)
-#endif
-#ifndef PT_SHADE4_LEAN_WAVES
-#define PT_SHADE4_LEAN_WAVES 2     // C5: 3885 us at 2 waves, 4142 at 3-4, 4830 at 5
-#endif
-#define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(NL == 1 ? (FORM == 2 ? PT_SHADE_WAVES : FORM == 1 ? PT_SHADE_NO_ENV_WAVES : PT_SHADE_LEAN_WAVES) \
-                                                                : (FORM == 2 ? PT_SHADE4_WAVES : FORM == 1 ? PT_SHADE4_NO_ENV_WAVES : PT_SHADE4_LEAN_WAVES))))
-#define PT_TRAV_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? PT_SWEEP_WAVES : PT_WALK_WAVES)))
-constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // stage the blob in LDS when it fits (keeps >= 2 workgroups per CU)
-
-enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_ACCUMULATE, ST_COUNT };
-
-// ------------------------------------------------------------------------------------------------ kernels
-// Every kernel is a persistent grid: blocks stage the scene blob into LDS (when USE_LDS), then walk the queue
-// with a grid stride.  Queue lengths live in device memory (`counts`), so no host round trip between bounces.
-// USE_LDS: 0 = everything is read from HBM/L2; 1 = the whole blob is copied to LDS; 2 = only the core section is (curves,
-// materials, instances, top-level BVH, sweep table: the words every lane keeps re-reading), the mesh data stays in HBM/L2
-// — scenes whose meshes do not fit the LDS budget but whose core does (C4: 470 KB of monkey, 24 KB of core).
-enum { PT_LDS_NONE = 0, PT_LDS_ALL = 1, PT_LDS_CORE = 2 };
-template <int USE_LDS>
-__device__ __forceinline__ SceneView stage_scene(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* tex, uint32_t* lds) {
-    SceneView s;
-    s.tex = tex;
-    const uint32_t core_words = blob[PT_HDR_CORE_WORDS];
-    if (USE_LDS != PT_LDS_NONE) {
-        const uint32_t words = USE_LDS == PT_LDS_ALL ? blob_words : core_words;
-        const uint4* src = reinterpret_cast<const uint4*>(blob);
-        uint4* dst = reinterpret_cast<uint4*>(lds);
-        for (uint32_t i = threadIdx.x; i < words / 4; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-        s.w = lds;
-        s.m = USE_LDS == PT_LDS_ALL ? lds + core_words : blob + core_words;
-    } else {
-        s.w = blob;
-        s.m = blob + core_words;
-    }
-    return s;
-}
-
-__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
-
-// ---- segmented queues -------------------------------------------------------------------------------------------
-// Every queue is cut into gridDim.x segments of `seg_cap` items; workgroup b owns segment b in every kernel of a pass:
-// it reads items [b*seg_cap, b*seg_cap + count_in[b]) and appends its survivors, compacted, to the same segment of the
-// output queue.  Compaction is a wave64 ballot + one LDS atomic per wave (shared_append) — no global atomics (a single hot
-// queue head saturates at ~88 returning atomics/us on MI355X, which was the whole cost of the first version of k_shade)
-// and no barrier; each wave's writes are one contiguous run per field.  The four waves of a workgroup stride through the
-// shared segment, which balances them; survival is statistically uniform over segments, which balances the workgroups.
-// Append without a barrier: one LDS atomic per wave claims the wave's run in the workgroup's segment.  The order of the
-// waves' runs inside the segment then depends on timing, which no result depends on (every queue item is processed on its
-// own; energy and film sums are keyed by slot and pixel).  Measured on k_shade: -6 % against block_append's barrier.
-__device__ __forceinline__ uint32_t shared_append(bool flag, uint32_t* lds_head) {
-    unsigned long long mask = __ballot(flag);
-    uint32_t start = 0;
-    if (lane_id() == 0 && mask != 0ull) start = atomicAdd(lds_head, (uint32_t)__popcll(mask));
-    start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
-    return start + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
-}
-__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    return v;  // valid in lane 0
-}
-
-// Per-workgroup statistics (Profile counters), owned by the workgroup: plain read-modify-write, summed on the host.
-enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_FIELDS };
-
-template <int NL>
-__global__ void __launch_bounds__(kBlock) k_generate(RenderParams rp, const uint32_t* __restrict__ pixels, Queue paths, float* __restrict__ energy,
-                                                    uint32_t n, uint32_t seg_cap, uint32_t* __restrict__ count_out) {
-    uint32_t base = blockIdx.x * seg_cap;
-    uint32_t cnt = base < n ? (n - base < seg_cap ? n - base : seg_cap) : 0u;
-    for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x) {
-        uint32_t slot = base + j;
-        uint32_t pixel = pixels[slot % rp.chunk_pixels];
-        PathVertexT<NL> p = stage_generate<NL>(rp, slot, pixel);
-        store_path<NL>(paths, slot, p);
-        for (int k = 0; k < NL; ++k) energy[(size_t)k * rp.energy_stride + slot] = 0.0f;
-    }
-    if (threadIdx.x == 0) count_out[blockIdx.x] = cnt;
-}
-
-template <int USE_LDS, int TRAV>
-__global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_extend(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
-                                                  Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
-    extern __shared__ __align__(16) uint32_t lds[];
-    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
-    uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
-    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
-        uint32_t i = base + j;
-        F3 o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
-        F3 d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
-        Hit h;
-        world_hit<TRAV>(s, o, d, &h);
-        store_hit(hits, i, h);
-    }
-}
-
-// FORM: what the scene can need at a vertex, so that the rest is compiled out (registers and code size, never results):
-// PT_SHADE_LEAN = no light sample picks the environment (env_sampling_probability = 0) and no GGX material (the Cornell box of C2 / C5),
-// PT_SHADE_NO_ENV = any material, PT_SHADE_FULL = everything.
-enum { PT_SHADE_LEAN = 0, PT_SHADE_NO_ENV = 1, PT_SHADE_FULL = 2 };
-template <int USE_LDS, int NL, int FORM>
-__global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
-                                                 RenderParams rp, uint32_t bounce, const uint32_t* __restrict__ pixels,
-                                                 Queue paths_in, Queue hits, Queue paths_out, Queue shadow, float* __restrict__ energy,
-                                                 uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ count_out,
-                                                 uint32_t* __restrict__ shadow_count, unsigned long long* __restrict__ block_stats) {
-    extern __shared__ __align__(16) uint32_t lds[];
-    __shared__ uint32_t lds_counts[16];  // [0] path queue head, [1] item queue head, [4..6] statistics
-    if (threadIdx.x < 16) lds_counts[threadIdx.x] = 0;
-    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);  // (barrier inside when staging; one below otherwise)
-    if (USE_LDS == PT_LDS_NONE) __syncthreads();
-    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
-    uint32_t st_vertices = 0, st_shadow = 0, st_env = 0;
-    const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
-    for (uint32_t r = 0; r < rounds; ++r) {  // whole waves stay in the loop: the appends are ballots
-        uint32_t j = r * blockDim.x + threadIdx.x;
-        bool active = j < n;
-        uint32_t i = base + j;
-        PathVertexT<NL> pv; Hit hit; hit.valid = false;
-        bool wants_item = false;
-        if (active) {
-            pv = load_path<NL>(paths_in, i);
-            hit = load_hit(hits, i);
-            wants_item = shade_wants_item(s, rp, hit);
-        }
-        // reserve the light-sample item first, so its rays stream straight from registers to the queue
-        uint32_t ipos = base + shared_append(wants_item, &lds_counts[1]);
-        ShadeOutT<NL> out;
-        out.survives = false; out.has_item = false; out.vertex_pushed = false; out.env_hit = false; out.shadow_count = 0; out.add_energy = false; out.env_mask = 0;
-        if (active) {
-            uint32_t pixel = pixels[pv.slot % rp.chunk_pixels];
-            out = stage_shade<NL, FORM == PT_SHADE_FULL, FORM != PT_SHADE_LEAN>(s, rp, bounce, pv, hit, pixel, [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(shadow, ipos, l, ray); });
-            if (wants_item) {
-                float lam[NL]; lam[0] = pv.lambda;
-                if (NL > 1) hero_lambdas<NL>(rp, pt_draw4(rp.seed, pixel, rp.first_sample + pv.slot / rp.chunk_pixels, PT_DIM_FILM).z, lam);
-                qsu(shadow, Layout<NL>::sh_slot, ipos, pv.slot); qsu(shadow, Layout<NL>::sh_flags, ipos, out.env_mask);
-                for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_lambda + k, ipos, lam[k]);
-                if (!out.has_item) clear_shadow_item<NL>(shadow, ipos, rp.light_samples);  // vertex dropped (NaN pdf, utils.rs:261-263)
-            }
-            if (out.add_energy) for (int k = 0; k < NL; ++k) energy[(size_t)k * rp.energy_stride + pv.slot] += out.energy_add[k];
-        }
-        uint32_t pos = base + shared_append(out.survives, &lds_counts[0]);
-        if (out.survives) store_path<NL>(paths_out, pos, out.next);
-        st_vertices += out.vertex_pushed ? 1u : 0u; st_env += out.env_hit ? 1u : 0u; st_shadow += out.shadow_count;
-    }
-    // workgroup totals -> this workgroup's statistics record
-    st_vertices = wave_reduce_add(st_vertices); st_shadow = wave_reduce_add(st_shadow); st_env = wave_reduce_add(st_env);
-    if (lane_id() == 0) { atomicAdd(&lds_counts[4], st_vertices); atomicAdd(&lds_counts[5], st_shadow); atomicAdd(&lds_counts[6], st_env); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        count_out[blockIdx.x] = lds_counts[0]; shadow_count[blockIdx.x] = lds_counts[1];
-        unsigned long long* bs = block_stats + (size_t)blockIdx.x * BS_FIELDS;
-        bs[BS_VERTICES] += lds_counts[4]; bs[BS_SHADOW_RAYS] += lds_counts[5]; bs[BS_ENV_HITS] += lds_counts[6];
-        bs[BS_SEGMENTS] += n;
-        bs[BS_ITEMS] += lds_counts[1];
-    }
-}
-
-template <int USE_LDS, int NL, int TRAV, bool ENV = true>
-__global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
-                                                  uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
-                                                  uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
-    extern __shared__ __align__(16) uint32_t lds[];
-    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
-    uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
-    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
-        stage_shadow_item<NL, TRAV, ENV>(s, light_samples, shadow, base + j, energy, energy_stride);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ parked traversal
-// Scenes whose sweep table holds walked meshes (PT_FLAG_SWEEP_WALKS: a few analytic shapes and small meshes around one or
-// more big meshes — the gem in the Cornell room, the monkey under the HDRI).  Most rays never enter a big mesh's box, and
-// the ones that do are scattered over the waves, so walking the mesh in line would leave a wave waiting for a handful of
-// lanes.  Instead a lane that reaches a walked-mesh bit *parks* its sweep state in the workgroup's scratch region, and
-// whenever a wave has 64 rays parked (and at the end) it resumes them together: a full wave, every lane in a mesh walk.  Nothing about a ray's own sequence of tests changes (same leaves, same order, same running closest hit).
-constexpr uint32_t kParkCap = 512, kParkFields = 16;
-enum { PK_ITEM, PK_HIT_LO, PK_HIT_HI, PK_CLOSEST, PK_BEST_INST, PK_BEST_TRIW, PK_T, PK_B0, PK_B1, PK_B2, PK_RAY, PK_BOUND, PK_KIND };
-__device__ __forceinline__ void park_store(uint32_t* pk, uint32_t e, uint32_t item, const SweepState& st, uint32_t ray, float bound, uint32_t kind) {
-    pk[PK_ITEM * kParkCap + e] = item; pk[PK_HIT_LO * kParkCap + e] = (uint32_t)st.hit; pk[PK_HIT_HI * kParkCap + e] = (uint32_t)(st.hit >> 32);
-    pk[PK_CLOSEST * kParkCap + e] = pt_f2u(st.closest); pk[PK_BEST_INST * kParkCap + e] = st.best_inst; pk[PK_BEST_TRIW * kParkCap + e] = st.best_triw;
-    pk[PK_T * kParkCap + e] = pt_f2u(st.bh.t); pk[PK_B0 * kParkCap + e] = pt_f2u(st.bh.b0); pk[PK_B1 * kParkCap + e] = pt_f2u(st.bh.b1); pk[PK_B2 * kParkCap + e] = pt_f2u(st.bh.b2);
-    pk[PK_RAY * kParkCap + e] = ray; pk[PK_BOUND * kParkCap + e] = pt_f2u(bound); pk[PK_KIND * kParkCap + e] = kind;
-}
-__device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32_t* item, SweepState* st, uint32_t* ray, float* bound, uint32_t* kind) {
-    *item = pk[PK_ITEM * kParkCap + e]; st->hit = (uint64_t)pk[PK_HIT_LO * kParkCap + e] | (uint64_t)pk[PK_HIT_HI * kParkCap + e] << 32;
-    st->closest = pt_u2f(pk[PK_CLOSEST * kParkCap + e]); st->best_inst = pk[PK_BEST_INST * kParkCap + e]; st->best_triw = pk[PK_BEST_TRIW * kParkCap + e];
-    st->bh.t = pt_u2f(pk[PK_T * kParkCap + e]); st->bh.b0 = pt_u2f(pk[PK_B0 * kParkCap + e]); st->bh.b1 = pt_u2f(pk[PK_B1 * kParkCap + e]); st->bh.b2 = pt_u2f(pk[PK_B2 * kParkCap + e]);
-    *ray = pk[PK_RAY * kParkCap + e]; *bound = pt_u2f(pk[PK_BOUND * kParkCap + e]); *kind = pk[PK_KIND * kParkCap + e];
-}
-// The resume loop shared by both kernels, per WAVE: every wave of the workgroup parks into its own quarter of the scratch
-// region (128 entries: fewer than 64 left over + at most 64 new per step) and resumes 64 parked rays at a time — full
-// waves — with no workgroup barrier anywhere: a wave that is deep in a mesh never holds the other three up.  (The first
-// version parked per workgroup with three barriers per drain; rocprofv3 showed the C4 shadow kernel waiting 68 % of its
-// wave cycles at 12 % VALU issue.)
-constexpr uint32_t kWaveParkCap = kParkCap / (kBlock / 64);
-template <typename Resume>
-__device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, bool last, Resume&& resume) {
-    const uint32_t lane = lane_id();
-    for (;;) {
-        __threadfence_block();             // this wave's parked entries are visible to its other lanes
-        const uint32_t cnt = *park_count;  // the same for every lane of the wave
-        if (!(cnt >= 64u || (last && cnt > 0u))) break;
-        const uint32_t take = cnt < 64u ? cnt : 64u, first = cnt - take;
-        const bool mine = lane < take;
-        uint32_t item = 0, ray = 0, kind = 0; float bound = PT_INF; SweepState st;
-        if (mine) park_load(pk, first + lane, &item, &st, &ray, &bound, &kind);
-        __threadfence_block();             // entries are in registers before any lane parks again into these slots
-        if (lane == 0) *park_count = first;
-        if (mine) resume(item, st, ray, bound, kind);
-    }
-}
-
-template <int USE_LDS>
-__global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
-                                                                     Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
-                                                                     uint32_t* __restrict__ park_all) {
-    extern __shared__ __align__(16) uint32_t lds[];
-    __shared__ uint32_t park_counts[kBlock / 64];
-    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
-    const uint32_t wave = threadIdx.x >> 6;
-    uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap + wave * kWaveParkCap;  // field f of entry e at pk[f * kParkCap + e]
-    uint32_t* park_count = &park_counts[wave];
-    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
-    const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
-    if (lane_id() == 0) *park_count = 0;
-    auto ray_of = [&](uint32_t i, F3* o, F3* d) {
-        *o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
-        *d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
-    };
-    auto settle = [&](uint32_t j, F3 o, F3 d, const SweepState& st, bool parked) {
-        if (parked) park_store(pk, atomicAdd(park_count, 1u), j, st, 0u, PT_INF, 0u);
-        else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, base + j, h); }
-    };
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t j = r * blockDim.x + threadIdx.x;
-        if (j < n) {
-            F3 o, d;
-            ray_of(base + j, &o, &d);
-            SweepState st;
-            sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
-            const TriRay wtr = tri_ray_prepare(o, d);
-            settle(j, o, d, st, sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true));
-        }
-        park_drain(pk, park_count, r + 1 == rounds, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t) {
-            F3 o, d;
-            ray_of(base + j2, &o, &d);
-            settle(j2, o, d, st, sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st));
-        });
-    }
-}
-
-template <int USE_LDS, int NL>
-__global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
-                                                                     uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
-                                                                     uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ park_all) {
-    extern __shared__ __align__(16) uint32_t lds[];
-    __shared__ uint32_t park_counts[kBlock / 64];
-    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
-    const uint32_t wave = threadIdx.x >> 6;
-    uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap + wave * kWaveParkCap;
-    uint32_t* park_count = &park_counts[wave];
-    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
-    const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
-    if (lane_id() == 0) *park_count = 0;
-    // a finished ray leaves its contribution where its factor was; the item's rays are summed in order at the end (an item's
-    // rays are parked and resumed by the wave that owns the item, so that sum needs no workgroup barrier either)
-    auto settle = [&](uint32_t j, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked) {
-        if (parked) { park_store(pk, atomicAdd(park_count, 1u), j, st, l, bound, env ? 1u : 0u); return; }
-        const uint32_t item = base + j;
-        float lambda[NL], c[NL];
-        for (int k = 0; k < NL; ++k) lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item);
-        Hit sh;
-        bool hit = sweep_finish(s, ray.o, ray.d, st, &sh);
-        shadow_ray_contribution<NL>(s, lambda, ray, env, hit, sh, c);
-        for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
-    };
-    // one ray of every item per step, so that a step parks at most one ray per lane
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t j = r * blockDim.x + threadIdx.x;
-        const uint32_t item = base + j, flags = j < n ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
-        for (uint32_t l = 0; l < light_samples; ++l) {
-            ShadowRayT<NL> ray;
-            if (j < n && load_shadow_ray<NL>(shadow, item, l, &ray)) {
-                const bool env = ((flags >> l) & 1u) != 0;
-                float bound = PT_INF; int stop = shadow_env_stop(s);
-                if (!env && !shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) {
-                    for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
-                } else {
-                    SweepState st;
-                    sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
-                    const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
-                    settle(j, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true));
-                }
-            }
-            park_drain(pk, park_count, r + 1 == rounds && l + 1 == light_samples, [&](uint32_t j2, SweepState& st, uint32_t l2, float bound, uint32_t kind) {
-                ShadowRayT<NL> pr;
-                load_shadow_ray<NL>(shadow, base + j2, l2, &pr);
-                const bool env = kind != 0u;
-                // a light ray searches with the early stop whenever it has a finite bound (shadow_light_bound)
-                const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
-                settle(j2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, stop2, st));
-            });
-        }
-    }
-    __threadfence_block();
-    for (uint32_t r = 0; r < rounds; ++r) {  // pt.rs:349-392, 596: the item's rays summed in order, divided by L
-        const uint32_t j = r * blockDim.x + threadIdx.x;
-        if (j >= n) continue;
-        const uint32_t item = base + j, slot = qu(shadow, Layout<NL>::sh_slot, item);
-        float lc[NL];
-        for (int k = 0; k < NL; ++k) lc[k] = 0.0f;
-        for (uint32_t l = 0; l < light_samples; ++l)
-            for (int k = 0; k < NL; ++k) lc[k] += qf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item);
-        for (int k = 0; k < NL; ++k) energy[(size_t)k * energy_stride + slot] += lc[k] / (float)light_samples;
-    }
-}
-
-template <int NL>
-__global__ void __launch_bounds__(kBlock) k_accumulate(RenderParams rp, const uint32_t* __restrict__ pixels, const float* __restrict__ energy,
-                                                      float* __restrict__ film) {
-    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < rp.chunk_pixels; p += gridDim.x * blockDim.x) {
-        uint32_t pixel = pixels[p];
-        float4* px = reinterpret_cast<float4*>(film) + pixel;
-        float4 v = *px;
-        float f[4] = {v.x, v.y, v.z, v.w};
-        stage_accumulate_pixel<NL>(rp, energy, p, pixel, f);
-        *px = make_float4(f[0], f[1], f[2], f[3]);
-    }
-}
-
-// ---- probes (parity tests of single stages)
-template <int USE_LDS>
-__global__ void __launch_bounds__(kBlock) k_probe_intersect(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
-                                                           uint32_t n, const float* __restrict__ o, const float* __restrict__ d, pt_hit* __restrict__ out) {
-    extern __shared__ __align__(16) uint32_t lds[];
-    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        Hit h;
-        bool ok = world_hit(s, f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), &h);
-        pt_hit r;
-        memset(&r, 0, sizeof(r));
-        if (ok) {
-            r.valid = 1; r.t = h.t; r.point[0] = h.p.x; r.point[1] = h.p.y; r.point[2] = h.p.z;
-            r.normal[0] = h.n.x; r.normal[1] = h.n.y; r.normal[2] = h.n.z; r.uv[0] = h.u; r.uv[1] = h.v;
-            r.material = h.material; r.instance = h.instance;
-        }
-        out[i] = r;
-    }
-}
 // mode 0: generate_and_evaluate(lambda, wi, s2) -> f, wo, pdf ; 1: bsdf(lambda, wi, wo) -> f, pdf ; 2: emission(lambda, wi) ; 3: curve(lambda)
 __global__ void __launch_bounds__(kBlock) k_probe_material(const uint32_t* __restrict__ blob, const float* __restrict__ tex, int mode, uint32_t record, uint32_t n,
                                                           const float* __restrict__ lambda, const float* __restrict__ a, const float* __restrict__ b,
@@ -582,6 +203,13 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     // the sweep table holds walked meshes: rays that reach one are parked and resumed in full waves (PT_AMD_NO_PARK=1: in line)
     const bool walks = (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) != 0;
     const bool parked = sweep && walks && b.park != nullptr && !env_u32("PT_AMD_NO_PARK", 0);
+    // PT_AMD_POOL=1: phase 3 of a pure sweep scene pooled per wave (sweep_run_pooled).  Bit-identical, but measured slower than the lane
+    // loop on MI355X (C2: k_extend 3155 vs 2475 us, k_shadow 5421 vs 4677 us; DESIGN.md section 5 has the breakdown), so it is not the default.
+    const bool pooled = sweep && !walks && mode == PT_LDS_ALL && lds_bytes + pool_lds_bytes() <= kLdsBlobLimitBytes && env_u32("PT_AMD_POOL", 0) != 0;
+    // (walked meshes in line under PT_AMD_NO_PARK, and every partly staged or unstaged blob: the run-time choice of PT_FORM_ANY)
+    const int trav_form = parked ? PT_FORM_PARKED : (mode != PT_LDS_ALL || (sweep && walks)) ? PT_FORM_ANY : pooled ? PT_FORM_POOLED : sweep ? PT_FORM_SWEEP : PT_FORM_WALK;
+    const LaunchCfg cfg{grid, lds_bytes, stream, mode};
+    const SceneArgs sargs{sc->d_blob, sc->blob_words, sc->d_tex};
     // light samples can pick the environment only if env_sampling_probability > 0: otherwise k_shade is the form without that branch
     float env_prob; std::memcpy(&env_prob, &sc->host.blob[PT_HDR_ENV_PROB], sizeof env_prob);
     bool has_ggx = false;
@@ -629,51 +257,11 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
         for (uint32_t bounce = 0; bounce < bounce_limit; ++bounce) {
             Queue qin = (bounce & 1) ? qb : qa, qout = (bounce & 1) ? qa : qb;
             uint32_t *cin = live[bounce & 1], *cout = live[(bounce + 1) & 1];
-            // kernel variant = staging mode (PT_LDS_*) x traversal form x wavelengths per path
-#define PT_ARGS_EXTEND sc->d_blob, sc->blob_words, sc->d_tex, qin, qh, seg_cap, cin
-#define PT_ARGS_SHADE sc->d_blob, sc->blob_words, sc->d_tex, rp, bounce, d_px, qin, qh, qout, qs, b.energy, seg_cap, cin, cout, nshadow, b.block_stats
-#define PT_ARGS_SHADOW sc->d_blob, sc->blob_words, sc->d_tex, rd.light_samples, qs, b.energy, b.capacity, seg_cap, nshadow
-#define PT_BY_MODE(K, ...) do { if (mode == PT_LDS_ALL) launch(K(PT_LDS_ALL), lds_bytes, grid, stream, __VA_ARGS__); \
-                                else if (mode == PT_LDS_CORE) launch(K(PT_LDS_CORE), lds_bytes, grid, stream, __VA_ARGS__); \
-                                else launch(K(PT_LDS_NONE), lds_bytes, grid, stream, __VA_ARGS__); } while (0)
-            timed(ST_EXTEND, [&] {
-#define K_EXT_PARKED(M) k_extend_parked<M>
-#define K_EXT_ANY(M) k_extend<M, PT_TRAV_ANY>
-                if (parked) PT_BY_MODE(K_EXT_PARKED, PT_ARGS_EXTEND, b.park);
-                else if (mode != PT_LDS_ALL || (sweep && walks)) PT_BY_MODE(K_EXT_ANY, PT_ARGS_EXTEND);   // (walked meshes in line: PT_AMD_NO_PARK)
-                else if (sweep) launch(k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>, lds_bytes, grid, stream, PT_ARGS_EXTEND);
-                else launch(k_extend<PT_LDS_ALL, PT_TRAV_WALK>, lds_bytes, grid, stream, PT_ARGS_EXTEND);
-            });
-            timed(ST_SHADE, [&] {
-#define K_SHADE1L(M) k_shade<M, 1, PT_SHADE_LEAN>
-#define K_SHADE4L(M) k_shade<M, 4, PT_SHADE_LEAN>
-#define K_SHADE1N(M) k_shade<M, 1, PT_SHADE_NO_ENV>
-#define K_SHADE4N(M) k_shade<M, 4, PT_SHADE_NO_ENV>
-#define K_SHADE1F(M) k_shade<M, 1, PT_SHADE_FULL>
-#define K_SHADE4F(M) k_shade<M, 4, PT_SHADE_FULL>
-                if (shade_form == PT_SHADE_FULL) { if (hero) PT_BY_MODE(K_SHADE4F, PT_ARGS_SHADE); else PT_BY_MODE(K_SHADE1F, PT_ARGS_SHADE); }
-                else if (shade_form == PT_SHADE_NO_ENV) { if (hero) PT_BY_MODE(K_SHADE4N, PT_ARGS_SHADE); else PT_BY_MODE(K_SHADE1N, PT_ARGS_SHADE); }
-                else if (hero) PT_BY_MODE(K_SHADE4L, PT_ARGS_SHADE); else PT_BY_MODE(K_SHADE1L, PT_ARGS_SHADE);
-            });
-            if (rd.light_samples > 0)
-                timed(ST_SHADOW, [&] {
-#define K_SH_PARKED1(M) k_shadow_parked<M, 1>
-#define K_SH_PARKED4(M) k_shadow_parked<M, 4>
-#define K_SH_ANY1(M) k_shadow<M, 1, PT_TRAV_ANY>
-#define K_SH_ANY4(M) k_shadow<M, 4, PT_TRAV_ANY>
-                    if (parked) { if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS_SHADOW, b.park); else PT_BY_MODE(K_SH_PARKED1, PT_ARGS_SHADOW, b.park); }
-                    else if (mode != PT_LDS_ALL || (sweep && walks)) { if (hero) PT_BY_MODE(K_SH_ANY4, PT_ARGS_SHADOW); else PT_BY_MODE(K_SH_ANY1, PT_ARGS_SHADOW); }
-                    else if (sweep) {   // (shade_form FULL = the scene can produce environment rays)
-                        if (shade_form == PT_SHADE_FULL) {
-                            if (hero) launch(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, true>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
-                            else launch(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, true>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
-                        } else if (hero) launch(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, false>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
-                        else launch(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, false>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
-                    } else {
-                        if (hero) launch(k_shadow<PT_LDS_ALL, 4, PT_TRAV_WALK>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
-                        else launch(k_shadow<PT_LDS_ALL, 1, PT_TRAV_WALK>, lds_bytes, grid, stream, PT_ARGS_SHADOW);
-                    }
-                });
+            // kernel variant = staging mode (PT_LDS_*) x traversal form x wavelengths per path (pt_launch.h)
+            timed(ST_EXTEND, [&] { launch_extend(cfg, trav_form, sargs, qin, qh, seg_cap, cin, b.park); });
+            timed(ST_SHADE, [&] { launch_shade(cfg, hero ? 4 : 1, shade_form, sargs, rp, bounce, d_px, qin, qh, qout, qs, b.energy, seg_cap, cin, cout, nshadow, b.block_stats); });
+            if (rd.light_samples > 0)   // (shade_form FULL = the scene can produce environment rays)
+                timed(ST_SHADOW, [&] { launch_shadow(cfg, trav_form, hero ? 4 : 1, shade_form == PT_SHADE_FULL, sargs, rd.light_samples, qs, b.energy, b.capacity, seg_cap, nshadow, b.park, qh); });
         }
         timed(ST_ACCUMULATE, [&] {
             if (hero) hipLaunchKernelGGL(k_accumulate<4>, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, b.energy, d_film);
@@ -769,40 +357,10 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     if (e == hipSuccess) e = hipMemcpy(sc->d_tex, sc->host.tex.data(), sizeof(float) * sc->host.tex.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { pt_scene_destroy(sc); return fail(e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE, hipGetErrorString(e)); }
     if (sc->lds_mode != PT_LDS_NONE) {
-        auto allow = [](const void* k) { hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBlobLimitBytes); };
-#define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
-#define K1(M) k_extend<M, PT_TRAV_ANY>
-#define K2(M) k_shadow<M, 1, PT_TRAV_ANY>
-#define K3(M) k_shadow<M, 4, PT_TRAV_ANY>
-#define K4(M) k_shade<M, 1, PT_SHADE_LEAN>
-#define K5(M) k_shade<M, 4, PT_SHADE_LEAN>
-#define K4E(M) k_shade<M, 1, PT_SHADE_FULL>
-#define K5E(M) k_shade<M, 4, PT_SHADE_FULL>
-#define K4N(M) k_shade<M, 1, PT_SHADE_NO_ENV>
-#define K5N(M) k_shade<M, 4, PT_SHADE_NO_ENV>
-#define K6(M) k_extend_parked<M>
-#define K7(M) k_shadow_parked<M, 1>
-#define K8(M) k_shadow_parked<M, 4>
-#define K9(M) k_probe_intersect<M>
-        PT_ALLOW_MODES(K1); PT_ALLOW_MODES(K2); PT_ALLOW_MODES(K3); PT_ALLOW_MODES(K4); PT_ALLOW_MODES(K5); PT_ALLOW_MODES(K4E); PT_ALLOW_MODES(K5E); PT_ALLOW_MODES(K4N); PT_ALLOW_MODES(K5N); PT_ALLOW_MODES(K6); PT_ALLOW_MODES(K7); PT_ALLOW_MODES(K8); PT_ALLOW_MODES(K9);
-#undef K1
-#undef K2
-#undef K3
-#undef K4
-#undef K5
-#undef K4E
-#undef K5E
-#undef K4N
-#undef K5N
-#undef K6
-#undef K7
-#undef K8
-#undef K9
-#undef PT_ALLOW_MODES
-        allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>));
-        allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP>));
-        allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP>));
-        allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, false>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, false>));
+        e = allow_lds_extend(kLdsBlobLimitBytes);
+        if (e == hipSuccess) e = allow_lds_shade(kLdsBlobLimitBytes);
+        if (e == hipSuccess) e = allow_lds_shadow(kLdsBlobLimitBytes);
+        if (e != hipSuccess) { pt_scene_destroy(sc); return fail(PT_ERR_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e)); }
     }
     *out = sc;
     return PT_OK;
@@ -847,9 +405,7 @@ pt_status pt_intersect(pt_scene* sc, size_t n, const float* origins, const float
     HIP_TRY(hipMemcpy(dd, directions, 12 * n, hipMemcpyHostToDevice));
     int grid = sc->num_cus * 4;
     const uint32_t lds_bytes = sc->lds_mode == PT_LDS_ALL ? sc->blob_words * 4u : (sc->lds_mode == PT_LDS_CORE ? sc->host.blob[PT_HDR_CORE_WORDS] * 4u : 0u);
-    if (sc->lds_mode == PT_LDS_ALL) launch(k_probe_intersect<PT_LDS_ALL>, lds_bytes, grid, (hipStream_t)0, sc->d_blob, sc->blob_words, sc->d_tex, (uint32_t)n, dor, dd, dh);
-    else if (sc->lds_mode == PT_LDS_CORE) launch(k_probe_intersect<PT_LDS_CORE>, lds_bytes, grid, (hipStream_t)0, sc->d_blob, sc->blob_words, sc->d_tex, (uint32_t)n, dor, dd, dh);
-    else launch(k_probe_intersect<PT_LDS_NONE>, lds_bytes, grid, (hipStream_t)0, sc->d_blob, sc->blob_words, sc->d_tex, (uint32_t)n, dor, dd, dh);
+    launch_probe_intersect(LaunchCfg{grid, lds_bytes, (hipStream_t)0, sc->lds_mode}, SceneArgs{sc->d_blob, sc->blob_words, sc->d_tex}, (uint32_t)n, dor, dd, dh);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(hits, dh, sizeof(pt_hit) * n, hipMemcpyDeviceToHost));

@@ -1,0 +1,46 @@
+// pt_kern_shade.hip — the vertex kernels (k_shade: 3 staging modes x 1 or 4 wavelengths x 3 forms) and their launcher.
+// PT_SHADE_NL selects the half of the family this translation unit holds (the build compiles the two halves in parallel).
+#include "pt_kernels.h"
+
+namespace ptk {
+
+#define PT_GO(K, ...) go(c, K, __VA_ARGS__)
+#define PT_BY_MODE(K, ...) do { if (c.lds_mode == PT_LDS_ALL) PT_GO(K(PT_LDS_ALL), __VA_ARGS__); else if (c.lds_mode == PT_LDS_CORE) PT_GO(K(PT_LDS_CORE), __VA_ARGS__); \
+                                else PT_GO(K(PT_LDS_NONE), __VA_ARGS__); } while (0)
+#define K_SHADE_L(M) k_shade<M, PT_SHADE_NL, PT_SHADE_LEAN>
+#define K_SHADE_N(M) k_shade<M, PT_SHADE_NL, PT_SHADE_NO_ENV>
+#define K_SHADE_F(M) k_shade<M, PT_SHADE_NL, PT_SHADE_FULL>
+#define PT_ARGS sc.blob, sc.blob_words, sc.tex, rp, bounce, pixels, paths_in, hits, paths_out, shadow, energy, seg_cap, count_in, count_out, shadow_count, block_stats
+#define PT_ARGS_FWD sc, rp, bounce, pixels, paths_in, hits, paths_out, shadow, energy, seg_cap, count_in, count_out, shadow_count, block_stats
+#define PT_CAT2(a, b) a##b
+#define PT_CAT(a, b) PT_CAT2(a, b)
+
+void PT_CAT(launch_shade_nl, PT_SHADE_NL)(const LaunchCfg& c, int form, const SceneArgs& sc, const RenderParams& rp, uint32_t bounce, const uint32_t* pixels, Queue paths_in,
+                                          Queue hits, Queue paths_out, Queue shadow, float* energy, uint32_t seg_cap, const uint32_t* count_in, uint32_t* count_out,
+                                          uint32_t* shadow_count, unsigned long long* block_stats) {
+    if (form == PT_SHADE_FULL) PT_BY_MODE(K_SHADE_F, PT_ARGS);
+    else if (form == PT_SHADE_NO_ENV) PT_BY_MODE(K_SHADE_N, PT_ARGS);
+    else PT_BY_MODE(K_SHADE_L, PT_ARGS);
+}
+hipError_t PT_CAT(allow_lds_shade_nl, PT_SHADE_NL)(uint32_t bytes) {
+    hipError_t worst = hipSuccess;
+    auto allow = [&](const void* k) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) worst = e; };
+#define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
+    PT_ALLOW_MODES(K_SHADE_L); PT_ALLOW_MODES(K_SHADE_N); PT_ALLOW_MODES(K_SHADE_F);
+    return worst;
+}
+
+#if PT_SHADE_NL == 1
+void launch_shade_nl4(const LaunchCfg&, int, const SceneArgs&, const RenderParams&, uint32_t, const uint32_t*, Queue, Queue, Queue, Queue, float*, uint32_t, const uint32_t*, uint32_t*,
+                      uint32_t*, unsigned long long*);
+hipError_t allow_lds_shade_nl4(uint32_t);
+void launch_shade(const LaunchCfg& c, int nl, int form, const SceneArgs& sc, const RenderParams& rp, uint32_t bounce, const uint32_t* pixels, Queue paths_in,
+                  Queue hits, Queue paths_out, Queue shadow, float* energy, uint32_t seg_cap, const uint32_t* count_in, uint32_t* count_out,
+                  uint32_t* shadow_count, unsigned long long* block_stats) {
+    if (nl == 4) launch_shade_nl4(c, form, PT_ARGS_FWD);
+    else launch_shade_nl1(c, form, PT_ARGS_FWD);
+}
+hipError_t allow_lds_shade(uint32_t bytes) { hipError_t a = allow_lds_shade_nl1(bytes), b = allow_lds_shade_nl4(bytes); return a != hipSuccess ? a : b; }
+#endif
+
+}  // namespace ptk

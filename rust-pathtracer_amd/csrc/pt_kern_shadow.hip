@@ -1,0 +1,52 @@
+// pt_kern_shadow.hip — the light-sample kernels (k_shadow in its traversal forms) and their launcher.
+#include <cstdlib>
+#include "pt_kernels.h"
+
+namespace ptk {
+
+#define PT_GO(K, ...) go(c, K, __VA_ARGS__)
+#define PT_BY_MODE(K, ...) do { if (c.lds_mode == PT_LDS_ALL) PT_GO(K(PT_LDS_ALL), __VA_ARGS__); else if (c.lds_mode == PT_LDS_CORE) PT_GO(K(PT_LDS_CORE), __VA_ARGS__); \
+                                else PT_GO(K(PT_LDS_NONE), __VA_ARGS__); } while (0)
+#define K_SH_PARKED1(M) k_shadow_parked<M, 1>
+#define K_SH_PARKED4(M) k_shadow_parked<M, 4>
+#define K_SH_ANY1(M) k_shadow<M, 1, PT_TRAV_ANY>
+#define K_SH_ANY4(M) k_shadow<M, 4, PT_TRAV_ANY>
+#define PT_ARGS sc.blob, sc.blob_words, sc.tex, light_samples, shadow, energy, energy_stride, seg_cap, count_in
+
+// `env`: the scene can produce environment rays (env_sampling_probability > 0); the sweep forms without them are leaner
+void launch_shadow(const LaunchCfg& c, int form, int nl, bool env, const SceneArgs& sc, uint32_t light_samples, Queue shadow, float* energy, uint32_t energy_stride,
+                   uint32_t seg_cap, const uint32_t* count_in, uint32_t* park, Queue idle_hits) {
+    const bool hero = nl == 4;
+#ifdef PT_EXPERIMENTS
+    if (const char* v = getenv("PT_AMD_EXP_SHADOW")) {
+        const int e = atoi(v);
+#define PT_EXP_CASE(E) if (e == E) { static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_shadow_exp<E>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true); (void)once; \
+                                     PT_GO(k_shadow_exp<E>, sc.blob, sc.blob_words, sc.tex, light_samples, shadow, idle_hits, seg_cap, count_in); }
+        PT_EXP_CASE(8) PT_EXP_CASE(2) PT_EXP_CASE(4) PT_EXP_CASE(0)
+    }
+#endif
+    if (form == PT_FORM_PARKED) { if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park); else PT_BY_MODE(K_SH_PARKED1, PT_ARGS, park); }
+    else if (form == PT_FORM_POOLED) {
+        if (env) { if (hero) PT_GO((k_shadow_pooled<PT_LDS_ALL, 4, true>), PT_ARGS); else PT_GO((k_shadow_pooled<PT_LDS_ALL, 1, true>), PT_ARGS); }
+        else if (hero) PT_GO((k_shadow_pooled<PT_LDS_ALL, 4, false>), PT_ARGS); else PT_GO((k_shadow_pooled<PT_LDS_ALL, 1, false>), PT_ARGS);
+    } else if (form == PT_FORM_SWEEP) {
+        if (env) { if (hero) PT_GO((k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, true>), PT_ARGS); else PT_GO((k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, true>), PT_ARGS); }
+        else if (hero) PT_GO((k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, false>), PT_ARGS); else PT_GO((k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, false>), PT_ARGS);
+    } else if (form == PT_FORM_WALK) { if (hero) PT_GO((k_shadow<PT_LDS_ALL, 4, PT_TRAV_WALK>), PT_ARGS); else PT_GO((k_shadow<PT_LDS_ALL, 1, PT_TRAV_WALK>), PT_ARGS); }
+    else if (hero) PT_BY_MODE(K_SH_ANY4, PT_ARGS); else PT_BY_MODE(K_SH_ANY1, PT_ARGS);
+}
+
+hipError_t allow_lds_shadow(uint32_t bytes) {
+    hipError_t worst = hipSuccess;
+    auto allow = [&](const void* k) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) worst = e; };
+#define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
+    PT_ALLOW_MODES(K_SH_ANY1); PT_ALLOW_MODES(K_SH_ANY4); PT_ALLOW_MODES(K_SH_PARKED1); PT_ALLOW_MODES(K_SH_PARKED4);
+    allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_WALK>));
+    allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, true>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, true>));
+    allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, false>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, false>));
+    allow(reinterpret_cast<const void*>(k_shadow_pooled<PT_LDS_ALL, 1, false>)); allow(reinterpret_cast<const void*>(k_shadow_pooled<PT_LDS_ALL, 4, false>));
+    allow(reinterpret_cast<const void*>(k_shadow_pooled<PT_LDS_ALL, 1, true>)); allow(reinterpret_cast<const void*>(k_shadow_pooled<PT_LDS_ALL, 4, true>));
+    return worst;
+}
+
+}  // namespace ptk

@@ -1,0 +1,551 @@
+// pt_kernels.h — the kernels of the wavefront path tracer (gfx950 / MI355X), as templates.
+//
+// Per bounce one launch each of extend -> shade -> shadow over segmented SoA queues in HBM (pt_stages.h; workgroup b owns segment b
+// of every queue and compacts survivors into its own segment with wave ballots + one LDS atomic per wave — no global atomics),
+// persistent grids that stage the scene blob (or its core section) into LDS once per workgroup, four traversal forms (pt_device.h:
+// BVH walk, leaf sweep, pooled leaf sweep, sweep + parked mesh walks), per-slot energy accumulation without float atomics, and an
+// accumulate kernel that owns one film pixel per lane so film sums keep the reference's order.
+//
+// The instantiations are compiled in separate translation units by kernel family (pt_kern_*.hip: the build runs them in parallel and
+// a change to one family recompiles one file); pt_engine.hip sees them as extern templates.  The lists at the end of this file are
+// the single source of both.
+#ifndef PT_KERNELS_H
+#define PT_KERNELS_H
+#include <hip/hip_runtime.h>
+#define PT_WAVE_KERNELS 1   /* pt_device.h: the wave-level device code (needs the HIP runtime header above) */
+#include "pt_launch.h"
+
+namespace ptk {
+using namespace ptd;
+
+template <typename K, typename... Args>
+inline void go(const LaunchCfg& c, K kernel, Args... args) { hipLaunchKernelGGL(kernel, dim3(c.grid), dim3(kBlock), c.lds_bytes, c.stream, args...); }
+
+// Register budgets: the number of waves per SIMD the compiler must leave room for (1 = no constraint), per kernel form.
+// Measured on MI355X (tools/occupancy_sweep.sh): the traversal kernels are VALU-issue bound and gain from a
+// 5th wave; k_shade is a large body (196 VGPRs unconstrained = 2 waves) that gains from a 3rd wave and loses with a 4th.
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 3
+#endif
+#ifndef PT_SHADE4_WAVES
+#define PT_SHADE4_WAVES 2
+#endif
+#ifndef PT_SWEEP_WAVES
+#define PT_SWEEP_WAVES 5
+#endif
+#ifndef PT_WALK_WAVES
+#define PT_WALK_WAVES 1
+#endif
+#ifndef PT_PARK_WAVES
+#define PT_PARK_WAVES 4
+#endif
+#define PT_PARK_OCC __attribute__((amdgpu_waves_per_eu(PT_PARK_WAVES)))
+// (forms of k_shade, see the kernel: FULL = PT_SHADE_WAVES / PT_SHADE4_WAVES above; measured with tools/shade_occupancy.sh.  FULL on C4:
+// 11442 us at 3 waves, 14735 at 2, 11869 at 4; NO_ENV on C3: 3564 at 3 or 2, 3902 at 4)
+#ifndef PT_SHADE_NO_ENV_WAVES
+#define PT_SHADE_NO_ENV_WAVES 3
+#endif
+#ifndef PT_SHADE4_NO_ENV_WAVES
+#define PT_SHADE4_NO_ENV_WAVES 3   // 6082 us at 3 waves, 7029 at 2, 6759 unconstrained (C5 before the lean form existed)
+#endif
+#ifndef PT_SHADE_LEAN_WAVES
+#define PT_SHADE_LEAN_WAVES 3      // 126 VGPRs without a constraint = 4 waves; 5 waves spill (3892 vs 2866 us)
+#endif
+#ifndef PT_SHADE4_LEAN_WAVES
+#define PT_SHADE4_LEAN_WAVES 2     // C5: 3885 us at 2 waves, 4142 at 3-4, 4830 at 5
+#endif
+#define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(NL == 1 ? (FORM == 2 ? PT_SHADE_WAVES : FORM == 1 ? PT_SHADE_NO_ENV_WAVES : PT_SHADE_LEAN_WAVES) \
+                                                                : (FORM == 2 ? PT_SHADE4_WAVES : FORM == 1 ? PT_SHADE4_NO_ENV_WAVES : PT_SHADE4_LEAN_WAVES))))
+#define PT_TRAV_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? PT_SWEEP_WAVES : PT_WALK_WAVES)))
+
+enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_ACCUMULATE, ST_COUNT };
+
+// ------------------------------------------------------------------------------------------------ kernels
+// Every kernel is a persistent grid: blocks stage the scene blob into LDS (when USE_LDS), then walk the queue
+// with a grid stride.  Queue lengths live in device memory (`counts`), so no host round trip between bounces.
+// USE_LDS: 0 = everything is read from HBM/L2; 1 = the whole blob is copied to LDS; 2 = only the core section is (curves,
+// materials, instances, top-level BVH, sweep table: the words every lane keeps re-reading), the mesh data stays in HBM/L2
+// — scenes whose meshes do not fit the LDS budget but whose core does (C4: 470 KB of monkey, 24 KB of core).
+template <int USE_LDS>
+__device__ __forceinline__ SceneView stage_scene(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* tex, uint32_t* lds) {
+    SceneView s;
+    s.tex = tex;
+    const uint32_t core_words = blob[PT_HDR_CORE_WORDS];
+    if (USE_LDS != PT_LDS_NONE) {
+        const uint32_t words = USE_LDS == PT_LDS_ALL ? blob_words : core_words;
+        const uint4* src = reinterpret_cast<const uint4*>(blob);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (uint32_t i = threadIdx.x; i < words / 4; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        s.w = lds;
+        s.m = USE_LDS == PT_LDS_ALL ? lds + core_words : blob + core_words;
+    } else {
+        s.w = blob;
+        s.m = blob + core_words;
+    }
+    return s;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// ---- segmented queues -------------------------------------------------------------------------------------------
+// Every queue is cut into gridDim.x segments of `seg_cap` items; workgroup b owns segment b in every kernel of a pass:
+// it reads items [b*seg_cap, b*seg_cap + count_in[b]) and appends its survivors, compacted, to the same segment of the
+// output queue.  Compaction is a wave64 ballot + one LDS atomic per wave (shared_append) — no global atomics (a single hot
+// queue head saturates at ~88 returning atomics/us on MI355X, which was the whole cost of the first version of k_shade)
+// and no barrier; each wave's writes are one contiguous run per field.  The four waves of a workgroup stride through the
+// shared segment, which balances them; survival is statistically uniform over segments, which balances the workgroups.
+// Append without a barrier: one LDS atomic per wave claims the wave's run in the workgroup's segment.  The order of the
+// waves' runs inside the segment then depends on timing, which no result depends on (every queue item is processed on its
+// own; energy and film sums are keyed by slot and pixel).  Measured on k_shade: -6 % against block_append's barrier.
+__device__ __forceinline__ uint32_t shared_append(bool flag, uint32_t* lds_head) {
+    unsigned long long mask = __ballot(flag);
+    uint32_t start = 0;
+    if (lane_id() == 0 && mask != 0ull) start = atomicAdd(lds_head, (uint32_t)__popcll(mask));
+    start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+    return start + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
+}
+__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;  // valid in lane 0
+}
+
+// Per-workgroup statistics (Profile counters), owned by the workgroup: plain read-modify-write, summed on the host.
+
+template <int NL>
+__global__ void __launch_bounds__(kBlock) k_generate(RenderParams rp, const uint32_t* __restrict__ pixels, Queue paths, float* __restrict__ energy,
+                                                    uint32_t n, uint32_t seg_cap, uint32_t* __restrict__ count_out) {
+    uint32_t base = blockIdx.x * seg_cap;
+    uint32_t cnt = base < n ? (n - base < seg_cap ? n - base : seg_cap) : 0u;
+    for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x) {
+        uint32_t slot = base + j;
+        uint32_t pixel = pixels[slot % rp.chunk_pixels];
+        PathVertexT<NL> p = stage_generate<NL>(rp, slot, pixel);
+        store_path<NL>(paths, slot, p);
+        for (int k = 0; k < NL; ++k) energy[(size_t)k * rp.energy_stride + slot] = 0.0f;
+    }
+    if (threadIdx.x == 0) count_out[blockIdx.x] = cnt;
+}
+
+template <int USE_LDS, int TRAV>
+__global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_extend(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                  Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+        uint32_t i = base + j;
+        F3 o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
+        F3 d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
+        Hit h;
+        world_hit<TRAV>(s, o, d, &h);
+        store_hit(hits, i, h);
+    }
+}
+
+// FORM: what the scene can need at a vertex, so that the rest is compiled out (registers and code size, never results):
+// PT_SHADE_LEAN = no light sample picks the environment (env_sampling_probability = 0) and no GGX material (the Cornell box of C2 / C5),
+// PT_SHADE_NO_ENV = any material, PT_SHADE_FULL = everything.
+template <int USE_LDS, int NL, int FORM>
+__global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                 RenderParams rp, uint32_t bounce, const uint32_t* __restrict__ pixels,
+                                                 Queue paths_in, Queue hits, Queue paths_out, Queue shadow, float* __restrict__ energy,
+                                                 uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ count_out,
+                                                 uint32_t* __restrict__ shadow_count, unsigned long long* __restrict__ block_stats) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ uint32_t lds_counts[16];  // [0] path queue head, [1] item queue head, [4..6] statistics
+    if (threadIdx.x < 16) lds_counts[threadIdx.x] = 0;
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);  // (barrier inside when staging; one below otherwise)
+    if (USE_LDS == PT_LDS_NONE) __syncthreads();
+    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    uint32_t st_vertices = 0, st_shadow = 0, st_env = 0;
+    const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
+    for (uint32_t r = 0; r < rounds; ++r) {  // whole waves stay in the loop: the appends are ballots
+        uint32_t j = r * blockDim.x + threadIdx.x;
+        bool active = j < n;
+        uint32_t i = base + j;
+        PathVertexT<NL> pv; Hit hit; hit.valid = false;
+        bool wants_item = false;
+        if (active) {
+            pv = load_path<NL>(paths_in, i);
+            hit = load_hit(hits, i);
+            wants_item = shade_wants_item(s, rp, hit);
+        }
+        // reserve the light-sample item first, so its rays stream straight from registers to the queue
+        uint32_t ipos = base + shared_append(wants_item, &lds_counts[1]);
+        ShadeOutT<NL> out;
+        out.survives = false; out.has_item = false; out.vertex_pushed = false; out.env_hit = false; out.shadow_count = 0; out.add_energy = false; out.env_mask = 0;
+        if (active) {
+            uint32_t pixel = pixels[pv.slot % rp.chunk_pixels];
+            out = stage_shade<NL, FORM == PT_SHADE_FULL, FORM != PT_SHADE_LEAN>(s, rp, bounce, pv, hit, pixel, [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(shadow, ipos, l, ray); });
+            if (wants_item) {
+                float lam[NL]; lam[0] = pv.lambda;
+                if (NL > 1) hero_lambdas<NL>(rp, pt_draw4(rp.seed, pixel, rp.first_sample + pv.slot / rp.chunk_pixels, PT_DIM_FILM).z, lam);
+                qsu(shadow, Layout<NL>::sh_slot, ipos, pv.slot); qsu(shadow, Layout<NL>::sh_flags, ipos, out.env_mask);
+                for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_lambda + k, ipos, lam[k]);
+                if (!out.has_item) clear_shadow_item<NL>(shadow, ipos, rp.light_samples);  // vertex dropped (NaN pdf, utils.rs:261-263)
+            }
+            if (out.add_energy) for (int k = 0; k < NL; ++k) energy[(size_t)k * rp.energy_stride + pv.slot] += out.energy_add[k];
+        }
+        uint32_t pos = base + shared_append(out.survives, &lds_counts[0]);
+        if (out.survives) store_path<NL>(paths_out, pos, out.next);
+        st_vertices += out.vertex_pushed ? 1u : 0u; st_env += out.env_hit ? 1u : 0u; st_shadow += out.shadow_count;
+    }
+    // workgroup totals -> this workgroup's statistics record
+    st_vertices = wave_reduce_add(st_vertices); st_shadow = wave_reduce_add(st_shadow); st_env = wave_reduce_add(st_env);
+    if (lane_id() == 0) { atomicAdd(&lds_counts[4], st_vertices); atomicAdd(&lds_counts[5], st_shadow); atomicAdd(&lds_counts[6], st_env); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        count_out[blockIdx.x] = lds_counts[0]; shadow_count[blockIdx.x] = lds_counts[1];
+        unsigned long long* bs = block_stats + (size_t)blockIdx.x * BS_FIELDS;
+        bs[BS_VERTICES] += lds_counts[4]; bs[BS_SHADOW_RAYS] += lds_counts[5]; bs[BS_ENV_HITS] += lds_counts[6];
+        bs[BS_SEGMENTS] += n;
+        bs[BS_ITEMS] += lds_counts[1];
+    }
+}
+
+template <int USE_LDS, int NL, int TRAV, bool ENV = true>
+__global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                  uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
+                                                  uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+        stage_shadow_item<NL, TRAV, ENV>(s, light_samples, shadow, base + j, energy, energy_stride);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pooled traversal
+// Pure sweep scenes (every leaf in the table: the Cornell box of C2 / C5).  Phases 1 and 2 per lane as in k_extend / k_shadow; phase
+// 3 for the wave's 64 rays together (sweep_run_pooled, pt_device.h): the candidate triangles of all of them are pooled in LDS and
+// tested 64 at a time, then every lane replays the acceptance of its own candidates in leaf order.  Bit-identical results; the
+// per-lane loop it replaces ran at ~0.4 lane utilisation (6.5 iterations per wave for 2.4 candidates per ray).
+#ifndef PT_POOL_WAVES
+#define PT_POOL_WAVES 5
+#endif
+#define PT_POOL_OCC __attribute__((amdgpu_waves_per_eu(PT_POOL_WAVES)))
+constexpr uint32_t kPoolBytes = (kBlock / 64) * PT_POOL_WORDS * 4u;
+
+template <int USE_LDS>
+__global__ void __launch_bounds__(kBlock) PT_POOL_OCC k_extend_pooled(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                                     Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ __align__(16) uint32_t pool_all[(kBlock / 64) * PT_POOL_WORDS];
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    uint32_t* ws = pool_all + (threadIdx.x >> 6) * PT_POOL_WORDS;
+    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
+    for (uint32_t r = 0; r < rounds; ++r) {  // whole waves stay in the loop
+        const uint32_t j = r * blockDim.x + threadIdx.x, i = base + j;
+        const bool active = j < n;
+        F3 o = f3(0, 0, 0), d = f3(0, 0, 1);
+        SweepState st;
+        sweep_state_init(st, 0);
+        if (active) {
+            o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
+            d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
+            st.hit = sweep_masks(s, o, d, PT_INF);
+        }
+        const TriRay wtr = tri_ray_prepare(o, d);
+        sweep_run_pooled(s, ws, o, d, wtr, st);
+        if (active) { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, i, h); }
+    }
+}
+
+template <int USE_LDS, int NL, bool ENV>
+__global__ void __launch_bounds__(kBlock) PT_POOL_OCC k_shadow_pooled(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                                     uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
+                                                                     uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ __align__(16) uint32_t pool_all[(kBlock / 64) * PT_POOL_WORDS];
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    uint32_t* ws = pool_all + (threadIdx.x >> 6) * PT_POOL_WORDS;
+    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t j = r * blockDim.x + threadIdx.x, item = base + j;
+        const bool active = j < n;
+        const uint32_t flags = (ENV && active) ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
+        float lambda[NL], lc[NL];
+        for (int k = 0; k < NL; ++k) { lambda[k] = active ? qf(shadow, Layout<NL>::sh_lambda + k, item) : 0.0f; lc[k] = 0.0f; }
+        for (uint32_t l = 0; l < light_samples; ++l) {   // stage_shadow_item, the rays of the wave's 64 items side by side
+            ShadowRayT<NL> ray; ray.o = f3(0, 0, 0); ray.d = f3(0, 0, 1);
+            bool live = active && load_shadow_ray<NL>(shadow, item, l, &ray);
+            const bool env = ENV && ((flags >> l) & 1u) != 0u;
+            SweepState st;
+            sweep_state_init(st, 0);
+            if (live) {
+                float bound = PT_INF; int stop = PT_STOP_NONE;
+                if (!env) live = shadow_light_bound(s, ray.o, ray.d, &bound, &stop);  // no light on the ray: nothing to trace
+                if (live) st.hit = sweep_masks(s, ray.o, ray.d, bound);
+            }
+            const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
+            sweep_run_pooled(s, ws, ray.o, ray.d, wtr, st);
+            if (live) {
+                float c[NL];
+                Hit sh; sh.valid = false;
+                const bool hit = st.best_inst != 0xffffffffu;
+                // only a light (an analytic shape on this path) or nothing at all contributes: the record of an occluder is never read
+                const bool wanted = hit && !env && sweep_best_is_light(s, st);
+                if (wanted) sweep_finish(s, ray.o, ray.d, st, &sh);
+                if (hit && !wanted) { sh.valid = true; sh.material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); }
+                shadow_ray_contribution<NL>(s, lambda, ray, env, hit, sh, c);
+                for (int k = 0; k < NL; ++k) lc[k] += c[k];
+            }
+        }
+        if (active) {
+            const uint32_t slot = qu(shadow, Layout<NL>::sh_slot, item);
+            for (int k = 0; k < NL; ++k) energy[(size_t)k * energy_stride + slot] += lc[k] / (float)light_samples;
+        }
+    }
+}
+
+#ifdef PT_EXPERIMENTS
+// Measurement only (make EXTRA=-DPT_EXPERIMENTS, PT_AMD_EXP=<bits>; tools/phase_costs.sh): k_extend with parts left out, launched in
+// front of the real kernel on the same input (its output is overwritten), so that the stage time grows by the cost of what is left in.
+// bits: 1 pooled form, 2 no phase 3, 4 no hit record, 8 / 0x10 / 0x20 / 0x40 pooled: no triangle chunks / replay / winner / candidate lists
+template <int EXP>
+__global__ void __launch_bounds__(kBlock) PT_POOL_OCC k_extend_exp(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                                  Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ __align__(16) uint32_t pool_all[(EXP & 1) ? (kBlock / 64) * PT_POOL_WORDS : 4];
+    SceneView s = stage_scene<PT_LDS_ALL>(blob, blob_words, tex, lds);
+    uint32_t* ws = pool_all + ((EXP & 1) ? (threadIdx.x >> 6) * PT_POOL_WORDS : 0);
+    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t j = r * blockDim.x + threadIdx.x, i = base + j;
+        const bool active = j < n;
+        F3 o = f3(0, 0, 0), d = f3(0, 0, 1);
+        SweepState st;
+        sweep_state_init(st, 0);
+        if (active) {
+            o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
+            d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
+            st.hit = sweep_masks(s, o, d, PT_INF);
+        }
+        if (EXP & 2) { if (active) { qsu(hits, HS_T, i, (uint32_t)st.hit); qsu(hits, HS_PX, i, (uint32_t)(st.hit >> 32)); } continue; }
+        const TriRay wtr = tri_ray_prepare(o, d);
+        if (EXP & 1) sweep_run_pooled<EXP>(s, ws, o, d, wtr, st);
+        else if (active) sweep_run<false>(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, false);
+        if (active) {
+            if (EXP & 4) { qsf(hits, HS_T, i, st.closest); qsu(hits, HS_PX, i, st.best_inst); }
+            else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, i, h); }
+        }
+    }
+}
+// k_shadow (lane form, no environment rays) with parts left out; its results go to the hit queue, which is idle at that time.
+// bits: 2 stop after the masks, 8 stop after the light bound, 4 no hit record / contribution
+template <int EXP>
+__global__ void __launch_bounds__(kBlock) PT_POOL_OCC k_shadow_exp(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                                  uint32_t light_samples, Queue shadow, Queue sink, uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    SceneView s = stage_scene<PT_LDS_ALL>(blob, blob_words, tex, lds);
+    uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+        const uint32_t item = base + j;
+        float lambda[1] = {qf(shadow, Layout<1>::sh_lambda, item)}, lc = 0.0f;
+        for (uint32_t l = 0; l < light_samples; ++l) {
+            ShadowRayT<1> ray;
+            if (!load_shadow_ray<1>(shadow, item, l, &ray)) continue;
+            float bound = PT_INF; int stop = PT_STOP_NONE;
+            if (!shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) continue;
+            if (EXP & 8) { lc += bound; continue; }
+            SweepState st;
+            sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
+            if (EXP & 2) { lc += (float)(uint32_t)st.hit + (float)(uint32_t)(st.hit >> 32); continue; }
+            const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
+            sweep_run<false>(s, ray.o, ray.d, wtr, bound, stop, st, false);
+            if (EXP & 4) { lc += st.closest + (float)st.best_inst; continue; }
+            Hit sh; float c[1];
+            bool hit = sweep_finish(s, ray.o, ray.d, st, &sh);
+            shadow_ray_contribution<1>(s, lambda, ray, false, hit, sh, c);
+            lc += c[0];
+        }
+        qsf(sink, HS_T, item, lc);
+    }
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------ parked traversal
+// Scenes whose sweep table holds walked meshes (PT_FLAG_SWEEP_WALKS: a few analytic shapes and small meshes around one or
+// more big meshes — the gem in the Cornell room, the monkey under the HDRI).  Most rays never enter a big mesh's box, and
+// the ones that do are scattered over the waves, so walking the mesh in line would leave a wave waiting for a handful of
+// lanes.  Instead a lane that reaches a walked-mesh bit *parks* its sweep state in the workgroup's scratch region, and
+// whenever a wave has 64 rays parked (and at the end) it resumes them together: a full wave, every lane in a mesh walk.  Nothing about a ray's own sequence of tests changes (same leaves, same order, same running closest hit).
+enum { PK_ITEM, PK_HIT_LO, PK_HIT_HI, PK_CLOSEST, PK_BEST_INST, PK_BEST_TRIW, PK_T, PK_B0, PK_B1, PK_B2, PK_RAY, PK_BOUND, PK_KIND };
+__device__ __forceinline__ void park_store(uint32_t* pk, uint32_t e, uint32_t item, const SweepState& st, uint32_t ray, float bound, uint32_t kind) {
+    pk[PK_ITEM * kParkCap + e] = item; pk[PK_HIT_LO * kParkCap + e] = (uint32_t)st.hit; pk[PK_HIT_HI * kParkCap + e] = (uint32_t)(st.hit >> 32);
+    pk[PK_CLOSEST * kParkCap + e] = pt_f2u(st.closest); pk[PK_BEST_INST * kParkCap + e] = st.best_inst; pk[PK_BEST_TRIW * kParkCap + e] = st.best_triw;
+    pk[PK_T * kParkCap + e] = pt_f2u(st.bh.t); pk[PK_B0 * kParkCap + e] = pt_f2u(st.bh.b0); pk[PK_B1 * kParkCap + e] = pt_f2u(st.bh.b1); pk[PK_B2 * kParkCap + e] = pt_f2u(st.bh.b2);
+    pk[PK_RAY * kParkCap + e] = ray; pk[PK_BOUND * kParkCap + e] = pt_f2u(bound); pk[PK_KIND * kParkCap + e] = kind;
+}
+__device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32_t* item, SweepState* st, uint32_t* ray, float* bound, uint32_t* kind) {
+    *item = pk[PK_ITEM * kParkCap + e]; st->hit = (uint64_t)pk[PK_HIT_LO * kParkCap + e] | (uint64_t)pk[PK_HIT_HI * kParkCap + e] << 32;
+    st->closest = pt_u2f(pk[PK_CLOSEST * kParkCap + e]); st->best_inst = pk[PK_BEST_INST * kParkCap + e]; st->best_triw = pk[PK_BEST_TRIW * kParkCap + e];
+    st->bh.t = pt_u2f(pk[PK_T * kParkCap + e]); st->bh.b0 = pt_u2f(pk[PK_B0 * kParkCap + e]); st->bh.b1 = pt_u2f(pk[PK_B1 * kParkCap + e]); st->bh.b2 = pt_u2f(pk[PK_B2 * kParkCap + e]);
+    *ray = pk[PK_RAY * kParkCap + e]; *bound = pt_u2f(pk[PK_BOUND * kParkCap + e]); *kind = pk[PK_KIND * kParkCap + e];
+}
+// The resume loop shared by both kernels, per WAVE: every wave of the workgroup parks into its own quarter of the scratch
+// region (128 entries: fewer than 64 left over + at most 64 new per step) and resumes 64 parked rays at a time — full
+// waves — with no workgroup barrier anywhere: a wave that is deep in a mesh never holds the other three up.  (The first
+// version parked per workgroup with three barriers per drain; rocprofv3 showed the C4 shadow kernel waiting 68 % of its
+// wave cycles at 12 % VALU issue.)
+constexpr uint32_t kWaveParkCap = kParkCap / (kBlock / 64);
+template <typename Resume>
+__device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, bool last, Resume&& resume) {
+    const uint32_t lane = lane_id();
+    for (;;) {
+        __threadfence_block();             // this wave's parked entries are visible to its other lanes
+        const uint32_t cnt = *park_count;  // the same for every lane of the wave
+        if (!(cnt >= 64u || (last && cnt > 0u))) break;
+        const uint32_t take = cnt < 64u ? cnt : 64u, first = cnt - take;
+        const bool mine = lane < take;
+        uint32_t item = 0, ray = 0, kind = 0; float bound = PT_INF; SweepState st;
+        if (mine) park_load(pk, first + lane, &item, &st, &ray, &bound, &kind);
+        __threadfence_block();             // entries are in registers before any lane parks again into these slots
+        if (lane == 0) *park_count = first;
+        if (mine) resume(item, st, ray, bound, kind);
+    }
+}
+
+template <int USE_LDS>
+__global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                                     Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
+                                                                     uint32_t* __restrict__ park_all) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ uint32_t park_counts[kBlock / 64];
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap + wave * kWaveParkCap;  // field f of entry e at pk[f * kParkCap + e]
+    uint32_t* park_count = &park_counts[wave];
+    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
+    if (lane_id() == 0) *park_count = 0;
+    auto ray_of = [&](uint32_t i, F3* o, F3* d) {
+        *o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
+        *d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
+    };
+    auto settle = [&](uint32_t j, F3 o, F3 d, const SweepState& st, bool parked) {
+        if (parked) park_store(pk, atomicAdd(park_count, 1u), j, st, 0u, PT_INF, 0u);
+        else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, base + j, h); }
+    };
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t j = r * blockDim.x + threadIdx.x;
+        if (j < n) {
+            F3 o, d;
+            ray_of(base + j, &o, &d);
+            SweepState st;
+            sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
+            const TriRay wtr = tri_ray_prepare(o, d);
+            settle(j, o, d, st, sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true));
+        }
+        park_drain(pk, park_count, r + 1 == rounds, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t) {
+            F3 o, d;
+            ray_of(base + j2, &o, &d);
+            settle(j2, o, d, st, sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st));
+        });
+    }
+}
+
+template <int USE_LDS, int NL>
+__global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                                     uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
+                                                                     uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ park_all) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ uint32_t park_counts[kBlock / 64];
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap + wave * kWaveParkCap;
+    uint32_t* park_count = &park_counts[wave];
+    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
+    if (lane_id() == 0) *park_count = 0;
+    // a finished ray leaves its contribution where its factor was; the item's rays are summed in order at the end (an item's
+    // rays are parked and resumed by the wave that owns the item, so that sum needs no workgroup barrier either)
+    auto settle = [&](uint32_t j, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked) {
+        if (parked) { park_store(pk, atomicAdd(park_count, 1u), j, st, l, bound, env ? 1u : 0u); return; }
+        const uint32_t item = base + j;
+        float lambda[NL], c[NL];
+        for (int k = 0; k < NL; ++k) lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item);
+        Hit sh;
+        bool hit = sweep_finish(s, ray.o, ray.d, st, &sh);
+        shadow_ray_contribution<NL>(s, lambda, ray, env, hit, sh, c);
+        for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
+    };
+    // one ray of every item per step, so that a step parks at most one ray per lane
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t j = r * blockDim.x + threadIdx.x;
+        const uint32_t item = base + j, flags = j < n ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
+        for (uint32_t l = 0; l < light_samples; ++l) {
+            ShadowRayT<NL> ray;
+            if (j < n && load_shadow_ray<NL>(shadow, item, l, &ray)) {
+                const bool env = ((flags >> l) & 1u) != 0;
+                float bound = PT_INF; int stop = shadow_env_stop(s);
+                if (!env && !shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) {
+                    for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
+                } else {
+                    SweepState st;
+                    sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
+                    const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
+                    settle(j, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true));
+                }
+            }
+            park_drain(pk, park_count, r + 1 == rounds && l + 1 == light_samples, [&](uint32_t j2, SweepState& st, uint32_t l2, float bound, uint32_t kind) {
+                ShadowRayT<NL> pr;
+                load_shadow_ray<NL>(shadow, base + j2, l2, &pr);
+                const bool env = kind != 0u;
+                // a light ray searches with the early stop whenever it has a finite bound (shadow_light_bound)
+                const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
+                settle(j2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, stop2, st));
+            });
+        }
+    }
+    __threadfence_block();
+    for (uint32_t r = 0; r < rounds; ++r) {  // pt.rs:349-392, 596: the item's rays summed in order, divided by L
+        const uint32_t j = r * blockDim.x + threadIdx.x;
+        if (j >= n) continue;
+        const uint32_t item = base + j, slot = qu(shadow, Layout<NL>::sh_slot, item);
+        float lc[NL];
+        for (int k = 0; k < NL; ++k) lc[k] = 0.0f;
+        for (uint32_t l = 0; l < light_samples; ++l)
+            for (int k = 0; k < NL; ++k) lc[k] += qf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item);
+        for (int k = 0; k < NL; ++k) energy[(size_t)k * energy_stride + slot] += lc[k] / (float)light_samples;
+    }
+}
+
+template <int NL>
+__global__ void __launch_bounds__(kBlock) k_accumulate(RenderParams rp, const uint32_t* __restrict__ pixels, const float* __restrict__ energy,
+                                                      float* __restrict__ film) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < rp.chunk_pixels; p += gridDim.x * blockDim.x) {
+        uint32_t pixel = pixels[p];
+        float4* px = reinterpret_cast<float4*>(film) + pixel;
+        float4 v = *px;
+        float f[4] = {v.x, v.y, v.z, v.w};
+        stage_accumulate_pixel<NL>(rp, energy, p, pixel, f);
+        *px = make_float4(f[0], f[1], f[2], f[3]);
+    }
+}
+
+// ---- probes (parity tests of single stages)
+template <int USE_LDS>
+__global__ void __launch_bounds__(kBlock) k_probe_intersect(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                           uint32_t n, const float* __restrict__ o, const float* __restrict__ d, pt_hit* __restrict__ out) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Hit h;
+        bool ok = world_hit(s, f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), &h);
+        pt_hit r;
+        memset(&r, 0, sizeof(r));
+        if (ok) {
+            r.valid = 1; r.t = h.t; r.point[0] = h.p.x; r.point[1] = h.p.y; r.point[2] = h.p.z;
+            r.normal[0] = h.n.x; r.normal[1] = h.n.y; r.normal[2] = h.n.z; r.uv[0] = h.u; r.uv[1] = h.v;
+            r.material = h.material; r.instance = h.instance;
+        }
+        out[i] = r;
+    }
+}
+}  // namespace ptk
+#endif

@@ -1,0 +1,36 @@
+// pt_launch.h — host-side launchers of the kernel families.  Each family's kernels are instantiated in its own translation unit
+// (pt_kern_extend.hip, pt_kern_shade.hip, pt_kern_shadow.hip: the build compiles them in parallel); the engine picks the variant —
+// staging mode (PT_LDS_*) x traversal form x wavelengths per path x what the scene can need — and calls these.
+#ifndef PT_LAUNCH_H
+#define PT_LAUNCH_H
+#include <hip/hip_runtime.h>
+#include "pt_stages.h"
+
+namespace ptk {
+
+enum { PT_LDS_NONE = 0, PT_LDS_ALL = 1, PT_LDS_CORE = 2 };                 // what stage_scene copies into LDS
+enum { PT_SHADE_LEAN = 0, PT_SHADE_NO_ENV = 1, PT_SHADE_FULL = 2 };       // k_shade forms
+enum { PT_FORM_ANY = 0, PT_FORM_WALK = 1, PT_FORM_SWEEP = 2, PT_FORM_POOLED = 3, PT_FORM_PARKED = 4 };  // traversal kernels
+constexpr int kBlock = 256;
+constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // stage the blob in LDS when it fits (keeps >= 2 workgroups per CU)
+constexpr uint32_t kParkCap = 512, kParkFields = 16;
+enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_FIELDS };  // per-workgroup statistics (Profile counters)
+uint32_t pool_lds_bytes();  // static LDS of the pooled traversal kernels, on top of the staged blob
+
+struct LaunchCfg { int grid; uint32_t lds_bytes; hipStream_t stream; int lds_mode; };
+struct SceneArgs { const uint32_t* blob; uint32_t blob_words; const float* tex; };
+
+void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, ptd::Queue paths, ptd::Queue hits, uint32_t seg_cap, const uint32_t* count_in, uint32_t* park);
+void launch_shade(const LaunchCfg& c, int nl, int form, const SceneArgs& sc, const ptd::RenderParams& rp, uint32_t bounce, const uint32_t* pixels, ptd::Queue paths_in,
+                  ptd::Queue hits, ptd::Queue paths_out, ptd::Queue shadow, float* energy, uint32_t seg_cap, const uint32_t* count_in, uint32_t* count_out,
+                  uint32_t* shadow_count, unsigned long long* block_stats);
+void launch_shadow(const LaunchCfg& c, int form, int nl, bool env, const SceneArgs& sc, uint32_t light_samples, ptd::Queue shadow, float* energy, uint32_t energy_stride,
+                   uint32_t seg_cap, const uint32_t* count_in, uint32_t* park, ptd::Queue idle_hits);
+void launch_probe_intersect(const LaunchCfg& c, const SceneArgs& sc, uint32_t n, const float* o, const float* d, pt_hit* out);
+// hipFuncAttributeMaxDynamicSharedMemorySize for every kernel of the family that stages the blob
+hipError_t allow_lds_extend(uint32_t bytes);
+hipError_t allow_lds_shade(uint32_t bytes);
+hipError_t allow_lds_shadow(uint32_t bytes);
+
+}  // namespace ptk
+#endif

@@ -403,7 +403,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             std::vector<uint32_t> bits;
             std::vector<int> root_of;  // per bit: the bit whose box test it copies (itself if none)
             uint32_t bit = 0;
-            uint64_t mesh_mask = 0;
+            uint64_t mesh_mask = 0, owner_mask = 0;
             bool any_walked = false;
             for (size_t j = 0; j < order.size(); ++j) {
                 const uint32_t* nd = &nodes[order[j] * PT_NODE_WORDS];
@@ -417,6 +417,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                 bits.insert(bits.end(), own, own + PT_SWEEP_BIT_WORDS);
                 root_of.push_back((int)first_bit);
                 if (in.kind == PT_SHAPE_MESH && walked[inst]) any_walked = true;
+                if (in.kind != PT_SHAPE_MESH) owner_mask |= 1ull << first_bit;
                 std::vector<uint32_t> leaders;  // word offsets of the triangle-leaf records that keep their own box test
                 uint64_t flat_leaders = 0;
                 if (in.kind == PT_SHAPE_MESH && !walked[inst]) {
@@ -447,6 +448,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                         } else if (root_of.back() != (int)first_bit) box_words = bits[(size_t)root_of.back() * PT_SWEEP_BIT_WORDS + 2];
                         uint32_t tb[PT_SWEEP_BIT_WORDS] = {rec_off, triw, box_words, (kf & ~0x100u) | flat << 8 | inst << 16, 0u, 0u, mesh_perm0[in.mesh], mesh_perm1[in.mesh]};
                         bits.insert(bits.end(), tb, tb + PT_SWEEP_BIT_WORDS);
+                        if (in.has_transform) owner_mask |= 1ull << bit;
                         ++tri_count; ++bit;
                     }
                 }
@@ -475,6 +477,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             w[PT_HDR_SWEEP_BITS_OFF] = (uint32_t)w.size();
             w.insert(w.end(), bits.begin(), bits.end());
             w[PT_HDR_SWEEP_MESH_MASK] = (uint32_t)mesh_mask; w[PT_HDR_SWEEP_MESH_MASK + 1] = (uint32_t)(mesh_mask >> 32);
+            w[PT_HDR_SWEEP_OWNER_MASK] = (uint32_t)owner_mask; w[PT_HDR_SWEEP_OWNER_MASK + 1] = (uint32_t)(owner_mask >> 32);
             w[PT_HDR_SWEEP_OFF] = sweep_off; w[PT_HDR_SWEEP_COUNT] = (uint32_t)order.size();
             if (any_walked) w[PT_HDR_FLAGS] |= PT_FLAG_SWEEP_WALKS;
         }

@@ -86,14 +86,15 @@ def test_golden_vectors(emu):
 def test_leaf_sweep_equals_bvh_walk(emu, pkg, monkeypatch, scene):
     """Scenes of <= 64 instances take world_hit_sweep (with the triangle leaves of small meshes in the table and the BVHs of
     big meshes walked from it); the pure BVH walk (flag 16), the exact slab test (2) and no culling (4) must give the same
-    bits: hits, films and ray counters."""
+    bits: hits, films and ray counters.  So must phase 3 as independent unbounded tests + ordered replay (128: the logic of the
+    wave-pooled kernels; with 4, the masks are not culled by the bound either)."""
     b = pkg.scene.SCENES[scene]()
     o, d = ps.golden_rays(scene, 4096, 33)
     # axis-parallel directions take the undecided path for every box
     d[:64] = np.eye(3, dtype=np.float32)[np.arange(64) % 3] * np.where(np.arange(64) % 2, -1.0, 1.0)[:, None].astype(np.float32)
     rd = pkg.api.render_desc(24, 24, 4, 5, light_samples=2)
     results = []
-    for flags in ("0", "16", "2", "18", "4"):
+    for flags in ("0", "16", "2", "18", "4", "128", "132"):
         monkeypatch.setenv("PTEMU_FLAGS", flags)
         sc = emu.create_scene(b)
         assert sc.uses_leaf_sweep() == (flags not in ("16", "18"))

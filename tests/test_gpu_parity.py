@@ -187,6 +187,22 @@ def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
         assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits), env
 
 
+@pytest.mark.parametrize("scene,L,hero", [("cornell_box", 2, 1), ("mixed_small", 3, 1), ("white_furnace", 6, 1), ("cornell_box", 2, 4)])
+def test_pooled_phase3_changes_nothing(engine, pkg, monkeypatch, scene, L, hero):
+    """Pure sweep scenes: phase 3 pooled per wave (PT_AMD_POOL=1: the candidate triangles of a wave's 64 rays tested 64 at a time, the
+    acceptance replayed per ray in leaf order) gives the film and the counters of the lane-by-lane loop bit for bit.  (It is not the
+    default form: measured slower)"""
+    b = pkg.scene.SCENES[scene]()
+    rd = pkg.api.render_desc(192, 160, 10, 8, light_samples=L, seed=4, hero_wavelengths=hero)
+    base, pbase = engine.create_scene(b).render(rd)
+    monkeypatch.setenv("PT_AMD_POOL", "1")
+    for blocks in ("64", "1"):   # long segments: many rounds per workgroup, pools refilled
+        monkeypatch.setenv("PT_AMD_BLOCKS_PER_CU", blocks)
+        film, prof = engine.create_scene(b).render(rd)
+        assert np.array_equal(base.view(np.uint32), film.view(np.uint32)), blocks
+        assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits)
+
+
 def test_full_size_cornell_properties(engine, oracle, pkg):
     """BASELINE.json C2 geometry (1024x1024, max_bounces 8, L = 2) at 2 spp (2 M paths: seconds for the threaded oracle on
     the GPU box's host): the north-star bar directly — film within 1e-4 L-inf of the oracle at matched seeds, ray counters
