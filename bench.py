@@ -26,6 +26,33 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# VALU issue rates measured on MI355X with tools/microbench/valu_issue.hip (profiles/r2a_valu_issue.txt), G wave64-instructions/s for the
+# whole chip at 5-8 waves per SIMD: v_fma/add/mul/mov/xor issue in 2 cycles, every other VALU instruction (min/max/cmp/cndmask/integer/
+# f64/packed/any with an SGPR operand) in 4.  The kernels here are ~80 % of the second kind.
+VALU_PEAK_4CYCLE, VALU_PEAK_2CYCLE = 600.0, 990.0
+# the reference's only self-reported figure: 23.9 Mrays/s on 20 threads of an unnamed CPU (/root/reference/data/config.toml:4-8)
+REFERENCE_SELF_REPORTED_MRAYS, REFERENCE_SELF_REPORTED_THREADS = 23.9, 20
+
+
+def usable_cpus():
+    """Host threads this process can really run on: the affinity mask capped by the cgroup CPU quota (the GPU boxes show 256 hardware
+    threads and a quota of 16 CPUs; 256 oracle threads there run at half the rate of 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 STAGES = ["generate", "extend", "shade", "shadow", "accumulate"]
 
 
@@ -49,7 +76,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=120, help="samples per pixel per step and per GPU (120 x 1024^2 = one full 128 Mi-slot pass)")
+    ap.add_argument("--spp-per-step", type=int, default=1024, help="samples per pixel per step and per GPU (1024 = a step is the whole C2 frame: 1.07 G samples in 128 Mi-slot passes)")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--max-bounces", type=int, default=8)
@@ -59,6 +86,7 @@ def main():
     ap.add_argument("--hero", type=int, default=1, help="wavelengths per path: 1, or 4 for the hero-wavelength variant (C5)")
     ap.add_argument("--workload", default=None, help="label for config.workload (default: derived from the arguments)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline (0 = skip)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl = RCCL) even for one process, so that the film reduce runs through RCCL")
     args = ap.parse_args()
 
     import numpy as np
@@ -72,8 +100,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     device_index = local_rank % max(1, torch.cuda.device_count())  # (a launcher that exposes one GPU per process shows it as device 0)
     torch.cuda.set_device(device_index)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
     n_gpus = world
 
@@ -98,7 +130,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -144,32 +176,52 @@ def main():
         cam = sum(p.camera_rays for p in profs)
         segs = kitems[1]
         d_bar = segs / cam if cam else 0.0
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this same command
+        # HBM bytes per launch of that kernel, and its VALU issue rate, from the committed rocprofv3 PMC passes of this same command
         # (profiles/<tag>_summary.json, tools/profile_gpu.sh): (2 x FETCH_SIZE + WRITE_SIZE) KiB — FETCH_SIZE reads 1/2 of a
         # coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact (calibrated on k_generate's 68 B/item).
-        traffic, traffic_src = None, None
+        # Only a profile taken on exactly this workload counts (every key below must match); otherwise the fields stay null.
+        workload_key = {"scene": args.scene, "width": W, "height": H, "max_bounces": args.max_bounces, "min_bounces": args.min_bounces,
+                        "light_samples": L, "hero": args.hero, "spp_per_step": S, "n_gpus": n_gpus}
+        traffic, traffic_src, valu = None, None, None
         try:
             import glob
-            # the newest committed profile (by tag) that was taken on this very workload
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), reverse=True):
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), key=os.path.getmtime, reverse=True):
                 summ = json.load(open(path))
-                wl = summ.get("workload")
-                if not wl or (wl["scene"], wl["spp_per_step"], wl["n_gpus"], int(wl["samples_per_step"])) != (args.scene, S, n_gpus, W * H * S):
+                if summ.get("workload_key") != workload_key:
                     continue
-                kname = "k_" + STAGES[dom]
+                # the stage's kernel under whichever of its forms ran (k_shadow, k_shadow_parked, ...): the one with the most time
+                names = [k for k in summ.get("kernels", {}) if k.startswith("k_" + STAGES[dom])]
+                if not names:
+                    continue
+                kname = max(names, key=lambda k: summ["kernels"][k]["total_ms"])
                 traffic = (2.0 * summ["FETCH_SIZE"][kname]["avg_per_launch"] + summ["WRITE_SIZE"][kname]["avg_per_launch"]) * 1024.0
                 traffic_src = os.path.basename(path)
+                sq = summ.get("SQ", {}).get(kname, {})
+                if sq.get("SQ_INSTS_VALU") and summ["kernels"][kname].get("total_ms"):
+                    # (the SQ counters were collected over the same launches the trace pass timed: same command, same step count)
+                    rate = sq["SQ_INSTS_VALU"] / (summ["kernels"][kname]["total_ms"] * 1e-3) / 1e9
+                    valu = {"kernel": kname, "achieved": rate, "unit": "G wave64-instructions/s", "peak_4cycle_class": VALU_PEAK_4CYCLE,
+                            "peak_2cycle_class": VALU_PEAK_2CYCLE, "frac_of_4cycle_peak": rate / VALU_PEAK_4CYCLE, "frac_of_2cycle_peak": rate / VALU_PEAK_2CYCLE,
+                            "lane_utilization": (sq["SQ_THREAD_CYCLES_VALU"] / (64.0 * sq["SQ_ACTIVE_INST_VALU"])) if sq.get("SQ_ACTIVE_INST_VALU") else None,
+                            "instructions_per_wave": sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"] if sq.get("SQ_WAVES") else None,
+                            "peaks_source": "profiles/r2a_valu_issue.txt (tools/microbench/valu_issue.hip on MI355X): fma/add/mul/mov/xor issue in 2 cycles per "
+                                            "wave64, min/max/cmp/cndmask/integer/f64/packed/SGPR-operand instructions in 4", "source": traffic_src}
                 break
         except Exception:
-            traffic = None
+            traffic, valu = None, None
+        # SURVEY.md 8(d)'s a-priori byte model next to the engine's own record sizes: B(sample) = 32 + D (192 + 72 L)
+        survey_bytes = 32.0 + d_bar * (192.0 + 72.0 * L)
         roofline = {"bound": "hbm", "kernel": "k_" + STAGES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_us": 1e6 * ksec[dom] / klaunch[dom], "algorithmic_bytes_per_launch": kbytes[dom] / klaunch[dom],
                     "device_time_share": ksec[dom] / sum(ksec) if sum(ksec) > 0 else None,
                     "whole_pipeline": {"bytes_per_sample": sum(kbytes) / cam if cam else None, "segments_per_sample": d_bar,
-                                       "achieved_GBs": sum(kbytes) / elapsed / 1e9, "frac": sum(kbytes) / elapsed / 1e9 / HBM_PEAK_GBS},
-                    "kernels": kernels,
-                    "note": "latency/VALU-bound by construction: the scene (%d B) is LDS-resident, HBM only carries the queues" % engine.lib.pt_debug_scene_info(scene.handle, 0)}
+                                       "achieved_GBs": sum(kbytes) / elapsed / 1e9, "frac": sum(kbytes) / elapsed / 1e9 / HBM_PEAK_GBS,
+                                       "survey_model": {"bytes_per_sample": survey_bytes, "achieved_GBs": value * 1e6 * survey_bytes / 1e9,
+                                                        "frac": value * 1e6 * survey_bytes / 1e9 / HBM_PEAK_GBS}},
+                    "kernels": kernels, "valu": valu,
+                    "binding_resource": "VALU issue, not HBM: the scene (%d B) is LDS-resident, HBM only carries the queues; `frac` is the fraction of the HBM roof "
+                                        "the contract asks for, `valu` (when a matching profile is committed) the fraction of the measured VALU issue rate" % engine.lib.pt_debug_scene_info(scene.handle, 0)}
 
         # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
         cpu = None
@@ -177,25 +229,28 @@ def main():
             import oracle_loader
             oracle = oracle_loader.load(pkg)
             oscene = oracle.create_scene(builder)
-            cores = os.cpu_count() or 1
-            probe = pkg.api.render_desc(W, H, 1, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, shard=(0, 4), hero_wavelengths=args.hero)
-            t = time.perf_counter(); _, pp = oscene.render(probe); dt = time.perf_counter() - t
+            cores = usable_cpus()
+
+            def orender(rd):
+                t = time.perf_counter(); _, pr = oracle_loader.render_mt(oracle, oscene, rd, cores); return pr, time.perf_counter() - t
+            # calibrate on ~1 s of work, then a bounded sample: every 32x32 tile of the film (the thread pool takes them from one
+            # queue) at as many samples per pixel as the budget buys — at least 4 tiles per thread of ~1 s each, so the tail is short
+            pp, dt = orender(pkg.api.render_desc(W, H, 1, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, shard=(0, 4), hero_wavelengths=args.hero))
             rate = pp.camera_rays / dt
-            # the short probe overestimates the sustained rate (caches, clocks): calibrate once more on ~2 s of work
-            spp2 = max(1, min(64, int(rate * 2.0 / (W * H))))
-            probe2 = pkg.api.render_desc(W, H, spp2, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, hero_wavelengths=args.hero)
-            t = time.perf_counter(); _, pp = oscene.render(probe2); dt = time.perf_counter() - t
+            pp, dt = orender(pkg.api.render_desc(W, H, max(1, min(16, int(rate * 2.0 / (W * H)))), args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, hero_wavelengths=args.hero))
             rate = pp.camera_rays / dt
-            budget = rate * args.cpu_seconds
-            shard_count = max(1, int((W * H) / max(budget, 1.0)) + 1) if budget < W * H else 1
-            spp = max(1, int(budget / (W * H))) if shard_count == 1 else 1
-            rdc = pkg.api.render_desc(W, H, spp, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, shard=(0, shard_count) if shard_count > 1 else (0, 0), hero_wavelengths=args.hero)
-            t = time.perf_counter(); _, pc = oscene.render(rdc); dt = time.perf_counter() - t
+            spp = max(1, int(rate * args.cpu_seconds / (W * H)))
+            pc, dt = orender(pkg.api.render_desc(W, H, spp, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, hero_wavelengths=args.hero))
+            rays_per_sample = (pc.bounce_rays + pc.shadow_rays) / max(1, pc.camera_rays)
             cpu = {"value": pc.camera_rays / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-                   "sample": "oracle (C++ restatement of the reference PT path, std::thread over 32x32 tiles) on %d host threads: "
-                             "tiles t %% %d == 0 of the %dx%d film at %d spp = %d samples in %.1f s; Rust reference not buildable here"
-                             % (cores, shard_count, W, H, spp, pc.camera_rays, dt),
-                   "rays_per_sample": (pc.bounce_rays + pc.shadow_rays) / max(1, pc.camera_rays)}
+                   "sample": "oracle (C++ restatement of the reference PT path, std::thread over a queue of 32x32 tiles) on %d host threads (os.cpu_count() = %d, "
+                             "capped by affinity and the cgroup CPU quota): the whole %dx%d film at %d spp = %d samples in %.1f s; Rust reference not buildable here"
+                             % (cores, os.cpu_count() or 0, W, H, spp, pc.camera_rays, dt),
+                   "rays_per_sample": rays_per_sample, "Mrays_per_s": (pc.bounce_rays + pc.shadow_rays) / dt / 1e6,
+                   "per_thread_Msamples_per_s": pc.camera_rays / dt / 1e6 / cores,
+                   "reference_self_reported": {"Mrays_per_s": REFERENCE_SELF_REPORTED_MRAYS, "threads": REFERENCE_SELF_REPORTED_THREADS,
+                                               "source": "data/config.toml:4-8 of the reference (its author's machine, CPU not named)",
+                                               "as_Msamples_per_s_at_this_rays_per_sample": REFERENCE_SELF_REPORTED_MRAYS / rays_per_sample if rays_per_sample else None}}
 
         out = {
             "metric": metric_name,
@@ -206,7 +261,7 @@ def main():
                                                      "light_samples=%d, wavelengths 380-750 nm" % (W, H, args.max_bounces, L) if (args.scene, args.hero) == ("cornell_box", 1)
                                                      else "%s %dx%d, PT+NEE, max_bounces=%d, min_bounces=%d, light_samples=%d, %d wavelength(s) per path" %
                                                      (args.scene, W, H, args.max_bounces, args.min_bounces, L, args.hero)),
-                       "scene": args.scene, "spp_per_step_per_gpu": args.spp_per_step, "spp_per_step": S, "samples_per_step": total_samples / args.steps,
+                       "workload_key": workload_key, "scene": args.scene, "spp_per_step_per_gpu": args.spp_per_step, "spp_per_step": S, "samples_per_step": total_samples / args.steps,
                        "parallelism": "film tiles 32x32 dealt along diagonals over %d GPU(s), one RCCL reduce of the XYZ film" % n_gpus,
                        "device": engine.device_info()},
             "rays_per_s": {"segments": counts[2] / elapsed, "shadow": counts[7] / elapsed,
@@ -215,7 +270,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

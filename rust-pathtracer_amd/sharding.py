@@ -27,7 +27,7 @@ def reduce_film(film, dst=0):
     """Sum the rank films into rank `dst` (the only exchange step of the whole path).  `film` is a torch tensor on the
     backend's device (HBM for nccl, host for gloo); returns it (complete on `dst` only)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():   # (also with one rank: bench.py --force-dist runs the RCCL call path on a single GPU)
         dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
     return film
 
@@ -35,7 +35,7 @@ def reduce_film(film, dst=0):
 def max_over_ranks(value, device):
     import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         t = torch.tensor([value], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -46,6 +46,6 @@ def sum_over_ranks(values, device):
     import torch
     import torch.distributed as dist
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(x) for x in t.tolist()]

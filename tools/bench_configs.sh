@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs bench.py on the BASELINE.json configurations C2..C5 (C1 is the CPU plumbing case) and stores one JSON line each.
 OUT=${1:-gpurun_out/configs}; mkdir -p $OUT
-python bench.py --steps 4 --warmup 1 --cpu-seconds 10 > $OUT/C2.json 2> $OUT/C2.err
+python bench.py --steps 4 --warmup 1 --cpu-seconds 10 --spp-per-step 120 > $OUT/C2.json 2> $OUT/C2.err
 python bench.py --scene cornell_gem --width 1920 --height 1080 --max-bounces 12 --spp-per-step 60 --steps 3 --warmup 1 --cpu-seconds 10 \
   --workload "C3: cornell_box_diamond_gem (moissanite GGX, brilliant_diamond.obj, env constant 0), 1920x1080, max_bounces=12, L=2" > $OUT/C3.json 2> $OUT/C3.err
 python bench.py --scene hdri_test --max-bounces 4 --light-samples 6 --spp-per-step 120 --steps 3 --warmup 1 --cpu-seconds 10 \

@@ -50,6 +50,7 @@ def main():
                 b = json.loads(line)
                 summary["workload"] = {"scene": b["config"]["scene"], "spp_per_step": b["config"]["spp_per_step"], "samples_per_step": b["config"]["samples_per_step"],
                                        "metric": b["metric"], "n_gpus": b["n_gpus"]}
+                summary["workload_key"] = b["config"].get("workload_key")   # bench.py only takes counters from a profile whose key equals its own
     except (OSError, ValueError, KeyError):
         pass
     # 1. kernel stats
@@ -110,7 +111,14 @@ def main():
     summary["derived"] = derived
     with open(os.path.join(prof, "%s_summary.json" % tag), "w") as fh:
         json.dump(summary, fh, indent=1, sort_keys=True)
-    print(json.dumps(summary, indent=1, sort_keys=True)[:6000])
+    # a copy next to the raw output: gpurun brings gpurun_out/ back, not profiles/
+    for name in ("%s_summary.json" % tag, "%s_kernel_stats.csv" % tag, "%s_rocprofv3_kernel_stats.csv" % tag):
+        try:
+            with open(os.path.join(prof, name)) as src, open(os.path.join(out_dir, name), "w") as dst:
+                dst.write(src.read())
+        except OSError:
+            pass
+    print(json.dumps(summary.get("derived", {}), indent=1, sort_keys=True)[:4000])
 
 
 if __name__ == "__main__":
