@@ -30,7 +30,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PT_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define PT_HD static inline

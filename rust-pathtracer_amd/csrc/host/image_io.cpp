@@ -5,12 +5,18 @@
 #include <zlib.h>
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <map>
 
 namespace pth {
 namespace {
+
+// Asset files are untrusted input: every size read from a header is checked against the file before it is used as an offset, and
+// no image may exceed this many pixels (2^28: a 16384 x 16384 map; 4 GB of f32 RGBA).
+constexpr uint64_t kMaxPixels = 1ull << 28;
+bool sane_dimensions(uint64_t w, uint64_t h) { return w > 0 && h > 0 && w <= (1u << 20) && h <= (1u << 20) && w * h <= kMaxPixels; }
 
 bool read_file(const std::string& path, std::vector<uint8_t>* out, std::string* error) {
     FILE* f = fopen(path.c_str(), "rb");
@@ -30,6 +36,7 @@ uint16_t le16(const uint8_t* p) { return (uint16_t)(p[1] << 8 | p[0]); }
 uint64_t le64(const uint8_t* p) { return (uint64_t)le32(p + 4) << 32 | le32(p); }
 
 bool inflate_all(const uint8_t* src, size_t n, std::vector<uint8_t>* dst, size_t expected, std::string* error) {
+    if (expected > (1ull << 33)) { *error = "compressed block claims an absurd size"; return false; }
     dst->resize(expected);
     uLongf len = (uLongf)expected;
     int rc = uncompress(dst->data(), &len, src, (uLong)n);
@@ -53,8 +60,11 @@ bool decode_png(const std::vector<uint8_t>& d, Raster8* out, std::string* error)
         uint32_t len = be32(&d[p]);
         const uint8_t* type = &d[p + 4];
         const uint8_t* body = &d[p + 8];
-        if (p + 12 + len > d.size()) { *error = "truncated PNG chunk"; return false; }
-        if (!memcmp(type, "IHDR", 4)) { w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+        if ((uint64_t)p + 12 + len > d.size()) { *error = "truncated PNG chunk"; return false; }
+        if (!memcmp(type, "IHDR", 4)) {
+            if (len < 13) { *error = "PNG IHDR chunk is too short"; return false; }
+            w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+        }
         else if (!memcmp(type, "PLTE", 4)) palette.assign(body, body + len);
         else if (!memcmp(type, "tRNS", 4)) trns.assign(body, body + len);
         else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
@@ -62,10 +72,11 @@ bool decode_png(const std::vector<uint8_t>& d, Raster8* out, std::string* error)
         p += 12 + len;
     }
     if (w == 0 || h == 0) { *error = "PNG without IHDR"; return false; }
+    if (!sane_dimensions(w, h)) { *error = "PNG dimensions out of range"; return false; }
     if (interlace != 0) { *error = "interlaced PNG is not supported"; return false; }
     int samples = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!samples || !(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3)))) { *error = "unsupported PNG colour type / depth"; return false; }
-    size_t bpp_bits = (size_t)samples * depth, stride = (w * bpp_bits + 7) / 8, bpp = bpp_bits < 8 ? 1 : bpp_bits / 8;
+    size_t bpp_bits = (size_t)samples * depth, stride = ((size_t)w * bpp_bits + 7) / 8, bpp = bpp_bits < 8 ? 1 : bpp_bits / 8;
     std::vector<uint8_t> raw;
     if (!inflate_all(idat.data(), idat.size(), &raw, (stride + 1) * h, error)) return false;
     if (raw.size() != (stride + 1) * h) { *error = "PNG data has the wrong size"; return false; }
@@ -114,15 +125,18 @@ bool decode_bmp(const std::vector<uint8_t>& d, Raster8* out, std::string* error)
     int32_t w = (int32_t)le32(&d[18]), h = (int32_t)le32(&d[22]);
     uint16_t bits = le16(&d[28]);
     uint32_t compression = le32(&d[30]), colors = hdr >= 40 ? le32(&d[46]) : 0;
-    if (hdr < 40 || w <= 0 || h == 0 || !(compression == 0 || (compression == 3 && bits == 32)) || !(bits == 8 || bits == 24 || bits == 32)) {
+    if (hdr < 40 || w <= 0 || h == 0 || h == INT32_MIN || !(compression == 0 || (compression == 3 && bits == 32)) || !(bits == 8 || bits == 24 || bits == 32)) {
         *error = "unsupported BMP variant"; return false;
     }
     bool top_down = h < 0;
     uint32_t H = (uint32_t)(h < 0 ? -h : h), W = (uint32_t)w;
+    if (!sane_dimensions(W, H)) { *error = "BMP dimensions out of range"; return false; }
     size_t stride = ((size_t)W * bits + 31) / 32 * 4;
-    if (offset + stride * H > d.size()) { *error = "truncated BMP"; return false; }
-    const uint8_t* pal = &d[14 + hdr];
+    if ((uint64_t)offset + (uint64_t)stride * H > d.size()) { *error = "truncated BMP"; return false; }
     if (bits == 8 && colors == 0) colors = 256;
+    if (colors > 256) { *error = "BMP palette too large"; return false; }
+    if (bits == 8 && (uint64_t)14 + hdr + 4ull * colors > d.size()) { *error = "BMP palette runs past the end of the file"; return false; }
+    const uint8_t* pal = bits == 8 ? &d[14 + hdr] : nullptr;
     out->w = W; out->h = H; out->grey = false;
     out->rgba.resize((size_t)W * H * 4);
     for (uint32_t y = 0; y < H; ++y) {
@@ -191,6 +205,7 @@ bool read_hdr(const std::string& path, float alpha_fill, Image* out, std::string
     line(&l);
     int h = 0, w = 0;
     if (sscanf(l.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) { *error = "unsupported HDR orientation: " + l; return false; }
+    if (!sane_dimensions((uint64_t)w, (uint64_t)h)) { *error = "HDR dimensions out of range"; return false; }
     out->width = (uint32_t)w; out->height = (uint32_t)h; out->channels = 4;
     out->data.resize((size_t)w * h * 4);
     std::vector<uint8_t> scan((size_t)w * 4);
@@ -241,7 +256,7 @@ bool read_exr(const std::string& path, Image* out, std::string* error) {
         ++p;
         if (p + 4 > d.size()) { *error = "truncated EXR header"; return false; }
         uint32_t size = le32(&d[p]); p += 4;
-        if (p + size > d.size()) { *error = "truncated EXR header"; return false; }
+        if ((uint64_t)p + size > d.size()) { *error = "truncated EXR header"; return false; }
         attr[name].assign(&d[p], &d[p] + size); p += size;
     }
     if (!attr.count("channels") || !attr.count("compression") || !attr.count("dataWindow")) { *error = "EXR header lacks required attributes"; return false; }
@@ -252,9 +267,11 @@ bool read_exr(const std::string& path, Image* out, std::string* error) {
         size_t q = 0;
         while (q < c.size() && c[q]) {
             Channel ch;
-            while (c[q]) ch.name.push_back((char)c[q++]);
+            while (q < c.size() && c[q]) ch.name.push_back((char)c[q++]);
             ++q;
+            if (q + 16 > c.size()) { *error = "truncated EXR channel list"; return false; }
             ch.type = (int)le32(&c[q]);
+            if (ch.type < 0 || ch.type > 2) { *error = "unknown EXR pixel type"; return false; }
             uint32_t xs = le32(&c[q + 8]), ys = le32(&c[q + 12]);
             if (xs != 1 || ys != 1) { *error = "subsampled EXR channels are not supported"; return false; }
             q += 16;
@@ -262,12 +279,16 @@ bool read_exr(const std::string& path, Image* out, std::string* error) {
             channels.push_back(ch);
         }
     }
+    if (attr["compression"].size() < 1 || attr["dataWindow"].size() < 16) { *error = "EXR header attribute is too short"; return false; }
+    if (channels.empty()) { *error = "EXR file without channels"; return false; }
     int compression = attr["compression"][0];
     if (compression > 3) { *error = "EXR compression " + std::to_string(compression) + " is not supported (only none, RLE, ZIPS, ZIP)"; return false; }
     const uint8_t* dw = attr["dataWindow"].data();
     int x0 = (int)le32(dw), y0 = (int)le32(dw + 4), x1 = (int)le32(dw + 8), y1 = (int)le32(dw + 12);
-    int W = x1 - x0 + 1, H = y1 - y0 + 1;
-    if (W <= 0 || H <= 0) { *error = "empty EXR data window"; return false; }
+    const int64_t W64 = (int64_t)x1 - x0 + 1, H64 = (int64_t)y1 - y0 + 1;
+    if (W64 <= 0 || H64 <= 0) { *error = "empty EXR data window"; return false; }
+    if (!sane_dimensions((uint64_t)W64, (uint64_t)H64)) { *error = "EXR data window out of range"; return false; }
+    const int W = (int)W64, H = (int)H64;
     out->width = (uint32_t)W; out->height = (uint32_t)H; out->channels = 4;
     out->data.assign((size_t)W * H * 4, 0.0f);
     bool has_alpha = false;
@@ -278,28 +299,35 @@ bool read_exr(const std::string& path, Image* out, std::string* error) {
     int tile_w = 0, tile_h = 0;
     if (tiled) {
         if (!attr.count("tiles")) { *error = "tiled EXR without a tiles attribute"; return false; }
+        if (attr["tiles"].size() < 9) { *error = "EXR tiles attribute is too short"; return false; }
         const uint8_t* t = attr["tiles"].data();
         tile_w = (int)le32(t); tile_h = (int)le32(t + 4);
+        if (tile_w <= 0 || tile_h <= 0) { *error = "bad EXR tile size"; return false; }
         if ((t[8] & 0xf) != 0) { *error = "mip/rip-mapped EXR files are not supported"; return false; }
     }
     int block_lines = compression == 3 ? 16 : 1;
     size_t blocks = tiled ? (size_t)((W + tile_w - 1) / tile_w) * ((H + tile_h - 1) / tile_h) : (size_t)(H + block_lines - 1) / block_lines;
-    if (p + 8 * blocks > d.size()) { *error = "truncated EXR offset table"; return false; }
+    if ((uint64_t)p + 8ull * blocks > d.size()) { *error = "truncated EXR offset table"; return false; }
     std::vector<uint8_t> raw, tmp;
     for (size_t b = 0; b < blocks; ++b) {
-        size_t off = (size_t)le64(&d[p + 8 * b]);
+        const uint64_t off64 = le64(&d[p + 8 * b]);
+        if (off64 > d.size()) { *error = "bad EXR block offset"; return false; }
+        const size_t off = (size_t)off64;
         int bx, by, bw, bh; uint32_t size; const uint8_t* src;
         if (tiled) {
             if (off + 20 > d.size()) { *error = "bad EXR tile offset"; return false; }
-            int tx = (int)le32(&d[off]), ty = (int)le32(&d[off + 4]);
+            const int64_t tx = (int32_t)le32(&d[off]), ty = (int32_t)le32(&d[off + 4]);
             size = le32(&d[off + 16]); src = &d[off + 20];
-            bx = tx * tile_w; by = ty * tile_h; bw = std::min(tile_w, W - bx); bh = std::min(tile_h, H - by);
+            if (tx < 0 || ty < 0 || tx * tile_w >= W || ty * tile_h >= H) { *error = "EXR tile coordinates outside the data window"; return false; }
+            bx = (int)(tx * tile_w); by = (int)(ty * tile_h); bw = std::min(tile_w, W - bx); bh = std::min(tile_h, H - by);
         } else {
             if (off + 8 > d.size()) { *error = "bad EXR scanline offset"; return false; }
-            by = (int)le32(&d[off]) - y0; size = le32(&d[off + 4]); src = &d[off + 8];
-            bx = 0; bw = W; bh = std::min(block_lines, H - by);
+            const int64_t line = (int64_t)(int32_t)le32(&d[off]) - y0;
+            size = le32(&d[off + 4]); src = &d[off + 8];
+            if (line < 0 || line >= H) { *error = "EXR scanline outside the data window"; return false; }
+            by = (int)line; bx = 0; bw = W; bh = std::min(block_lines, H - by);
         }
-        if (src + size > d.data() + d.size() || bw <= 0 || bh <= 0 || by < 0) { *error = "bad EXR block"; return false; }
+        if ((uint64_t)(src - d.data()) + size > d.size() || bw <= 0 || bh <= 0 || by < 0 || bx < 0 || bx + bw > W || by + bh > H) { *error = "bad EXR block"; return false; }
         size_t expect = pixel_bytes * (size_t)bw * bh;
         const uint8_t* data = src;
         if (compression != 0 && size < expect) {
@@ -310,6 +338,7 @@ bool read_exr(const std::string& path, Image* out, std::string* error) {
                     int n = (int8_t)src[q++];
                     if (n < 0) { n = -n; if (q + n > size) { *error = "bad EXR RLE data"; return false; } tmp.insert(tmp.end(), src + q, src + q + n); q += n; }
                     else { if (q >= size) { *error = "bad EXR RLE data"; return false; } tmp.insert(tmp.end(), (size_t)n + 1, src[q++]); }
+                    if (tmp.size() > expect) { *error = "EXR RLE block is longer than its tile"; return false; }
                 }
             } else if (!inflate_all(src, size, &tmp, expect, error)) return false;
             if (tmp.size() != expect) { *error = "EXR block has the wrong size"; return false; }

@@ -25,13 +25,14 @@ namespace {
 struct Options {
     std::string config = "data/config.toml", scene, root, output_dir = "output", stdout_log_level = "warn";
     bool has_scene = false, dry_run = false, write_film = false;
+    uint32_t hero = 0;   // --hero-wavelengths: 0 = as the render settings say (1)
     uint64_t seed = 1;
 };
 
 int usage(const char* msg) {
     if (msg) fprintf(stderr, "error: %s\n", msg);
     fprintf(stderr, "usage: ptcli [--config FILE] [--scene FILE] [-n|--dry-run] [--stdout-log-level LEVEL] [--write-log-level LEVEL]\n"
-                    "             [--root DIR] [--output-dir DIR] [--seed N] [--write-film]\n");
+                    "             [--root DIR] [--output-dir DIR] [--seed N] [--write-film] [--hero-wavelengths 1|4]\n");
     return 2;
 }
 
@@ -65,6 +66,7 @@ int main(int argc, char** argv) {
         else if (a == "--output-dir") { if (!value(&o.output_dir)) return usage("--output-dir needs a value"); }
         else if (a == "--seed") { if (!value(&v)) return usage("--seed needs a value"); o.seed = strtoull(v.c_str(), nullptr, 10); }
         else if (a == "--write-film") o.write_film = true;
+        else if (a == "--hero-wavelengths") { if (!value(&v)) return usage("--hero-wavelengths needs a value"); o.hero = (uint32_t)strtoul(v.c_str(), nullptr, 10); }
         else if (a == "-h" || a == "--help") { usage(nullptr); return 0; }
         else return usage(("unknown option " + a).c_str());
     }
@@ -104,6 +106,7 @@ int main(int argc, char** argv) {
                 fprintf(stderr, "skipping render settings %u: %s\n", i, pt_scene_file_last_error());
                 continue;
             }
+            if (o.hero) rd.hero_wavelengths = o.hero;   // engine extension (not in the reference's files): 4 wavelengths per path
             std::vector<float> film((size_t)rd.width * rd.height * 4);
             pt_profile prof;
             printf("rendering %ux%u, %u spp, max_bounces %u, light_samples %u\n", rd.width, rd.height, rd.spp, rd.max_bounces, rd.light_samples);

@@ -819,7 +819,9 @@ pt_status pt_config_render_desc(const pt_config* c, uint32_t i, uint64_t seed, p
     else {  // NaiveRenderer (src/renderer/naive.rs:67-103): pixels in row-major order, all samples summed, one division
         out->tile_width = s.width; out->tile_height = s.height; out->phase_samples = s.min_samples;
     }
-    out->hero_wavelengths = s.hwss ? 4u : 1u;
+    // `hwss` is parsed by the reference (src/parsing/config.rs:51) and read by nothing on the PT path: a no-op here too.  The engine's
+    // hero-wavelength variant is asked for explicitly (pt_render_desc.hero_wavelengths; ptcli --hero-wavelengths 4).
+    out->hero_wavelengths = 1u;
     return PT_OK;
 }
 pt_status pt_config_output_desc(const pt_config* c, uint32_t i, float factor, pt_output_desc* out) {

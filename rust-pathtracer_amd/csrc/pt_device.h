@@ -276,12 +276,13 @@ PT_HD bool aabb_hit(F4 a, F4 b, const RayPrep& rp, float* entry) {
 // Conservative cull: a node whose (approximate or exact) entry distance exceeds the closest hit so far by more than a margin cannot
 // contain a primitive whose computed hit is closer.  Primitives lie inside their boxes (except the reference's half-size Disk box,
 // for which culling is switched off), but a computed t can fall short of the box.  A triangle's t is an average of its vertices'
-// depths with same-sign weights, a rect's or disk's one division: a few ulp, margin 1e-5 (`beyond`).  A sphere's comes out of
-// sqrt(b^2 - 4ac), whose cancellation for a grazing ray costs up to sqrt(2 eps) = 4.9e-4 of t: margin 2e-3 (`wide`) for sphere
-// instances and for the nodes of the top-level BVH, which may hold one.  (Every box had 1e-5 until the GPU soak met that grazing
-// ray — fuzz seed 101684: a light sphere hit at t = 3.97678 in f32 whose box begins at 3.97688; the light-sample ray bounded by
-// its own light hit culled the light.)
-PT_HD bool beyond(float entry, float closest, float base, bool wide = false) { return entry > closest * (wide ? 1.002f : 1.00001f) + base; }
+// depths with same-sign weights, a rect's or disk's one division: a few ulp, margin 1e-5.  A sphere's comes out of -b - sqrt(b^2 - ac):
+// for a grazing ray the cancellation under the root costs up to sqrt(2 eps) = 4.9e-4 of t, and for a ray that starts close to a big
+// sphere the cancellation of -b against the root costs eps * |b|, which no margin relative to t covers.  So a box that holds a sphere
+// is never culled: sphere instances in the sweep table, and the nodes of the top-level BVH flagged PT_NODE_NO_CULL by the host.
+// (History: every box had margin 1e-5 until the GPU soak met a grazing ray — fuzz seed 101684, a light-sample ray bounded by its own
+// sphere light culled the light; spheres then got a margin of 2e-3, which the second case above still defeats.)
+PT_HD bool beyond(float entry, float closest, float base) { return entry > closest * 1.00001f + base; }
 
 // Three-way form of the filtered test for the leaf sweep: 1 = hit, 0 = miss, 2 = too close to call (the caller settles it
 // with aabb_hit_exact).  Requires rp.fast and no zero direction component.  `flat` (a box of zero thickness, known per leaf
@@ -585,7 +586,7 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
         float entry = 0.0f;
         bool ih = false, iu = true;   // (a ray the filter cannot take: every box is undecided)
         if (quick) aabb_classify2(a, b, wr, (kf & 0x100u) != 0, &entry, &ih, &iu);
-        if (bounded && cull_top && ih && beyond(entry, bound, wr.base, (kf & 0xffu) == PT_SHAPE_SPHERE)) ih = false;
+        if (bounded && cull_top && ih && (kf & 0xffu) != PT_SHAPE_SPHERE && beyond(entry, bound, wr.base)) ih = false;
         mark(ih, iu, pt_f2u(h0.z), pt_f2u(h0.w));
         const bool inside = ih || iu;
         if ((kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH && (kf >> 24) != 0u && PT_WAVE_ANY(inside)) {
@@ -625,7 +626,7 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
         float entry;
         PT_STAT(box_exact);
         bool h = aabb_hit_exact(bf4(s, box), bf4(s, box + 4), ro, rd, &entry);
-        if (bounded && h && (triw != 0u ? cull_mesh : cull_top) && beyond(entry, bound, 0.0f, (kf & 0xffu) == PT_SHAPE_SPHERE)) h = false;
+        if (bounded && h && (triw != 0u ? cull_mesh : cull_top) && (kf & 0xffu) != PT_SHAPE_SPHERE && beyond(entry, bound, 0.0f)) h = false;
         unc &= ~followers;
         if (h) hit |= 1ull << k | followers;
         else if (triw == 0u && (kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH) {
@@ -1036,7 +1037,7 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
             F4 a = *reinterpret_cast<const F4*>(nb), b = *reinterpret_cast<const F4*>(nb + 4);
             uint32_t exit_i = PT_NODE_EXIT(pt_f2u(a.w)), shape = pt_f2u(b.w);
             float entry;
-            bool box = aabb_hit_node(a, b, cr, cr_quick, &entry) && !((level_inst != NONE ? cull_mesh : cull_top) && beyond(entry, limit, cr.base, level_inst == NONE));
+            bool box = aabb_hit_node(a, b, cr, cr_quick, &entry) && !((level_inst != NONE ? cull_mesh : cull_top) && !(pt_f2u(a.w) & PT_NODE_NO_CULL) && beyond(entry, limit, cr.base));
             if (shape == PT_NODE_INNER) { i = box ? i + 1 : exit_i; }
             else { i = exit_i; if (box) pending = shape; }
         }

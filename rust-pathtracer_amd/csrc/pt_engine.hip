@@ -79,6 +79,17 @@ __global__ void __launch_bounds__(kBlock) k_probe_numerics(int which, uint32_t n
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// A device allocation that is freed on every way out of its scope (the probes below return early on any HIP error).
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
 struct DeviceBuffers {
     uint32_t capacity = 0, light_samples = 0, nl = 0;
     uint32_t *paths_a = nullptr, *paths_b = nullptr, *hits = nullptr, *shadow = nullptr, *pixels = nullptr, *counts = nullptr, *park = nullptr;
@@ -103,6 +114,8 @@ struct pt_scene {
     int device = 0, num_cus = 0;
     DeviceBuffers buf;
     std::vector<hipEvent_t> events;  // pairs (start, stop), grown on demand
+    float* film_cache = nullptr;     // pt_render's device film, kept between calls
+    size_t film_cache_bytes = 0;
 };
 
 namespace {
@@ -176,7 +189,11 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     if (capacity < 1024) capacity = 1024;
     uint64_t want = (uint64_t)pixels.size() * rd.sample_count;
     if (want < capacity) capacity = (uint32_t)(want ? want : 1);
-    const int grid = sc->num_cus * (int)env_u32("PT_AMD_BLOCKS_PER_CU", 64);  // queue segments = workgroups per launch
+    const uint32_t blocks_per_cu = env_u32("PT_AMD_BLOCKS_PER_CU", 64);
+    if (blocks_per_cu == 0 || blocks_per_cu > 1024) return fail(PT_ERR_INVALID_ARGUMENT, "PT_AMD_BLOCKS_PER_CU must be in 1..1024");
+    const int grid = sc->num_cus * (int)blocks_per_cu;  // queue segments = workgroups per launch
+    // a pass holds at least one whole phase of one pixel (pt_plan.cpp): the queues must too (NaiveRenderer settings: phase = spp)
+    { const uint32_t phase = rd.sample_count < rd.phase_samples ? rd.sample_count : rd.phase_samples; if (capacity < phase) capacity = phase; }
     const bool hero = rd.hero_wavelengths == 4;
     if (hero && capacity > (1u << 26)) capacity = 1u << 26;  // 4-wavelength queues are ~1.5x wider: 64 Mi slots ~ 24 GB
     pt_status st = ensure_buffers(sc, capacity, rd.light_samples, pixels.size() ? pixels.size() : 1, grid, hero ? 4u : 1u);
@@ -247,6 +264,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
         accumulated_pixels += pass.pixel_count;
         rp.chunk_pixels = pass.pixel_count; rp.first_sample = pass.first_sample; rp.pass_samples = pass.sample_count;
         uint32_t n = pass.pixel_count * pass.sample_count;
+        if (n > b.capacity) return fail(PT_ERR_DEVICE, "internal: a pass of " + std::to_string(n) + " slots exceeds the queue capacity " + std::to_string(b.capacity));
         uint32_t seg_cap = segment_capacity(n, grid);
         camera_rays += n;
         const uint32_t* d_px = b.pixels + pass.pixel_begin;
@@ -296,20 +314,20 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
 pt_status probe_material(pt_scene* sc, int mode, uint32_t record, size_t n, const float* lambda, const float* a, size_t a_w, const float* b, size_t b_w,
                          float* f, float* wo, float* pdf) {
     HIP_TRY(hipSetDevice(sc->device));
-    float *dl = nullptr, *da = nullptr, *db = nullptr, *df = nullptr, *dwo = nullptr, *dp = nullptr;
+    DevBuf dl, da, db, df, dwo, dp;
     size_t m = n ? n : 1;
-    HIP_TRY(hipMalloc(&dl, 4 * m)); HIP_TRY(hipMalloc(&da, 4 * m * 3)); HIP_TRY(hipMalloc(&db, 4 * m * 3));
-    HIP_TRY(hipMalloc(&df, 4 * m)); HIP_TRY(hipMalloc(&dwo, 4 * m * 3)); HIP_TRY(hipMalloc(&dp, 4 * m));
-    HIP_TRY(hipMemcpy(dl, lambda, 4 * n, hipMemcpyHostToDevice));
-    if (a) HIP_TRY(hipMemcpy(da, a, 4 * n * a_w, hipMemcpyHostToDevice));
-    if (b) HIP_TRY(hipMemcpy(db, b, 4 * n * b_w, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_probe_material, dim3(256), dim3(kBlock), 0, 0, sc->d_blob, sc->d_tex, mode, record, (uint32_t)n, dl, da, db, df, dwo, dp);
+    HIP_TRY(dl.alloc(4 * m)); HIP_TRY(da.alloc(4 * m * 3)); HIP_TRY(db.alloc(4 * m * 3));
+    HIP_TRY(df.alloc(4 * m)); HIP_TRY(dwo.alloc(4 * m * 3)); HIP_TRY(dp.alloc(4 * m));
+    HIP_TRY(hipMemcpy(dl.p, lambda, 4 * n, hipMemcpyHostToDevice));
+    if (a) HIP_TRY(hipMemcpy(da.p, a, 4 * n * a_w, hipMemcpyHostToDevice));
+    if (b) HIP_TRY(hipMemcpy(db.p, b, 4 * n * b_w, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_material, dim3(256), dim3(kBlock), 0, 0, sc->d_blob, sc->d_tex, mode, record, (uint32_t)n, dl.as<float>(), da.as<float>(), db.as<float>(),
+                       df.as<float>(), dwo.as<float>(), dp.as<float>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    if (f) HIP_TRY(hipMemcpy(f, df, 4 * n, hipMemcpyDeviceToHost));
-    if (wo) HIP_TRY(hipMemcpy(wo, dwo, 4 * n * 3, hipMemcpyDeviceToHost));
-    if (pdf) HIP_TRY(hipMemcpy(pdf, dp, 4 * n, hipMemcpyDeviceToHost));
-    hipFree(dl); hipFree(da); hipFree(db); hipFree(df); hipFree(dwo); hipFree(dp);
+    if (f) HIP_TRY(hipMemcpy(f, df.p, 4 * n, hipMemcpyDeviceToHost));
+    if (wo) HIP_TRY(hipMemcpy(wo, dwo.p, 4 * n * 3, hipMemcpyDeviceToHost));
+    if (pdf) HIP_TRY(hipMemcpy(pdf, dp.p, 4 * n, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 
@@ -370,7 +388,7 @@ void pt_scene_destroy(pt_scene* sc) {
     if (!sc) return;
     hipSetDevice(sc->device);
     sc->buf.release();
-    hipFree(sc->d_blob); hipFree(sc->d_tex);
+    hipFree(sc->d_blob); hipFree(sc->d_tex); hipFree(sc->film_cache);
     for (auto& e : sc->events) hipEventDestroy(e);
     delete sc;
 }
@@ -383,33 +401,33 @@ pt_status pt_render(pt_scene* sc, const pt_render_desc* rd, float* film, pt_prof
     if (!sc || !rd || !film) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     if (rd->width == 0 || rd->height == 0) return fail(PT_ERR_INVALID_ARGUMENT, "width and height must be positive");
     HIP_TRY(hipSetDevice(sc->device));
-    float* d_film = nullptr;
-    size_t bytes = sizeof(float) * 4 * (size_t)rd->width * rd->height;
-    HIP_TRY(hipMalloc(&d_film, bytes));
-    pt_status st = render_impl(sc, rd, d_film, nullptr, profile);
-    if (st == PT_OK) {
-        hipError_t e = hipMemcpy(film, d_film, bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) st = fail(PT_ERR_DEVICE, hipGetErrorString(e));
+    const size_t bytes = sizeof(float) * 4 * (size_t)rd->width * rd->height;
+    if (sc->film_cache_bytes < bytes) {   // the device film lives as long as the scene: a sequence of renders allocates it once
+        if (sc->film_cache) hipFree(sc->film_cache);
+        sc->film_cache = nullptr; sc->film_cache_bytes = 0;
+        HIP_TRY(hipMalloc(&sc->film_cache, bytes));
+        sc->film_cache_bytes = bytes;
     }
-    hipFree(d_film);
-    return st;
+    pt_status st = render_impl(sc, rd, sc->film_cache, nullptr, profile);
+    if (st != PT_OK) return st;
+    HIP_TRY(hipMemcpy(film, sc->film_cache, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
 }
 
 pt_status pt_intersect(pt_scene* sc, size_t n, const float* origins, const float* directions, pt_hit* hits) {
     if (!sc || !origins || !directions || !hits) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(sc->device));
-    float *dor = nullptr, *dd = nullptr; pt_hit* dh = nullptr;
-    HIP_TRY(hipMalloc(&dor, 12 * n)); HIP_TRY(hipMalloc(&dd, 12 * n)); HIP_TRY(hipMalloc(&dh, sizeof(pt_hit) * n));
-    HIP_TRY(hipMemcpy(dor, origins, 12 * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dd, directions, 12 * n, hipMemcpyHostToDevice));
+    DevBuf dor, dd, dh;
+    HIP_TRY(dor.alloc(12 * n)); HIP_TRY(dd.alloc(12 * n)); HIP_TRY(dh.alloc(sizeof(pt_hit) * n));
+    HIP_TRY(hipMemcpy(dor.p, origins, 12 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dd.p, directions, 12 * n, hipMemcpyHostToDevice));
     int grid = sc->num_cus * 4;
     const uint32_t lds_bytes = sc->lds_mode == PT_LDS_ALL ? sc->blob_words * 4u : (sc->lds_mode == PT_LDS_CORE ? sc->host.blob[PT_HDR_CORE_WORDS] * 4u : 0u);
-    launch_probe_intersect(LaunchCfg{grid, lds_bytes, (hipStream_t)0, sc->lds_mode}, SceneArgs{sc->d_blob, sc->blob_words, sc->d_tex}, (uint32_t)n, dor, dd, dh);
+    launch_probe_intersect(LaunchCfg{grid, lds_bytes, (hipStream_t)0, sc->lds_mode}, SceneArgs{sc->d_blob, sc->blob_words, sc->d_tex}, (uint32_t)n, dor.as<float>(), dd.as<float>(), dh.as<pt_hit>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(hits, dh, sizeof(pt_hit) * n, hipMemcpyDeviceToHost));
-    hipFree(dor); hipFree(dd); hipFree(dh);
+    HIP_TRY(hipMemcpy(hits, dh.p, sizeof(pt_hit) * n, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 
@@ -434,14 +452,13 @@ pt_status pt_curve_eval(pt_scene* sc, uint32_t curve, size_t n, const float* lam
 pt_status pt_debug_numerics(int which, size_t n, const float* x, const float* y, float* out) {
     pt_status st = ensure_device();
     if (st != PT_OK) return st;
-    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(&dx, 4 * n)); HIP_TRY(hipMalloc(&dy, 4 * n)); HIP_TRY(hipMalloc(&dout, 4 * n));
-    HIP_TRY(hipMemcpy(dx, x, 4 * n, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dy, y, 4 * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_probe_numerics, dim3(256), dim3(kBlock), 0, 0, which, (uint32_t)n, dx, dy, dout);
+    DevBuf dx, dy, dout;
+    HIP_TRY(dx.alloc(4 * n)); HIP_TRY(dy.alloc(4 * n)); HIP_TRY(dout.alloc(4 * n));
+    HIP_TRY(hipMemcpy(dx.p, x, 4 * n, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dy.p, y, 4 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_numerics, dim3(256), dim3(kBlock), 0, 0, which, (uint32_t)n, dx.as<float>(), dy.as<float>(), dout.as<float>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, dout, 4 * n, hipMemcpyDeviceToHost));
-    hipFree(dx); hipFree(dy); hipFree(dout);
+    HIP_TRY(hipMemcpy(out, dout.p, 4 * n, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

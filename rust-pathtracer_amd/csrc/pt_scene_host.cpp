@@ -38,6 +38,7 @@ struct BvhBuilder {
     std::vector<uint32_t>& out;  // PT_NODE_WORDS per node
     uint32_t base;               // first node's index (0)
     std::vector<uint32_t> leaf_of_shape;  // node index of each shape's leaf
+    std::vector<char> no_cull;            // per shape (empty = none): its computed hit distance may fall short of its box (spheres): nodes holding one are never culled
     explicit BvhBuilder(const std::vector<Box>& s, std::vector<uint32_t>& o) : shapes(s), out(o), base(0), leaf_of_shape(s.size(), 0) {}
 
     uint32_t node_count() const { return (uint32_t)(out.size() / PT_NODE_WORDS); }
@@ -89,7 +90,9 @@ struct BvhBuilder {
         // [3]: the node to continue with when this subtree is done or skipped; bit 31 (PT_NODE_FLAT) marks a box of zero thickness,
         // which the filtered slab test must take axis by axis (aabb_classify)
         const bool flat = b.mn[0] == b.mx[0] || b.mn[1] == b.mx[1] || b.mn[2] == b.mx[2];
-        out[at + 0] = fbits(b.mn[0]); out[at + 1] = fbits(b.mn[1]); out[at + 2] = fbits(b.mn[2]); out[at + 3] = node_count() | (flat ? PT_NODE_FLAT : 0u);
+        bool keep = false;
+        if (!no_cull.empty()) for (uint32_t i : idx) keep = keep || no_cull[i] != 0;
+        out[at + 0] = fbits(b.mn[0]); out[at + 1] = fbits(b.mn[1]); out[at + 2] = fbits(b.mn[2]); out[at + 3] = node_count() | (flat ? PT_NODE_FLAT : 0u) | (keep ? PT_NODE_NO_CULL : 0u);
         out[at + 4] = fbits(b.mx[0]); out[at + 5] = fbits(b.mx[1]); out[at + 6] = fbits(b.mx[2]); out[at + 7] = leaf ? idx[0] : PT_NODE_INNER;
         if (leaf) leaf_of_shape[idx[0]] = (uint32_t)(at / PT_NODE_WORDS);
     }
@@ -368,7 +371,10 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
     // top-level BVH over instances
     pad16(w);
     {
-        std::vector<uint32_t> nodes; BvhBuilder bb(ibox, nodes); bb.build();
+        std::vector<uint32_t> nodes; BvhBuilder bb(ibox, nodes);
+        bb.no_cull.assign(d.instance_count, 0);
+        for (uint32_t i = 0; i < d.instance_count; ++i) bb.no_cull[i] = d.instances[i].kind == PT_SHAPE_SPHERE;
+        bb.build();
         w[PT_HDR_TOP_NODE_OFF] = (uint32_t)w.size(); w[PT_HDR_TOP_NODE_COUNT] = (uint32_t)(nodes.size() / PT_NODE_WORDS);
         uint32_t top = (uint32_t)w.size();
         w.insert(w.end(), nodes.begin(), nodes.end());

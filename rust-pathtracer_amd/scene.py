@@ -604,6 +604,26 @@ def mixed_small():
     return b
 
 
+def big_sphere_light():
+    """A sphere light of radius 20 000 hanging 0.02 above a floor (not a reference scene): from the floor under it a light sample's hit
+    distance is 0.02 .. 1 while the terms of the sphere's quadratic are ~4e8 (|oc|^2 - r^2) and ~2e4 (-b, the root), so the computed
+    distance is good to ~1e-3 at best — far more than any margin relative to the distance.  A box that holds the sphere must never
+    be culled by a distance computed from the sphere itself (csrc/pt_device.h `beyond`)."""
+    b = SceneBuilder()
+    add_library_curves(b, ["simple_sky_blue"])
+    b.set_environment_constant(b.curve("simple_sky_blue"), 0.0)
+    b.env_sampling_probability = 0.0
+    light = add_library_material(b, "diffuse_light_flat_x5")
+    white = add_library_material(b, "lambertian_white")
+    red = add_library_material(b, "lambertian_red")
+    b.add_rect((40, 40), (0.0, 0.0, 0.0), "Z", True, white)
+    b.add_sphere(20000.0, (0.0, 0.0, 20000.02), light)
+    b.add_rect((1.0, 1.0), (3.0, 0.0, 0.5), "X", True, red)
+    b.add_rect((1.0, 1.0), (0.0, 3.0, 0.5), "Y", True, red)
+    b.add_camera((-6.0, 0.5, 0.4), (0.0, 0.0, 0.1), 40.0, focal_distance=6.0, aperture_diameter=0.01)
+    return b
+
+
 def empty_env():
     """No instance at all: a constant environment and a camera (edge case: empty BVH, empty light list)."""
     b = SceneBuilder()
@@ -686,4 +706,5 @@ def hdri_c4_small():
 
 
 SCENES = {"hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
-          "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test, "panorama_test": panorama_test, "empty_env": empty_env}
+          "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test, "panorama_test": panorama_test, "empty_env": empty_env,
+          "big_sphere_light": big_sphere_light}

@@ -34,12 +34,12 @@ def assert_hits_equal(a, b):
         assert same.all(), (field, int((~same).sum()), x[~same.reshape(x.shape)][:4] if x.ndim == 1 else None)
 
 
-def check_film(film, ref, prof=None, ref_prof=None):
+def check_film(film, ref, prof=None, ref_prof=None, max_bad=1e-2):
     # a non-finite pixel is a result like any other (the reference lets a 0/0 of its NEE weights through to the film, where the
     # tonemapper paints it mauve): it must sit in the same place on both sides; the bars apply to the finite pixels
     bad = ~np.isfinite(ref)
     assert np.array_equal(~np.isfinite(film), bad)
-    assert bad.mean() < 1e-2
+    assert bad.mean() < max_bad, bad.mean()
     if bad.any():
         film, ref = np.where(bad, 0.0, film).astype(np.float32), np.where(bad, 0.0, ref).astype(np.float32)
     m = film_metrics(film, ref)
@@ -78,12 +78,12 @@ def material_parity(impl, oracle, scene_name, n=2048, seed=9):
         assert np.array_equal(si.curve_eval(c, lam2).view(np.uint32), so.curve_eval(c, lam2).view(np.uint32)), c
 
 
-def render_parity(impl, oracle, scene_name, width, height, spp, max_bounces, **kw):
+def render_parity(impl, oracle, scene_name, width, height, spp, max_bounces, max_bad=1e-2, **kw):
     b = pkg().scene.SCENES[scene_name]()
     rd = pkg().api.render_desc(width, height, spp, max_bounces, **kw)
     film, prof = impl.create_scene(b).render(rd)
     ref, rprof = oracle.create_scene(b).render(rd)
-    return check_film(film, ref, prof, rprof)
+    return check_film(film, ref, prof, rprof, max_bad=max_bad)
 
 
 def golden_render(impl, name):

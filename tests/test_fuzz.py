@@ -50,6 +50,25 @@ def test_grazing_sphere_light_is_not_culled_by_its_own_bound(engine, oracle, pkg
     ps.check_film(film, ref, prof, rprof)
 
 
+@pytest.mark.parametrize("flags", ["0", "16"])
+def test_emulation_big_sphere_light_is_not_culled_by_its_own_bound(emu, oracle, pkg, monkeypatch, flags):  # noqa: F811
+    """A light sample towards a sphere of radius 20 000 from 0.02 .. 1 below it: the computed hit distance is off by ~1e-3 absolute (the
+    cancellations in the sphere's quadratic), i.e. by several per cent of itself — far more than the 0.2 % margin sphere boxes once
+    had (with that margin this test fails: the light culls itself).  Boxes that hold a sphere are never culled (sweep table and, with
+    flag 16, the BVH walk's flagged nodes)."""
+    monkeypatch.setenv("PTEMU_FLAGS", flags)
+    ps.render_parity(emu, oracle, "big_sphere_light", 48, 32, 6, 4, max_bad=0.1, light_samples=3, seed=3)   # (3 % of the pixels are NaN on both sides: NEE from the light to itself)
+    ps.intersect_parity(emu, oracle, "big_sphere_light")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_sweep", ["0", "1"])
+def test_big_sphere_light_is_not_culled_by_its_own_bound(engine, oracle, pkg, monkeypatch, no_sweep):
+    monkeypatch.setenv("PT_AMD_NO_SWEEP", no_sweep)
+    ps.render_parity(engine, oracle, "big_sphere_light", 256, 192, 8, 4, max_bad=0.1, light_samples=3, seed=3)
+    ps.intersect_parity(engine, oracle, "big_sphere_light", n=1 << 15)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(200, 210))
 def test_engine_bvh_walk_on_random_scenes(engine, oracle, pkg, monkeypatch, seed):

@@ -9,6 +9,9 @@ import pytest
 
 import parity_suite as ps
 
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "..", "rust-pathtracer_amd", "csrc")
+
 
 @pytest.fixture(scope="module")
 def sfmod(pkg):
@@ -46,8 +49,8 @@ def test_config_defaults_and_second_pass(sfmod, pkg):
     assert (s.filename, s.min_bounces, s.max_bounces, s.hwss, s.only_direct, s.russian_roulette, s.threads) == (b"direct_only", -1, 3, 1, 1, -1, 2)
     assert s.has_wavelength_bounds == 0 and s.has_premultiply == 0 and s.silenced == 0 and cfg.render_settings(0).silenced == 1
     rd = cfg.render_desc(1)
-    # defaults of src/integrator/mod.rs:59-105: min_bounces 4, bounds [380, 750]; hwss selects the hero-wavelength variant
-    assert (rd.min_bounces, rd.wavelength_lo, rd.wavelength_hi, rd.hero_wavelengths, rd.only_direct) == (4, 380.0, 750.0, 4, 1)
+    # defaults of src/integrator/mod.rs:59-105: min_bounces 4, bounds [380, 750]; hwss is parsed and, as in the reference, changes nothing
+    assert (rd.min_bounces, rd.wavelength_lo, rd.wavelength_hi, rd.hero_wavelengths, rd.only_direct) == (4, 380.0, 750.0, 1, 1)
     assert cfg.output_desc(1).key_value == np.float32(0.2)
 
 
@@ -224,9 +227,9 @@ def test_scene_errors(sfmod, tmp_path):
         load(lens)
 
 
-def test_image_readers(sfmod, tmp_path):
-    """Texture4 (PNG RGBA, palette PNG, BMP), Texture1 (luma of an RGB PNG) and HDR (RGBE with run-length scanlines) through
-    a literal texture library."""
+def _write_test_images(tmp_path):
+    """Valid files of every format the readers take: PNG RGBA / RGB, BMP, Radiance HDR with run-length scanlines, OpenEXR ZIP / ZIPS /
+    RLE / tiled.  Returns the pixel arrays they hold."""
     import struct
     import zlib
     rng = np.random.default_rng(5)
@@ -322,6 +325,13 @@ def test_image_readers(sfmod, tmp_path):
                  "exr_tiled": dict(compression=0, tiled=(8, 16))}
     for n, kw in exr_cases.items():
         exr(tmp_path / (n + ".exr"), img, **kw)
+    return rgba, rgb, bmp_px, img, exr_cases, rgbe
+
+
+def test_image_readers(sfmod, tmp_path):
+    """Texture4 (PNG RGBA, palette PNG, BMP), Texture1 (luma of an RGB PNG) and HDR (RGBE with run-length scanlines) through
+    a literal texture library."""
+    rgba, rgb, bmp_px, img, exr_cases, rgbe = _write_test_images(tmp_path)
     lib = 'curves = { one = { type = "Flat", strength = 1.0 } }\nmaterials = {}\nmeshes = {}\n'
     tex = "[textures]\n" + "\n".join('%s = [{ type = "%s", filename = "%s", %s }]' % (n, t, tmp_path / f, c) for n, t, f, c in (
         ("rgba", "Texture4", "rgba.png", 'curves = ["one", "one", "one", "one"]'), ("bmp", "Texture4", "t.bmp", 'curves = ["one", "one", "one", "one"]'),
@@ -339,9 +349,74 @@ def test_image_readers(sfmod, tmp_path):
         got = np.ctypeslib.as_array(d.texture_data, shape=(d.texture_data_count,))[layer.data_offset:layer.data_offset + n]
         if expect is None:
             scale = np.where(rgbe[..., 3] == 0, 0.0, np.ldexp(1.0, rgbe[..., 3].astype(np.int32) - 136)).astype(np.float32)
-            expect = np.concatenate([rgbe[..., :3].astype(np.float32) * scale[..., None], np.full((h, w, 1), 0.25, np.float32)], axis=2)
+            expect = np.concatenate([rgbe[..., :3].astype(np.float32) * scale[..., None], np.full(rgbe.shape[:2] + (1,), 0.25, np.float32)], axis=2)
         assert (layer.height, layer.width) == expect.shape[:2], name
         assert np.array_equal(got.reshape(expect.shape), expect.astype(np.float32)), name
+
+
+def test_malformed_images(tmp_path):
+    """Asset files are untrusted: truncated, bit-flipped and hand-crafted hostile PNG / BMP / HDR / EXR files (negative tile coordinates,
+    zero tile size, unterminated channel list, overflowing data window, short IHDR, a BMP header that points past the file ...) go
+    through all four readers of csrc/host/image_io.cpp built with AddressSanitizer + UBSan.  A reader may reject; it may not read or
+    write out of bounds (the decoders trusted header fields)."""
+    import struct
+    import subprocess
+    good = tmp_path / "good"; good.mkdir()
+    _write_test_images(good)
+    exe = tmp_path / "image_fuzz"
+    src = [os.path.join(HERE, "host_emulation", "image_fuzz.cpp"), os.path.join(CSRC, "host", "image_io.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", str(exe)] + src + ["-lz"])
+    bad = tmp_path / "bad"; bad.mkdir()
+    rng = np.random.default_rng(11)
+    count = 0
+    for f in sorted(os.listdir(good)):
+        d = open(good / f, "rb").read()
+        mutants = [d[:k] for k in sorted(set([0, 1, 4, 8, 12, 20, 26, 33, 40, 54, 60, 100, 150, 200, 300, 400, len(d) // 2, len(d) - 1]) ) if k < len(d)]
+        for _ in range(120):   # a few bytes of the header region (and some anywhere) replaced by random or extreme values
+            m = bytearray(d)
+            for _ in range(int(rng.integers(1, 5))):
+                pos = int(rng.integers(0, min(len(m), 420))) if rng.random() < 0.8 else int(rng.integers(0, len(m)))
+                m[pos] = int(rng.choice([0, 1, 0x7f, 0x80, 0xff, int(rng.integers(0, 256))]))
+            mutants.append(bytes(m))
+        for _ in range(30):    # a 32-bit field overwritten with a hostile value
+            m = bytearray(d)
+            pos = int(rng.integers(0, min(len(m) - 4, 400)))
+            m[pos:pos + 4] = struct.pack("<i", int(rng.choice([-1, -2, -2**31, 2**31 - 1, 0, 1 << 30, 65536])))
+            mutants.append(bytes(m))
+        for k, m in enumerate(mutants):
+            open(bad / ("%s.%03d" % (f, k)), "wb").write(m); count += 1
+    # hand-crafted: the tiled EXR with tile coordinates (-1, 0), tile size 0, and a channel list without its terminator
+    d = bytearray(open(good / "exr_tiled.exr", "rb").read())
+    tiles_at = d.index(b"tiles\0tiledesc\0") + len(b"tiles\0tiledesc\0") + 4
+    head_end = d.index(b"tiles\0tiledesc\0") + len(b"tiles\0tiledesc\0") + 4 + 9 + 1
+    first_block = struct.unpack("<Q", d[head_end:head_end + 8])[0]
+    m = bytearray(d); m[first_block:first_block + 4] = struct.pack("<i", -1); open(bad / "tile_negative.exr", "wb").write(m)
+    m = bytearray(d); m[first_block:first_block + 4] = struct.pack("<i", 1 << 20); open(bad / "tile_far.exr", "wb").write(m)
+    m = bytearray(d); m[tiles_at:tiles_at + 4] = struct.pack("<I", 0); open(bad / "tile_size_zero.exr", "wb").write(m)
+    ch_at = d.index(b"channels\0chlist\0") + len(b"channels\0chlist\0")
+    m = bytearray(d); m[ch_at:ch_at + 4] = struct.pack("<i", 3); open(bad / "chlist_short.exr", "wb").write(m)
+    dw_at = d.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+    m = bytearray(d); m[dw_at:dw_at + 16] = struct.pack("<4i", -2**31, -2**31, 2**31 - 1, 2**31 - 1); open(bad / "window_overflow.exr", "wb").write(m)
+    m = bytearray(d); m[dw_at - 4:dw_at] = struct.pack("<i", 4); open(bad / "window_short.exr", "wb").write(m)
+    p = bytearray(open(good / "rgba.png", "rb").read())
+    m = bytearray(p); m[8:12] = struct.pack(">I", 5); open(bad / "ihdr_short.png", "wb").write(m)
+    m = bytearray(p); m[16:24] = struct.pack(">II", 0xffffffff, 0xffffffff); open(bad / "huge.png", "wb").write(m)
+    b = bytearray(open(good / "t.bmp", "rb").read())
+    m = bytearray(b); m[14:18] = struct.pack("<I", 0x7fffffff); m[28:30] = struct.pack("<H", 8); open(bad / "header_far.bmp", "wb").write(m)
+    m = bytearray(b); m[22:26] = struct.pack("<i", -2**31); open(bad / "height_min.bmp", "wb").write(m)
+    m = bytearray(b); m[10:14] = struct.pack("<I", 0xfffffff0); open(bad / "offset_far.bmp", "wb").write(m)
+    count += 11
+    files = sorted(str(bad / f) for f in os.listdir(bad))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:allocator_may_return_null=1", UBSAN_OPTIONS="halt_on_error=1")
+    for i in range(0, len(files), 400):
+        r = subprocess.run([str(exe)] + files[i:i + 400], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, (r.stdout[-400:], r.stderr[-3000:])
+    assert count > 1000
+    # and the untouched files are still read
+    r = subprocess.run([str(exe)] + sorted(str(good / f) for f in os.listdir(good)), env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("accepted"), (r.stdout, r.stderr[-2000:])
+    assert int(r.stdout.split()[1]) >= 10   # PNG and BMP through both 8-bit readers, HDR, four EXR
+
 
 
 def test_image_reader_entry_point(sfmod, pkg):
