@@ -64,6 +64,11 @@ def library():
     return _lib
 
 
+def set_root(path=None):
+    """The directory the "data/..." file names of config and scene files are relative to (default: this package)."""
+    library().pt_scene_file_set_root((path or DATA_ROOT).encode())
+
+
 def _check(status):
     if status != api.PT_OK:
         raise SceneFileError(status, library().pt_scene_file_last_error().decode())
