@@ -269,9 +269,13 @@ def main():
             "segments_per_sample": counts[2] / total_samples,
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+    else:
+        out = None
     if use_dist:
         dist.destroy_process_group()
+    if out is not None:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)   # the last line of stdout, after anything RCCL had to say
 
 
 if __name__ == "__main__":

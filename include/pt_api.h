@@ -248,6 +248,17 @@ pt_status pt_render(pt_scene* scene, const pt_render_desc* desc, float* film_xyz
 pt_status pt_render_device(pt_scene* scene, const pt_render_desc* desc, void* film_device,
                            void* hip_stream, pt_profile* profile);
 
+/* The whole node from one blocking call — what `impl Renderer for HipRenderer` calls (Renderer::render, src/renderer/mod.rs:107-112,
+ * is one blocking call; SURVEY 8(b): the library owns devices and streams).  `device_mask`: bit d = HIP device d; 0 = every visible
+ * device.  The library keeps one scene replica, one stream and one host thread per device, deals the film's 32x32 tiles to the
+ * devices (PT_TILE_SHARD, as shard_index / shard_count do across processes), and sums the device films into the first device of the
+ * mask with one RCCL reduce (a single-process communicator over xGMI; the shards are disjoint, so the sum is a gather and the film
+ * is bit-identical to the one-device film).  `desc->shard_count` must be 0.  Counters of `profile` are summed over the devices,
+ * `seconds` is the wall time of the call's render window, the per-stage device seconds are summed over the devices. */
+pt_status pt_render_multi(pt_scene* scene, const pt_render_desc* desc, uint64_t device_mask, float* film_xyzw, pt_profile* profile);
+/* HIP devices visible to the library (0 without a device). */
+uint32_t pt_device_count(void);
+
 /* Probes of the trait surface, used for parity tests of single stages. Host arrays in, host arrays out. */
 pt_status pt_intersect(pt_scene* scene, size_t n, const float* origins, const float* directions, pt_hit* hits);
 pt_status pt_bsdf_sample(pt_scene* scene, uint32_t material, size_t n, const float* lambda, const float* wi,

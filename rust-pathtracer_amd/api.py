@@ -143,7 +143,7 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("point", "<f4", 3), ("normal", "<f4", 3), (
 assert HIT_DTYPE.itemsize == C.sizeof(Hit)
 
 # every entry point include/pt_api.h declares (without prefix)
-API_FUNCTIONS = ["scene_create", "scene_destroy", "last_error", "render", "render_device", "intersect",
+API_FUNCTIONS = ["scene_create", "scene_destroy", "last_error", "render", "render_device", "render_multi", "device_count", "intersect",
                  "bsdf_sample", "bsdf_eval", "emission", "curve_eval", "device_info", "output_film", "write_png", "write_exr", "compare_films"]
 
 
@@ -191,6 +191,8 @@ class Library:
         self._last_error = bind("last_error", C.c_char_p, [])
         self._render = bind("render", C.c_int32, [vp, C.POINTER(RenderDesc), fpp, C.POINTER(Profile)])
         self._render_device = bind("render_device", C.c_int32, [vp, C.POINTER(RenderDesc), vp, vp, C.POINTER(Profile)], required=False)
+        self._render_multi = bind("render_multi", C.c_int32, [vp, C.POINTER(RenderDesc), C.c_uint64, fpp, C.POINTER(Profile)], required=False)
+        self._device_count = bind("device_count", u32, [], required=False)
         self._intersect = bind("intersect", C.c_int32, [vp, sz, fpp, fpp, C.POINTER(Hit)])
         self._bsdf_sample = bind("bsdf_sample", C.c_int32, [vp, u32, sz, fpp, fpp, fpp, fpp, fpp, fpp])
         self._bsdf_eval = bind("bsdf_eval", C.c_int32, [vp, u32, sz, fpp, fpp, fpp, fpp, fpp])
@@ -281,6 +283,13 @@ class Scene:
         film = np.zeros((rd.height, rd.width, 4), dtype=np.float32)
         prof = Profile()
         self.library.check(self.library._render(self.handle, C.byref(rd), _fp(film), C.byref(prof)))
+        return film, prof
+
+    def render_multi(self, rd, device_mask=0):
+        """pt_render_multi: every device of the mask (0 = all) from one blocking call."""
+        film = np.zeros((rd.height, rd.width, 4), dtype=np.float32)
+        prof = Profile()
+        self.library.check(self.library._render_multi(self.handle, C.byref(rd), C.c_uint64(device_mask), _fp(film), C.byref(prof)))
         return film, prof
 
     def render_device(self, rd, film_ptr, stream_ptr=None):

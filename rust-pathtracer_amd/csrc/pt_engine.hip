@@ -8,7 +8,12 @@
 // order.  No CPU fallback: every entry point fails with PT_ERR_NO_DEVICE when HIP has no device.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <chrono>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -116,6 +121,7 @@ struct pt_scene {
     std::vector<hipEvent_t> events;  // pairs (start, stop), grown on demand
     float* film_cache = nullptr;     // pt_render's device film, kept between calls
     size_t film_cache_bytes = 0;
+    std::vector<pt_scene*> replicas; // pt_render_multi: this scene on the other devices, by device index (nullptr = not made yet / this one)
 };
 
 namespace {
@@ -349,17 +355,12 @@ const char* pt_device_info(void) {
     return g_device_info.c_str();
 }
 
-pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
-    if (!desc || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
-    pt_status st = ensure_device();
-    if (st != PT_OK) return st;
-    pt_scene* sc = new pt_scene();
-    std::string err;
-    if (!pth::build_host_scene(*desc, &sc->host, &err)) { delete sc; return fail(PT_ERR_INVALID_ARGUMENT, err); }
+// Device side of a scene: the blob and the texels on the current device, the staging mode, the kernels' LDS allowance.
+static pt_status scene_to_device(pt_scene* sc) {
     hipError_t e = hipGetDevice(&sc->device);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, sc->device);
-    if (e != hipSuccess) { delete sc; return fail(PT_ERR_NO_DEVICE, hipGetErrorString(e)); }
+    if (e != hipSuccess) return fail(PT_ERR_NO_DEVICE, hipGetErrorString(e));
     sc->num_cus = prop.multiProcessorCount;
     if (env_u32("PT_AMD_EXACT_SLAB", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_EXACT_SLAB;
     if (env_u32("PT_AMD_NO_CULL", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_CULL;
@@ -373,19 +374,33 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     if (e == hipSuccess) e = hipMalloc(&sc->d_tex, sizeof(float) * (sc->host.tex.size() + 4));
     if (e == hipSuccess) e = hipMemcpy(sc->d_blob, sc->host.blob.data(), sizeof(uint32_t) * sc->host.blob.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(sc->d_tex, sc->host.tex.data(), sizeof(float) * sc->host.tex.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { pt_scene_destroy(sc); return fail(e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE, hipGetErrorString(e)); }
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE, hipGetErrorString(e));
     if (sc->lds_mode != PT_LDS_NONE) {
         e = allow_lds_extend(kLdsBlobLimitBytes);
         if (e == hipSuccess) e = allow_lds_shade(kLdsBlobLimitBytes);
         if (e == hipSuccess) e = allow_lds_shadow(kLdsBlobLimitBytes);
-        if (e != hipSuccess) { pt_scene_destroy(sc); return fail(PT_ERR_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
     }
+    return PT_OK;
+}
+
+pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
+    if (!desc || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    pt_status st = ensure_device();
+    if (st != PT_OK) return st;
+    pt_scene* sc = new pt_scene();
+    std::string err;
+    if (!pth::build_host_scene(*desc, &sc->host, &err)) { delete sc; return fail(PT_ERR_INVALID_ARGUMENT, err); }
+    st = scene_to_device(sc);
+    if (st != PT_OK) { const std::string msg = g_error; pt_scene_destroy(sc); g_error = msg; return st; }
     *out = sc;
     return PT_OK;
 }
 
 void pt_scene_destroy(pt_scene* sc) {
     if (!sc) return;
+    for (pt_scene* r : sc->replicas) if (r) pt_scene_destroy(r);
+    sc->replicas.clear();
     hipSetDevice(sc->device);
     sc->buf.release();
     hipFree(sc->d_blob); hipFree(sc->d_tex); hipFree(sc->film_cache);
@@ -411,6 +426,138 @@ pt_status pt_render(pt_scene* sc, const pt_render_desc* rd, float* film, pt_prof
     pt_status st = render_impl(sc, rd, sc->film_cache, nullptr, profile);
     if (st != PT_OK) return st;
     HIP_TRY(hipMemcpy(film, sc->film_cache, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+uint32_t pt_device_count(void) {
+    int n = 0;
+    return (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? (uint32_t)n : 0u;
+}
+
+// RCCL, bound on first use: a single-process render pays nothing for it, and the library loads on machines without it.
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclReduce) reduce = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    bool ok() const { return comm_init_all && comm_destroy && reduce && group_start && group_end && error_string; }
+};
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (r.handle) break; }
+        if (!r.handle) return;
+        r.comm_init_all = reinterpret_cast<decltype(r.comm_init_all)>(dlsym(r.handle, "ncclCommInitAll"));
+        r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(r.handle, "ncclCommDestroy"));
+        r.reduce = reinterpret_cast<decltype(r.reduce)>(dlsym(r.handle, "ncclReduce"));
+        r.group_start = reinterpret_cast<decltype(r.group_start)>(dlsym(r.handle, "ncclGroupStart"));
+        r.group_end = reinterpret_cast<decltype(r.group_end)>(dlsym(r.handle, "ncclGroupEnd"));
+        r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(r.handle, "ncclGetErrorString"));
+    });
+    return r;
+}
+}  // namespace
+
+pt_status pt_render_multi(pt_scene* sc, const pt_render_desc* rdp, uint64_t device_mask, float* film, pt_profile* profile) {
+    if (!sc || !rdp || !film) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    if (rdp->width == 0 || rdp->height == 0) return fail(PT_ERR_INVALID_ARGUMENT, "width and height must be positive");
+    if (rdp->shard_count > 1) return fail(PT_ERR_INVALID_ARGUMENT, "pt_render_multi deals the tiles itself: shard_count must be 0");
+    const uint32_t visible = pt_device_count();
+    if (visible == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available: the product path has no CPU fallback");
+    std::vector<int> devices;
+    for (uint32_t d = 0; d < visible && d < 64; ++d) if (device_mask == 0 || ((device_mask >> d) & 1ull)) devices.push_back((int)d);
+    if (devices.empty()) return fail(PT_ERR_INVALID_ARGUMENT, "device_mask names no visible HIP device");
+    const int n = (int)devices.size();
+    // PT_AMD_MULTI_RCCL=1: take the RCCL reduce even for one device (the call path of a multi-device node, exercised on a single GPU)
+    const bool use_rccl = n > 1 || env_u32("PT_AMD_MULTI_RCCL", 0) != 0;
+    if (!use_rccl && devices[0] == sc->device) return pt_render(sc, rdp, film, profile);
+
+    // one replica per device (this scene itself on its own device), made on first use and kept
+    if (sc->replicas.size() < visible) sc->replicas.resize(visible, nullptr);
+    std::vector<pt_scene*> scene_of(n, nullptr);
+    for (int i = 0; i < n; ++i) {
+        const int d = devices[i];
+        if (d == sc->device) { scene_of[i] = sc; continue; }
+        if (!sc->replicas[d]) {
+            HIP_TRY(hipSetDevice(d));
+            pt_scene* r = new pt_scene();
+            r->host = sc->host;
+            pt_status st = scene_to_device(r);
+            if (st != PT_OK) { const std::string msg = g_error; pt_scene_destroy(r); hipSetDevice(sc->device); g_error = msg; return st; }
+            sc->replicas[d] = r;
+        }
+        scene_of[i] = sc->replicas[d];
+    }
+    const size_t bytes = sizeof(float) * 4 * (size_t)rdp->width * rdp->height;
+    std::vector<float*> d_film(n, nullptr);
+    std::vector<hipStream_t> streams(n, nullptr);
+    std::vector<pt_status> status(n, PT_OK);
+    std::vector<std::string> errors(n);
+    std::vector<pt_profile> profiles(n);
+    std::vector<ncclComm_t> comms(n, nullptr);
+    auto cleanup = [&] {
+        for (int i = 0; i < n; ++i) {
+            hipSetDevice(devices[i]);
+            if (comms[i]) rccl().comm_destroy(comms[i]);
+            if (streams[i]) hipStreamDestroy(streams[i]);
+            if (d_film[i]) hipFree(d_film[i]);
+        }
+        hipSetDevice(sc->device);
+    };
+    if (use_rccl) {
+        if (!rccl().ok()) return fail(PT_ERR_DEVICE, "librccl.so could not be loaded: pt_render_multi needs RCCL for more than one device");
+        ncclResult_t rc = rccl().comm_init_all(comms.data(), n, devices.data());
+        if (rc != ncclSuccess) { cleanup(); return fail(PT_ERR_DEVICE, std::string("ncclCommInitAll: ") + rccl().error_string(rc)); }
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&](int i) {
+        auto bad = [&](pt_status st, const std::string& msg) { status[i] = st; errors[i] = msg; };
+        if (hipSetDevice(devices[i]) != hipSuccess) return bad(PT_ERR_DEVICE, "hipSetDevice failed");
+        if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess) return bad(PT_ERR_DEVICE, "hipStreamCreate failed");
+        if (hipMalloc(&d_film[i], bytes) != hipSuccess) return bad(PT_ERR_OUT_OF_MEMORY, "hipMalloc of the device film failed");
+        pt_render_desc rd = *rdp;
+        if (n > 1) { rd.shard_index = (uint32_t)i; rd.shard_count = (uint32_t)n; }
+        pt_status st = render_impl(scene_of[i], &rd, d_film[i], streams[i], &profiles[i]);
+        if (st != PT_OK) bad(st, g_error);   // (g_error is thread-local: carried back to the caller below)
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int i = 1; i < n; ++i) pool.emplace_back(worker, i);
+        worker(0);
+        for (auto& t : pool) t.join();
+    }
+    for (int i = 0; i < n; ++i) if (status[i] != PT_OK) { const pt_status st = status[i]; const std::string msg = "device " + std::to_string(devices[i]) + ": " + errors[i]; cleanup(); return fail(st, msg); }
+    if (use_rccl) {
+        // the only exchange step of the path: every device's film (zero outside its own tiles) summed into the first device's
+        ncclResult_t rc = rccl().group_start();
+        for (int i = 0; i < n && rc == ncclSuccess; ++i) {
+            hipSetDevice(devices[i]);
+            rc = rccl().reduce(d_film[i], d_film[i], (size_t)4 * rdp->width * rdp->height, ncclFloat, ncclSum, 0, comms[i], streams[i]);
+        }
+        ncclResult_t rc2 = rccl().group_end();
+        if (rc == ncclSuccess) rc = rc2;
+        if (rc != ncclSuccess) { cleanup(); return fail(PT_ERR_DEVICE, std::string("ncclReduce: ") + rccl().error_string(rc)); }
+        for (int i = 0; i < n; ++i) { hipSetDevice(devices[i]); if (hipStreamSynchronize(streams[i]) != hipSuccess) { cleanup(); return fail(PT_ERR_DEVICE, "stream synchronisation after the film reduce failed"); } }
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    hipSetDevice(devices[0]);
+    hipError_t e = hipMemcpy(film, d_film[0], bytes, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(PT_ERR_DEVICE, hipGetErrorString(e));
+    if (profile) {
+        memset(profile, 0, sizeof(*profile));
+        for (const pt_profile& p : profiles) {
+            profile->bounce_rays += p.bounce_rays; profile->shadow_rays += p.shadow_rays; profile->light_rays += p.light_rays;
+            profile->camera_rays += p.camera_rays; profile->env_hits += p.env_hits;
+            for (int k = 0; k < 8; ++k) { profile->kernel_seconds[k] += p.kernel_seconds[k]; profile->kernel_launches[k] += p.kernel_launches[k]; profile->stage_items[k] += p.stage_items[k]; }
+        }
+        profile->seconds = std::chrono::duration<double>(t1 - t0).count();
+    }
     return PT_OK;
 }
 

@@ -17,7 +17,7 @@ def declared_functions():
 
 def test_header_declares_the_boundary():
     names = declared_functions()
-    for required in ("pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device", "pt_intersect", "pt_bsdf_sample",
+    for required in ("pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device", "pt_render_multi", "pt_intersect", "pt_bsdf_sample",
                      "pt_bsdf_eval", "pt_emission", "pt_curve_eval", "pt_last_error", "pt_device_info"):
         assert required in names
 
@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_oracle_exports_the_same_boundary(pkg, oracle):
     for name in declared_functions():
-        if name in ("pt_render_device", "pt_device_info", "pt_write_png", "pt_write_exr"):
+        if name in ("pt_render_device", "pt_render_multi", "pt_device_count", "pt_device_info", "pt_write_png", "pt_write_exr"):
             continue
         assert hasattr(oracle.lib, "ptref_" + name[3:]), name
 

@@ -203,6 +203,32 @@ def test_pooled_phase3_changes_nothing(engine, pkg, monkeypatch, scene, L, hero)
         assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits)
 
 
+def test_whole_node_render_from_one_call(engine, pkg, monkeypatch):
+    """pt_render_multi (the one blocking call a Rust `impl Renderer` makes): every device of the mask renders its tiles on its own
+    host thread and stream, the device films are summed with RCCL.  On the one GPU of this box: mask 0 and mask 1 give pt_render's film
+    bit for bit, with the RCCL reduce forced (PT_AMD_MULTI_RCCL=1: single-process communicator, ncclReduce on the render stream) too;
+    a mask that names no visible device and a sharded desc are refused."""
+    n = engine.lib.pt_device_count()
+    assert n >= 1
+    b = pkg.scene.cornell_box()
+    sc = engine.create_scene(b)
+    rd = pkg.api.render_desc(160, 96, 7, 6, seed=5)
+    base, pbase = sc.render(rd)
+    for mask in (0, 1):
+        film, prof = sc.render_multi(rd, mask)
+        assert np.array_equal(film.view(np.uint32), base.view(np.uint32)), mask
+        assert (prof.camera_rays, prof.bounce_rays, prof.shadow_rays) == (pbase.camera_rays, pbase.bounce_rays, pbase.shadow_rays)
+    monkeypatch.setenv("PT_AMD_MULTI_RCCL", "1")
+    film, prof = sc.render_multi(rd, 1)
+    assert np.array_equal(film.view(np.uint32), base.view(np.uint32))
+    assert prof.seconds > 0 and prof.camera_rays == pbase.camera_rays
+    monkeypatch.delenv("PT_AMD_MULTI_RCCL")
+    with pytest.raises(pkg.api.PtError):
+        sc.render_multi(rd, 1 << 40)
+    with pytest.raises(pkg.api.PtError):
+        sc.render_multi(pkg.api.render_desc(160, 96, 7, 6, seed=5, shard=(0, 2)), 0)
+
+
 def test_full_size_cornell_properties(engine, oracle, pkg):
     """BASELINE.json C2 geometry (1024x1024, max_bounces 8, L = 2) at 2 spp (2 M paths: seconds for the threaded oracle on
     the GPU box's host): the north-star bar directly — film within 1e-4 L-inf of the oracle at matched seeds, ray counters

@@ -62,3 +62,27 @@ def test_two_process_gloo_reduce_equals_single_process(pkg, tmp_path):
         film, _ = scene.render(pkg.api.render_desc(56, 40, 2 * S, 4, tile=(16, 16), first_sample=k * S, sample_count=S))
         whole += film
     assert np.array_equal(reduced, whole)
+
+
+import json  # noqa: E402
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_on_one_gpu(tmp_path):
+    """bench.py --force-dist: torch.distributed with backend nccl (= RCCL) initialised for a single rank, so that the barrier, the film
+    reduce and the max / sum over ranks of the N-GPU bench run through RCCL on the one GPU this box has.  The line must be the same
+    kind of record as the plain run's."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 1000), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--spp-per-step", "16", "--cpu-seconds", "0"]
+    lines = {}
+    for tag, extra in (("dist", ["--force-dist"]), ("plain", [])):
+        r = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.strip().splitlines()[-1].startswith('{"metric"'), r.stdout[-500:]   # the record is the last line of stdout
+        lines[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    for tag, d in lines.items():
+        assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["samples_per_step"] == 1024 * 1024 * 16, tag
+    assert lines["dist"]["segments_per_sample"] == lines["plain"]["segments_per_sample"]   # same paths, whoever sums the film
