@@ -274,6 +274,11 @@ def main():
     if use_dist:
         dist.destroy_process_group()
     if out is not None:
+        try:   # RCCL's version banner sits in the C library's stdout buffer until exit: push it out first
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)   # the last line of stdout, after anything RCCL had to say
 
