@@ -120,10 +120,11 @@
 // Leaf sweep table (world_hit_sweep).  One mask bit per top-level leaf (instance) and per triangle leaf, numbered in
 // traversal pre-order: instance j gets bit `first`, its triangle leaves first+1 .. first+count.
 // Per instance, in the pre-order of the top-level BVH's leaves (16 words):
-//   [0] instance record offset, [1] kind | flat << 8 | has_transform << 9 | walked << 10 | first mask bit << 16 | tested triangle leaves << 24,
+//   [0] instance record offset, [1] kind | flat << 8 | has_transform << 9 | walked << 10 | form of the box test << 11 (0 thick, 1 / 2 / 3 flat
+//   along x / y / z, 4 flat along several axes) | first mask bit << 16 | tested triangle leaves << 24,
 //   [2..3] the mask its box test sets, [4..6] box min, [7] triangle-leaf list offset, [8..10] box max, [11] triangle-leaf count (all of them),
-//   [12..13] which of the tested triangle leaves (by list index) have a flat box, [14] instance id
-// Triangle leaf (8 words, in the pre-order of the mesh BVH's leaves; only the leaves that keep a box test of their own): [0..2] box
+//   [12] the tested triangle leaves come grouped by the form of their box test: sizes of the groups 0..3, 8 bits each (the rest is group 4), [14] instance id
+// Triangle leaf (8 words, grouped by test form and in the pre-order of the mesh BVH's leaves inside a group; only the leaves that keep a box test of their own): [0..2] box
 //   min, [4..6] box max, [3] and [7] the low and high word of the mask the test sets = the leaf's own bit (the lowest) and the bits
 //   of the later leaves of the instance whose box is bit-identical: they are tested against the same ray, so the decision is theirs
 //   too and they have no record here.  Leaves whose box is the untransformed instance's own box ride in the instance's mask (the

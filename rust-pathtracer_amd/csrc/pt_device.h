@@ -33,6 +33,7 @@
 
 namespace ptd {
 
+template <int V> struct IntC { static constexpr int value = V; };   // a compile-time integer as a value (generic lambdas)
 struct F3 { float x, y, z; };
 struct alignas(16) F4 { float x, y, z, w; };
 
@@ -318,6 +319,44 @@ PT_HD void aabb_classify2(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry
     *hit = !miss && (m0 < x0 - e0 && m1 < x1 - e1 && m2 < x2 - e2);
     *undecided = !miss && !*hit;
 }
+// A box that is flat along exactly one axis K (every axis-aligned wall): both planes of that axis are the same plane, reached at t_K,
+// and AABB::hit's decision — max(entries, 0) <= min(exits) on the quotients it computes — is t_K >= max(n_i, n_l, 0) and
+// t_K <= min(x_i, x_l) for the other two axes i, l (n <= x holds per axis by construction, n_K = x_K = t_K exactly: the same division
+// twice).  Five planes instead of six and two comparisons instead of three pairs; same margin rule as above.
+template <int K>
+PT_HD void aabb_classify_flat1(F4 a, F4 b, const RayPrep& rp, float* entry, bool* hit, bool* undecided) {
+    PT_STAT(box_tests);
+    const float ak = K == 0 ? a.x : (K == 1 ? a.y : a.z), rk = K == 0 ? rp.r.x : (K == 1 ? rp.r.y : rp.r.z), nk = K == 0 ? rp.nor.x : (K == 1 ? rp.nor.y : rp.nor.z);
+    const float ai = K == 0 ? a.y : a.x, bi = K == 0 ? b.y : b.x, ri = K == 0 ? rp.r.y : rp.r.x, ni_ = K == 0 ? rp.nor.y : rp.nor.x;
+    const float al = K == 2 ? a.y : a.z, bl = K == 2 ? b.y : b.z, rl = K == 2 ? rp.r.y : rp.r.z, nl_ = K == 2 ? rp.nor.y : rp.nor.z;
+    const float tk = approx_fma(ak, rk, nk);
+    const float pi = approx_fma(ai, ri, ni_), qi = approx_fma(bi, ri, ni_), pl = approx_fma(al, rl, nl_), ql = approx_fma(bl, rl, nl_);
+    const float n_i = __builtin_fminf(pi, qi), x_i = __builtin_fmaxf(pi, qi), n_l = __builtin_fminf(pl, ql), x_l = __builtin_fmaxf(pl, ql);
+    const float lo = slab_entry(n_i, n_l, n_l), hi = __builtin_fminf(x_i, x_l);
+    const float e = approx_fma(PT_SLAB_EPS, (lo + pt_abs(hi)) + pt_abs(tk), rp.base);
+    const float g1 = lo - tk, g2 = tk - hi;
+    *entry = tk;
+    *hit = g1 < -e && g2 < -e;
+    *undecided = !*hit && !(g1 > e || g2 > e);
+}
+// The form the host chose for a box (pt_scene_host.cpp flat_code): 0 thick, 1..3 flat along one axis, 4 flat along several
+template <int CODE>
+PT_HD void aabb_classify_code(F4 a, F4 b, const RayPrep& rp, float* entry, bool* hit, bool* undecided) {
+    if (CODE == 0) aabb_classify2(a, b, rp, false, entry, hit, undecided);
+    else if (CODE == 1) aabb_classify_flat1<0>(a, b, rp, entry, hit, undecided);
+    else if (CODE == 2) aabb_classify_flat1<1>(a, b, rp, entry, hit, undecided);
+    else if (CODE == 3) aabb_classify_flat1<2>(a, b, rp, entry, hit, undecided);
+    else aabb_classify2(a, b, rp, true, entry, hit, undecided);
+}
+PT_HD void aabb_classify_by(uint32_t code, F4 a, F4 b, const RayPrep& rp, float* entry, bool* hit, bool* undecided) {   // `code` wave-uniform
+    switch (code) {
+        case 0: aabb_classify_code<0>(a, b, rp, entry, hit, undecided); break;
+        case 1: aabb_classify_code<1>(a, b, rp, entry, hit, undecided); break;
+        case 2: aabb_classify_code<2>(a, b, rp, entry, hit, undecided); break;
+        case 3: aabb_classify_code<3>(a, b, rp, entry, hit, undecided); break;
+        default: aabb_classify_code<4>(a, b, rp, entry, hit, undecided); break;
+    }
+}
 // (the same as one three-way value, for the per-lane loops — BVH walk steps, mesh sweep — whose compiled form is better with it)
 PT_HD int aabb_classify(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry) {
     PT_STAT(box_tests);
@@ -585,25 +624,28 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
         const uint32_t kf = PT_UNIFORM(pt_f2u(h0.y));
         float entry = 0.0f;
         bool ih = false, iu = true;   // (a ray the filter cannot take: every box is undecided)
-        if (quick) aabb_classify2(a, b, wr, (kf & 0x100u) != 0, &entry, &ih, &iu);
+        if (quick) aabb_classify_by((kf >> 11) & 7u, a, b, wr, &entry, &ih, &iu);
         if (bounded && cull_top && ih && (kf & 0xffu) != PT_SHAPE_SPHERE && beyond(entry, bound, wr.base)) ih = false;
         mark(ih, iu, pt_f2u(h0.z), pt_f2u(h0.w));
         const bool inside = ih || iu;
         if ((kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH && (kf >> 24) != 0u && PT_WAVE_ANY(inside)) {
             const uint32_t tl = PT_UNIFORM(pt_f2u(a.w)), tc = kf >> 24;   // the leaves with a box test of their own
-            const F4 fl = bf4(s, e + 12);
-            const uint32_t flat_lo = PT_UNIFORM(pt_f2u(fl.x)), flat_hi = PT_UNIFORM(pt_f2u(fl.y));
+            const uint32_t groups = PT_UNIFORM(pt_f2u(bf4(s, e + 12).x));   // the leaves come grouped by the form of their box test
             // the triangle leaves against the instance's ray: the world ray itself unless the instance is transformed (a branch
             // on a wave-uniform flag, not a copy of the prepared ray: 20 registers moved per mesh instance otherwise)
             auto leaves = [&](const RayPrep& lr, bool lquick) {
-                for (uint32_t t = 0; t < tc; ++t) {
-                    const F4 ta = bf4(s, tl + t * PT_SWEEP_TRI_WORDS), tb = bf4(s, tl + t * PT_SWEEP_TRI_WORDS + 4);
-                    const bool flat = (((t < 32u ? flat_lo : flat_hi) >> (t & 31u)) & 1u) != 0u;
-                    bool th = false, tu = true;
-                    if (lquick) aabb_classify2(ta, tb, lr, flat, &entry, &th, &tu);
-                    if (bounded && cull_mesh && th && beyond(entry, bound, lr.base)) th = false;
-                    mark(th && inside, tu && inside, pt_f2u(ta.w), pt_f2u(tb.w));
-                }
+                uint32_t t = 0;
+                auto group = [&](auto code, uint32_t n) {
+                    for (const uint32_t end = t + n; t < end; ++t) {
+                        const F4 ta = bf4(s, tl + t * PT_SWEEP_TRI_WORDS), tb = bf4(s, tl + t * PT_SWEEP_TRI_WORDS + 4);
+                        bool th = false, tu = true;
+                        if (lquick) aabb_classify_code<decltype(code)::value>(ta, tb, lr, &entry, &th, &tu);
+                        if (bounded && cull_mesh && th && beyond(entry, bound, lr.base)) th = false;
+                        mark(th && inside, tu && inside, pt_f2u(ta.w), pt_f2u(tb.w));
+                    }
+                };
+                const uint32_t n0 = groups & 0xffu, n1 = (groups >> 8) & 0xffu, n2 = (groups >> 16) & 0xffu, n3 = groups >> 24;
+                group(IntC<0>(), n0); group(IntC<1>(), n1); group(IntC<2>(), n2); group(IntC<3>(), n3); group(IntC<4>(), tc - (n0 + n1 + n2 + n3));
             };
             if (kf & 0x200u) {
                 F3 lo, ld;

@@ -401,6 +401,12 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
         }
         if (d.instance_count > 0 && d.instance_count <= PT_SWEEP_MAX_BITS) {
             auto is_flat = [](const uint32_t* node) { return node[0] == node[4] || node[1] == node[5] || node[2] == node[6]; };
+            // which form of the filtered slab test a box takes (pt_device.h aabb_classify_code): 0 = it has thickness on every axis, 1 / 2 / 3 =
+            // flat along x / y / z only, 4 = flat along more than one axis
+            auto flat_code = [](const uint32_t* node) {
+                const int fx = node[0] == node[4], fy = node[1] == node[5], fz = node[2] == node[6];
+                return fx + fy + fz == 0 ? 0u : (fx + fy + fz > 1 ? 4u : (fx ? 1u : (fy ? 2u : 3u)));
+            };
             pad16(w);
             std::vector<uint32_t> order;  // top-level leaf nodes in pre-order
             for (size_t k = 0; k < nodes.size() / PT_NODE_WORDS; ++k) if (nodes[k * PT_NODE_WORDS + 7] != PT_NODE_INNER) order.push_back((uint32_t)k);
@@ -417,7 +423,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                 const pt_instance& in = d.instances[inst];
                 uint32_t e = sweep_off + (uint32_t)j * PT_SWEEP_INST_WORDS;
                 uint32_t rec_off = w[PT_HDR_INSTANCE_OFF] + inst * PT_INST_WORDS;
-                uint32_t kf = (uint32_t)in.kind | (is_flat(nd) ? 1u << 8 : 0u) | (in.has_transform ? 1u << 9 : 0u) | (walked[inst] ? PT_SWEEP_WALKED : 0u);
+                uint32_t kf = (uint32_t)in.kind | (is_flat(nd) ? 1u << 8 : 0u) | (in.has_transform ? 1u << 9 : 0u) | (walked[inst] ? PT_SWEEP_WALKED : 0u) | flat_code(nd) << 11;
                 uint32_t tri_list = 0, tri_count = 0, first_bit = bit++;
                 uint32_t own[PT_SWEEP_BIT_WORDS] = {rec_off, 0u, e + 4, kf | inst << 16, 0u, 0u, 0u, 0u};
                 bits.insert(bits.end(), own, own + PT_SWEEP_BIT_WORDS);
@@ -425,7 +431,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                 if (in.kind == PT_SHAPE_MESH && walked[inst]) any_walked = true;
                 if (in.kind != PT_SHAPE_MESH) owner_mask |= 1ull << first_bit;
                 std::vector<uint32_t> leaders;  // word offsets of the triangle-leaf records that keep their own box test
-                uint64_t flat_leaders = 0;
+                std::vector<uint32_t> leader_code;
                 if (in.kind == PT_SHAPE_MESH && !walked[inst]) {
                     mesh_mask |= 1ull << first_bit;
                     pad16(w);
@@ -446,7 +452,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                         uint32_t triw = tri_base + mn[7] * PT_TRI_WORDS, flat = is_flat(mn) ? 1u : 0u;
                         uint32_t box_words = e + 4;  // a copy of the instance's own box: settled with it, never looked up
                         if (!alias) {
-                            if (flat) flat_leaders |= 1ull << leaders.size();
+                            leader_code.push_back(flat_code(mn));
                             leaders.push_back((uint32_t)w.size());
                             uint32_t rec[PT_SWEEP_TRI_WORDS] = {mn[0], mn[1], mn[2], 0u, mn[4], mn[5], mn[6], 0u};  // [3], [7]: the mask, below
                             box_words = (uint32_t)w.size();
@@ -468,11 +474,32 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                         w[off + 3] = (uint32_t)m; w[off + 7] = (uint32_t)(m >> 32);
                     }
                 }
+                // The order of the box tests is free (the masks carry the leaf order): the records are grouped by the form of the test, so
+                // that the sweep runs one specialised loop per form; [12] holds the sizes of the groups 0..3, the rest is group 4.
+                uint32_t group_sizes = 0;
+                if (!leaders.empty()) {
+                    std::vector<size_t> order(leaders.size());
+                    for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+                    std::stable_sort(order.begin(), order.end(), [&](size_t a2, size_t b2) { return leader_code[a2] < leader_code[b2]; });
+                    std::vector<uint32_t> block(leaders.size() * PT_SWEEP_TRI_WORDS);
+                    std::vector<uint32_t> moved(leaders.size());   // new word offset of leader k
+                    for (size_t pos = 0; pos < order.size(); ++pos) {
+                        const size_t k = order[pos];
+                        for (int q = 0; q < PT_SWEEP_TRI_WORDS; ++q) block[pos * PT_SWEEP_TRI_WORDS + q] = w[leaders[k] + q];
+                        moved[k] = tri_list + (uint32_t)pos * PT_SWEEP_TRI_WORDS;
+                        if (leader_code[k] < 4) group_sizes += 1u << (8 * leader_code[k]);
+                    }
+                    for (uint32_t b2 = first_bit + 1; b2 < bit; ++b2) {   // the bit table's box references follow the records
+                        uint32_t& bw = bits[(size_t)b2 * PT_SWEEP_BIT_WORDS + 2];
+                        for (size_t k = 0; k < leaders.size(); ++k) if (bw == leaders[k]) { bw = moved[k]; break; }
+                    }
+                    for (size_t q = 0; q < block.size(); ++q) w[tri_list + q] = block[q];
+                }
                 uint64_t own_mask = mask_of(first_bit);
                 uint32_t* r = &w[e];
                 r[0] = rec_off; r[1] = kf | first_bit << 16 | (uint32_t)leaders.size() << 24; r[2] = (uint32_t)own_mask; r[3] = (uint32_t)(own_mask >> 32);
                 r[4] = nd[0]; r[5] = nd[1]; r[6] = nd[2]; r[7] = tri_list; r[8] = nd[4]; r[9] = nd[5]; r[10] = nd[6]; r[11] = tri_count;
-                r[12] = (uint32_t)flat_leaders; r[13] = (uint32_t)(flat_leaders >> 32); r[14] = inst; r[15] = 0u;
+                r[12] = group_sizes; r[13] = 0u; r[14] = inst; r[15] = 0u;
             }
             for (size_t k = 0; k < root_of.size(); ++k)
                 if (root_of[k] != (int)k) {
