@@ -20,7 +20,8 @@
 #define PT_NODE_FLAT 0x80000000u  /* in the exit word [3]: the box has zero thickness along an axis */
 #define PT_NODE_NO_CULL 0x40000000u /* in the exit word: the subtree holds a sphere, whose computed hit distance can fall short of its box by more
                                       than any relative margin (cancellation in the quadratic): never culled by the closest hit or a bound */
-#define PT_NODE_EXIT(w) ((w) & 0x3fffffffu)
+#define PT_NODE_CODE(w) (((w) >> 27) & 7u) /* in the exit word: the form of the filtered box test (0 thick, 1..3 flat along x / y / z, 4 flat along several axes) */
+#define PT_NODE_EXIT(w) ((w) & 0x07ffffffu)
 
 // A BVH node: two float4.  a = (min.xyz, bits(exit)), b = (max.xyz, bits(shape or PT_NODE_INNER)).
 // Pre-order array with skip links (src/accelerator/lbvh.rs:16-45): an inner node that is hit continues at

@@ -31,6 +31,17 @@
 #define PT_STAT_RAY(o, d)
 #endif
 
+// Wave-level helpers: device code sees the wave, the host emulation one lane at a time.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_KEEP_BRANCH() asm volatile("" ::: "memory")   /* inside a rarely taken block: the compiler must not turn it into selects */
+#define PT_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
+#define PT_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* a value every lane of the wave holds */
+#else
+#define PT_KEEP_BRANCH()
+#define PT_WAVE_ANY(x) (x)
+#define PT_UNIFORM(x) (x)
+#endif
+
 namespace ptd {
 
 template <int V> struct IntC { static constexpr int value = V; };   // a compile-time integer as a value (generic lambdas)
@@ -377,12 +388,24 @@ PT_HD int aabb_classify(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry) 
     if (m0 > x0 + e0 || m1 > x1 + e1 || m2 > x2 + e2) return 0;
     return (m0 < x0 - e0 && m1 < x1 - e1 && m2 < x2 - e2) ? 1 : 2;
 }
+
+
 // The box test of a BVH walk step: the three-way classification when the ray allows it (`quick`: rp.fast and no zero direction
-// component; a non-flat node then takes the cheap form), the per-axis filtered test otherwise; the exact test settles what is left.
+// component; a node with thickness takes the cheap form, a flat one the per-axis form — lanes of a wave stand on different nodes
+// here, so two forms, not five), the per-axis filtered test otherwise; the exact test settles what is left.
 PT_HD bool aabb_hit_node(F4 a, F4 b, const RayPrep& rp, bool quick, float* entry) {
     if (!quick) return aabb_hit(a, b, rp, entry);
     const int c = aabb_classify(a, b, rp, (pt_f2u(a.w) & PT_NODE_FLAT) != 0u, entry);
     if (c != 2) return c == 1;
+    PT_STAT(box_exact);
+    return aabb_hit_exact(a, b, rp.o, rp.d, entry);
+}
+// The same for a node every lane of the wave tests together (the light list of nearest_light_hit): the form the host chose for it.
+PT_HD bool aabb_hit_uniform_node(F4 a, F4 b, const RayPrep& rp, bool quick, float* entry) {
+    if (!quick) return aabb_hit(a, b, rp, entry);
+    bool h, u;
+    aabb_classify_by(PT_UNIFORM(PT_NODE_CODE(pt_f2u(a.w))), a, b, rp, entry, &h, &u);
+    if (!u) return h;
     PT_STAT(box_exact);
     return aabb_hit_exact(a, b, rp.o, rp.d, entry);
 }
@@ -550,16 +573,19 @@ PT_HD void hit_record(const SceneView& s, F3 o, F3 d, uint32_t best_inst, uint32
         uint32_t normal_off = bu(s, mesh + PT_MESH_NORMAL_OFF);
         F4 q0 = mf4(s, triw), q1 = mf4(s, triw + 4), q2 = mf4(s, triw + 8);
         F3 p0 = f3(q0.x, q0.y, q0.z), p1 = f3(q1.x, q1.y, q1.z), p2 = f3(q2.x, q2.y, q2.z);
-        F3 n = normalize(cross(sub(p0, p2), sub(p1, p2)));
         if (normal_off != 0) {
             uint32_t nn = normal_off + (triw - bu(s, mesh + PT_MESH_TRI_OFF));
             F4 m0 = mf4(s, nn), m1 = mf4(s, nn + 4), m2 = mf4(s, nn + 8);
-            n = add(add(mul(f3(m0.x, m0.y, m0.z), bh.b0), mul(f3(m1.x, m1.y, m1.z), bh.b1)), mul(f3(m2.x, m2.y, m2.z), bh.b2));
+            F3 n = add(add(mul(f3(m0.x, m0.y, m0.z), bh.b0), mul(f3(m1.x, m1.y, m1.z), bh.b1)), mul(f3(m2.x, m2.y, m2.z), bh.b2));
+            h.n = normalize(n);
+        } else {
+            // the face normal, normalize(normalize(cross(p0 - p2, p1 - p2))), as the host computed it with these same functions (pt_scene_host.cpp)
+            const F4 fn = mf4(s, pt_f2u(q1.w));
+            h.n = f3(fn.x, fn.y, fn.z);
         }
         h.t = bh.t;
         h.p = add(add(mul(p0, bh.b0), mul(p1, bh.b1)), mul(p2, bh.b2));
         h.u = 0.0f; h.v = 0.0f;
-        h.n = normalize(n);
         h.material = pt_f2u(q0.w);
     } else {
         analytic_hit(s, inst, bu(s, inst + PT_INST_KIND), lo, ld, PT_INF, &h);
@@ -585,15 +611,6 @@ PT_HD void hit_record(const SceneView& s, F3 o, F3 d, uint32_t best_inst, uint32
 //   3. the primitive tests of the lane's hit leaves in bit order = pre-order.
 // Same leaves, same order, same arithmetic as world_hit: same bits.  The tree walk keeps 32 % of the VALU lanes busy
 // (profiles/r1c); here step 1, the bulk of the work, keeps all of them busy.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PT_KEEP_BRANCH() asm volatile("" ::: "memory")   /* inside a rarely taken block: the compiler must not turn it into selects */
-#define PT_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
-#define PT_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* a value every lane of the wave holds */
-#else
-#define PT_KEEP_BRANCH()
-#define PT_WAVE_ANY(x) (x)
-#define PT_UNIFORM(x) (x)
-#endif
 PT_HD uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
 // Phases 1 and 2: the mask of leaves whose own box the ray hits (walked mesh instances keep their instance bit).
 PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
@@ -720,7 +737,7 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                 const uint32_t e = PT_UNIFORM(leaf_off + (first + t) * 8u);
                 const F4 ta = mf4(s, e), tb = mf4(s, e + 4);
                 float entry = 0.0f;
-                int ct = quick ? aabb_classify(ta, tb, cr, PT_UNIFORM(pt_f2u(tb.w)) != 0u, &entry) : 2;
+                int ct = quick ? aabb_classify(ta, tb, cr, PT_UNIFORM(pt_f2u(tb.w)) != 0u, &entry) : 2;   // ([7]: the test form; two forms here, measured: the five-way switch costs C3 8 %)
                 if (ct == 1 && cull && beyond(entry, limit, cr.base)) ct = 0;
                 const uint32_t m = 1u << (t & 31u);
                 if (t < 32u) { hit_lo |= ct == 1 ? m : 0u; unc_lo |= ct == 2 ? m : 0u; } else { hit_hi |= ct == 1 ? m : 0u; unc_hi |= ct == 2 ? m : 0u; }
@@ -1156,12 +1173,13 @@ PT_HD float nearest_light_hit(const SceneView& s, F3 o, F3 d) {
     const uint32_t n = bu(s, PT_HDR_LIGHT_COUNT), lo_ = bu(s, PT_HDR_LIGHT_OFF), ln = bu(s, PT_HDR_LIGHT_NODE_OFF), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
     RayPrep wr = ray_prepare(o, d);
     if (bu(s, PT_HDR_FLAGS) & PT_FLAG_EXACT_SLAB) wr.fast = false;
+    const bool quick = wr.fast && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f;
     float best = PT_INF;
     for (uint32_t k = 0; k < n; ++k) {
         uint32_t node = bu(s, ln + k);
         F4 a = bf4(s, node), b = bf4(s, node + 4);
         float entry;
-        if (!aabb_hit(a, b, wr, &entry)) continue;
+        if (!aabb_hit_uniform_node(a, b, wr, quick, &entry)) continue;
         uint32_t inst = inst_off + bu(s, lo_ + k) * PT_INST_WORDS;
         F3 l0, l1;
         instance_local_ray(s, inst, o, d, &l0, &l1);

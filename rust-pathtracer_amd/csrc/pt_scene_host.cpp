@@ -92,7 +92,9 @@ struct BvhBuilder {
         const bool flat = b.mn[0] == b.mx[0] || b.mn[1] == b.mx[1] || b.mn[2] == b.mx[2];
         bool keep = false;
         if (!no_cull.empty()) for (uint32_t i : idx) keep = keep || no_cull[i] != 0;
-        out[at + 0] = fbits(b.mn[0]); out[at + 1] = fbits(b.mn[1]); out[at + 2] = fbits(b.mn[2]); out[at + 3] = node_count() | (flat ? PT_NODE_FLAT : 0u) | (keep ? PT_NODE_NO_CULL : 0u);
+        const int fx = b.mn[0] == b.mx[0], fy = b.mn[1] == b.mx[1], fz = b.mn[2] == b.mx[2];
+        const uint32_t code = fx + fy + fz == 0 ? 0u : (fx + fy + fz > 1 ? 4u : (fx ? 1u : (fy ? 2u : 3u)));   // aabb_classify_by (pt_device.h)
+        out[at + 0] = fbits(b.mn[0]); out[at + 1] = fbits(b.mn[1]); out[at + 2] = fbits(b.mn[2]); out[at + 3] = node_count() | (flat ? PT_NODE_FLAT : 0u) | (keep ? PT_NODE_NO_CULL : 0u) | code << 27;
         out[at + 4] = fbits(b.mx[0]); out[at + 5] = fbits(b.mx[1]); out[at + 6] = fbits(b.mx[2]); out[at + 7] = leaf ? idx[0] : PT_NODE_INNER;
         if (leaf) leaf_of_shape[idx[0]] = (uint32_t)(at / PT_NODE_WORDS);
     }
@@ -263,6 +265,22 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                 md.push_back(fbits(p[0])); md.push_back(fbits(p[1])); md.push_back(fbits(p[2])); md.push_back(k == 0 ? mat : 0u);
             }
         }
+        // Without vertex normals a hit's normal is the face's: normalize(cross(p0 - p2, p1 - p2)) (mesh.rs:176-181), normalised once more by
+        // HitRecord::new (hittable.rs:30-39).  Both depend on the triangle alone, so they are computed here, with the very operations
+        // hit_record would use (same header, no contraction, IEEE division and square root on both sides), and the second vertex's spare
+        // word points at the result: two square roots, six divisions and a cross product less per closest hit.
+        if (m.normal_offset < 0) {
+            pad16(md);
+            const uint32_t fn_off = (uint32_t)md.size();
+            for (uint32_t f = 0; f < m.face_count; ++f) {
+                const size_t at = tri_off + (size_t)f * PT_TRI_WORDS;
+                auto vert = [&](int k) { return ptd::f3(pt_u2f(md[at + 4 * k]), pt_u2f(md[at + 4 * k + 1]), pt_u2f(md[at + 4 * k + 2])); };
+                const ptd::F3 p0 = vert(0), p1 = vert(1), p2 = vert(2);
+                const ptd::F3 n = ptd::normalize(ptd::normalize(ptd::cross(ptd::sub(p0, p2), ptd::sub(p1, p2))));
+                md[at + 7] = fn_off + 4 * f;
+                md.push_back(fbits(n.x)); md.push_back(fbits(n.y)); md.push_back(fbits(n.z)); md.push_back(0u);
+            }
+        }
         uint32_t normal_off = 0;
         if (m.normal_offset >= 0) {
             const float* N = d.normals + 3 * (size_t)m.normal_offset;
@@ -295,8 +313,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             for (size_t k = 0; k < nodes.size() / PT_NODE_WORDS; ++k) {
                 const uint32_t* nd = &nodes[k * PT_NODE_WORDS];
                 if (nd[7] == PT_NODE_INNER) continue;
-                uint32_t flat = (nd[0] == nd[4] || nd[1] == nd[5] || nd[2] == nd[6]) ? 1u : 0u;
-                uint32_t rec[8] = {nd[0], nd[1], nd[2], tri_off + nd[7] * PT_TRI_WORDS, nd[4], nd[5], nd[6], flat};
+                uint32_t rec[8] = {nd[0], nd[1], nd[2], tri_off + nd[7] * PT_TRI_WORDS, nd[4], nd[5], nd[6], PT_NODE_CODE(nd[3])};   // [7]: the form of the box test
                 md.insert(md.end(), rec, rec + 8);
                 ++leaf_count;
             }
