@@ -95,15 +95,18 @@ struct DevBuf {
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+constexpr uint32_t kUnitCounters = 2 * 64 + 2;   // two parked launches per bounce, max_bounces <= 64
 struct DeviceBuffers {
     uint32_t capacity = 0, light_samples = 0, nl = 0;
     uint32_t *paths_a = nullptr, *paths_b = nullptr, *hits = nullptr, *shadow = nullptr, *pixels = nullptr, *counts = nullptr, *park = nullptr;
+    uint32_t* unit_counters = nullptr;   // parked kernels with dynamic units: one counter per launch of a pass (kUnitCounters), zeroed per pass
     float* energy = nullptr;
     unsigned long long* block_stats = nullptr;
     size_t pixel_capacity = 0;
     int grid = 0;  // segments per queue == workgroups per launch
     void release() {
         hipFree(paths_a); hipFree(paths_b); hipFree(hits); hipFree(shadow); hipFree(pixels); hipFree(counts); hipFree(energy); hipFree(block_stats); hipFree(park);
+        hipFree(unit_counters);
         *this = DeviceBuffers();
     }
 };
@@ -162,6 +165,7 @@ pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples
         HIP_TRY(hipMalloc(&b.counts, sizeof(uint32_t) * 3 * (size_t)grid));
         HIP_TRY(hipMalloc(&b.block_stats, sizeof(unsigned long long) * BS_FIELDS * (size_t)grid));
         if (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) HIP_TRY(hipMalloc(&b.park, sizeof(uint32_t) * kParkFields * kParkCap * (size_t)grid));
+        if (!b.unit_counters) HIP_TRY(hipMalloc(&b.unit_counters, sizeof(uint32_t) * kUnitCounters));
         b.capacity = total; b.light_samples = ls; b.grid = grid;
     }
     if (b.pixel_capacity < n_pixels) {
@@ -231,7 +235,14 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     const bool pooled = sweep && !walks && mode == PT_LDS_ALL && lds_bytes + pool_lds_bytes() <= kLdsBlobLimitBytes && env_u32("PT_AMD_POOL", 0) != 0;
     // (walked meshes in line under PT_AMD_NO_PARK, and every partly staged or unstaged blob: the run-time choice of PT_FORM_ANY)
     const int trav_form = parked ? PT_FORM_PARKED : (mode != PT_LDS_ALL || (sweep && walks)) ? PT_FORM_ANY : pooled ? PT_FORM_POOLED : sweep ? PT_FORM_SWEEP : PT_FORM_WALK;
-    const LaunchCfg cfg{grid, lds_bytes, stream, mode};
+    // The parked kernels take units of work from a counter, a few persistent workgroups per CU, when the whole blob is staged in LDS
+    // (C3: k_extend 9175 -> 7880 us, k_shadow 8008 -> 7105, 487 -> 543 Msamples/s: park lists that live across units keep the drains
+    // full).  With the mesh in HBM/L2 (C4) the static form wins, 1128 vs 1083 Msamples/s: a wave's parked rays then come from one
+    // region of the film and walk the same part of the mesh.  PT_AMD_PARK_DYNAMIC=0 / 1 forces either.
+    const bool park_dynamic = parked && env_u32("PT_AMD_PARK_DYNAMIC", mode == PT_LDS_ALL ? 1 : 0) != 0;
+    const int dyn_grid = sc->num_cus * (int)env_u32("PT_AMD_PARK_BLOCKS_PER_CU", 4);
+    LaunchCfg cfg{grid, lds_bytes, stream, mode};
+    cfg.dyn_grid = dyn_grid < grid ? dyn_grid : grid;
     const SceneArgs sargs{sc->d_blob, sc->blob_words, sc->d_tex};
     // light samples can pick the environment only if env_sampling_probability > 0: otherwise k_shade is the form without that branch
     float env_prob; std::memcpy(&env_prob, &sc->host.blob[PT_HDR_ENV_PROB], sizeof env_prob);
@@ -274,6 +285,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
         uint32_t seg_cap = segment_capacity(n, grid);
         camera_rays += n;
         const uint32_t* d_px = b.pixels + pass.pixel_begin;
+        if (park_dynamic) HIP_TRY(hipMemsetAsync(b.unit_counters, 0, sizeof(uint32_t) * kUnitCounters, stream));
         timed(ST_GENERATE, [&] {
             if (hero) hipLaunchKernelGGL(k_generate<4>, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, qa, b.energy, n, seg_cap, live[0]);
             else hipLaunchKernelGGL(k_generate<1>, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, qa, b.energy, n, seg_cap, live[0]);
@@ -282,7 +294,9 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
             Queue qin = (bounce & 1) ? qb : qa, qout = (bounce & 1) ? qa : qb;
             uint32_t *cin = live[bounce & 1], *cout = live[(bounce + 1) & 1];
             // kernel variant = staging mode (PT_LDS_*) x traversal form x wavelengths per path (pt_launch.h)
+            if (park_dynamic) cfg.unit_counter = b.unit_counters + 2 * bounce;
             timed(ST_EXTEND, [&] { launch_extend(cfg, trav_form, sargs, qin, qh, seg_cap, cin, b.park); });
+            if (park_dynamic) cfg.unit_counter = b.unit_counters + 2 * bounce + 1;
             timed(ST_SHADE, [&] { launch_shade(cfg, hero ? 4 : 1, shade_form, sargs, rp, bounce, d_px, qin, qh, qout, qs, b.energy, seg_cap, cin, cout, nshadow, b.block_stats); });
             if (rd.light_samples > 0)   // (shade_form FULL = the scene can produce environment rays)
                 timed(ST_SHADOW, [&] { launch_shadow(cfg, trav_form, hero ? 4 : 1, shade_form == PT_SHADE_FULL, sargs, rd.light_samples, qs, b.energy, b.capacity, seg_cap, nshadow, b.park, qh); });

@@ -23,7 +23,13 @@ void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, Queue path
         PT_EXP_CASE(0x6) PT_EXP_CASE(0x4) PT_EXP_CASE(0x0) PT_EXP_CASE(0x7) PT_EXP_CASE(0x7d) PT_EXP_CASE(0x3d) PT_EXP_CASE(0x35) PT_EXP_CASE(0x25) PT_EXP_CASE(0x5) PT_EXP_CASE(0x1)
     }
 #endif
-    if (form == PT_FORM_PARKED) PT_BY_MODE(K_EXT_PARKED, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park);
+    if (form == PT_FORM_PARKED && c.unit_counter) {
+        LaunchCfg d = c; d.grid = c.dyn_grid;
+#define K_EXT_PARKED_DYN(M) k_extend_parked_dyn<M>
+        if (c.lds_mode == PT_LDS_ALL) go(d, K_EXT_PARKED_DYN(PT_LDS_ALL), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter);
+        else if (c.lds_mode == PT_LDS_CORE) go(d, K_EXT_PARKED_DYN(PT_LDS_CORE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter);
+        else go(d, K_EXT_PARKED_DYN(PT_LDS_NONE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter);
+    } else if (form == PT_FORM_PARKED) PT_BY_MODE(K_EXT_PARKED, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park);
     else if (form == PT_FORM_POOLED) PT_GO(k_extend_pooled<PT_LDS_ALL>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
     else if (form == PT_FORM_SWEEP) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
     else if (form == PT_FORM_WALK) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_WALK>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
@@ -39,6 +45,8 @@ hipError_t allow_lds_extend(uint32_t bytes) {
     auto allow = [&](const void* k) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) worst = e; };
 #define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
     PT_ALLOW_MODES(K_EXT_ANY); PT_ALLOW_MODES(K_EXT_PARKED); PT_ALLOW_MODES(K_PROBE);
+#define K_EXT_PARKED_DYN2(M) k_extend_parked_dyn<M>
+    PT_ALLOW_MODES(K_EXT_PARKED_DYN2);
     allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>));
     allow(reinterpret_cast<const void*>(k_extend_pooled<PT_LDS_ALL>));
     return worst;

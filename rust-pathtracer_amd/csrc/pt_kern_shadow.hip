@@ -25,7 +25,15 @@ void launch_shadow(const LaunchCfg& c, int form, int nl, bool env, const SceneAr
         PT_EXP_CASE(8) PT_EXP_CASE(2) PT_EXP_CASE(4) PT_EXP_CASE(0)
     }
 #endif
-    if (form == PT_FORM_PARKED) { if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park); else PT_BY_MODE(K_SH_PARKED1, PT_ARGS, park); }
+    if (form == PT_FORM_PARKED && c.unit_counter) {
+        LaunchCfg d = c; d.grid = c.dyn_grid;
+#define PT_DYN_ARGS sc.blob, sc.blob_words, sc.tex, light_samples, shadow, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter
+#define PT_DYN_BY_MODE(NL) do { if (c.lds_mode == PT_LDS_ALL) go(d, k_shadow_parked_dyn<PT_LDS_ALL, NL>, PT_DYN_ARGS); else if (c.lds_mode == PT_LDS_CORE) go(d, k_shadow_parked_dyn<PT_LDS_CORE, NL>, PT_DYN_ARGS); \
+                                else go(d, k_shadow_parked_dyn<PT_LDS_NONE, NL>, PT_DYN_ARGS); } while (0)
+        LaunchCfg plain = c; plain.lds_bytes = 0;
+        if (hero) { PT_DYN_BY_MODE(4); go(plain, k_shadow_sum<4>, light_samples, shadow, energy, energy_stride, seg_cap, count_in); }
+        else { PT_DYN_BY_MODE(1); go(plain, k_shadow_sum<1>, light_samples, shadow, energy, energy_stride, seg_cap, count_in); }
+    } else if (form == PT_FORM_PARKED) { if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park); else PT_BY_MODE(K_SH_PARKED1, PT_ARGS, park); }
     else if (form == PT_FORM_POOLED) {
         if (env) { if (hero) PT_GO((k_shadow_pooled<PT_LDS_ALL, 4, true>), PT_ARGS); else PT_GO((k_shadow_pooled<PT_LDS_ALL, 1, true>), PT_ARGS); }
         else if (hero) PT_GO((k_shadow_pooled<PT_LDS_ALL, 4, false>), PT_ARGS); else PT_GO((k_shadow_pooled<PT_LDS_ALL, 1, false>), PT_ARGS);
@@ -41,6 +49,9 @@ hipError_t allow_lds_shadow(uint32_t bytes) {
     auto allow = [&](const void* k) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) worst = e; };
 #define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
     PT_ALLOW_MODES(K_SH_ANY1); PT_ALLOW_MODES(K_SH_ANY4); PT_ALLOW_MODES(K_SH_PARKED1); PT_ALLOW_MODES(K_SH_PARKED4);
+#define K_SH_DYN1(M) k_shadow_parked_dyn<M, 1>
+#define K_SH_DYN4(M) k_shadow_parked_dyn<M, 4>
+    PT_ALLOW_MODES(K_SH_DYN1); PT_ALLOW_MODES(K_SH_DYN4);
     allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_WALK>));
     allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, true>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, true>));
     allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, false>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, false>));

@@ -515,6 +515,141 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
     }
 }
 
+// ---- the parked kernels with dynamic work distribution ------------------------------------------------------------------------------
+// The static form above gives every workgroup one queue segment; its park lists start empty and end with a partly filled drain, and
+// at deep bounces a segment holds too few rays that enter the big mesh to ever fill a wave.  Here a few persistent workgroups per CU
+// take UNITS of work — kUnitItems consecutive items of a segment — from one counter, wave by wave: a wave's park list lives across
+// all the units it takes, so drains stay full until the very end, and the hardware no longer has to balance segments of different cost
+// (the static variant with several segments per workgroup gained 7 % on C3 and lost 24 % on C4 for that reason).  Waves are fully
+// independent: no workgroup barrier after the blob is staged.
+constexpr uint32_t kUnitItems = 1024;
+__device__ __forceinline__ bool next_unit(uint32_t* __restrict__ counter, uint32_t total_units, uint32_t units_per_seg, uint32_t seg_cap,
+                                          const uint32_t* __restrict__ count_in, uint32_t* first, uint32_t* cnt) {
+    uint32_t u = 0;
+    if (lane_id() == 0) u = atomicAdd(counter, 1u);
+    u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+    *first = 0; *cnt = 0;
+    if (u >= total_units) return false;
+    const uint32_t seg = u / units_per_seg, c = u - seg * units_per_seg, n = count_in[seg];
+    *first = seg * seg_cap + c * kUnitItems;
+    *cnt = n > c * kUnitItems ? (n - c * kUnitItems < kUnitItems ? n - c * kUnitItems : kUnitItems) : 0u;
+    return true;
+}
+
+template <int USE_LDS>
+__global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_extend_parked_dyn(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                                         Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
+                                                                         uint32_t* __restrict__ park_all, uint32_t n_segments, uint32_t* __restrict__ unit_counter) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ uint32_t park_counts[kBlock / 64];
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap + wave * kWaveParkCap;
+    uint32_t* park_count = &park_counts[wave];
+    if (lane == 0) *park_count = 0;
+    const uint32_t units_per_seg = (seg_cap + kUnitItems - 1) / kUnitItems, total_units = n_segments * units_per_seg;
+    auto ray_of = [&](uint32_t i, F3* o, F3* d) {
+        *o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
+        *d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
+    };
+    auto settle = [&](uint32_t i, F3 o, F3 d, const SweepState& st, bool parked) {   // `i`: the item's index in the queue
+        if (parked) park_store(pk, atomicAdd(park_count, 1u), i, st, 0u, PT_INF, 0u);
+        else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, i, h); }
+    };
+    auto resume = [&](uint32_t i2, SweepState& st, uint32_t, float, uint32_t) {
+        F3 o, d;
+        ray_of(i2, &o, &d);
+        settle(i2, o, d, st, sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st));
+    };
+    for (;;) {
+        uint32_t first, cnt;
+        const bool more = next_unit(unit_counter, total_units, units_per_seg, seg_cap, count_in, &first, &cnt);
+        for (uint32_t off = 0; off < cnt; off += 64u) {
+            if (off + lane < cnt) {
+                const uint32_t i = first + off + lane;
+                F3 o, d;
+                ray_of(i, &o, &d);
+                SweepState st;
+                sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
+                const TriRay wtr = tri_ray_prepare(o, d);
+                settle(i, o, d, st, sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true));
+            }
+            park_drain(pk, park_count, false, resume);
+        }
+        if (!more) { park_drain(pk, park_count, true, resume); break; }
+    }
+}
+
+// The rays only: every finished ray leaves its contribution where its factor was; k_shadow_sum adds an item's rays up afterwards.
+template <int USE_LDS, int NL>
+__global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked_dyn(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                                         uint32_t light_samples, Queue shadow, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
+                                                                         uint32_t* __restrict__ park_all, uint32_t n_segments, uint32_t* __restrict__ unit_counter) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ uint32_t park_counts[kBlock / 64];
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap + wave * kWaveParkCap;
+    uint32_t* park_count = &park_counts[wave];
+    if (lane == 0) *park_count = 0;
+    const uint32_t units_per_seg = (seg_cap + kUnitItems - 1) / kUnitItems, total_units = n_segments * units_per_seg;
+    auto settle = [&](uint32_t item, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked) {
+        if (parked) { park_store(pk, atomicAdd(park_count, 1u), item, st, l, bound, env ? 1u : 0u); return; }
+        float lambda[NL], c[NL];
+        for (int k = 0; k < NL; ++k) lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item);
+        Hit sh;
+        bool hit = sweep_finish(s, ray.o, ray.d, st, &sh);
+        shadow_ray_contribution<NL>(s, lambda, ray, env, hit, sh, c);
+        for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
+    };
+    auto resume = [&](uint32_t item2, SweepState& st, uint32_t l2, float bound, uint32_t kind) {
+        ShadowRayT<NL> pr;
+        load_shadow_ray<NL>(shadow, item2, l2, &pr);
+        const bool env = kind != 0u;
+        const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
+        settle(item2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, stop2, st));
+    };
+    for (;;) {
+        uint32_t first, cnt;
+        const bool more = next_unit(unit_counter, total_units, units_per_seg, seg_cap, count_in, &first, &cnt);
+        for (uint32_t off = 0; off < cnt; off += 64u) {
+            const bool active = off + lane < cnt;
+            const uint32_t item = first + off + lane, flags = active ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
+            for (uint32_t l = 0; l < light_samples; ++l) {   // one ray of every item per step, so that a step parks at most one ray per lane
+                ShadowRayT<NL> ray;
+                if (active && load_shadow_ray<NL>(shadow, item, l, &ray)) {
+                    const bool env = ((flags >> l) & 1u) != 0;
+                    float bound = PT_INF; int stop = shadow_env_stop(s);
+                    if (!env && !shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) {
+                        for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
+                    } else {
+                        SweepState st;
+                        sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
+                        const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
+                        settle(item, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true));
+                    }
+                }
+                park_drain(pk, park_count, false, resume);
+            }
+        }
+        if (!more) { park_drain(pk, park_count, true, resume); break; }
+    }
+}
+// pt.rs:349-392, 596: an item's rays summed in order, divided by L, added to its slot (workgroup b owns segment b, as everywhere)
+template <int NL>
+__global__ void __launch_bounds__(kBlock) k_shadow_sum(uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
+                                                      uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
+    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+        const uint32_t item = base + j, slot = qu(shadow, Layout<NL>::sh_slot, item);
+        float lc[NL];
+        for (int k = 0; k < NL; ++k) lc[k] = 0.0f;
+        for (uint32_t l = 0; l < light_samples; ++l)
+            for (int k = 0; k < NL; ++k) lc[k] += qf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item);
+        for (int k = 0; k < NL; ++k) energy[(size_t)k * energy_stride + slot] += lc[k] / (float)light_samples;
+    }
+}
+
 template <int NL>
 __global__ void __launch_bounds__(kBlock) k_accumulate(RenderParams rp, const uint32_t* __restrict__ pixels, const float* __restrict__ energy,
                                                       float* __restrict__ film) {

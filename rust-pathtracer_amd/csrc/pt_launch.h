@@ -17,7 +17,8 @@ constexpr uint32_t kParkCap = 512, kParkFields = 16;
 enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_FIELDS };  // per-workgroup statistics (Profile counters)
 uint32_t pool_lds_bytes();  // static LDS of the pooled traversal kernels, on top of the staged blob
 
-struct LaunchCfg { int grid; uint32_t lds_bytes; hipStream_t stream; int lds_mode; };
+struct LaunchCfg { int grid; uint32_t lds_bytes; hipStream_t stream; int lds_mode;
+                   int dyn_grid = 0; uint32_t* unit_counter = nullptr; };   // parked kernels with dynamic units: persistent workgroups and this launch's counter (zeroed)
 struct SceneArgs { const uint32_t* blob; uint32_t blob_words; const float* tex; };
 
 void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, ptd::Queue paths, ptd::Queue hits, uint32_t seg_cap, const uint32_t* count_in, uint32_t* park);
