@@ -102,7 +102,8 @@ enum {
     PT_MATERIAL_LAMBERTIAN = 0,    /* src/materials/lambertian.rs */
     PT_MATERIAL_GGX = 1,           /* src/materials/ggx.rs */
     PT_MATERIAL_DIFFUSE_LIGHT = 2, /* src/materials/diffuse_light.rs */
-    PT_MATERIAL_SHARP_LIGHT = 3    /* src/materials/sharp_light.rs */
+    PT_MATERIAL_SHARP_LIGHT = 3,   /* src/materials/sharp_light.rs */
+    PT_MATERIAL_PASSTHROUGH = 4    /* src/materials/passthrough.rs: the boundary of a medium; colour = curve_bounce */
 };
 enum { PT_SIDED_FORWARD = 0, PT_SIDED_REVERSE = 1, PT_SIDED_DUAL = 2 }; /* math::Sidedness */
 
@@ -114,7 +115,17 @@ typedef struct pt_material {
     int32_t curve_emit, curve_bounce;            /* DiffuseLight / SharpLight */
     float sharpness;       /* SharpLight: the value from the scene file; the library applies 1 + |s| (sharp_light.rs:26) */
     int32_t sidedness;
+    int32_t outer_medium, inner_medium; /* MediumId (GGX, PassthroughFilter; ggx.rs:188-189, passthrough.rs:6-7): 0 = vacuum, k = mediums[k - 1] */
 } pt_material;
+
+/* ---- participating media: src/mediums (read by the medium-aware walk only, pt_render_desc::medium_aware) */
+enum { PT_MEDIUM_HG = 0, PT_MEDIUM_RAYLEIGH = 1 };
+typedef struct pt_medium {
+    int32_t kind;
+    int32_t curve_g, curve_sigma_a, curve_sigma_s; /* HenyeyGreensteinHomogeneous (hg.rs:16-24): g is stored + 1 */
+    int32_t curve_ior;                             /* Rayleigh (rayleigh.rs:6-9) */
+    float corrective_factor;
+} pt_medium;
 
 /* ---- geometry: src/geometry */
 enum { PT_SHAPE_RECT = 0, PT_SHAPE_SPHERE = 1, PT_SHAPE_DISK = 2, PT_SHAPE_MESH = 3 };
@@ -187,6 +198,7 @@ typedef struct pt_scene_desc {
     uint32_t camera_count;       const pt_camera* cameras;
     pt_environment environment;
     float env_sampling_probability; /* World::env_sampling_probability (src/world/mod.rs:26,170-176) */
+    uint32_t medium_count;       const pt_medium* mediums;     /* World::mediums (MediumTable); at most 255 */
 } pt_scene_desc;
 
 /* Which shard renders tile t (t = index in the reference's tile order, tiled.rs:190-277; tiles_per_row = full tiles per film row):
@@ -213,6 +225,8 @@ typedef struct pt_render_desc {
     uint32_t sample_count;       /* 0 = all spp. With a partial range the film holds the un-normalised running sum. */
     uint32_t phase_samples;      /* samples summed before their sum is added to the pixel: 0 = 10 (TiledRenderer, src/renderer/tiled.rs:347-361);
                                     >= spp = all of them, then one division (NaiveRenderer, src/renderer/naive.rs:82-103) */
+    uint32_t medium_aware;       /* IntegratorType::PT { medium_aware } (src/parsing/config.rs:60-75): random_walk_medium instead of
+                                    random_walk (src/integrator/pt.rs:447, utils.rs:708-1103); single wavelength only */
 } pt_render_desc;
 
 typedef struct pt_profile {      /* Profile (src/profile.rs:2-8) + timing */

@@ -116,6 +116,17 @@ PT_HD pt_f32x4 pt_draw4(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t
     return o;
 }
 
+/* The same with another Philox tag word: the medium-aware walk's draws (the reference takes them from the thread RNG, utils.rs:773-778,
+ * 1036-1041): tag "mdst", block b = the free-flight samples of bounce b for up to four tracked mediums (x, y, z, w); tag "mphs",
+ * block b = x, y: the phase-function sample of bounce b. */
+#define PT_TAG_MEDIUM_DISTANCE 0x6d647374u
+#define PT_TAG_MEDIUM_PHASE 0x6d706873u
+PT_HD pt_f32x4 pt_draw4_tagged(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t tag) {
+    pt_u32x4 r = pt_philox4x32(pixel, sample, dim, tag, (uint32_t)seed, (uint32_t)(seed >> 32));
+    pt_f32x4 o; o.x = pt_u01(r.x); o.y = pt_u01(r.y); o.z = pt_u01(r.z); o.w = pt_u01(r.w);
+    return o;
+}
+
 /* Dimension-block layout of one camera sample (DESIGN.md "RNG dimensions"):
  *   block 0                : x,y = pixel jitter (tiled.rs:369), z = wavelength (pt.rs:406)
  *   blocks 1..16           : aperture rejection tries, two (x,y),(z,w) per block
@@ -240,6 +251,15 @@ PT_HD double pt_log64(double x) {
     p = p * z + 1.0;
     double fe = (double)e;
     return fe * 6.93147180369123816490e-01 + (2.0 * s * p + fe * 1.90821492927058770002e-10);
+}
+
+/* f32::ln and f32::cbrt for the mediums (hg.rs:98, rayleigh.rs:72-75, 104): through the f64 kernels, rounded once. */
+PT_HD float pt_ln(float x) { return (float)pt_log64((double)x); }
+PT_HD float pt_cbrt(float x) {
+    if (x != x || x == 0.0f) return x;
+    const double a = x < 0.0f ? -(double)x : (double)x;
+    const float r = (float)pt_exp64(pt_log64(a) / 3.0);
+    return x < 0.0f ? -r : r;
 }
 
 /* x^y for x >= 0 (the only use is |cos|^n, sharp_light.rs:202-204). */

@@ -551,6 +551,7 @@ struct Scene {
     std::vector<pt_curve> curves; std::vector<float> curve_data;
     std::vector<pt_texture_layer> layers; std::vector<pt_texstack> texstacks; std::vector<float> texture_data;
     std::vector<pt_material> materials; std::vector<int> metallic;
+    std::vector<pt_medium> mediums;
     std::vector<MeshData> meshes;
     std::vector<Instance> instances; std::vector<AABB> instance_aabbs; std::vector<FlatNode> bvh;
     std::vector<uint32_t> lights;
@@ -879,6 +880,9 @@ inline void ggx_transmission(float alpha, bool metallic, float eo, float ei, flo
 void material_bsdf(const Scene& s, uint32_t mat_index, float lambda, float u, float v, V3 wi, V3 wo, float* f_out, float* pdf_out) {
     const pt_material& m = s.materials[mat_index];
     switch (m.kind) {
+        case PT_MATERIAL_PASSTHROUGH:  // passthrough.rs:27-38: colour / |wo.z|, pdf 1, whatever wi is
+            *f_out = curve_at(s, m.curve_bounce, lambda) / std::fabs(wo.z); *pdf_out = 1.0f;
+            return;
         case PT_MATERIAL_LAMBERTIAN:  // lambertian.rs:16-33
             if (wo.z * wi.z > 0.0f) { *f_out = pt_min(texstack_eval(s, m.texstack, lambda, u, v), 1.0f) / PT_PI; *pdf_out = std::fabs(wo.z) / PT_PI; }
             else { *f_out = 0.0f; *pdf_out = 0.0f; }
@@ -923,6 +927,10 @@ void material_bsdf(const Scene& s, uint32_t mat_index, float lambda, float u, fl
 void material_generate_and_evaluate(const Scene& s, uint32_t mat_index, float lambda, float u, float v, float sx, float sy,
                                     V3 wi, float* f_out, V3* wo_out, float* pdf_out) {
     const pt_material& m = s.materials[mat_index];
+    if (m.kind == PT_MATERIAL_PASSTHROUGH) {  // passthrough.rs:55-68: straight through
+        *f_out = curve_at(s, m.curve_bounce, lambda) / std::fabs(wi.z); *wo_out = -wi; *pdf_out = 1.0f;
+        return;
+    }
     if (m.kind != PT_MATERIAL_GGX) {
         // lambertian.rs:50-66, diffuse_light.rs:60-76, sharp_light.rs:183-198
         V3 d = random_cosine_direction(sx, sy) * pt_signum(wi.z);
@@ -1204,9 +1212,9 @@ Ray camera_get_ray(const Camera& cam, const Sampler& smp, float u, float v) {
 
 // =============================================================== integrator
 enum VertexType { VT_EYE, VT_CAMERA, VT_LIGHT_INSTANCE, VT_LIGHT_ENV };
-struct SurfaceVertex {  // src/integrator/utils.rs:39-55
+struct SurfaceVertex {  // src/integrator/utils.rs:39-55; `medium`: the vertex is a Vertex::Medium (utils.rs:57-96, 640-706) of the medium-aware walk
     VertexType type; float lambda; V3 local_wi, point, normal; float u, v; uint32_t material_id, instance_id;
-    float throughput, pdf_forward;
+    float throughput, pdf_forward; bool medium = false;
 };
 struct RenderCtx {
     const Scene* scene; pt_render_desc rd; Camera camera;
@@ -1332,6 +1340,145 @@ void random_walk(const RenderCtx& ctx, Ray ray, float lambda, uint32_t bounce_li
     profile.bounce_rays += vertices.size();
 }
 
+// ================================================================= mediums (src/mediums; the medium-aware walk only)
+// phase_hg, hg.rs:5-15
+inline float phase_hg(float cos_theta, float g) {
+    float denom = 1.0f + g * g + 2.0f * g * cos_theta;
+    return (1.0f - g * g) / (denom * std::sqrt(denom) * 2.0f * (2.0f * PT_PI));
+}
+// Rayleigh::ior_factor / sigma_s, rayleigh.rs:24-40 (powi by repeated squaring)
+inline float rayleigh_sigma_s(const Scene& s, const pt_medium& m, float lambda) {
+    float n = curve_at(s, m.curve_ior, lambda), n2 = n * n;
+    float q = (n2 - 1.0f) / (n2 + 2.0f), ior_factor = q * q;
+    float r = 1.0f / (lambda / 1000.0f), r2 = r * r, lambda_factor = r2 * r2;
+    return ior_factor * m.corrective_factor * lambda_factor;
+}
+// Medium::tr: hg.rs:112-115 (sigma_a + sigma_s), rayleigh.rs:96-99
+inline float medium_tr(const Scene& s, const pt_medium& m, float lambda, V3 p0, V3 p1) {
+    float sigma = m.kind == PT_MEDIUM_HG ? curve_at(s, m.curve_sigma_a, lambda) + curve_at(s, m.curve_sigma_s, lambda) : rayleigh_sigma_s(s, m, lambda);
+    return pt_exp(-sigma * norm(p1 - p0));
+}
+// Medium::sample with ray.tmax = inf (every ray of the walk, Ray::new): the flight always ends in the medium.  hg.rs:96-111
+// returns tr, rayleigh.rs:100-113 tr * sigma_s.
+inline void medium_sample(const Scene& s, const pt_medium& m, float lambda, const Ray& ray, float x, V3* point, float* weight) {
+    float sigma_s = m.kind == PT_MEDIUM_HG ? curve_at(s, m.curve_sigma_s, lambda) : rayleigh_sigma_s(s, m, lambda);
+    float dist = -pt_ln(1.0f - x) / sigma_s;
+    *point = ray.origin + ray.direction * dist;
+    float tr = medium_tr(s, m, lambda, ray.origin, *point);
+    *weight = m.kind == PT_MEDIUM_HG ? tr : tr * sigma_s;
+}
+// Medium::sample_p: hg.rs:68-95, rayleigh.rs:57-95 (TangentFrame::from_normal(wi); the direction is not renormalised)
+inline V3 medium_sample_p(const Scene& s, const pt_medium& m, float lambda, V3 wi, float sx, float sy, float* pdf) {
+    Frame frame = frame_from_normal(wi);
+    float sn, cs;
+    if (m.kind == PT_MEDIUM_HG) {
+        float g = curve_at(s, m.curve_g, lambda) + 0.001f - 1.0f;
+        float cos_theta;
+        if (std::fabs(g) < 0.001f) cos_theta = 1.0f - 2.0f * sx;
+        else { float sqr = (1.0f - g * g) / (1.0f + g - 2.0f * g * sx); cos_theta = -(1.0f + g * g - sqr * sqr) / (2.0f * g); }
+        float sin_theta = std::sqrt(pt_max(0.0f, 1.0f - cos_theta * cos_theta));
+        pt_sincos((2.0f * PT_PI) * sy, &sn, &cs);
+        *pdf = phase_hg(cos_theta, g);
+        return to_world(frame, v3(sin_theta * cs, sin_theta * sn, cos_theta));
+    }
+    float x = sx; bool flipped = choose(x, 0.5f, true, false);
+    float z = 2.0f * (2.0f * x - 1.0f);
+    float right = std::sqrt(z * z + 1.0f);
+    float cos_theta = pt_cbrt(z + right) + pt_cbrt(z - right);
+    float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta) * (flipped ? 1.0f : -1.0f);
+    pt_sincos(sy * (2.0f * PT_PI), &sn, &cs);
+    *pdf = 3.0f * (1.0f + cos_theta * cos_theta) / 8.0f;
+    return to_world(frame, v3(sn * sin_theta, cs * sin_theta, cos_theta));
+}
+
+// random_walk_medium (TransportMode::Importance), src/integrator/utils.rs:708-1103.  The reference draws the free-flight and phase
+// samples from the thread RNG (Sample1D / Sample2D::new_random_sample, :773-778, :1036-1041); here they are counter-based like every
+// other dimension (pt_numerics.h PT_TAG_MEDIUM_*).  The list of tracked mediums holds at most four entries (a fifth is dropped).
+const uint32_t kMaxTrackedMediums = 4;
+void random_walk_medium(const RenderCtx& ctx, Ray ray, float lambda, uint32_t bounce_limit, float start_throughput,
+                        const Sampler& smp, std::vector<SurfaceVertex>& vertices, uint32_t rr_start, pt_profile& profile) {
+    const Scene& s = *ctx.scene;
+    float beta = start_throughput;
+    uint32_t tracked[kMaxTrackedMediums]; uint32_t n_tracked = 0;
+    auto remove_medium = [&](uint32_t id) { for (uint32_t i = 0; i < n_tracked; ++i) if (tracked[i] == id) { for (uint32_t j = i + 1; j < n_tracked; ++j) tracked[j - 1] = tracked[j]; --n_tracked; return; } };
+    auto add_medium = [&](uint32_t id) {  // push + sort_unstable (:965-968)
+        if (n_tracked == kMaxTrackedMediums) return;
+        uint32_t i = n_tracked++;
+        while (i > 0 && tracked[i - 1] > id) { tracked[i] = tracked[i - 1]; --i; }
+        tracked[i] = id;
+    };
+    for (uint32_t bounce = 0; bounce < bounce_limit; ++bounce) {
+        HitRecord hit;
+        if (world_hit(s, ray, 0.0f, ray.tmax, &hit)) {
+            hit.lambda = lambda;
+            SurfaceVertex vertex;   // :733-749: throughput is beta BEFORE this segment's attenuation
+            vertex.type = VT_EYE; vertex.lambda = lambda; vertex.local_wi = -ray.direction; vertex.point = hit.point; vertex.normal = hit.normal;
+            vertex.u = hit.u; vertex.v = hit.v; vertex.material_id = hit.material; vertex.instance_id = hit.instance_id;
+            vertex.throughput = beta; vertex.pdf_forward = 1.0f;
+            // the nearest scattering event of the tracked mediums in front of the hit (:766-793)
+            float medium_time = hit.time; V3 medium_point = hit.point; uint32_t medium_id = 0;
+            float hero_weight = 1.0f, hero_tr = 1.0f;
+            pt_f32x4 fd = pt_draw4_tagged(smp.seed, smp.pixel, smp.sample, bounce, PT_TAG_MEDIUM_DISTANCE);
+            const float flight[4] = {fd.x, fd.y, fd.z, fd.w};
+            for (uint32_t k = 0; k < n_tracked; ++k) {
+                const pt_medium& m = s.mediums[tracked[k] - 1];
+                V3 p; float tr;
+                medium_sample(s, m, lambda, ray, flight[k], &p, &tr);
+                float t = norm(p - ray.origin);
+                if (t < medium_time) { medium_time = t; medium_point = p; hero_weight = tr; hero_tr = medium_tr(s, m, lambda, ray.origin, p); medium_id = tracked[k]; }
+            }
+            beta *= hero_weight;
+            float combined = 1.0f;
+            for (uint32_t k = 0; k < n_tracked; ++k) combined *= medium_tr(s, s.mediums[tracked[k] - 1], lambda, ray.origin, medium_point);
+            beta *= combined / hero_tr;
+            if (medium_id == 0) {
+                Frame frame = frame_from_normal(hit.normal);
+                V3 wi = normalized(to_local(frame, -ray.direction));
+                if (PT_MATERIAL_TAG(hit.material) == PT_TAG_CAMERA) break;
+                const uint32_t mat = PT_MATERIAL_INDEX(hit.material);
+                const pt_material& material = s.materials[mat];
+                pt_f32x4 r = smp.bounce(bounce);
+                float f0, pdf0; V3 wo;   // Material::generate = the direction of generate_and_evaluate (materials/mod.rs:76-86; passthrough.rs:39-48)
+                material_generate_and_evaluate(s, mat, lambda, hit.u, hit.v, r.x, r.y, wi, &f0, &wo, &pdf0);
+                float f, pdf;
+                material_bsdf(s, mat, lambda, hit.u, hit.v, wi, wo, &f, &pdf);
+                float cos_i = std::fabs(wo.z);
+                if (pdf == 0.0f || pt_isnan(pdf)) break;                      // :858-860: the vertex is never pushed
+                float rr_continue_prob = (bounce >= rr_start) ? pt_min(f / pdf, 1.0f) : 1.0f;
+                if (r.z > rr_continue_prob) break;                             // :866-869: nor here
+                beta *= f * std::fabs(cos_i) * (1.0f / (rr_continue_prob * pdf));
+                vertex.pdf_forward = pdf * (rr_continue_prob / cos_i);
+                vertices.push_back(vertex);
+                // medium transitions (:925-991): only on transmission through a boundary whose two sides differ
+                uint32_t outer = (uint32_t)material.outer_medium, inner = (uint32_t)material.inner_medium;
+                if (!(wi.z * wo.z > 0.0f) && inner != outer) {
+                    if (wo.z < 0.0f) { if (outer != 0) remove_medium(outer); if (inner != 0) add_medium(inner); }
+                    else { if (inner != 0) remove_medium(inner); if (outer != 0) add_medium(outer); }
+                }
+                ray = ray_new(hit.point + hit.normal * 0.001f * (wo.z > 0.0f ? 1.0f : -1.0f), normalized(to_world(frame, wo)));
+            } else {
+                // Vertex::Medium (:1031-1066): the phase function picks the new direction; beta is left alone
+                vertex.medium = true; vertex.point = medium_point; vertex.material_id = medium_id;
+                pt_f32x4 ph = pt_draw4_tagged(smp.seed, smp.pixel, smp.sample, bounce, PT_TAG_MEDIUM_PHASE);
+                float phase;
+                V3 wo = medium_sample_p(s, s.mediums[medium_id - 1], lambda, -ray.direction, ph.x, ph.y, &phase);
+                vertex.pdf_forward = phase;
+                vertices.push_back(vertex);
+                ray = ray_new(medium_point, wo);
+            }
+        } else {
+            SurfaceVertex vertex;   // :1069-1096
+            vertex.type = VT_LIGHT_ENV; vertex.lambda = lambda; vertex.local_wi = ray.direction;
+            vertex.point = ray.direction * s.radius; vertex.normal = ray.direction; vertex.u = 0; vertex.v = 0;
+            vertex.material_id = PT_MATERIAL_ID(PT_TAG_LIGHT, 0); vertex.instance_id = 0;
+            vertex.throughput = beta; vertex.pdf_forward = 0.0f;
+            vertices.push_back(vertex);
+            break;
+        }
+    }
+    profile.bounce_rays += vertices.size();
+}
+
 // PathTracingIntegrator::color, src/integrator/pt.rs:397-615.  Returns (energy, lambda); XYZ conversion by the caller.
 void color(const RenderCtx& ctx, const Sampler& smp, float cam_u, float cam_v, pt_profile& profile, float* lambda_out, float* energy_out) {
     const Scene& s = *ctx.scene;
@@ -1350,11 +1497,17 @@ void color(const RenderCtx& ctx, const Sampler& smp, float cam_u, float cam_v, p
     first.normal = camera_ray.direction; first.u = 0; first.v = 0; first.material_id = PT_MATERIAL_ID(PT_TAG_CAMERA, 0);
     first.instance_id = 0; first.throughput = throughput_and_pdf; first.pdf_forward = 100.0f;
     path.push_back(first);
-    random_walk(ctx, camera_ray, lambda, max_bounces, throughput_and_pdf, smp, path, ctx.rd.min_bounces, profile);
+    if (ctx.rd.medium_aware) random_walk_medium(ctx, camera_ray, lambda, max_bounces, throughput_and_pdf, smp, path, ctx.rd.min_bounces, profile);   // pt.rs:447-461
+    else random_walk(ctx, camera_ray, lambda, max_bounces, throughput_and_pdf, smp, path, ctx.rd.min_bounces, profile);
     for (size_t index = 1; index < path.size(); ++index) {
         const SurfaceVertex& prev_vertex = path[index - 1];
         const SurfaceVertex& vertex = path[index];
         uint32_t bounce = (uint32_t)index - 1;
+        if (prev_vertex.medium || vertex.medium) continue;   // pt.rs:606-611: only (Surface, Surface) pairs are looked at
+        // random_walk_medium never tags a vertex LightSource(Instance) (a light scatters like any surface, utils.rs:818-821), so the
+        // reference reaches its `panic!("material should not be emissive")` (pt.rs:575-582) at every light vertex whose emitting side
+        // faces the previous vertex; here such a vertex contributes nothing and takes no light samples (deliberate deviation).
+        if (ctx.rd.medium_aware && vertex.type != VT_LIGHT_ENV && PT_MATERIAL_TAG(vertex.material_id) == PT_TAG_LIGHT) continue;
         if (vertex.type == VT_LIGHT_ENV) {
             V3 wo = vertex.normal;
             float u = 0.0f, v = 0.0f;
@@ -1627,6 +1780,7 @@ pt_status ptref_scene_create(const pt_scene_desc* d, pt_scene** out) {
     s.texstacks.assign(d->texstacks, d->texstacks + d->texstack_count);
     s.texture_data.assign(d->texture_data, d->texture_data + d->texture_data_count);
     s.materials.assign(d->materials, d->materials + d->material_count);
+    if (d->medium_count) s.mediums.assign(d->mediums, d->mediums + d->medium_count);
     s.cameras.assign(d->cameras, d->cameras + d->camera_count);
     s.env = d->environment; s.env_sampling_probability = d->env_sampling_probability;
     // GGX::new: metallic = kappa.evaluate_integral(BOUNDED_VISIBLE_RANGE, 100, false) > 0 (ggx.rs:205)
@@ -1854,6 +2008,26 @@ void ptref_generate_tiles(uint32_t w, uint32_t h, uint32_t tw, uint32_t th, uint
     std::vector<TileRect> t = generate_tiles(w, h, tw, th);
     if (out_xyxy) for (size_t i = 0; i < t.size(); ++i) { out_xyxy[4 * i] = t[i].x0; out_xyxy[4 * i + 1] = t[i].x1; out_xyxy[4 * i + 2] = t[i].y0; out_xyxy[4 * i + 3] = t[i].y1; }
     *count = (uint32_t)t.size();
+}
+// Test hook: Medium::sample_p of a homogeneous medium whose curves are constants (kind PT_MEDIUM_*; g_stored = the library's g + 1), and the
+// phase function / free flight pieces: out = (wo.xyz, pdf) per sample; flight[i] = the sampled distance and its weight for sigma_s, sigma_a.
+void ptref_medium_sample_p(int kind, float g_stored, size_t n, const float* wi, const float* s2, float* wo, float* pdf) {
+    Scene s;
+    pt_curve c; c.kind = PT_CURVE_CONST; c.mode = 0; c.p0 = g_stored; c.p1 = 0.0f; c.data_offset = 0; c.data_count = 0;
+    s.curves.push_back(c);
+    pt_medium m; std::memset(&m, 0, sizeof(m)); m.kind = kind; m.curve_g = m.curve_sigma_a = m.curve_sigma_s = m.curve_ior = 0; m.corrective_factor = 1.0f;
+    for (size_t i = 0; i < n; ++i) {
+        V3 w = medium_sample_p(s, m, 550.0f, v3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), s2[2 * i], s2[2 * i + 1], &pdf[i]);
+        wo[3 * i] = w.x; wo[3 * i + 1] = w.y; wo[3 * i + 2] = w.z;
+    }
+}
+void ptref_medium_flight(float sigma_s, float sigma_a, size_t n, const float* x, float* distance, float* weight) {
+    Scene s;
+    pt_curve c; c.kind = PT_CURVE_CONST; c.mode = 0; c.p1 = 0.0f; c.data_offset = 0; c.data_count = 0;
+    c.p0 = sigma_s; s.curves.push_back(c); c.p0 = sigma_a; s.curves.push_back(c);
+    pt_medium m; std::memset(&m, 0, sizeof(m)); m.kind = PT_MEDIUM_HG; m.curve_sigma_s = 0; m.curve_sigma_a = 1; m.curve_g = 0;
+    Ray ray = ray_new(v3(0, 0, 0), v3(0, 0, 1));
+    for (size_t i = 0; i < n; ++i) { V3 p; medium_sample(s, m, 550.0f, ray, x[i], &p, &weight[i]); distance[i] = p.z; }
 }
 void ptref_xyz_bar(float lambda_nm, float* xyz) { float a = lambda_nm * 10.0f; xyz[0] = x_bar(a); xyz[1] = y_bar(a); xyz[2] = z_bar(a); }
 void ptref_numerics(int which, size_t n, const float* x, const float* y, float* out) {

@@ -14,7 +14,8 @@ MATERIAL_NONE = 0xFFFFFFFF
 CURVE_LINEAR, CURVE_TABULATED, CURVE_CAUCHY, CURVE_EXPONENTIAL, CURVE_INV_EXPONENTIAL, CURVE_BLACKBODY, CURVE_CONST = range(7)
 INTERP_LINEAR, INTERP_NEAREST, INTERP_CUBIC = range(3)
 TEXTURE1, TEXTURE4 = 1, 4
-MATERIAL_LAMBERTIAN, MATERIAL_GGX, MATERIAL_DIFFUSE_LIGHT, MATERIAL_SHARP_LIGHT = range(4)
+MATERIAL_LAMBERTIAN, MATERIAL_GGX, MATERIAL_DIFFUSE_LIGHT, MATERIAL_SHARP_LIGHT, MATERIAL_PASSTHROUGH = range(5)
+MEDIUM_HG, MEDIUM_RAYLEIGH = range(2)
 SIDED_FORWARD, SIDED_REVERSE, SIDED_DUAL = range(3)
 SHAPE_RECT, SHAPE_SPHERE, SHAPE_DISK, SHAPE_MESH = range(4)
 AXIS_X, AXIS_Y, AXIS_Z = range(3)
@@ -43,7 +44,12 @@ class Material(C.Structure):
     _fields_ = [("kind", C.c_int32), ("texstack", C.c_int32), ("alpha", C.c_float),
                 ("curve_eta", C.c_int32), ("curve_eta_o", C.c_int32), ("curve_kappa", C.c_int32),
                 ("curve_emit", C.c_int32), ("curve_bounce", C.c_int32), ("sharpness", C.c_float),
-                ("sidedness", C.c_int32)]
+                ("sidedness", C.c_int32), ("outer_medium", C.c_int32), ("inner_medium", C.c_int32)]
+
+
+class Medium(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("curve_g", C.c_int32), ("curve_sigma_a", C.c_int32), ("curve_sigma_s", C.c_int32),
+                ("curve_ior", C.c_int32), ("corrective_factor", C.c_float)]
 
 
 class Mesh(C.Structure):
@@ -90,6 +96,7 @@ class SceneDesc(C.Structure):
         ("camera_count", C.c_uint32), ("cameras", C.POINTER(Camera)),
         ("environment", Environment),
         ("env_sampling_probability", C.c_float),
+        ("medium_count", C.c_uint32), ("mediums", C.POINTER(Medium)),
     ]
 
 
@@ -99,7 +106,8 @@ class RenderDesc(C.Structure):
                 ("wavelength_lo", C.c_float), ("wavelength_hi", C.c_float), ("camera_index", C.c_uint32),
                 ("seed", C.c_uint64), ("tile_width", C.c_uint32), ("tile_height", C.c_uint32),
                 ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("hero_wavelengths", C.c_uint32),
-                ("first_sample", C.c_uint32), ("sample_count", C.c_uint32), ("phase_samples", C.c_uint32)]
+                ("first_sample", C.c_uint32), ("sample_count", C.c_uint32), ("phase_samples", C.c_uint32),
+                ("medium_aware", C.c_uint32)]
 
 
 class Profile(C.Structure):
@@ -159,10 +167,10 @@ def _fp(a):
 
 def render_desc(width, height, spp, max_bounces, min_bounces=1, light_samples=2, only_direct=False,
                 wavelength=(380.0, 750.0), camera_index=0, seed=1, tile=(32, 32), shard=(0, 0),
-                hero_wavelengths=1, first_sample=0, sample_count=0, phase_samples=0):
+                hero_wavelengths=1, first_sample=0, sample_count=0, phase_samples=0, medium_aware=False):
     return RenderDesc(width, height, spp, min_bounces, max_bounces, light_samples, int(bool(only_direct)),
                       wavelength[0], wavelength[1], camera_index, seed, tile[0], tile[1], shard[0], shard[1],
-                      hero_wavelengths, first_sample, sample_count, phase_samples)
+                      hero_wavelengths, first_sample, sample_count, phase_samples, int(bool(medium_aware)))
 
 
 class Library:

@@ -277,6 +277,7 @@ struct pt_scene_file {
     std::vector<pt_curve> curves; std::vector<float> curve_data;
     std::vector<pt_texture_layer> layers; std::vector<pt_texstack> texstacks; std::vector<float> texture_data;
     std::vector<pt_material> materials;
+    std::vector<pt_medium> mediums; std::map<std::string, int> medium_ids;   // MediumId = position in the library + 1 (0 = vacuum)
     std::vector<pt_mesh> meshes; std::vector<float> vertices; std::vector<uint32_t> indices; std::vector<float> normals; std::vector<uint32_t> face_materials;
     std::vector<pt_instance> instances;
     std::vector<pt_camera> cameras;
@@ -384,7 +385,10 @@ struct Loader {
             if (ok) m.curve_eta_o = curve_ref(f.req("eta_o"), ctx + ".eta_o", &ok); else f.req("eta_o");
             if (ok) m.curve_kappa = curve_ref(f.req("kappa"), ctx + ".kappa", &ok); else f.req("kappa");
             f.f32("permeability");
-            if (f.has("inner_medium_id") || f.has("outer_medium_id")) sf.warn(ctx + ": medium ids are ignored (mediums are not on the PT path)");
+            // material.rs:86-91: an unknown or missing name is the vacuum
+            auto medium_of = [&](const char* key) { const toml::Value* v2 = f.opt(key); if (!v2) return 0; if (v2->kind != toml::Value::String) fail(ctx + "." + key + ": expected a string");
+                                                    auto it = sf.medium_ids.find(v2->s); return it == sf.medium_ids.end() ? 0 : it->second; };
+            m.outer_medium = medium_of("outer_medium_id"); m.inner_medium = medium_of("inner_medium_id");
         } else if (type == "DiffuseLight" || type == "SharpLight") {
             light = true;
             m.kind = type == "DiffuseLight" ? PT_MATERIAL_DIFFUSE_LIGHT : PT_MATERIAL_SHARP_LIGHT;
@@ -416,6 +420,7 @@ void build_desc(pt_scene_file& sf) {
     d.face_material_count = sf.face_materials.size(); d.face_materials = sf.face_materials.data();
     d.instance_count = (uint32_t)sf.instances.size(); d.instances = sf.instances.data();
     d.camera_count = (uint32_t)sf.cameras.size(); d.cameras = sf.cameras.data();
+    d.medium_count = (uint32_t)sf.mediums.size(); d.mediums = sf.mediums.empty() ? nullptr : sf.mediums.data();
 }
 
 void load_scene(const std::string& path, const pt_config* config, pt_scene_file& sf) {
@@ -424,7 +429,11 @@ void load_scene(const std::string& path, const pt_config* config, pt_scene_file&
     memset(&sf.desc, 0, sizeof(sf.desc));
     Loader L{sf, config, resolve_lib(top.req("curves"), "curves"), resolve_lib(top.req("textures"), "textures"),
              resolve_lib(top.req("materials"), "materials"), resolve_lib(top.req("meshes"), "meshes")};
-    if (top.has("mediums")) sf.warn("mediums are not on the PT path and are ignored");
+    // mediums (mod.rs:389-419, medium.rs): every entry of the library, in file order.  The reference numbers them from 0 in HashMap order while
+    // its walk reads id 0 as the vacuum and id k as mediums[k - 1] (utils.rs:768-770), so a material there tracks the medium BEFORE the one
+    // it names; here a name means its own medium: id = position + 1.
+    std::vector<std::pair<std::string, toml::Value>> medium_entries;
+    if (const toml::Value* mv = top.opt("mediums")) { Lib ml = resolve_lib(*mv, "mediums"); medium_entries = ml.table()->items; }
     sf.desc.env_sampling_probability = top.f32_or("env_sampling_probability", 0.5f);  // mod.rs:559
     const toml::Value& instances = top.req("instances");
     const toml::Value& cameras = top.req("cameras");
@@ -441,6 +450,25 @@ void load_scene(const std::string& path, const pt_config* config, pt_scene_file&
         sf.curve_names["__mauve"] = m.curve_emit;
         sf.materials.push_back(m);
         sf.material_ids["error"] = PT_MATERIAL_ID(PT_TAG_LIGHT, 0);
+    }
+
+    for (auto& kv : medium_entries) {
+        const std::string ctx = "mediums." + kv.first;
+        Fields f(kv.second, ctx);
+        const std::string type = f.str("type");
+        pt_medium m; memset(&m, 0, sizeof(m));
+        m.curve_g = m.curve_sigma_a = m.curve_sigma_s = m.curve_ior = -1;
+        if (type == "HG") {
+            m.kind = PT_MEDIUM_HG;
+            m.curve_g = L.curve_ref(f.req("g"), ctx + ".g"); m.curve_sigma_s = L.curve_ref(f.req("sigma_s"), ctx + ".sigma_s"); m.curve_sigma_a = L.curve_ref(f.req("sigma_a"), ctx + ".sigma_a");
+        } else if (type == "Rayleigh") {
+            m.kind = PT_MEDIUM_RAYLEIGH;
+            m.curve_ior = L.curve_ref(f.req("ior"), ctx + ".ior"); m.corrective_factor = f.f32("corrective_factor");
+        } else fail(ctx + ": unknown variant `" + type + "`");
+        f.done();
+        if (sf.mediums.size() >= 255) fail("more than 255 mediums");
+        sf.mediums.push_back(m);
+        sf.medium_ids[kv.first] = (int)sf.mediums.size();
     }
 
     // ---- scan: which materials and meshes the instances use (mod.rs:192-262)
@@ -803,7 +831,7 @@ pt_status pt_config_render_desc(const pt_config* c, uint32_t i, uint64_t seed, p
     if (!c || !out || i >= c->settings.size()) { g_error = "render settings index out of range"; return PT_ERR_INVALID_ARGUMENT; }
     const pt_render_settings& s = c->settings[i]->s;
     if (s.integrator != PT_INTEGRATOR_PT) { g_error = "only the PT integrator is on this path"; return PT_ERR_UNSUPPORTED; }
-    if (s.medium_aware) { g_error = "medium_aware path tracing is not on this path"; return PT_ERR_UNSUPPORTED; }
+
     if (s.max_bounces < 0) { g_error = "max_bounces is required (the reference unwrap()s it, src/integrator/mod.rs:97)"; return PT_ERR_INVALID_ARGUMENT; }
     memset(out, 0, sizeof(*out));
     out->width = s.width; out->height = s.height; out->spp = s.min_samples;
@@ -819,6 +847,7 @@ pt_status pt_config_render_desc(const pt_config* c, uint32_t i, uint64_t seed, p
     else {  // NaiveRenderer (src/renderer/naive.rs:67-103): pixels in row-major order, all samples summed, one division
         out->tile_width = s.width; out->tile_height = s.height; out->phase_samples = s.min_samples;
     }
+    out->medium_aware = s.medium_aware ? 1u : 0u;   // random_walk_medium (src/integrator/pt.rs:447)
     // `hwss` is parsed by the reference (src/parsing/config.rs:51) and read by nothing on the PT path: a no-op here too.  The engine's
     // hero-wavelength variant is asked for explicitly (pt_render_desc.hero_wavelengths; ptcli --hero-wavelengths 4).
     out->hero_wavelengths = 1u;

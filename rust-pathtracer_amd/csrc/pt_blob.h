@@ -69,14 +69,26 @@
 #define PT_MAT_SHARPNESS 8   /* already 1 + |s| */
 #define PT_MAT_SIDEDNESS 9
 #define PT_MAT_METALLIC 10
+#define PT_MAT_MEDIUMS 11    /* outer medium id | inner medium id << 8 (MediumId: 0 = vacuum, k = medium record k - 1) */
+
+// Medium record (8 words): kind, curve record offsets of g / sigma_a / sigma_s (HG) and of the ior (Rayleigh), corrective factor, pad, pad
+#define PT_MEDIUM_WORDS 8
+#define PT_MED_KIND 0
+#define PT_MED_G 1
+#define PT_MED_SIGMA_A 2
+#define PT_MED_SIGMA_S 3
+#define PT_MED_IOR 4
+#define PT_MED_CORRECTIVE 5
 
 // Curve record (8 words): kind, mode, p0, p1, data_off (word offset), data_count, pad, pad
 #define PT_CURVE_WORDS 8
 // Texstack record: layer_count, then per layer 8 words: kind, curve0..3 (word offsets), width, height, texel offset (floats, into texture memory)
 #define PT_LAYER_WORDS 8
 
-// Header (64 words)
-#define PT_HDR_WORDS 64
+// Header (72 words)
+#define PT_HDR_WORDS 72
+#define PT_HDR_MEDIUM_OFF 64       /* medium records (0 = none) */
+#define PT_HDR_MEDIUM_COUNT 65
 #define PT_HDR_MAGIC 0
 #define PT_HDR_TOTAL_WORDS 1
 #define PT_HDR_TOP_NODE_OFF 2

@@ -1345,6 +1345,7 @@ PT_HD MatEval material_prepare(const SceneView& s, uint32_t m, float lambda, flo
     MatEval e;
     e.kind = bu(s, m + PT_MAT_KIND); e.metallic = false; e.alpha = 0.0f; e.refl = 0.0f; e.ei = e.eo = e.kappa = 0.0f;
     if (e.kind == PT_MATERIAL_LAMBERTIAN) e.refl = pt_min(texstack_eval(s, bu(s, m + PT_MAT_TEXSTACK), lambda, u, v), 1.0f);
+    else if (GGX && e.kind == PT_MATERIAL_PASSTHROUGH) e.refl = curve_eval(s, bu(s, m + PT_MAT_BOUNCE), lambda);   // PassthroughFilter::color, unclamped (passthrough.rs:36)
     else if (!GGX || e.kind != PT_MATERIAL_GGX) e.refl = pt_clamp(curve_eval(s, bu(s, m + PT_MAT_BOUNCE), lambda), 0.0f, 1.0f);
     else {
         e.alpha = bf(s, m + PT_MAT_ALPHA);
@@ -1358,6 +1359,7 @@ PT_HD MatEval material_prepare(const SceneView& s, uint32_t m, float lambda, flo
 // Material::bsdf (lambertian.rs:16-33, diffuse_light.rs:29-45, sharp_light.rs:43-60, ggx.rs:256-400)
 template <bool GGX = true>
 PT_HD void material_bsdf_p(const MatEval& e, F3 wi, F3 wo, float* f_out, float* pdf_out) {
+    if (GGX && e.kind == PT_MATERIAL_PASSTHROUGH) { *f_out = e.refl / pt_abs(wo.z); *pdf_out = 1.0f; return; }   // passthrough.rs:27-38 (the GGX-free kernel forms never see one)
     if (!GGX || e.kind != PT_MATERIAL_GGX) {
         if (wo.z * wi.z > 0.0f) { *f_out = e.refl / PT_PI; *pdf_out = pt_abs(wo.z) / PT_PI; }
         else { *f_out = 0.0f; *pdf_out = 0.0f; }
@@ -1392,6 +1394,7 @@ PT_HD void material_bsdf_p(const MatEval& e, F3 wi, F3 wo, float* f_out, float* 
 // Material::generate_and_evaluate (lambertian.rs:50-66, diffuse_light.rs:60-76, sharp_light.rs:183-198, ggx.rs:401-590)
 template <bool GGX = true>
 PT_HD void material_sample_p(const MatEval& e, float sx, float sy, F3 wi, float* f_out, F3* wo_out, float* pdf_out) {
+    if (GGX && e.kind == PT_MATERIAL_PASSTHROUGH) { *f_out = e.refl / pt_abs(wi.z); *wo_out = neg(wi); *pdf_out = 1.0f; return; }   // passthrough.rs:55-68
     if (!GGX || e.kind != PT_MATERIAL_GGX) {
         F3 d = mul(random_cosine_direction(sx, sy), pt_signum(wi.z));
         *f_out = e.refl / PT_PI; *wo_out = d; *pdf_out = pt_abs(d.z) / PT_PI;
@@ -1454,6 +1457,76 @@ PT_HD float material_emission(const SceneView& s, uint32_t m, float lambda, F3 w
 }
 PT_HD uint32_t material_record(const SceneView& s, uint32_t material_id) {
     return bu(s, PT_HDR_MATERIAL_OFF) + PT_MATERIAL_INDEX(material_id) * PT_MAT_WORDS;
+}
+
+// ---------------------------------------------------------------- participating media (src/mediums; the medium-aware walk only)
+PT_HD float phase_hg(float cos_theta, float g) {   // hg.rs:5-15
+    float denom = 1.0f + g * g + 2.0f * g * cos_theta;
+    return (1.0f - g * g) / (denom * pt_sqrt(denom) * 2.0f * (2.0f * PT_PI));
+}
+PT_HD float rayleigh_sigma_s(const SceneView& s, uint32_t m, float lambda) {   // rayleigh.rs:24-40
+    float n = curve_eval(s, bu(s, m + PT_MED_IOR), lambda), n2 = n * n;
+    float q = (n2 - 1.0f) / (n2 + 2.0f), ior_factor = q * q;
+    float r = 1.0f / (lambda / 1000.0f), r2 = r * r, lambda_factor = r2 * r2;
+    return ior_factor * bf(s, m + PT_MED_CORRECTIVE) * lambda_factor;
+}
+PT_HD uint32_t medium_record(const SceneView& s, uint32_t medium_id) { return bu(s, PT_HDR_MEDIUM_OFF) + (medium_id - 1u) * PT_MEDIUM_WORDS; }
+// The wavelength-only part of a medium, evaluated once per vertex: sigma_s (free flight), sigma_t (transmittance), g
+struct MediumEval { uint32_t kind; float sigma_s, sigma_t, g; };
+PT_HD MediumEval medium_prepare(const SceneView& s, uint32_t m, float lambda) {
+    MediumEval e; e.kind = bu(s, m + PT_MED_KIND); e.g = 0.0f;
+    if (e.kind == PT_MEDIUM_HG) {
+        e.sigma_s = curve_eval(s, bu(s, m + PT_MED_SIGMA_S), lambda);
+        e.sigma_t = curve_eval(s, bu(s, m + PT_MED_SIGMA_A), lambda) + e.sigma_s;   // hg.rs:35-37
+        e.g = curve_eval(s, bu(s, m + PT_MED_G), lambda) + 0.001f - 1.0f;         // hg.rs:69
+    } else { e.sigma_s = rayleigh_sigma_s(s, m, lambda); e.sigma_t = e.sigma_s; }
+    return e;
+}
+PT_HD float medium_tr(const MediumEval& e, F3 p0, F3 p1) { return pt_exp(-e.sigma_t * norm(sub(p1, p0))); }   // hg.rs:112-115, rayleigh.rs:96-99
+// Medium::sample with tmax = inf: hg.rs:96-111 (weight tr), rayleigh.rs:100-113 (weight tr * sigma_s)
+PT_HD void medium_sample(const MediumEval& e, F3 o, F3 d, float x, F3* point, float* weight) {
+    float dist = -pt_ln(1.0f - x) / e.sigma_s;
+    *point = add(o, mul(d, dist));
+    float tr = medium_tr(e, o, *point);
+    *weight = e.kind == PT_MEDIUM_HG ? tr : tr * e.sigma_s;
+}
+// Medium::sample_p: hg.rs:68-95, rayleigh.rs:57-95
+PT_HD F3 medium_sample_p(const MediumEval& e, F3 wi, float sx, float sy, float* pdf) {
+    Frame frame = frame_from_normal(wi);
+    float sn, cs;
+    if (e.kind == PT_MEDIUM_HG) {
+        float g = e.g, cos_theta;
+        if (pt_abs(g) < 0.001f) cos_theta = 1.0f - 2.0f * sx;
+        else { float sqr = (1.0f - g * g) / (1.0f + g - 2.0f * g * sx); cos_theta = -(1.0f + g * g - sqr * sqr) / (2.0f * g); }
+        float sin_theta = pt_sqrt(pt_max(0.0f, 1.0f - cos_theta * cos_theta));
+        pt_sincos((2.0f * PT_PI) * sy, &sn, &cs);
+        *pdf = phase_hg(cos_theta, g);
+        return to_world(frame, f3(sin_theta * cs, sin_theta * sn, cos_theta));
+    }
+    float x = sx; bool flipped = choose_first(&x, 0.5f);
+    float z = 2.0f * (2.0f * x - 1.0f);
+    float right = pt_sqrt(z * z + 1.0f);
+    float cos_theta = pt_cbrt(z + right) + pt_cbrt(z - right);
+    float sin_theta = pt_sqrt(1.0f - cos_theta * cos_theta) * (flipped ? 1.0f : -1.0f);
+    pt_sincos(sy * (2.0f * PT_PI), &sn, &cs);
+    *pdf = 3.0f * (1.0f + cos_theta * cos_theta) / 8.0f;
+    return to_world(frame, f3(sn * sin_theta, cs * sin_theta, cos_theta));
+}
+// The list of tracked mediums (utils.rs:731): at most four ids in one word, ascending, zero bytes behind them
+PT_HD uint32_t mediums_remove(uint32_t list, uint32_t id) {   // the first occurrence (:944-951)
+    for (uint32_t i = 0; i < 4u; ++i)
+        if (((list >> (8u * i)) & 0xffu) == id) {
+            const uint32_t low = list & ((1u << (8u * i)) - 1u), high = i == 3u ? 0u : (list >> (8u * (i + 1u))) << (8u * i);
+            return low | high;
+        }
+    return list;
+}
+PT_HD uint32_t mediums_add(uint32_t list, uint32_t id) {      // push + sort_unstable (:965-968); a fifth entry is dropped
+    if ((list >> 24) != 0u) return list;
+    uint32_t i = 0;
+    while (i < 4u && ((list >> (8u * i)) & 0xffu) != 0u && ((list >> (8u * i)) & 0xffu) <= id) ++i;
+    const uint32_t low = list & ((1u << (8u * i)) - 1u), high = i == 3u ? 0u : (list >> (8u * i)) << (8u * (i + 1u));
+    return low | id << (8u * i) | high;
 }
 
 // ---------------------------------------------------------------- light sampling (Hittable::sample / psa_pdf)

@@ -206,7 +206,8 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     { const uint32_t phase = rd.sample_count < rd.phase_samples ? rd.sample_count : rd.phase_samples; if (capacity < phase) capacity = phase; }
     const bool hero = rd.hero_wavelengths == 4;
     if (hero && capacity > (1u << 26)) capacity = 1u << 26;  // 4-wavelength queues are ~1.5x wider: 64 Mi slots ~ 24 GB
-    pt_status st = ensure_buffers(sc, capacity, rd.light_samples, pixels.size() ? pixels.size() : 1, grid, hero ? 4u : 1u);
+    // (the medium-aware walk keeps its two extra path fields where the hero layout keeps the passengers' throughputs)
+    pt_status st = ensure_buffers(sc, capacity, rd.light_samples, pixels.size() ? pixels.size() : 1, grid, (hero || rd.medium_aware) ? 4u : 1u);
     if (st != PT_OK) return st;
     DeviceBuffers& b = sc->buf;
     if (!pixels.empty()) HIP_TRY(hipMemcpyAsync(b.pixels, pixels.data(), sizeof(uint32_t) * pixels.size(), hipMemcpyHostToDevice, stream));
@@ -247,8 +248,13 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     // light samples can pick the environment only if env_sampling_probability > 0: otherwise k_shade is the form without that branch
     float env_prob; std::memcpy(&env_prob, &sc->host.blob[PT_HDR_ENV_PROB], sizeof env_prob);
     bool has_ggx = false;
-    for (uint32_t i = 0; i < sc->host.blob[PT_HDR_MATERIAL_COUNT]; ++i) has_ggx = has_ggx || sc->host.blob[sc->host.blob[PT_HDR_MATERIAL_OFF] + i * PT_MAT_WORDS + PT_MAT_KIND] == PT_MATERIAL_GGX;
-    const int shade_form = (env_prob != 0.0f || env_u32("PT_AMD_SHADE_FORM", 0) == 2) ? PT_SHADE_FULL : (has_ggx || env_u32("PT_AMD_SHADE_FORM", 0) == 1) ? PT_SHADE_NO_ENV : PT_SHADE_LEAN;
+    for (uint32_t i = 0; i < sc->host.blob[PT_HDR_MATERIAL_COUNT]; ++i) {
+        const uint32_t kind = sc->host.blob[sc->host.blob[PT_HDR_MATERIAL_OFF] + i * PT_MAT_WORDS + PT_MAT_KIND];
+        has_ggx = has_ggx || kind == PT_MATERIAL_GGX || kind == PT_MATERIAL_PASSTHROUGH;
+    }
+    // (a PassthroughFilter lives in the forms that hold the GGX code)
+    const int shade_form = rd.medium_aware ? PT_SHADE_MEDIUM
+                         : (env_prob != 0.0f || env_u32("PT_AMD_SHADE_FORM", 0) == 2) ? PT_SHADE_FULL : (has_ggx || env_u32("PT_AMD_SHADE_FORM", 0) == 1) ? PT_SHADE_NO_ENV : PT_SHADE_LEAN;
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
     const bool timing = env_u32("PT_AMD_STAGE_TIMING", 1) != 0;
     double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0};
@@ -299,7 +305,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
             if (park_dynamic) cfg.unit_counter = b.unit_counters + 2 * bounce + 1;
             timed(ST_SHADE, [&] { launch_shade(cfg, hero ? 4 : 1, shade_form, sargs, rp, bounce, d_px, qin, qh, qout, qs, b.energy, seg_cap, cin, cout, nshadow, b.block_stats); });
             if (rd.light_samples > 0)   // (shade_form FULL = the scene can produce environment rays)
-                timed(ST_SHADOW, [&] { launch_shadow(cfg, trav_form, hero ? 4 : 1, shade_form == PT_SHADE_FULL, sargs, rd.light_samples, qs, b.energy, b.capacity, seg_cap, nshadow, b.park, qh); });
+                timed(ST_SHADOW, [&] { launch_shadow(cfg, trav_form, hero ? 4 : 1, shade_form == PT_SHADE_FULL || shade_form == PT_SHADE_MEDIUM, sargs, rd.light_samples, qs, b.energy, b.capacity, seg_cap, nshadow, b.park, qh); });
         }
         timed(ST_ACCUMULATE, [&] {
             if (hero) hipLaunchKernelGGL(k_accumulate<4>, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, b.energy, d_film);

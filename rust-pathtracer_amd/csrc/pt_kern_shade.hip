@@ -18,6 +18,10 @@ namespace ptk {
 void PT_CAT(launch_shade_nl, PT_SHADE_NL)(const LaunchCfg& c, int form, const SceneArgs& sc, const RenderParams& rp, uint32_t bounce, const uint32_t* pixels, Queue paths_in,
                                           Queue hits, Queue paths_out, Queue shadow, float* energy, uint32_t seg_cap, const uint32_t* count_in, uint32_t* count_out,
                                           uint32_t* shadow_count, unsigned long long* block_stats) {
+#if PT_SHADE_NL == 1
+#define K_SHADE_M(M) k_shade_medium<M>
+    if (form == PT_SHADE_MEDIUM) { PT_BY_MODE(K_SHADE_M, PT_ARGS); return; }
+#endif
     if (form == PT_SHADE_FULL) PT_BY_MODE(K_SHADE_F, PT_ARGS);
     else if (form == PT_SHADE_NO_ENV) PT_BY_MODE(K_SHADE_N, PT_ARGS);
     else PT_BY_MODE(K_SHADE_L, PT_ARGS);
@@ -27,6 +31,9 @@ hipError_t PT_CAT(allow_lds_shade_nl, PT_SHADE_NL)(uint32_t bytes) {
     auto allow = [&](const void* k) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) worst = e; };
 #define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
     PT_ALLOW_MODES(K_SHADE_L); PT_ALLOW_MODES(K_SHADE_N); PT_ALLOW_MODES(K_SHADE_F);
+#if PT_SHADE_NL == 1
+    PT_ALLOW_MODES(K_SHADE_M);
+#endif
     return worst;
 }
 

@@ -57,6 +57,12 @@ inline void go(const LaunchCfg& c, K kernel, Args... args) { hipLaunchKernelGGL(
 #define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(NL == 1 ? (FORM == 2 ? PT_SHADE_WAVES : FORM == 1 ? PT_SHADE_NO_ENV_WAVES : PT_SHADE_LEAN_WAVES) \
                                                                 : (FORM == 2 ? PT_SHADE4_WAVES : FORM == 1 ? PT_SHADE4_NO_ENV_WAVES : PT_SHADE4_LEAN_WAVES))))
 #define PT_TRAV_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? PT_SWEEP_WAVES : PT_WALK_WAVES)))
+// (k_shadow's sweep form takes a sixth wave: measured on one box after the round-2 changes, tools/occupancy_c2.sh: k_shadow 5203 / 4622 / 4395 /
+// 5479 us at 4 / 5 / 6 / 8 waves, k_extend 2610 / 2270 / 2362 / 3989)
+#ifndef PT_SHADOW_SWEEP_WAVES
+#define PT_SHADOW_SWEEP_WAVES 6
+#endif
+#define PT_SHADOW_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? PT_SHADOW_SWEEP_WAVES : PT_WALK_WAVES)))
 
 enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_ACCUMULATE, ST_COUNT };
 
@@ -204,8 +210,64 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
     }
 }
 
+// The medium-aware walk's vertex kernel (stage_shade_medium; pt_render_desc::medium_aware): k_shade with the tracked mediums and the
+// "previous vertex was a medium vertex" flag carried in two more fields of the path record.
+template <int USE_LDS>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES)))
+k_shade_medium(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex, RenderParams rp, uint32_t bounce, const uint32_t* __restrict__ pixels,
+               Queue paths_in, Queue hits, Queue paths_out, Queue shadow, float* __restrict__ energy, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
+               uint32_t* __restrict__ count_out, uint32_t* __restrict__ shadow_count, unsigned long long* __restrict__ block_stats) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ uint32_t lds_counts[16];
+    if (threadIdx.x < 16) lds_counts[threadIdx.x] = 0;
+    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    if (USE_LDS == PT_LDS_NONE) __syncthreads();
+    const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    uint32_t st_vertices = 0, st_shadow = 0, st_env = 0;
+    const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t j = r * blockDim.x + threadIdx.x, i = base + j;
+        const bool active = j < n;
+        PathVertexT<1> pv; Hit hit; hit.valid = false;
+        MediumState ms{0u, 0u}, ms_next{0u, 0u};
+        bool wants_item = false;
+        if (active) {
+            pv = load_path<1>(paths_in, i);
+            hit = load_hit(hits, i);
+            if (bounce != 0) { ms.mediums = qu(paths_in, PS_MEDIUMS, i); ms.prev_medium = qu(paths_in, PS_PREV_MEDIUM, i); }   // (the camera starts in vacuum)
+            wants_item = shade_medium_wants_item(s, rp, hit, ms);
+        }
+        const uint32_t ipos = base + shared_append(wants_item, &lds_counts[1]);
+        ShadeOutT<1> out;
+        out.survives = false; out.has_item = false; out.vertex_pushed = false; out.env_hit = false; out.shadow_count = 0; out.add_energy = false; out.env_mask = 0;
+        if (active) {
+            const uint32_t pixel = pixels[pv.slot % rp.chunk_pixels];
+            out = stage_shade_medium(s, rp, bounce, pv, hit, pixel, ms, &ms_next, [&](uint32_t l, const ShadowRayT<1>& ray) { store_shadow_ray<1>(shadow, ipos, l, ray); });
+            if (wants_item) {
+                qsu(shadow, Layout<1>::sh_slot, ipos, pv.slot); qsu(shadow, Layout<1>::sh_flags, ipos, out.env_mask);
+                qsf(shadow, Layout<1>::sh_lambda, ipos, pv.lambda);
+                if (!out.has_item) clear_shadow_item<1>(shadow, ipos, rp.light_samples);   // a medium vertex, or a surface vertex that was never pushed
+            }
+            if (out.add_energy) energy[pv.slot] += out.energy_add[0];
+        }
+        const uint32_t pos = base + shared_append(out.survives, &lds_counts[0]);
+        if (out.survives) { store_path<1>(paths_out, pos, out.next); qsu(paths_out, PS_MEDIUMS, pos, ms_next.mediums); qsu(paths_out, PS_PREV_MEDIUM, pos, ms_next.prev_medium); }
+        st_vertices += out.vertex_pushed ? 1u : 0u; st_env += out.env_hit ? 1u : 0u; st_shadow += out.shadow_count;
+    }
+    st_vertices = wave_reduce_add(st_vertices); st_shadow = wave_reduce_add(st_shadow); st_env = wave_reduce_add(st_env);
+    if (lane_id() == 0) { atomicAdd(&lds_counts[4], st_vertices); atomicAdd(&lds_counts[5], st_shadow); atomicAdd(&lds_counts[6], st_env); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        count_out[blockIdx.x] = lds_counts[0]; shadow_count[blockIdx.x] = lds_counts[1];
+        unsigned long long* bs = block_stats + (size_t)blockIdx.x * BS_FIELDS;
+        bs[BS_VERTICES] += lds_counts[4]; bs[BS_SHADOW_RAYS] += lds_counts[5]; bs[BS_ENV_HITS] += lds_counts[6];
+        bs[BS_SEGMENTS] += n;
+        bs[BS_ITEMS] += lds_counts[1];
+    }
+}
+
 template <int USE_LDS, int NL, int TRAV, bool ENV = true>
-__global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+__global__ void __launch_bounds__(kBlock) PT_SHADOW_OCC k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                   uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                   uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
     extern __shared__ __align__(16) uint32_t lds[];

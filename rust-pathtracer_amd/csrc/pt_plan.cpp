@@ -113,6 +113,7 @@ bool normalize_render_desc(const pt_render_desc& in, uint32_t camera_count, pt_r
     if (rd.first_sample + rd.sample_count > rd.spp) { *error = "sample range exceeds spp"; return false; }
     if (!(rd.wavelength_hi >= rd.wavelength_lo)) { *error = "bad wavelength bounds"; return false; }
     if (rd.max_bounces > 64) { *error = "max_bounces > 64"; return false; }
+    if (rd.medium_aware && rd.hero_wavelengths != 1) { *error = "the medium-aware walk carries one wavelength"; return false; }
     *out = rd;
     return true;
 }

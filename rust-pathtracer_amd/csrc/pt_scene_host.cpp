@@ -144,8 +144,18 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             case PT_MATERIAL_GGX: if (!curve_ok(m.curve_eta) || !curve_ok(m.curve_eta_o) || !curve_ok(m.curve_kappa)) return fail("ggx curve out of range");
                 if (!(m.alpha > 0.0f)) return fail("ggx alpha must be positive"); break;
             case PT_MATERIAL_DIFFUSE_LIGHT: case PT_MATERIAL_SHARP_LIGHT: if (!curve_ok(m.curve_emit) || !curve_ok(m.curve_bounce)) return fail("light curve out of range"); break;
+            case PT_MATERIAL_PASSTHROUGH: if (!curve_ok(m.curve_bounce)) return fail("passthrough colour curve out of range"); break;
             default: return fail("unknown material kind");
         }
+        if (m.outer_medium < 0 || m.inner_medium < 0 || (uint32_t)m.outer_medium > d.medium_count || (uint32_t)m.inner_medium > d.medium_count) return fail("material medium id out of range");
+    }
+    if (d.medium_count > 255) return fail("more than 255 mediums");   // MediumId is a u8 (src/prelude.rs)
+    if (d.medium_count && !d.mediums) return fail("mediums missing");
+    for (uint32_t i = 0; i < d.medium_count; ++i) {
+        const pt_medium& m = d.mediums[i];
+        if (m.kind == PT_MEDIUM_HG) { if (!curve_ok(m.curve_g) || !curve_ok(m.curve_sigma_a) || !curve_ok(m.curve_sigma_s)) return fail("HG medium curve out of range"); }
+        else if (m.kind == PT_MEDIUM_RAYLEIGH) { if (!curve_ok(m.curve_ior)) return fail("Rayleigh medium curve out of range"); }
+        else return fail("unknown medium kind");
     }
     for (uint32_t i = 0; i < d.texstack_count; ++i) {
         const pt_texstack& t = d.texstacks[i];
@@ -219,7 +229,23 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             r[PT_MAT_METALLIC] = sum > 0.0f ? 1u : 0u;
         }
         if (m.kind == PT_MATERIAL_DIFFUSE_LIGHT || m.kind == PT_MATERIAL_SHARP_LIGHT) { r[PT_MAT_EMIT] = curve_off[m.curve_emit]; r[PT_MAT_BOUNCE] = curve_off[m.curve_bounce]; }
+        if (m.kind == PT_MATERIAL_PASSTHROUGH) r[PT_MAT_BOUNCE] = curve_off[m.curve_bounce];
+        r[PT_MAT_MEDIUMS] = (uint32_t)m.outer_medium | (uint32_t)m.inner_medium << 8;
         w.insert(w.end(), r, r + PT_MAT_WORDS);
+    }
+    // mediums (World::mediums): read by the medium-aware walk only
+    if (d.medium_count) {
+        pad16(w);
+        w[PT_HDR_MEDIUM_OFF] = (uint32_t)w.size(); w[PT_HDR_MEDIUM_COUNT] = d.medium_count;
+        for (uint32_t i = 0; i < d.medium_count; ++i) {
+            const pt_medium& m = d.mediums[i];
+            uint32_t r[PT_MEDIUM_WORDS] = {0};
+            r[PT_MED_KIND] = (uint32_t)m.kind;
+            if (m.kind == PT_MEDIUM_HG) { r[PT_MED_G] = curve_off[m.curve_g]; r[PT_MED_SIGMA_A] = curve_off[m.curve_sigma_a]; r[PT_MED_SIGMA_S] = curve_off[m.curve_sigma_s]; }
+            else r[PT_MED_IOR] = curve_off[m.curve_ior];
+            r[PT_MED_CORRECTIVE] = fbits(m.corrective_factor);
+            w.insert(w.end(), r, r + PT_MEDIUM_WORDS);
+        }
     }
 
     // meshes: per-mesh BVH over triangles (Mesh::init, mesh.rs:283-305) + gathered triangle records

@@ -304,6 +304,160 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     return out;
 }
 
+// ------------------------------------------------------------------------------------------------ shade, medium-aware
+// One vertex of random_walk_medium (utils.rs:708-1103) + the matching iteration of color()'s second pass, which only looks at pairs of
+// SURFACE vertices (pt.rs:481-611): a surface vertex behind a medium vertex takes no light samples, an environment vertex behind one
+// adds nothing.  Differences from the plain walk that matter: the vertex carries the throughput from BEFORE this segment's
+// attenuation (utils.rs:733-749); the direction comes from Material::generate and f, pdf from Material::bsdf; a vertex whose pdf is 0 or
+// NaN, or that the roulette stops, is never pushed (:858-869); the walk does not stop when the throughput reaches 0.  The free-flight
+// and phase samples are counter-based (PT_TAG_MEDIUM_*; the reference takes them from the thread RNG).  A light-tagged vertex adds
+// nothing and takes no light samples (the reference panics there, pt.rs:575-582).  Single wavelength.
+// Path state beyond PathVertexT: the tracked mediums (mediums_add / mediums_remove) and whether the previous vertex was a medium vertex.
+enum { PS_MEDIUMS = PS_FIELDS, PS_PREV_MEDIUM = PS_FIELDS + 1 };   // (the passenger-throughput fields of the hero layout: the two variants exclude each other)
+struct MediumState { uint32_t mediums, prev_medium; };
+PT_HD bool shade_medium_wants_item(const SceneView& s, const RenderParams& rp, const Hit& hit, const MediumState& ms) {
+    return ms.prev_medium == 0u && shade_wants_item(s, rp, hit);
+}
+template <typename RaySink>
+PT_HD ShadeOutT<1> stage_shade_medium(const SceneView& s, const RenderParams& rp, uint32_t bounce, const PathVertexT<1>& pv, const Hit& hit,
+                                      uint32_t pixel, const MediumState& ms, MediumState* ms_out, RaySink&& sink) {
+    ShadeOutT<1> out;
+    out.survives = false; out.add_energy = false; out.vertex_pushed = false; out.env_hit = false;
+    out.shadow_count = 0; out.env_mask = 0; out.has_item = false; out.energy_add[0] = 0.0f;
+    *ms_out = ms;
+    const uint32_t sample = rp.first_sample + pv.slot / rp.chunk_pixels;
+    const float lambda = pv.lambda;
+    const bool more = bounce + 1 < (rp.only_direct ? 1u : rp.max_bounces);
+    if (!hit.valid) {
+        out.vertex_pushed = true;   // the environment vertex (utils.rs:1069-1096); looked at only behind a surface vertex
+        if (ms.prev_medium == 0u) {
+            F3 wo = pv.d;
+            float u = 0.0f, v = 0.0f;
+            if (bu(s, PT_HDR_ENV_KIND) != PT_ENV_CONSTANT) direction_to_uv(wo, &u, &v);
+            float cos_i = pt_abs(dot(pv.prev_n, wo));
+            float nee_psa_pdf = env_pdf_for(s, u, v) / pt_abs(cos_i);
+            float bsdf_psa_pdf = pv.prev_pdf / pt_abs(cos_i);
+            float weight = (bsdf_psa_pdf * bsdf_psa_pdf) / (bsdf_psa_pdf * bsdf_psa_pdf + nee_psa_pdf * nee_psa_pdf);
+            out.energy_add[0] = weight * pv.beta[0] * env_emission(s, u, v, lambda);
+            out.add_energy = true; out.env_hit = true;
+        }
+        return out;
+    }
+    // the nearest scattering event of the tracked mediums in front of the hit (utils.rs:766-793), then the segment's attenuation (:794-806)
+    MediumEval me[4];
+    uint32_t n_tracked = 0;
+    for (; n_tracked < 4u && ((ms.mediums >> (8u * n_tracked)) & 0xffu) != 0u; ++n_tracked)
+        me[n_tracked] = medium_prepare(s, medium_record(s, (ms.mediums >> (8u * n_tracked)) & 0xffu), lambda);
+    float medium_time = hit.t; F3 medium_point = hit.p; uint32_t medium_slot = 4u;
+    float hero_weight = 1.0f, hero_tr = 1.0f;
+    if (n_tracked != 0u) {
+        const pt_f32x4 fd = pt_draw4_tagged(rp.seed, pixel, sample, bounce, PT_TAG_MEDIUM_DISTANCE);
+        const float flight[4] = {fd.x, fd.y, fd.z, fd.w};
+        for (uint32_t k = 0; k < n_tracked; ++k) {
+            F3 p; float w;
+            medium_sample(me[k], pv.o, pv.d, flight[k], &p, &w);
+            const float t = norm(sub(p, pv.o));
+            if (t < medium_time) { medium_time = t; medium_point = p; hero_weight = w; hero_tr = medium_tr(me[k], pv.o, p); medium_slot = k; }
+        }
+    }
+    float beta = pv.beta[0] * hero_weight;
+    float combined = 1.0f;
+    for (uint32_t k = 0; k < n_tracked; ++k) combined *= medium_tr(me[k], pv.o, medium_point);
+    beta *= combined / hero_tr;
+    if (medium_slot != 4u) {
+        // Vertex::Medium (utils.rs:1031-1066): a new direction from the phase function, the throughput untouched
+        const pt_f32x4 ph = pt_draw4_tagged(rp.seed, pixel, sample, bounce, PT_TAG_MEDIUM_PHASE);
+        float phase;
+        const F3 wo = medium_sample_p(me[medium_slot], neg(pv.d), ph.x, ph.y, &phase);
+        out.vertex_pushed = true;
+        ms_out->prev_medium = 1u;
+        out.survives = more;
+        out.next.o = medium_point; out.next.d = wo; out.next.beta[0] = beta; out.next.lambda = lambda; out.next.slot = pv.slot;
+        out.next.prev_pdf = phase; out.next.prev_n = wo; out.next.prev_p = medium_point;
+        return out;
+    }
+    const Frame frame = frame_from_normal(hit.n);
+    const F3 wi = normalize(to_local(frame, neg(pv.d)));
+    if (PT_MATERIAL_TAG(hit.material) == PT_TAG_CAMERA) return out;
+    const uint32_t m = material_record(s, hit.material);
+    const pt_f32x4 r = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples));
+    const MatEval mev = material_prepare(s, m, lambda, hit.u, hit.v);
+    float f0, pdf0, f, pdf; F3 wo;
+    material_sample_p(mev, r.x, r.y, wi, &f0, &wo, &pdf0);   // Material::generate: the direction of generate_and_evaluate (materials/mod.rs:76-86)
+    material_bsdf_p(mev, wi, wo, &f, &pdf);
+    const float cos_i = pt_abs(wo.z);
+    if (pdf == 0.0f || pt_isnan(pdf)) return out;            // never pushed (:858-860)
+    const float rr = (bounce >= rp.min_bounces) ? pt_min(f / pdf, 1.0f) : 1.0f;
+    if (r.z > rr) return out;                                // nor here (:866-869)
+    beta *= f * pt_abs(cos_i) * (1.0f / (rr * pdf));
+    const float pdf_forward = pdf * (rr / cos_i);
+    out.vertex_pushed = true;
+    // the second pass at this vertex (pt.rs:562-604): light samples with the vertex's own throughput, unless the pair is not (Surface, Surface)
+    if (ms.prev_medium == 0u && PT_MATERIAL_TAG(hit.material) != PT_TAG_LIGHT && rp.light_samples > 0) {
+        const uint32_t n_lights = bu(s, PT_HDR_LIGHT_COUNT);
+        const float env_p = bf(s, PT_HDR_ENV_PROB);
+        if (!(n_lights == 0 && env_p == 0.0f)) {
+            const F3 hn = normalize(hit.n);
+            const Frame fr2 = frame_from_normal(hn);
+            const F3 wi2 = to_local(fr2, normalize(sub(pv.prev_p, hit.p)));
+            const EnvCurves ec = env_p > 0.0f ? env_curves(s, lambda) : EnvCurves{{0.0f, 0.0f, 0.0f, 0.0f}, false};
+            for (uint32_t l = 0; l < rp.light_samples; ++l) {
+                ShadowRayT<1> ray; ray.o = f3(0, 0, 0); ray.d = f3(0, 0, 0); ray.factor[0] = 0.0f;
+                const pt_f32x4 q = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples) + 1u + l);
+                float x = q.x;
+                if (choose_first(&x, env_p)) {   // estimate_direct_illumination_from_world, pt.rs:224-331
+                    float eu, ev, light_pdf;
+                    env_sample_uv(s, q.y, q.z, &eu, &ev, &light_pdf);
+                    const F3 direction = uv_to_direction(eu, ev);
+                    const F3 local_wo = to_local(fr2, direction);
+                    if (local_wo.z > 0.0f) {
+                        float refl, spdf;
+                        material_bsdf_p(mev, wi2, local_wo, &refl, &spdf);
+                        const float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + spdf);
+                        ray.o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(direction.z)));
+                        ray.d = direction;
+                        ray.factor[0] = pv.beta[0] * weight * refl * env_emission(s, eu, ev, lambda, ec) * pt_abs(local_wo.z) * (1.0f / light_pdf);
+                        out.shadow_count += 1;
+                        if (ray_is_live<1>(ray)) out.env_mask |= 1u << l;
+                    }
+                } else if (n_lights != 0) {      // estimate_direct_illumination, pt.rs:146-218
+                    const float fi = pt_clamp((float)n_lights * x, 0.0f, (float)n_lights - 1.0f);
+                    const uint32_t light_id = bu(s, bu(s, PT_HDR_LIGHT_OFF) + (uint32_t)fi);
+                    F3 ldir; float light_pdf;
+                    light_sample(s, bu(s, PT_HDR_INSTANCE_OFF) + light_id * PT_INST_WORDS, q.y, q.z, hit.p, &ldir, &light_pdf);
+                    light_pdf = light_pdf * (1.0f / (float)n_lights);
+                    if (light_pdf != 0.0f) {
+                        const F3 bsdf_wo = to_local(fr2, ldir);
+                        float refl, bpdf;
+                        material_bsdf_p(mev, wi2, bsdf_wo, &refl, &bpdf);
+                        const float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + bpdf);
+                        ray.o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(bsdf_wo.z)));
+                        ray.d = ldir;
+                        ray.factor[0] = refl * pv.beta[0] * pt_abs(bsdf_wo.z) * weight / light_pdf;
+                        out.shadow_count += 1;
+                    }
+                }
+                sink(l, ray);
+            }
+            out.has_item = true;
+        }
+    }
+    // medium transitions (utils.rs:925-991): only on transmission through a boundary whose two sides differ
+    const uint32_t mm = bu(s, m + PT_MAT_MEDIUMS), outer = mm & 0xffu, inner = (mm >> 8) & 0xffu;
+    uint32_t list = ms.mediums;
+    if (!(wi.z * wo.z > 0.0f) && inner != outer) {
+        if (wo.z < 0.0f) { if (outer != 0u) list = mediums_remove(list, outer); if (inner != 0u) list = mediums_add(list, inner); }
+        else { if (inner != 0u) list = mediums_remove(list, inner); if (outer != 0u) list = mediums_add(list, outer); }
+    }
+    ms_out->mediums = list; ms_out->prev_medium = 0u;
+    out.survives = more;
+    out.next.o = add(hit.p, mul(mul(hit.n, 0.001f), wo.z > 0.0f ? 1.0f : -1.0f));
+    out.next.d = normalize(to_world(frame, wo));
+    out.next.beta[0] = beta; out.next.lambda = lambda; out.next.slot = pv.slot;
+    out.next.prev_pdf = pdf_forward; out.next.prev_n = hit.n; out.next.prev_p = hit.p;
+    return out;
+}
+
 // queue I/O of one light-sample ray
 template <int NL>
 PT_HD void store_shadow_ray(const Queue& q, uint32_t item, uint32_t l, const ShadowRayT<NL>& ray) {

@@ -123,6 +123,8 @@ class SceneBuilder:
         self.texstack_names = {}
         self.materials = []
         self.material_ids = {}    # name -> packed MaterialId
+        self.mediums = []         # api.Medium; MediumId = index + 1 (0 = vacuum)
+        self.medium_ids = {}
         self.meshes = []
         self.vertices = []
         self.indices = []
@@ -218,8 +220,22 @@ class SceneBuilder:
     def material_lambertian(self, name, texstack):
         return self._add_material(name, api.Material(api.MATERIAL_LAMBERTIAN, texstack, 0.0, -1, -1, -1, -1, -1, 0.0, 0), False)
 
-    def material_ggx(self, name, alpha, eta, eta_o, kappa):
-        return self._add_material(name, api.Material(api.MATERIAL_GGX, -1, alpha, eta, eta_o, kappa, -1, -1, 0.0, 0), False)
+    def material_ggx(self, name, alpha, eta, eta_o, kappa, outer_medium=0, inner_medium=0):
+        return self._add_material(name, api.Material(api.MATERIAL_GGX, -1, alpha, eta, eta_o, kappa, -1, -1, 0.0, 0, outer_medium, inner_medium), False)
+
+    def material_passthrough(self, name, color, outer_medium=0, inner_medium=0):   # PassthroughFilter (src/materials/passthrough.rs)
+        return self._add_material(name, api.Material(api.MATERIAL_PASSTHROUGH, -1, 0.0, -1, -1, -1, -1, color, 0.0, 0, outer_medium, inner_medium), False)
+
+    # ---- mediums (src/parsing/medium.rs; MediumId = position + 1, src/parsing/mod.rs)
+    def medium_hg(self, name, g, sigma_a, sigma_s):
+        self.mediums.append(api.Medium(api.MEDIUM_HG, g, sigma_a, sigma_s, -1, 0.0))
+        self.medium_ids[name] = len(self.mediums)
+        return self.medium_ids[name]
+
+    def medium_rayleigh(self, name, ior, corrective_factor):
+        self.mediums.append(api.Medium(api.MEDIUM_RAYLEIGH, -1, -1, -1, ior, corrective_factor))
+        self.medium_ids[name] = len(self.mediums)
+        return self.medium_ids[name]
 
     def material_diffuse_light(self, name, emit, bounce, sidedness):
         return self._add_material(name, api.Material(api.MATERIAL_DIFFUSE_LIGHT, -1, 0.0, -1, -1, -1, emit, bounce, 0.0, sidedness), True)
@@ -354,6 +370,7 @@ class SceneBuilder:
         d.camera_count = len(self.cameras); d.cameras = arr("cameras", self.cameras, api.Camera)
         d.environment = self.environment
         d.env_sampling_probability = self.env_sampling_probability
+        d.medium_count = len(self.mediums); d.mediums = arr("mediums", self.mediums, api.Medium)
         return d, keep
 
 
@@ -624,6 +641,37 @@ def big_sphere_light():
     return b
 
 
+def fog_ball():
+    """The medium-aware walk (pt_render_desc.medium_aware; not a reference scene): a ball of forward-scattering HG fog and one of
+    Rayleigh-scattering air behind PassthroughFilter boundaries, a rough glass ball filled with absorbing fog (GGX carries medium ids
+    too), a white floor, a constant sky as the only light — the reference's medium-aware colour panics at any light vertex that faces
+    the path."""
+    b = SceneBuilder()
+    add_library_curves(b, ["simple_sky_blue"])
+    b.set_environment_constant(b.curve("simple_sky_blue"), 1.0)
+    b.env_sampling_probability = 1.0
+    white = add_library_material(b, "lambertian_white")
+    one = b.curve_flat("flat_one_fog", 1.0)
+    g_forward = b.curve_flat("hg_g_forward", 1.6)     # the library stores g + 1 (hg.rs:20-22)
+    zero = b.curve_flat("flat_zero_fog", 0.0)
+    dense = b.curve_flat("sigma_s_dense", 1.5)
+    thin = b.curve_flat("sigma_a_thin", 0.4)
+    air = b.curve_cauchy("air_ior_fog", 1.5, 0.0)
+    fog = b.medium_hg("fog", g_forward, zero, dense)
+    haze = b.medium_rayleigh("haze", air, 0.6)
+    murk = b.medium_hg("murk", b.curve_flat("hg_g_iso", 1.0), thin, b.curve_flat("sigma_s_murk", 0.8))
+    boundary_fog = b.material_passthrough("fog_boundary", one, 0, fog)
+    boundary_haze = b.material_passthrough("haze_boundary", one, 0, haze)
+    eta = b.curve_cauchy("glass_eta_fog", 1.45, 3540.0)
+    glass = b.material_ggx("ggx_glass_murky", 0.2, eta, b.curve_flat("eta_o_fog", 1.0), zero, 0, murk)
+    b.add_rect((12, 12), (0.0, 0.0, -1.0), "Z", True, white)
+    b.add_sphere(0.9, (0.0, -1.1, 0.0), boundary_fog)
+    b.add_sphere(0.8, (0.3, 1.0, -0.2), boundary_haze)
+    b.add_sphere(0.5, (-1.2, 0.1, -0.5), glass)
+    b.add_camera((-5.0, 0.0, 0.6), (0.0, 0.0, -0.1), 40.0, focal_distance=5.0, aperture_diameter=0.02)
+    return b
+
+
 def empty_env():
     """No instance at all: a constant environment and a camera (edge case: empty BVH, empty light list)."""
     b = SceneBuilder()
@@ -707,4 +755,4 @@ def hdri_c4_small():
 
 SCENES = {"hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
           "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test, "panorama_test": panorama_test, "empty_env": empty_env,
-          "big_sphere_light": big_sphere_light}
+          "big_sphere_light": big_sphere_light, "fog_ball": fog_ball}

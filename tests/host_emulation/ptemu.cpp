@@ -65,7 +65,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
     rp.energy_stride = capacity;
     rp.camera = pth::camera_params(sc->host.cameras[rd.camera_index], (float)rd.width / (float)rd.height);
     typedef Layout<NL> LY;
-    std::vector<uint32_t> pa((size_t)LY::path_fields * capacity), pb((size_t)LY::path_fields * capacity), ph((size_t)HS_FIELDS * capacity),
+    std::vector<uint32_t> pa((size_t)(LY::path_fields + 2) * capacity), pb((size_t)(LY::path_fields + 2) * capacity), ph((size_t)HS_FIELDS * capacity),
         psh((size_t)LY::shadow_fields(PT_MAX_LIGHT_SAMPLES) * capacity);
     std::vector<float> energy((size_t)NL * capacity);
     Queue qa{pa.data(), capacity}, qb{pb.data(), capacity}, qh{ph.data(), capacity}, qs{psh.data(), capacity};
@@ -79,7 +79,10 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
         for (uint32_t i = 0; i < n; ++i) { store_path<NL>(qa, i, stage_generate<NL>(rp, i, px[i % rp.chunk_pixels])); for (int k = 0; k < NL; ++k) energy[(size_t)k * capacity + i] = 0.0f; }
         uint32_t live = n;
         bool has_ggx = false;
-        for (uint32_t i = 0; i < bu(s, PT_HDR_MATERIAL_COUNT); ++i) has_ggx = has_ggx || bu(s, bu(s, PT_HDR_MATERIAL_OFF) + i * PT_MAT_WORDS + PT_MAT_KIND) == PT_MATERIAL_GGX;
+        for (uint32_t i = 0; i < bu(s, PT_HDR_MATERIAL_COUNT); ++i) {
+            const uint32_t kind = bu(s, bu(s, PT_HDR_MATERIAL_OFF) + i * PT_MAT_WORDS + PT_MAT_KIND);
+            has_ggx = has_ggx || kind == PT_MATERIAL_GGX || kind == PT_MATERIAL_PASSTHROUGH;
+        }
         const int forced = getenv("PTEMU_SHADE_FORM") ? atoi(getenv("PTEMU_SHADE_FORM")) : 0;
         const int shade_form = (bf(s, PT_HDR_ENV_PROB) != 0.0f || forced == 2) ? 2 : (has_ggx || forced == 1) ? 1 : 0;
         for (uint32_t bounce = 0; bounce < bounce_limit; ++bounce) {
@@ -93,15 +96,28 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
             for (uint32_t i = 0; i < live; ++i) {
                 PathVertexT<NL> pv = load_path<NL>(qin, i);
                 Hit hit = load_hit(qh, i);
-                bool wants = shade_wants_item(s, rp, hit);
+                bool wants = shade_wants_item(s, rp, hit);   // (the medium-aware walk overrides this below)
                 uint32_t ipos = items;
                 auto sink = [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(qs, ipos, l, ray); };
                 // the kernel form the engine launches (PT_SHADE_LEAN / NO_ENV / FULL): without the environment-sampling branch when
                 // env_sampling_probability is 0, without the GGX code when the scene has no GGX material
                 const uint32_t px_i = px[pv.slot % rp.chunk_pixels];
-                ShadeOutT<NL> out = shade_form == 2 ? stage_shade<NL, true, true>(s, rp, bounce, pv, hit, px_i, sink)
-                                  : shade_form == 1 ? stage_shade<NL, false, true>(s, rp, bounce, pv, hit, px_i, sink)
-                                                    : stage_shade<NL, false, false>(s, rp, bounce, pv, hit, px_i, sink);
+                ShadeOutT<NL> out;
+                MediumState ms_next{0u, 0u};
+                bool medium_walk = false;
+                if constexpr (NL == 1) {
+                    if (rd.medium_aware) {   // the medium-aware walk (k_shade_medium): its two extra path fields ride behind the plain record
+                        medium_walk = true;
+                        MediumState ms{0u, 0u};
+                        if (bounce != 0) { ms.mediums = qu(qin, PS_MEDIUMS, i); ms.prev_medium = qu(qin, PS_PREV_MEDIUM, i); }
+                        wants = shade_medium_wants_item(s, rp, hit, ms);
+                        out = stage_shade_medium(s, rp, bounce, pv, hit, px_i, ms, &ms_next, sink);
+                    }
+                }
+                if (!medium_walk)
+                    out = shade_form == 2 ? stage_shade<NL, true, true>(s, rp, bounce, pv, hit, px_i, sink)
+                        : shade_form == 1 ? stage_shade<NL, false, true>(s, rp, bounce, pv, hit, px_i, sink)
+                                          : stage_shade<NL, false, false>(s, rp, bounce, pv, hit, px_i, sink);
                 if (wants) {
                     items++;
                     float lam[NL]; lam[0] = pv.lambda;
@@ -111,11 +127,14 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
                     if (!out.has_item) clear_shadow_item<NL>(qs, ipos, rp.light_samples);
                 }
                 if (out.add_energy) for (int k = 0; k < NL; ++k) energy[(size_t)k * capacity + pv.slot] += out.energy_add[k];
-                if (out.survives) store_path<NL>(qout, next++, out.next);
+                if (out.survives) {
+                    if (medium_walk) { qsu(qout, PS_MEDIUMS, next, ms_next.mediums); qsu(qout, PS_PREV_MEDIUM, next, ms_next.prev_medium); }
+                    store_path<NL>(qout, next++, out.next);
+                }
                 bounce_rays += out.vertex_pushed; env_hits += out.env_hit; shadow_rays += out.shadow_count;
             }
             for (uint32_t i = 0; i < items; ++i) {
-                if (shade_form == 2) stage_shadow_item<NL, PT_TRAV_ANY, true>(s, rp.light_samples, qs, i, energy.data(), capacity);
+                if (shade_form == 2 || rd.medium_aware) stage_shadow_item<NL, PT_TRAV_ANY, true>(s, rp.light_samples, qs, i, energy.data(), capacity);
                 else stage_shadow_item<NL, PT_TRAV_ANY, false>(s, rp.light_samples, qs, i, energy.data(), capacity);
             }
             live = next;

@@ -76,6 +76,11 @@ def test_materials_bit_exact(engine, oracle, scene):
     ("cornell_gem", 64, 48, 6, 12, {"hero_wavelengths": 4}),
     ("hdri_small", 48, 48, 6, 4, {"hero_wavelengths": 4, "light_samples": 3}),
     ("hdri_c4_small", 96, 96, 6, 4, {"light_samples": 6}),   # C4 scene (monkey mesh: blob too big for LDS -> HBM/L2 path)
+    ("fog_ball", 160, 120, 12, 10, {"medium_aware": True}),  # the medium-aware walk (k_shade_medium)
+    ("fog_ball", 96, 64, 8, 12, {"medium_aware": True, "light_samples": 3, "min_bounces": 3, "seed": 9}),
+    ("cornell_box", 96, 96, 8, 6, {"medium_aware": True}),
+    ("cornell_gem", 96, 54, 6, 8, {"medium_aware": True}),   # (parked traversal under the medium-aware vertex kernel)
+    ("hdri_c4_small", 64, 64, 6, 4, {"medium_aware": True, "light_samples": 3}),
 ])
 def test_film_parity(engine, oracle, scene, w, h, spp, mb, kw):
     ps.render_parity(engine, oracle, scene, w, h, spp, mb, **kw)

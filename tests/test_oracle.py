@@ -433,3 +433,47 @@ def test_reference_instance_case(pkg, oracle):
             n = (rx @ ry) @ np.array([0.0, 0.0, 1.0])
             assert abs(h["t"] - 10.0) < 1e-4 and np.allclose(h["point"], [0, 0, 0], atol=1e-4)
             assert np.allclose(np.abs(np.dot(h["normal"], n)), 1.0, atol=1e-5) and np.dot(h["normal"], [0, 0, 1]) > 0   # two-sided: faces the ray
+
+
+def test_mediums(pkg, oracle):
+    """src/mediums: the Henyey-Greenstein phase function (pbrt's convention: both directions point away from the scattering point, so the
+    mean of wi . wo is -g and g > 0 scatters forward) is a normalised pdf, its sampler follows it and returns unit vectors in the frame
+    of wi (TangentFrame::from_normal(wi), hg.rs:82-91), g stored + 1 with the 0.001 nudge of hg.rs:69;
+    the Rayleigh sampler's cosine solves the cubic of rayleigh.rs:70-75 and reports 3 (1 + cos^2) / 8; a free flight is
+    -ln(1 - x) / sigma_s long and weighs exp(-sigma_t d) (hg.rs:96-115)."""
+    import ctypes as C
+    from util import fptr
+    L = oracle.lib
+    L.ptref_medium_sample_p.restype = None
+    L.ptref_medium_sample_p.argtypes = [C.c_int, C.c_float, C.c_size_t] + [C.POINTER(C.c_float)] * 4
+    L.ptref_medium_flight.restype = None
+    L.ptref_medium_flight.argtypes = [C.c_float, C.c_float, C.c_size_t] + [C.POINTER(C.c_float)] * 3
+    rng = np.random.default_rng(3)
+    n = 1 << 16
+    wi = rng.normal(size=(n, 3)).astype(np.float32); wi /= np.linalg.norm(wi, axis=1, keepdims=True).astype(np.float32)
+    s2 = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    for g_stored in (1.0, 1.6, 0.3):
+        wo = np.zeros((n, 3), np.float32); pdf = np.zeros(n, np.float32)
+        L.ptref_medium_sample_p(0, g_stored, n, fptr(wi), fptr(s2), fptr(wo), fptr(pdf))
+        g = np.float32(g_stored) + np.float32(0.001) - np.float32(1.0)
+        cos = (wo * wi).sum(axis=1)
+        assert np.allclose(np.linalg.norm(wo, axis=1), 1.0, atol=1e-5)
+        assert abs(cos.mean() + g) < 0.01, (g_stored, cos.mean())                      # mean of wi . wo = -g
+        denom = 1.0 + g * g + 2.0 * g * cos.astype(np.float64)
+        # the pdf the sampler reports is phase_hg evaluated at the sampled cosine, and phase_hg integrates to 1 over the sphere
+        assert np.allclose(pdf, (1.0 - g * g) / (denom * np.sqrt(denom) * 4.0 * np.pi), rtol=2e-4)
+        mu = np.linspace(-1, 1, 20001)
+        d = 1.0 + g * g + 2.0 * g * mu
+        assert abs(np.trapezoid((1.0 - g * g) / (d * np.sqrt(d) * 4.0 * np.pi), mu) * 2.0 * np.pi - 1.0) < 1e-3
+    wo = np.zeros((n, 3), np.float32); pdf = np.zeros(n, np.float32)
+    L.ptref_medium_sample_p(1, 0.0, n, fptr(wi), fptr(s2), fptr(wo), fptr(pdf))
+    cos = (wo * wi).sum(axis=1).astype(np.float64)
+    assert np.allclose(np.linalg.norm(wo, axis=1), 1.0, atol=1e-4) and (np.abs(cos) <= 1.0 + 1e-5).all()
+    assert np.allclose(pdf, 3.0 * (1.0 + cos * cos) / 8.0, rtol=1e-3, atol=1e-4)
+    x = np.where(s2[:, 0] < 0.5, s2[:, 0] / 0.5, (s2[:, 0] - 0.5) / 0.5).astype(np.float64)   # Sample1D::choose(0.5)
+    z = 2.0 * (2.0 * x - 1.0)
+    assert np.allclose(cos ** 3 + 3.0 * cos, 2.0 * z, atol=2e-3)                      # cbrt(z + r) + cbrt(z - r) solves c^3 + 3 c = 2 z
+    xs = rng.uniform(0, 0.999, 4096).astype(np.float32); dist = np.zeros_like(xs); w = np.zeros_like(xs)
+    L.ptref_medium_flight(0.7, 0.2, xs.size, fptr(xs), fptr(dist), fptr(w))
+    assert np.allclose(dist, -np.log((np.float32(1.0) - xs).astype(np.float64)) / np.float64(np.float32(0.7)), rtol=1e-5)   # (1 - x is taken in f32, hg.rs:98)
+    assert np.allclose(w, np.exp(-np.float64(np.float32(0.2) + np.float32(0.7)) * dist.astype(np.float64)), rtol=1e-5)

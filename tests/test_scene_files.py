@@ -495,3 +495,56 @@ def test_engine_renders_the_same_film_from_either_front_end(sfmod, pkg, engine, 
     film_b, prof_b = engine.create_scene(pkg.scene.SCENES[name]()).render(rd)
     assert np.array_equal(film_f.view(np.uint32), film_b.view(np.uint32))
     assert (prof_f.bounce_rays, prof_f.shadow_rays, prof_f.env_hits) == (prof_b.bounce_rays, prof_b.shadow_rays, prof_b.env_hits)
+
+
+def test_mediums_and_the_medium_aware_flag(sfmod, tmp_path):
+    """the mediums library (src/parsing/medium.rs: HG and Rayleigh), GGX's outer / inner medium names (material.rs:86-91; a name
+    that is not in the library is the vacuum) and IntegratorType::PT { medium_aware } reach the flat descriptors.  A medium's id is its
+    position in the library + 1 (the reference's own numbering is off by one against its walk, see scene_file.cpp)."""
+    scene = """meshes = {}
+textures = {}
+env_sampling_probability = 1.0
+[curves]
+one = { type = "Flat", strength = 1.0 }
+zero = { type = "Flat", strength = 0.0 }
+glass = { type = "Cauchy", a = 1.45, b = 3540.0 }
+[mediums]
+fog = { type = "HG", g = "one", sigma_a = "zero", sigma_s = { type = "Flat", strength = 0.25 } }
+haze = { type = "Rayleigh", ior = "glass", corrective_factor = 23.0 }
+[materials.murky]
+type = "GGX"
+alpha = 0.1
+eta = "glass"
+eta_o = "one"
+kappa = "zero"
+permeability = 0.0
+inner_medium_id = "haze"
+outer_medium_id = "not in the library"
+[environment]
+type = "Constant"
+color = "one"
+strength = 1.0
+[[instances]]
+material_name = "murky"
+[instances.aggregate]
+type = "Sphere"
+radius = 1.0
+origin = [0.0, 0.0, 0.0]
+[[cameras]]
+type = "SimpleCamera"
+name = "main"
+look_from = [-5.0, 0.0, 0.0]
+look_at = [0.0, 0.0, 0.0]
+vfov = 30.0
+"""
+    sf = sfmod.SceneFile(_write(tmp_path, "fog.toml", scene))
+    d = sf.desc
+    assert d.medium_count == 2
+    assert (d.mediums[0].kind, d.mediums[1].kind) == (0, 1) and d.mediums[1].corrective_factor == 23.0
+    assert d.mediums[0].curve_sigma_s >= 0 and d.mediums[1].curve_ior == sf.curve("glass")
+    m = d.materials[sf.material("murky") & 0xffff]
+    assert (m.inner_medium, m.outer_medium) == (2, 0)
+    base = open(data(sfmod, "", "config_cornell_c1.toml")).read() if False else None
+    cfg_text = open(os.path.join(os.path.dirname(sfmod.__file__), "data", "config_cornell_c1.toml")).read().replace("medium_aware = false", "medium_aware = true")
+    cfg = sfmod.Config(_write(tmp_path, "cfg.toml", cfg_text))
+    assert cfg.render_desc(0).medium_aware == 1 and cfg.render_settings(0).medium_aware == 1
