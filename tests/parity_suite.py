@@ -90,9 +90,10 @@ def golden_render(impl, name):
     cfg = GOLDEN_RENDERS[name]
     scene, w, h, spp, mb, ls, seed = cfg[:7]
     hero = cfg[7] if len(cfg) > 7 else 1
+    medium = cfg[8] if len(cfg) > 8 else False
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     film, prof = impl.create_scene(pkg().scene.SCENES[scene]()).render(
-        pkg().api.render_desc(w, h, spp, mb, light_samples=ls, seed=seed, hero_wavelengths=hero))
+        pkg().api.render_desc(w, h, spp, mb, light_samples=ls, seed=seed, hero_wavelengths=hero, medium_aware=medium))
     return film, prof, z["film"], z["counters"]
 
 

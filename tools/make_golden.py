@@ -51,13 +51,14 @@ def material_inputs(n, seed):
 
 
 GOLDEN_RENDERS = {
-    # name: (scene, width, height, spp, max_bounces, light_samples, seed[, hero_wavelengths])
+    # name: (scene, width, height, spp, max_bounces, light_samples, seed[, hero_wavelengths[, medium_aware]])
     "cornell_64x64_4spp": ("cornell_box", 64, 64, 4, 4, 2, 1),
     "gem_48x32_6spp": ("cornell_gem", 48, 32, 6, 12, 2, 1),
     "mixed_40x40_12spp": ("mixed_primitives", 40, 40, 12, 6, 3, 7),
     "furnace_24x24_16spp": ("white_furnace", 24, 24, 16, 8, 6, 3),
     "hdri_32x32_8spp": ("hdri_small", 32, 32, 8, 4, 6, 2),
     "cornell_hero_48x48_6spp": ("cornell_box", 48, 48, 6, 8, 2, 4, 4),
+    "fog_48x32_8spp_medium": ("fog_ball", 48, 32, 8, 8, 2, 3, 1, True),   # the medium-aware walk
 }
 
 
@@ -67,14 +68,20 @@ def main():
     ora = oracle_loader.load(pkg)
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
+    only = sys.argv[1:]   # names to (re)generate; default all
     for name, cfg in GOLDEN_RENDERS.items():
+        if only and name not in only:
+            continue
         scene, w, h, spp, mb, ls, seed = cfg[:7]
         hero = cfg[7] if len(cfg) > 7 else 1
+        medium = cfg[8] if len(cfg) > 8 else False
         sc = ora.create_scene(pkg.scene.SCENES[scene]())
-        film, prof = sc.render(pkg.api.render_desc(w, h, spp, mb, light_samples=ls, seed=seed, hero_wavelengths=hero))
+        film, prof = sc.render(pkg.api.render_desc(w, h, spp, mb, light_samples=ls, seed=seed, hero_wavelengths=hero, medium_aware=medium))
         np.savez_compressed(os.path.join(out, name + ".npz"), film=film,
                             counters=np.array([prof.camera_rays, prof.bounce_rays, prof.shadow_rays, prof.env_hits], np.uint64))
         print(name, film[..., :3].mean(axis=(0, 1)), prof.bounce_rays, prof.shadow_rays, prof.env_hits)
+    if only:
+        return
     for scene in ("cornell_box", "mixed_primitives", "cornell_gem"):
         b = pkg.scene.SCENES[scene]()
         sc = ora.create_scene(b)
