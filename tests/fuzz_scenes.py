@@ -90,12 +90,42 @@ def random_scene(seed):
                               face_materials=api.material_id(api.TAG_MATERIAL, mats[k % len(mats)] & 0xFFFF))
             b.add_mesh_instance(mesh, mats[int(rng2.integers(len(mats)))] if rng2.random() < 0.5 else None,
                                 S.transform_from_data(None, None, rng2.uniform(-1.0, 1.0, 3).tolist()) if rng2.random() < 0.7 else None)
+    if seed >= 200000:  # (its own seed space again) participating media for the medium-aware walk: HG and Rayleigh mediums behind passthrough
+        # boundaries and inside glass, nested and overlapping, so that the list of tracked mediums grows, shrinks and overflows
+        rng3 = np.random.default_rng(seed + 4242)
+        ids = []
+        for k in range(int(rng3.integers(1, 6))):
+            if rng3.random() < 0.7:
+                ids.append(b.medium_hg("hg%d" % k, b.curve_flat(None, float(rng3.uniform(0.2, 1.9))), b.curve_flat(None, float(rng3.choice([0.0, 0.1, 0.6]))),
+                                       b.curve_flat(None, float(rng3.uniform(0.05, 3.0)))))
+            else:
+                ids.append(b.medium_rayleigh("ray%d" % k, b.curve_cauchy(None, float(rng3.uniform(1.1, 1.8)), float(rng3.uniform(0.0, 5000.0))), float(rng3.uniform(0.05, 2.0))))
+        tint = b.curve_flat(None, float(rng3.uniform(0.5, 1.0)))
+        eta = b.curve_cauchy(None, 1.45, 3540.0); one = b.curve_flat(None, 1.0); zero = b.curve_flat(None, 0.0)
+        for k in range(int(rng3.integers(2, 7))):
+            inner = int(rng3.choice(ids)); outer = int(rng3.choice([0, 0, int(rng3.choice(ids))]))
+            if rng3.random() < 0.6:
+                m = b.material_passthrough("pass%d" % k, tint, outer, inner)
+            else:
+                m = b.material_ggx("glass%d" % k, float(rng3.choice([0.01, 0.1, 0.4])), eta, one, zero, outer, inner)
+            o3 = rng3.uniform(-1.0, 1.0, 3).tolist()
+            if rng3.random() < 0.7:
+                b.add_sphere(float(rng3.uniform(0.3, 1.2)), o3, m, transform() if rng3.random() < 0.3 else None)
+            else:
+                p2, f2, n2 = S._octahedron()
+                mesh = b.add_mesh((p2 * rng3.uniform(0.5, 1.2, 3).astype(np.float32)).astype(np.float32), f2, None, face_materials=api.material_id(api.TAG_MATERIAL, 0))
+                b.add_mesh_instance(mesh, m, S.transform_from_data(None, None, o3))
     eye = rng.normal(size=3); eye = eye / np.linalg.norm(eye) * rng.uniform(3.0, 6.0); eye[2] = abs(eye[2]) * 0.5
     if rng.random() < 0.2:
         b.add_panorama_camera(eye.tolist(), (0.0, 0.0, 0.0), (float(rng.uniform(60, 360)), float(rng.uniform(40, 180))))
     else:
         b.add_camera(eye.tolist(), (0.0, 0.0, -0.3), float(rng.uniform(25, 60)), focal_distance=float(np.linalg.norm(eye)), aperture_diameter=float(rng.choice([0.0, 0.01, 0.1])))
     return b
+
+
+def medium_aware(seed):
+    """The seeds whose scenes hold media are rendered with the medium-aware walk."""
+    return seed >= 200000
 
 
 def random_rays(seed, n):

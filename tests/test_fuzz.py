@@ -13,13 +13,13 @@ def run(impl, oracle, pkg, seed, n_rays, w, h, spp):
     o, d = fuzz_scenes.random_rays(seed, n_rays)
     si, so = impl.create_scene(b), oracle.create_scene(b)
     ps.assert_hits_equal(si.intersect(o, d), so.intersect(o, d))
-    rd = pkg.api.render_desc(w, h, spp, 6, light_samples=int(1 + seed % 3), seed=seed, hero_wavelengths=4 if seed % 5 == 0 else 1)
+    rd = pkg.api.render_desc(w, h, spp, 6, light_samples=int(1 + seed % 3), seed=seed, hero_wavelengths=4 if seed % 5 == 0 and not fuzz_scenes.medium_aware(seed) else 1, medium_aware=fuzz_scenes.medium_aware(seed))
     film, prof = si.render(rd)
     ref, rprof = so.render(rd)
     ps.check_film(film, ref, prof, rprof)
 
 
-@pytest.mark.parametrize("seed", list(range(12)) + [100000, 100001])
+@pytest.mark.parametrize("seed", list(range(12)) + [100000, 100001] + list(range(200000, 200010)))   # >= 200000: media, the medium-aware walk
 def test_emulation_on_random_scenes(emu, oracle, pkg, seed):  # noqa: F811
     run(emu, oracle, pkg, seed, 2048, 20, 16, 3)
 
@@ -34,7 +34,7 @@ def test_emulation_bvh_walk_on_random_scenes(emu, oracle, pkg, monkeypatch, seed
 # 5427: a NaN pixel (NEE from a point of a light to that light), same on both sides; 49682: two walked meshes in one sweep table (an
 # octahedron that no longer fits and the gem) — a wave resumes parked rays of both, and the mesh sweep must not assume one mesh per wave;
 # 30295: pixel values of 3700, whose f32 ulp is above the absolute film bar
-@pytest.mark.parametrize("seed", list(range(100, 140)) + [5427, 49682, 30295] + list(range(100000, 100008)))   # >= 100000: several walked meshes per scene
+@pytest.mark.parametrize("seed", list(range(100, 140)) + [5427, 49682, 30295] + list(range(100000, 100008)) + list(range(200000, 200016)))   # >= 100000: several walked meshes per scene; >= 200000: media
 def test_engine_on_random_scenes(engine, oracle, pkg, seed):
     run(engine, oracle, pkg, seed, 1 << 14, 48, 40, 4)
 

@@ -24,7 +24,7 @@ for seed in range(first, first + count):
         se, so = engine.create_scene(b), oracle.create_scene(b)
         forms["sweep" if se.uses_leaf_sweep() else "walk"] += 1
         ps.assert_hits_equal(se.intersect(o, d), so.intersect(o, d))
-        rd = pkg.api.render_desc(W, H, SPP, 6, light_samples=int(1 + seed % 3), seed=seed, hero_wavelengths=4 if seed % 5 == 0 else 1)
+        rd = pkg.api.render_desc(W, H, SPP, 6, light_samples=int(1 + seed % 3), seed=seed, hero_wavelengths=4 if seed % 5 == 0 and not fuzz_scenes.medium_aware(seed) else 1, medium_aware=fuzz_scenes.medium_aware(seed))
         film, prof = se.render(rd)
         ref, rprof = so.render(rd)
         ps.check_film(film, ref, prof, rprof)
