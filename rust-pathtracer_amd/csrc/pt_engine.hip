@@ -1,11 +1,11 @@
-// pt_engine.hip — the HIP engine behind include/pt_api.h (gfx950 / MI355X only).
+// pt_engine.hip — the host side of the HIP engine behind include/pt_api.h (gfx950 / MI355X only).
 //
-// Wavefront path tracer: per bounce one launch each of extend -> shade -> shadow over segmented SoA queues in HBM
-// (pt_stages.h; workgroup b owns segment b of every queue and compacts survivors into its own segment with an LDS prefix
-// sum — no global atomics), persistent grids that stage the scene blob (or its core section) into LDS once per workgroup,
-// three traversal forms (pt_device.h: BVH walk, leaf sweep, sweep + parked mesh walks), per-slot energy accumulation
-// without float atomics, and an accumulate kernel that owns one film pixel per lane so film sums keep the reference's
-// order.  No CPU fallback: every entry point fails with PT_ERR_NO_DEVICE when HIP has no device.
+// Scene upload (one flat blob + texels per device), buffer management, the pass loop — per bounce one launch each of extend -> shade ->
+// shadow over segmented SoA queues in HBM, with HIP events around every launch so that per-stage device time is measured inside the
+// timed region —, the choice of kernel variant per scene (pt_launch.h: staging mode x traversal form x wavelengths x what the scene can
+// need), the probes of the trait surface, and pt_render_multi: one replica, host thread and stream per device and one RCCL reduce.
+// The kernels themselves are templates in pt_kernels.h, instantiated per family in pt_kern_*.hip.  No CPU fallback: every entry point
+// fails with PT_ERR_NO_DEVICE when HIP has no device.
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>

@@ -623,22 +623,26 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_extend_parked_dyn(const 
         ray_of(i2, &o, &d);
         settle(i2, o, d, st, sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st));
     };
+    // one loop, one drain site (the resume code is the bulk of the kernel: two inlined copies cost 25 KB of instruction cache): each turn
+    // takes the next 64 items of the current unit — or a new unit, or nothing when the counter has run out — and drains; the last turn
+    // drains the partial wave that is left
+    uint32_t first = 0, cnt = 0, off = 0;
+    bool more = true;
     for (;;) {
-        uint32_t first, cnt;
-        const bool more = next_unit(unit_counter, total_units, units_per_seg, seg_cap, count_in, &first, &cnt);
-        for (uint32_t off = 0; off < cnt; off += 64u) {
-            if (off + lane < cnt) {
-                const uint32_t i = first + off + lane;
-                F3 o, d;
-                ray_of(i, &o, &d);
-                SweepState st;
-                sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
-                const TriRay wtr = tri_ray_prepare(o, d);
-                settle(i, o, d, st, sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true));
-            }
-            park_drain(pk, park_count, false, resume);
+        if (off >= cnt && more) { more = next_unit(unit_counter, total_units, units_per_seg, seg_cap, count_in, &first, &cnt); off = 0; }
+        if (off + lane < cnt) {
+            const uint32_t i = first + off + lane;
+            F3 o, d;
+            ray_of(i, &o, &d);
+            SweepState st;
+            sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
+            const TriRay wtr = tri_ray_prepare(o, d);
+            settle(i, o, d, st, sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true));
         }
-        if (!more) { park_drain(pk, park_count, true, resume); break; }
+        off += 64u;
+        const bool last = !more && off >= cnt;
+        park_drain(pk, park_count, last, resume);
+        if (last) break;
     }
 }
 
@@ -671,30 +675,31 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked_dyn(const 
         const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
         settle(item2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, stop2, st));
     };
+    uint32_t first = 0, cnt = 0, off = 0;   // (one loop, one drain site: see k_extend_parked_dyn)
+    bool more = true;
     for (;;) {
-        uint32_t first, cnt;
-        const bool more = next_unit(unit_counter, total_units, units_per_seg, seg_cap, count_in, &first, &cnt);
-        for (uint32_t off = 0; off < cnt; off += 64u) {
-            const bool active = off + lane < cnt;
-            const uint32_t item = first + off + lane, flags = active ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
-            for (uint32_t l = 0; l < light_samples; ++l) {   // one ray of every item per step, so that a step parks at most one ray per lane
-                ShadowRayT<NL> ray;
-                if (active && load_shadow_ray<NL>(shadow, item, l, &ray)) {
-                    const bool env = ((flags >> l) & 1u) != 0;
-                    float bound = PT_INF; int stop = shadow_env_stop(s);
-                    if (!env && !shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) {
-                        for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
-                    } else {
-                        SweepState st;
-                        sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
-                        const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
-                        settle(item, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true));
-                    }
+        if (off >= cnt && more) { more = next_unit(unit_counter, total_units, units_per_seg, seg_cap, count_in, &first, &cnt); off = 0; }
+        const bool active = off + lane < cnt;
+        const uint32_t item = first + off + lane, flags = active ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
+        off += 64u;
+        const bool last_turn = !more && off >= cnt;
+        for (uint32_t l = 0; l < light_samples; ++l) {   // one ray of every item per step, so that a step parks at most one ray per lane
+            ShadowRayT<NL> ray;
+            if (active && load_shadow_ray<NL>(shadow, item, l, &ray)) {
+                const bool env = ((flags >> l) & 1u) != 0;
+                float bound = PT_INF; int stop = shadow_env_stop(s);
+                if (!env && !shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) {
+                    for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
+                } else {
+                    SweepState st;
+                    sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
+                    const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
+                    settle(item, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true));
                 }
-                park_drain(pk, park_count, false, resume);
             }
+            park_drain(pk, park_count, last_turn && l + 1 == light_samples, resume);
         }
-        if (!more) { park_drain(pk, park_count, true, resume); break; }
+        if (last_turn) break;
     }
 }
 // pt.rs:349-392, 596: an item's rays summed in order, divided by L, added to its slot (workgroup b owns segment b, as everywhere)
