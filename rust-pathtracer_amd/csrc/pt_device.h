@@ -730,6 +730,68 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
         // chunk culled by the closest hit the chunks before it left — the same leaves in the same order as the walk below
         const uint32_t leaf_count = PT_UNIFORM(bu(s, mesh + PT_MESH_LEAF_COUNT));
         const bool quick = cr.fast && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f;
+        // the settled box tests' triangles in bit order, against the running closest hit; returns true when the search is over (early stop)
+        auto triangles = [&](uint64_t hit, uint32_t first) {
+            while (hit != 0) {
+                const uint32_t k = ctz64(hit);
+                hit &= hit - 1;
+                const uint32_t t = mu(s, leaf_off + (first + k) * 8u + 3u);
+                F4 q0 = mf4(s, t), q1 = mf4(s, t + 4), q2 = mf4(s, t + 8);
+                TriHit th;
+                if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
+                    st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th;
+                    limit = __builtin_fminf(st.closest, bound);
+                    if (stop == PT_STOP_ANY) { st.hit = 0; return true; }
+                    if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
+                        uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+                        if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) { st.hit = 0; return true; }
+                    }
+                }
+            }
+            return false;
+        };
+        const uint32_t group_off = PT_UNIFORM(bu(s, mesh + PT_MESH_GROUP_OFF));
+        if (group_off != 0u) {
+            // A bigger mesh (the gem of C3: 302 leaves): the boxes of the groups of PT_MESH_GROUP consecutive leaves first, every lane the
+            // same box (wave-uniform addresses); then every lane the leaves of the groups ITS ray enters, in order, a group's triangles
+            // right after its boxes.  A group's box holds its leaves' boxes, so a leaf whose box passes AABB::hit is in an entered group
+            // (the slab test is monotone under rounding, as for a BVH ancestor); same leaves in the same order as the walk.
+            const uint32_t groups = (leaf_count + PT_MESH_GROUP - 1u) / PT_MESH_GROUP;
+            uint32_t entered = 0;
+            for (uint32_t g = 0; g < groups; ++g) {
+                const uint32_t e = PT_UNIFORM(group_off + g * 8u);
+                const F4 ga = mf4(s, e), gb = mf4(s, e + 4);
+                float entry = 0.0f;
+                int ct = quick ? aabb_classify(ga, gb, cr, PT_UNIFORM(pt_f2u(gb.w)) != 0u, &entry) : 2;
+                if (ct == 1 && cull && beyond(entry, limit, cr.base)) ct = 0;
+                entered |= ct != 0 ? 1u << g : 0u;
+            }
+            while (entered != 0u) {
+                const uint32_t g = (uint32_t)__builtin_ctz(entered);
+                entered &= entered - 1u;
+                const uint32_t first = g * PT_MESH_GROUP, chunk = leaf_count - first < PT_MESH_GROUP ? leaf_count - first : PT_MESH_GROUP;
+                uint32_t hit = 0, unc = 0;
+                for (uint32_t t = 0; t < PT_MESH_GROUP; ++t) {
+                    if (t >= chunk) break;
+                    const uint32_t e = leaf_off + (first + t) * 8u;
+                    const F4 ta = mf4(s, e), tb = mf4(s, e + 4);
+                    float entry = 0.0f;
+                    int ct = quick ? aabb_classify(ta, tb, cr, pt_f2u(tb.w) != 0u, &entry) : 2;
+                    if (ct == 1 && cull && beyond(entry, limit, cr.base)) ct = 0;
+                    hit |= ct == 1 ? 1u << t : 0u; unc |= ct == 2 ? 1u << t : 0u;
+                }
+                while (unc != 0u) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(unc);
+                    unc &= unc - 1u;
+                    const uint32_t e = leaf_off + (first + k) * 8u;
+                    float entry;
+                    PT_STAT(box_exact);
+                    if (aabb_hit_exact(mf4(s, e), mf4(s, e + 4), lo, ld, &entry)) hit |= 1u << k;
+                }
+                if (triangles(hit, first)) return;
+            }
+            return;
+        }
         for (uint32_t first = 0; first < leaf_count; first += 64u) {
             const uint32_t chunk = leaf_count - first < 64u ? leaf_count - first : 64u;
             uint32_t hit_lo = 0, hit_hi = 0, unc_lo = 0, unc_hi = 0;
@@ -751,22 +813,7 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                 PT_STAT(box_exact);
                 if (aabb_hit_exact(mf4(s, e), mf4(s, e + 4), lo, ld, &entry)) hit |= 1ull << k;
             }
-            while (hit != 0) {
-                const uint32_t k = ctz64(hit);
-                hit &= hit - 1;
-                const uint32_t t = mu(s, leaf_off + (first + k) * 8u + 3u);
-                F4 q0 = mf4(s, t), q1 = mf4(s, t + 4), q2 = mf4(s, t + 8);
-                TriHit th;
-                if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
-                    st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th;
-                    limit = __builtin_fminf(st.closest, bound);
-                    if (stop == PT_STOP_ANY) { st.hit = 0; return; }
-                    if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
-                        uint32_t im = bu(s, inst + PT_INST_MATERIAL);
-                        if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) { st.hit = 0; return; }
-                    }
-                }
-            }
+            if (triangles(hit, first)) return;
         }
         return;
     }

@@ -29,6 +29,7 @@ float box_area(const Box& b) {  // src/aabb.rs:97-100
 }
 
 uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+float bits_f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 // Skip-link BVH in pre-order, SAH with 6 buckets on the widest centroid axis, median split when the centroids
 // coincide, one shape per leaf: the reference's build (src/accelerator/bvh.rs:299-457) emitted directly in
@@ -344,8 +345,25 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                 ++leaf_count;
             }
         }
+        // group boxes for mesh_sweep: a ray tests the group boxes first and then only the leaves of the groups it enters (a box that
+        // holds a leaf's box passes AABB::hit whenever the leaf's does, like a BVH ancestor)
+        uint32_t group_off = 0;
+        if (leaf_count > PT_MESH_GROUP_MIN) {
+            pad16(md);
+            group_off = (uint32_t)md.size();
+            for (uint32_t first = 0; first < leaf_count; first += PT_MESH_GROUP) {
+                float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (uint32_t t = first; t < leaf_count && t < first + PT_MESH_GROUP; ++t) {
+                    const uint32_t* lf = &md[leaf_off + t * 8u];
+                    for (int k = 0; k < 3; ++k) { mn[k] = std::fmin(mn[k], bits_f(lf[k])); mx[k] = std::fmax(mx[k], bits_f(lf[4 + k])); }
+                }
+                const uint32_t flat = (mn[0] == mx[0] || mn[1] == mx[1] || mn[2] == mx[2]) ? 1u : 0u;
+                uint32_t rec[8] = {fbits(mn[0]), fbits(mn[1]), fbits(mn[2]), 0u, fbits(mx[0]), fbits(mx[1]), fbits(mx[2]), flat};
+                md.insert(md.end(), rec, rec + 8);
+            }
+        }
         mesh_off[mi] = (uint32_t)w.size();
-        uint32_t rec[PT_MESH_WORDS] = {node_off, (uint32_t)(nodes.size() / PT_NODE_WORDS), tri_off, normal_off, m.face_count, leaf_off, leaf_count, 0};
+        uint32_t rec[PT_MESH_WORDS] = {node_off, (uint32_t)(nodes.size() / PT_NODE_WORDS), tri_off, normal_off, m.face_count, leaf_off, leaf_count, group_off};
         w.insert(w.end(), rec, rec + PT_MESH_WORDS);
     }
 
