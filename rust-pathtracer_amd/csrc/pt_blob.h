@@ -43,7 +43,9 @@
 #define PT_MESH_LEAF_OFF 5     /* leaf list for mesh_sweep (0 = none): per leaf in pre-order 8 words = min.xyz, triangle word offset, max.xyz, flat */
 #define PT_MESH_LEAF_COUNT 6
 #define PT_MESH_GROUP_OFF 7    /* meshes of more than PT_MESH_GROUP_MIN leaves: per PT_MESH_GROUP consecutive leaves 8 words = the box that holds theirs (min.xyz, 0, max.xyz, flat); 0 = none */
+#ifndef PT_MESH_GROUP
 #define PT_MESH_GROUP 16
+#endif
 #define PT_MESH_GROUP_MIN 96
 #define PT_MESH_SWEEP_MAX 512  /* meshes of at most this many triangles get a leaf list */
 

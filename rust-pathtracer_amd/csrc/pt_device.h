@@ -757,18 +757,19 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
             // right after its boxes.  A group's box holds its leaves' boxes, so a leaf whose box passes AABB::hit is in an entered group
             // (the slab test is monotone under rounding, as for a BVH ancestor); same leaves in the same order as the walk.
             const uint32_t groups = (leaf_count + PT_MESH_GROUP - 1u) / PT_MESH_GROUP;
-            uint32_t entered = 0;
+            static_assert((PT_MESH_SWEEP_MAX + PT_MESH_GROUP - 1) / PT_MESH_GROUP <= 64 && PT_MESH_GROUP <= 32, "one bit per group, one per leaf of a group");
+            uint64_t entered = 0;
             for (uint32_t g = 0; g < groups; ++g) {
                 const uint32_t e = PT_UNIFORM(group_off + g * 8u);
                 const F4 ga = mf4(s, e), gb = mf4(s, e + 4);
                 float entry = 0.0f;
                 int ct = quick ? aabb_classify(ga, gb, cr, PT_UNIFORM(pt_f2u(gb.w)) != 0u, &entry) : 2;
                 if (ct == 1 && cull && beyond(entry, limit, cr.base)) ct = 0;
-                entered |= ct != 0 ? 1u << g : 0u;
+                entered |= ct != 0 ? 1ull << g : 0ull;
             }
-            while (entered != 0u) {
-                const uint32_t g = (uint32_t)__builtin_ctz(entered);
-                entered &= entered - 1u;
+            while (entered != 0) {
+                const uint32_t g = ctz64(entered);
+                entered &= entered - 1;
                 const uint32_t first = g * PT_MESH_GROUP, chunk = leaf_count - first < PT_MESH_GROUP ? leaf_count - first : PT_MESH_GROUP;
                 uint32_t hit = 0, unc = 0;
                 for (uint32_t t = 0; t < PT_MESH_GROUP; ++t) {

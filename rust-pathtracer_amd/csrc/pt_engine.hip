@@ -388,7 +388,8 @@ static pt_status scene_to_device(pt_scene* sc) {
     if (env_u32("PT_AMD_NO_MESH_SWEEP", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_MESH_SWEEP;
     sc->blob_words = (uint32_t)sc->host.blob.size();
     const bool no_lds = env_u32("PT_AMD_NO_LDS", 0) != 0;
-    sc->lds_mode = no_lds ? PT_LDS_NONE : (sc->blob_words * 4 <= kLdsBlobLimitBytes ? PT_LDS_ALL
+    const uint32_t all_limit = env_u32("PT_AMD_LDS_ALL_LIMIT", kLdsAllLimitBytes);   // (experiments: the largest blob staged whole)
+    sc->lds_mode = no_lds ? PT_LDS_NONE : (sc->blob_words * 4 <= (all_limit < kLdsBlobLimitBytes ? all_limit : kLdsBlobLimitBytes) ? PT_LDS_ALL
                  : (sc->host.blob[PT_HDR_CORE_WORDS] * 4 <= kLdsBlobLimitBytes && !env_u32("PT_AMD_NO_CORE_LDS", 0) ? PT_LDS_CORE : PT_LDS_NONE));
     e = hipMalloc(&sc->d_blob, sizeof(uint32_t) * sc->host.blob.size());
     if (e == hipSuccess) e = hipMalloc(&sc->d_tex, sizeof(float) * (sc->host.tex.size() + 4));
@@ -632,7 +633,8 @@ pt_status pt_debug_numerics(int which, size_t n, const float* x, const float* y,
 // Not part of pt_api.h: size of the scene blob and whether kernels read it from LDS (reported by bench.py).
 uint32_t pt_debug_scene_info(pt_scene* sc, int what) {
     switch (what) { case 0: return sc->blob_words * 4; case 1: return (uint32_t)sc->lds_mode; case 2: return sc->host.light_count; case 3: return (uint32_t)sc->num_cus;
-                    case 4: return sc->host.blob[PT_HDR_SWEEP_OFF] != 0 && !(sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP) ? 1u : 0u; default: return 0; }
+                    case 4: return sc->host.blob[PT_HDR_SWEEP_OFF] != 0 && !(sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP) ? 1u : 0u;
+                    case 7: return sc->host.blob[PT_HDR_CORE_WORDS] * 4; default: return 0; }
 }
 
 }  // extern "C"

@@ -40,6 +40,12 @@ inline void go(const LaunchCfg& c, K kernel, Args... args) { hipLaunchKernelGGL(
 #define PT_PARK_WAVES 4
 #endif
 #define PT_PARK_OCC __attribute__((amdgpu_waves_per_eu(PT_PARK_WAVES)))
+// (the closest-hit form gains from a fifth wave, the light-sample form loses: tools/park_occupancy.sh, C3 k_extend_parked 3288 / 2708 / 2797 / 2883 us and
+// k_shadow_parked 3745 / 3919 / 3917 / 4142 us at 4 / 5 / 6 / 8 waves; C4 1222 / 1117 / 1156 / 1199 and 6503 / 7018 / 7362 / 7411)
+#ifndef PT_PARK_EXTEND_WAVES
+#define PT_PARK_EXTEND_WAVES 5
+#endif
+#define PT_PARK_EXTEND_OCC __attribute__((amdgpu_waves_per_eu(PT_PARK_EXTEND_WAVES)))
 // (forms of k_shade, see the kernel: FULL = PT_SHADE_WAVES / PT_SHADE4_WAVES above; measured with tools/shade_occupancy.sh.  FULL on C4:
 // 11442 us at 3 waves, 14735 at 2, 11869 at 4; NO_ENV on C3: 3564 at 3 or 2, 3902 at 4)
 #ifndef PT_SHADE_NO_ENV_WAVES
@@ -473,7 +479,7 @@ __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, b
 }
 
 template <int USE_LDS>
-__global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+__global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                      Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
                                                                      uint32_t* __restrict__ park_all) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -599,7 +605,7 @@ __device__ __forceinline__ bool next_unit(uint32_t* __restrict__ counter, uint32
 }
 
 template <int USE_LDS>
-__global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_extend_parked_dyn(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+__global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked_dyn(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                          Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
                                                                          uint32_t* __restrict__ park_all, uint32_t n_segments, uint32_t* __restrict__ unit_counter) {
     extern __shared__ __align__(16) uint32_t lds[];

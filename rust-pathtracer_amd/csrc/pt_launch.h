@@ -12,7 +12,11 @@ enum { PT_LDS_NONE = 0, PT_LDS_ALL = 1, PT_LDS_CORE = 2 };                 // wh
 enum { PT_SHADE_LEAN = 0, PT_SHADE_NO_ENV = 1, PT_SHADE_FULL = 2, PT_SHADE_MEDIUM = 3 };   // k_shade forms (MEDIUM: k_shade_medium, one wavelength)
 enum { PT_FORM_ANY = 0, PT_FORM_WALK = 1, PT_FORM_SWEEP = 2, PT_FORM_POOLED = 3, PT_FORM_PARKED = 4 };  // traversal kernels
 constexpr int kBlock = 256;
-constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // stage the blob in LDS when it fits (keeps >= 2 workgroups per CU)
+constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // the most LDS a staged blob (or its core section) may take
+// The whole blob is staged only while it leaves the CU its occupancy: six workgroups of 24 KB fit the 160 KB.  Measured (tools/lds_mode.sh):
+// the 65 KB blob of C3 staged whole leaves two workgroups per CU, 615 Msamples/s; its 6.7 KB core alone, the mesh read through L1/L2,
+// 752.  C2's 14 KB blob staged whole: 1519; its 7 KB core alone: 1089 (the sweep reads the triangles of the two boxes for every ray).
+constexpr uint32_t kLdsAllLimitBytes = 24 * 1024;
 constexpr uint32_t kParkCap = 512, kParkFields = 16;
 enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_FIELDS };  // per-workgroup statistics (Profile counters)
 uint32_t pool_lds_bytes();  // static LDS of the pooled traversal kernels, on top of the staged blob

@@ -32,6 +32,8 @@ pt_status ptemu_scene_create(const pt_scene_desc* d, pt_scene** out) {
 void ptemu_scene_destroy(pt_scene* sc) { delete sc; }
 uint32_t ptemu_debug_scene_info(pt_scene* sc, int what) {
     const std::vector<uint32_t>& w = sc->host.blob;
+    if (what == 0) return (uint32_t)w.size() * 4u;          // bytes of the blob
+    if (what == 7) return w[PT_HDR_CORE_WORDS] * 4u;        // bytes of its core section
     if (what == 4) return w[PT_HDR_SWEEP_OFF] != 0 && !(w[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP) ? 1u : 0u;
     if ((what == 5 || what == 6) && w[PT_HDR_SWEEP_OFF] != 0) {  // 5: mask bits in use, 6: bits whose box test is a copy
         uint32_t bits = 0, copies = 0;
