@@ -722,7 +722,8 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
     const uint32_t node_off = bu(s, mesh + PT_MESH_NODE_OFF), node_count = bu(s, mesh + PT_MESH_NODE_COUNT), tri_off = bu(s, mesh + PT_MESH_TRI_OFF);
     float limit = __builtin_fminf(st.closest, bound);
     const uint32_t leaf_off = bu(s, mesh + PT_MESH_LEAF_OFF);
-    // (bounded searches — light rays, which also stop at the first opaque hit — prune so much of the tree that the walk wins)
+    // (bounded searches — light rays, which also stop at the first opaque hit — prune so much of the tree that the walk wins; measured
+    // again with the group boxes below: C3 k_shadow_parked 5730 us through the grouped sweep, 5635 through the walk)
     // The mesh sweep reads its leaf list with wave-uniform addresses: every lane that takes it must be in the same mesh.  A table
     // with two walked meshes can resume lanes of both in one wave — those waves walk (same result, lane by lane).
     if (leaf_off != 0u && !(bound < PT_INF) && !(flags & (PT_FLAG_NO_SWEEP | PT_FLAG_NO_MESH_SWEEP)) && !PT_WAVE_ANY(mesh != PT_UNIFORM(mesh))) {

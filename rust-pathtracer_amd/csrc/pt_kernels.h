@@ -172,10 +172,37 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
     const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
     uint32_t st_vertices = 0, st_shadow = 0, st_env = 0;
     const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
-    for (uint32_t r = 0; r < rounds; ++r) {  // whole waves stay in the loop: the appends are ballots
-        uint32_t j = r * blockDim.x + threadIdx.x;
-        bool active = j < n;
-        uint32_t i = base + j;
+    // FULL form (scenes with an environment that light samples can pick): a path that left the scene is a cheap vertex (one MIS-weighted
+    // emission), a surface vertex an expensive one (C4: six light samples through the importance map), and a wave that holds both runs the
+    // expensive part with the lanes of the cheap ones idle (C4: 38 % of the vertices, lane utilisation 0.60).  So a wave shades the
+    // environment vertices of its 64 items at once and keeps the surface vertices' indices in a list of its own, shading them 64 at a time
+    // whenever the list holds that many (and what is left at the end): full waves in the expensive part.  No vertex' result depends on
+    // when it is shaded (queue appends are order-free, energy is keyed by slot).  One call site of the vertex body for both.
+    constexpr bool kSplit = FORM == PT_SHADE_FULL;
+    __shared__ uint32_t later[kSplit ? kBlock * 2 : 1];   // per wave: 128 item indices (fewer than 64 left over + at most 64 new)
+    uint32_t* my_later = later + (kSplit ? (threadIdx.x >> 6) * 128u : 0u);
+    uint32_t later_count = 0;   // (wave-uniform)
+    for (uint32_t r = 0;;) {  // whole waves stay in the loop: the appends are ballots
+        uint32_t i = 0;
+        bool active = false;
+        if (kSplit && (later_count >= 64u || (r == rounds && later_count > 0u))) {
+            const uint32_t take = later_count < 64u ? later_count : 64u;
+            later_count -= take;
+            active = lane_id() < take;
+            if (active) i = my_later[later_count + lane_id()];
+        } else if (r < rounds) {
+            const uint32_t j = r * blockDim.x + threadIdx.x;
+            ++r;
+            active = j < n; i = base + j;
+            if (kSplit) {
+                const bool surface = active && qf(hits, HS_T, i) >= 0.0f;
+                const unsigned long long m = __ballot(surface);
+                if (surface) my_later[later_count + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = i;
+                later_count += (uint32_t)__popcll(m);
+                active = active && !surface;
+                __builtin_amdgcn_wave_barrier();   // (the list is the wave's own: its writes are in LDS before any of its lanes reads them)
+            }
+        } else break;
         PathVertexT<NL> pv; Hit hit; hit.valid = false;
         bool wants_item = false;
         if (active) {
