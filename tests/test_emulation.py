@@ -49,7 +49,7 @@ def test_materials_bit_exact(emu, oracle, scene):
     ("empty_env", 1, 1, 1, 0, {}),                            # edge cases: no instances, 1x1 film, no bounces
     ("empty_env", 5, 3, 2, 4, {"light_samples": 3}),
     ("cornell_box", 3, 2, 1, 1, {"tile": (64, 64)}),          # film smaller than a tile
-    ("hdri_c4_small", 24, 24, 4, 4, {"light_samples": 3}),    # monkey mesh: hot BVH nodes re-laid out breadth first
+    ("hdri_c4_small", 24, 24, 4, 4, {"light_samples": 3}),    # monkey mesh: walked through its BVH (the triangles do not fit the sweep table)
     ("white_furnace", 16, 16, 12, 8, {"light_samples": 6}),
     ("cornell_box", 40, 36, 11, 6, {"hero_wavelengths": 4}),  # C5 shape: hero wavelength + 3 passengers
     ("mixed_primitives", 32, 32, 6, 6, {"hero_wavelengths": 4, "light_samples": 3}),
