@@ -641,8 +641,11 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
         const uint32_t kf = PT_UNIFORM(pt_f2u(h0.y));
         float entry = 0.0f;
         bool ih = false, iu = true;   // (a ray the filter cannot take: every box is undecided)
-        if (quick) aabb_classify_by((kf >> 11) & 7u, a, b, wr, &entry, &ih, &iu);
-        if (bounded && cull_top && ih && (kf & 0xffu) != PT_SHAPE_SPHERE && beyond(entry, bound, wr.base)) ih = false;
+        if ((kf & PT_SWEEP_NO_OWN_TEST) && !(flags & PT_FLAG_OWN_TESTS)) { ih = true; iu = false; }   // the instance's box holds every leaf's: it passes whenever one of them does (pt_blob.h)
+        else {
+            if (quick) aabb_classify_by((kf >> 11) & 7u, a, b, wr, &entry, &ih, &iu);
+            if (bounded && cull_top && ih && (kf & 0xffu) != PT_SHAPE_SPHERE && beyond(entry, bound, wr.base)) ih = false;
+        }
         mark(ih, iu, pt_f2u(h0.z), pt_f2u(h0.w));
         const bool inside = ih || iu;
         if ((kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH && (kf >> 24) != 0u && PT_WAVE_ANY(inside)) {
@@ -849,8 +852,12 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
 // Phase 3: the primitive tests of the set bits in pre-order (ties are broken by that order, as in world_hit_walk).  With
 // `park_at_walked` the loop returns true when the next bit is a walked mesh instance, leaving the bit set: the caller
 // parks the state and resumes with sweep_resume; otherwise walked meshes are walked in line.
+// `known_inst`, `known_t`: an instance whose test the caller has run on this very ray already (the nearest light of a light-sample ray,
+// nearest_light_hit) and the distance it found: the leaf takes that distance through the interval rule of its shape instead of running
+// the test again — the same number through the same comparison.
 template <bool WALKS = true>
-PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bound, int stop, SweepState& st, bool park_at_walked) {
+PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bound, int stop, SweepState& st, bool park_at_walked,
+                     uint32_t known_inst = 0xffffffffu, float known_t = 0.0f) {
     const uint32_t bits_off = bu(s, PT_HDR_SWEEP_BITS_OFF);
     while (st.hit != 0) {
         const uint32_t k = ctz64(st.hit);
@@ -886,6 +893,12 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
                     uint32_t im = bu(s, inst + PT_INST_MATERIAL);
                     if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) st.hit = 0;  // something opaque in front of every light
                 }
+            }
+        } else if ((kf >> 16) == known_inst) {
+            // rect.rs / disk.rs reject t > t1, sphere.rs accepts t < t1 (the nearer root first; the farther one is beyond it)
+            if ((kf & 0xffu) == PT_SHAPE_SPHERE ? known_t < st.closest : !(known_t > st.closest)) {
+                st.closest = known_t; st.best_inst = kf >> 16; st.best_triw = 0;
+                if (stop == PT_STOP_ANY) st.hit = 0;   // (a light: PT_STOP_NONLIGHT does not end at it)
             }
         } else {
             F3 lo, ld;
@@ -1092,14 +1105,14 @@ PT_HD bool sweep_best_is_light(const SceneView& s, const SweepState& st) {
     return PT_MATERIAL_TAG(m) == PT_TAG_LIGHT;
 }
 template <bool WALKS = true>
-PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, int stop) {
+PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, int stop, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f) {
     SweepState st;
     sweep_state_init(st, sweep_masks(s, o, d, bound));
     const TriRay wtr = tri_ray_prepare(o, d);
 #if !defined(__HIP_DEVICE_COMPILE__)
     if ((bu(s, PT_HDR_FLAGS) & (PT_FLAG_REPLAY | PT_FLAG_SWEEP_WALKS)) == PT_FLAG_REPLAY) { sweep_run_replay(s, o, d, wtr, st); return sweep_finish(s, o, d, st, out); }
 #endif
-    sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, false);
+    sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, false, known_inst, known_t);
     return sweep_finish(s, o, d, st, out);
 }
 
@@ -1209,21 +1222,22 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
 #define PT_TRAV_SWEEP 2
 PT_HD bool scene_uses_sweep(const SceneView& s) { return bu(s, PT_HDR_SWEEP_OFF) != 0u && !(bu(s, PT_HDR_FLAGS) & PT_FLAG_NO_SWEEP); }
 template <int TRAV = PT_TRAV_ANY>
-PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_INF, int stop = PT_STOP_NONE) {
-    if (TRAV == PT_TRAV_SWEEP) return world_hit_sweep<false>(s, o, d, out, bound, stop);
-    if (TRAV == PT_TRAV_ANY && scene_uses_sweep(s)) return world_hit_sweep<true>(s, o, d, out, bound, stop);
+PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_INF, int stop = PT_STOP_NONE, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f) {
+    if (TRAV == PT_TRAV_SWEEP) return world_hit_sweep<false>(s, o, d, out, bound, stop, known_inst, known_t);
+    if (TRAV == PT_TRAV_ANY && scene_uses_sweep(s)) return world_hit_sweep<true>(s, o, d, out, bound, stop, known_inst, known_t);
     return world_hit_walk(s, o, d, out, bound, stop);
 }
 
 // Nearest hit among the light instances that the reference's walk would test for this ray (an instance is tested iff
 // its own leaf box passes AABB::hit; ancestor boxes contain it, and the slab test is monotone under rounding, so they
 // pass too).  Returns +inf if no light is hit.  Same arithmetic as the walk, so the distance is the one the walk finds.
-PT_HD float nearest_light_hit(const SceneView& s, F3 o, F3 d) {
+PT_HD float nearest_light_hit(const SceneView& s, F3 o, F3 d, uint32_t* which = nullptr) {
     const uint32_t n = bu(s, PT_HDR_LIGHT_COUNT), lo_ = bu(s, PT_HDR_LIGHT_OFF), ln = bu(s, PT_HDR_LIGHT_NODE_OFF), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
     RayPrep wr = ray_prepare(o, d);
     if (bu(s, PT_HDR_FLAGS) & PT_FLAG_EXACT_SLAB) wr.fast = false;
     const bool quick = wr.fast && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f;
     float best = PT_INF;
+    uint32_t light = 0xffffffffu;
     for (uint32_t k = 0; k < n; ++k) {
         uint32_t node = bu(s, ln + k);
         F4 a = bf4(s, node), b = bf4(s, node + 4);
@@ -1233,8 +1247,9 @@ PT_HD float nearest_light_hit(const SceneView& s, F3 o, F3 d) {
         F3 l0, l1;
         instance_local_ray(s, inst, o, d, &l0, &l1);
         Hit h;
-        if (analytic_hit(s, inst, bu(s, inst + PT_INST_KIND), l0, l1, PT_INF, &h)) best = __builtin_fminf(best, h.t);
+        if (analytic_hit(s, inst, bu(s, inst + PT_INST_KIND), l0, l1, PT_INF, &h) && h.t < best) { best = h.t; light = bu(s, lo_ + k); }
     }
+    if (which != nullptr) *which = light;   // (the instance that gave the distance; 0xffffffff: none)
     return best;
 }
 

@@ -502,9 +502,11 @@ PT_HD void shadow_ray_contribution(const SceneView& s, const float* lambda, cons
 }
 // The bound of a light ray's search: the nearest light hit (+inf: no light on the ray, nothing to trace), or "unbounded"
 // when the scene forbids the shortcut.  Returns false when the ray cannot contribute.
-PT_HD bool shadow_light_bound(const SceneView& s, F3 o, F3 d, float* bound, int* stop) {
+PT_HD bool shadow_light_bound(const SceneView& s, F3 o, F3 d, float* bound, int* stop, uint32_t* light = nullptr) {
+    if (light != nullptr) *light = 0xffffffffu;
     if (bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_CULL)) { *bound = PT_INF; *stop = PT_STOP_NONE; return true; }
-    float t_light = nearest_light_hit(s, o, d);
+    float t_light = nearest_light_hit(s, o, d, light);
+    if (light != nullptr && (bu(s, PT_HDR_FLAGS) & PT_FLAG_NO_KNOWN_LIGHT)) *light = 0xffffffffu;
     *bound = t_light; *stop = PT_STOP_NONLIGHT;
     return t_light < PT_INF;
 }
@@ -517,10 +519,11 @@ template <int NL, int TRAV = PT_TRAV_ANY, bool ENV = true>
 PT_HD void stage_shadow_ray(const SceneView& s, const float* lambda, const ShadowRayT<NL>& ray, bool env, float* contribution) {
     for (int k = 0; k < NL; ++k) contribution[k] = 0.0f;
     float bound = PT_INF; int stop = PT_STOP_NONE;
+    uint32_t light = 0xffffffffu;   // the light whose hit bounds the search: its test has been run, phase 3 takes the distance (sweep_run)
     if (ENV && env) stop = shadow_env_stop(s);
-    else if (!shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) return;
+    else if (!shadow_light_bound(s, ray.o, ray.d, &bound, &stop, &light)) return;
     Hit sh;
-    bool hit = world_hit<TRAV>(s, ray.o, ray.d, &sh, bound, stop);
+    bool hit = world_hit<TRAV>(s, ray.o, ray.d, &sh, bound, stop, light, bound);
     shadow_ray_contribution<NL>(s, lambda, ray, ENV && env, hit, sh, contribution);
 }
 // One light-sample item: L rays, summed in order, divided by L (pt.rs:349-392, 596)

@@ -170,6 +170,30 @@ def test_filtered_slab_test_and_culling_change_nothing(engine, pkg, monkeypatch)
         parity_suite.assert_hits_equal(hits_fast, plain.intersect(o, d))
 
 
+@pytest.mark.parametrize("scene,L", [("cornell_box", 2), ("mixed_small", 3), ("mixed_primitives", 3), ("cornell_gem", 2)])
+def test_sweep_shortcuts_change_nothing(engine, pkg, monkeypatch, scene, L):
+    """Two shortcuts of the leaf sweep: an untransformed mesh instance whose leaves are all in the table skips its own box test (every
+    leaf's box lies in it), and phase 3 of a light-sample ray takes the distance of the light that bounds it from the light pre-pass
+    instead of testing that light again.  Switched off one by one and together: the same film, counters and hits bit for bit."""
+    import parity_suite
+    b = pkg.scene.SCENES[scene]()
+    rd = pkg.api.render_desc(160, 120, 9, 8, light_samples=L, seed=4)
+    o, d = parity_suite.golden_rays(scene, 1 << 15, 5)
+    ref = engine.create_scene(b)
+    base, pbase = ref.render(rd)
+    hits = ref.intersect(o, d)
+    for env in ({"PT_AMD_NO_KNOWN_LIGHT": "1"}, {"PT_AMD_OWN_TESTS": "1"}, {"PT_AMD_NO_KNOWN_LIGHT": "1", "PT_AMD_OWN_TESTS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other = engine.create_scene(b)
+        for k in env:
+            monkeypatch.delenv(k)
+        film, prof = other.render(rd)
+        assert np.array_equal(base.view(np.uint32), film.view(np.uint32)), env
+        assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits), env
+        parity_suite.assert_hits_equal(hits, other.intersect(o, d))
+
+
 @pytest.mark.parametrize("scene,L", [("cornell_gem", 2), ("hdri_c4_small", 6), ("mixed_primitives", 3)])
 def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
     """Hybrid scenes (sweep table + walked meshes): parked rays resumed in full waves, walked meshes in line, mesh sweep
