@@ -133,7 +133,6 @@
 #define PT_FLAG_NO_MESH_SWEEP 64u  /* diagnostics (PT_AMD_NO_MESH_SWEEP=1): walk every mesh BVH */
 #define PT_FLAG_NO_SWEEP 16u      /* diagnostics (PT_AMD_NO_SWEEP=1): always walk the BVHs */
 #define PT_FLAG_NO_KNOWN_LIGHT 256u /* diagnostics (PT_AMD_NO_KNOWN_LIGHT=1): phase 3 tests the nearest light again instead of taking the light pre-pass' distance */
-#define PT_FLAG_OWN_TESTS 512u     /* diagnostics (PT_AMD_OWN_TESTS=1): every mesh instance of the sweep table keeps its own box test (PT_SWEEP_NO_OWN_TEST off) */
 #define PT_FLAG_REPLAY 128u       /* diagnostics (host emulation): phase 3 of the sweep as unbounded tests + ordered replay (the pooled form's logic) */
 #define PT_FLAG_NO_TOP_CULL 1u   /* a Disk instance exists: its reference box (radius/2, disk.rs:24-28) does not contain it */
 
@@ -155,8 +154,6 @@
 // distances from its record to its copies permuted for a dominant x axis (y, z, x) and y axis (z, x, y) — the mesh-data
 // section keeps the triangles of every mesh in the table in all three vertex permutations (triangle_test_permuted)
 #define PT_SWEEP_WALKED 0x400u     /* kind/flags word: a mesh instance whose triangles are not in the table; its BVH is walked */
-#define PT_SWEEP_NO_OWN_TEST 0x4000u /* kind/flags word: an untransformed mesh instance with its triangle leaves in the table and no leaf that shares its box:
-                                       every leaf's box lies in the instance's, so a leaf whose box passes AABB::hit has an instance whose box passes — not tested */
 #define PT_SWEEP_INST_WORDS 16
 #define PT_SWEEP_TRI_WORDS 8
 #define PT_SWEEP_BIT_WORDS 8

@@ -641,11 +641,10 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
         const uint32_t kf = PT_UNIFORM(pt_f2u(h0.y));
         float entry = 0.0f;
         bool ih = false, iu = true;   // (a ray the filter cannot take: every box is undecided)
-        if ((kf & PT_SWEEP_NO_OWN_TEST) && !(flags & PT_FLAG_OWN_TESTS)) { ih = true; iu = false; }   // the instance's box holds every leaf's: it passes whenever one of them does (pt_blob.h)
-        else {
-            if (quick) aabb_classify_by((kf >> 11) & 7u, a, b, wr, &entry, &ih, &iu);
-            if (bounded && cull_top && ih && (kf & 0xffu) != PT_SHAPE_SPHERE && beyond(entry, bound, wr.base)) ih = false;
-        }
+        // (An untransformed mesh instance's box holds every box of its leaves, so its own test decides nothing — but it lets a wave whose
+        // rays all miss the instance skip the leaves: without it C2's k_extend takes 2360 us instead of 2283, k_shadow 4648 instead of 4466.)
+        if (quick) aabb_classify_by((kf >> 11) & 7u, a, b, wr, &entry, &ih, &iu);
+        if (bounded && cull_top && ih && (kf & 0xffu) != PT_SHAPE_SPHERE && beyond(entry, bound, wr.base)) ih = false;
         mark(ih, iu, pt_f2u(h0.z), pt_f2u(h0.w));
         const bool inside = ih || iu;
         if ((kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH && (kf >> 24) != 0u && PT_WAVE_ANY(inside)) {

@@ -387,7 +387,6 @@ static pt_status scene_to_device(pt_scene* sc) {
     if (env_u32("PT_AMD_NO_SWEEP", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_SWEEP;
     if (env_u32("PT_AMD_NO_MESH_SWEEP", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_MESH_SWEEP;
     if (env_u32("PT_AMD_NO_KNOWN_LIGHT", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_KNOWN_LIGHT;
-    if (env_u32("PT_AMD_OWN_TESTS", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_OWN_TESTS;
     sc->blob_words = (uint32_t)sc->host.blob.size();
     const bool no_lds = env_u32("PT_AMD_NO_LDS", 0) != 0;
     const uint32_t all_limit = env_u32("PT_AMD_LDS_ALL_LIMIT", kLdsAllLimitBytes);   // (experiments: the largest blob staged whole)

@@ -558,8 +558,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                 }
                 uint64_t own_mask = mask_of(first_bit);
                 uint32_t* r = &w[e];
-                const bool no_own_test = in.kind == PT_SHAPE_MESH && !walked[inst] && !in.has_transform && !leaders.empty() && own_mask == 1ull << first_bit;
-                r[0] = rec_off; r[1] = kf | (no_own_test ? PT_SWEEP_NO_OWN_TEST : 0u) | first_bit << 16 | (uint32_t)leaders.size() << 24; r[2] = (uint32_t)own_mask; r[3] = (uint32_t)(own_mask >> 32);
+                r[0] = rec_off; r[1] = kf | first_bit << 16 | (uint32_t)leaders.size() << 24; r[2] = (uint32_t)own_mask; r[3] = (uint32_t)(own_mask >> 32);
                 r[4] = nd[0]; r[5] = nd[1]; r[6] = nd[2]; r[7] = tri_list; r[8] = nd[4]; r[9] = nd[5]; r[10] = nd[6]; r[11] = tri_count;
                 r[12] = group_sizes; r[13] = 0u; r[14] = inst; r[15] = 0u;
             }

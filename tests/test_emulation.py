@@ -99,9 +99,8 @@ def test_leaf_sweep_equals_bvh_walk(emu, pkg, monkeypatch, scene):
     d[:64] = np.eye(3, dtype=np.float32)[np.arange(64) % 3] * np.where(np.arange(64) % 2, -1.0, 1.0)[:, None].astype(np.float32)
     rd = pkg.api.render_desc(24, 24, 4, 5, light_samples=2)
     results = []
-    # (64: big meshes walked instead of swept through their group boxes; 256: the nearest light tested again in phase 3; 512: every mesh
-    # instance of the table keeps its own box test)
-    for flags in ("0", "16", "2", "18", "4", "128", "132", "64", "66", "256", "512", "770"):
+    # (64: big meshes walked instead of swept through their group boxes; 256: the nearest light tested again in phase 3)
+    for flags in ("0", "16", "2", "18", "4", "128", "132", "64", "66", "256", "258"):
         monkeypatch.setenv("PTEMU_FLAGS", flags)
         sc = emu.create_scene(b)
         assert sc.uses_leaf_sweep() == (flags not in ("16", "18"))

@@ -171,10 +171,9 @@ def test_filtered_slab_test_and_culling_change_nothing(engine, pkg, monkeypatch)
 
 
 @pytest.mark.parametrize("scene,L", [("cornell_box", 2), ("mixed_small", 3), ("mixed_primitives", 3), ("cornell_gem", 2)])
-def test_sweep_shortcuts_change_nothing(engine, pkg, monkeypatch, scene, L):
-    """Two shortcuts of the leaf sweep: an untransformed mesh instance whose leaves are all in the table skips its own box test (every
-    leaf's box lies in it), and phase 3 of a light-sample ray takes the distance of the light that bounds it from the light pre-pass
-    instead of testing that light again.  Switched off one by one and together: the same film, counters and hits bit for bit."""
+def test_known_light_changes_nothing(engine, pkg, monkeypatch, scene, L):
+    """Phase 3 of a light-sample ray takes the distance of the light that bounds it from the light pre-pass instead of testing that light
+    again (sweep_run's known_inst).  Switched off: the same film, counters and hits bit for bit."""
     import parity_suite
     b = pkg.scene.SCENES[scene]()
     rd = pkg.api.render_desc(160, 120, 9, 8, light_samples=L, seed=4)
@@ -182,7 +181,7 @@ def test_sweep_shortcuts_change_nothing(engine, pkg, monkeypatch, scene, L):
     ref = engine.create_scene(b)
     base, pbase = ref.render(rd)
     hits = ref.intersect(o, d)
-    for env in ({"PT_AMD_NO_KNOWN_LIGHT": "1"}, {"PT_AMD_OWN_TESTS": "1"}, {"PT_AMD_NO_KNOWN_LIGHT": "1", "PT_AMD_OWN_TESTS": "1"}):
+    for env in ({"PT_AMD_NO_KNOWN_LIGHT": "1"},):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         other = engine.create_scene(b)
