@@ -1103,7 +1103,9 @@ PT_HD bool sweep_best_is_light(const SceneView& s, const SweepState& st) {
     if (m == PT_MATERIAL_NONE) m = st.best_triw != 0u ? pt_f2u(mf4(s, st.best_triw).w) : PT_MATERIAL_ID(PT_TAG_MATERIAL, 0);
     return PT_MATERIAL_TAG(m) == PT_TAG_LIGHT;
 }
-template <bool WALKS = true>
+// LIGHT_ONLY (light-sample rays): only a light's record is ever read (shadow_ray_contribution) — of any other closest hit the caller
+// learns that it exists and that it is no light, and the record (a triangle's vertices, barycentric point and normal) is not built.
+template <bool WALKS = true, bool LIGHT_ONLY = false>
 PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, int stop, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f) {
     SweepState st;
     sweep_state_init(st, sweep_masks(s, o, d, bound));
@@ -1112,6 +1114,7 @@ PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound
     if ((bu(s, PT_HDR_FLAGS) & (PT_FLAG_REPLAY | PT_FLAG_SWEEP_WALKS)) == PT_FLAG_REPLAY) { sweep_run_replay(s, o, d, wtr, st); return sweep_finish(s, o, d, st, out); }
 #endif
     sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, false, known_inst, known_t);
+    if (LIGHT_ONLY && st.best_inst != 0xffffffffu && !sweep_best_is_light(s, st)) { out->valid = true; out->material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); return true; }
     return sweep_finish(s, o, d, st, out);
 }
 
@@ -1220,10 +1223,10 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
 #define PT_TRAV_WALK 1
 #define PT_TRAV_SWEEP 2
 PT_HD bool scene_uses_sweep(const SceneView& s) { return bu(s, PT_HDR_SWEEP_OFF) != 0u && !(bu(s, PT_HDR_FLAGS) & PT_FLAG_NO_SWEEP); }
-template <int TRAV = PT_TRAV_ANY>
+template <int TRAV = PT_TRAV_ANY, bool LIGHT_ONLY = false>
 PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_INF, int stop = PT_STOP_NONE, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f) {
-    if (TRAV == PT_TRAV_SWEEP) return world_hit_sweep<false>(s, o, d, out, bound, stop, known_inst, known_t);
-    if (TRAV == PT_TRAV_ANY && scene_uses_sweep(s)) return world_hit_sweep<true>(s, o, d, out, bound, stop, known_inst, known_t);
+    if (TRAV == PT_TRAV_SWEEP) return world_hit_sweep<false, LIGHT_ONLY>(s, o, d, out, bound, stop, known_inst, known_t);
+    if (TRAV == PT_TRAV_ANY && scene_uses_sweep(s)) return world_hit_sweep<true, LIGHT_ONLY>(s, o, d, out, bound, stop, known_inst, known_t);
     return world_hit_walk(s, o, d, out, bound, stop);
 }
 

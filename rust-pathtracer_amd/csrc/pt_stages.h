@@ -523,7 +523,7 @@ PT_HD void stage_shadow_ray(const SceneView& s, const float* lambda, const Shado
     if (ENV && env) stop = shadow_env_stop(s);
     else if (!shadow_light_bound(s, ray.o, ray.d, &bound, &stop, &light)) return;
     Hit sh;
-    bool hit = world_hit<TRAV>(s, ray.o, ray.d, &sh, bound, stop, light, bound);
+    bool hit = world_hit<TRAV, true>(s, ray.o, ray.d, &sh, bound, stop, light, bound);
     shadow_ray_contribution<NL>(s, lambda, ray, ENV && env, hit, sh, contribution);
 }
 // One light-sample item: L rays, summed in order, divided by L (pt.rs:349-392, 596)
