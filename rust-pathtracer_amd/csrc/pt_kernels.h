@@ -445,16 +445,19 @@ __global__ void __launch_bounds__(kBlock) PT_POOL_OCC k_shadow_exp(const uint32_
             ShadowRayT<1> ray;
             if (!load_shadow_ray<1>(shadow, item, l, &ray)) continue;
             float bound = PT_INF; int stop = PT_STOP_NONE;
-            if (!shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) continue;
+            uint32_t light = 0xffffffffu;
+            if (!shadow_light_bound(s, ray.o, ray.d, &bound, &stop, &light)) continue;
             if (EXP & 8) { lc += bound; continue; }
             SweepState st;
             sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
             if (EXP & 2) { lc += (float)(uint32_t)st.hit + (float)(uint32_t)(st.hit >> 32); continue; }
             const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
-            sweep_run<false>(s, ray.o, ray.d, wtr, bound, stop, st, false);
+            sweep_run<false>(s, ray.o, ray.d, wtr, bound, stop, st, false, light, bound);
             if (EXP & 4) { lc += st.closest + (float)st.best_inst; continue; }
             Hit sh; float c[1];
-            bool hit = sweep_finish(s, ray.o, ray.d, st, &sh);
+            bool hit = st.best_inst != 0xffffffffu;
+            if (hit && !sweep_best_is_light(s, st)) { sh.valid = true; sh.material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); }
+            else hit = sweep_finish(s, ray.o, ray.d, st, &sh);
             shadow_ray_contribution<1>(s, lambda, ray, false, hit, sh, c);
             lc += c[0];
         }
