@@ -916,14 +916,14 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
     return false;
 }
 // A parked lane: walk the mesh of its lowest set bit, then carry on with phase 3 (it may park again at another walked mesh).
-PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st) {
+PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f) {
     const uint32_t k = ctz64(st.hit);
     const F4 be = bf4(s, bu(s, PT_HDR_SWEEP_BITS_OFF) + k * PT_SWEEP_BIT_WORDS);
     st.hit &= st.hit - 1;
     mesh_walk(s, pt_f2u(be.x), pt_f2u(be.w) >> 16, o, d, bound, stop, st);
     if (st.hit == 0) return false;
     const TriRay wtr = tri_ray_prepare(o, d);
-    return sweep_run<true>(s, o, d, wtr, bound, stop, st, true);
+    return sweep_run<true>(s, o, d, wtr, bound, stop, st, true, known_inst, known_t);
 }
 PT_HD bool sweep_finish(const SceneView& s, F3 o, F3 d, const SweepState& st, Hit* out) {
     if (st.best_inst == 0xffffffffu) { out->valid = false; return false; }

@@ -563,23 +563,28 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
     if (lane_id() == 0) *park_count = 0;
     // a finished ray leaves its contribution where its factor was; the item's rays are summed in order at the end (an item's
     // rays are parked and resumed by the wave that owns the item, so that sum needs no workgroup barrier either)
-    auto settle = [&](uint32_t j, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked) {
-        if (parked) { park_store(pk, atomicAdd(park_count, 1u), j, st, l, bound, env ? 1u : 0u); return; }
+    auto settle = [&](uint32_t j, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked, uint32_t light) {
+        if (parked) { park_store(pk, atomicAdd(park_count, 1u), j, st, l, bound, (env ? 1u : 0u) | (light + 1u) << 1); return; }
         const uint32_t item = base + j;
         float lambda[NL], c[NL];
         for (int k = 0; k < NL; ++k) lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item);
-        Hit sh;
-        bool hit = sweep_finish(s, ray.o, ray.d, st, &sh);
+        Hit sh; sh.valid = false;
+        const bool hit = st.best_inst != 0xffffffffu;
+        // only a light or nothing at all contributes: the record of an occluder is never read (shadow_ray_contribution)
+        const bool wanted = hit && !env && sweep_best_is_light(s, st);
+        if (wanted) sweep_finish(s, ray.o, ray.d, st, &sh);
+        if (hit && !wanted) { sh.valid = true; sh.material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); }
         shadow_ray_contribution<NL>(s, lambda, ray, env, hit, sh, c);
         for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
     };
+    // (the parked `kind` word: bit 0 = an environment sample, the rest = 1 + the light whose hit bounds the search, sweep_run's known_inst)
     auto resume_parked = [&](uint32_t j2, SweepState& st, uint32_t l2, float bound, uint32_t kind) {
         ShadowRayT<NL> pr;
         load_shadow_ray<NL>(shadow, base + j2, l2, &pr);
-        const bool env = kind != 0u;
+        const bool env = (kind & 1u) != 0u;
         // a light ray searches with the early stop whenever it has a finite bound (shadow_light_bound)
         const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
-        settle(j2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, stop2, st));
+        settle(j2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound), (kind >> 1) - 1u);
     };
     // The rays that are traced at all — a light sample below the horizon of its surface, or with a zero factor, is not: four in five of
     // C4's — are listed per wave (item and sample number) and traced 64 at a time, so that a step of the wave is 64 live rays and parks at
@@ -612,13 +617,14 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
             load_shadow_ray<NL>(shadow, item, l, &ray);
             const bool env = ((qu(shadow, Layout<NL>::sh_flags, item) >> l) & 1u) != 0;
             float bound = PT_INF; int stop = shadow_env_stop(s);
-            if (!env && !shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) {
+            uint32_t light = 0xffffffffu;
+            if (!env && !shadow_light_bound(s, ray.o, ray.d, &bound, &stop, &light)) {
                 for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
             } else {
                 SweepState st;
                 sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
                 const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
-                settle(j, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true));
+                settle(j, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound), light);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -719,21 +725,24 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked_dyn(const 
     uint32_t* park_count = &park_counts[wave];
     if (lane == 0) *park_count = 0;
     const uint32_t units_per_seg = (seg_cap + kUnitItems - 1) / kUnitItems, total_units = n_segments * units_per_seg;
-    auto settle = [&](uint32_t item, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked) {
-        if (parked) { park_store(pk, atomicAdd(park_count, 1u), item, st, l, bound, env ? 1u : 0u); return; }
+    auto settle = [&](uint32_t item, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked, uint32_t light) {
+        if (parked) { park_store(pk, atomicAdd(park_count, 1u), item, st, l, bound, (env ? 1u : 0u) | (light + 1u) << 1); return; }
         float lambda[NL], c[NL];
         for (int k = 0; k < NL; ++k) lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item);
-        Hit sh;
-        bool hit = sweep_finish(s, ray.o, ray.d, st, &sh);
+        Hit sh; sh.valid = false;
+        const bool hit = st.best_inst != 0xffffffffu;
+        const bool wanted = hit && !env && sweep_best_is_light(s, st);   // (the record of an occluder is never read)
+        if (wanted) sweep_finish(s, ray.o, ray.d, st, &sh);
+        if (hit && !wanted) { sh.valid = true; sh.material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); }
         shadow_ray_contribution<NL>(s, lambda, ray, env, hit, sh, c);
         for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
     };
-    auto resume = [&](uint32_t item2, SweepState& st, uint32_t l2, float bound, uint32_t kind) {
+    auto resume = [&](uint32_t item2, SweepState& st, uint32_t l2, float bound, uint32_t kind) {   // (`kind`: see k_shadow_parked)
         ShadowRayT<NL> pr;
         load_shadow_ray<NL>(shadow, item2, l2, &pr);
-        const bool env = kind != 0u;
+        const bool env = (kind & 1u) != 0u;
         const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
-        settle(item2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, stop2, st));
+        settle(item2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound), (kind >> 1) - 1u);
     };
     uint32_t first = 0, cnt = 0, off = 0;   // (one loop, one drain site: see k_extend_parked_dyn)
     bool more = true;
@@ -748,13 +757,14 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked_dyn(const 
             if (active && load_shadow_ray<NL>(shadow, item, l, &ray)) {
                 const bool env = ((flags >> l) & 1u) != 0;
                 float bound = PT_INF; int stop = shadow_env_stop(s);
-                if (!env && !shadow_light_bound(s, ray.o, ray.d, &bound, &stop)) {
+                uint32_t light = 0xffffffffu;
+                if (!env && !shadow_light_bound(s, ray.o, ray.d, &bound, &stop, &light)) {
                     for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
                 } else {
                     SweepState st;
                     sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
                     const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
-                    settle(item, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true));
+                    settle(item, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound), light);
                 }
             }
             park_drain(pk, park_count, last_turn && l + 1 == light_samples, resume);
