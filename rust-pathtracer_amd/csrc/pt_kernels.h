@@ -2,13 +2,13 @@
 //
 // Per bounce one launch each of extend -> shade -> shadow over segmented SoA queues in HBM (pt_stages.h; workgroup b owns segment b
 // of every queue and compacts survivors into its own segment with wave ballots + one LDS atomic per wave — no global atomics),
-// persistent grids that stage the scene blob (or its core section) into LDS once per workgroup, four traversal forms (pt_device.h:
-// BVH walk, leaf sweep, pooled leaf sweep, sweep + parked mesh walks), per-slot energy accumulation without float atomics, and an
-// accumulate kernel that owns one film pixel per lane so film sums keep the reference's order.
+// grids of 64 workgroups per CU that stage the scene blob (or its core section) into LDS once per workgroup, the traversal forms of
+// pt_device.h (BVH walk, leaf sweep, sweep + parked mesh walks with static segments or units taken from a counter, and the pooled leaf
+// sweep kept as a measured experiment), per-slot energy accumulation without float atomics, and an accumulate kernel that owns one film
+// pixel per lane so film sums keep the reference's order.
 //
-// The instantiations are compiled in separate translation units by kernel family (pt_kern_*.hip: the build runs them in parallel and
-// a change to one family recompiles one file); pt_engine.hip sees them as extern templates.  The lists at the end of this file are
-// the single source of both.
+// The kernels are instantiated where they are launched: one translation unit per kernel family (pt_kern_extend / shadow / shade.hip behind
+// the launchers of pt_launch.h), so that the build compiles the families side by side and a change to one recompiles one file.
 #ifndef PT_KERNELS_H
 #define PT_KERNELS_H
 #include <hip/hip_runtime.h>
