@@ -76,6 +76,9 @@ def test_materials_bit_exact(engine, oracle, scene):
     ("cornell_gem", 64, 48, 6, 12, {"hero_wavelengths": 4}),
     ("hdri_small", 48, 48, 6, 4, {"hero_wavelengths": 4, "light_samples": 3}),
     ("hdri_c4_small", 96, 96, 6, 4, {"light_samples": 6}),   # C4 scene (monkey mesh: blob too big for LDS -> HBM/L2 path)
+    ("hdri_c4_small", 80, 64, 5, 4, {"light_samples": 8}),   # the most light samples an item can hold (the per-wave lists of live rays at their longest)
+    ("cornell_gem", 64, 48, 5, 8, {"light_samples": 8}),
+    ("cornell_box", 64, 48, 5, 6, {"light_samples": 8}),
     ("fog_ball", 160, 120, 12, 10, {"medium_aware": True}),  # the medium-aware walk (k_shade_medium)
     ("fog_ball", 96, 64, 8, 12, {"medium_aware": True, "light_samples": 3, "min_bounces": 3, "seed": 9}),
     ("cornell_box", 96, 96, 8, 6, {"medium_aware": True}),
