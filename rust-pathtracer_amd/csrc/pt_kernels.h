@@ -490,6 +490,9 @@ __device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32
 // waves — with no workgroup barrier anywhere: a wave that is deep in a mesh never holds the other three up.  (The first
 // version parked per workgroup with three barriers per drain; rocprofv3 showed the C4 shadow kernel waiting 68 % of its
 // wave cycles at 12 % VALU issue.)
+#ifndef PT_PARKED_EXP
+#define PT_PARKED_EXP 0   // measurement variants of k_shadow_parked (tools/phase_costs_parked.sh); 0 = the product
+#endif
 constexpr uint32_t kWaveParkCap = kParkCap / (kBlock / 64);
 constexpr uint32_t kLiveCap = 64u * PT_MAX_LIGHT_SAMPLES + 64u;   // a wave's list of live light-sample rays: fewer than 64 left over + the rays of 64 items
 template <typename Resume>
@@ -611,6 +614,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
         }
         const uint32_t take = live_count < 64u ? live_count : 64u;
         live_count -= take;
+        if (PT_PARKED_EXP & 1) continue;   // (measurement: the listing of the live rays alone)
         if (lane_id() < take) {
             const uint32_t e = live[live_count + lane_id()], j = e >> 3, l = e & 7u, item = base + j;
             ShadowRayT<NL> ray;
@@ -623,8 +627,11 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
             } else {
                 SweepState st;
                 sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
+                if (PT_PARKED_EXP & 2) { qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, (float)(uint32_t)st.hit); continue; }   // (measurement: up to the masks)
                 const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
-                settle(j, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound), light);
+                const bool parks = sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound);
+                if ((PT_PARKED_EXP & 4) && parks) { qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, 0.0f); continue; }   // (measurement: parked rays dropped)
+                settle(j, l, ray, env, bound, st, parks, light);
             }
         }
         __builtin_amdgcn_wave_barrier();
