@@ -13,7 +13,8 @@ from . import api, scene, scene_file, sharding  # noqa: F401
 
 PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PACKAGE_DIR)
-LIBRARY_PATH = os.path.join(PACKAGE_DIR, "csrc", "libptamd.so")
+# (PT_AMD_LIBRARY: another build of the same engine, for A/B measurements of kernel variants — tools/ab_libs.sh)
+LIBRARY_PATH = os.environ.get("PT_AMD_LIBRARY") or os.path.join(PACKAGE_DIR, "csrc", "libptamd.so")
 
 _library = None
 

@@ -42,7 +42,44 @@
 #define PT_UNIFORM(x) (x)
 #endif
 
+// A loop the compiler must keep rolled (the per-wavelength loops of the hero variant: four inlined copies of a curve evaluation cost
+// registers and instruction cache for nothing).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_ROLLED _Pragma("clang loop unroll(disable)")
+#else
+#define PT_ROLLED
+#endif
+
 namespace ptd {
+
+// Element k of a small per-wavelength array held in registers, k a loop counter of a ROLLED loop: addressing the array with k would send
+// it — and the struct around it — to scratch memory (k_shade<4> kept 304 B per lane there, k_shadow<4> 44 B).  k is wave-uniform, so a chain
+// of N - 1 selects on scalar conditions reads it and N selects write it; every index below is a constant after unrolling.
+// (Written out, not as loops over i, and every element passed through an empty asm statement: left to itself the optimiser folds the
+// chain of selects over loads from one array back into a single load at a[k] — the very indexed access this is here to avoid.)
+PT_HD float pl_opaque(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(x));
+#endif
+    return x;
+}
+template <int N> PT_HD float pl_get(const float (&a)[N], int k) {
+    static_assert(N >= 1 && N <= 4, "per-wavelength arrays hold 1 or 4 values");
+    if (N == 1) return a[0];
+    float r = pl_opaque(a[0]);
+    if (N > 1) r = (k == 1) ? pl_opaque(a[1 % N]) : r;
+    if (N > 2) r = (k == 2) ? pl_opaque(a[2 % N]) : r;
+    if (N > 3) r = (k == 3) ? pl_opaque(a[3 % N]) : r;
+    return r;
+}
+template <int N> PT_HD void pl_set(float (&a)[N], int k, float x) {
+    static_assert(N >= 1 && N <= 4, "per-wavelength arrays hold 1 or 4 values");
+    if (N == 1) { a[0] = x; return; }
+    a[0] = (k == 0) ? x : pl_opaque(a[0]);
+    if (N > 1) a[1 % N] = (k == 1) ? x : pl_opaque(a[1 % N]);
+    if (N > 2) a[2 % N] = (k == 2) ? x : pl_opaque(a[2 % N]);
+    if (N > 3) a[3 % N] = (k == 3) ? x : pl_opaque(a[3 % N]);
+}
 
 template <int V> struct IntC { static constexpr int value = V; };   // a compile-time integer as a value (generic lambdas)
 struct F3 { float x, y, z; };
@@ -64,13 +101,19 @@ struct SceneView {
     const uint32_t* w;  // core section of the blob (everything but mesh data): LDS copy or HBM
     const float* tex;   // texture texels, HBM
     const uint32_t* m;  // mesh-data section (BVH nodes, triangles, normals, leaf lists; offsets relative to it): LDS copy or HBM
+    // What the scene is known NOT to hold (PT_SCENE_*): a kernel form sets it from a template constant, and after inlining the branches
+    // that depend on it fold away — registers and code size change, results do not (a scene that does hold the thing never gets the form).
+    uint32_t lacks = 0u;
 };
+#define PT_SCENE_NO_XF 1u   /* no instance carries a transform (the Cornell box): instance_local_ray and the hit record's way back are identities */
 PT_HD uint32_t bu(const SceneView& s, uint32_t off) { return s.w[off]; }
 PT_HD float bf(const SceneView& s, uint32_t off) { return pt_u2f(s.w[off]); }
 PT_HD F4 bf4(const SceneView& s, uint32_t off) { return *reinterpret_cast<const F4*>(s.w + off); }
 PT_HD F3 bf3(const SceneView& s, uint32_t off) { return f3(bf(s, off), bf(s, off + 1), bf(s, off + 2)); }
 PT_HD uint32_t mu(const SceneView& s, uint32_t off) { return s.m[off]; }
 PT_HD F4 mf4(const SceneView& s, uint32_t off) { return *reinterpret_cast<const F4*>(s.m + off); }
+PT_HD bool instance_is_transformed(const SceneView& s, uint32_t inst) { return !(s.lacks & PT_SCENE_NO_XF) && (bu(s, inst + PT_INST_FLAGS) & 1u) != 0u; }
+PT_HD bool sweep_leaf_transformed(const SceneView& s, uint32_t kf) { return !(s.lacks & PT_SCENE_NO_XF) && (kf & 0x200u) != 0u; }   // (kf: the sweep table's kind-and-flags word)
 
 // TangentFrame::from_normal (math crate): Duff et al. 2017.
 struct Frame { F3 t, b, n; };
@@ -557,7 +600,7 @@ PT_HD bool analytic_hit(const SceneView& s, uint32_t inst, uint32_t kind, F3 o, 
 // disk / triangle accept t <= closest, sphere t < closest), and the HitRecord is built once, after the walk, from
 // (instance, triangle, barycentrics) or by re-running the analytic test — same arithmetic, same bits.
 PT_HD void instance_local_ray(const SceneView& s, uint32_t inst, F3 o, F3 d, F3* lo, F3* ld) {
-    if (bu(s, inst + PT_INST_FLAGS) & 1u) { *lo = xf_point(s, inst + PT_INST_REVERSE, o); *ld = xf_vec(s, inst + PT_INST_REVERSE, d); }
+    if (instance_is_transformed(s, inst)) { *lo = xf_point(s, inst + PT_INST_REVERSE, o); *ld = xf_vec(s, inst + PT_INST_REVERSE, d); }
     else { *lo = o; *ld = d; }
 }
 // HitRecord of the winning primitive (Instance::hit, instance.rs:89-131; mesh.rs:160-197): `triw` is the word offset of the
@@ -590,7 +633,7 @@ PT_HD void hit_record(const SceneView& s, F3 o, F3 d, uint32_t best_inst, uint32
     } else {
         analytic_hit(s, inst, bu(s, inst + PT_INST_KIND), lo, ld, PT_INF, &h);
     }
-    if (bu(s, inst + PT_INST_FLAGS) & 1u) {
+    if (instance_is_transformed(s, inst)) {
         h.n = normalize(xf_vec_transposed(s, inst + PT_INST_REVERSE, h.n));
         h.p = xf_point(s, inst + PT_INST_FORWARD, h.p);
     }
@@ -666,7 +709,7 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
                 const uint32_t n0 = groups & 0xffu, n1 = (groups >> 8) & 0xffu, n2 = (groups >> 16) & 0xffu, n3 = groups >> 24;
                 group(IntC<0>(), n0); group(IntC<1>(), n1); group(IntC<2>(), n2); group(IntC<3>(), n3); group(IntC<4>(), tc - (n0 + n1 + n2 + n3));
             };
-            if (kf & 0x200u) {
+            if (sweep_leaf_transformed(s, kf)) {
                 F3 lo, ld;
                 instance_local_ray(s, pt_f2u(h0.x), o, d, &lo, &ld);
                 const RayPrep lr = ray_prepare(lo, ld);
@@ -883,7 +926,7 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
                 return triangle_test_permuted(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th);
             };
             bool accepted;
-            if (kf & 0x200u) { F3 lo, ld; instance_local_ray(s, inst, o, d, &lo, &ld); const TriRay ltr = tri_ray_prepare(lo, ld); accepted = test(ltr); }
+            if (sweep_leaf_transformed(s, kf)) { F3 lo, ld; instance_local_ray(s, inst, o, d, &lo, &ld); const TriRay ltr = tri_ray_prepare(lo, ld); accepted = test(ltr); }
             else accepted = test(wtr);
             if (accepted) {
                 st.closest = th.t; st.best_inst = kf >> 16; st.best_triw = triw; st.bh = th;
@@ -983,8 +1026,8 @@ PT_HD void cand_winner(const SceneView& s, uint32_t bits_off, uint32_t k, F3 o, 
     st.closest = t; st.best_inst = kf >> 16; st.best_triw = triw;
     if (triw == 0u) return;
     TriRay ltr;
-    if (kf & 0x200u) { F3 lo, ld; instance_local_ray(s, inst, o, d, &lo, &ld); ltr = tri_ray_prepare(lo, ld); }
-    const TriRay& tr = (kf & 0x200u) ? ltr : wtr;
+    if (sweep_leaf_transformed(s, kf)) { F3 lo, ld; instance_local_ray(s, inst, o, d, &lo, &ld); ltr = tri_ray_prepare(lo, ld); }
+    const TriRay& tr = sweep_leaf_transformed(s, kf) ? ltr : wtr;
     const uint32_t tp = triw + (tr.kz == 0u ? pt_f2u(bp.z) : (tr.kz == 1u ? pt_f2u(bp.w) : 0u));
     const F4 q0 = mf4(s, tp), q1 = mf4(s, tp + 4), q2 = mf4(s, tp + 8);
     triangle_test_permuted(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, PT_INF, &st.bh);
@@ -1190,7 +1233,7 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
                 uint32_t mesh = bu(s, inst + PT_INST_MESH);
                 top_resume = i; level_inst = pending;
                 node_off = bu(s, mesh + PT_MESH_NODE_OFF); node_count = bu(s, mesh + PT_MESH_NODE_COUNT); tri_off = bu(s, mesh + PT_MESH_TRI_OFF);
-                if (bu(s, inst + PT_INST_FLAGS) & 1u) {
+                if (instance_is_transformed(s, inst)) {
                     cr = ray_prepare(lo, ld);
                     if (exact) cr.fast = false;
                     cr_quick = cr.fast && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f;
@@ -1422,6 +1465,27 @@ PT_HD MatEval material_prepare(const SceneView& s, uint32_t m, float lambda, flo
     return e;
 }
 
+// The same for the N wavelengths of a hero-wavelength path: what does not depend on the wavelength once, the spectral values per k.
+template <int N> struct MatEvalN { uint32_t kind; bool metallic; float alpha; float refl[N], ei[N], eo[N], kappa[N]; };
+template <int N, bool GGX = true>
+PT_HD MatEvalN<N> material_prepare_n(const SceneView& s, uint32_t m, const float (&lambda)[N], float u, float v) {
+    MatEvalN<N> e;
+    e.kind = bu(s, m + PT_MAT_KIND); e.metallic = false; e.alpha = 0.0f;
+    for (int k = 0; k < N; ++k) e.refl[k] = e.ei[k] = e.eo[k] = e.kappa[k] = 0.0f;
+    PT_ROLLED for (int k = 0; k < N; ++k) {
+        const MatEval one = material_prepare<GGX>(s, m, pl_get<N>(lambda, k), u, v);
+        e.metallic = one.metallic; e.alpha = one.alpha;
+        pl_set<N>(e.refl, k, one.refl);
+        if (GGX) { pl_set<N>(e.ei, k, one.ei); pl_set<N>(e.eo, k, one.eo); pl_set<N>(e.kappa, k, one.kappa); }
+    }
+    return e;
+}
+template <int N> PT_HD MatEval material_at(const MatEvalN<N>& e, int k) {
+    MatEval one; one.kind = e.kind; one.metallic = e.metallic; one.alpha = e.alpha;
+    one.refl = pl_get<N>(e.refl, k); one.ei = pl_get<N>(e.ei, k); one.eo = pl_get<N>(e.eo, k); one.kappa = pl_get<N>(e.kappa, k);
+    return one;
+}
+
 // Material::bsdf (lambertian.rs:16-33, diffuse_light.rs:29-45, sharp_light.rs:43-60, ggx.rs:256-400)
 template <bool GGX = true>
 PT_HD void material_bsdf_p(const MatEval& e, F3 wi, F3 wo, float* f_out, float* pdf_out) {
@@ -1599,7 +1663,7 @@ PT_HD uint32_t mediums_add(uint32_t list, uint32_t id) {      // push + sort_uns
 // rect.rs:113-173, sphere.rs:88-152, disk.rs:63-104, instance.rs:134-170
 PT_HD void light_sample(const SceneView& s, uint32_t inst, float sx, float sy, F3 from, F3* dir, float* pdf) {
     uint32_t kind = bu(s, inst + PT_INST_KIND), flags = bu(s, inst + PT_INST_FLAGS);
-    bool xf = (flags & 1u) != 0, two_sided = (flags & 2u) != 0;
+    bool xf = instance_is_transformed(s, inst), two_sided = (flags & 2u) != 0;
     if (xf) from = xf_point(s, inst + PT_INST_REVERSE, from);
     F3 origin = bf3(s, inst + PT_INST_ORIGIN);
     F3 point, normal; float area_pdf;
@@ -1634,8 +1698,8 @@ PT_HD void light_sample(const SceneView& s, uint32_t inst, float sx, float sy, F
     *dir = dn; *pdf = p;
 }
 PT_HD float light_psa_pdf(const SceneView& s, uint32_t inst, float cos_o, float cos_i, F3 from, F3 to) {
-    uint32_t kind = bu(s, inst + PT_INST_KIND), flags = bu(s, inst + PT_INST_FLAGS);
-    if (flags & 1u) { from = xf_point(s, inst + PT_INST_FORWARD, from); to = xf_point(s, inst + PT_INST_FORWARD, to); }
+    uint32_t kind = bu(s, inst + PT_INST_KIND);
+    if (instance_is_transformed(s, inst)) { from = xf_point(s, inst + PT_INST_FORWARD, from); to = xf_point(s, inst + PT_INST_FORWARD, to); }
     F3 dd = sub(to, from);
     float d2 = dot(dd, dd);
     if (kind == PT_SHAPE_RECT) { float s0 = bf(s, inst + PT_INST_SIZE), s1 = bf(s, inst + PT_INST_SIZE + 1); return (1.0f / (s0 * s1)) * d2 / pt_abs(cos_i) / pt_abs(cos_o); }

@@ -119,6 +119,7 @@ struct pt_scene {
     float* d_tex = nullptr;
     uint32_t blob_words = 0;
     int lds_mode = 0;  // PT_LDS_*
+    uint32_t lacks = 0; // PT_SCENE_* bits: what the scene does not hold (kernel forms without it)
     int device = 0, num_cus = 0;
     DeviceBuffers buf;
     std::vector<hipEvent_t> events;  // pairs (start, stop), grown on demand
@@ -244,6 +245,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     const int dyn_grid = sc->num_cus * (int)env_u32("PT_AMD_PARK_BLOCKS_PER_CU", 4);
     LaunchCfg cfg{grid, lds_bytes, stream, mode};
     cfg.dyn_grid = dyn_grid < grid ? dyn_grid : grid;
+    cfg.lacks = sc->lacks;
     const SceneArgs sargs{sc->d_blob, sc->blob_words, sc->d_tex};
     // light samples can pick the environment only if env_sampling_probability > 0: otherwise k_shade is the form without that branch
     float env_prob; std::memcpy(&env_prob, &sc->host.blob[PT_HDR_ENV_PROB], sizeof env_prob);
@@ -255,11 +257,16 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     // (a PassthroughFilter lives in the forms that hold the GGX code)
     const int shade_form = rd.medium_aware ? PT_SHADE_MEDIUM
                          : (env_prob != 0.0f || env_u32("PT_AMD_SHADE_FORM", 0) == 2) ? PT_SHADE_FULL : (has_ggx || env_u32("PT_AMD_SHADE_FORM", 0) == 1) ? PT_SHADE_NO_ENV : PT_SHADE_LEAN;
+    // k_shade that traces its own segments (PT_AMD_FUSE): exists for the pure sweep form of a fully staged, transform-free scene shaded by the lean form
+    cfg.fuse = env_u32("PT_AMD_FUSE", 0) != 0 && trav_form == PT_FORM_SWEEP && shade_form == PT_SHADE_LEAN && (cfg.lacks & PT_SCENE_NO_XF) != 0;
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
     const bool timing = env_u32("PT_AMD_STAGE_TIMING", 1) != 0;
     double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0};
     uint64_t stage_launches[ST_COUNT] = {0, 0, 0, 0, 0};
-    Queue qa{b.paths_a, b.capacity}, qb{b.paths_b, b.capacity}, qh{b.hits, b.capacity}, qs{b.shadow, b.capacity};
+    // (a queue's tiles are laid out by the number of fields this render uses, pt_stages.h: the buffers are sized for the widest layout seen)
+    const uint32_t path_fields = hero ? Layout<4>::path_fields : (rd.medium_aware ? (uint32_t)PS_FIELDS + 2u : Layout<1>::path_fields);
+    const uint32_t item_fields = hero ? Layout<4>::shadow_fields(rd.light_samples ? rd.light_samples : 1) : Layout<1>::shadow_fields(rd.light_samples ? rd.light_samples : 1);
+    Queue qa{b.paths_a, b.capacity, path_fields}, qb{b.paths_b, b.capacity, path_fields}, qh{b.hits, b.capacity, HS_FIELDS}, qs{b.shadow, b.capacity, item_fields};
     uint32_t* live[2] = {b.counts, b.counts + grid};  // per-segment live-path counts, ping-pong with the path queues
     uint32_t* nshadow = b.counts + 2 * grid;          // per-segment light-sample item counts
 
@@ -301,7 +308,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
             uint32_t *cin = live[bounce & 1], *cout = live[(bounce + 1) & 1];
             // kernel variant = staging mode (PT_LDS_*) x traversal form x wavelengths per path (pt_launch.h)
             if (park_dynamic) cfg.unit_counter = b.unit_counters + 2 * bounce;
-            timed(ST_EXTEND, [&] { launch_extend(cfg, trav_form, sargs, qin, qh, seg_cap, cin, b.park); });
+            if (!cfg.fuse) timed(ST_EXTEND, [&] { launch_extend(cfg, trav_form, sargs, qin, qh, seg_cap, cin, b.park); });
             if (park_dynamic) cfg.unit_counter = b.unit_counters + 2 * bounce + 1;
             timed(ST_SHADE, [&] { launch_shade(cfg, hero ? 4 : 1, shade_form, sargs, rp, bounce, d_px, qin, qh, qout, qs, b.energy, seg_cap, cin, cout, nshadow, b.block_stats); });
             if (rd.light_samples > 0)   // (shade_form FULL = the scene can produce environment rays)
@@ -388,6 +395,12 @@ static pt_status scene_to_device(pt_scene* sc) {
     if (env_u32("PT_AMD_NO_MESH_SWEEP", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_MESH_SWEEP;
     if (env_u32("PT_AMD_NO_KNOWN_LIGHT", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_KNOWN_LIGHT;
     sc->blob_words = (uint32_t)sc->host.blob.size();
+    {   // no instance carries a transform (the Cornell box): the forms without the matrix paths (PT_AMD_GENERAL_FORMS=1 keeps the general ones)
+        bool any_xf = false;
+        const std::vector<uint32_t>& bl = sc->host.blob;
+        for (uint32_t i = 0; i < bl[PT_HDR_INSTANCE_COUNT]; ++i) any_xf = any_xf || (bl[bl[PT_HDR_INSTANCE_OFF] + i * PT_INST_WORDS + PT_INST_FLAGS] & 1u) != 0u;
+        sc->lacks = (!any_xf && !env_u32("PT_AMD_GENERAL_FORMS", 0)) ? PT_SCENE_NO_XF : 0u;
+    }
     const bool no_lds = env_u32("PT_AMD_NO_LDS", 0) != 0;
     const uint32_t all_limit = env_u32("PT_AMD_LDS_ALL_LIMIT", kLdsAllLimitBytes);   // (experiments: the largest blob staged whole)
     sc->lds_mode = no_lds ? PT_LDS_NONE : (sc->blob_words * 4 <= (all_limit < kLdsBlobLimitBytes ? all_limit : kLdsBlobLimitBytes) ? PT_LDS_ALL

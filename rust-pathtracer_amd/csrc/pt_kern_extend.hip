@@ -31,6 +31,7 @@ void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, Queue path
         else go(d, K_EXT_PARKED_DYN(PT_LDS_NONE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter);
     } else if (form == PT_FORM_PARKED) PT_BY_MODE(K_EXT_PARKED, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park);
     else if (form == PT_FORM_POOLED) PT_GO(k_extend_pooled<PT_LDS_ALL>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
+    else if (form == PT_FORM_SWEEP && (c.lacks & PT_SCENE_NO_XF)) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_SWEEP, PT_SCENE_NO_XF>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
     else if (form == PT_FORM_SWEEP) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
     else if (form == PT_FORM_WALK) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_WALK>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
     else PT_BY_MODE(K_EXT_ANY, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
@@ -48,6 +49,7 @@ hipError_t allow_lds_extend(uint32_t bytes) {
 #define K_EXT_PARKED_DYN2(M) k_extend_parked_dyn<M>
     PT_ALLOW_MODES(K_EXT_PARKED_DYN2);
     allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>));
+    allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_SWEEP, PT_SCENE_NO_XF>));
     allow(reinterpret_cast<const void*>(k_extend_pooled<PT_LDS_ALL>));
     return worst;
 }

@@ -8,6 +8,8 @@ namespace ptk {
 #define PT_BY_MODE(K, ...) do { if (c.lds_mode == PT_LDS_ALL) PT_GO(K(PT_LDS_ALL), __VA_ARGS__); else if (c.lds_mode == PT_LDS_CORE) PT_GO(K(PT_LDS_CORE), __VA_ARGS__); \
                                 else PT_GO(K(PT_LDS_NONE), __VA_ARGS__); } while (0)
 #define K_SHADE_L(M) k_shade<M, PT_SHADE_NL, PT_SHADE_LEAN>
+#define K_SHADE_LX(M) k_shade<M, PT_SHADE_NL, PT_SHADE_LEAN, PT_SCENE_NO_XF>
+#define K_SHADE_FUSED k_shade<PT_LDS_ALL, PT_SHADE_NL, PT_SHADE_LEAN, PT_SCENE_NO_XF, PT_TRAV_SWEEP>
 #define K_SHADE_N(M) k_shade<M, PT_SHADE_NL, PT_SHADE_NO_ENV>
 #define K_SHADE_F(M) k_shade<M, PT_SHADE_NL, PT_SHADE_FULL>
 #define PT_ARGS sc.blob, sc.blob_words, sc.tex, rp, bounce, pixels, paths_in, hits, paths_out, shadow, energy, seg_cap, count_in, count_out, shadow_count, block_stats
@@ -24,13 +26,16 @@ void PT_CAT(launch_shade_nl, PT_SHADE_NL)(const LaunchCfg& c, int form, const Sc
 #endif
     if (form == PT_SHADE_FULL) PT_BY_MODE(K_SHADE_F, PT_ARGS);
     else if (form == PT_SHADE_NO_ENV) PT_BY_MODE(K_SHADE_N, PT_ARGS);
+    else if (c.fuse) PT_GO(K_SHADE_FUSED, PT_ARGS);   // (the engine asks for it only where this form exists: PT_LDS_ALL, lean, no transforms, pure sweep)
+    else if (c.lacks & PT_SCENE_NO_XF) PT_BY_MODE(K_SHADE_LX, PT_ARGS);
     else PT_BY_MODE(K_SHADE_L, PT_ARGS);
 }
 hipError_t PT_CAT(allow_lds_shade_nl, PT_SHADE_NL)(uint32_t bytes) {
     hipError_t worst = hipSuccess;
     auto allow = [&](const void* k) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) worst = e; };
 #define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
-    PT_ALLOW_MODES(K_SHADE_L); PT_ALLOW_MODES(K_SHADE_N); PT_ALLOW_MODES(K_SHADE_F);
+    allow(reinterpret_cast<const void*>(K_SHADE_FUSED));
+    PT_ALLOW_MODES(K_SHADE_L); PT_ALLOW_MODES(K_SHADE_LX); PT_ALLOW_MODES(K_SHADE_N); PT_ALLOW_MODES(K_SHADE_F);
 #if PT_SHADE_NL == 1
     PT_ALLOW_MODES(K_SHADE_M);
 #endif

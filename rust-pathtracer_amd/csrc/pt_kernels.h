@@ -60,15 +60,28 @@ inline void go(const LaunchCfg& c, K kernel, Args... args) { hipLaunchKernelGGL(
 #ifndef PT_SHADE4_LEAN_WAVES
 #define PT_SHADE4_LEAN_WAVES 2     // C5: 3885 us at 2 waves, 4142 at 3-4, 4830 at 5
 #endif
-#define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(NL == 1 ? (FORM == 2 ? PT_SHADE_WAVES : FORM == 1 ? PT_SHADE_NO_ENV_WAVES : PT_SHADE_LEAN_WAVES) \
+// (the fused form — k_shade that traces its own segment, FUSE_TRAV below — holds the traversal too: its own budget)
+#ifndef PT_FUSED_WAVES
+#define PT_FUSED_WAVES 4
+#endif
+#ifndef PT_FUSED4_WAVES
+#define PT_FUSED4_WAVES 3
+#endif
+#define PT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(FUSE_TRAV != PT_NO_FUSE ? (NL == 1 ? PT_FUSED_WAVES : PT_FUSED4_WAVES) : \
+                                                        NL == 1 ? (FORM == 2 ? PT_SHADE_WAVES : FORM == 1 ? PT_SHADE_NO_ENV_WAVES : PT_SHADE_LEAN_WAVES) \
                                                                 : (FORM == 2 ? PT_SHADE4_WAVES : FORM == 1 ? PT_SHADE4_NO_ENV_WAVES : PT_SHADE4_LEAN_WAVES))))
+#define PT_NO_FUSE (-1)
 #define PT_TRAV_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? PT_SWEEP_WAVES : PT_WALK_WAVES)))
 // (k_shadow's sweep form takes a sixth wave: measured on one box after the round-2 changes, tools/occupancy_c2.sh: k_shadow 5203 / 4622 / 4395 /
 // 5479 us at 4 / 5 / 6 / 8 waves, k_extend 2610 / 2270 / 2362 / 3989)
 #ifndef PT_SHADOW_SWEEP_WAVES
 #define PT_SHADOW_SWEEP_WAVES 6
 #endif
-#define PT_SHADOW_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? PT_SHADOW_SWEEP_WAVES : PT_WALK_WAVES)))
+// (with four wavelengths per path the six-wave form spills 9 registers, the five-wave form none: 91 VGPRs)
+#ifndef PT_SHADOW4_SWEEP_WAVES
+#define PT_SHADOW4_SWEEP_WAVES 6
+#endif
+#define PT_SHADOW_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? (NL == 1 ? PT_SHADOW_SWEEP_WAVES : PT_SHADOW4_SWEEP_WAVES) : PT_WALK_WAVES)))
 
 enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_ACCUMULATE, ST_COUNT };
 
@@ -78,10 +91,14 @@ enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_ACCUMULATE, ST_COUNT };
 // USE_LDS: 0 = everything is read from HBM/L2; 1 = the whole blob is copied to LDS; 2 = only the core section is (curves,
 // materials, instances, top-level BVH, sweep table: the words every lane keeps re-reading), the mesh data stays in HBM/L2
 // — scenes whose meshes do not fit the LDS budget but whose core does (C4: 470 KB of monkey, 24 KB of core).
-template <int USE_LDS>
+#ifndef PT_EXP_LACKS
+#define PT_EXP_LACKS 0u   /* experiments: what every kernel of the build assumes the scene lacks */
+#endif
+template <int USE_LDS, uint32_t LACKS = 0u>
 __device__ __forceinline__ SceneView stage_scene(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* tex, uint32_t* lds) {
     SceneView s;
     s.tex = tex;
+    s.lacks = LACKS | PT_EXP_LACKS;
     const uint32_t core_words = blob[PT_HDR_CORE_WORDS];
     if (USE_LDS != PT_LDS_NONE) {
         const uint32_t words = USE_LDS == PT_LDS_ALL ? blob_words : core_words;
@@ -139,11 +156,12 @@ __global__ void __launch_bounds__(kBlock) k_generate(RenderParams rp, const uint
     if (threadIdx.x == 0) count_out[blockIdx.x] = cnt;
 }
 
-template <int USE_LDS, int TRAV>
+// LACKS (here and in k_shade / k_shadow): what the scene is known not to hold (PT_SCENE_*, pt_device.h) — compiled out of the form.
+template <int USE_LDS, int TRAV, uint32_t LACKS = 0u>
 __global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_extend(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                   Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
     extern __shared__ __align__(16) uint32_t lds[];
-    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);
     uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
     for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
         uint32_t i = base + j;
@@ -158,7 +176,10 @@ __global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_extend(const uint32_t* _
 // FORM: what the scene can need at a vertex, so that the rest is compiled out (registers and code size, never results):
 // PT_SHADE_LEAN = no light sample picks the environment (env_sampling_probability = 0) and no GGX material (the Cornell box of C2 / C5),
 // PT_SHADE_NO_ENV = any material, PT_SHADE_FULL = everything.
-template <int USE_LDS, int NL, int FORM>
+// FUSE_TRAV: PT_NO_FUSE = the closest hits come from k_extend through the hit queue; a traversal form (PT_TRAV_*) = this kernel traces its
+// own segments first (World::hit, then the vertex, as random_walk's loop body does: utils.rs:171-221) — the 44-byte hit record never
+// reaches HBM, the ray is read once, and one launch per bounce goes away.  Not for the FULL form (it sorts its items by the hit queue).
+template <int USE_LDS, int NL, int FORM, uint32_t LACKS = 0u, int FUSE_TRAV = PT_NO_FUSE>
 __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                  RenderParams rp, uint32_t bounce, const uint32_t* __restrict__ pixels,
                                                  Queue paths_in, Queue hits, Queue paths_out, Queue shadow, float* __restrict__ energy,
@@ -167,7 +188,7 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ uint32_t lds_counts[16];  // [0] path queue head, [1] item queue head, [4..6] statistics
     if (threadIdx.x < 16) lds_counts[threadIdx.x] = 0;
-    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);  // (barrier inside when staging; one below otherwise)
+    SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);  // (barrier inside when staging; one below otherwise)
     if (USE_LDS == PT_LDS_NONE) __syncthreads();
     const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
     uint32_t st_vertices = 0, st_shadow = 0, st_env = 0;
@@ -205,9 +226,14 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
         } else break;
         PathVertexT<NL> pv; Hit hit; hit.valid = false;
         bool wants_item = false;
+        static_assert(FUSE_TRAV == PT_NO_FUSE || FORM != PT_SHADE_FULL, "the fused form has no hit queue to sort by");
         if (active) {
+            if (FUSE_TRAV != PT_NO_FUSE) {   // the ray alone during the search; the rest of the path record after it
+                const F3 o = f3(qf(paths_in, PS_OX, i), qf(paths_in, PS_OY, i), qf(paths_in, PS_OZ, i));
+                const F3 d = f3(qf(paths_in, PS_DX, i), qf(paths_in, PS_DY, i), qf(paths_in, PS_DZ, i));
+                world_hit<FUSE_TRAV == PT_NO_FUSE ? PT_TRAV_ANY : FUSE_TRAV>(s, o, d, &hit);
+            } else hit = load_hit(hits, i);
             pv = load_path<NL>(paths_in, i);
-            hit = load_hit(hits, i);
             wants_item = shade_wants_item(s, rp, hit);
         }
         // reserve the light-sample item first, so its rays stream straight from registers to the queue
@@ -299,12 +325,12 @@ k_shade_medium(const uint32_t* __restrict__ blob, uint32_t blob_words, const flo
     }
 }
 
-template <int USE_LDS, int NL, int TRAV, bool ENV = true>
+template <int USE_LDS, int NL, int TRAV, bool ENV = true, uint32_t LACKS = 0u>
 __global__ void __launch_bounds__(kBlock) PT_SHADOW_OCC k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                   uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                   uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
     extern __shared__ __align__(16) uint32_t lds[];
-    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);
     uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
     for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
         stage_shadow_item<NL, TRAV, ENV>(s, light_samples, shadow, base + j, energy, energy_stride);

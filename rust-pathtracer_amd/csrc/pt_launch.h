@@ -22,7 +22,9 @@ enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_FIELD
 uint32_t pool_lds_bytes();  // static LDS of the pooled traversal kernels, on top of the staged blob
 
 struct LaunchCfg { int grid; uint32_t lds_bytes; hipStream_t stream; int lds_mode;
-                   int dyn_grid = 0; uint32_t* unit_counter = nullptr; };   // parked kernels with dynamic units: persistent workgroups and this launch's counter (zeroed)
+                   int dyn_grid = 0; uint32_t* unit_counter = nullptr;   // parked kernels with dynamic units: persistent workgroups and this launch's counter (zeroed)
+                   uint32_t lacks = 0;    // PT_SCENE_* bits of what the scene does not hold: the pure sweep forms and the lean k_shade have forms without it
+                   bool fuse = false; };  // k_shade traces its own segments (pure sweep scenes, lean form, no transforms): no k_extend launch, no hit queue
 struct SceneArgs { const uint32_t* blob; uint32_t blob_words; const float* tex; };
 
 void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, ptd::Queue paths, ptd::Queue hits, uint32_t seg_cap, const uint32_t* count_in, uint32_t* park);

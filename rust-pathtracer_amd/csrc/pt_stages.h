@@ -37,11 +37,21 @@ template <int NL> struct Layout {
     static constexpr uint32_t shadow_fields(uint32_t light_samples) { return sh_head + light_samples * sr_fields; }
 };
 
-struct Queue { uint32_t* base; uint32_t capacity; };
-PT_HD float qf(const Queue& q, uint32_t field, uint32_t i) { return pt_u2f(q.base[(size_t)field * q.capacity + i]); }
-PT_HD uint32_t qu(const Queue& q, uint32_t field, uint32_t i) { return q.base[(size_t)field * q.capacity + i]; }
-PT_HD void qsf(const Queue& q, uint32_t field, uint32_t i, float v) { q.base[(size_t)field * q.capacity + i] = pt_f2u(v); }
-PT_HD void qsu(const Queue& q, uint32_t field, uint32_t i, uint32_t v) { q.base[(size_t)field * q.capacity + i] = v; }
+struct Queue { uint32_t* base; uint32_t capacity; uint32_t fields; };
+#ifdef PT_QUEUE_SOA
+PT_HD size_t qindex(const Queue& q, uint32_t field, uint32_t i) { return (size_t)field * q.capacity + i; }
+#else
+// Tiles of 64 items: field k of item i at base[((i / 64) * fields + k) * 64 + i % 64].  A wave still reads or writes 256 contiguous bytes per
+// field, and all fields of an item lie within fields * 256 bytes of one address: one 64-bit address per item and queue, the field as the
+// instruction's immediate offset (the field-major layout kept a 64-bit address or an add per field alive: 13 VGPRs in k_shadow).
+// (tile < 2^24 since capacity <= 2^30, fields < 2^24: masked operands let the compiler take the full-rate 24-bit multiply)
+PT_HD uint32_t qtile(uint32_t tile, uint32_t fields) { return (tile & 0xffffffu) * (fields & 0xffffffu); }
+PT_HD size_t qindex(const Queue& q, uint32_t field, uint32_t i) { return ((size_t)qtile(i >> 6, q.fields) << 6) + (i & 63u) + ((size_t)field << 6); }
+#endif
+PT_HD float qf(const Queue& q, uint32_t field, uint32_t i) { return pt_u2f(q.base[qindex(q, field, i)]); }
+PT_HD uint32_t qu(const Queue& q, uint32_t field, uint32_t i) { return q.base[qindex(q, field, i)]; }
+PT_HD void qsf(const Queue& q, uint32_t field, uint32_t i, float v) { q.base[qindex(q, field, i)] = pt_f2u(v); }
+PT_HD void qsu(const Queue& q, uint32_t field, uint32_t i, uint32_t v) { q.base[qindex(q, field, i)] = v; }
 
 struct RenderParams {
     uint64_t seed;
@@ -180,7 +190,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
         float nee_psa_pdf = env_pdf_for(s, u, v) / pt_abs(cos_i);
         float bsdf_psa_pdf = pv.prev_pdf / pt_abs(cos_i);
         float weight = (bsdf_psa_pdf * bsdf_psa_pdf) / (bsdf_psa_pdf * bsdf_psa_pdf + nee_psa_pdf * nee_psa_pdf);
-        for (int k = 0; k < NL; ++k) out.energy_add[k] = weight * pv.beta[k] * env_emission(s, u, v, lam[k]);
+        PT_ROLLED for (int k = 0; k < NL; ++k) pl_set<NL>(out.energy_add, k, weight * pl_get<NL>(pv.beta, k) * env_emission(s, u, v, pl_get<NL>(lam, k)));
         out.add_energy = true;
         out.vertex_pushed = true; out.env_hit = true;
         return out;
@@ -191,9 +201,10 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     bool is_light = PT_MATERIAL_TAG(hit.material) == PT_TAG_LIGHT;
     pt_f32x4 r = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples));
     float f, pdf; F3 wo;
-    MatEval me[NL];
-    for (int k = 0; k < NL; ++k) me[k] = material_prepare<GGX>(s, m, lam[k], hit.u, hit.v);
-    material_sample_p<GGX>(me[0], r.x, r.y, wi, &f, &wo, &pdf);
+    // (per-wavelength loops stay rolled, their arrays in registers: pl_get / pl_set, pt_device.h)
+    const MatEvalN<NL> me = material_prepare_n<NL, GGX>(s, m, lam, hit.u, hit.v);
+    const MatEval me0 = material_at<NL>(me, 0);
+    material_sample_p<GGX>(me0, r.x, r.y, wi, &f, &wo, &pdf);
     float cos_o = pt_abs(wo.z);
     if (pt_isnan(pdf)) return out;  // utils.rs:261-263: the vertex is never pushed
     float rr = (bounce >= rp.min_bounces) ? pt_min(f / pdf, 1.0f) : 1.0f;
@@ -206,7 +217,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
         if (emission > 0.0f) {
             if (rp.light_samples == 0 || prev_is_camera) {
                 out.energy_add[0] = pv.beta[0] * emission;
-                for (int k = 1; k < NL; ++k) out.energy_add[k] = pv.beta[k] * material_emission(s, m, lam[k], wi);
+                PT_ROLLED for (int k = 1; k < NL; ++k) pl_set<NL>(out.energy_add, k, pl_get<NL>(pv.beta, k) * material_emission(s, m, pl_get<NL>(lam, k), wi));
                 out.add_energy = true;
             } else if (!rp.only_direct) {
                 F3 nee_dir = normalize(sub(hit.p, pv.prev_p));
@@ -215,7 +226,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                 float a = pv.prev_pdf;
                 float weight = (a * a) / (a * a + pdfh * pdfh);
                 out.energy_add[0] = weight * pv.beta[0] * emission;
-                for (int k = 1; k < NL; ++k) out.energy_add[k] = weight * pv.beta[k] * material_emission(s, m, lam[k], wi);
+                PT_ROLLED for (int k = 1; k < NL; ++k) pl_set<NL>(out.energy_add, k, weight * pl_get<NL>(pv.beta, k) * material_emission(s, m, pl_get<NL>(lam, k), wi));
                 out.add_energy = true;
             }
         }
@@ -243,13 +254,13 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                     F3 local_wo = to_local(fr2, direction);
                     if (local_wo.z > 0.0f) {
                         float refl, spdf;
-                        material_bsdf_p<GGX>(me[0], wi2, local_wo, &refl, &spdf);
+                        material_bsdf_p<GGX>(me0, wi2, local_wo, &refl, &spdf);
                         float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + spdf);
                         ray.o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(direction.z)));
                         ray.d = direction;
                         ray.factor[0] = pv.beta[0] * weight * refl * env_emission(s, eu, ev, lambda, ec[0]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
-                        for (int k = 1; k < NL; ++k) {
-                            float rk, pk; material_bsdf_p<GGX>(me[k], wi2, local_wo, &rk, &pk);
+                        for (int k = 1; k < NL; ++k) {   // (hero wavelengths under an environment that light samples pick: no BASELINE configuration; unrolled)
+                            float rk, pk; material_bsdf_p<GGX>(material_at<NL>(me, k), wi2, local_wo, &rk, &pk);
                             ray.factor[k] = pv.beta[k] * weight * rk * env_emission(s, eu, ev, lam[k], ec[k]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
                         }
                         out.shadow_count += 1;
@@ -267,17 +278,19 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                     if (light_pdf != 0.0f) {
                         F3 bsdf_wo = to_local(fr2, ldir);
                         float refl, bpdf;
-                        material_bsdf_p<GGX>(me[0], wi2, bsdf_wo, &refl, &bpdf);
+                        material_bsdf_p<GGX>(me0, wi2, bsdf_wo, &refl, &bpdf);
                         float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + bpdf);
                         ray.o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(bsdf_wo.z)));
                         ray.d = ldir;
                         // pt.rs:196-202: reflectance * throughput * cos_i * cos_o * emission * weight / light_pdf; cos_i and the
                         // emission are only known at the shadow hit and are multiplied in there.
                         ray.factor[0] = refl * pv.beta[0] * pt_abs(bsdf_wo.z) * weight / light_pdf;
-                        for (int k = 1; k < NL; ++k) {
-                            float rk, pk; material_bsdf_p<GGX>(me[k], wi2, bsdf_wo, &rk, &pk);
-                            ray.factor[k] = rk * pv.beta[k] * pt_abs(bsdf_wo.z) * weight / light_pdf;
-                        }
+                        auto passenger = [&](int k) {
+                            float rk, pk; material_bsdf_p<GGX>(material_at<NL>(me, k), wi2, bsdf_wo, &rk, &pk);
+                            pl_set<NL>(ray.factor, k, rk * pl_get<NL>(pv.beta, k) * pt_abs(bsdf_wo.z) * weight / light_pdf);
+                        };
+                        // (the microfacet evaluation is a big body: rolled; the Lambertian one a few instructions: the compiler's choice)
+                        if (GGX) { PT_ROLLED for (int k = 1; k < NL; ++k) passenger(k); } else { for (int k = 1; k < NL; ++k) passenger(k); }
                         out.shadow_count += 1;
                     }
                 }
@@ -289,8 +302,12 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
 
     // continue the walk (utils.rs:301-329); passengers are divided by the hero's pdf (sketch utils.rs:493)
     float beta[NL];
+    for (int k = 1; k < NL; ++k) beta[k] = 0.0f;
     beta[0] = pv.beta[0] * (f / pdf_forward);
-    for (int k = 1; k < NL; ++k) { float fk, pk; material_bsdf_p<GGX>(me[k], wi, wo, &fk, &pk); beta[k] = pv.beta[k] * (fk / pdf_forward); }
+    {
+        auto passenger = [&](int k) { float fk, pk; material_bsdf_p<GGX>(material_at<NL>(me, k), wi, wo, &fk, &pk); pl_set<NL>(beta, k, pl_get<NL>(pv.beta, k) * (fk / pdf_forward)); };
+        if (GGX) { PT_ROLLED for (int k = 1; k < NL; ++k) passenger(k); } else { for (int k = 1; k < NL; ++k) passenger(k); }
+    }
     if (pdf_forward == 0.0f) for (int k = 0; k < NL; ++k) beta[k] = 0.0f;
     if (beta[0] == 0.0f) return out;
     if (r.z > rr) return out;
@@ -491,14 +508,14 @@ PT_HD void clear_shadow_item(const Queue& q, uint32_t item, uint32_t light_sampl
 // What a traced light-sample ray adds, given its closest hit: a light ray contributes only if that hit is a light, with
 // the emission evaluated there (pt.rs:177-217); an environment ray only if nothing was hit (pt.rs:300-330).
 template <int NL>
-PT_HD void shadow_ray_contribution(const SceneView& s, const float* lambda, const ShadowRayT<NL>& ray, bool env, bool hit, const Hit& sh, float* contribution) {
+PT_HD void shadow_ray_contribution(const SceneView& s, const float (&lambda)[NL], const ShadowRayT<NL>& ray, bool env, bool hit, const Hit& sh, float (&contribution)[NL]) {
     for (int k = 0; k < NL; ++k) contribution[k] = 0.0f;
     if (env) { if (!hit) for (int k = 0; k < NL; ++k) contribution[k] = ray.factor[k]; return; }
     if (!hit || PT_MATERIAL_TAG(sh.material) != PT_TAG_LIGHT) return;
     Frame lf = frame_from_normal(sh.n);
     F3 lwi = to_local(lf, neg(ray.d));
     uint32_t lm = material_record(s, sh.material);
-    for (int k = 0; k < NL; ++k) contribution[k] = ray.factor[k] * pt_abs(lwi.z) * material_emission(s, lm, lambda[k], lwi);
+    PT_ROLLED for (int k = 0; k < NL; ++k) pl_set<NL>(contribution, k, pl_get<NL>(ray.factor, k) * pt_abs(lwi.z) * material_emission(s, lm, pl_get<NL>(lambda, k), lwi));
 }
 // The bound of a light ray's search: the nearest light hit (+inf: no light on the ray, nothing to trace), or "unbounded"
 // when the scene forbids the shortcut.  Returns false when the ray cannot contribute.
@@ -516,7 +533,7 @@ PT_HD int shadow_env_stop(const SceneView& s) { return (bu(s, PT_HDR_FLAGS) & PT
 // wave whose lanes hold both kinds traces them together.  ENV = false: the caller knows the scene produces no environment rays
 // (env_sampling_probability = 0) and that half is compiled out.
 template <int NL, int TRAV = PT_TRAV_ANY, bool ENV = true>
-PT_HD void stage_shadow_ray(const SceneView& s, const float* lambda, const ShadowRayT<NL>& ray, bool env, float* contribution) {
+PT_HD void stage_shadow_ray(const SceneView& s, const float (&lambda)[NL], const ShadowRayT<NL>& ray, bool env, float (&contribution)[NL]) {
     for (int k = 0; k < NL; ++k) contribution[k] = 0.0f;
     float bound = PT_INF; int stop = PT_STOP_NONE;
     uint32_t light = 0xffffffffu;   // the light whose hit bounds the search: its test has been run, phase 3 takes the distance (sweep_run)

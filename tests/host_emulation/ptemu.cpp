@@ -67,10 +67,11 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
     rp.energy_stride = capacity;
     rp.camera = pth::camera_params(sc->host.cameras[rd.camera_index], (float)rd.width / (float)rd.height);
     typedef Layout<NL> LY;
-    std::vector<uint32_t> pa((size_t)(LY::path_fields + 2) * capacity), pb((size_t)(LY::path_fields + 2) * capacity), ph((size_t)HS_FIELDS * capacity),
-        psh((size_t)LY::shadow_fields(PT_MAX_LIGHT_SAMPLES) * capacity);
+    const size_t cap64 = ((size_t)capacity + 63u) & ~(size_t)63u;   // queues are tiled by 64 items (pt_stages.h)
+    std::vector<uint32_t> pa((size_t)(LY::path_fields + 2) * cap64), pb((size_t)(LY::path_fields + 2) * cap64), ph((size_t)HS_FIELDS * cap64),
+        psh((size_t)LY::shadow_fields(PT_MAX_LIGHT_SAMPLES) * cap64);
     std::vector<float> energy((size_t)NL * capacity);
-    Queue qa{pa.data(), capacity}, qb{pb.data(), capacity}, qh{ph.data(), capacity}, qs{psh.data(), capacity};
+    Queue qa{pa.data(), capacity, LY::path_fields + 2}, qb{pb.data(), capacity, LY::path_fields + 2}, qh{ph.data(), capacity, HS_FIELDS}, qs{psh.data(), capacity, LY::shadow_fields(PT_MAX_LIGHT_SAMPLES)};
     uint64_t bounce_rays = 0, shadow_rays = 0, env_hits = 0, camera_rays = 0;
     uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
     for (const pth::Pass& pass : pth::plan_passes((uint32_t)pixels.size(), rd.first_sample, rd.sample_count, capacity, rd.phase_samples)) {

@@ -221,6 +221,27 @@ def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
         assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits), env
 
 
+@pytest.mark.parametrize("scene,L,hero", [("cornell_box", 2, 1), ("cornell_box", 3, 4), ("white_furnace", 6, 1), ("hdri_small", 3, 1)])
+def test_forms_without_transforms_change_nothing(engine, pkg, monkeypatch, scene, L, hero):
+    """A scene in which no instance carries a transform (the Cornell box) runs kernel forms with the matrix paths compiled out
+    (PT_SCENE_NO_XF: k_extend / k_shadow in their sweep forms, the lean k_shade).  The general forms (PT_AMD_GENERAL_FORMS=1) give the same
+    film, counters and hits bit for bit; a scene that does hold a transform never gets the lean forms."""
+    import parity_suite
+    b = pkg.scene.SCENES[scene]()
+    rd = pkg.api.render_desc(192, 160, 10, 8, light_samples=L, seed=4, hero_wavelengths=hero)
+    o, d = parity_suite.golden_rays(scene, 1 << 14, 5)
+    ref = engine.create_scene(b)
+    base, pbase = ref.render(rd)
+    hits = ref.intersect(o, d)
+    monkeypatch.setenv("PT_AMD_GENERAL_FORMS", "1")
+    other = engine.create_scene(b)
+    monkeypatch.delenv("PT_AMD_GENERAL_FORMS")
+    film, prof = other.render(rd)
+    assert np.array_equal(base.view(np.uint32), film.view(np.uint32))
+    assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits)
+    parity_suite.assert_hits_equal(hits, other.intersect(o, d))
+
+
 @pytest.mark.parametrize("scene,L,hero", [("cornell_box", 2, 1), ("mixed_small", 3, 1), ("white_furnace", 6, 1), ("cornell_box", 2, 4)])
 def test_pooled_phase3_changes_nothing(engine, pkg, monkeypatch, scene, L, hero):
     """Pure sweep scenes: phase 3 pooled per wave (PT_AMD_POOL=1: the candidate triangles of a wave's 64 rays tested 64 at a time, the

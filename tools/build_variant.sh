@@ -1,0 +1,15 @@
+#!/bin/bash
+# Builds one variant of the engine into variants/<name>.so (git-ignored, travels with gpurun): tools/build_variant.sh <name> [extra hipcc flags]
+# The object files go to a scratch directory, so the product build in rust-pathtracer_amd/csrc is left alone.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd); name=$1; shift
+SRC=$ROOT/rust-pathtracer_amd/csrc; OBJ=/tmp/pt_variant_$name; mkdir -p $OBJ $ROOT/variants
+FLAGS="--offload-arch=gfx950 -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -w $*"
+cd $SRC
+pids=()
+for f in pt_engine.hip pt_kern_extend.hip pt_kern_shadow.hip pt_output.hip pt_compare.hip pt_scene_host.cpp pt_plan.cpp; do /opt/rocm/bin/hipcc $FLAGS -c $f -o $OBJ/${f%.*}.o & pids+=($!); done
+/opt/rocm/bin/hipcc $FLAGS -DPT_SHADE_NL=1 -c pt_kern_shade.hip -o $OBJ/pt_kern_shade1.o & pids+=($!)
+/opt/rocm/bin/hipcc $FLAGS -DPT_SHADE_NL=4 -c pt_kern_shade.hip -o $OBJ/pt_kern_shade4.o & pids+=($!)
+for p in "${pids[@]}"; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $ROOT/variants/$name.so $OBJ/*.o
+echo built variants/$name.so
