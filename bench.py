@@ -5,9 +5,11 @@ max_bounces = 8, PT + NEE, L = 2), one process per GPU.
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step = one pass of the wavefront pipeline over this rank's film shard at `--spp-per-step` x N samples per pixel
-(weak scaling: tiles are dealt along diagonals to ranks, every rank renders 1/N of the pixels at N times the samples, so
-per-GPU work is fixed).  Scene upload, BVH build and buffer allocation happen before the timed region (the window of
+A step = one pass of the wavefront pipeline over this rank's film shard.  `--scaling weak` (the default, what the driver's scaling
+curve assumes): `--spp-per-step` x N samples per pixel — tiles are dealt along diagonals to ranks, every rank renders 1/N of the
+pixels at N times the samples, so per-GPU work is fixed.  `--scaling strong`: the fixed frame of the BASELINE configurations (C2 = 1024
+spp, C4 = 2048 spp of one 1024 x 1024 film) — `--spp-per-step` samples per pixel whatever N is, the tiles of that one frame dealt over
+the N ranks, one reduce; total work is fixed and every fixed cost per call shows.  With one GPU the two modes are the same run.  Scene upload, BVH build and buffer allocation happen before the timed region (the window of
 src/renderer/tiled.rs:294 -> 536); the film stays in HBM.  After the last step the rank films are summed into rank 0
 with one RCCL reduce (disjoint shards, so the sum is a gather) inside the timed region.
 
@@ -86,6 +88,8 @@ def main():
     ap.add_argument("--hero", type=int, default=1, help="wavelengths per path: 1, or 4 for the hero-wavelength variant (C5)")
     ap.add_argument("--workload", default=None, help="label for config.workload (default: derived from the arguments)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline (0 = skip)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every GPU renders 1/N of the pixels at N x --spp-per-step (per-GPU work fixed); strong: the frame is fixed at --spp-per-step, its tiles dealt over the N GPUs")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl = RCCL) even for one process, so that the film reduce runs through RCCL")
     args = ap.parse_args()
 
@@ -114,7 +118,8 @@ def main():
     scene = engine.create_scene(builder)
 
     W, H, L = args.width, args.height, args.light_samples
-    S = sharding.weak_scaling_samples(args.spp_per_step, n_gpus)   # weak scaling: N x the samples on 1/N of the pixels
+    # weak scaling: N x the samples on 1/N of the pixels; strong scaling: the frame's own samples on 1/N of the pixels
+    S = sharding.weak_scaling_samples(args.spp_per_step, n_gpus) if args.scaling == "weak" else args.spp_per_step
     total_spp = S * (args.steps + args.warmup)
     assert total_spp <= 65535 * 16
     film_step = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
@@ -185,7 +190,8 @@ def main():
         traffic, traffic_src, valu = None, None, None
         try:
             import glob
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), key=os.path.getmtime, reverse=True):
+            # (by tag, newest round and letter first: r3b before r3a before r2s — file times do not survive a checkout)
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), key=os.path.basename, reverse=True):
                 summ = json.load(open(path))
                 if summ.get("workload_key") != workload_key:
                     continue
@@ -255,7 +261,7 @@ def main():
         out = {
             "metric": metric_name,
             "value": value, "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload or ("C2: Cornell box (authored mesh + reference light/camera), %dx%d, PT+NEE, max_bounces=%d, min_bounces=1, "
                                                      "light_samples=%d, wavelengths 380-750 nm" % (W, H, args.max_bounces, L) if (args.scene, args.hero) == ("cornell_box", 1)
@@ -263,6 +269,9 @@ def main():
                                                      (args.scene, W, H, args.max_bounces, args.min_bounces, L, args.hero)),
                        "workload_key": workload_key, "scene": args.scene, "spp_per_step_per_gpu": args.spp_per_step, "spp_per_step": S, "samples_per_step": total_samples / args.steps,
                        "parallelism": "film tiles 32x32 dealt along diagonals over %d GPU(s), one RCCL reduce of the XYZ film" % n_gpus,
+                       "scaling_modes": {"weak": "every GPU renders 1/N of the pixels at N x %d spp per step: per-GPU work fixed (default)" % args.spp_per_step,
+                                         "strong": "the frame is fixed at %d spp per step, its tiles dealt over the N GPUs: total work fixed (--scaling strong)" % args.spp_per_step,
+                                         "this_run": args.scaling},
                        "device": engine.device_info()},
             "rays_per_s": {"segments": counts[2] / elapsed, "shadow": counts[7] / elapsed,
                            "total_Mrays": (counts[2] + counts[7]) / elapsed / 1e6},

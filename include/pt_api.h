@@ -229,10 +229,48 @@ typedef struct pt_render_desc {
                                     random_walk (src/integrator/pt.rs:447, utils.rs:708-1103); single wavelength only */
 } pt_render_desc;
 
+/* ---- engine tuning: the run-time switches of the HIP engine as one explicit struct.  None of them changes a result (the GPU tests
+ * compare every one against the default bit for bit); they choose kernel forms, staging and batch sizes.  A scene takes its tuning
+ * when it is created and keeps it: pt_scene_create reads the PT_AMD_* environment ONCE through pt_tuning_default (the variable named
+ * with each field), pt_scene_create_tuned takes the struct from the caller — a Rust host sets these per scene, and a variable that
+ * changes after the scene exists changes nothing.  (The reference has no counterpart: its renderer has no forms to choose.) */
+enum {
+    PT_TUNE_NO_LDS = 1u << 0,          /* PT_AMD_NO_LDS: the blob is read from HBM/L2, nothing staged */
+    PT_TUNE_NO_CORE_LDS = 1u << 1,     /* PT_AMD_NO_CORE_LDS: a blob too big to stage whole is not staged by its core either */
+    PT_TUNE_NO_PARK = 1u << 2,         /* PT_AMD_NO_PARK: walked meshes of a hybrid scene are walked in line */
+    PT_TUNE_POOL = 1u << 3,            /* PT_AMD_POOL: phase 3 of a pure sweep scene pooled per wave (measured slower) */
+    PT_TUNE_EXACT_SLAB = 1u << 4,      /* PT_AMD_EXACT_SLAB: the six-division box test everywhere */
+    PT_TUNE_NO_CULL = 1u << 5,         /* PT_AMD_NO_CULL: no culling by the closest hit, no early stop */
+    PT_TUNE_NO_SWEEP = 1u << 6,        /* PT_AMD_NO_SWEEP: the BVH walk even where a sweep table exists */
+    PT_TUNE_NO_MESH_SWEEP = 1u << 7,   /* PT_AMD_NO_MESH_SWEEP: walked meshes never swept */
+    PT_TUNE_NO_KNOWN_LIGHT = 1u << 8,  /* PT_AMD_NO_KNOWN_LIGHT: a light-sample ray tests its bounding light again in phase 3 */
+    PT_TUNE_GENERAL_FORMS = 1u << 9,   /* PT_AMD_GENERAL_FORMS: no kernel forms specialised by what the scene lacks (transforms) */
+    PT_TUNE_NO_FUSE = 1u << 10,        /* PT_AMD_NO_FUSE: k_extend + k_shade as two launches even where the fused form (k_shade tracing its own segments) exists */
+    PT_TUNE_NO_STAGE_TIMING = 1u << 11,/* PT_AMD_STAGE_TIMING=0: no HIP events around the launches (pt_profile::kernel_seconds stay 0) */
+    PT_TUNE_MULTI_RCCL = 1u << 12      /* PT_AMD_MULTI_RCCL: pt_render_multi takes the RCCL reduce even for one device */
+};
+typedef struct pt_tuning {
+    uint32_t flags;               /* PT_TUNE_* */
+    uint32_t batch_slots;         /* PT_AMD_BATCH: path slots per pass; 0 = 2^27 (2^26 with hero wavelengths) */
+    uint32_t blocks_per_cu;       /* PT_AMD_BLOCKS_PER_CU: queue segments = workgroups per CU; 0 = 64 */
+    uint32_t park_blocks_per_cu;  /* PT_AMD_PARK_BLOCKS_PER_CU: persistent workgroups per CU of the parked kernels with dynamic units; 0 = 4 */
+    int32_t park_dynamic;         /* PT_AMD_PARK_DYNAMIC: 0 static segments, 1 units from a counter, -1 = by staging mode */
+    uint32_t shade_form;          /* PT_AMD_SHADE_FORM: 0 = the leanest form the scene allows, 1 = at least NO_ENV, 2 = FULL */
+    uint32_t lds_all_limit;       /* PT_AMD_LDS_ALL_LIMIT: largest blob staged whole, bytes; 0 = 24 KB */
+    uint32_t multi_virtual;       /* PT_AMD_MULTI_VIRTUAL: pt_render_multi treats every device of the mask as this many (test mode:
+                                     k host threads, streams and replicas per device, films summed on the device); 0 / 1 = off */
+    uint32_t reserved[8];         /* must be 0 */
+} pt_tuning;
+/* The defaults, overridden by whatever PT_AMD_* variables the environment holds at the time of the call. */
+void pt_tuning_default(pt_tuning* tuning);
+
 typedef struct pt_profile {      /* Profile (src/profile.rs:2-8) + timing */
     uint64_t bounce_rays, shadow_rays, light_rays, camera_rays, env_hits;
     double seconds;              /* render loop only: the window of src/renderer/tiled.rs:294 -> :536 */
-    double kernel_seconds[8];    /* HIP-event time per stage: generate, extend, shade, shadow, accumulate, 3 spare */
+    double kernel_seconds[8];    /* HIP-event time per stage: generate, extend, shade, shadow, accumulate; pt_render_multi adds
+                                    [5] = host seconds spent on set-up before the render window (replicas, streams, device films,
+                                    communicator: paid by the first call with a device set and film size, cached on the scene after),
+                                    [6] = host seconds of the film reduce; [7] spare */
     uint64_t kernel_launches[8];
     uint64_t stage_items[8];     /* work items per stage summed over launches: paths generated, segments extended,
                                     vertices shaded, light-sample items traced, pixels accumulated */
@@ -250,7 +288,8 @@ typedef struct pt_hit {          /* HitRecord (src/hittable.rs:7-16) */
 
 typedef struct pt_scene pt_scene;
 
-pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out);
+pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out);   /* tuning = pt_tuning_default */
+pt_status pt_scene_create_tuned(const pt_scene_desc* desc, const pt_tuning* tuning, pt_scene** out);
 void pt_scene_destroy(pt_scene* scene);
 const char* pt_last_error(void);
 

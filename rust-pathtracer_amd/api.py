@@ -121,6 +121,18 @@ class Profile(C.Structure):
                 "kernel_seconds": list(self.kernel_seconds), "kernel_launches": list(self.kernel_launches), "stage_items": list(self.stage_items)}
 
 
+# pt_tuning flags (include/pt_api.h)
+TUNE_NO_LDS, TUNE_NO_CORE_LDS, TUNE_NO_PARK, TUNE_POOL, TUNE_EXACT_SLAB, TUNE_NO_CULL, TUNE_NO_SWEEP, TUNE_NO_MESH_SWEEP, TUNE_NO_KNOWN_LIGHT, \
+    TUNE_GENERAL_FORMS, TUNE_NO_FUSE, TUNE_NO_STAGE_TIMING, TUNE_MULTI_RCCL = (1 << i for i in range(13))
+
+
+class Tuning(C.Structure):
+    """pt_tuning: the engine's run-time switches, taken by a scene when it is created."""
+    _fields_ = [("flags", C.c_uint32), ("batch_slots", C.c_uint32), ("blocks_per_cu", C.c_uint32), ("park_blocks_per_cu", C.c_uint32),
+                ("park_dynamic", C.c_int32), ("shade_form", C.c_uint32), ("lds_all_limit", C.c_uint32), ("multi_virtual", C.c_uint32),
+                ("reserved", C.c_uint32 * 8)]
+
+
 class OutputDesc(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("tonemap", C.c_int32), ("luminance_only", C.c_int32),
                 ("exposure", C.c_float), ("key_value", C.c_float), ("white_point", C.c_float), ("colorspace", C.c_int32),
@@ -151,7 +163,7 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("point", "<f4", 3), ("normal", "<f4", 3), (
 assert HIT_DTYPE.itemsize == C.sizeof(Hit)
 
 # every entry point include/pt_api.h declares (without prefix)
-API_FUNCTIONS = ["scene_create", "scene_destroy", "last_error", "render", "render_device", "render_multi", "device_count", "intersect",
+API_FUNCTIONS = ["scene_create", "scene_create_tuned", "tuning_default", "scene_destroy", "last_error", "render", "render_device", "render_multi", "device_count", "intersect",
                  "bsdf_sample", "bsdf_eval", "emission", "curve_eval", "device_info", "output_film", "write_png", "write_exr", "compare_films"]
 
 
@@ -195,6 +207,8 @@ class Library:
 
         vp, fpp, sz, u32 = C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_uint32
         self._scene_create = bind("scene_create", C.c_int32, [C.POINTER(SceneDesc), C.POINTER(vp)])
+        self._scene_create_tuned = bind("scene_create_tuned", C.c_int32, [C.POINTER(SceneDesc), C.POINTER(Tuning), C.POINTER(vp)], required=False)
+        self._tuning_default = bind("tuning_default", None, [C.POINTER(Tuning)], required=False)
         self._scene_destroy = bind("scene_destroy", None, [vp])
         self._last_error = bind("last_error", C.c_char_p, [])
         self._render = bind("render", C.c_int32, [vp, C.POINTER(RenderDesc), fpp, C.POINTER(Profile)])
@@ -224,8 +238,14 @@ class Library:
     def device_info(self):
         return self._device_info().decode() if self._device_info else "cpu oracle"
 
-    def create_scene(self, builder):
-        return Scene(self, builder)
+    def create_scene(self, builder, tuning=None):
+        """`tuning`: a Tuning (pt_scene_create_tuned); None = pt_scene_create, which reads the PT_AMD_* environment once."""
+        return Scene(self, builder, tuning)
+
+    def tuning_default(self):
+        t = Tuning()
+        self._tuning_default(C.byref(t))
+        return t
 
     def output_film(self, film, tonemap=TONEMAP_CLAMP, luminance_only=True, exposure=0.0, key_value=0.18, white_point=1.0,
                     colorspace=COLORSPACE_SRGB, factor=1.0, want_linear=True):
@@ -262,14 +282,17 @@ class Library:
 class Scene:
     """Owns a pt_scene handle created from a SceneBuilder (rust-pathtracer_amd.scene)."""
 
-    def __init__(self, library, builder):
+    def __init__(self, library, builder, tuning=None):
         self.library = library
         self.builder = builder
         # a SceneBuilder (scene.py) or a SceneFile (scene_file.py, the C++ TOML front end)
         desc, keep = builder.desc_and_keepalive() if hasattr(builder, "desc_and_keepalive") else builder.desc()
         self._keep = keep
         handle = C.c_void_p()
-        library.check(library._scene_create(C.byref(desc), C.byref(handle)))
+        if tuning is not None:
+            library.check(library._scene_create_tuned(C.byref(desc), C.byref(tuning), C.byref(handle)))
+        else:
+            library.check(library._scene_create(C.byref(desc), C.byref(handle)))
         self.handle = handle
 
     def close(self):

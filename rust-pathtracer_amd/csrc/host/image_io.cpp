@@ -237,6 +237,171 @@ bool read_hdr(const std::string& path, float alpha_fill, Image* out, std::string
     return true;
 }
 
+// ---- PIZ (OpenEXR compression 4): what the reference's `exr` crate decodes for any Poly-Haven-style HDRI (src/parsing/texture.rs:75-89).
+// A block holds, per channel and 16-bit half of its samples, a plane of u16 values that were (1) mapped through a table of the values
+// that occur (a bitmap of 65536 bits lists them), (2) transformed by a two-dimensional Haar-like wavelet (the 14-bit form when the
+// largest table index is below 2^14, the modulo-2^16 form otherwise) and (3) Huffman-coded with canonical codes of up to 58 bits and a
+// run-length symbol.  Restated from the published format (OpenEXR's ImfPizCompressor / ImfHuf / ImfWav); every length and index that comes
+// from the file is checked before use.
+namespace piz {
+const int kEncBits = 16, kEncSize = (1 << kEncBits) + 1;   // 65536 symbols + the run-length symbol
+struct BitReader {
+    const uint8_t* p; const uint8_t* end; uint64_t c = 0; int lc = 0;
+    bool get(int n, uint32_t* v) {   // n <= 32, most significant bit first
+        while (lc < n) { if (p >= end) return false; c = (c << 8) | *p++; lc += 8; }
+        lc -= n; *v = (uint32_t)((c >> lc) & ((1ull << n) - 1ull)); return true;
+    }
+};
+// hufUncompress: 20-byte header (first and last symbol, table length, number of data bits, reserved), packed code lengths, data
+bool huf_uncompress(const uint8_t* in, size_t n_in, uint16_t* out, size_t n_out, std::string* error) {
+    if (n_in == 0) { if (n_out != 0) { *error = "EXR PIZ block without data"; return false; } return true; }
+    if (n_in < 20) { *error = "truncated EXR PIZ Huffman header"; return false; }
+    const uint32_t im = le32(in), iM = le32(in + 4), n_bits = le32(in + 12);
+    if (im >= (uint32_t)kEncSize || iM >= (uint32_t)kEncSize || im > iM) { *error = "bad EXR PIZ symbol range"; return false; }
+    // code lengths, 6 bits each; 59..62 = a run of 2..5 zero lengths, 63 = a run of 6 + (next 8 bits)
+    std::vector<uint8_t> len((size_t)kEncSize, 0);
+    BitReader br{in + 20, in + n_in};
+    for (uint32_t sym = im; sym <= iM; ++sym) {
+        uint32_t l;
+        if (!br.get(6, &l)) { *error = "truncated EXR PIZ code table"; return false; }
+        if (l >= 59) {
+            uint32_t run = l - 59 + 2;
+            if (l == 63) { uint32_t more; if (!br.get(8, &more)) { *error = "truncated EXR PIZ code table"; return false; } run = more + 6; }
+            if (sym + run > iM + 1) { *error = "bad EXR PIZ code table"; return false; }
+            sym += run - 1;   // (the lengths stay 0)
+        } else len[sym] = (uint8_t)l;
+    }
+    const uint8_t* data = br.p;   // the table ends on a byte boundary
+    if ((uint64_t)n_bits > 8ull * (uint64_t)(in + n_in - data)) { *error = "bad EXR PIZ bit count"; return false; }
+    // canonical codes (hufCanonicalCodeTable): within a length, codes rise with the symbol; first[l] = the length's first code
+    uint64_t count[59] = {0}, first[59] = {0};
+    for (uint32_t sym = im; sym <= iM; ++sym) count[len[sym]]++;
+    { uint64_t c = 0; for (int l = 58; l > 0; --l) { const uint64_t nc = (c + count[l]) >> 1; first[l] = c; c = nc; } }
+    std::vector<uint32_t> offset(60, 0), sorted;
+    for (int l = 1; l <= 58; ++l) offset[l + 1] = offset[l] + (uint32_t)count[l];
+    sorted.resize(offset[59]);
+    { std::vector<uint32_t> at(offset.begin(), offset.end()); for (uint32_t sym = im; sym <= iM; ++sym) if (len[sym]) sorted[at[len[sym]]++] = sym; }
+    // decode bit by bit (hufDecode's result without its 14-bit table): a code of length l is a symbol iff code - first[l] < count[l]
+    const uint32_t rlc = iM;
+    size_t produced = 0; uint64_t left = n_bits;
+    BitReader dr{data, in + n_in};
+    while (left > 0) {
+        uint64_t code = 0; int l = 0; uint32_t sym = 0; bool found = false;
+        while (l < 58 && left > 0) {
+            uint32_t bit;
+            if (!dr.get(1, &bit)) { *error = "truncated EXR PIZ data"; return false; }
+            code = (code << 1) | bit; ++l; --left;
+            if (count[l] != 0 && code >= first[l] && code - first[l] < count[l]) { sym = sorted[offset[l] + (uint32_t)(code - first[l])]; found = true; break; }
+        }
+        if (!found) { *error = "bad EXR PIZ code"; return false; }   // (the header's bit count is exact: no padding inside it)
+        if (sym == rlc) {
+            uint32_t run;
+            if (left < 8 || !dr.get(8, &run)) { *error = "truncated EXR PIZ run"; return false; }
+            left -= 8;
+            if (produced == 0 || produced + run > n_out) { *error = "bad EXR PIZ run"; return false; }
+            for (uint32_t k = 0; k < run; ++k) out[produced + k] = out[produced - 1];
+            produced += run;
+        } else {
+            if (produced >= n_out) { *error = "EXR PIZ block is longer than its tile"; return false; }
+            out[produced++] = (uint16_t)sym;
+        }
+    }
+    if (produced != n_out) { *error = "EXR PIZ block has the wrong size"; return false; }
+    return true;
+}
+inline void wdec14(uint16_t l, uint16_t h, uint16_t* a, uint16_t* b) {
+    const int ls = (int16_t)l, hs = (int16_t)h;
+    const int ai = ls + (hs & 1) + (hs >> 1);
+    *a = (uint16_t)(int16_t)ai; *b = (uint16_t)(int16_t)(ai - hs);
+}
+inline void wdec16(uint16_t l, uint16_t h, uint16_t* a, uint16_t* b) {
+    const int m = l, d = h;
+    const int bb = (m - (d >> 1)) & 0xffff, aa = (d + bb - 0x8000) & 0xffff;
+    *b = (uint16_t)bb; *a = (uint16_t)aa;
+}
+// wav2Decode on nx x ny values, ox / oy apart (in u16 units), mx = the largest value the encoder's table produced
+void wav2_decode(uint16_t* in, int nx, int ox, int ny, int oy, uint16_t mx) {
+    const bool w14 = mx < (1 << 14);
+    const int n = nx > ny ? ny : nx;
+    int p = 1, p2;
+    while (p <= n) p <<= 1;
+    p >>= 1; p2 = p; p >>= 1;
+    while (p >= 1) {
+        uint16_t* py = in;
+        uint16_t* const ey = in + (ptrdiff_t)oy * (ny - p2);
+        const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
+        uint16_t i00, i01, i10, i11;
+        for (; py <= ey; py += oy2) {
+            uint16_t* px = py;
+            uint16_t* const ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t* p01 = px + ox1; uint16_t* p10 = px + oy1; uint16_t* p11 = p10 + ox1;
+                if (w14) { wdec14(*px, *p10, &i00, &i10); wdec14(*p01, *p11, &i01, &i11); wdec14(i00, i01, px, p01); wdec14(i10, i11, p10, p11); }
+                else { wdec16(*px, *p10, &i00, &i10); wdec16(*p01, *p11, &i01, &i11); wdec16(i00, i01, px, p01); wdec16(i10, i11, p10, p11); }
+            }
+            if (nx & p) {
+                uint16_t* p10 = px + oy1;
+                if (w14) wdec14(*px, *p10, &i00, p10); else wdec16(*px, *p10, &i00, p10);
+                *px = i00;
+            }
+        }
+        if (ny & p) {
+            uint16_t* px = py;
+            uint16_t* const ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t* p01 = px + ox1;
+                if (w14) wdec14(*px, *p01, &i00, p01); else wdec16(*px, *p01, &i00, p01);
+                *px = i00;
+            }
+        }
+        p2 = p; p >>= 1;
+    }
+}
+// One block of bw x bh pixels with the given channel types (1 = half: one u16 per sample, else two) -> the block's scanline-ordered bytes
+bool decode_block(const uint8_t* src, size_t size, const std::vector<int>& types, int bw, int bh, std::vector<uint8_t>* raw, std::string* error) {
+    if (size < 4) { *error = "truncated EXR PIZ block"; return false; }
+    const uint32_t min_nz = le16(src), max_nz = le16(src + 2);
+    const uint32_t kBitmap = 8192;
+    if (max_nz >= kBitmap) { *error = "bad EXR PIZ bitmap range"; return false; }
+    std::vector<uint8_t> bitmap(kBitmap, 0);
+    size_t q = 4;
+    if (min_nz <= max_nz) {
+        const size_t n = (size_t)max_nz - min_nz + 1;
+        if (q + n > size) { *error = "truncated EXR PIZ bitmap"; return false; }
+        memcpy(&bitmap[min_nz], src + q, n); q += n;
+    }
+    std::vector<uint16_t> lut(65536, 0);
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < 65536; ++i) if (i == 0 || (bitmap[i >> 3] & (1u << (i & 7)))) lut[k++] = (uint16_t)i;
+    const uint16_t max_value = (uint16_t)(k - 1);
+    if (q + 4 > size) { *error = "truncated EXR PIZ block"; return false; }
+    const uint32_t length = le32(src + q); q += 4;
+    if ((uint64_t)q + length > size) { *error = "bad EXR PIZ data length"; return false; }
+    size_t total = 0;
+    for (int t : types) total += (size_t)bw * bh * (t == 1 ? 1 : 2);
+    std::vector<uint16_t> buf(total);
+    if (!huf_uncompress(src + q, length, buf.data(), total, error)) return false;
+    size_t start = 0;
+    std::vector<size_t> starts;
+    for (int t : types) {
+        const int sz = t == 1 ? 1 : 2;
+        starts.push_back(start);
+        for (int j = 0; j < sz; ++j) wav2_decode(buf.data() + start + j, bw, sz, bh, bw * sz, max_value);
+        start += (size_t)bw * bh * sz;
+    }
+    for (uint16_t& v : buf) v = lut[v];
+    raw->resize(total * 2);
+    size_t o = 0;
+    for (int y = 0; y < bh; ++y)
+        for (size_t c = 0; c < types.size(); ++c) {
+            const size_t n = (size_t)bw * (types[c] == 1 ? 1 : 2);
+            const uint16_t* from = buf.data() + starts[c] + n * y;
+            for (size_t i = 0; i < n; ++i) { (*raw)[o++] = (uint8_t)(from[i] & 0xff); (*raw)[o++] = (uint8_t)(from[i] >> 8); }   // little-endian, as the other codecs leave it
+        }
+    return true;
+}
+}  // namespace piz
+
 bool read_exr(const std::string& path, Image* out, std::string* error) {
     std::vector<uint8_t> d;
     if (!read_file(path, &d, error)) return false;
@@ -282,7 +447,7 @@ bool read_exr(const std::string& path, Image* out, std::string* error) {
     if (attr["compression"].size() < 1 || attr["dataWindow"].size() < 16) { *error = "EXR header attribute is too short"; return false; }
     if (channels.empty()) { *error = "EXR file without channels"; return false; }
     int compression = attr["compression"][0];
-    if (compression > 3) { *error = "EXR compression " + std::to_string(compression) + " is not supported (only none, RLE, ZIPS, ZIP)"; return false; }
+    if (compression > 4) { *error = "EXR compression " + std::to_string(compression) + " is not supported (only none, RLE, ZIPS, ZIP, PIZ)"; return false; }
     const uint8_t* dw = attr["dataWindow"].data();
     int x0 = (int)le32(dw), y0 = (int)le32(dw + 4), x1 = (int)le32(dw + 8), y1 = (int)le32(dw + 12);
     const int64_t W64 = (int64_t)x1 - x0 + 1, H64 = (int64_t)y1 - y0 + 1;
@@ -305,7 +470,9 @@ bool read_exr(const std::string& path, Image* out, std::string* error) {
         if (tile_w <= 0 || tile_h <= 0) { *error = "bad EXR tile size"; return false; }
         if ((t[8] & 0xf) != 0) { *error = "mip/rip-mapped EXR files are not supported"; return false; }
     }
-    int block_lines = compression == 3 ? 16 : 1;
+    int block_lines = compression == 3 ? 16 : compression == 4 ? 32 : 1;
+    std::vector<int> channel_types;
+    for (auto& c : channels) channel_types.push_back(c.type);
     size_t blocks = tiled ? (size_t)((W + tile_w - 1) / tile_w) * ((H + tile_h - 1) / tile_h) : (size_t)(H + block_lines - 1) / block_lines;
     if ((uint64_t)p + 8ull * blocks > d.size()) { *error = "truncated EXR offset table"; return false; }
     std::vector<uint8_t> raw, tmp;
@@ -330,7 +497,11 @@ bool read_exr(const std::string& path, Image* out, std::string* error) {
         if ((uint64_t)(src - d.data()) + size > d.size() || bw <= 0 || bh <= 0 || by < 0 || bx < 0 || bx + bw > W || by + bh > H) { *error = "bad EXR block"; return false; }
         size_t expect = pixel_bytes * (size_t)bw * bh;
         const uint8_t* data = src;
-        if (compression != 0 && size < expect) {
+        if (compression == 4 && size < expect) {
+            if (!piz::decode_block(src, size, channel_types, bw, bh, &raw, error)) return false;
+            if (raw.size() != expect) { *error = "EXR block has the wrong size"; return false; }
+            data = raw.data();
+        } else if (compression != 0 && size < expect) {
             if (compression == 1) {  // RLE
                 tmp.clear();
                 size_t q = 0;

@@ -113,8 +113,23 @@ struct DeviceBuffers {
 
 }  // namespace
 
+// What pt_render_multi sets up for a set of devices and a film size, kept on the scene: a frame-by-frame caller pays for streams, device
+// films and the RCCL communicator once (round-2 advice: they were made and destroyed on every call, outside the timed window).
+struct MultiSetup {
+    std::vector<int> devices;         // physical devices of the mask
+    uint32_t virt = 1;                // virtual devices per physical one (pt_tuning::multi_virtual)
+    bool rccl = false;
+    size_t film_bytes = 0;
+    std::vector<float*> films;        // per virtual device, on its physical device
+    std::vector<hipStream_t> streams; // per virtual device
+    std::vector<ncclComm_t> comms;    // per physical device (rccl only)
+    bool valid = false;
+};
+
 struct pt_scene {
     pth::HostScene host;
+    pt_tuning tuning;
+    MultiSetup multi;
     uint32_t* d_blob = nullptr;
     float* d_tex = nullptr;
     uint32_t blob_words = 0;
@@ -125,7 +140,7 @@ struct pt_scene {
     std::vector<hipEvent_t> events;  // pairs (start, stop), grown on demand
     float* film_cache = nullptr;     // pt_render's device film, kept between calls
     size_t film_cache_bytes = 0;
-    std::vector<pt_scene*> replicas; // pt_render_multi: this scene on the other devices, by device index (nullptr = not made yet / this one)
+    std::vector<pt_scene*> replicas; // pt_render_multi: this scene on the other (virtual) devices, by device index x virtual index (nullptr = not made yet / this one)
 };
 
 namespace {
@@ -187,6 +202,8 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
     if (!v || !*v) return dflt;
     return (uint32_t)strtoul(v, nullptr, 10);
 }
+// the value a tuning field stands for (0 = "the default" in the struct)
+uint32_t tuned(uint32_t value, uint32_t dflt) { return value ? value : dflt; }
 
 pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hipStream_t stream, pt_profile* profile) {
     if (!sc || !rdp || !d_film) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
@@ -196,12 +213,13 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     HIP_TRY(hipSetDevice(sc->device));
 
     std::vector<uint32_t> pixels = pth::shard_pixels(rd.width, rd.height, rd.tile_width, rd.tile_height, rd.shard_index, rd.shard_count);
-    uint32_t capacity = env_u32("PT_AMD_BATCH", 1u << 27);  // path slots per pass (128 Mi ~ 32 GB of queues of the 288 GB; tools/sweep.sh)
+    const pt_tuning& tn = sc->tuning;
+    uint32_t capacity = tuned(tn.batch_slots, 1u << 27);  // path slots per pass (128 Mi ~ 32 GB of queues of the 288 GB; tools/sweep.sh)
     if (capacity < 1024) capacity = 1024;
     uint64_t want = (uint64_t)pixels.size() * rd.sample_count;
     if (want < capacity) capacity = (uint32_t)(want ? want : 1);
-    const uint32_t blocks_per_cu = env_u32("PT_AMD_BLOCKS_PER_CU", 64);
-    if (blocks_per_cu == 0 || blocks_per_cu > 1024) return fail(PT_ERR_INVALID_ARGUMENT, "PT_AMD_BLOCKS_PER_CU must be in 1..1024");
+    const uint32_t blocks_per_cu = tuned(tn.blocks_per_cu, 64);
+    if (blocks_per_cu > 1024) return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning::blocks_per_cu (PT_AMD_BLOCKS_PER_CU) must be in 1..1024");
     const int grid = sc->num_cus * (int)blocks_per_cu;  // queue segments = workgroups per launch
     // a pass holds at least one whole phase of one pixel (pt_plan.cpp): the queues must too (NaiveRenderer settings: phase = spp)
     { const uint32_t phase = rd.sample_count < rd.phase_samples ? rd.sample_count : rd.phase_samples; if (capacity < phase) capacity = phase; }
@@ -231,18 +249,18 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     const bool sweep = sc->host.blob[PT_HDR_SWEEP_OFF] != 0 && !(sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP);
     // the sweep table holds walked meshes: rays that reach one are parked and resumed in full waves (PT_AMD_NO_PARK=1: in line)
     const bool walks = (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) != 0;
-    const bool parked = sweep && walks && b.park != nullptr && !env_u32("PT_AMD_NO_PARK", 0);
+    const bool parked = sweep && walks && b.park != nullptr && !(tn.flags & PT_TUNE_NO_PARK);
     // PT_AMD_POOL=1: phase 3 of a pure sweep scene pooled per wave (sweep_run_pooled).  Bit-identical, but measured slower than the lane
     // loop on MI355X (C2: k_extend 3155 vs 2475 us, k_shadow 5421 vs 4677 us; DESIGN.md section 5 has the breakdown), so it is not the default.
-    const bool pooled = sweep && !walks && mode == PT_LDS_ALL && lds_bytes + pool_lds_bytes() <= kLdsBlobLimitBytes && env_u32("PT_AMD_POOL", 0) != 0;
+    const bool pooled = sweep && !walks && mode == PT_LDS_ALL && lds_bytes + pool_lds_bytes() <= kLdsBlobLimitBytes && (tn.flags & PT_TUNE_POOL) != 0;
     // (walked meshes in line under PT_AMD_NO_PARK, and every partly staged or unstaged blob: the run-time choice of PT_FORM_ANY)
     const int trav_form = parked ? PT_FORM_PARKED : (mode != PT_LDS_ALL || (sweep && walks)) ? PT_FORM_ANY : pooled ? PT_FORM_POOLED : sweep ? PT_FORM_SWEEP : PT_FORM_WALK;
     // The parked kernels take units of work from a counter, a few persistent workgroups per CU, when the whole blob is staged in LDS
     // (C3: k_extend 9175 -> 7880 us, k_shadow 8008 -> 7105, 487 -> 543 Msamples/s: park lists that live across units keep the drains
     // full).  With the mesh in HBM/L2 (C4) the static form wins, 1128 vs 1083 Msamples/s: a wave's parked rays then come from one
     // region of the film and walk the same part of the mesh.  PT_AMD_PARK_DYNAMIC=0 / 1 forces either.
-    const bool park_dynamic = parked && env_u32("PT_AMD_PARK_DYNAMIC", mode == PT_LDS_ALL ? 1 : 0) != 0;
-    const int dyn_grid = sc->num_cus * (int)env_u32("PT_AMD_PARK_BLOCKS_PER_CU", 4);
+    const bool park_dynamic = parked && (tn.park_dynamic < 0 ? mode == PT_LDS_ALL : tn.park_dynamic != 0);
+    const int dyn_grid = sc->num_cus * (int)tuned(tn.park_blocks_per_cu, 4);
     LaunchCfg cfg{grid, lds_bytes, stream, mode};
     cfg.dyn_grid = dyn_grid < grid ? dyn_grid : grid;
     cfg.lacks = sc->lacks;
@@ -256,11 +274,13 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     }
     // (a PassthroughFilter lives in the forms that hold the GGX code)
     const int shade_form = rd.medium_aware ? PT_SHADE_MEDIUM
-                         : (env_prob != 0.0f || env_u32("PT_AMD_SHADE_FORM", 0) == 2) ? PT_SHADE_FULL : (has_ggx || env_u32("PT_AMD_SHADE_FORM", 0) == 1) ? PT_SHADE_NO_ENV : PT_SHADE_LEAN;
-    // k_shade that traces its own segments (PT_AMD_FUSE): exists for the pure sweep form of a fully staged, transform-free scene shaded by the lean form
-    cfg.fuse = env_u32("PT_AMD_FUSE", 0) != 0 && trav_form == PT_FORM_SWEEP && shade_form == PT_SHADE_LEAN && (cfg.lacks & PT_SCENE_NO_XF) != 0;
+                         : (env_prob != 0.0f || tn.shade_form == 2) ? PT_SHADE_FULL : (has_ggx || tn.shade_form == 1) ? PT_SHADE_NO_ENV : PT_SHADE_LEAN;
+    // k_shade that traces its own segments: exists for the pure sweep form of a fully staged, transform-free scene shaded by the lean form.
+    // Measured (profiles/r3_experiments.md): C2 +4..5 % (4370 us against 2095 + 2490..2640 per bounce); with four wavelengths per path it
+    // loses (C5 996 against 1093 Msamples/s: the traversal then runs at the three waves per SIMD the wide vertex code leaves), so single wavelength only.
+    cfg.fuse = !(tn.flags & PT_TUNE_NO_FUSE) && !hero && trav_form == PT_FORM_SWEEP && shade_form == PT_SHADE_LEAN && (cfg.lacks & PT_SCENE_NO_XF) != 0;
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
-    const bool timing = env_u32("PT_AMD_STAGE_TIMING", 1) != 0;
+    const bool timing = !(tn.flags & PT_TUNE_NO_STAGE_TIMING);
     double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0};
     uint64_t stage_launches[ST_COUNT] = {0, 0, 0, 0, 0};
     // (a queue's tiles are laid out by the number of fields this render uses, pt_stages.h: the buffers are sized for the widest layout seen)
@@ -389,22 +409,23 @@ static pt_status scene_to_device(pt_scene* sc) {
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, sc->device);
     if (e != hipSuccess) return fail(PT_ERR_NO_DEVICE, hipGetErrorString(e));
     sc->num_cus = prop.multiProcessorCount;
-    if (env_u32("PT_AMD_EXACT_SLAB", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_EXACT_SLAB;
-    if (env_u32("PT_AMD_NO_CULL", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_CULL;
-    if (env_u32("PT_AMD_NO_SWEEP", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_SWEEP;
-    if (env_u32("PT_AMD_NO_MESH_SWEEP", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_MESH_SWEEP;
-    if (env_u32("PT_AMD_NO_KNOWN_LIGHT", 0)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_KNOWN_LIGHT;
+    const pt_tuning& tn = sc->tuning;
+    if (tn.flags & PT_TUNE_EXACT_SLAB) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_EXACT_SLAB;
+    if (tn.flags & PT_TUNE_NO_CULL) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_CULL;
+    if (tn.flags & PT_TUNE_NO_SWEEP) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_SWEEP;
+    if (tn.flags & PT_TUNE_NO_MESH_SWEEP) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_MESH_SWEEP;
+    if (tn.flags & PT_TUNE_NO_KNOWN_LIGHT) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_KNOWN_LIGHT;
     sc->blob_words = (uint32_t)sc->host.blob.size();
     {   // no instance carries a transform (the Cornell box): the forms without the matrix paths (PT_AMD_GENERAL_FORMS=1 keeps the general ones)
         bool any_xf = false;
         const std::vector<uint32_t>& bl = sc->host.blob;
         for (uint32_t i = 0; i < bl[PT_HDR_INSTANCE_COUNT]; ++i) any_xf = any_xf || (bl[bl[PT_HDR_INSTANCE_OFF] + i * PT_INST_WORDS + PT_INST_FLAGS] & 1u) != 0u;
-        sc->lacks = (!any_xf && !env_u32("PT_AMD_GENERAL_FORMS", 0)) ? PT_SCENE_NO_XF : 0u;
+        sc->lacks = (!any_xf && !(tn.flags & PT_TUNE_GENERAL_FORMS)) ? PT_SCENE_NO_XF : 0u;
     }
-    const bool no_lds = env_u32("PT_AMD_NO_LDS", 0) != 0;
-    const uint32_t all_limit = env_u32("PT_AMD_LDS_ALL_LIMIT", kLdsAllLimitBytes);   // (experiments: the largest blob staged whole)
+    const bool no_lds = (tn.flags & PT_TUNE_NO_LDS) != 0;
+    const uint32_t all_limit = tuned(tn.lds_all_limit, kLdsAllLimitBytes);   // (experiments: the largest blob staged whole)
     sc->lds_mode = no_lds ? PT_LDS_NONE : (sc->blob_words * 4 <= (all_limit < kLdsBlobLimitBytes ? all_limit : kLdsBlobLimitBytes) ? PT_LDS_ALL
-                 : (sc->host.blob[PT_HDR_CORE_WORDS] * 4 <= kLdsBlobLimitBytes && !env_u32("PT_AMD_NO_CORE_LDS", 0) ? PT_LDS_CORE : PT_LDS_NONE));
+                 : (sc->host.blob[PT_HDR_CORE_WORDS] * 4 <= kLdsBlobLimitBytes && !(tn.flags & PT_TUNE_NO_CORE_LDS) ? PT_LDS_CORE : PT_LDS_NONE));
     e = hipMalloc(&sc->d_blob, sizeof(uint32_t) * sc->host.blob.size());
     if (e == hipSuccess) e = hipMalloc(&sc->d_tex, sizeof(float) * (sc->host.tex.size() + 4));
     if (e == hipSuccess) e = hipMemcpy(sc->d_blob, sc->host.blob.data(), sizeof(uint32_t) * sc->host.blob.size(), hipMemcpyHostToDevice);
@@ -419,11 +440,39 @@ static pt_status scene_to_device(pt_scene* sc) {
     return PT_OK;
 }
 
+void pt_tuning_default(pt_tuning* t) {
+    if (!t) return;
+    memset(t, 0, sizeof(*t));
+    const struct { const char* name; uint32_t bit; } flags[] = {
+        {"PT_AMD_NO_LDS", PT_TUNE_NO_LDS}, {"PT_AMD_NO_CORE_LDS", PT_TUNE_NO_CORE_LDS}, {"PT_AMD_NO_PARK", PT_TUNE_NO_PARK}, {"PT_AMD_POOL", PT_TUNE_POOL},
+        {"PT_AMD_EXACT_SLAB", PT_TUNE_EXACT_SLAB}, {"PT_AMD_NO_CULL", PT_TUNE_NO_CULL}, {"PT_AMD_NO_SWEEP", PT_TUNE_NO_SWEEP}, {"PT_AMD_NO_MESH_SWEEP", PT_TUNE_NO_MESH_SWEEP},
+        {"PT_AMD_NO_KNOWN_LIGHT", PT_TUNE_NO_KNOWN_LIGHT}, {"PT_AMD_GENERAL_FORMS", PT_TUNE_GENERAL_FORMS}, {"PT_AMD_NO_FUSE", PT_TUNE_NO_FUSE}, {"PT_AMD_MULTI_RCCL", PT_TUNE_MULTI_RCCL}};
+    for (const auto& f : flags) if (env_u32(f.name, 0)) t->flags |= f.bit;
+    if (env_u32("PT_AMD_STAGE_TIMING", 1) == 0) t->flags |= PT_TUNE_NO_STAGE_TIMING;
+    t->batch_slots = env_u32("PT_AMD_BATCH", 0);
+    t->blocks_per_cu = env_u32("PT_AMD_BLOCKS_PER_CU", 0);
+    t->park_blocks_per_cu = env_u32("PT_AMD_PARK_BLOCKS_PER_CU", 0);
+    t->park_dynamic = getenv("PT_AMD_PARK_DYNAMIC") && *getenv("PT_AMD_PARK_DYNAMIC") ? (env_u32("PT_AMD_PARK_DYNAMIC", 0) != 0 ? 1 : 0) : -1;
+    t->shade_form = env_u32("PT_AMD_SHADE_FORM", 0);
+    t->lds_all_limit = env_u32("PT_AMD_LDS_ALL_LIMIT", 0);
+    t->multi_virtual = env_u32("PT_AMD_MULTI_VIRTUAL", 0);
+}
+
 pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
-    if (!desc || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    pt_tuning t;
+    pt_tuning_default(&t);   // the only place the PT_AMD_* environment is read
+    return pt_scene_create_tuned(desc, &t, out);
+}
+
+pt_status pt_scene_create_tuned(const pt_scene_desc* desc, const pt_tuning* tuning, pt_scene** out) {
+    if (!desc || !out || !tuning) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    for (uint32_t r : tuning->reserved) if (r != 0) return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning::reserved must be 0");
+    if (tuning->shade_form > 2 || tuning->park_dynamic < -1 || tuning->park_dynamic > 1 || tuning->multi_virtual > 64)
+        return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning: shade_form in 0..2, park_dynamic in -1..1, multi_virtual <= 64");
     pt_status st = ensure_device();
     if (st != PT_OK) return st;
     pt_scene* sc = new pt_scene();
+    sc->tuning = *tuning;
     std::string err;
     if (!pth::build_host_scene(*desc, &sc->host, &err)) { delete sc; return fail(PT_ERR_INVALID_ARGUMENT, err); }
     st = scene_to_device(sc);
@@ -432,10 +481,12 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     return PT_OK;
 }
 
+static void multi_release(MultiSetup& m);
 void pt_scene_destroy(pt_scene* sc) {
     if (!sc) return;
     for (pt_scene* r : sc->replicas) if (r) pt_scene_destroy(r);
     sc->replicas.clear();
+    if (sc->multi.valid) multi_release(sc->multi);
     hipSetDevice(sc->device);
     sc->buf.release();
     hipFree(sc->d_blob); hipFree(sc->d_tex); hipFree(sc->film_cache);
@@ -498,6 +549,49 @@ Rccl& rccl() {
 }
 }  // namespace
 
+// dst += src over n float4 pixels: the films of the virtual devices that share one physical device (pt_tuning::multi_virtual)
+__global__ void __launch_bounds__(kBlock) k_film_add(float4* __restrict__ dst, const float4* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 a = dst[i], b = src[i];
+        dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+static void multi_release(MultiSetup& m) {
+    for (size_t v = 0; v < m.films.size(); ++v) {
+        if (m.devices.empty()) break;
+        hipSetDevice(m.devices[v / m.virt]);
+        if (v < m.streams.size() && m.streams[v]) hipStreamDestroy(m.streams[v]);
+        if (m.films[v]) hipFree(m.films[v]);
+    }
+    for (size_t p = 0; p < m.comms.size(); ++p) if (m.comms[p]) { hipSetDevice(m.devices[p]); rccl().comm_destroy(m.comms[p]); }
+    m = MultiSetup();
+}
+
+// Streams, device films and (for more than one physical device) the RCCL communicator of a device set, made once per scene and film size.
+static pt_status multi_setup(pt_scene* sc, const std::vector<int>& devices, uint32_t virt, bool use_rccl, size_t film_bytes) {
+    MultiSetup& m = sc->multi;
+    if (m.valid && m.devices == devices && m.virt == virt && m.rccl == use_rccl && m.film_bytes >= film_bytes) return PT_OK;
+    multi_release(m);
+    m.devices = devices; m.virt = virt; m.rccl = use_rccl; m.film_bytes = film_bytes;
+    const size_t nv = devices.size() * virt;
+    m.films.assign(nv, nullptr); m.streams.assign(nv, nullptr);
+    for (size_t v = 0; v < nv; ++v) {
+        hipError_t e = hipSetDevice(devices[v / virt]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&m.streams[v], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc(&m.films[v], film_bytes);
+        if (e != hipSuccess) { multi_release(m); return fail(e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE, std::string("pt_render_multi set-up: ") + hipGetErrorString(e)); }
+    }
+    if (use_rccl) {
+        if (!rccl().ok()) { multi_release(m); return fail(PT_ERR_DEVICE, "librccl.so could not be loaded: pt_render_multi needs RCCL for more than one device"); }
+        m.comms.assign(devices.size(), nullptr);
+        ncclResult_t rc = rccl().comm_init_all(m.comms.data(), (int)devices.size(), devices.data());
+        if (rc != ncclSuccess) { multi_release(m); return fail(PT_ERR_DEVICE, std::string("ncclCommInitAll: ") + rccl().error_string(rc)); }
+    }
+    m.valid = true;
+    return PT_OK;
+}
+
 pt_status pt_render_multi(pt_scene* sc, const pt_render_desc* rdp, uint64_t device_mask, float* film, pt_profile* profile) {
     if (!sc || !rdp || !film) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     if (rdp->width == 0 || rdp->height == 0) return fail(PT_ERR_INVALID_ARGUMENT, "width and height must be positive");
@@ -507,91 +601,93 @@ pt_status pt_render_multi(pt_scene* sc, const pt_render_desc* rdp, uint64_t devi
     std::vector<int> devices;
     for (uint32_t d = 0; d < visible && d < 64; ++d) if (device_mask == 0 || ((device_mask >> d) & 1ull)) devices.push_back((int)d);
     if (devices.empty()) return fail(PT_ERR_INVALID_ARGUMENT, "device_mask names no visible HIP device");
-    const int n = (int)devices.size();
-    // PT_AMD_MULTI_RCCL=1: take the RCCL reduce even for one device (the call path of a multi-device node, exercised on a single GPU)
-    const bool use_rccl = n > 1 || env_u32("PT_AMD_MULTI_RCCL", 0) != 0;
-    if (!use_rccl && devices[0] == sc->device) return pt_render(sc, rdp, film, profile);
+    const int np = (int)devices.size();                                         // physical devices
+    const uint32_t virt = sc->tuning.multi_virtual > 1 ? sc->tuning.multi_virtual : 1u;   // virtual devices per physical one (test mode)
+    const int n = np * (int)virt;                                               // shards = host threads = streams = replicas
+    // the RCCL reduce for more than one physical device; PT_TUNE_MULTI_RCCL takes it even for one (the call path of a node, on a single GPU)
+    const bool use_rccl = np > 1 || (sc->tuning.flags & PT_TUNE_MULTI_RCCL) != 0;
+    if (!use_rccl && n == 1 && devices[0] == sc->device) return pt_render(sc, rdp, film, profile);
 
-    // one replica per device (this scene itself on its own device), made on first use and kept
-    if (sc->replicas.size() < visible) sc->replicas.resize(visible, nullptr);
+    // whatever happens below, the caller gets its current device back
+    struct DeviceGuard { int d = 0; bool ok = false; DeviceGuard() { ok = hipGetDevice(&d) == hipSuccess; } ~DeviceGuard() { if (ok) hipSetDevice(d); } } guard;
+    const auto t_entry = std::chrono::steady_clock::now();
+
+    // one replica per (virtual) device — this scene itself for the first one on its own device — made on first use and kept
+    if (sc->replicas.size() < (size_t)visible * virt) sc->replicas.resize((size_t)visible * virt, nullptr);
     std::vector<pt_scene*> scene_of(n, nullptr);
-    for (int i = 0; i < n; ++i) {
-        const int d = devices[i];
-        if (d == sc->device) { scene_of[i] = sc; continue; }
-        if (!sc->replicas[d]) {
+    for (int v = 0; v < n; ++v) {
+        const int d = devices[v / virt];
+        const size_t slot = (size_t)d * virt + (size_t)v % virt;
+        if (d == sc->device && v % (int)virt == 0) { scene_of[v] = sc; continue; }
+        if (!sc->replicas[slot]) {
             HIP_TRY(hipSetDevice(d));
             pt_scene* r = new pt_scene();
             r->host = sc->host;
+            r->tuning = sc->tuning;
             pt_status st = scene_to_device(r);
-            if (st != PT_OK) { const std::string msg = g_error; pt_scene_destroy(r); hipSetDevice(sc->device); g_error = msg; return st; }
-            sc->replicas[d] = r;
+            if (st != PT_OK) { const std::string msg = g_error; pt_scene_destroy(r); g_error = msg; return st; }
+            sc->replicas[slot] = r;
         }
-        scene_of[i] = sc->replicas[d];
+        scene_of[v] = sc->replicas[slot];
     }
     const size_t bytes = sizeof(float) * 4 * (size_t)rdp->width * rdp->height;
-    std::vector<float*> d_film(n, nullptr);
-    std::vector<hipStream_t> streams(n, nullptr);
+    pt_status st = multi_setup(sc, devices, virt, use_rccl, bytes);
+    if (st != PT_OK) return st;
+    MultiSetup& m = sc->multi;
     std::vector<pt_status> status(n, PT_OK);
     std::vector<std::string> errors(n);
     std::vector<pt_profile> profiles(n);
-    std::vector<ncclComm_t> comms(n, nullptr);
-    auto cleanup = [&] {
-        for (int i = 0; i < n; ++i) {
-            hipSetDevice(devices[i]);
-            if (comms[i]) rccl().comm_destroy(comms[i]);
-            if (streams[i]) hipStreamDestroy(streams[i]);
-            if (d_film[i]) hipFree(d_film[i]);
-        }
-        hipSetDevice(sc->device);
-    };
-    if (use_rccl) {
-        if (!rccl().ok()) return fail(PT_ERR_DEVICE, "librccl.so could not be loaded: pt_render_multi needs RCCL for more than one device");
-        ncclResult_t rc = rccl().comm_init_all(comms.data(), n, devices.data());
-        if (rc != ncclSuccess) { cleanup(); return fail(PT_ERR_DEVICE, std::string("ncclCommInitAll: ") + rccl().error_string(rc)); }
-    }
     const auto t0 = std::chrono::steady_clock::now();
-    auto worker = [&](int i) {
-        auto bad = [&](pt_status st, const std::string& msg) { status[i] = st; errors[i] = msg; };
-        if (hipSetDevice(devices[i]) != hipSuccess) return bad(PT_ERR_DEVICE, "hipSetDevice failed");
-        if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess) return bad(PT_ERR_DEVICE, "hipStreamCreate failed");
-        if (hipMalloc(&d_film[i], bytes) != hipSuccess) return bad(PT_ERR_OUT_OF_MEMORY, "hipMalloc of the device film failed");
+    auto worker = [&](int v) {
+        auto bad = [&](pt_status s2, const std::string& msg) { status[v] = s2; errors[v] = msg; };
+        if (hipSetDevice(devices[v / virt]) != hipSuccess) return bad(PT_ERR_DEVICE, "hipSetDevice failed");
         pt_render_desc rd = *rdp;
-        if (n > 1) { rd.shard_index = (uint32_t)i; rd.shard_count = (uint32_t)n; }
-        pt_status st = render_impl(scene_of[i], &rd, d_film[i], streams[i], &profiles[i]);
-        if (st != PT_OK) bad(st, g_error);   // (g_error is thread-local: carried back to the caller below)
+        if (n > 1) { rd.shard_index = (uint32_t)v; rd.shard_count = (uint32_t)n; }
+        pt_status s2 = render_impl(scene_of[v], &rd, m.films[v], m.streams[v], &profiles[v]);
+        if (s2 != PT_OK) bad(s2, g_error);   // (g_error is thread-local: carried back to the caller below)
     };
     {
         std::vector<std::thread> pool;
-        for (int i = 1; i < n; ++i) pool.emplace_back(worker, i);
+        for (int v = 1; v < n; ++v) pool.emplace_back(worker, v);
         worker(0);
         for (auto& t : pool) t.join();
     }
-    for (int i = 0; i < n; ++i) if (status[i] != PT_OK) { const pt_status st = status[i]; const std::string msg = "device " + std::to_string(devices[i]) + ": " + errors[i]; cleanup(); return fail(st, msg); }
-    if (use_rccl) {
-        // the only exchange step of the path: every device's film (zero outside its own tiles) summed into the first device's
+    for (int v = 0; v < n; ++v) if (status[v] != PT_OK) return fail(status[v], "device " + std::to_string(devices[v / virt]) + (virt > 1 ? "." + std::to_string(v % virt) : "") + ": " + errors[v]);
+    // the only exchange step of the path.  Every film is zero outside its own tiles, so the sums are gathers and keep every bit.
+    const auto t_reduce = std::chrono::steady_clock::now();
+    const size_t pixels = (size_t)rdp->width * rdp->height;
+    for (int p = 0; p < np && virt > 1; ++p) {   // (1) the virtual devices of one physical device: added on that device (render_impl has synchronised their streams)
+        HIP_TRY(hipSetDevice(devices[p]));
+        for (uint32_t j = 1; j < virt; ++j)
+            hipLaunchKernelGGL(k_film_add, dim3(1024), dim3(kBlock), 0, m.streams[(size_t)p * virt], reinterpret_cast<float4*>(m.films[(size_t)p * virt]), reinterpret_cast<const float4*>(m.films[(size_t)p * virt + j]), pixels);
+        HIP_TRY(hipGetLastError());
+        if (!use_rccl) HIP_TRY(hipStreamSynchronize(m.streams[(size_t)p * virt]));
+    }
+    if (use_rccl) {   // (2) the physical devices: one ncclReduce(sum) into the first device of the mask, over xGMI
         ncclResult_t rc = rccl().group_start();
-        for (int i = 0; i < n && rc == ncclSuccess; ++i) {
-            hipSetDevice(devices[i]);
-            rc = rccl().reduce(d_film[i], d_film[i], (size_t)4 * rdp->width * rdp->height, ncclFloat, ncclSum, 0, comms[i], streams[i]);
+        for (int p = 0; p < np && rc == ncclSuccess; ++p) {
+            hipSetDevice(devices[p]);
+            float* f = m.films[(size_t)p * virt];
+            rc = rccl().reduce(f, f, pixels * 4, ncclFloat, ncclSum, 0, m.comms[p], m.streams[(size_t)p * virt]);
         }
         ncclResult_t rc2 = rccl().group_end();
         if (rc == ncclSuccess) rc = rc2;
-        if (rc != ncclSuccess) { cleanup(); return fail(PT_ERR_DEVICE, std::string("ncclReduce: ") + rccl().error_string(rc)); }
-        for (int i = 0; i < n; ++i) { hipSetDevice(devices[i]); if (hipStreamSynchronize(streams[i]) != hipSuccess) { cleanup(); return fail(PT_ERR_DEVICE, "stream synchronisation after the film reduce failed"); } }
+        if (rc != ncclSuccess) { multi_release(m); return fail(PT_ERR_DEVICE, std::string("ncclReduce: ") + rccl().error_string(rc)); }
+        for (int p = 0; p < np; ++p) { hipSetDevice(devices[p]); if (hipStreamSynchronize(m.streams[(size_t)p * virt]) != hipSuccess) { multi_release(m); return fail(PT_ERR_DEVICE, "stream synchronisation after the film reduce failed"); } }
     }
     const auto t1 = std::chrono::steady_clock::now();
-    hipSetDevice(devices[0]);
-    hipError_t e = hipMemcpy(film, d_film[0], bytes, hipMemcpyDeviceToHost);
-    cleanup();
-    if (e != hipSuccess) return fail(PT_ERR_DEVICE, hipGetErrorString(e));
+    HIP_TRY(hipSetDevice(devices[0]));
+    HIP_TRY(hipMemcpy(film, m.films[0], bytes, hipMemcpyDeviceToHost));
     if (profile) {
         memset(profile, 0, sizeof(*profile));
         for (const pt_profile& p : profiles) {
             profile->bounce_rays += p.bounce_rays; profile->shadow_rays += p.shadow_rays; profile->light_rays += p.light_rays;
             profile->camera_rays += p.camera_rays; profile->env_hits += p.env_hits;
-            for (int k = 0; k < 8; ++k) { profile->kernel_seconds[k] += p.kernel_seconds[k]; profile->kernel_launches[k] += p.kernel_launches[k]; profile->stage_items[k] += p.stage_items[k]; }
+            for (int k = 0; k < 5; ++k) { profile->kernel_seconds[k] += p.kernel_seconds[k]; profile->kernel_launches[k] += p.kernel_launches[k]; profile->stage_items[k] += p.stage_items[k]; }
         }
         profile->seconds = std::chrono::duration<double>(t1 - t0).count();
+        profile->kernel_seconds[5] = std::chrono::duration<double>(t0 - t_entry).count();    // set-up (replicas, streams, films, communicator): ~0 on a repeated call
+        profile->kernel_seconds[6] = std::chrono::duration<double>(t1 - t_reduce).count();   // the film reduce
     }
     return PT_OK;
 }

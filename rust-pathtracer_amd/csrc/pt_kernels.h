@@ -232,8 +232,16 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
                 const F3 o = f3(qf(paths_in, PS_OX, i), qf(paths_in, PS_OY, i), qf(paths_in, PS_OZ, i));
                 const F3 d = f3(qf(paths_in, PS_DX, i), qf(paths_in, PS_DY, i), qf(paths_in, PS_DZ, i));
                 world_hit<FUSE_TRAV == PT_NO_FUSE ? PT_TRAV_ANY : FUSE_TRAV>(s, o, d, &hit);
-            } else hit = load_hit(hits, i);
-            pv = load_path<NL>(paths_in, i);
+                pv = load_path<NL>(paths_in, i);
+            } else {
+                // (the path record first: its sixteen loads are in flight while the hit record's first word — which decides whether the rest
+                // is read at all — comes back; the other order leaves that latency exposed: k_shade 2506 -> 2893 us on C2)
+                pv = load_path<NL>(paths_in, i);
+#ifndef PT_SHADE_EAGER
+#define PT_SHADE_EAGER true   /* the lean form (closed scenes: nearly every segment ends on a surface) reads the whole hit record at once */
+#endif
+                hit = load_hit<PT_SHADE_EAGER && FORM == PT_SHADE_LEAN>(hits, i);
+            }
             wants_item = shade_wants_item(s, rp, hit);
         }
         // reserve the light-sample item first, so its rays stream straight from registers to the queue
@@ -411,7 +419,7 @@ __global__ void __launch_bounds__(kBlock) PT_POOL_OCC k_shadow_pooled(const uint
                 const bool wanted = hit && !env && sweep_best_is_light(s, st);
                 if (wanted) sweep_finish(s, ray.o, ray.d, st, &sh);
                 if (hit && !wanted) { sh.valid = true; sh.material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); }
-                shadow_ray_contribution<NL>(s, lambda, ray, env, hit, sh, c);
+                shadow_ray_contribution<NL>(s, [&](int k) { return pl_get<NL>(lambda, k); }, ray, env, hit, sh, c);
                 for (int k = 0; k < NL; ++k) lc[k] += c[k];
             }
         }
@@ -603,7 +611,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
         const bool wanted = hit && !env && sweep_best_is_light(s, st);
         if (wanted) sweep_finish(s, ray.o, ray.d, st, &sh);
         if (hit && !wanted) { sh.valid = true; sh.material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); }
-        shadow_ray_contribution<NL>(s, lambda, ray, env, hit, sh, c);
+        shadow_ray_contribution<NL>(s, [&](int k) { return pl_get<NL>(lambda, k); }, ray, env, hit, sh, c);
         for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
     };
     // (the parked `kind` word: bit 0 = an environment sample, the rest = 1 + the light whose hit bounds the search, sweep_run's known_inst)
@@ -767,7 +775,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked_dyn(const 
         const bool wanted = hit && !env && sweep_best_is_light(s, st);   // (the record of an occluder is never read)
         if (wanted) sweep_finish(s, ray.o, ray.d, st, &sh);
         if (hit && !wanted) { sh.valid = true; sh.material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); }
-        shadow_ray_contribution<NL>(s, lambda, ray, env, hit, sh, c);
+        shadow_ray_contribution<NL>(s, [&](int k) { return pl_get<NL>(lambda, k); }, ray, env, hit, sh, c);
         for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
     };
     auto resume = [&](uint32_t item2, SweepState& st, uint32_t l2, float bound, uint32_t kind) {   // (`kind`: see k_shadow_parked)

@@ -111,9 +111,12 @@ PT_HD void store_hit(const Queue& q, uint32_t i, const Hit& h) {
     qsf(q, HS_NX, i, h.n.x); qsf(q, HS_NY, i, h.n.y); qsf(q, HS_NZ, i, h.n.z);
     qsf(q, HS_U, i, h.u); qsf(q, HS_V, i, h.v); qsu(q, HS_MAT, i, h.material); qsu(q, HS_INST, i, h.instance);
 }
+// EAGER: every field is read at once, whatever the first word says (a miss's other fields hold stale words that nothing uses) — the reads
+// overlap instead of waiting for the first; for scenes where nearly every segment hits something.
+template <bool EAGER = false>
 PT_HD Hit load_hit(const Queue& q, uint32_t i) {
     Hit h; h.t = qf(q, HS_T, i); h.valid = h.t >= 0.0f;
-    if (!h.valid) return h;
+    if (!EAGER && !h.valid) return h;
     h.p = f3(qf(q, HS_PX, i), qf(q, HS_PY, i), qf(q, HS_PZ, i));
     h.n = f3(qf(q, HS_NX, i), qf(q, HS_NY, i), qf(q, HS_NZ, i));
     h.u = qf(q, HS_U, i); h.v = qf(q, HS_V, i); h.material = qu(q, HS_MAT, i); h.instance = qu(q, HS_INST, i);
@@ -485,14 +488,15 @@ PT_HD void store_shadow_ray(const Queue& q, uint32_t item, uint32_t l, const Sha
         qsf(q, f0 + SR_DX, item, ray.d.x); qsf(q, f0 + SR_DY, item, ray.d.y); qsf(q, f0 + SR_DZ, item, ray.d.z);
     }
 }
-template <int NL>
+// (EAGER: origin and direction are read along with the factors instead of after them — a dead ray's are stale words, unused)
+template <int NL, bool EAGER = false>
 PT_HD bool load_shadow_ray(const Queue& q, uint32_t item, uint32_t l, ShadowRayT<NL>* ray) {
     uint32_t f0 = Layout<NL>::sh_head + l * Layout<NL>::sr_fields;
     for (int k = 0; k < NL; ++k) ray->factor[k] = qf(q, f0 + SR_FACTOR + k, item);
-    if (!ray_is_live<NL>(*ray)) return false;
+    if (!EAGER && !ray_is_live<NL>(*ray)) return false;
     ray->o = f3(qf(q, f0 + SR_OX, item), qf(q, f0 + SR_OY, item), qf(q, f0 + SR_OZ, item));
     ray->d = f3(qf(q, f0 + SR_DX, item), qf(q, f0 + SR_DY, item), qf(q, f0 + SR_DZ, item));
-    return true;
+    return ray_is_live<NL>(*ray);
 }
 template <int NL>
 PT_HD void clear_shadow_item(const Queue& q, uint32_t item, uint32_t light_samples) {
@@ -507,15 +511,21 @@ PT_HD void clear_shadow_item(const Queue& q, uint32_t item, uint32_t light_sampl
 // the ray contributes nothing and is not walked.  The result is the reference's in every case.
 // What a traced light-sample ray adds, given its closest hit: a light ray contributes only if that hit is a light, with
 // the emission evaluated there (pt.rs:177-217); an environment ray only if nothing was hit (pt.rs:300-330).
-template <int NL>
-PT_HD void shadow_ray_contribution(const SceneView& s, const float (&lambda)[NL], const ShadowRayT<NL>& ray, bool env, bool hit, const Hit& sh, float (&contribution)[NL]) {
+// `lambda_of(k)`: the item's k-th wavelength — a register of the caller, or (hero wavelengths, where four of them held across two searches
+// cost the six-wave kernel registers it does not have) a read of the item's record at the moment it is needed.
+template <int NL, typename LambdaOf, typename FactorOf>
+PT_HD void shadow_ray_contribution(const SceneView& s, LambdaOf&& lambda_of, FactorOf&& factor_of, F3 ray_d, bool env, bool hit, const Hit& sh, float (&contribution)[NL]) {
     for (int k = 0; k < NL; ++k) contribution[k] = 0.0f;
-    if (env) { if (!hit) for (int k = 0; k < NL; ++k) contribution[k] = ray.factor[k]; return; }
+    if (env) { if (!hit) for (int k = 0; k < NL; ++k) contribution[k] = factor_of(k); return; }
     if (!hit || PT_MATERIAL_TAG(sh.material) != PT_TAG_LIGHT) return;
     Frame lf = frame_from_normal(sh.n);
-    F3 lwi = to_local(lf, neg(ray.d));
+    F3 lwi = to_local(lf, neg(ray_d));
     uint32_t lm = material_record(s, sh.material);
-    PT_ROLLED for (int k = 0; k < NL; ++k) pl_set<NL>(contribution, k, pl_get<NL>(ray.factor, k) * pt_abs(lwi.z) * material_emission(s, lm, pl_get<NL>(lambda, k), lwi));
+    PT_ROLLED for (int k = 0; k < NL; ++k) pl_set<NL>(contribution, k, factor_of(k) * pt_abs(lwi.z) * material_emission(s, lm, lambda_of(k), lwi));
+}
+template <int NL, typename LambdaOf>
+PT_HD void shadow_ray_contribution(const SceneView& s, LambdaOf&& lambda_of, const ShadowRayT<NL>& ray, bool env, bool hit, const Hit& sh, float (&contribution)[NL]) {
+    shadow_ray_contribution<NL>(s, lambda_of, [&](int k) { return pl_get<NL>(ray.factor, k); }, ray.d, env, hit, sh, contribution);
 }
 // The bound of a light ray's search: the nearest light hit (+inf: no light on the ray, nothing to trace), or "unbounded"
 // when the scene forbids the shortcut.  Returns false when the ray cannot contribute.
@@ -532,28 +542,36 @@ PT_HD int shadow_env_stop(const SceneView& s) { return (bu(s, PT_HDR_FLAGS) & PT
 // blocks it, so its search ends at the first one; PT_AMD_NO_CULL keeps the full search).  One search call site for both kinds — a
 // wave whose lanes hold both kinds traces them together.  ENV = false: the caller knows the scene produces no environment rays
 // (env_sampling_probability = 0) and that half is compiled out.
-template <int NL, int TRAV = PT_TRAV_ANY, bool ENV = true>
-PT_HD void stage_shadow_ray(const SceneView& s, const float (&lambda)[NL], const ShadowRayT<NL>& ray, bool env, float (&contribution)[NL]) {
+template <int NL, int TRAV = PT_TRAV_ANY, bool ENV = true, typename LambdaOf, typename FactorOf>
+PT_HD void stage_shadow_ray(const SceneView& s, LambdaOf&& lambda_of, FactorOf&& factor_of, F3 o, F3 d, bool env, float (&contribution)[NL]) {
     for (int k = 0; k < NL; ++k) contribution[k] = 0.0f;
     float bound = PT_INF; int stop = PT_STOP_NONE;
     uint32_t light = 0xffffffffu;   // the light whose hit bounds the search: its test has been run, phase 3 takes the distance (sweep_run)
     if (ENV && env) stop = shadow_env_stop(s);
-    else if (!shadow_light_bound(s, ray.o, ray.d, &bound, &stop, &light)) return;
+    else if (!shadow_light_bound(s, o, d, &bound, &stop, &light)) return;
     Hit sh;
-    bool hit = world_hit<TRAV, true>(s, ray.o, ray.d, &sh, bound, stop, light, bound);
-    shadow_ray_contribution<NL>(s, lambda, ray, ENV && env, hit, sh, contribution);
+    bool hit = world_hit<TRAV, true>(s, o, d, &sh, bound, stop, light, bound);
+    shadow_ray_contribution<NL>(s, lambda_of, factor_of, d, ENV && env, hit, sh, contribution);
 }
 // One light-sample item: L rays, summed in order, divided by L (pt.rs:349-392, 596)
 template <int NL, int TRAV = PT_TRAV_ANY, bool ENV = true>
 PT_HD void stage_shadow_item(const SceneView& s, uint32_t light_samples, const Queue& shadow, uint32_t item, float* energy, uint32_t energy_stride) {
     uint32_t slot = qu(shadow, Layout<NL>::sh_slot, item), flags = ENV ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
-    float lambda[NL], lc[NL];
-    for (int k = 0; k < NL; ++k) { lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item); lc[k] = 0.0f; }
+    float lambda0 = 0.0f, lc[NL];
+    if (NL == 1) lambda0 = qf(shadow, Layout<NL>::sh_lambda, item);
+    for (int k = 0; k < NL; ++k) lc[k] = 0.0f;
+    auto lambda_of = [&](int k) { return NL == 1 ? lambda0 : qf(shadow, Layout<NL>::sh_lambda + (uint32_t)k, item); };
     for (uint32_t l = 0; l < light_samples; ++l) {
         ShadowRayT<NL> ray;
-        if (!load_shadow_ray<NL>(shadow, item, l, &ray)) continue;
+#ifndef PT_SHADOW_EAGER
+#define PT_SHADOW_EAGER false  /* (true: the pure sweep form reads a ray's words at once — measured: k_shadow 3525 -> 3600 us on C2, not used) */
+#endif
+        if (!load_shadow_ray<NL, PT_SHADOW_EAGER && TRAV == PT_TRAV_SWEEP>(shadow, item, l, &ray)) continue;
         float c[NL];
-        stage_shadow_ray<NL, TRAV, ENV>(s, lambda, ray, ((flags >> l) & 1u) != 0u, c);
+        // (hero wavelengths: the factors too are read again when the ray contributes, not held across its search)
+        const uint32_t ff = Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR;
+        auto factor_of = [&](int k) { return NL == 1 ? ray.factor[0] : qf(shadow, ff + (uint32_t)k, item); };
+        stage_shadow_ray<NL, TRAV, ENV>(s, lambda_of, factor_of, ray.o, ray.d, ((flags >> l) & 1u) != 0u, c);
         for (int k = 0; k < NL; ++k) lc[k] += c[k];
     }
     for (int k = 0; k < NL; ++k) energy[(size_t)k * energy_stride + slot] += lc[k] / (float)light_samples;

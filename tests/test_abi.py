@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_oracle_exports_the_same_boundary(pkg, oracle):
     for name in declared_functions():
-        if name in ("pt_render_device", "pt_render_multi", "pt_device_count", "pt_device_info", "pt_write_png", "pt_write_exr"):
+        if name in ("pt_render_device", "pt_render_multi", "pt_device_count", "pt_device_info", "pt_write_png", "pt_write_exr", "pt_scene_create_tuned", "pt_tuning_default"):
             continue
         assert hasattr(oracle.lib, "ptref_" + name[3:]), name
 
@@ -46,7 +46,7 @@ def test_struct_layouts_match_the_header(pkg):
 #include <stdio.h>
 #include "pt_api.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pt_curve), sizeof(pt_texture_layer), sizeof(pt_texstack),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pt_tuning), sizeof(pt_curve), sizeof(pt_texture_layer), sizeof(pt_texstack),
          sizeof(pt_material), sizeof(pt_mesh), sizeof(pt_instance), sizeof(pt_environment), sizeof(pt_camera), sizeof(pt_scene_desc),
          sizeof(pt_render_desc), sizeof(pt_profile), sizeof(pt_hit), sizeof(pt_output_desc), sizeof(pt_compare_stats));
   return 0; }'''
@@ -55,7 +55,7 @@ int main(void) {
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
     a = pkg.api
-    mine = [C.sizeof(t) for t in (a.Curve, a.TextureLayer, a.TexStack, a.Material, a.Mesh, a.Instance, a.Environment, a.Camera,
+    mine = [C.sizeof(t) for t in (a.Tuning, a.Curve, a.TextureLayer, a.TexStack, a.Material, a.Mesh, a.Instance, a.Environment, a.Camera,
                                   a.SceneDesc, a.RenderDesc, a.Profile, a.Hit, a.OutputDesc, a.CompareStats)]
     assert mine == sizes
 

@@ -233,13 +233,19 @@ def test_forms_without_transforms_change_nothing(engine, pkg, monkeypatch, scene
     ref = engine.create_scene(b)
     base, pbase = ref.render(rd)
     hits = ref.intersect(o, d)
-    monkeypatch.setenv("PT_AMD_GENERAL_FORMS", "1")
-    other = engine.create_scene(b)
-    monkeypatch.delenv("PT_AMD_GENERAL_FORMS")
-    film, prof = other.render(rd)
-    assert np.array_equal(base.view(np.uint32), film.view(np.uint32))
-    assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits)
-    parity_suite.assert_hits_equal(hits, other.intersect(o, d))
+    for env in ({"PT_AMD_GENERAL_FORMS": "1"}, {"PT_AMD_NO_FUSE": "1"}, {"PT_AMD_NO_FUSE": "1", "PT_AMD_BLOCKS_PER_CU": "1"}, {"PT_AMD_BLOCKS_PER_CU": "2"}):
+        # (the fused form — k_shade tracing its own segments, the default for single-wavelength scenes of this kind — against k_extend + k_shade;
+        # long segments: many rounds per workgroup)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other = engine.create_scene(b)
+        for k in env:
+            monkeypatch.delenv(k)
+        film, prof = other.render(rd)
+        assert np.array_equal(base.view(np.uint32), film.view(np.uint32)), env
+        assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits), env
+        assert (prof.kernel_launches[1] == 0) == (scene == "cornell_box" and hero == 1 and "PT_AMD_NO_FUSE" not in env and "PT_AMD_GENERAL_FORMS" not in env), env
+        parity_suite.assert_hits_equal(hits, other.intersect(o, d))
 
 
 @pytest.mark.parametrize("scene,L,hero", [("cornell_box", 2, 1), ("mixed_small", 3, 1), ("white_furnace", 6, 1), ("cornell_box", 2, 4)])
@@ -258,10 +264,10 @@ def test_pooled_phase3_changes_nothing(engine, pkg, monkeypatch, scene, L, hero)
         assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits)
 
 
-def test_whole_node_render_from_one_call(engine, pkg, monkeypatch):
+def test_whole_node_render_from_one_call(engine, pkg):
     """pt_render_multi (the one blocking call a Rust `impl Renderer` makes): every device of the mask renders its tiles on its own
     host thread and stream, the device films are summed with RCCL.  On the one GPU of this box: mask 0 and mask 1 give pt_render's film
-    bit for bit, with the RCCL reduce forced (PT_AMD_MULTI_RCCL=1: single-process communicator, ncclReduce on the render stream) too;
+    bit for bit, with the RCCL reduce forced (PT_TUNE_MULTI_RCCL: single-process communicator, ncclReduce on the render stream) too;
     a mask that names no visible device and a sharded desc are refused."""
     n = engine.lib.pt_device_count()
     assert n >= 1
@@ -273,15 +279,47 @@ def test_whole_node_render_from_one_call(engine, pkg, monkeypatch):
         film, prof = sc.render_multi(rd, mask)
         assert np.array_equal(film.view(np.uint32), base.view(np.uint32)), mask
         assert (prof.camera_rays, prof.bounce_rays, prof.shadow_rays) == (pbase.camera_rays, pbase.bounce_rays, pbase.shadow_rays)
-    monkeypatch.setenv("PT_AMD_MULTI_RCCL", "1")
-    film, prof = sc.render_multi(rd, 1)
+    t = engine.tuning_default()
+    t.flags |= pkg.api.TUNE_MULTI_RCCL
+    rc = engine.create_scene(b, t)
+    film, prof = rc.render_multi(rd, 1)
     assert np.array_equal(film.view(np.uint32), base.view(np.uint32))
     assert prof.seconds > 0 and prof.camera_rays == pbase.camera_rays
-    monkeypatch.delenv("PT_AMD_MULTI_RCCL")
+    setup_first = prof.kernel_seconds[5]
+    film, prof = rc.render_multi(rd, 1)   # the communicator, the stream and the device film are the scene's now
+    assert np.array_equal(film.view(np.uint32), base.view(np.uint32))
+    assert prof.kernel_seconds[5] < 1e-3 and prof.kernel_seconds[5] <= setup_first, (setup_first, prof.kernel_seconds[5])
     with pytest.raises(pkg.api.PtError):
         sc.render_multi(rd, 1 << 40)
     with pytest.raises(pkg.api.PtError):
         sc.render_multi(pkg.api.render_desc(160, 96, 7, 6, seed=5, shard=(0, 2)), 0)
+
+
+@pytest.mark.parametrize("scene,virt,rccl", [("cornell_box", 2, False), ("cornell_box", 8, False), ("cornell_gem", 3, False), ("hdri_small", 4, True)])
+def test_whole_node_with_virtual_devices(engine, pkg, scene, virt, rccl):
+    """pt_render_multi with N > 1 on the one GPU there is: pt_tuning::multi_virtual = k treats the device as k devices — k host threads,
+    k streams, k scene replicas with their own queues, shard_index = 0..k-1 of shard_count = k, each into its own device film — and the
+    films are summed on the device (and then, with PT_TUNE_MULTI_RCCL, handed to the RCCL reduce as a node's first device would).  The
+    thread-per-device / replica / shard path of a node with N devices, with the reduce between physical devices left out.  The film equals
+    pt_render's bit for bit, the counters add up, a second call pays no set-up, and the caller's current device is left as it was."""
+    import torch
+    b = pkg.scene.SCENES[scene]()
+    rd = pkg.api.render_desc(200, 136, 9, 6, light_samples=3, seed=11)
+    base, pbase = engine.create_scene(b).render(rd)
+    t = engine.tuning_default()
+    t.multi_virtual = virt
+    if rccl:
+        t.flags |= pkg.api.TUNE_MULTI_RCCL
+    sc = engine.create_scene(b, t)
+    before = torch.cuda.current_device()
+    for call in range(2):
+        film, prof = sc.render_multi(rd, 1)
+        assert np.array_equal(film.view(np.uint32), base.view(np.uint32)), (virt, call)
+        assert (prof.camera_rays, prof.bounce_rays, prof.shadow_rays, prof.env_hits) == (pbase.camera_rays, pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits)
+        assert prof.kernel_launches[2] == virt * pbase.kernel_launches[2]   # every virtual device ran its own pipeline
+        if call == 1:
+            assert prof.kernel_seconds[5] < 1e-3, prof.kernel_seconds[5]    # set-up: replicas, streams and films are cached on the scene
+    assert torch.cuda.current_device() == before
 
 
 def test_full_size_cornell_properties(engine, oracle, pkg):

@@ -78,7 +78,7 @@ def test_bench_rccl_path_on_one_gpu(tmp_path):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--spp-per-step", "16", "--cpu-seconds", "0"]
     lines = {}
-    for tag, extra in (("dist", ["--force-dist"]), ("plain", [])):
+    for tag, extra in (("dist", ["--force-dist"]), ("plain", []), ("strong", ["--scaling", "strong"])):
         r = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert r.stdout.strip().splitlines()[-1].startswith('{"metric"'), r.stdout[-500:]   # the record is the last line of stdout
@@ -86,3 +86,63 @@ def test_bench_rccl_path_on_one_gpu(tmp_path):
     for tag, d in lines.items():
         assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["samples_per_step"] == 1024 * 1024 * 16, tag
     assert lines["dist"]["segments_per_sample"] == lines["plain"]["segments_per_sample"]   # same paths, whoever sums the film
+    # with one GPU the fixed-frame (strong scaling) run is the weak-scaling run: the same work, the same record but for the mode's name
+    assert lines["strong"]["scaling"] == "strong" and lines["plain"]["scaling"] == "weak"
+    for key in ("metric", "unit", "n_gpus", "steps", "segments_per_sample", "dtype"):
+        assert lines["strong"][key] == lines["plain"][key], key
+    assert lines["strong"]["config"]["workload_key"] == lines["plain"]["config"]["workload_key"]
+
+
+GPU_WORKER = r'''
+import importlib, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, {here!r})
+pkg = importlib.import_module("rust-pathtracer_amd")
+rank, local_rank, world = pkg.sharding.rank_world()
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+engine = pkg.load()                       # the real engine (libptamd.so): both processes on device 0
+scene = engine.create_scene(pkg.scene.SCENES[{scene!r}]())
+S = pkg.sharding.weak_scaling_samples(4, world)
+total = torch.zeros(({h}, {w}, 4), dtype=torch.float32)
+cam = 0
+for k in range(2):
+    rd = pkg.api.render_desc({w}, {h}, 2 * S, 6, light_samples=3, shard=pkg.sharding.shard(rank, world), first_sample=k * S, sample_count=S)
+    film, prof = scene.render(rd)         # pt_render through the C ABI
+    total += torch.from_numpy(film)
+    cam += prof.camera_rays
+pkg.sharding.reduce_film(total, dst=0)    # host reduce over gloo: the exchange step of the N-process path
+c = pkg.sharding.sum_over_ranks([cam], "cpu")
+if rank == 0:
+    np.save({out!r}, total.numpy())
+    assert c[0] == {w} * {h} * 2 * S, c
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["cornell_box", "hdri_small"])
+def test_two_processes_on_one_gpu_equal_single_process(pkg, tmp_path, scene):
+    """N > 1 with the real engine: two processes (gloo, world size 2), each rendering its shard of the film on device 0 with pt_render,
+    the films summed on the host — and the result must equal the single-process film bit for bit (disjoint shards, RNG keyed by pixel)."""
+    w, h = 232, 136
+    out = str(tmp_path / "film.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(GPU_WORKER.format(root=ROOT, here=HERE, out=out, scene=scene, w=w, h=h))
+    port = 29700 + (os.getpid() % 1000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    reduced = np.load(out)
+    engine = pkg.load()
+    sc = engine.create_scene(pkg.scene.SCENES[scene]())
+    S = pkg.sharding.weak_scaling_samples(4, 2)
+    whole = np.zeros_like(reduced)
+    for k in range(2):
+        film, _ = sc.render(pkg.api.render_desc(w, h, 2 * S, 6, light_samples=3, first_sample=k * S, sample_count=S))
+        whole += film
+    assert np.array_equal(reduced.view(np.uint32), whole.view(np.uint32))

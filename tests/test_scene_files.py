@@ -285,6 +285,10 @@ def _write_test_images(tmp_path):
                     raw += row.astype(np.float16).tobytes() if n in half else row.astype(np.float32).tobytes()
             if compression == 0:
                 return raw
+            if compression == 4:   # PIZ: the test-side encoder (tests/piz_encode.py), channel planes of the block
+                import piz_encode
+                comp = piz_encode.block_from_rows([img[y0:y0 + bh, x0:x0 + bw, slot[n]].astype(np.float16 if n in half else np.float32) for n in names])
+                return comp if len(comp) < len(raw) else raw
             a = np.frombuffer(raw, np.uint8)
             inter = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
             pred = inter.copy(); pred[1:] = (inter[1:] - inter[:-1] + 128 + 256) % 256
@@ -310,7 +314,7 @@ def _write_test_images(tmp_path):
                     d = block(tx * tiled[0], ty * tiled[1], bw, bh)
                     blocks.append(struct.pack("<4iI", tx, ty, 0, 0, len(d)) + d)
         else:
-            lines = 16 if compression == 3 else 1
+            lines = 16 if compression == 3 else 32 if compression == 4 else 1
             for y0 in range(0, hh, lines):
                 d = block(0, y0, ww, min(lines, hh - y0))
                 blocks.append(struct.pack("<iI", y0, len(d)) + d)
@@ -323,9 +327,29 @@ def _write_test_images(tmp_path):
     img[..., 0] = xx * 0.25; img[..., 1] = yy * 0.5 + 0.125; img[..., 2] = (xx + yy) % 5; img[..., 3] = 0.5
     exr_cases = {"exr_zip": dict(compression=3, half=("G",), channels="BGR"), "exr_zips": dict(compression=2), "exr_rle": dict(compression=1, half=("R", "A")),
                  "exr_tiled": dict(compression=0, tiled=(8, 16))}
+    # PIZ (what a Poly-Haven-style HDRI uses): half channels in 32-line blocks with a remnant block, float channels (two 16-bit planes per
+    # sample), tiles, and a noisy image wide enough for a block to hold more than 2^14 distinct values (the wavelet's modulo-2^16 form)
+    exr_cases.update({"exr_piz": dict(compression=4, half=("R", "G", "B"), channels="BGR"), "exr_piz_float": dict(compression=4, half=("A",)),
+                      "exr_piz_tiled": dict(compression=4, half=("R", "G", "B", "A"), tiled=(16, 8))})
     for n, kw in exr_cases.items():
         exr(tmp_path / (n + ".exr"), img, **kw)
+    noise = np.random.default_rng(9).random((40, 150, 4)).astype(np.float32) * 50.0
+    noise[5:9, 10:90] = 0.0   # runs of equal symbols
+    exr(tmp_path / "exr_piz_noise.exr", noise, compression=4, half=("R",))
+    exr_cases["exr_piz_noise"] = dict(image=noise, half=("R",))
     return rgba, rgb, bmp_px, img, exr_cases, rgbe
+
+
+def _exr_expect(img, kw):
+    """What the reader must return for a test EXR: the image it was written from (its own, for the noise case), half channels rounded to
+    half precision, alpha 1 where the file has no A channel."""
+    e = np.array(kw.get("image", img), np.float32)
+    for c, n in enumerate("RGBA"):
+        if n in kw.get("half", ()):
+            e[..., c] = e[..., c].astype(np.float16).astype(np.float32)
+    if "A" not in kw.get("channels", "ABGR"):
+        e[..., 3] = 1.0
+    return e
 
 
 def test_image_readers(sfmod, tmp_path):
@@ -340,7 +364,7 @@ def test_image_readers(sfmod, tmp_path):
     for name, expect in (("rgba", rgba.astype(np.float32) / np.float32(255)),
                          ("bmp", np.concatenate([bmp_px, np.full((3, 5, 1), 255, np.uint8)], axis=2).astype(np.float32) / np.float32(255)),
                          ("luma", ((2126 * rgb[..., 0].astype(np.uint32) + 7152 * rgb[..., 1].astype(np.uint32) + 722 * rgb[..., 2].astype(np.uint32)) // 10000).astype(np.float32) / np.float32(255)),
-                         ("hdr", None)) + tuple((n, np.where(np.arange(4) == 3, np.float32(1.0), img) if n == "exr_zip" else img) for n in exr_cases):
+                         ("hdr", None)) + tuple((n, _exr_expect(img, kw)) for n, kw in exr_cases.items()):
         scene = lib + 'env_sampling_probability = 1.0\ninstances = []\n[environment]\ntype = "HDRI"\ntexture_name = "%s"\nstrength = 1.0\n[[cameras]]\ntype = "SimpleCamera"\nname = "c"\nlook_from = [0.0, 0.0, 0.0]\nlook_at = [1.0, 0.0, 0.0]\nvfov = 30.0\n' % name + tex
         sf = sfmod.SceneFile(_write(tmp_path, "tex_%s.toml" % name, scene))
         d = sf.desc
