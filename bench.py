@@ -170,6 +170,9 @@ def main():
         kitems = [sum(p.stage_items[i] for p in profs) for i in range(5)]
         dom = max(range(5), key=lambda i: ksec[i])
         per_item = [algorithmic_bytes(s, L) for s in STAGES]
+        fused = klaunch[1] == 0 and klaunch[2] > 0      # k_shade traced its own segments: no hit queue, the ray read with the rest of the path record
+        if fused:
+            per_item[2] -= 11 * 4                       # no hit record to read (and k_extend's 24 + 44 B per segment are not moved at all)
         kbytes = [per_item[i] * kitems[i] for i in range(5)]
         kbytes[4] += 4 * sum(p.camera_rays for p in profs)          # accumulate also reads one energy per sample
         kernels = {}
@@ -225,7 +228,7 @@ def main():
                                        "achieved_GBs": sum(kbytes) / elapsed / 1e9, "frac": sum(kbytes) / elapsed / 1e9 / HBM_PEAK_GBS,
                                        "survey_model": {"bytes_per_sample": survey_bytes, "achieved_GBs": value * 1e6 * survey_bytes / 1e9,
                                                         "frac": value * 1e6 * survey_bytes / 1e9 / HBM_PEAK_GBS}},
-                    "kernels": kernels, "valu": valu,
+                    "kernels": kernels, "valu": valu, "fused_extend_shade": fused,
                     "binding_resource": "VALU issue, not HBM: the scene (%d B) is LDS-resident, HBM only carries the queues; `frac` is the fraction of the HBM roof "
                                         "the contract asks for, `valu` (when a matching profile is committed) the fraction of the measured VALU issue rate" % engine.lib.pt_debug_scene_info(scene.handle, 0)}
 

@@ -71,7 +71,18 @@ inline V3 point_at(const Ray& r, float t) { return r.origin + r.direction * t; }
 
 // TangentFrame::from_normal: Duff et al. 2017 "Building an Orthonormal Basis, Revisited".
 struct Frame { V3 tangent, bitangent, normal; };
+// ---- Alternative readings of the un-vendored `math` / `rust_optics` crates (DESIGN.md section 2's table), selectable at compile time
+// with -DPTREF_ALT_<NAME> for tools/oracle_sensitivity.py ONLY: the script builds one private copy of the oracle per alternative and reports
+// how far the film moves, so that a maintainer with the crates in hand knows which of the restated choices to check first.  No test, no
+// golden vector and nothing in the product is built with any of them.
 inline Frame frame_from_normal(V3 n) {
+#ifdef PTREF_ALT_FRAME_FRISVAD
+    // Frisvad 2012, with its singularity branch
+    Frame g; g.normal = n;
+    if (n.z < -0.9999999f) { g.tangent = v3(0.0f, -1.0f, 0.0f); g.bitangent = v3(-1.0f, 0.0f, 0.0f); return g; }
+    { const float a = 1.0f / (1.0f + n.z), b = -n.x * n.y * a;
+      g.tangent = v3(1.0f - n.x * n.x * a, b, -n.x); g.bitangent = v3(b, 1.0f - n.y * n.y * a, -n.y); return g; }
+#endif
     float sign = (pt_f2u(n.z) & 0x80000000u) ? -1.0f : 1.0f;  // 1.0f32.copysign(z)
     float a = -1.0f / (sign + n.z);
     float b = n.x * n.y * a;
@@ -105,13 +116,34 @@ inline V3 mul_vec_transposed(const M4& a, V3 v) {
 // Sample1D::choose: x < split -> (x/split, a) else ((x-split)/(1-split), b).
 template <typename T>
 inline T choose(float& x, float split, T a, T b) {
+#if defined(PTREF_ALT_CHOOSE_LE)
+    if (x <= split) { x = x / split; return a; }
+#elif defined(PTREF_ALT_CHOOSE_NO_RESCALE)
+    if (x < split) return a;
+    return b;
+#else
     if (x < split) { x = x / split; return a; }
+#endif
     x = (x - split) / (1.0f - split);
     return b;
 }
 
 // math::random
 inline V3 random_cosine_direction(float u, float v) {
+#if defined(PTREF_ALT_COSINE_CONCENTRIC)
+    {   // Shirley-Chiu concentric disk, projected up
+        const float a = 2.0f * u - 1.0f, b = 2.0f * v - 1.0f;
+        float r, phi;
+        if (a == 0.0f && b == 0.0f) { r = 0.0f; phi = 0.0f; }
+        else if (std::fabs(a) > std::fabs(b)) { r = a; phi = (PT_PI / 4.0f) * (b / a); }
+        else { r = b; phi = PT_PI / 2.0f - (PT_PI / 4.0f) * (a / b); }
+        float sn, cs; pt_sincos(phi, &sn, &cs);
+        const float x = r * cs, y = r * sn;
+        return v3(x, y, std::sqrt(pt_max(0.0f, 1.0f - x * x - y * y)));
+    }
+#elif defined(PTREF_ALT_COSINE_SWAP_UV)
+    { const float t = u; u = v; v = t; }
+#endif
     float z = std::sqrt(1.0f - v);
     float phi = 2.0f * PT_PI * u;
     float s, c; pt_sincos(phi, &s, &c);
@@ -119,6 +151,9 @@ inline V3 random_cosine_direction(float u, float v) {
     return v3(c * r, s * r, z);
 }
 inline V3 random_on_unit_sphere(float x, float y) {
+#ifdef PTREF_ALT_SPHERE_Z_FROM_X
+    { const float t = x; x = y; y = t; }
+#endif
     float phi = x * 2.0f * PT_PI;
     float z = y * 2.0f - 1.0f;
     float r = std::sqrt(1.0f - z * z);
@@ -133,7 +168,11 @@ inline V3 random_in_unit_disk(float x, float y) {
 }
 
 // math::misc
+#ifdef PTREF_ALT_POWER_BETA1
+inline float power_heuristic(float a, float b) { return a / (a + b); }
+#else
 inline float power_heuristic(float a, float b) { return (a * a) / (a * a + b * b); }
+#endif
 // src/lib.rs:114-119 (in tree): despite its name this is the balance heuristic.
 inline float power_heuristic_generic(float a, float b) { return a / (a + b); }
 
@@ -144,9 +183,15 @@ inline V3 uv_to_direction(float u, float v) {
     float st, ct, sp, cp;
     pt_sincos(theta, &st, &ct);
     pt_sincos(phi, &sp, &cp);
+#ifdef PTREF_ALT_UV_Y_UP
+    return v3(sp * ct, cp, sp * st);
+#endif
     return v3(sp * ct, sp * st, cp);
 }
 inline void direction_to_uv(V3 d, float* u, float* v) {
+#ifdef PTREF_ALT_UV_Y_UP
+    d = v3(d.x, d.z, d.y);
+#endif
     float theta = pt_atan2(d.y, d.x);
     float phi = pt_acos(d.z);
     *u = theta / 2.0f / PT_PI + 0.5f;
@@ -160,6 +205,17 @@ inline double gaussian64(double x, double alpha, double mu, double s1, double s2
     double t = (x - mu) / (x < mu ? s1 : s2);
     return alpha * pt_exp64(-(t * t) / 2.0);
 }
+#if defined(PTREF_ALT_XYZ_F32)
+inline float gaussian32x(float x, float alpha, float mu, float s1, float s2) { float t = (x - mu) / (x < mu ? s1 : s2); return alpha * pt_exp(-(t * t) / 2.0f); }
+inline float x_bar(float a) { return gaussian32x(a, 1.056f, 5998.0f, 379.0f, 310.0f) + gaussian32x(a, 0.362f, 4420.0f, 160.0f, 267.0f) + gaussian32x(a, -0.065f, 5011.0f, 204.0f, 262.0f); }
+inline float y_bar(float a) { return gaussian32x(a, 0.821f, 5688.0f, 469.0f, 405.0f) + gaussian32x(a, 0.286f, 5309.0f, 163.0f, 311.0f); }
+inline float z_bar(float a) { return gaussian32x(a, 1.217f, 4370.0f, 118.0f, 360.0f) + gaussian32x(a, 0.681f, 4590.0f, 260.0f, 138.0f); }
+#elif defined(PTREF_ALT_XYZ_SINGLE_LOBE)
+// the simple (single-lobe) fit of the same paper, wavelength in nm
+inline float x_bar(float a) { const double l = a / 10.0, t1 = (l - 595.8) / 33.33, t2 = (l - 446.8) / 19.44; return (float)(1.065 * pt_exp64(-0.5 * t1 * t1) + 0.366 * pt_exp64(-0.5 * t2 * t2)); }
+inline float y_bar(float a) { const double l = a / 10.0, t = (pt_log64(l) - pt_log64(556.3)) / 0.075; return (float)(1.014 * pt_exp64(-0.5 * t * t)); }
+inline float z_bar(float a) { const double l = a / 10.0, t = (pt_log64(l) - pt_log64(449.8)) / 0.051; return (float)(1.839 * pt_exp64(-0.5 * t * t)); }
+#else
 inline float x_bar(float a) {
     return (float)(gaussian64(a, 1.056, 5998.0, 379.0, 310.0) + gaussian64(a, 0.362, 4420.0, 160.0, 267.0) +
                    gaussian64(a, -0.065, 5011.0, 204.0, 262.0));
@@ -170,6 +226,7 @@ inline float y_bar(float a) {
 inline float z_bar(float a) {
     return (float)(gaussian64(a, 1.217, 4370.0, 118.0, 360.0) + gaussian64(a, 0.681, 4590.0, 260.0, 138.0));
 }
+#endif
 
 // ------------------------------------------------------------------ curves
 struct Scene;  // fwd
@@ -199,6 +256,13 @@ inline float interp(int mode, float t, float left, float right) {
     return h00 * left + h01 * right;
 }
 
+#ifdef PTREF_ALT_CUBIC_CATMULL_ROM
+// uniform Catmull-Rom through four neighbouring samples (knot spacing ignored, as an index-space spline would)
+inline float catmull_rom(float t, float p0, float p1, float p2, float p3) {
+    const float t2 = t * t, t3 = t2 * t;
+    return 0.5f * ((2.0f * p1) + (-p0 + p2) * t + (2.0f * p0 - 5.0f * p1 + 4.0f * p2 - p3) * t2 + (-p0 + 3.0f * p1 - 3.0f * p2 + p3) * t3);
+}
+#endif
 // Curve::evaluate (math::curves). evaluate_power == evaluate; CurveWithCDF::evaluate_power == pdf.evaluate
 // (the `.pdf` field is the original curve: src/texture.rs:49,128).
 float curve_eval(const pt_curve& c, const float* data, float lambda) {
@@ -207,8 +271,12 @@ float curve_eval(const pt_curve& c, const float* data, float lambda) {
         case PT_CURVE_CONST: return pt_max(c.p0, 0.0f);
         case PT_CURVE_LINEAR: {
             float lower = c.p0, upper = c.p1;
-            if (lambda < lower || lambda > upper) return 0.0f;
             uint32_t n = c.data_count;
+#ifdef PTREF_ALT_LINEAR_CLAMP
+            if (lambda < lower) return d[0];
+            if (lambda > upper) return d[n - 1];
+#endif
+            if (lambda < lower || lambda > upper) return 0.0f;
             float step = (upper - lower) / (float)n;
             float fi = (lambda - lower) / step;
             uint32_t index = (fi >= 0.0f) ? (uint32_t)fi : 0u;
@@ -217,6 +285,10 @@ float curve_eval(const pt_curve& c, const float* data, float lambda) {
             if (index + 1 >= n) return left;
             float right = d[index + 1];
             float t = (lambda - (lower + (float)index * step)) / step;
+#ifdef PTREF_ALT_CUBIC_CATMULL_ROM
+            if (c.mode != PT_INTERP_LINEAR && c.mode != PT_INTERP_NEAREST)
+                return catmull_rom(t, d[index > 0 ? index - 1 : 0], left, right, d[index + 2 < n ? index + 2 : n - 1]);
+#endif
             return interp(c.mode, t, left, right);
         }
         case PT_CURVE_TABULATED: {
@@ -228,11 +300,18 @@ float curve_eval(const pt_curve& c, const float* data, float lambda) {
                 if (d[2 * mid] < lambda) lo = mid + 1; else hi = mid;
             }
             uint32_t index = lo;
+#ifdef PTREF_ALT_TABULATED_ZERO_OUTSIDE
+            if (index == n || (index == 0 && d[0] != lambda)) return 0.0f;
+#endif
             if (index == n) return d[2 * (n - 1) + 1];
             if (index == 0) return d[1];
             float lx = d[2 * (index - 1)], ly = d[2 * (index - 1) + 1];
             float rx = d[2 * index], ry = d[2 * index + 1];
             float t = (lambda - lx) / (rx - lx);
+#ifdef PTREF_ALT_CUBIC_CATMULL_ROM
+            if (c.mode != PT_INTERP_LINEAR && c.mode != PT_INTERP_NEAREST)
+                return catmull_rom(t, d[2 * (index >= 2 ? index - 2 : 0) + 1], ly, ry, d[2 * (index + 1 < n ? index + 1 : n - 1) + 1]);
+#endif
             return interp(c.mode, t, ly, ry);
         }
         case PT_CURVE_CAUCHY: return c.p0 + c.p1 / (lambda * lambda);
@@ -251,6 +330,13 @@ float curve_eval(const pt_curve& c, const float* data, float lambda) {
         case PT_CURVE_BLACKBODY: {
             float temperature = c.p0, boost = c.p1;
             if (boost == 0.0f) return blackbody(temperature, lambda);
+#ifdef PTREF_ALT_BLACKBODY_MEAN_VISIBLE
+            {   // normalised by its mean over the visible range instead of its Wien peak
+                float sum = 0.0f;
+                for (int i = 0; i < 100; ++i) sum += blackbody(temperature, 380.0f + (750.0f - 380.0f) * ((float)i + 0.5f) / 100.0f);
+                return boost * blackbody(temperature, lambda) / (sum / 100.0f);
+            }
+#endif
             return boost * blackbody(temperature, lambda) / blackbody(temperature, max_blackbody_lambda(temperature));
         }
     }
@@ -1196,6 +1282,9 @@ Ray camera_get_ray(const Camera& cam, const Sampler& smp, float u, float v) {
         return ray_new(cam.origin, cam.u * vec.x + cam.v * vec.y + cam.w * vec.z);
     }
     float ax = 0.0f, ay = 0.0f; bool ok = false;
+#ifdef PTREF_ALT_APERTURE_POLAR
+    { pt_f32x4 r = smp.aperture(0); V3 p = random_in_unit_disk(r.x, r.y); ax = p.x; ay = p.y; ok = true; }   // polar disk sampling, no rejection
+#endif
     for (uint32_t blk = 0; blk < PT_APERTURE_BLOCKS && !ok; ++blk) {
         pt_f32x4 r = smp.aperture(blk);
         float x = r.x * 2.0f - 1.0f, y = r.y * 2.0f - 1.0f;

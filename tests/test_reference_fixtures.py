@@ -225,3 +225,38 @@ def test_reference_scenes_that_load_render_on_the_oracle(sfmod, oracle, pkg, nam
     # black for a reason: two caustic set-ups light the camera only through a prism / an orb from a narrow sharp light (nothing at 4 spp
     # and depth 4), and test_lighting_north.toml puts its camera inside the opaque unit sphere
     assert lit or name in ("cornell_box_parallel_prism", "cornell_box_single_orb_caustic", "test_lighting_north"), name
+
+
+def test_showcase_cornell_box_chromaticities(oracle, pkg):
+    """A loose STATISTICAL pin of the oracle against the only pixels in the tree that the reference itself produced:
+    showcase/cornell_box_1080p.png.  Its render settings are unknown (exposure, tone mapper, sample count, the author's own cornell_box.obj),
+    so nothing absolute can be compared; what survives those unknowns is the chromaticity of large flat patches — the Cornell light's
+    spectrum times each wall's reflectance curve, through the colour-matching functions, the XYZ -> sRGB matrix and the OETF.  The oracle
+    renders this repository's C2 scene (same camera, light and library curves as data/scenes/cornell_box.toml), the film goes through
+    output_film, and the linearised patch colours must have the showcase's chromaticities within a generous tolerance.  This catches a wrong
+    unit, matrix, curve table or wall assignment; it does NOT decide between the close alternatives of profiles/r3_oracle_sensitivity.md
+    (those move chromaticities by < 0.01).  Parity stays unpinned."""
+    import oracle_loader
+    show = _decode_png(os.path.join(REF, "showcase", "cornell_box_1080p.png"))[..., :3].astype(np.float64) / 255.0
+    assert show.shape[:2] == (1080, 1080)
+    sc = oracle.create_scene(pkg.scene.cornell_box())
+    film, _ = oracle_loader.render_mt(oracle, sc, pkg.api.render_desc(120, 120, 48, 8, seed=3), os.cpu_count() or 4)
+    rgba, _ = oracle.output_film(film, tonemap=pkg.api.TONEMAP_CLAMP, exposure=3.0)   # (bright enough for the 8-bit quantisation not to matter)
+    ours = rgba[..., :3].astype(np.float64) / 255.0
+
+    def lin(c):
+        return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+
+    def chroma(img, cx, cy, r=0.03):
+        h, w, _ = img.shape
+        p = lin(img[int((cy - r) * h):int((cy + r) * h), int((cx - r) * w):int((cx + r) * w)].reshape(-1, 3).mean(0))
+        return p[0] / p.sum(), p[1] / p.sum()
+    # patch centres as fractions of the (square) image; tolerance on (r, g) chromaticity
+    patches = {"back wall": (0.5, 0.35, 0.05), "right wall (red)": (0.93, 0.5, 0.05), "left wall (green)": (0.08, 0.5, 0.10), "floor": (0.75, 0.95, 0.06),
+               "ceiling": (0.3, 0.04, 0.05), "tall block front": (0.33, 0.62, 0.06), "short block top": (0.62, 0.70, 0.07)}
+    for name, (cx, cy, tol) in patches.items():
+        a, b = chroma(show, cx, cy), chroma(ours, cx, cy)
+        assert abs(a[0] - b[0]) <= tol and abs(a[1] - b[1]) <= tol, (name, a, b)
+    # the layout itself: green on the left, red on the right, a warm white in between (as the showcase has it)
+    gl, rr, bw = chroma(ours, 0.08, 0.5), chroma(ours, 0.93, 0.5), chroma(ours, 0.5, 0.35)
+    assert gl[1] > gl[0] and rr[0] > 0.9 and rr[0] > bw[0] > gl[0]
