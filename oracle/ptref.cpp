@@ -139,7 +139,7 @@ inline V3 random_cosine_direction(float u, float v) {
         else { r = b; phi = PT_PI / 2.0f - (PT_PI / 4.0f) * (a / b); }
         float sn, cs; pt_sincos(phi, &sn, &cs);
         const float x = r * cs, y = r * sn;
-        return v3(x, y, std::sqrt(pt_max(0.0f, 1.0f - x * x - y * y)));
+        return v3(x, y, std::sqrt(pt_max(1e-12f, 1.0f - x * x - y * y)));   // (never exactly grazing: a pdf of 0 here would be this alternative's artefact, not the crate's)
     }
 #elif defined(PTREF_ALT_COSINE_SWAP_UV)
     { const float t = u; u = v; v = t; }
@@ -1491,7 +1491,7 @@ void random_walk_medium(const RenderCtx& ctx, Ray ray, float lambda, uint32_t bo
     uint32_t tracked[kMaxTrackedMediums]; uint32_t n_tracked = 0;
     auto remove_medium = [&](uint32_t id) { for (uint32_t i = 0; i < n_tracked; ++i) if (tracked[i] == id) { for (uint32_t j = i + 1; j < n_tracked; ++j) tracked[j - 1] = tracked[j]; --n_tracked; return; } };
     auto add_medium = [&](uint32_t id) {  // push + sort_unstable (:965-968)
-        if (n_tracked == kMaxTrackedMediums) return;
+        if (n_tracked == kMaxTrackedMediums) { profile.stage_items[5] += 1; return; }   // (counted: the reference's Vec has no such limit)
         uint32_t i = n_tracked++;
         while (i > 0 && tracked[i - 1] > id) { tracked[i] = tracked[i - 1]; --i; }
         tracked[i] = id;
@@ -1804,6 +1804,7 @@ std::vector<TileRect> generate_tiles(uint32_t width, uint32_t height, uint32_t t
 inline void add_profile(pt_profile& a, const pt_profile& b) {
     a.bounce_rays += b.bounce_rays; a.shadow_rays += b.shadow_rays; a.light_rays += b.light_rays;
     a.camera_rays += b.camera_rays; a.env_hits += b.env_hits;
+    a.stage_items[5] += b.stage_items[5];   // tracked mediums dropped (the medium-aware walk's fifth nested medium)
 }
 
 // TiledRenderer::render_sampled, src/renderer/tiled.rs:279-542 (per-tile body :344-398)

@@ -33,7 +33,7 @@
 #define PT_TRI_WORDS 12
 
 // Mesh record (8 words): node_off (float4 units... all offsets are WORD offsets), node_count, tri_off, normal_off
-// (0 = none), face_count, pad x3
+// (0 = none), face_count, leaf list, group boxes
 #define PT_MESH_WORDS 8
 #define PT_MESH_NODE_OFF 0
 #define PT_MESH_NODE_COUNT 1
@@ -161,6 +161,8 @@
 #define PT_HDR_SWEEP_BITS_OFF 56
 #define PT_HDR_IMAP_MARG_GUIDE 59   /* guide tables for the CDF searches (float offsets into texture memory, u32 bit patterns): */
 #define PT_HDR_IMAP_ROW_GUIDE 60    /* n + 3 entries per table, entry j = first index whose cmf is >= j / n (pt_device.h sample_cmf) */
+#define PT_HDR_IMAP_STRIDE 66        /* floats between consecutive entries of a pdf or cmf table: 2 = the tables are interleaved, (cmf[k], pdf[k]) pairs — the three or four
+                                       values a sample ends on (cmf[k - 1], cmf[k], pdf[k], pdf[k + 1]) then lie on one 128-byte line instead of two */
 #define PT_HDR_CORE_WORDS 61        /* words of the core section; the mesh-data section follows it */
 #define PT_HDR_SWEEP_MESH_MASK 57  /* 2 words: the bits that stand for mesh instances (no primitive of their own) */
 #define PT_HDR_SWEEP_OWNER_MASK 62 /* 2 words: the bits whose primitive test needs the ray itself (analytic shapes, triangles of transformed

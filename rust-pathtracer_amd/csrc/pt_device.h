@@ -106,6 +106,7 @@ struct SceneView {
     uint32_t lacks = 0u;
 };
 #define PT_SCENE_NO_XF 1u   /* no instance carries a transform (the Cornell box): instance_local_ray and the hit record's way back are identities */
+#define PT_SCENE_NO_LIGHTS 2u /* the light list is empty (an environment is the only emitter: hdri_test): no light vertex, no light to sample */
 PT_HD uint32_t bu(const SceneView& s, uint32_t off) { return s.w[off]; }
 PT_HD float bf(const SceneView& s, uint32_t off) { return pt_u2f(s.w[off]); }
 PT_HD F4 bf4(const SceneView& s, uint32_t off) { return *reinterpret_cast<const F4*>(s.w + off); }
@@ -1651,8 +1652,8 @@ PT_HD uint32_t mediums_remove(uint32_t list, uint32_t id) {   // the first occur
         }
     return list;
 }
-PT_HD uint32_t mediums_add(uint32_t list, uint32_t id) {      // push + sort_unstable (:965-968); a fifth entry is dropped
-    if ((list >> 24) != 0u) return list;
+PT_HD uint32_t mediums_add(uint32_t list, uint32_t id, uint32_t* dropped = nullptr) {      // push + sort_unstable (:965-968); a fifth entry is dropped — and counted (pt_profile::stage_items[5])
+    if ((list >> 24) != 0u) { if (dropped) *dropped += 1u; return list; }
     uint32_t i = 0;
     while (i < 4u && ((list >> (8u * i)) & 0xffu) != 0u && ((list >> (8u * i)) & 0xffu) <= id) ++i;
     const uint32_t low = list & ((1u << (8u * i)) - 1u), high = i == 3u ? 0u : (list >> (8u * i)) << (8u * (i + 1u));
@@ -1711,22 +1712,23 @@ PT_HD float light_psa_pdf(const SceneView& s, uint32_t inst, float cos_o, float 
 
 // ---------------------------------------------------------------- environment (src/world/environment.rs)
 // Curve::Linear{bounds (0,1), Nearest}.evaluate over a table in texture memory
-PT_HD float linear01_nearest(const float* signal, uint32_t n, float x) {
+// (`stride`: floats between consecutive entries — 2 where a pdf table is interleaved with its cmf, PT_HDR_IMAP_STRIDE)
+PT_HD float linear01_nearest(const float* signal, uint32_t n, float x, uint32_t stride = 1u) {
     if (x < 0.0f || x > 1.0f) return 0.0f;
     float step = 1.0f / (float)n;
     float fi = x / step;
     uint32_t index = (uint32_t)fi;
     if (index >= n) index = n - 1;
-    float left = signal[index];
+    float left = signal[(size_t)index * stride];
     if (index + 1 >= n) return left;
     float t = (x - (float)index * step) / step;
-    return t < 0.5f ? left : signal[index + 1];
+    return t < 0.5f ? left : signal[(size_t)(index + 1) * stride];
 }
 // CurveWithCDF::sample_power_and_pdf on a (pdf, cmf) table pair (math crate, restated)
 // `guide` (optional, n + 3 entries of u32 bits: entry j = lower bound of j / n) brackets the search: with
 // j = max(0, floor(x n) - 1), j / n <= x < (j + 3) / n whatever the rounding, so the lower bound of x lies in
 // [guide[j], guide[j + 3]] and the search inside the bracket returns the index the search of the whole table returns.
-PT_HD void sample_cmf(const float* pdf, const float* cmf, uint32_t n, float x, float* coord, float* p, const float* guide = nullptr) {
+PT_HD void sample_cmf(const float* pdf, const float* cmf, uint32_t n, float x, float* coord, float* p, const float* guide = nullptr, uint32_t stride = 1u) {
     uint32_t lo = 0, hi = n;
     if (guide != nullptr && x >= 0.0f && x <= 1.0f) {
         float fj = pt_floor(x * (float)n) - 1.0f;
@@ -1734,14 +1736,14 @@ PT_HD void sample_cmf(const float* pdf, const float* cmf, uint32_t n, float x, f
         if (j > n - 1u) j = n - 1u;
         lo = pt_f2u(guide[j]); hi = pt_f2u(guide[j + 3u]);
     }
-    while (lo < hi) { uint32_t mid = lo + (hi - lo) / 2; if (cmf[mid] < x) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { uint32_t mid = lo + (hi - lo) / 2; if (cmf[(size_t)mid * stride] < x) lo = mid + 1; else hi = mid; }
     uint32_t k = lo < n ? lo : n - 1;
-    float below = k == 0 ? 0.0f : cmf[k - 1];
-    float width = cmf[k] - below;
+    float below = k == 0 ? 0.0f : cmf[(size_t)(k - 1) * stride];
+    float width = cmf[(size_t)k * stride] - below;
     float t = width > 0.0f ? (x - below) / width : 0.0f;
     float c = ((float)k + t) / (float)n;
     c = pt_clamp(c, 0.0f, 1.0f - PT_F32_EPSILON);
-    *coord = c; *p = linear01_nearest(pdf, n, c);
+    *coord = c; *p = linear01_nearest(pdf, n, c, stride);
 }
 PT_HD float env_emission(const SceneView& s, float u, float v, float lambda) {
     uint32_t kind = bu(s, PT_HDR_ENV_KIND);
@@ -1792,8 +1794,9 @@ PT_HD float env_pdf_for(const SceneView& s, float u, float v) {
         F3 nd = xf_vec(s, PT_HDR_ENV_REVERSE, uv_to_direction(u, v));
         float u2, v2; direction_to_uv(nd, &u2, &v2);
         uint32_t row = (uint32_t)(pt_clamp(u2, 0.0f, 1.0f - PT_F32_EPSILON) * (float)rows);
-        return linear01_nearest(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), rows, u2) *
-                   linear01_nearest(s.tex + bu(s, PT_HDR_IMAP_ROW_PDF) + (size_t)row * cols, cols, v2) *
+        const uint32_t stride = bu(s, PT_HDR_IMAP_STRIDE);
+        return linear01_nearest(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), rows, u2, stride) *
+                   linear01_nearest(s.tex + bu(s, PT_HDR_IMAP_ROW_PDF) + (size_t)row * cols * stride, cols, v2, stride) *
                    (2.0f * PT_PI * PT_PI * pt_sin(PT_PI * v2) + 0.001f) +
                0.001f;
     }
@@ -1815,10 +1818,11 @@ PT_HD void env_sample_uv(const SceneView& s, float sx, float sy, float* u, float
         uint32_t cols = bu(s, PT_HDR_IMAP_COLS);
         float mu, row_pdf, mv, column_pdf;
         const uint32_t mg = bu(s, PT_HDR_IMAP_MARG_GUIDE), rg = bu(s, PT_HDR_IMAP_ROW_GUIDE);
-        sample_cmf(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), s.tex + bu(s, PT_HDR_IMAP_MARG_CMF), rows, sy, &mu, &row_pdf, mg ? s.tex + mg : nullptr);
+        const uint32_t stride = bu(s, PT_HDR_IMAP_STRIDE);
+        sample_cmf(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), s.tex + bu(s, PT_HDR_IMAP_MARG_CMF), rows, sy, &mu, &row_pdf, mg ? s.tex + mg : nullptr, stride);
         uint32_t row = (uint32_t)(mu * (float)rows);
-        sample_cmf(s.tex + bu(s, PT_HDR_IMAP_ROW_PDF) + (size_t)row * cols, s.tex + bu(s, PT_HDR_IMAP_ROW_CMF) + (size_t)row * cols, cols, sx, &mv, &column_pdf,
-                   rg ? s.tex + rg + (size_t)row * (cols + 3u) : nullptr);
+        sample_cmf(s.tex + bu(s, PT_HDR_IMAP_ROW_PDF) + (size_t)row * cols * stride, s.tex + bu(s, PT_HDR_IMAP_ROW_CMF) + (size_t)row * cols * stride, cols, sx, &mv, &column_pdf,
+                   rg ? s.tex + rg + (size_t)row * (cols + 3u) : nullptr, stride);
         F3 new_wo = xf_vec(s, PT_HDR_ENV_FORWARD, uv_to_direction(mu, mv));
         float u2, v2; direction_to_uv(new_wo, &u2, &v2);
         *u = u2; *v = v2;

@@ -350,7 +350,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
         memset(profile, 0, sizeof(*profile));
         std::vector<unsigned long long> bs((size_t)grid * BS_FIELDS);
         HIP_TRY(hipMemcpy(bs.data(), b.block_stats, sizeof(unsigned long long) * bs.size(), hipMemcpyDeviceToHost));
-        unsigned long long c[BS_FIELDS] = {0, 0, 0, 0, 0};
+        unsigned long long c[BS_FIELDS] = {0, 0, 0, 0, 0, 0};
         for (int g = 0; g < grid; ++g) for (int k = 0; k < BS_FIELDS; ++k) c[k] += bs[(size_t)g * BS_FIELDS + k];
         profile->camera_rays = camera_rays;
         profile->bounce_rays = c[BS_VERTICES] + camera_rays;  // vertices.len() counts the camera vertex (utils.rs:375)
@@ -360,6 +360,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
         for (int i = 0; i < ST_COUNT; ++i) { profile->kernel_seconds[i] = stage_ms[i] * 1e-3; profile->kernel_launches[i] = stage_launches[i]; }
         profile->stage_items[ST_GENERATE] = camera_rays; profile->stage_items[ST_EXTEND] = c[BS_SEGMENTS]; profile->stage_items[ST_SHADE] = c[BS_SEGMENTS];
         profile->stage_items[ST_SHADOW] = c[BS_ITEMS]; profile->stage_items[ST_ACCUMULATE] = accumulated_pixels;
+        profile->stage_items[5] = c[BS_MEDIUM_DROPS];   // the medium-aware walk tracks four nested mediums: what a fifth level lost (0 = the walk is the reference's)
     }
     return PT_OK;
 }
@@ -420,7 +421,7 @@ static pt_status scene_to_device(pt_scene* sc) {
         bool any_xf = false;
         const std::vector<uint32_t>& bl = sc->host.blob;
         for (uint32_t i = 0; i < bl[PT_HDR_INSTANCE_COUNT]; ++i) any_xf = any_xf || (bl[bl[PT_HDR_INSTANCE_OFF] + i * PT_INST_WORDS + PT_INST_FLAGS] & 1u) != 0u;
-        sc->lacks = (!any_xf && !(tn.flags & PT_TUNE_GENERAL_FORMS)) ? PT_SCENE_NO_XF : 0u;
+        sc->lacks = (tn.flags & PT_TUNE_GENERAL_FORMS) ? 0u : ((any_xf ? 0u : PT_SCENE_NO_XF) | (bl[PT_HDR_LIGHT_COUNT] == 0u ? PT_SCENE_NO_LIGHTS : 0u));
     }
     const bool no_lds = (tn.flags & PT_TUNE_NO_LDS) != 0;
     const uint32_t all_limit = tuned(tn.lds_all_limit, kLdsAllLimitBytes);   // (experiments: the largest blob staged whole)
@@ -684,6 +685,7 @@ pt_status pt_render_multi(pt_scene* sc, const pt_render_desc* rdp, uint64_t devi
             profile->bounce_rays += p.bounce_rays; profile->shadow_rays += p.shadow_rays; profile->light_rays += p.light_rays;
             profile->camera_rays += p.camera_rays; profile->env_hits += p.env_hits;
             for (int k = 0; k < 5; ++k) { profile->kernel_seconds[k] += p.kernel_seconds[k]; profile->kernel_launches[k] += p.kernel_launches[k]; profile->stage_items[k] += p.stage_items[k]; }
+            profile->stage_items[5] += p.stage_items[5];
         }
         profile->seconds = std::chrono::duration<double>(t1 - t0).count();
         profile->kernel_seconds[5] = std::chrono::duration<double>(t0 - t_entry).count();    // set-up (replicas, streams, films, communicator): ~0 on a repeated call

@@ -12,6 +12,7 @@ namespace ptk {
 #define K_SHADE_FUSED k_shade<PT_LDS_ALL, PT_SHADE_NL, PT_SHADE_LEAN, PT_SCENE_NO_XF, PT_TRAV_SWEEP>
 #define K_SHADE_N(M) k_shade<M, PT_SHADE_NL, PT_SHADE_NO_ENV>
 #define K_SHADE_F(M) k_shade<M, PT_SHADE_NL, PT_SHADE_FULL>
+#define K_SHADE_FE(M) k_shade<M, PT_SHADE_NL, PT_SHADE_FULL, PT_SCENE_NO_LIGHTS>
 #define PT_ARGS sc.blob, sc.blob_words, sc.tex, rp, bounce, pixels, paths_in, hits, paths_out, shadow, energy, seg_cap, count_in, count_out, shadow_count, block_stats
 #define PT_ARGS_FWD sc, rp, bounce, pixels, paths_in, hits, paths_out, shadow, energy, seg_cap, count_in, count_out, shadow_count, block_stats
 #define PT_CAT2(a, b) a##b
@@ -24,7 +25,8 @@ void PT_CAT(launch_shade_nl, PT_SHADE_NL)(const LaunchCfg& c, int form, const Sc
 #define K_SHADE_M(M) k_shade_medium<M>
     if (form == PT_SHADE_MEDIUM) { PT_BY_MODE(K_SHADE_M, PT_ARGS); return; }
 #endif
-    if (form == PT_SHADE_FULL) PT_BY_MODE(K_SHADE_F, PT_ARGS);
+    if (form == PT_SHADE_FULL && (c.lacks & PT_SCENE_NO_LIGHTS) && PT_SHADE_NL == 1) PT_BY_MODE(K_SHADE_FE, PT_ARGS);   // (an environment is the scene's only emitter)
+    else if (form == PT_SHADE_FULL) PT_BY_MODE(K_SHADE_F, PT_ARGS);
     else if (form == PT_SHADE_NO_ENV) PT_BY_MODE(K_SHADE_N, PT_ARGS);
     else if (c.fuse) PT_GO(K_SHADE_FUSED, PT_ARGS);   // (the engine asks for it only where this form exists: PT_LDS_ALL, lean, no transforms, pure sweep)
     else if (c.lacks & PT_SCENE_NO_XF) PT_BY_MODE(K_SHADE_LX, PT_ARGS);
@@ -36,6 +38,9 @@ hipError_t PT_CAT(allow_lds_shade_nl, PT_SHADE_NL)(uint32_t bytes) {
 #define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
     allow(reinterpret_cast<const void*>(K_SHADE_FUSED));
     PT_ALLOW_MODES(K_SHADE_L); PT_ALLOW_MODES(K_SHADE_LX); PT_ALLOW_MODES(K_SHADE_N); PT_ALLOW_MODES(K_SHADE_F);
+#if PT_SHADE_NL == 1
+    PT_ALLOW_MODES(K_SHADE_FE);
+#endif
 #if PT_SHADE_NL == 1
     PT_ALLOW_MODES(K_SHADE_M);
 #endif

@@ -8,6 +8,7 @@ namespace ptk {
 #define PT_BY_MODE(K, ...) do { if (c.lds_mode == PT_LDS_ALL) PT_GO(K(PT_LDS_ALL), __VA_ARGS__); else if (c.lds_mode == PT_LDS_CORE) PT_GO(K(PT_LDS_CORE), __VA_ARGS__); \
                                 else PT_GO(K(PT_LDS_NONE), __VA_ARGS__); } while (0)
 #define K_SH_PARKED1(M) k_shadow_parked<M, 1>
+#define K_SH_PARKED1E(M) k_shadow_parked<M, 1, PT_SCENE_NO_LIGHTS>
 #define K_SH_PARKED4(M) k_shadow_parked<M, 4>
 #define K_SH_ANY1(M) k_shadow<M, 1, PT_TRAV_ANY>
 #define K_SH_ANY4(M) k_shadow<M, 4, PT_TRAV_ANY>
@@ -33,7 +34,11 @@ void launch_shadow(const LaunchCfg& c, int form, int nl, bool env, const SceneAr
         LaunchCfg plain = c; plain.lds_bytes = 0;
         if (hero) { PT_DYN_BY_MODE(4); go(plain, k_shadow_sum<4>, light_samples, shadow, energy, energy_stride, seg_cap, count_in); }
         else { PT_DYN_BY_MODE(1); go(plain, k_shadow_sum<1>, light_samples, shadow, energy, energy_stride, seg_cap, count_in); }
-    } else if (form == PT_FORM_PARKED) { if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park); else PT_BY_MODE(K_SH_PARKED1, PT_ARGS, park); }
+    } else if (form == PT_FORM_PARKED) {
+        if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park);
+        else if (c.lacks & PT_SCENE_NO_LIGHTS) PT_BY_MODE(K_SH_PARKED1E, PT_ARGS, park);   // (an environment is the scene's only emitter)
+        else PT_BY_MODE(K_SH_PARKED1, PT_ARGS, park);
+    }
     else if (form == PT_FORM_POOLED) {
         if (env) { if (hero) PT_GO((k_shadow_pooled<PT_LDS_ALL, 4, true>), PT_ARGS); else PT_GO((k_shadow_pooled<PT_LDS_ALL, 1, true>), PT_ARGS); }
         else if (hero) PT_GO((k_shadow_pooled<PT_LDS_ALL, 4, false>), PT_ARGS); else PT_GO((k_shadow_pooled<PT_LDS_ALL, 1, false>), PT_ARGS);
@@ -51,7 +56,7 @@ hipError_t allow_lds_shadow(uint32_t bytes) {
     hipError_t worst = hipSuccess;
     auto allow = [&](const void* k) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) worst = e; };
 #define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
-    PT_ALLOW_MODES(K_SH_ANY1); PT_ALLOW_MODES(K_SH_ANY4); PT_ALLOW_MODES(K_SH_PARKED1); PT_ALLOW_MODES(K_SH_PARKED4);
+    PT_ALLOW_MODES(K_SH_ANY1); PT_ALLOW_MODES(K_SH_ANY4); PT_ALLOW_MODES(K_SH_PARKED1); PT_ALLOW_MODES(K_SH_PARKED4); PT_ALLOW_MODES(K_SH_PARKED1E);
 #define K_SH_DYN1(M) k_shadow_parked_dyn<M, 1>
 #define K_SH_DYN4(M) k_shadow_parked_dyn<M, 4>
     PT_ALLOW_MODES(K_SH_DYN1); PT_ALLOW_MODES(K_SH_DYN4);

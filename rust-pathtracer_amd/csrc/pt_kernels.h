@@ -290,7 +290,7 @@ k_shade_medium(const uint32_t* __restrict__ blob, uint32_t blob_words, const flo
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
     if (USE_LDS == PT_LDS_NONE) __syncthreads();
     const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
-    uint32_t st_vertices = 0, st_shadow = 0, st_env = 0;
+    uint32_t st_vertices = 0, st_shadow = 0, st_env = 0, st_drops = 0;
     const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t j = r * blockDim.x + threadIdx.x, i = base + j;
@@ -319,10 +319,10 @@ k_shade_medium(const uint32_t* __restrict__ blob, uint32_t blob_words, const flo
         }
         const uint32_t pos = base + shared_append(out.survives, &lds_counts[0]);
         if (out.survives) { store_path<1>(paths_out, pos, out.next); qsu(paths_out, PS_MEDIUMS, pos, ms_next.mediums); qsu(paths_out, PS_PREV_MEDIUM, pos, ms_next.prev_medium); }
-        st_vertices += out.vertex_pushed ? 1u : 0u; st_env += out.env_hit ? 1u : 0u; st_shadow += out.shadow_count;
+        st_vertices += out.vertex_pushed ? 1u : 0u; st_env += out.env_hit ? 1u : 0u; st_shadow += out.shadow_count; st_drops += ms_next.dropped;
     }
-    st_vertices = wave_reduce_add(st_vertices); st_shadow = wave_reduce_add(st_shadow); st_env = wave_reduce_add(st_env);
-    if (lane_id() == 0) { atomicAdd(&lds_counts[4], st_vertices); atomicAdd(&lds_counts[5], st_shadow); atomicAdd(&lds_counts[6], st_env); }
+    st_vertices = wave_reduce_add(st_vertices); st_shadow = wave_reduce_add(st_shadow); st_env = wave_reduce_add(st_env); st_drops = wave_reduce_add(st_drops);
+    if (lane_id() == 0) { atomicAdd(&lds_counts[4], st_vertices); atomicAdd(&lds_counts[5], st_shadow); atomicAdd(&lds_counts[6], st_env); atomicAdd(&lds_counts[7], st_drops); }
     __syncthreads();
     if (threadIdx.x == 0) {
         count_out[blockIdx.x] = lds_counts[0]; shadow_count[blockIdx.x] = lds_counts[1];
@@ -330,6 +330,7 @@ k_shade_medium(const uint32_t* __restrict__ blob, uint32_t blob_words, const flo
         bs[BS_VERTICES] += lds_counts[4]; bs[BS_SHADOW_RAYS] += lds_counts[5]; bs[BS_ENV_HITS] += lds_counts[6];
         bs[BS_SEGMENTS] += n;
         bs[BS_ITEMS] += lds_counts[1];
+        bs[BS_MEDIUM_DROPS] += lds_counts[7];
     }
 }
 
@@ -585,13 +586,16 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
     }
 }
 
-template <int USE_LDS, int NL>
+// (LACKS = PT_SCENE_NO_LIGHTS: the light list is empty — hdri_test — so every light-sample ray is an environment ray: the light pre-pass, the
+// light's record and its emission are compiled out)
+template <int USE_LDS, int NL, uint32_t LACKS = 0u>
 __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                      uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                                      uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ park_all) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ uint32_t park_counts[kBlock / 64];
-    SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
+    SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);
+    constexpr bool kOnlyEnv = (LACKS & PT_SCENE_NO_LIGHTS) != 0u;
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap + wave * kWaveParkCap;
     uint32_t* park_count = &park_counts[wave];
@@ -618,7 +622,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
     auto resume_parked = [&](uint32_t j2, SweepState& st, uint32_t l2, float bound, uint32_t kind) {
         ShadowRayT<NL> pr;
         load_shadow_ray<NL>(shadow, base + j2, l2, &pr);
-        const bool env = (kind & 1u) != 0u;
+        const bool env = kOnlyEnv || (kind & 1u) != 0u;
         // a light ray searches with the early stop whenever it has a finite bound (shadow_light_bound)
         const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
         settle(j2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound), (kind >> 1) - 1u);
@@ -653,7 +657,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
             const uint32_t e = live[live_count + lane_id()], j = e >> 3, l = e & 7u, item = base + j;
             ShadowRayT<NL> ray;
             load_shadow_ray<NL>(shadow, item, l, &ray);
-            const bool env = ((qu(shadow, Layout<NL>::sh_flags, item) >> l) & 1u) != 0;
+            const bool env = kOnlyEnv || ((qu(shadow, Layout<NL>::sh_flags, item) >> l) & 1u) != 0;
             float bound = PT_INF; int stop = shadow_env_stop(s);
             uint32_t light = 0xffffffffu;
             if (!env && !shadow_light_bound(s, ray.o, ray.d, &bound, &stop, &light)) {

@@ -18,7 +18,7 @@ constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // the most LDS a staged blo
 // 752.  C2's 14 KB blob staged whole: 1519; its 7 KB core alone: 1089 (the sweep reads the triangles of the two boxes for every ray).
 constexpr uint32_t kLdsAllLimitBytes = 24 * 1024;
 constexpr uint32_t kParkCap = 512, kParkFields = 16;
-enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_FIELDS };  // per-workgroup statistics (Profile counters)
+enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_MEDIUM_DROPS, BS_FIELDS };  // per-workgroup statistics (Profile counters)
 uint32_t pool_lds_bytes();  // static LDS of the pooled traversal kernels, on top of the staged blob
 
 struct LaunchCfg { int grid; uint32_t lds_bytes; hipStream_t stream; int lds_mode;

@@ -278,6 +278,8 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
         }
         pad16(md);
         uint32_t node_off = (uint32_t)md.size();
+        // (a node's exit link is 27 bits of a word that also holds the form of its box test, pt_blob.h: 2 n - 1 nodes must fit)
+        if (2ull * tb.size() >= (1ull << 27)) { *err = "mesh " + std::to_string(mi) + ": " + std::to_string(tb.size()) + " triangles make a BVH of 2^27 or more nodes (the skip-link field is 27 bits)"; return false; }
         std::vector<uint32_t> nodes; BvhBuilder bb(tb, nodes); bb.build();
         md.insert(md.end(), nodes.begin(), nodes.end());
         mesh_node_off[mi] = node_off; mesh_node_count[mi] = (uint32_t)(nodes.size() / PT_NODE_WORDS);
@@ -432,6 +434,7 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
     // top-level BVH over instances
     pad16(w);
     {
+        if (2ull * d.instance_count >= (1ull << 27)) { *err = std::to_string(d.instance_count) + " instances make a top-level BVH of 2^27 or more nodes (the skip-link field is 27 bits)"; return false; }
         std::vector<uint32_t> nodes; BvhBuilder bb(ibox, nodes);
         bb.no_cull.assign(d.instance_count, 0);
         for (uint32_t i = 0; i < d.instance_count; ++i) bb.no_cull[i] = d.instances[i].kind == PT_SHAPE_SPHERE;
@@ -639,12 +642,18 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             }
             float run = 0.0f;
             for (uint32_t row = 0; row < V; ++row) { mpdf[row] /= total; run += mpdf[row]; mcmf[row] = run; }
-            if (hs->tex.size() + 2 * row_pdf.size() + 2 * (size_t)V > 0xffffffffull) return fail("importance map too large");
+            if (hs->tex.size() + 2 * row_pdf.size() + 2 * (size_t)V + 64 > 0xffffffffull) return fail("importance map too large");
             w[PT_HDR_IMAP_ROWS] = V; w[PT_HDR_IMAP_COLS] = H;
-            w[PT_HDR_IMAP_ROW_PDF] = (uint32_t)hs->tex.size(); hs->tex.insert(hs->tex.end(), row_pdf.begin(), row_pdf.end());
-            w[PT_HDR_IMAP_ROW_CMF] = (uint32_t)hs->tex.size(); hs->tex.insert(hs->tex.end(), row_cmf.begin(), row_cmf.end());
-            w[PT_HDR_IMAP_MARG_PDF] = (uint32_t)hs->tex.size(); hs->tex.insert(hs->tex.end(), mpdf.begin(), mpdf.end());
-            w[PT_HDR_IMAP_MARG_CMF] = (uint32_t)hs->tex.size(); hs->tex.insert(hs->tex.end(), mcmf.begin(), mcmf.end());
+            // pdf and cmf of a table interleaved, (cmf[k], pdf[k]): what a sample reads at its end lies on one line (pt_blob.h PT_HDR_IMAP_STRIDE);
+            // the tables start on 128-byte lines (the texel array in front of them has any length)
+            auto interleaved = [&](const std::vector<float>& cmf, const std::vector<float>& pdf, int cmf_hdr, int pdf_hdr) {
+                while (hs->tex.size() % 32) hs->tex.push_back(0.0f);
+                w[cmf_hdr] = (uint32_t)hs->tex.size(); w[pdf_hdr] = (uint32_t)hs->tex.size() + 1u;
+                for (size_t k = 0; k < cmf.size(); ++k) { hs->tex.push_back(cmf[k]); hs->tex.push_back(pdf[k]); }
+            };
+            w[PT_HDR_IMAP_STRIDE] = 2u;
+            interleaved(row_cmf, row_pdf, PT_HDR_IMAP_ROW_CMF, PT_HDR_IMAP_ROW_PDF);
+            interleaved(mcmf, mpdf, PT_HDR_IMAP_MARG_CMF, PT_HDR_IMAP_MARG_PDF);
             // guide tables: entry j = lower bound of j / n in the cmf, so that a search starts in a bracket of a few entries
             // instead of at the whole table (ten dependent loads from L2/HBM per search otherwise)
             auto guide = [&](const float* cmf, uint32_t n) {

@@ -201,7 +201,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     Frame frame = frame_from_normal(hit.n);
     F3 wi = normalize(to_local(frame, neg(pv.d)));
     uint32_t m = material_record(s, hit.material);
-    bool is_light = PT_MATERIAL_TAG(hit.material) == PT_TAG_LIGHT;
+    bool is_light = !(s.lacks & PT_SCENE_NO_LIGHTS) && PT_MATERIAL_TAG(hit.material) == PT_TAG_LIGHT;
     pt_f32x4 r = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples));
     float f, pdf; F3 wo;
     // (per-wavelength loops stay rolled, their arrays in registers: pl_get / pl_set, pt_device.h)
@@ -235,7 +235,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
         }
     } else if (rp.light_samples > 0) {
         // pt.rs:562-604 -> estimate_direct_illumination_with_loop (pt.rs:333-393)
-        uint32_t n_lights = bu(s, PT_HDR_LIGHT_COUNT);
+        uint32_t n_lights = (s.lacks & PT_SCENE_NO_LIGHTS) ? 0u : bu(s, PT_HDR_LIGHT_COUNT);
         float env_p = bf(s, PT_HDR_ENV_PROB);
         if (!(n_lights == 0 && env_p == 0.0f)) {
             F3 hn = normalize(hit.n);  // HitRecord::from(vertex) renormalises (utils.rs:117-134)
@@ -334,7 +334,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
 // nothing and takes no light samples (the reference panics there, pt.rs:575-582).  Single wavelength.
 // Path state beyond PathVertexT: the tracked mediums (mediums_add / mediums_remove) and whether the previous vertex was a medium vertex.
 enum { PS_MEDIUMS = PS_FIELDS, PS_PREV_MEDIUM = PS_FIELDS + 1 };   // (the passenger-throughput fields of the hero layout: the two variants exclude each other)
-struct MediumState { uint32_t mediums, prev_medium; };
+struct MediumState { uint32_t mediums, prev_medium; uint32_t dropped = 0u; };   // `dropped`: out only — mediums a fifth nesting level lost at this vertex (not part of the path record)
 PT_HD bool shade_medium_wants_item(const SceneView& s, const RenderParams& rp, const Hit& hit, const MediumState& ms) {
     return ms.prev_medium == 0u && shade_wants_item(s, rp, hit);
 }
@@ -466,8 +466,8 @@ PT_HD ShadeOutT<1> stage_shade_medium(const SceneView& s, const RenderParams& rp
     const uint32_t mm = bu(s, m + PT_MAT_MEDIUMS), outer = mm & 0xffu, inner = (mm >> 8) & 0xffu;
     uint32_t list = ms.mediums;
     if (!(wi.z * wo.z > 0.0f) && inner != outer) {
-        if (wo.z < 0.0f) { if (outer != 0u) list = mediums_remove(list, outer); if (inner != 0u) list = mediums_add(list, inner); }
-        else { if (inner != 0u) list = mediums_remove(list, inner); if (outer != 0u) list = mediums_add(list, outer); }
+        if (wo.z < 0.0f) { if (outer != 0u) list = mediums_remove(list, outer); if (inner != 0u) list = mediums_add(list, inner, &ms_out->dropped); }
+        else { if (inner != 0u) list = mediums_remove(list, inner); if (outer != 0u) list = mediums_add(list, outer, &ms_out->dropped); }
     }
     ms_out->mediums = list; ms_out->prev_medium = 0u;
     out.survives = more;

@@ -72,7 +72,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
         psh((size_t)LY::shadow_fields(PT_MAX_LIGHT_SAMPLES) * cap64);
     std::vector<float> energy((size_t)NL * capacity);
     Queue qa{pa.data(), capacity, LY::path_fields + 2}, qb{pb.data(), capacity, LY::path_fields + 2}, qh{ph.data(), capacity, HS_FIELDS}, qs{psh.data(), capacity, LY::shadow_fields(PT_MAX_LIGHT_SAMPLES)};
-    uint64_t bounce_rays = 0, shadow_rays = 0, env_hits = 0, camera_rays = 0;
+    uint64_t bounce_rays = 0, shadow_rays = 0, env_hits = 0, camera_rays = 0, medium_drops = 0;
     uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
     for (const pth::Pass& pass : pth::plan_passes((uint32_t)pixels.size(), rd.first_sample, rd.sample_count, capacity, rd.phase_samples)) {
         rp.chunk_pixels = pass.pixel_count; rp.first_sample = pass.first_sample; rp.pass_samples = pass.sample_count;
@@ -134,7 +134,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
                     if (medium_walk) { qsu(qout, PS_MEDIUMS, next, ms_next.mediums); qsu(qout, PS_PREV_MEDIUM, next, ms_next.prev_medium); }
                     store_path<NL>(qout, next++, out.next);
                 }
-                bounce_rays += out.vertex_pushed; env_hits += out.env_hit; shadow_rays += out.shadow_count;
+                bounce_rays += out.vertex_pushed; env_hits += out.env_hit; shadow_rays += out.shadow_count; medium_drops += ms_next.dropped;
             }
             for (uint32_t i = 0; i < items; ++i) {
                 if (shade_form == 2 || rd.medium_aware) stage_shadow_item<NL, PT_TRAV_ANY, true>(s, rp.light_samples, qs, i, energy.data(), capacity);
@@ -147,6 +147,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
     if (profile) {
         std::memset(profile, 0, sizeof(*profile));
         profile->camera_rays = camera_rays; profile->bounce_rays = bounce_rays + camera_rays; profile->shadow_rays = shadow_rays; profile->env_hits = env_hits;
+        profile->stage_items[5] = medium_drops;
     }
     return PT_OK;
 }

@@ -88,7 +88,7 @@ def test_golden_vectors(emu):
         ps.golden_materials(emu, scene)
 
 
-@pytest.mark.parametrize("scene", ["cornell_box", "mixed_small", "white_furnace", "cornell_gem", "mixed_primitives", "hdri_small"])
+@pytest.mark.parametrize("scene", ["cornell_box", "mixed_small", "white_furnace", "cornell_gem", "mixed_primitives", "hdri_small", "hdri_c4_small"])
 def test_leaf_sweep_equals_bvh_walk(emu, pkg, monkeypatch, scene):
     """Scenes of <= 64 instances take world_hit_sweep (with the triangle leaves of small meshes in the table and the BVHs of
     big meshes walked from it); the pure BVH walk (flag 16), the exact slab test (2) and no culling (4) must give the same
@@ -101,10 +101,10 @@ def test_leaf_sweep_equals_bvh_walk(emu, pkg, monkeypatch, scene):
     rd = pkg.api.render_desc(24, 24, 4, 5, light_samples=2)
     results = []
     # (64: big meshes walked instead of swept through their group boxes; 256: the nearest light tested again in phase 3)
-    for flags in ("0", "16", "2", "18", "4", "128", "132", "64", "66", "256", "258"):
+    for flags in ("0", "16", "2", "18", "4", "128", "132", "64", "66", "256", "258", "80"):
         monkeypatch.setenv("PTEMU_FLAGS", flags)
         sc = emu.create_scene(b)
-        assert sc.uses_leaf_sweep() == (flags not in ("16", "18"))
+        assert sc.uses_leaf_sweep() == (flags not in ("16", "18", "80"))
         film, prof = sc.render(rd)
         results.append((sc.intersect(o, d), film, (prof.camera_rays, prof.bounce_rays, prof.shadow_rays, prof.env_hits)))
     for hits, film, counts in results[1:]:

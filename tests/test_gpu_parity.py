@@ -209,7 +209,8 @@ def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
     base, pbase = ref_scene.render(rd)
     for env in ({"PT_AMD_NO_PARK": "1"}, {"PT_AMD_NO_MESH_SWEEP": "1"}, {"PT_AMD_NO_SWEEP": "1"}, {"PT_AMD_NO_LDS": "1"}, {"PT_AMD_NO_CORE_LDS": "1"},
                 {"PT_AMD_BLOCKS_PER_CU": "32"}, {"PT_AMD_PARK_DYNAMIC": "0"}, {"PT_AMD_PARK_DYNAMIC": "1"}, {"PT_AMD_PARK_DYNAMIC": "1", "PT_AMD_PARK_BLOCKS_PER_CU": "1"},
-                {"PT_AMD_LDS_ALL_LIMIT": "65536"}, {"PT_AMD_LDS_ALL_LIMIT": "65536", "PT_AMD_PARK_DYNAMIC": "0"}, {"PT_AMD_LDS_ALL_LIMIT": "4096"}):
+                {"PT_AMD_LDS_ALL_LIMIT": "65536"}, {"PT_AMD_LDS_ALL_LIMIT": "65536", "PT_AMD_PARK_DYNAMIC": "0"}, {"PT_AMD_LDS_ALL_LIMIT": "4096"},
+                {"PT_AMD_NO_MESH_SWEEP": "1", "PT_AMD_NO_PARK": "1"}):
         # (the parked kernels with one static segment per workgroup / with units taken from a counter by persistent workgroups; the whole
         # blob staged in LDS however large — the gem's is 65 KB, staged as its core section by default — / only ever the core section)
         for k, v in env.items():
@@ -293,6 +294,22 @@ def test_whole_node_render_from_one_call(engine, pkg):
         sc.render_multi(rd, 1 << 40)
     with pytest.raises(pkg.api.PtError):
         sc.render_multi(pkg.api.render_desc(160, 96, 7, 6, seed=5, shard=(0, 2)), 0)
+
+
+def test_whole_node_on_two_physical_devices(engine, pkg):
+    """pt_render_multi over two real devices (runs only where the box has them): tiles dealt to both, one RCCL reduce over xGMI, the film
+    of pt_render bit for bit; a second call reuses the communicator."""
+    if engine.lib.pt_device_count() < 2:
+        pytest.skip("one HIP device on this box")
+    b = pkg.scene.cornell_box()
+    sc = engine.create_scene(b)
+    rd = pkg.api.render_desc(256, 160, 9, 6, seed=5)
+    base, pbase = sc.render(rd)
+    for call in range(2):
+        film, prof = sc.render_multi(rd, 0b11)
+        assert np.array_equal(film.view(np.uint32), base.view(np.uint32)), call
+        assert (prof.camera_rays, prof.bounce_rays, prof.shadow_rays) == (pbase.camera_rays, pbase.bounce_rays, pbase.shadow_rays)
+    assert prof.kernel_seconds[5] < 1e-3
 
 
 @pytest.mark.parametrize("scene,virt,rccl", [("cornell_box", 2, False), ("cornell_box", 8, False), ("cornell_gem", 3, False), ("hdri_small", 4, True)])

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Runs on the GPU box: C2 with different register budgets of the sweep form of k_shadow (waves per SIMD).
+source "$(dirname "$0")/lib_build.sh"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT
 for w in ${@:-5 6 7 8}; do
   touch rust-pathtracer_amd/csrc/pt_kern_shadow.hip
-  make -j8 -C rust-pathtracer_amd/csrc EXTRA="-DPT_SHADOW_SWEEP_WAVES=$w" libptamd.so > /dev/null 2>&1
+  pt_make -j8 -C rust-pathtracer_amd/csrc EXTRA="-DPT_SHADOW_SWEEP_WAVES=$w" libptamd.so
   python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --spp-per-step 480 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['roofline']['kernels']
 print('k_shadow at $w waves: %.1f Ms/s' % d['value'], {n: round(v['avg_us']) for n,v in k.items()})"
 done
-touch rust-pathtracer_amd/csrc/pt_kern_shadow.hip; make -j8 -C rust-pathtracer_amd/csrc libptamd.so > /dev/null 2>&1
+touch rust-pathtracer_amd/csrc/pt_kern_shadow.hip; pt_make -j8 -C rust-pathtracer_amd/csrc libptamd.so

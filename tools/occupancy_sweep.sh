@@ -1,5 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box: rebuilds the engine with different register budgets and benches C2..C5 with each (experiment).
+source "$(dirname "$0")/lib_build.sh"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT
 show() { python - <<PY
 import json
@@ -11,8 +12,8 @@ PY
 }
 for cfg in "${@:-3 1 5 1}"; do
   set -- $cfg
-  make -C rust-pathtracer_amd/csrc clean > /dev/null
-  make -C rust-pathtracer_amd/csrc EXTRA="-DPT_SHADE_WAVES=$1 -DPT_SHADE4_WAVES=$2 -DPT_SWEEP_WAVES=$3 -DPT_WALK_WAVES=$4" > /dev/null 2>&1
+  pt_make -C rust-pathtracer_amd/csrc clean
+  pt_make -C rust-pathtracer_amd/csrc EXTRA="-DPT_SHADE_WAVES=$1 -DPT_SHADE4_WAVES=$2 -DPT_SWEEP_WAVES=$3 -DPT_WALK_WAVES=$4"
   echo "== shade $1 shade4 $2 sweep $3 walk $4"
   T=gpurun_out/occ_$1_$2_$3_$4
   python bench.py --steps 3 --warmup 1 --cpu-seconds 0 > ${T}_C2.json 2> ${T}_C2.err; show ${T}_C2.json C2

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box: A/B of the optimisation level of the engine on C2..C5, alternating builds (experiment).
+source "$(dirname "$0")/lib_build.sh"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT
-build() { (cd rust-pathtracer_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 $1 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -w -shared -o libptamd.so pt_engine.hip pt_output.hip pt_compare.hip pt_scene_host.cpp pt_plan.cpp) > /dev/null 2>&1; }
+build() { (cd rust-pathtracer_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 $1 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -w -shared -o libptamd.so pt_engine.hip pt_output.hip pt_compare.hip pt_scene_host.cpp pt_plan.cpp) > /dev/null 2>&1 || { echo "BUILD FAILED: $1"; exit 1; }; }
 one() { timeout 200 python bench.py --steps 3 --warmup 1 --cpu-seconds 0 "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['roofline']['kernels']
@@ -14,4 +15,4 @@ for round in 1 2; do for flags in "-O3" "-O2"; do
   one --hero 4 --spp-per-step 60
 done; done
 build "-O2"; timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-make -C rust-pathtracer_amd/csrc clean > /dev/null; make -C rust-pathtracer_amd/csrc all > /dev/null 2>&1
+pt_make -C rust-pathtracer_amd/csrc clean; pt_make -C rust-pathtracer_amd/csrc all

@@ -3,8 +3,9 @@
 # (-DPT_EXPERIMENTS: k_extend_exp<bits>, pt_kernels.h), runs the bench once per variant — the variant is launched in front of the real
 # kernel, so the extend stage grows by the variant's cost — and prints the differences.  The product build is restored afterwards.
 # bits: 1 pooled form, 2 no phase 3, 4 no hit record, pooled only: 8 no triangle chunks, 0x10 no replay, 0x20 no winner, 0x40 no candidate lists
+source "$(dirname "$0")/lib_build.sh"
 OUT=${1:-gpurun_out/phase_costs}; mkdir -p $OUT
-cd rust-pathtracer_amd/csrc && touch pt_kern_extend.hip pt_kern_shadow.hip && make -j8 EXTRA=-DPT_EXPERIMENTS libptamd.so > /dev/null 2>&1; cd ../..
+cd rust-pathtracer_amd/csrc && touch pt_kern_extend.hip pt_kern_shadow.hip && pt_make -j8 EXTRA=-DPT_EXPERIMENTS libptamd.so; cd ../..
 for e in none 6 4 0 7 125 61 53 37 5 1; do
   if [ $e = none ]; then unset PT_AMD_EXP; else export PT_AMD_EXP=$e; fi
   PT_AMD_NO_POOL=1 python bench.py --steps 2 --warmup 1 --cpu-seconds 0 > $OUT/exp_$e.json 2> $OUT/exp_$e.err
@@ -35,4 +36,4 @@ for e in ["none", "6", "4", "0", "7", "125", "61", "53", "37", "5", "1"]:
     except Exception as ex:
         print(e, "failed", ex)
 PY
-cd rust-pathtracer_amd/csrc && touch pt_kern_extend.hip pt_kern_shadow.hip && make -j8 libptamd.so > /dev/null 2>&1
+cd rust-pathtracer_amd/csrc && touch pt_kern_extend.hip pt_kern_shadow.hip && pt_make -j8 libptamd.so
