@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(kBlock) PT_POOL_OCC k_shadow_exp(const uint32_
             bool hit = st.best_inst != 0xffffffffu;
             if (hit && !sweep_best_is_light(s, st)) { sh.valid = true; sh.material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); }
             else hit = sweep_finish(s, ray.o, ray.d, st, &sh);
-            shadow_ray_contribution<1>(s, lambda, ray, false, hit, sh, c);
+            shadow_ray_contribution<1>(s, [&](int) { return lambda[0]; }, ray, false, hit, sh, c);
             lc += c[0];
         }
         qsf(sink, HS_T, item, lc);
