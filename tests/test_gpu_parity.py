@@ -265,6 +265,38 @@ def test_pooled_phase3_changes_nothing(engine, pkg, monkeypatch, scene, L, hero)
         assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits)
 
 
+def test_tuning_is_taken_at_scene_creation(engine, pkg, monkeypatch):
+    """pt_tuning: the engine's switches as an explicit struct (what a Rust host sets per scene).  pt_scene_create_tuned with a flag set does what
+    the variable does through pt_tuning_default; a variable that changes AFTER the scene exists changes nothing (the environment is read once,
+    when the scene is created, never during a render); a struct with reserved words set is refused."""
+    b = pkg.scene.cornell_box()
+    rd = pkg.api.render_desc(96, 64, 5, 6, seed=2)
+    default = engine.create_scene(b)
+    film0, p0 = default.render(rd)
+    assert p0.kernel_launches[1] == 0            # the fused form: no k_extend launches
+    t = engine.tuning_default()
+    assert t.flags == 0 and t.batch_slots == 0 and t.park_dynamic == -1
+    t.flags |= pkg.api.TUNE_NO_FUSE
+    t.blocks_per_cu = 2
+    film1, p1 = engine.create_scene(b, t).render(rd)
+    assert p1.kernel_launches[1] > 0 and np.array_equal(film0.view(np.uint32), film1.view(np.uint32))
+    monkeypatch.setenv("PT_AMD_NO_FUSE", "1")
+    assert engine.tuning_default().flags & pkg.api.TUNE_NO_FUSE
+    film2, p2 = default.render(rd)               # the scene was created before the variable was set: still fused
+    assert p2.kernel_launches[1] == 0 and np.array_equal(film0.view(np.uint32), film2.view(np.uint32))
+    film3, p3 = engine.create_scene(b).render(rd)
+    assert p3.kernel_launches[1] > 0
+    monkeypatch.delenv("PT_AMD_NO_FUSE")
+    bad = engine.tuning_default()
+    bad.reserved[3] = 1
+    with pytest.raises(pkg.api.PtError):
+        engine.create_scene(b, bad)
+    bad = engine.tuning_default()
+    bad.shade_form = 7
+    with pytest.raises(pkg.api.PtError):
+        engine.create_scene(b, bad)
+
+
 def test_whole_node_render_from_one_call(engine, pkg):
     """pt_render_multi (the one blocking call a Rust `impl Renderer` makes): every device of the mask renders its tiles on its own
     host thread and stream, the device films are summed with RCCL.  On the one GPU of this box: mask 0 and mask 1 give pt_render's film

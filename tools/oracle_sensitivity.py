@@ -95,7 +95,7 @@ def main():
              "against the default reading, same scenes, same seeds.  `C1 L-inf / RMSE`: BASELINE C1 (Cornell 256 x 256, 16 spp, depth 4) at matched seeds —",
              "0 means the alternative never changes a path or a value on this scene.  `d mean Y`, `d(x, y)`: relative change of the film's mean luminance and",
              "absolute change of its mean chromaticity on converged renders — a bias that a reference render would show, where it exceeds the row NOISE FLOOR",
-             "(the default reading at another seed: what sampling noise alone does to these means; the gem's caustics make its mean the noisiest).  Read it as a checklist order: the rows with the largest converged change are the ones to verify first against the crates.", "",
+             "(the default reading at another seed: what sampling noise alone does to these means; the gem's caustics make its mean the noisiest).  An alternative that changes values but no path (curve interpolation, colour matching, blackbody, MIS weights, the uv axis) is compared at matched seeds on identical paths: its difference is exact, far below the noise floor of a single render; one that changes paths (cosine mapping, tangent frame, aperture) shows a difference of the size of the noise floor, i.e. no bias beyond it.  Read it as a checklist order: the rows with the largest converged change are the ones to verify first against the crates.", "",
              "| alternative reading | C1 L-inf | C1 RMSE | Cornell d mean Y | Cornell d(x, y) | gem d mean Y | HDRI d mean Y | HDRI d(x, y) | sun d mean Y |", "|---|---|---|---|---|---|---|---|---|"]
     rows = []
     for name, text in ALTERNATIVES + [("SEED2", "NOISE FLOOR: the default reading itself at another seed")]:
