@@ -83,6 +83,12 @@ inline void go(const LaunchCfg& c, K kernel, Args... args) { hipLaunchKernelGGL(
 #endif
 #define PT_SHADOW_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? (NL == 1 ? PT_SHADOW_SWEEP_WAVES : PT_SHADOW4_SWEEP_WAVES) : PT_WALK_WAVES)))
 
+// The lean form of k_shade (closed scenes: nearly every segment ends on a surface) reads the whole hit record at once instead of waiting for its
+// first word to say whether there is a hit (load_hit<EAGER>, pt_stages.h): -1.5 % of the kernel on C2.
+#ifndef PT_SHADE_EAGER
+#define PT_SHADE_EAGER true
+#endif
+
 enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_ACCUMULATE, ST_COUNT };
 
 // ------------------------------------------------------------------------------------------------ kernels
@@ -92,7 +98,8 @@ enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_ACCUMULATE, ST_COUNT };
 // materials, instances, top-level BVH, sweep table: the words every lane keeps re-reading), the mesh data stays in HBM/L2
 // — scenes whose meshes do not fit the LDS budget but whose core does (C4: 470 KB of monkey, 24 KB of core).
 #ifndef PT_EXP_LACKS
-#define PT_EXP_LACKS 0u   /* experiments: what every kernel of the build assumes the scene lacks */
+#define PT_EXP_LACKS 0u   /* register-pressure experiments in the build container only (tools/isa_pressure.py on one kernel): what that kernel is compiled to
+                             assume the scene lacks, whatever its template says.  Never for a library that renders: a scene holding the thing would be wrong. */
 #endif
 template <int USE_LDS, uint32_t LACKS = 0u>
 __device__ __forceinline__ SceneView stage_scene(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* tex, uint32_t* lds) {
@@ -116,6 +123,13 @@ __device__ __forceinline__ SceneView stage_scene(const uint32_t* __restrict__ bl
 }
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+// The lane's number computed where it stands (two instructions the compiler may not hoist): for a loop whose only use of threadIdx.x is the
+// item index of a round — the input register then dies at once instead of being spilled across the kernel (k_extend_parked: its one spill).
+__device__ __forceinline__ uint32_t fresh_lane_id() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 
 // ---- segmented queues -------------------------------------------------------------------------------------------
 // Every queue is cut into gridDim.x segments of `seg_cap` items; workgroup b owns segment b in every kernel of a pass:
@@ -237,9 +251,6 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
                 // (the path record first: its sixteen loads are in flight while the hit record's first word — which decides whether the rest
                 // is read at all — comes back; the other order leaves that latency exposed: k_shade 2506 -> 2893 us on C2)
                 pv = load_path<NL>(paths_in, i);
-#ifndef PT_SHADE_EAGER
-#define PT_SHADE_EAGER true   /* the lean form (closed scenes: nearly every segment ends on a surface) reads the whole hit record at once */
-#endif
                 hit = load_hit<PT_SHADE_EAGER && FORM == PT_SHADE_LEAN>(hits, i);
             }
             wants_item = shade_wants_item(s, rp, hit);
@@ -554,7 +565,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ uint32_t park_counts[kBlock / 64];
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = PT_UNIFORM(threadIdx.x >> 6);   // (a scalar: with fresh_lane_id below, threadIdx.x need not stay in a register across the rounds)
     uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap + wave * kWaveParkCap;  // field f of entry e at pk[f * kParkCap + e]
     uint32_t* park_count = &park_counts[wave];
     const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
@@ -569,7 +580,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
         else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, base + j, h); }
     };
     for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t j = r * blockDim.x + threadIdx.x;
+        const uint32_t j = r * blockDim.x + (wave << 6 | fresh_lane_id());
         if (j < n) {
             F3 o, d;
             ray_of(base + j, &o, &d);

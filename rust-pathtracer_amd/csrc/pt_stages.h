@@ -553,6 +553,10 @@ PT_HD void stage_shadow_ray(const SceneView& s, LambdaOf&& lambda_of, FactorOf&&
     bool hit = world_hit<TRAV, true>(s, o, d, &sh, bound, stop, light, bound);
     shadow_ray_contribution<NL>(s, lambda_of, factor_of, d, ENV && env, hit, sh, contribution);
 }
+// (PT_SHADOW_EAGER true: the pure sweep form reads a ray's origin and direction along with its factor — measured: k_shadow 3525 -> 3600 us on C2, not used)
+#ifndef PT_SHADOW_EAGER
+#define PT_SHADOW_EAGER false
+#endif
 // One light-sample item: L rays, summed in order, divided by L (pt.rs:349-392, 596)
 template <int NL, int TRAV = PT_TRAV_ANY, bool ENV = true>
 PT_HD void stage_shadow_item(const SceneView& s, uint32_t light_samples, const Queue& shadow, uint32_t item, float* energy, uint32_t energy_stride) {
@@ -563,9 +567,6 @@ PT_HD void stage_shadow_item(const SceneView& s, uint32_t light_samples, const Q
     auto lambda_of = [&](int k) { return NL == 1 ? lambda0 : qf(shadow, Layout<NL>::sh_lambda + (uint32_t)k, item); };
     for (uint32_t l = 0; l < light_samples; ++l) {
         ShadowRayT<NL> ray;
-#ifndef PT_SHADOW_EAGER
-#define PT_SHADOW_EAGER false  /* (true: the pure sweep form reads a ray's words at once — measured: k_shadow 3525 -> 3600 us on C2, not used) */
-#endif
         if (!load_shadow_ray<NL, PT_SHADOW_EAGER && TRAV == PT_TRAV_SWEEP>(shadow, item, l, &ray)) continue;
         float c[NL];
         // (hero wavelengths: the factors too are read again when the ray contributes, not held across its search)
