@@ -95,3 +95,19 @@ def test_command_line_renderer_dry_run(pkg):
         assert r.returncode == 1 and "couldn't read config.toml" in r.stderr
         r = subprocess.run([exe, "--bogus"], capture_output=True, text=True, cwd=d)
         assert r.returncode == 2
+
+
+def test_tuning_default_reads_the_environment_once(pkg, monkeypatch):
+    """pt_tuning_default (no device needed): the PT_AMD_* variables map onto the struct's fields; unset variables leave the defaults (0 / -1)."""
+    lib = pkg.api.Library(pkg.LIBRARY_PATH, "pt_")
+    for name in ("PT_AMD_BATCH", "PT_AMD_BLOCKS_PER_CU", "PT_AMD_NO_FUSE", "PT_AMD_PARK_DYNAMIC", "PT_AMD_MULTI_VIRTUAL", "PT_AMD_STAGE_TIMING", "PT_AMD_GENERAL_FORMS"):
+        monkeypatch.delenv(name, raising=False)
+    t = lib.tuning_default()
+    assert (t.flags, t.batch_slots, t.blocks_per_cu, t.park_blocks_per_cu, t.park_dynamic, t.shade_form, t.lds_all_limit, t.multi_virtual) == (0, 0, 0, 0, -1, 0, 0, 0)
+    assert list(t.reserved) == [0] * 8
+    monkeypatch.setenv("PT_AMD_BATCH", "4096"); monkeypatch.setenv("PT_AMD_BLOCKS_PER_CU", "8"); monkeypatch.setenv("PT_AMD_NO_FUSE", "1")
+    monkeypatch.setenv("PT_AMD_PARK_DYNAMIC", "0"); monkeypatch.setenv("PT_AMD_MULTI_VIRTUAL", "4"); monkeypatch.setenv("PT_AMD_STAGE_TIMING", "0")
+    monkeypatch.setenv("PT_AMD_GENERAL_FORMS", "1")
+    t = lib.tuning_default()
+    assert (t.batch_slots, t.blocks_per_cu, t.park_dynamic, t.multi_virtual) == (4096, 8, 0, 4)
+    assert t.flags == pkg.api.TUNE_NO_FUSE | pkg.api.TUNE_NO_STAGE_TIMING | pkg.api.TUNE_GENERAL_FORMS
