@@ -447,7 +447,7 @@ bool read_exr(const std::string& path, Image* out, std::string* error) {
     if (attr["compression"].size() < 1 || attr["dataWindow"].size() < 16) { *error = "EXR header attribute is too short"; return false; }
     if (channels.empty()) { *error = "EXR file without channels"; return false; }
     int compression = attr["compression"][0];
-    if (compression > 4) { *error = "EXR compression " + std::to_string(compression) + " is not supported (only none, RLE, ZIPS, ZIP, PIZ)"; return false; }
+    if (compression > 5) { *error = "EXR compression " + std::to_string(compression) + " is not supported (only none, RLE, ZIPS, ZIP, PIZ, PXR24)"; return false; }
     const uint8_t* dw = attr["dataWindow"].data();
     int x0 = (int)le32(dw), y0 = (int)le32(dw + 4), x1 = (int)le32(dw + 8), y1 = (int)le32(dw + 12);
     const int64_t W64 = (int64_t)x1 - x0 + 1, H64 = (int64_t)y1 - y0 + 1;
@@ -470,7 +470,7 @@ bool read_exr(const std::string& path, Image* out, std::string* error) {
         if (tile_w <= 0 || tile_h <= 0) { *error = "bad EXR tile size"; return false; }
         if ((t[8] & 0xf) != 0) { *error = "mip/rip-mapped EXR files are not supported"; return false; }
     }
-    int block_lines = compression == 3 ? 16 : compression == 4 ? 32 : 1;
+    int block_lines = compression == 3 || compression == 5 ? 16 : compression == 4 ? 32 : 1;
     std::vector<int> channel_types;
     for (auto& c : channels) channel_types.push_back(c.type);
     size_t blocks = tiled ? (size_t)((W + tile_w - 1) / tile_w) * ((H + tile_h - 1) / tile_h) : (size_t)(H + block_lines - 1) / block_lines;
@@ -497,7 +497,36 @@ bool read_exr(const std::string& path, Image* out, std::string* error) {
         if ((uint64_t)(src - d.data()) + size > d.size() || bw <= 0 || bh <= 0 || by < 0 || bx < 0 || bx + bw > W || by + bh > H) { *error = "bad EXR block"; return false; }
         size_t expect = pixel_bytes * (size_t)bw * bh;
         const uint8_t* data = src;
-        if (compression == 4 && size < expect) {
+        if (compression == 5 && size < expect) {
+            // PXR24 (ImfPxr24Compressor): zlib over, per scanline and channel, byte planes of the differences between consecutive samples —
+            // two planes for a half, four for an unsigned int, three for a float cut to its upper 24 bits (the one lossy step, the writer's)
+            size_t planes = 0;
+            for (int t : channel_types) planes += t == 1 ? 2 : t == 0 ? 4 : 3;
+            const size_t packed = planes * (size_t)bw * bh;
+            if (!inflate_all(src, size, &tmp, packed, error)) return false;
+            if (tmp.size() != packed) { *error = "EXR block has the wrong size"; return false; }
+            raw.resize(expect);
+            size_t in = 0, o = 0;
+            for (int y = 0; y < bh; ++y)
+                for (int t : channel_types) {
+                    const size_t n = (size_t)bw;
+                    uint32_t pixel = 0;
+                    const uint8_t* q = tmp.data() + in;
+                    if (t == 1) {
+                        for (size_t x = 0; x < n; ++x) { pixel += (uint32_t)q[x] << 8 | q[n + x]; raw[o++] = (uint8_t)pixel; raw[o++] = (uint8_t)(pixel >> 8); }
+                        in += 2 * n;
+                    } else if (t == 0) {
+                        for (size_t x = 0; x < n; ++x) { pixel += (uint32_t)q[x] << 24 | (uint32_t)q[n + x] << 16 | (uint32_t)q[2 * n + x] << 8 | q[3 * n + x];
+                                                         raw[o++] = (uint8_t)pixel; raw[o++] = (uint8_t)(pixel >> 8); raw[o++] = (uint8_t)(pixel >> 16); raw[o++] = (uint8_t)(pixel >> 24); }
+                        in += 4 * n;
+                    } else {
+                        for (size_t x = 0; x < n; ++x) { pixel += (uint32_t)q[x] << 24 | (uint32_t)q[n + x] << 16 | (uint32_t)q[2 * n + x] << 8;
+                                                         raw[o++] = (uint8_t)pixel; raw[o++] = (uint8_t)(pixel >> 8); raw[o++] = (uint8_t)(pixel >> 16); raw[o++] = (uint8_t)(pixel >> 24); }
+                        in += 3 * n;
+                    }
+                }
+            data = raw.data();
+        } else if (compression == 4 && size < expect) {
             if (!piz::decode_block(src, size, channel_types, bw, bh, &raw, error)) return false;
             if (raw.size() != expect) { *error = "EXR block has the wrong size"; return false; }
             data = raw.data();

@@ -285,6 +285,23 @@ def _write_test_images(tmp_path):
                     raw += row.astype(np.float16).tobytes() if n in half else row.astype(np.float32).tobytes()
             if compression == 0:
                 return raw
+            if compression == 5:   # PXR24: per scanline and channel, byte planes of sample differences (floats cut to 24 bits), zlib over all
+                packed = b""
+                for y in range(y0, y0 + bh):
+                    for n in names:
+                        row = img[y, x0:x0 + bw, slot[n]]
+                        if n in half:
+                            v = row.astype(np.float16).view(np.uint16).astype(np.uint32)
+                            d = (v - np.concatenate([[0], v[:-1]])) & 0xffff
+                            packed += (d >> 8).astype(np.uint8).tobytes() + (d & 0xff).astype(np.uint8).tobytes()
+                        else:
+                            bits = row.astype(np.float32).view(np.uint32)
+                            assert not (bits & 0xff).any(), "the test image must survive the cut to 24 bits"
+                            v = (bits >> 8).astype(np.uint32)
+                            d = (v - np.concatenate([[0], v[:-1]])) & 0xffffff
+                            packed += (d >> 16).astype(np.uint8).tobytes() + ((d >> 8) & 0xff).astype(np.uint8).tobytes() + (d & 0xff).astype(np.uint8).tobytes()
+                comp = zlib.compress(packed)
+                return comp if len(comp) < len(raw) else raw
             if compression == 4:   # PIZ: the test-side encoder (tests/piz_encode.py), channel planes of the block
                 import piz_encode
                 comp = piz_encode.block_from_rows([img[y0:y0 + bh, x0:x0 + bw, slot[n]].astype(np.float16 if n in half else np.float32) for n in names])
@@ -314,7 +331,7 @@ def _write_test_images(tmp_path):
                     d = block(tx * tiled[0], ty * tiled[1], bw, bh)
                     blocks.append(struct.pack("<4iI", tx, ty, 0, 0, len(d)) + d)
         else:
-            lines = 16 if compression == 3 else 32 if compression == 4 else 1
+            lines = 16 if compression in (3, 5) else 32 if compression == 4 else 1
             for y0 in range(0, hh, lines):
                 d = block(0, y0, ww, min(lines, hh - y0))
                 blocks.append(struct.pack("<iI", y0, len(d)) + d)
@@ -330,7 +347,8 @@ def _write_test_images(tmp_path):
     # PIZ (what a Poly-Haven-style HDRI uses): half channels in 32-line blocks with a remnant block, float channels (two 16-bit planes per
     # sample), tiles, and a noisy image wide enough for a block to hold more than 2^14 distinct values (the wavelet's modulo-2^16 form)
     exr_cases.update({"exr_piz": dict(compression=4, half=("R", "G", "B"), channels="BGR"), "exr_piz_float": dict(compression=4, half=("A",)),
-                      "exr_piz_tiled": dict(compression=4, half=("R", "G", "B", "A"), tiled=(16, 8))})
+                      "exr_piz_tiled": dict(compression=4, half=("R", "G", "B", "A"), tiled=(16, 8)),
+                      "exr_pxr24": dict(compression=5, half=("G", "A")), "exr_pxr24_tiled": dict(compression=5, half=("R",), channels="BGR", tiled=(8, 8))})
     for n, kw in exr_cases.items():
         exr(tmp_path / (n + ".exr"), img, **kw)
     noise = np.random.default_rng(9).random((40, 150, 4)).astype(np.float32) * 50.0
