@@ -476,7 +476,7 @@ def test_compare_tool_on_rendered_files(sfmod, pkg, engine, tmp_path):
     """ptcompare (src/bin/compare_exr.rs) on two EXR files written by ptcli: its statistics are those of pt_compare_films on
     the images read back, the RMSE mode writes the viridis PNG."""
     import subprocess
-    exe_dir = os.path.dirname(pkg.LIBRARY_PATH)
+    exe_dir = os.path.join(pkg.PACKAGE_DIR, "csrc")
     outs = []
     for seed in ("3", "4"):
         out = tmp_path / ("out" + seed)
@@ -504,7 +504,7 @@ def test_command_line_render_matches_the_library(sfmod, pkg, engine, tmp_path):
     """ptcli end to end on the GPU: config + scene TOML -> film, EXR, PNG; the raw film equals the one rendered through
     the Python front end with the same settings, bit for bit."""
     import subprocess
-    exe = os.path.join(os.path.dirname(pkg.LIBRARY_PATH), "ptcli")
+    exe = os.path.join(os.path.join(pkg.PACKAGE_DIR, "csrc"), "ptcli")
     out = tmp_path / "out"
     r = subprocess.run([exe, "--root", pkg.PACKAGE_DIR, "--config", "data/config_two_passes.toml", "--output-dir", str(out), "--seed", "5", "--write-film"],
                        capture_output=True, text=True, cwd=str(tmp_path))
