@@ -259,7 +259,11 @@ typedef struct pt_tuning {
     uint32_t lds_all_limit;       /* PT_AMD_LDS_ALL_LIMIT: largest blob staged whole, bytes; 0 = 24 KB */
     uint32_t multi_virtual;       /* PT_AMD_MULTI_VIRTUAL: pt_render_multi treats every device of the mask as this many (test mode:
                                      k host threads, streams and replicas per device, films summed on the device); 0 / 1 = off */
-    uint32_t reserved[8];         /* must be 0 */
+    uint32_t walk_evict_below;    /* PT_AMD_WALK_EVICT_BELOW: the parked kernels leave a resumed wave's mesh walks once fewer lanes than this are still
+                                     walking (the rays park again and go on in a later wave); 1 = never, at most 64; 0 = the default */
+    uint32_t walk_search_below;   /* PT_AMD_WALK_SEARCH_BELOW: a mesh walk's inner loop (box to box until the lane holds a leaf) ends once fewer lanes than
+                                     this are still searching while others hold a leaf; 1 = never, at most 64; 0 = the default */
+    uint32_t reserved[6];         /* must be 0 */
 } pt_tuning;
 /* The defaults, overridden by whatever PT_AMD_* variables the environment holds at the time of the call. */
 void pt_tuning_default(pt_tuning* tuning);

@@ -36,10 +36,12 @@
 #define PT_KEEP_BRANCH() asm volatile("" ::: "memory")   /* inside a rarely taken block: the compiler must not turn it into selects */
 #define PT_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
 #define PT_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* a value every lane of the wave holds */
+#define PT_WAVE_ACTIVE(host_value) ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)))  /* the lanes that execute this line */
 #else
 #define PT_KEEP_BRANCH()
 #define PT_WAVE_ANY(x) (x)
 #define PT_UNIFORM(x) (x)
+#define PT_WAVE_ACTIVE(host_value) (host_value)
 #endif
 
 // A loop the compiler must keep rolled (the per-wavelength loops of the hero variant: four inlined copies of a curve evaluation cost
@@ -755,7 +757,18 @@ PT_HD void sweep_state_init(SweepState& st, uint64_t hit) {
 }
 // Mesh::hit (src/geometry/mesh.rs:314-360) for one instance, against the running closest hit: the mesh half of
 // world_hit_walk on its own (same while-while loop, same filtered box test, same culling).
-PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, F3 d, float bound, int stop, SweepState& st) {
+//
+// `policy` (the parked kernels, whose waves are 64 walks; pt_tuning::walk_evict_below | walk_search_below << 8; 0 = the plain loop): a walk's length
+// varies by an order of magnitude between the rays of a wave, and so does the number of boxes between one leaf and the next.
+//  * Eviction (low byte E, needs `cursor`): after a triangle test, when fewer than E lanes of the wave are still walking, those lanes leave the walk
+//    with the node they would visit next in `*cursor` (returns true); the caller parks them again and they go on — from that node, with the closest
+//    hit they carry — in a later wave of 64, next to rays that are as far from done as they are.  `*cursor` on entry: where to go on (0 = a walk
+//    that has not begun).
+//  * Short searches (second byte X): the inner loop — every lane steps from box to box until it holds a leaf — ends once fewer than X lanes are
+//    still searching while others hold one: those test their triangles and search on, instead of waiting for the wave's longest search.
+// A ray's own sequence of tests is untouched by either.
+PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, F3 d, float bound, int stop, SweepState& st,
+                     uint32_t* cursor = nullptr, uint32_t policy = 0u) {
     const uint32_t NONE = 0xffffffffu;
     const uint32_t flags = bu(s, PT_HDR_FLAGS);
     const bool cull = (flags & PT_FLAG_NO_CULL) == 0;
@@ -772,7 +785,8 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
     // again with the group boxes below: C3 k_shadow_parked 5730 us through the grouped sweep, 5635 through the walk)
     // The mesh sweep reads its leaf list with wave-uniform addresses: every lane that takes it must be in the same mesh.  A table
     // with two walked meshes can resume lanes of both in one wave — those waves walk (same result, lane by lane).
-    if (leaf_off != 0u && !(bound < PT_INF) && !(flags & (PT_FLAG_NO_SWEEP | PT_FLAG_NO_MESH_SWEEP)) && !PT_WAVE_ANY(mesh != PT_UNIFORM(mesh))) {
+    const uint32_t begin_at = cursor != nullptr ? *cursor : 0u;   // (a ray that was evicted from a walk goes on walking — and so does its whole wave)
+    if (leaf_off != 0u && !(bound < PT_INF) && !(flags & (PT_FLAG_NO_SWEEP | PT_FLAG_NO_MESH_SWEEP)) && !PT_WAVE_ANY(mesh != PT_UNIFORM(mesh) || begin_at != 0u)) {
         // mesh sweep: the leaf-box sweep of world_hit_sweep applied to this mesh, 64 leaves (in pre-order) at a time, each
         // chunk culled by the closest hit the chunks before it left — the same leaves in the same order as the walk below
         const uint32_t leaf_count = PT_UNIFORM(bu(s, mesh + PT_MESH_LEAF_COUNT));
@@ -836,9 +850,9 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                     PT_STAT(box_exact);
                     if (aabb_hit_exact(mf4(s, e), mf4(s, e + 4), lo, ld, &entry)) hit |= 1u << k;
                 }
-                if (triangles(hit, first)) return;
+                if (triangles(hit, first)) return false;
             }
-            return;
+            return false;
         }
         for (uint32_t first = 0; first < leaf_count; first += 64u) {
             const uint32_t chunk = leaf_count - first < 64u ? leaf_count - first : 64u;
@@ -861,36 +875,50 @@ PT_HD void mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                 PT_STAT(box_exact);
                 if (aabb_hit_exact(mf4(s, e), mf4(s, e + 4), lo, ld, &entry)) hit |= 1ull << k;
             }
-            if (triangles(hit, first)) return;
+            if (triangles(hit, first)) return false;
         }
-        return;
+        return false;
     }
-    uint32_t i = 0;
+    uint32_t i = begin_at;
     const bool walk_quick = cr.fast && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f;
+    PT_STAT_EVENT(7 + stop);   // (tools/walk_stats.py: a walk begins; 5 = a node's box test, 6 = a triangle test)
+#if defined(PT_PARKED_EXP) && (PT_PARKED_EXP & 8)
+    i = node_count;   // (measurement, tools/phase_costs_parked.sh: a walk's prologue and what follows it, without its loop)
+#endif
+    const uint32_t evict_below = policy & 0xffu, search_below = (policy >> 8) & 0xffu;
     for (;;) {
         uint32_t pending = NONE;
+        const uint32_t walking = search_below != 0u ? PT_WAVE_ACTIVE(2u) : 0u;   // (the emulation's lane: "one of two", so every search is cut short)
         while (i < node_count && pending == NONE) {
+            PT_STAT_EVENT(5);
             F4 a = mf4(s, node_off + i * PT_NODE_WORDS), b = mf4(s, node_off + i * PT_NODE_WORDS + 4);
             uint32_t exit_i = PT_NODE_EXIT(pt_f2u(a.w)), shape = pt_f2u(b.w);
             float entry;
             bool box = aabb_hit_node(a, b, cr, walk_quick, &entry) && !(cull && beyond(entry, limit, cr.base));
             if (shape == PT_NODE_INNER) i = box ? i + 1 : exit_i;
             else { i = exit_i; if (box) pending = shape; }
+            if (search_below != 0u) { const uint32_t searching = PT_WAVE_ACTIVE(1u); if (searching < search_below && searching < walking) break; }
         }
-        if (pending == NONE) break;
-        uint32_t t = tri_off + pending * PT_TRI_WORDS;
-        F4 q0 = mf4(s, t), q1 = mf4(s, t + 4), q2 = mf4(s, t + 8);
-        TriHit th;
-        if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
-            st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th;
-            limit = __builtin_fminf(st.closest, bound);
-            if (stop == PT_STOP_ANY) { st.hit = 0; break; }
-            if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
-                uint32_t im = bu(s, inst + PT_INST_MATERIAL);
-                if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) { st.hit = 0; break; }  // something opaque in front of every light
+        bool over = false;
+        if (pending != NONE) {
+            PT_STAT_EVENT(6);
+            uint32_t t = tri_off + pending * PT_TRI_WORDS;
+            F4 q0 = mf4(s, t), q1 = mf4(s, t + 4), q2 = mf4(s, t + 8);
+            TriHit th;
+            if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
+                st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th;
+                limit = __builtin_fminf(st.closest, bound);
+                if (stop == PT_STOP_ANY) { st.hit = 0; over = true; }
+                else if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
+                    uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+                    if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) { st.hit = 0; over = true; }  // something opaque in front of every light
+                }
             }
         }
+        if (over || i >= node_count) break;
+        if (evict_below != 0u && PT_WAVE_ACTIVE(0u) < evict_below) { *cursor = i; return true; }
     }
+    return false;
 }
 // Phase 3: the primitive tests of the set bits in pre-order (ties are broken by that order, as in world_hit_walk).  With
 // `park_at_walked` the loop returns true when the next bit is a walked mesh instance, leaving the bit set: the caller
@@ -959,12 +987,15 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
     }
     return false;
 }
-// A parked lane: walk the mesh of its lowest set bit, then carry on with phase 3 (it may park again at another walked mesh).
-PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f) {
+// A parked lane: walk the mesh of its lowest set bit, then carry on with phase 3 (it may park again at another walked mesh).  With
+// a `policy` that evicts, the walk may be left unfinished (mesh_walk): true then too, the bit still set and `*cursor` where the walk goes on.
+PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f,
+                        uint32_t* cursor = nullptr, uint32_t policy = 0u) {
     const uint32_t k = ctz64(st.hit);
     const F4 be = bf4(s, bu(s, PT_HDR_SWEEP_BITS_OFF) + k * PT_SWEEP_BIT_WORDS);
-    st.hit &= st.hit - 1;
-    mesh_walk(s, pt_f2u(be.x), pt_f2u(be.w) >> 16, o, d, bound, stop, st);
+    if (mesh_walk(s, pt_f2u(be.x), pt_f2u(be.w) >> 16, o, d, bound, stop, st, cursor, policy)) return true;
+    if (cursor != nullptr) *cursor = 0u;
+    st.hit &= st.hit - 1;   // (zero already after an early stop)
     if (st.hit == 0) return false;
     const TriRay wtr = tri_ray_prepare(o, d);
     return sweep_run<true>(s, o, d, wtr, bound, stop, st, true, known_inst, known_t);
@@ -1156,6 +1187,14 @@ PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound
     const TriRay wtr = tri_ray_prepare(o, d);
 #if !defined(__HIP_DEVICE_COMPILE__)
     if ((bu(s, PT_HDR_FLAGS) & (PT_FLAG_REPLAY | PT_FLAG_SWEEP_WALKS)) == PT_FLAG_REPLAY) { sweep_run_replay(s, o, d, wtr, st); return sweep_finish(s, o, d, st, out); }
+#endif
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if ((bu(s, PT_HDR_FLAGS) & (PT_FLAG_REPLAY | PT_FLAG_SWEEP_WALKS)) == (PT_FLAG_REPLAY | PT_FLAG_SWEEP_WALKS)) {
+        // the parked kernels' protocol, lane by lane: park at a walked mesh, resume, and leave the walk at every chance (mesh_walk's eviction)
+        uint32_t cursor = 0u;
+        bool parked = sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, true, known_inst, known_t);
+        while (parked) parked = sweep_resume(s, o, d, bound, stop, st, known_inst, known_t, &cursor, 0x201u);
+    } else
 #endif
     sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, false, known_inst, known_t);
     if (LIGHT_ONLY && st.best_inst != 0xffffffffu && !sweep_best_is_light(s, st)) { out->valid = true; out->material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); return true; }

@@ -264,6 +264,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     LaunchCfg cfg{grid, lds_bytes, stream, mode};
     cfg.dyn_grid = dyn_grid < grid ? dyn_grid : grid;
     cfg.lacks = sc->lacks;
+    cfg.walk_policy = (tn.walk_evict_below ? tn.walk_evict_below : kWalkEvictBelow) | (tn.walk_search_below ? tn.walk_search_below : kWalkSearchBelow) << 8;
     const SceneArgs sargs{sc->d_blob, sc->blob_words, sc->d_tex};
     // light samples can pick the environment only if env_sampling_probability > 0: otherwise k_shade is the form without that branch
     float env_prob; std::memcpy(&env_prob, &sc->host.blob[PT_HDR_ENV_PROB], sizeof env_prob);
@@ -457,6 +458,8 @@ void pt_tuning_default(pt_tuning* t) {
     t->shade_form = env_u32("PT_AMD_SHADE_FORM", 0);
     t->lds_all_limit = env_u32("PT_AMD_LDS_ALL_LIMIT", 0);
     t->multi_virtual = env_u32("PT_AMD_MULTI_VIRTUAL", 0);
+    t->walk_evict_below = env_u32("PT_AMD_WALK_EVICT_BELOW", 0);
+    t->walk_search_below = env_u32("PT_AMD_WALK_SEARCH_BELOW", 0);
 }
 
 pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
@@ -468,8 +471,8 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
 pt_status pt_scene_create_tuned(const pt_scene_desc* desc, const pt_tuning* tuning, pt_scene** out) {
     if (!desc || !out || !tuning) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     for (uint32_t r : tuning->reserved) if (r != 0) return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning::reserved must be 0");
-    if (tuning->shade_form > 2 || tuning->park_dynamic < -1 || tuning->park_dynamic > 1 || tuning->multi_virtual > 64)
-        return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning: shade_form in 0..2, park_dynamic in -1..1, multi_virtual <= 64");
+    if (tuning->shade_form > 2 || tuning->park_dynamic < -1 || tuning->park_dynamic > 1 || tuning->multi_virtual > 64 || tuning->walk_evict_below > 64 || tuning->walk_search_below > 64)
+        return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning: shade_form in 0..2, park_dynamic in -1..1, multi_virtual, walk_evict_below, walk_search_below <= 64");
     pt_status st = ensure_device();
     if (st != PT_OK) return st;
     pt_scene* sc = new pt_scene();

@@ -26,10 +26,10 @@ void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, Queue path
     if (form == PT_FORM_PARKED && c.unit_counter) {
         LaunchCfg d = c; d.grid = c.dyn_grid;
 #define K_EXT_PARKED_DYN(M) k_extend_parked_dyn<M>
-        if (c.lds_mode == PT_LDS_ALL) go(d, K_EXT_PARKED_DYN(PT_LDS_ALL), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter);
-        else if (c.lds_mode == PT_LDS_CORE) go(d, K_EXT_PARKED_DYN(PT_LDS_CORE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter);
-        else go(d, K_EXT_PARKED_DYN(PT_LDS_NONE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter);
-    } else if (form == PT_FORM_PARKED) PT_BY_MODE(K_EXT_PARKED, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park);
+        if (c.lds_mode == PT_LDS_ALL) go(d, K_EXT_PARKED_DYN(PT_LDS_ALL), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
+        else if (c.lds_mode == PT_LDS_CORE) go(d, K_EXT_PARKED_DYN(PT_LDS_CORE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
+        else go(d, K_EXT_PARKED_DYN(PT_LDS_NONE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
+    } else if (form == PT_FORM_PARKED) PT_BY_MODE(K_EXT_PARKED, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy);
     else if (form == PT_FORM_POOLED) PT_GO(k_extend_pooled<PT_LDS_ALL>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
     else if (form == PT_FORM_SWEEP && (c.lacks & PT_SCENE_NO_XF)) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_SWEEP, PT_SCENE_NO_XF>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
     else if (form == PT_FORM_SWEEP) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);

@@ -28,16 +28,16 @@ void launch_shadow(const LaunchCfg& c, int form, int nl, bool env, const SceneAr
 #endif
     if (form == PT_FORM_PARKED && c.unit_counter) {
         LaunchCfg d = c; d.grid = c.dyn_grid;
-#define PT_DYN_ARGS sc.blob, sc.blob_words, sc.tex, light_samples, shadow, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter
+#define PT_DYN_ARGS sc.blob, sc.blob_words, sc.tex, light_samples, shadow, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy
 #define PT_DYN_BY_MODE(NL) do { if (c.lds_mode == PT_LDS_ALL) go(d, k_shadow_parked_dyn<PT_LDS_ALL, NL>, PT_DYN_ARGS); else if (c.lds_mode == PT_LDS_CORE) go(d, k_shadow_parked_dyn<PT_LDS_CORE, NL>, PT_DYN_ARGS); \
                                 else go(d, k_shadow_parked_dyn<PT_LDS_NONE, NL>, PT_DYN_ARGS); } while (0)
         LaunchCfg plain = c; plain.lds_bytes = 0;
         if (hero) { PT_DYN_BY_MODE(4); go(plain, k_shadow_sum<4>, light_samples, shadow, energy, energy_stride, seg_cap, count_in); }
         else { PT_DYN_BY_MODE(1); go(plain, k_shadow_sum<1>, light_samples, shadow, energy, energy_stride, seg_cap, count_in); }
     } else if (form == PT_FORM_PARKED) {
-        if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park);
-        else if (c.lacks & PT_SCENE_NO_LIGHTS) PT_BY_MODE(K_SH_PARKED1E, PT_ARGS, park);   // (an environment is the scene's only emitter)
-        else PT_BY_MODE(K_SH_PARKED1, PT_ARGS, park);
+        if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park, c.walk_policy);
+        else if (c.lacks & PT_SCENE_NO_LIGHTS) PT_BY_MODE(K_SH_PARKED1E, PT_ARGS, park, c.walk_policy);   // (an environment is the scene's only emitter)
+        else PT_BY_MODE(K_SH_PARKED1, PT_ARGS, park, c.walk_policy);
     }
     else if (form == PT_FORM_POOLED) {
         if (env) { if (hero) PT_GO((k_shadow_pooled<PT_LDS_ALL, 4, true>), PT_ARGS); else PT_GO((k_shadow_pooled<PT_LDS_ALL, 1, true>), PT_ARGS); }

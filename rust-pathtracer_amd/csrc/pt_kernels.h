@@ -518,18 +518,19 @@ __global__ void __launch_bounds__(kBlock) PT_POOL_OCC k_shadow_exp(const uint32_
 // the ones that do are scattered over the waves, so walking the mesh in line would leave a wave waiting for a handful of
 // lanes.  Instead a lane that reaches a walked-mesh bit *parks* its sweep state in the workgroup's scratch region, and
 // whenever a wave has 64 rays parked (and at the end) it resumes them together: a full wave, every lane in a mesh walk.  Nothing about a ray's own sequence of tests changes (same leaves, same order, same running closest hit).
-enum { PK_ITEM, PK_HIT_LO, PK_HIT_HI, PK_CLOSEST, PK_BEST_INST, PK_BEST_TRIW, PK_T, PK_B0, PK_B1, PK_B2, PK_RAY, PK_BOUND, PK_KIND };
-__device__ __forceinline__ void park_store(uint32_t* pk, uint32_t e, uint32_t item, const SweepState& st, uint32_t ray, float bound, uint32_t kind) {
+enum { PK_ITEM, PK_HIT_LO, PK_HIT_HI, PK_CLOSEST, PK_BEST_INST, PK_BEST_TRIW, PK_T, PK_B0, PK_B1, PK_B2, PK_RAY, PK_BOUND, PK_KIND, PK_CURSOR };
+static_assert(PK_CURSOR < kParkFields, "a parked entry's fields");
+__device__ __forceinline__ void park_store(uint32_t* pk, uint32_t e, uint32_t item, const SweepState& st, uint32_t ray, float bound, uint32_t kind, uint32_t cursor) {
     pk[PK_ITEM * kParkCap + e] = item; pk[PK_HIT_LO * kParkCap + e] = (uint32_t)st.hit; pk[PK_HIT_HI * kParkCap + e] = (uint32_t)(st.hit >> 32);
     pk[PK_CLOSEST * kParkCap + e] = pt_f2u(st.closest); pk[PK_BEST_INST * kParkCap + e] = st.best_inst; pk[PK_BEST_TRIW * kParkCap + e] = st.best_triw;
     pk[PK_T * kParkCap + e] = pt_f2u(st.bh.t); pk[PK_B0 * kParkCap + e] = pt_f2u(st.bh.b0); pk[PK_B1 * kParkCap + e] = pt_f2u(st.bh.b1); pk[PK_B2 * kParkCap + e] = pt_f2u(st.bh.b2);
-    pk[PK_RAY * kParkCap + e] = ray; pk[PK_BOUND * kParkCap + e] = pt_f2u(bound); pk[PK_KIND * kParkCap + e] = kind;
+    pk[PK_RAY * kParkCap + e] = ray; pk[PK_BOUND * kParkCap + e] = pt_f2u(bound); pk[PK_KIND * kParkCap + e] = kind; pk[PK_CURSOR * kParkCap + e] = cursor;
 }
-__device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32_t* item, SweepState* st, uint32_t* ray, float* bound, uint32_t* kind) {
+__device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32_t* item, SweepState* st, uint32_t* ray, float* bound, uint32_t* kind, uint32_t* cursor) {
     *item = pk[PK_ITEM * kParkCap + e]; st->hit = (uint64_t)pk[PK_HIT_LO * kParkCap + e] | (uint64_t)pk[PK_HIT_HI * kParkCap + e] << 32;
     st->closest = pt_u2f(pk[PK_CLOSEST * kParkCap + e]); st->best_inst = pk[PK_BEST_INST * kParkCap + e]; st->best_triw = pk[PK_BEST_TRIW * kParkCap + e];
     st->bh.t = pt_u2f(pk[PK_T * kParkCap + e]); st->bh.b0 = pt_u2f(pk[PK_B0 * kParkCap + e]); st->bh.b1 = pt_u2f(pk[PK_B1 * kParkCap + e]); st->bh.b2 = pt_u2f(pk[PK_B2 * kParkCap + e]);
-    *ray = pk[PK_RAY * kParkCap + e]; *bound = pt_u2f(pk[PK_BOUND * kParkCap + e]); *kind = pk[PK_KIND * kParkCap + e];
+    *ray = pk[PK_RAY * kParkCap + e]; *bound = pt_u2f(pk[PK_BOUND * kParkCap + e]); *kind = pk[PK_KIND * kParkCap + e]; *cursor = pk[PK_CURSOR * kParkCap + e];
 }
 // The resume loop shared by both kernels, per WAVE: every wave of the workgroup parks into its own quarter of the scratch
 // region (128 entries: fewer than 64 left over + at most 64 new per step) and resumes 64 parked rays at a time — full
@@ -541,8 +542,11 @@ __device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32
 #endif
 constexpr uint32_t kWaveParkCap = kParkCap / (kBlock / 64);
 constexpr uint32_t kLiveCap = 64u * PT_MAX_LIGHT_SAMPLES + 64u;   // a wave's list of live light-sample rays: fewer than 64 left over + the rays of 64 items
+// `walk_policy` (mesh_walk's: pt_tuning::walk_evict_below | walk_search_below << 8): a resumed wave's walks are left by its last lanes once
+// fewer than walk_evict_below are still walking — they park again with their cursor and go on in a later drain.  Not in the very last drain
+// of a wave, which has nobody left to wait for.
 template <typename Resume>
-__device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, bool last, Resume&& resume) {
+__device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, bool last, uint32_t walk_policy, Resume&& resume) {
     const uint32_t lane = lane_id();
     for (;;) {
         __threadfence_block();             // this wave's parked entries are visible to its other lanes
@@ -550,18 +554,18 @@ __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, b
         if (!(cnt >= 64u || (last && cnt > 0u))) break;
         const uint32_t take = cnt < 64u ? cnt : 64u, first = cnt - take;
         const bool mine = lane < take;
-        uint32_t item = 0, ray = 0, kind = 0; float bound = PT_INF; SweepState st;
-        if (mine) park_load(pk, first + lane, &item, &st, &ray, &bound, &kind);
+        uint32_t item = 0, ray = 0, kind = 0, cursor = 0; float bound = PT_INF; SweepState st;
+        if (mine) park_load(pk, first + lane, &item, &st, &ray, &bound, &kind, &cursor);
         __threadfence_block();             // entries are in registers before any lane parks again into these slots
         if (lane == 0) *park_count = first;
-        if (mine) resume(item, st, ray, bound, kind);
+        if (mine) resume(item, st, ray, bound, kind, cursor, last && first == 0u ? walk_policy & ~0xffu : walk_policy);
     }
 }
 
 template <int USE_LDS>
 __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                      Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
-                                                                     uint32_t* __restrict__ park_all) {
+                                                                     uint32_t* __restrict__ park_all, uint32_t walk_policy) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ uint32_t park_counts[kBlock / 64];
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
@@ -575,8 +579,8 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
         *o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
         *d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
     };
-    auto settle = [&](uint32_t j, F3 o, F3 d, const SweepState& st, bool parked) {
-        if (parked) park_store(pk, atomicAdd(park_count, 1u), j, st, 0u, PT_INF, 0u);
+    auto settle = [&](uint32_t j, F3 o, F3 d, const SweepState& st, bool parked, uint32_t cursor) {
+        if (parked) park_store(pk, atomicAdd(park_count, 1u), j, st, 0u, PT_INF, 0u, cursor);
         else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, base + j, h); }
     };
     for (uint32_t r = 0; r < rounds; ++r) {
@@ -587,12 +591,13 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
             SweepState st;
             sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
             const TriRay wtr = tri_ray_prepare(o, d);
-            settle(j, o, d, st, sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true));
+            settle(j, o, d, st, sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true), 0u);
         }
-        park_drain(pk, park_count, r + 1 == rounds, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t) {
+        park_drain(pk, park_count, r + 1 == rounds, walk_policy, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t, uint32_t cursor, uint32_t policy) {
             F3 o, d;
             ray_of(base + j2, &o, &d);
-            settle(j2, o, d, st, sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st));
+            const bool again = sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy);
+            settle(j2, o, d, st, again, cursor);
         });
     }
 }
@@ -602,7 +607,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
 template <int USE_LDS, int NL, uint32_t LACKS = 0u>
 __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                      uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
-                                                                     uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ park_all) {
+                                                                     uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ park_all, uint32_t walk_policy) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ uint32_t park_counts[kBlock / 64];
     SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);
@@ -615,8 +620,8 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
     if (lane_id() == 0) *park_count = 0;
     // a finished ray leaves its contribution where its factor was; the item's rays are summed in order at the end (an item's
     // rays are parked and resumed by the wave that owns the item, so that sum needs no workgroup barrier either)
-    auto settle = [&](uint32_t j, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked, uint32_t light) {
-        if (parked) { park_store(pk, atomicAdd(park_count, 1u), j, st, l, bound, (env ? 1u : 0u) | (light + 1u) << 1); return; }
+    auto settle = [&](uint32_t j, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked, uint32_t light, uint32_t cursor) {
+        if (parked) { park_store(pk, atomicAdd(park_count, 1u), j, st, l, bound, (env ? 1u : 0u) | (light + 1u) << 1, cursor); return; }
         const uint32_t item = base + j;
         float lambda[NL], c[NL];
         for (int k = 0; k < NL; ++k) lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item);
@@ -630,13 +635,14 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
         for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
     };
     // (the parked `kind` word: bit 0 = an environment sample, the rest = 1 + the light whose hit bounds the search, sweep_run's known_inst)
-    auto resume_parked = [&](uint32_t j2, SweepState& st, uint32_t l2, float bound, uint32_t kind) {
+    auto resume_parked = [&](uint32_t j2, SweepState& st, uint32_t l2, float bound, uint32_t kind, uint32_t cursor, uint32_t policy) {
         ShadowRayT<NL> pr;
         load_shadow_ray<NL>(shadow, base + j2, l2, &pr);
         const bool env = kOnlyEnv || (kind & 1u) != 0u;
         // a light ray searches with the early stop whenever it has a finite bound (shadow_light_bound)
         const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
-        settle(j2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound), (kind >> 1) - 1u);
+        const bool again = sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound, &cursor, policy);
+        settle(j2, l2, pr, env, bound, st, again, (kind >> 1) - 1u, cursor);
     };
     // The rays that are traced at all — a light sample below the horizon of its surface, or with a zero factor, is not: four in five of
     // C4's — are listed per wave (item and sample number) and traced 64 at a time, so that a step of the wave is 64 live rays and parks at
@@ -680,11 +686,11 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
                 const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
                 const bool parks = sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound);
                 if ((PT_PARKED_EXP & 4) && parks) { qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, 0.0f); continue; }   // (measurement: parked rays dropped)
-                settle(j, l, ray, env, bound, st, parks, light);
+                settle(j, l, ray, env, bound, st, parks, light, 0u);
             }
         }
         __builtin_amdgcn_wave_barrier();
-        park_drain(pk, park_count, r == rounds && live_count == 0u, resume_parked);
+        park_drain(pk, park_count, r == rounds && live_count == 0u, walk_policy, resume_parked);
     }
     __threadfence_block();
     for (uint32_t r = 0; r < rounds; ++r) {  // pt.rs:349-392, 596: the item's rays summed in order, divided by L
@@ -723,7 +729,7 @@ __device__ __forceinline__ bool next_unit(uint32_t* __restrict__ counter, uint32
 template <int USE_LDS>
 __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked_dyn(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                          Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
-                                                                         uint32_t* __restrict__ park_all, uint32_t n_segments, uint32_t* __restrict__ unit_counter) {
+                                                                         uint32_t* __restrict__ park_all, uint32_t n_segments, uint32_t* __restrict__ unit_counter, uint32_t walk_policy) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ uint32_t park_counts[kBlock / 64];
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
@@ -736,14 +742,15 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked_dyn
         *o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
         *d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
     };
-    auto settle = [&](uint32_t i, F3 o, F3 d, const SweepState& st, bool parked) {   // `i`: the item's index in the queue
-        if (parked) park_store(pk, atomicAdd(park_count, 1u), i, st, 0u, PT_INF, 0u);
+    auto settle = [&](uint32_t i, F3 o, F3 d, const SweepState& st, bool parked, uint32_t cursor) {   // `i`: the item's index in the queue
+        if (parked) park_store(pk, atomicAdd(park_count, 1u), i, st, 0u, PT_INF, 0u, cursor);
         else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, i, h); }
     };
-    auto resume = [&](uint32_t i2, SweepState& st, uint32_t, float, uint32_t) {
+    auto resume = [&](uint32_t i2, SweepState& st, uint32_t, float, uint32_t, uint32_t cursor, uint32_t policy) {
         F3 o, d;
         ray_of(i2, &o, &d);
-        settle(i2, o, d, st, sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st));
+        const bool again = sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy);
+        settle(i2, o, d, st, again, cursor);
     };
     // one loop, one drain site (the resume code is the bulk of the kernel: two inlined copies cost 25 KB of instruction cache): each turn
     // takes the next 64 items of the current unit — or a new unit, or nothing when the counter has run out — and drains; the last turn
@@ -759,11 +766,11 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked_dyn
             SweepState st;
             sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
             const TriRay wtr = tri_ray_prepare(o, d);
-            settle(i, o, d, st, sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true));
+            settle(i, o, d, st, sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true), 0u);
         }
         off += 64u;
         const bool last = !more && off >= cnt;
-        park_drain(pk, park_count, last, resume);
+        park_drain(pk, park_count, last, walk_policy, resume);
         if (last) break;
     }
 }
@@ -772,7 +779,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked_dyn
 template <int USE_LDS, int NL>
 __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked_dyn(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                          uint32_t light_samples, Queue shadow, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
-                                                                         uint32_t* __restrict__ park_all, uint32_t n_segments, uint32_t* __restrict__ unit_counter) {
+                                                                         uint32_t* __restrict__ park_all, uint32_t n_segments, uint32_t* __restrict__ unit_counter, uint32_t walk_policy) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ uint32_t park_counts[kBlock / 64];
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
@@ -781,8 +788,8 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked_dyn(const 
     uint32_t* park_count = &park_counts[wave];
     if (lane == 0) *park_count = 0;
     const uint32_t units_per_seg = (seg_cap + kUnitItems - 1) / kUnitItems, total_units = n_segments * units_per_seg;
-    auto settle = [&](uint32_t item, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked, uint32_t light) {
-        if (parked) { park_store(pk, atomicAdd(park_count, 1u), item, st, l, bound, (env ? 1u : 0u) | (light + 1u) << 1); return; }
+    auto settle = [&](uint32_t item, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked, uint32_t light, uint32_t cursor) {
+        if (parked) { park_store(pk, atomicAdd(park_count, 1u), item, st, l, bound, (env ? 1u : 0u) | (light + 1u) << 1, cursor); return; }
         float lambda[NL], c[NL];
         for (int k = 0; k < NL; ++k) lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item);
         Hit sh; sh.valid = false;
@@ -793,12 +800,13 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked_dyn(const 
         shadow_ray_contribution<NL>(s, [&](int k) { return pl_get<NL>(lambda, k); }, ray, env, hit, sh, c);
         for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
     };
-    auto resume = [&](uint32_t item2, SweepState& st, uint32_t l2, float bound, uint32_t kind) {   // (`kind`: see k_shadow_parked)
+    auto resume = [&](uint32_t item2, SweepState& st, uint32_t l2, float bound, uint32_t kind, uint32_t cursor, uint32_t policy) {   // (`kind`: see k_shadow_parked)
         ShadowRayT<NL> pr;
         load_shadow_ray<NL>(shadow, item2, l2, &pr);
         const bool env = (kind & 1u) != 0u;
         const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
-        settle(item2, l2, pr, env, bound, st, sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound), (kind >> 1) - 1u);
+        const bool again = sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound, &cursor, policy);
+        settle(item2, l2, pr, env, bound, st, again, (kind >> 1) - 1u, cursor);
     };
     uint32_t first = 0, cnt = 0, off = 0;   // (one loop, one drain site: see k_extend_parked_dyn)
     bool more = true;
@@ -820,10 +828,10 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked_dyn(const 
                     SweepState st;
                     sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
                     const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
-                    settle(item, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound), light);
+                    settle(item, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound), light, 0u);
                 }
             }
-            park_drain(pk, park_count, last_turn && l + 1 == light_samples, resume);
+            park_drain(pk, park_count, last_turn && l + 1 == light_samples, walk_policy, resume);
         }
         if (last_turn) break;
     }

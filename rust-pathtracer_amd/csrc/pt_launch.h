@@ -18,12 +18,14 @@ constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // the most LDS a staged blo
 // 752.  C2's 14 KB blob staged whole: 1519; its 7 KB core alone: 1089 (the sweep reads the triangles of the two boxes for every ray).
 constexpr uint32_t kLdsAllLimitBytes = 24 * 1024;
 constexpr uint32_t kParkCap = 512, kParkFields = 16;
+constexpr uint32_t kWalkEvictBelow = 32, kWalkSearchBelow = 16;   // pt_tuning::walk_evict_below's and walk_search_below's defaults
 enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_MEDIUM_DROPS, BS_FIELDS };  // per-workgroup statistics (Profile counters)
 uint32_t pool_lds_bytes();  // static LDS of the pooled traversal kernels, on top of the staged blob
 
 struct LaunchCfg { int grid; uint32_t lds_bytes; hipStream_t stream; int lds_mode;
                    int dyn_grid = 0; uint32_t* unit_counter = nullptr;   // parked kernels with dynamic units: persistent workgroups and this launch's counter (zeroed)
                    uint32_t lacks = 0;    // PT_SCENE_* bits of what the scene does not hold: the pure sweep forms and the lean k_shade have forms without it
+                   uint32_t walk_policy = 0;   // parked kernels: mesh_walk's policy word (pt_tuning::walk_evict_below | walk_search_below << 8)
                    bool fuse = false; };  // k_shade traces its own segments (pure sweep scenes, lean form, no transforms): no k_extend launch, no hit queue
 struct SceneArgs { const uint32_t* blob; uint32_t blob_words; const float* tex; };
 

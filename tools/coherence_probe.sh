@@ -2,7 +2,7 @@
 # Runs on the GPU box: tools/coherence_probe.py under rocprofv3, then the duration of every k_probe_intersect launch.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/coherence; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/coherence_probe.py "$@" > $OUT/probe.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/coherence_probe.py "$@" > $OUT/probe.log 2>&1
 cat $OUT/probe.log | grep -v "^W2\|rocprof" | tail -8
 python3 - <<PY
 import csv, glob

@@ -6,7 +6,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/${1:-gpurun_out/lds_conflicts}; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
 export PT_AMD_LIBRARY=$ROOT/variants/exp.so PT_AMD_NO_FUSE=1
 for e in 6 4 0; do
-  PT_AMD_EXP=$e rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAVES --kernel-trace --output-format csv -d $OUT/exp_$e -- python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-seconds 0 --spp-per-step 240 > $OUT/bench_$e.log 2>&1
+  PT_AMD_EXP=$e timeout 900 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAVES --kernel-trace --output-format csv -d $OUT/exp_$e -- python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-seconds 0 --spp-per-step 240 > $OUT/bench_$e.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections

@@ -5,7 +5,7 @@ OUT=$ROOT/gpurun_out/pmc_ab
 mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
 for mode in fast exact; do
   if [ $mode = exact ]; then export PT_AMD_EXACT_SLAB=1 PT_AMD_NO_CULL=1; else unset PT_AMD_EXACT_SLAB PT_AMD_NO_CULL; fi
-  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d "$OUT/$mode" -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --cpu-seconds 0 > "$OUT/$mode.log" 2>&1
+  timeout 900 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d "$OUT/$mode" -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --cpu-seconds 0 > "$OUT/$mode.log" 2>&1
 done
 cd "$ROOT"; python3 - <<'PY'
 import csv, glob, collections, re

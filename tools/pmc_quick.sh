@@ -2,7 +2,7 @@
 # Runs on the GPU box: a few PMC counters of a bench workload, summed / averaged per kernel.  usage: tools/pmc_quick.sh <out dir> "<counters>" <bench args...>
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/$1; CTRS=$2; shift 2
 mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 "$@" > $OUT/bench.log 2>&1
+timeout 600 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 "$@" > $OUT/bench.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
