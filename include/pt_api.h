@@ -247,7 +247,9 @@ enum {
     PT_TUNE_GENERAL_FORMS = 1u << 9,   /* PT_AMD_GENERAL_FORMS: no kernel forms specialised by what the scene lacks (transforms) */
     PT_TUNE_NO_FUSE = 1u << 10,        /* PT_AMD_NO_FUSE: k_extend + k_shade as two launches even where the fused form (k_shade tracing its own segments) exists */
     PT_TUNE_NO_STAGE_TIMING = 1u << 11,/* PT_AMD_STAGE_TIMING=0: no HIP events around the launches (pt_profile::kernel_seconds stay 0) */
-    PT_TUNE_MULTI_RCCL = 1u << 12      /* PT_AMD_MULTI_RCCL: pt_render_multi takes the RCCL reduce even for one device */
+    PT_TUNE_MULTI_RCCL = 1u << 12,     /* PT_AMD_MULTI_RCCL: pt_render_multi takes the RCCL reduce even for one device */
+    PT_TUNE_NO_AXIS_SCAN = 1u << 13    /* PT_AMD_NO_AXIS_SCAN: the parked kernels walk a ray that is parallel to an axis of its mesh like any other (by default the
+                                          whole wave scans the mesh's leaves for it: such a ray passes most boxes, AABB::hit ignoring the axes its direction is zero along) */
 };
 typedef struct pt_tuning {
     uint32_t flags;               /* PT_TUNE_* */

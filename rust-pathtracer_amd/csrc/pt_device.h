@@ -37,11 +37,17 @@
 #define PT_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
 #define PT_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* a value every lane of the wave holds */
 #define PT_WAVE_ACTIVE(host_value) ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)))  /* the lanes that execute this line */
+#define PT_WAVE_BALLOT(x) ((unsigned long long)__builtin_amdgcn_ballot_w64(x))
+#define PT_WAVE_RANK(mask) ((uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)((mask) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mask), 0u)))  /* set bits of `mask` below this lane */
+#define PT_WAVE_READ(x, lane) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (int)(lane)))   /* lane's value of a 32-bit x, in every lane (a scalar) */
 #else
 #define PT_KEEP_BRANCH()
 #define PT_WAVE_ANY(x) (x)
 #define PT_UNIFORM(x) (x)
 #define PT_WAVE_ACTIVE(host_value) (host_value)
+#define PT_WAVE_BALLOT(x) ((x) ? 1ull : 0ull)
+#define PT_WAVE_RANK(mask) 0u
+#define PT_WAVE_READ(x, lane) ((uint32_t)(x))
 #endif
 
 // A loop the compiler must keep rolled (the per-wavelength loops of the hero variant: four inlined copies of a curve evaluation cost
@@ -755,6 +761,63 @@ struct SweepState { uint64_t hit; float closest; uint32_t best_inst, best_triw; 
 PT_HD void sweep_state_init(SweepState& st, uint64_t hit) {
     st.hit = hit; st.closest = PT_INF; st.best_inst = 0xffffffffu; st.best_triw = 0u; st.bh.t = 0.0f; st.bh.b0 = st.bh.b1 = st.bh.b2 = 0.0f;
 }
+// One ray — every argument the same in all the lanes of `lanes`, the caller's wave — against all the leaves of a mesh, the lanes side by
+// side.  For the rays a walk is worst at: AABB::hit ignores an axis along which the direction is zero (aabb.rs:41-45: its slab becomes
+// [0, inf) wherever the origin lies), so a ray parallel to an axis passes every box that overlaps it in the other axes only — an environment
+// sample at the pole of the map, (0, 0, 1), passes eight in ten of the monkey's 8375 boxes and tests half its triangles: 8000 dependent steps
+// of one lane, 3-6 ms, while a wave lives 0.5 ms on average (tools/wave_timeline.py: they were the last third of C4's k_shadow_parked and
+// four fifths of its deep bounces).  Same leaves, same order, same arithmetic as the walk, 64 nodes per step: a leaf is tested iff its own box
+// passes (the slab test is monotone: then every ancestor passes; the walk's culling by the closest hit only skips leaves whose triangle
+// could not be accepted), its triangle against the unbounded interval, and the acceptances are replayed in node order against the running
+// closest hit with the walk's own comparison (triangle_outside split in two, as in the pooled sweep) and its early stops.
+PT_HD void mesh_scan(const SceneView& s, uint32_t inst, uint32_t node_off, uint32_t node_count, uint32_t tri_off, const RayPrep& cr, const TriRay& tr, float bound, int stop,
+                     unsigned long long lanes, float* closest, uint32_t* best_triw, bool* stopped) {
+    const uint32_t width = (uint32_t)__builtin_popcountll(lanes), rank = PT_WAVE_RANK(lanes);
+    for (uint32_t base = 0; base < node_count; base += width) {
+        const uint32_t k = base + rank;
+        float ts = 0.0f, det = 0.0f, t = 0.0f;   // (det == 0: this lane holds no candidate)
+        uint32_t triw = 0u;
+        if (k < node_count) {
+            const F4 a = mf4(s, node_off + k * PT_NODE_WORDS), b = mf4(s, node_off + k * PT_NODE_WORDS + 4);
+            const uint32_t shape = pt_f2u(b.w);
+            float entry;
+            if (shape != PT_NODE_INNER && aabb_hit(a, b, cr, &entry)) {
+                triw = tri_off + shape * PT_TRI_WORDS;
+                const F4 q0 = mf4(s, triw), q1 = mf4(s, triw + 4), q2 = mf4(s, triw + 8);
+                TriEdges g;
+                if (triangle_edges(tri_shuffle(sub(f3(q0.x, q0.y, q0.z), tr.o), tr.kz), tri_shuffle(sub(f3(q1.x, q1.y, q1.z), tr.o), tr.kz), tri_shuffle(sub(f3(q2.x, q2.y, q2.z), tr.o), tr.kz), tr, &g)
+                    && !triangle_outside(g.ts, g.det, 0.0f, PT_INF)) { ts = g.ts; det = g.det; t = g.ts * (1.0f / g.det); }
+            }
+        }
+        unsigned long long m = PT_WAVE_BALLOT(det != 0.0f);
+        while (m != 0ull) {
+            const uint32_t j = ctz64(m);
+            m &= m - 1ull;
+            const float tsj = pt_u2f(PT_WAVE_READ(pt_f2u(ts), j)), detj = pt_u2f(PT_WAVE_READ(pt_f2u(det), j));
+            if (detj < 0.0f ? tsj < *closest * detj : tsj > *closest * detj) continue;   // (beyond the closest hit so far: triangle_outside's second half)
+            *closest = pt_u2f(PT_WAVE_READ(pt_f2u(t), j));
+            *best_triw = PT_WAVE_READ(triw, j);
+            if (stop == PT_STOP_ANY) { *stopped = true; return; }
+            if (stop == PT_STOP_NONLIGHT && *closest < bound) {
+                const uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+                if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : mu(s, *best_triw + 3u)) != PT_TAG_LIGHT) { *stopped = true; return; }
+            }
+        }
+    }
+}
+
+#if defined(PT_TIMELINE_RAYS)
+// (measurement build, tools/wave_timeline.py: the rays whose walk took more than 1500 box tests)
+static __device__ float g_tl_rays[1 + 4096 * 12];
+#endif
+#if defined(PT_TIMELINE_RAYS) && defined(__HIP_DEVICE_COMPILE__)
+#define PT_TL_STEP() (++tl_steps)
+#define PT_TL_DONE() do { if (tl_steps > 1500u) { const uint32_t e = atomicAdd(reinterpret_cast<uint32_t*>(g_tl_rays), 1u); if (e < 4096u) { float* r = g_tl_rays + 1 + e * 12; \
+    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = bound; r[7] = (float)stop; r[8] = (float)tl_steps; r[9] = lo.x; r[10] = ld.x; r[11] = st.closest; } } } while (0)
+#else
+#define PT_TL_STEP()
+#define PT_TL_DONE()
+#endif
 // Mesh::hit (src/geometry/mesh.rs:314-360) for one instance, against the running closest hit: the mesh half of
 // world_hit_walk on its own (same while-while loop, same filtered box test, same culling).
 //
@@ -766,7 +829,9 @@ PT_HD void sweep_state_init(SweepState& st, uint64_t hit) {
 //    that has not begun).
 //  * Short searches (second byte X): the inner loop — every lane steps from box to box until it holds a leaf — ends once fewer than X lanes are
 //    still searching while others hold one: those test their triangles and search on, instead of waiting for the wave's longest search.
-// A ray's own sequence of tests is untouched by either.
+//  * Axis rays (PT_WALK_SCAN_AXIS): a ray with a zero direction component is not walked but scanned by the whole wave (mesh_scan).
+// A ray's own sequence of tests is untouched by the first two; the third tests the same leaves side by side and replays their order.
+#define PT_WALK_SCAN_AXIS 0x10000u
 PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, F3 d, float bound, int stop, SweepState& st,
                      uint32_t* cursor = nullptr, uint32_t policy = 0u) {
     const uint32_t NONE = 0xffffffffu;
@@ -881,16 +946,54 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
     }
     uint32_t i = begin_at;
     const bool walk_quick = cr.fast && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f;
+    if (policy & PT_WALK_SCAN_AXIS) {
+        // rays parallel to an axis of the mesh: one after the other, the whole wave on each (mesh_scan)
+        const bool axis = begin_at == 0u && (ld.x == 0.0f || ld.y == 0.0f || ld.z == 0.0f);
+        unsigned long long am = PT_WAVE_BALLOT(axis);
+        if (am != 0ull) {
+            PT_KEEP_BRANCH();
+            const unsigned long long lanes = PT_WAVE_BALLOT(true);
+            const uint32_t me = PT_WAVE_RANK(~0ull);
+            while (am != 0ull) {
+                const uint32_t L = ctz64(am);
+                am &= am - 1ull;
+                auto rd = [&](float x) { return pt_u2f(PT_WAVE_READ(pt_f2u(x), L)); };
+                RayPrep ucr; TriRay utr;
+                ucr.o = f3(rd(cr.o.x), rd(cr.o.y), rd(cr.o.z)); ucr.d = f3(rd(cr.d.x), rd(cr.d.y), rd(cr.d.z)); ucr.r = f3(rd(cr.r.x), rd(cr.r.y), rd(cr.r.z));
+                ucr.nor = f3(rd(cr.nor.x), rd(cr.nor.y), rd(cr.nor.z)); ucr.base = rd(cr.base); ucr.fast = PT_WAVE_READ(cr.fast ? 1u : 0u, L) != 0u;
+                utr.o = ucr.o; utr.kz = PT_WAVE_READ(tr.kz, L); utr.sx = rd(tr.sx); utr.sy = rd(tr.sy); utr.sz = rd(tr.sz); utr.os = f3(rd(tr.os.x), rd(tr.os.y), rd(tr.os.z));
+                const uint32_t uinst = PT_WAVE_READ(inst, L), umesh = bu(s, uinst + PT_INST_MESH);
+                float closest = rd(st.closest);
+                uint32_t best = 0xffffffffu;
+                bool stopped = false;
+                mesh_scan(s, uinst, bu(s, umesh + PT_MESH_NODE_OFF), bu(s, umesh + PT_MESH_NODE_COUNT), bu(s, umesh + PT_MESH_TRI_OFF), ucr, utr, rd(bound),
+                          (int)PT_WAVE_READ((uint32_t)stop, L), lanes, &closest, &best, &stopped);
+                if (me == L && best != 0xffffffffu) {
+                    // the winner's record: its test again (the numbers do not depend on the interval)
+                    const F4 q0 = mf4(s, best), q1 = mf4(s, best + 4), q2 = mf4(s, best + 8);
+                    TriHit th;
+                    triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, PT_INF, &th);
+                    st.closest = th.t; st.best_inst = inst_id; st.best_triw = best; st.bh = th;
+                    if (stopped) st.hit = 0;
+                }
+            }
+            if (axis) return false;
+        }
+    }
     PT_STAT_EVENT(7 + stop);   // (tools/walk_stats.py: a walk begins; 5 = a node's box test, 6 = a triangle test)
 #if defined(PT_PARKED_EXP) && (PT_PARKED_EXP & 8)
     i = node_count;   // (measurement, tools/phase_costs_parked.sh: a walk's prologue and what follows it, without its loop)
 #endif
     const uint32_t evict_below = policy & 0xffu, search_below = (policy >> 8) & 0xffu;
+#if defined(PT_TIMELINE_RAYS) && defined(__HIP_DEVICE_COMPILE__)
+    uint32_t tl_steps = 0;
+#endif
     for (;;) {
         uint32_t pending = NONE;
         const uint32_t walking = search_below != 0u ? PT_WAVE_ACTIVE(2u) : 0u;   // (the emulation's lane: "one of two", so every search is cut short)
         while (i < node_count && pending == NONE) {
             PT_STAT_EVENT(5);
+            PT_TL_STEP();
             F4 a = mf4(s, node_off + i * PT_NODE_WORDS), b = mf4(s, node_off + i * PT_NODE_WORDS + 4);
             uint32_t exit_i = PT_NODE_EXIT(pt_f2u(a.w)), shape = pt_f2u(b.w);
             float entry;
@@ -916,8 +1019,9 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
             }
         }
         if (over || i >= node_count) break;
-        if (evict_below != 0u && PT_WAVE_ACTIVE(0u) < evict_below) { *cursor = i; return true; }
+        if (evict_below != 0u && PT_WAVE_ACTIVE(0u) < evict_below) { *cursor = i; PT_TL_DONE(); return true; }
     }
+    PT_TL_DONE();
     return false;
 }
 // Phase 3: the primitive tests of the set bits in pre-order (ties are broken by that order, as in world_hit_walk).  With
@@ -1193,7 +1297,7 @@ PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound
         // the parked kernels' protocol, lane by lane: park at a walked mesh, resume, and leave the walk at every chance (mesh_walk's eviction)
         uint32_t cursor = 0u;
         bool parked = sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, true, known_inst, known_t);
-        while (parked) parked = sweep_resume(s, o, d, bound, stop, st, known_inst, known_t, &cursor, 0x201u);
+        while (parked) parked = sweep_resume(s, o, d, bound, stop, st, known_inst, known_t, &cursor, 0x201u | PT_WALK_SCAN_AXIS);
     } else
 #endif
     sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, false, known_inst, known_t);

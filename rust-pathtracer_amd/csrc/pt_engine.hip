@@ -264,7 +264,8 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     LaunchCfg cfg{grid, lds_bytes, stream, mode};
     cfg.dyn_grid = dyn_grid < grid ? dyn_grid : grid;
     cfg.lacks = sc->lacks;
-    cfg.walk_policy = (tn.walk_evict_below ? tn.walk_evict_below : kWalkEvictBelow) | (tn.walk_search_below ? tn.walk_search_below : kWalkSearchBelow) << 8;
+    cfg.walk_policy = (tn.walk_evict_below ? tn.walk_evict_below : kWalkEvictBelow) | (tn.walk_search_below ? tn.walk_search_below : kWalkSearchBelow) << 8
+                    | ((tn.flags & PT_TUNE_NO_AXIS_SCAN) ? 0u : PT_WALK_SCAN_AXIS);
     const SceneArgs sargs{sc->d_blob, sc->blob_words, sc->d_tex};
     // light samples can pick the environment only if env_sampling_probability > 0: otherwise k_shade is the form without that branch
     float env_prob; std::memcpy(&env_prob, &sc->host.blob[PT_HDR_ENV_PROB], sizeof env_prob);
@@ -448,7 +449,7 @@ void pt_tuning_default(pt_tuning* t) {
     const struct { const char* name; uint32_t bit; } flags[] = {
         {"PT_AMD_NO_LDS", PT_TUNE_NO_LDS}, {"PT_AMD_NO_CORE_LDS", PT_TUNE_NO_CORE_LDS}, {"PT_AMD_NO_PARK", PT_TUNE_NO_PARK}, {"PT_AMD_POOL", PT_TUNE_POOL},
         {"PT_AMD_EXACT_SLAB", PT_TUNE_EXACT_SLAB}, {"PT_AMD_NO_CULL", PT_TUNE_NO_CULL}, {"PT_AMD_NO_SWEEP", PT_TUNE_NO_SWEEP}, {"PT_AMD_NO_MESH_SWEEP", PT_TUNE_NO_MESH_SWEEP},
-        {"PT_AMD_NO_KNOWN_LIGHT", PT_TUNE_NO_KNOWN_LIGHT}, {"PT_AMD_GENERAL_FORMS", PT_TUNE_GENERAL_FORMS}, {"PT_AMD_NO_FUSE", PT_TUNE_NO_FUSE}, {"PT_AMD_MULTI_RCCL", PT_TUNE_MULTI_RCCL}};
+        {"PT_AMD_NO_KNOWN_LIGHT", PT_TUNE_NO_KNOWN_LIGHT}, {"PT_AMD_GENERAL_FORMS", PT_TUNE_GENERAL_FORMS}, {"PT_AMD_NO_FUSE", PT_TUNE_NO_FUSE}, {"PT_AMD_MULTI_RCCL", PT_TUNE_MULTI_RCCL}, {"PT_AMD_NO_AXIS_SCAN", PT_TUNE_NO_AXIS_SCAN}};
     for (const auto& f : flags) if (env_u32(f.name, 0)) t->flags |= f.bit;
     if (env_u32("PT_AMD_STAGE_TIMING", 1) == 0) t->flags |= PT_TUNE_NO_STAGE_TIMING;
     t->batch_slots = env_u32("PT_AMD_BATCH", 0);

@@ -1,5 +1,8 @@
 // pt_kern_shadow.hip — the light-sample kernels (k_shadow in its traversal forms) and their launcher.
 #include <cstdlib>
+#ifdef PT_TIMELINE
+#define PT_TIMELINE_RAYS   // (measurement build: pt_device.h records the long walks of this family's kernels)
+#endif
 #include "pt_kernels.h"
 
 namespace ptk {
@@ -38,6 +41,9 @@ void launch_shadow(const LaunchCfg& c, int form, int nl, bool env, const SceneAr
         if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park, c.walk_policy);
         else if (c.lacks & PT_SCENE_NO_LIGHTS) PT_BY_MODE(K_SH_PARKED1E, PT_ARGS, park, c.walk_policy);   // (an environment is the scene's only emitter)
         else PT_BY_MODE(K_SH_PARKED1, PT_ARGS, park, c.walk_policy);
+#ifdef PT_TIMELINE
+        hipLaunchKernelGGL(k_tl_bump, dim3(1), dim3(1), 0, c.stream);
+#endif
     }
     else if (form == PT_FORM_POOLED) {
         if (env) { if (hero) PT_GO((k_shadow_pooled<PT_LDS_ALL, 4, true>), PT_ARGS); else PT_GO((k_shadow_pooled<PT_LDS_ALL, 1, true>), PT_ARGS); }
@@ -69,5 +75,21 @@ hipError_t allow_lds_shadow(uint32_t bytes) {
     allow(reinterpret_cast<const void*>(k_shadow_pooled<PT_LDS_ALL, 1, true>)); allow(reinterpret_cast<const void*>(k_shadow_pooled<PT_LDS_ALL, 4, true>));
     return worst;
 }
+
+#ifdef PT_TIMELINE
+// (measurement build: the wave records of the launches so far, and the launch counter back to zero)
+extern "C" int pt_debug_timeline(unsigned long long* out, size_t bytes, uint32_t* launches) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(launches, HIP_SYMBOL(g_tl_launch), sizeof(uint32_t)) != hipSuccess) return 2;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl), bytes < sizeof(g_tl) ? bytes : sizeof(g_tl)) != hipSuccess) return 3;
+    const uint32_t zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tl_launch), &zero, sizeof(zero)) != hipSuccess) return 4;
+    if (bytes > sizeof(g_tl) && hipMemcpyFromSymbol(reinterpret_cast<char*>(out) + sizeof(g_tl), HIP_SYMBOL(ptd::g_tl_rays), sizeof(ptd::g_tl_rays)) != hipSuccess) return 6;
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(ptd::g_tl_rays)) != hipSuccess || hipMemset(p, 0, sizeof(ptd::g_tl_rays)) != hipSuccess) return 7;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tl)) != hipSuccess || hipMemset(p, 0, sizeof(g_tl)) != hipSuccess) return 5;
+    return 0;
+}
+#endif
 
 }  // namespace ptk

@@ -545,6 +545,14 @@ constexpr uint32_t kLiveCap = 64u * PT_MAX_LIGHT_SAMPLES + 64u;   // a wave's li
 // `walk_policy` (mesh_walk's: pt_tuning::walk_evict_below | walk_search_below << 8): a resumed wave's walks are left by its last lanes once
 // fewer than walk_evict_below are still walking — they park again with their cursor and go on in a later drain.  Not in the very last drain
 // of a wave, which has nobody left to wait for.
+#ifdef PT_TIMELINE
+// (measurement build, tools/wave_timeline.py: when every wave of k_shadow_parked began and ended, how many items its segment held and how many
+// parked rays it resumed — one record per launch, workgroup and wave)
+constexpr uint32_t kTlLaunches = 32, kTlBlocks = 16384;
+static __device__ unsigned long long g_tl[kTlLaunches][kTlBlocks][4][4];
+static __device__ uint32_t g_tl_launch;
+static __global__ void k_tl_bump() { g_tl_launch = g_tl_launch + 1u; }
+#endif
 template <typename Resume>
 __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, bool last, uint32_t walk_policy, Resume&& resume) {
     const uint32_t lane = lane_id();
@@ -635,7 +643,14 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
         for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
     };
     // (the parked `kind` word: bit 0 = an environment sample, the rest = 1 + the light whose hit bounds the search, sweep_run's known_inst)
+#ifdef PT_TIMELINE
+    const unsigned long long tl0 = wall_clock64();
+    uint32_t tl_resumed = 0;
+#endif
     auto resume_parked = [&](uint32_t j2, SweepState& st, uint32_t l2, float bound, uint32_t kind, uint32_t cursor, uint32_t policy) {
+#ifdef PT_TIMELINE
+        ++tl_resumed;
+#endif
         ShadowRayT<NL> pr;
         load_shadow_ray<NL>(shadow, base + j2, l2, &pr);
         const bool env = kOnlyEnv || (kind & 1u) != 0u;
@@ -692,6 +707,13 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
         __builtin_amdgcn_wave_barrier();
         park_drain(pk, park_count, r == rounds && live_count == 0u, walk_policy, resume_parked);
     }
+#ifdef PT_TIMELINE
+    if (g_tl_launch < kTlLaunches && blockIdx.x < kTlBlocks) {
+        unsigned long long* rec = g_tl[g_tl_launch][blockIdx.x][wave];
+        if (lane_id() == 0) { rec[0] = tl0; rec[1] = wall_clock64(); rec[2] = n; }
+        atomicAdd(&rec[3], (unsigned long long)tl_resumed);
+    }
+#endif
     __threadfence_block();
     for (uint32_t r = 0; r < rounds; ++r) {  // pt.rs:349-392, 596: the item's rays summed in order, divided by L
         const uint32_t j = r * blockDim.x + threadIdx.x;
