@@ -832,13 +832,52 @@ static __device__ float g_tl_rays[1 + 4096 * 12];
 //  * Axis rays (PT_WALK_SCAN_AXIS): a ray with a zero direction component is not walked but scanned by the whole wave (mesh_scan).
 // A ray's own sequence of tests is untouched by the first two; the third tests the same leaves side by side and replays their order.
 #define PT_WALK_SCAN_AXIS 0x10000u
+// `alive` (the parked kernels' last, partly filled drains): a lane without a ray of its own comes along — with the instance of one that has — to
+// take its share of the scans, and leaves before the walk.
 PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, F3 d, float bound, int stop, SweepState& st,
-                     uint32_t* cursor = nullptr, uint32_t policy = 0u) {
+                     uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true) {
     const uint32_t NONE = 0xffffffffu;
     const uint32_t flags = bu(s, PT_HDR_FLAGS);
     const bool cull = (flags & PT_FLAG_NO_CULL) == 0;
     F3 lo, ld;
     instance_local_ray(s, inst, o, d, &lo, &ld);
+    const uint32_t begin_at = cursor != nullptr ? *cursor : 0u;   // (a ray that was evicted from a walk goes on walking — and so does its whole wave)
+    if (policy & PT_WALK_SCAN_AXIS) {
+        // rays parallel to an axis of the mesh: one after the other, the whole wave on each (mesh_scan).  Before this lane's own constants
+        // are made: the scan works on the broadcast ray's, and the two sets need not be held at once.
+        const bool axis = alive && begin_at == 0u && (ld.x == 0.0f || ld.y == 0.0f || ld.z == 0.0f);
+        unsigned long long am = PT_WAVE_BALLOT(axis);
+        if (am != 0ull) {
+            PT_KEEP_BRANCH();
+            const unsigned long long lanes = PT_WAVE_BALLOT(true);
+            const uint32_t me = PT_WAVE_RANK(~0ull);
+            while (am != 0ull) {
+                const uint32_t L = ctz64(am);
+                am &= am - 1ull;
+                auto rd = [&](float x) { return pt_u2f(PT_WAVE_READ(pt_f2u(x), L)); };
+                const F3 ulo = f3(rd(lo.x), rd(lo.y), rd(lo.z)), uld = f3(rd(ld.x), rd(ld.y), rd(ld.z));
+                RayPrep ucr = ray_prepare(ulo, uld);
+                if (flags & PT_FLAG_EXACT_SLAB) ucr.fast = false;
+                const TriRay utr = tri_ray_prepare(ulo, uld);
+                const uint32_t uinst = PT_WAVE_READ(inst, L), umesh = bu(s, uinst + PT_INST_MESH);
+                float closest = rd(st.closest);
+                uint32_t best = 0xffffffffu;
+                bool stopped = false;
+                mesh_scan(s, uinst, bu(s, umesh + PT_MESH_NODE_OFF), bu(s, umesh + PT_MESH_NODE_COUNT), bu(s, umesh + PT_MESH_TRI_OFF), ucr, utr, rd(bound),
+                          (int)PT_WAVE_READ((uint32_t)stop, L), lanes, &closest, &best, &stopped);
+                if (me == L && best != 0xffffffffu) {
+                    // the winner's record: its test again (the numbers do not depend on the interval)
+                    const F4 q0 = mf4(s, best), q1 = mf4(s, best + 4), q2 = mf4(s, best + 8);
+                    TriHit th;
+                    triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), utr, 0.0f, PT_INF, &th);
+                    st.closest = th.t; st.best_inst = inst_id; st.best_triw = best; st.bh = th;
+                    if (stopped) st.hit = 0;
+                }
+            }
+            if (axis) return false;
+        }
+    }
+    if (!alive) return false;
     RayPrep cr = ray_prepare(lo, ld);
     if (flags & PT_FLAG_EXACT_SLAB) cr.fast = false;
     const TriRay tr = tri_ray_prepare(lo, ld);
@@ -850,7 +889,6 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
     // again with the group boxes below: C3 k_shadow_parked 5730 us through the grouped sweep, 5635 through the walk)
     // The mesh sweep reads its leaf list with wave-uniform addresses: every lane that takes it must be in the same mesh.  A table
     // with two walked meshes can resume lanes of both in one wave — those waves walk (same result, lane by lane).
-    const uint32_t begin_at = cursor != nullptr ? *cursor : 0u;   // (a ray that was evicted from a walk goes on walking — and so does its whole wave)
     if (leaf_off != 0u && !(bound < PT_INF) && !(flags & (PT_FLAG_NO_SWEEP | PT_FLAG_NO_MESH_SWEEP)) && !PT_WAVE_ANY(mesh != PT_UNIFORM(mesh) || begin_at != 0u)) {
         // mesh sweep: the leaf-box sweep of world_hit_sweep applied to this mesh, 64 leaves (in pre-order) at a time, each
         // chunk culled by the closest hit the chunks before it left — the same leaves in the same order as the walk below
@@ -946,45 +984,12 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
     }
     uint32_t i = begin_at;
     const bool walk_quick = cr.fast && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f;
-    if (policy & PT_WALK_SCAN_AXIS) {
-        // rays parallel to an axis of the mesh: one after the other, the whole wave on each (mesh_scan)
-        const bool axis = begin_at == 0u && (ld.x == 0.0f || ld.y == 0.0f || ld.z == 0.0f);
-        unsigned long long am = PT_WAVE_BALLOT(axis);
-        if (am != 0ull) {
-            PT_KEEP_BRANCH();
-            const unsigned long long lanes = PT_WAVE_BALLOT(true);
-            const uint32_t me = PT_WAVE_RANK(~0ull);
-            while (am != 0ull) {
-                const uint32_t L = ctz64(am);
-                am &= am - 1ull;
-                auto rd = [&](float x) { return pt_u2f(PT_WAVE_READ(pt_f2u(x), L)); };
-                RayPrep ucr; TriRay utr;
-                ucr.o = f3(rd(cr.o.x), rd(cr.o.y), rd(cr.o.z)); ucr.d = f3(rd(cr.d.x), rd(cr.d.y), rd(cr.d.z)); ucr.r = f3(rd(cr.r.x), rd(cr.r.y), rd(cr.r.z));
-                ucr.nor = f3(rd(cr.nor.x), rd(cr.nor.y), rd(cr.nor.z)); ucr.base = rd(cr.base); ucr.fast = PT_WAVE_READ(cr.fast ? 1u : 0u, L) != 0u;
-                utr.o = ucr.o; utr.kz = PT_WAVE_READ(tr.kz, L); utr.sx = rd(tr.sx); utr.sy = rd(tr.sy); utr.sz = rd(tr.sz); utr.os = f3(rd(tr.os.x), rd(tr.os.y), rd(tr.os.z));
-                const uint32_t uinst = PT_WAVE_READ(inst, L), umesh = bu(s, uinst + PT_INST_MESH);
-                float closest = rd(st.closest);
-                uint32_t best = 0xffffffffu;
-                bool stopped = false;
-                mesh_scan(s, uinst, bu(s, umesh + PT_MESH_NODE_OFF), bu(s, umesh + PT_MESH_NODE_COUNT), bu(s, umesh + PT_MESH_TRI_OFF), ucr, utr, rd(bound),
-                          (int)PT_WAVE_READ((uint32_t)stop, L), lanes, &closest, &best, &stopped);
-                if (me == L && best != 0xffffffffu) {
-                    // the winner's record: its test again (the numbers do not depend on the interval)
-                    const F4 q0 = mf4(s, best), q1 = mf4(s, best + 4), q2 = mf4(s, best + 8);
-                    TriHit th;
-                    triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, PT_INF, &th);
-                    st.closest = th.t; st.best_inst = inst_id; st.best_triw = best; st.bh = th;
-                    if (stopped) st.hit = 0;
-                }
-            }
-            if (axis) return false;
-        }
-    }
     PT_STAT_EVENT(7 + stop);   // (tools/walk_stats.py: a walk begins; 5 = a node's box test, 6 = a triangle test)
 #if defined(PT_PARKED_EXP) && (PT_PARKED_EXP & 8)
     i = node_count;   // (measurement, tools/phase_costs_parked.sh: a walk's prologue and what follows it, without its loop)
 #endif
     const uint32_t evict_below = policy & 0xffu, search_below = (policy >> 8) & 0xffu;
+    bool evicted = false;
 #if defined(PT_TIMELINE_RAYS) && defined(__HIP_DEVICE_COMPILE__)
     uint32_t tl_steps = 0;
 #endif
@@ -1019,10 +1024,11 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
             }
         }
         if (over || i >= node_count) break;
-        if (evict_below != 0u && PT_WAVE_ACTIVE(0u) < evict_below) { *cursor = i; PT_TL_DONE(); return true; }
+        if (evict_below != 0u && PT_WAVE_ACTIVE(0u) < evict_below) { evicted = true; break; }
     }
     PT_TL_DONE();
-    return false;
+    if (evicted) *cursor = i;
+    return evicted;
 }
 // Phase 3: the primitive tests of the set bits in pre-order (ties are broken by that order, as in world_hit_walk).  With
 // `park_at_walked` the loop returns true when the next bit is a walked mesh instance, leaving the bit set: the caller
@@ -1094,10 +1100,13 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
 // A parked lane: walk the mesh of its lowest set bit, then carry on with phase 3 (it may park again at another walked mesh).  With
 // a `policy` that evicts, the walk may be left unfinished (mesh_walk): true then too, the bit still set and `*cursor` where the walk goes on.
 PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f,
-                        uint32_t* cursor = nullptr, uint32_t policy = 0u) {
-    const uint32_t k = ctz64(st.hit);
+                        uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true) {
+    const uint32_t k = alive ? ctz64(st.hit) : 0u;
     const F4 be = bf4(s, bu(s, PT_HDR_SWEEP_BITS_OFF) + k * PT_SWEEP_BIT_WORDS);
-    if (mesh_walk(s, pt_f2u(be.x), pt_f2u(be.w) >> 16, o, d, bound, stop, st, cursor, policy)) return true;
+    uint32_t inst = pt_f2u(be.x);
+    if (!alive) inst = PT_WAVE_READ(inst, ctz64(PT_WAVE_BALLOT(alive)));   // (mesh_walk: a lane that only helps; some lane of the wave is alive)
+    if (mesh_walk(s, inst, pt_f2u(be.w) >> 16, o, d, bound, stop, st, cursor, policy, alive)) return true;
+    if (!alive) return false;
     if (cursor != nullptr) *cursor = 0u;
     st.hit &= st.hit - 1;   // (zero already after an early stop)
     if (st.hit == 0) return false;

@@ -29,7 +29,7 @@ void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, Queue path
         if (c.lds_mode == PT_LDS_ALL) go(d, K_EXT_PARKED_DYN(PT_LDS_ALL), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
         else if (c.lds_mode == PT_LDS_CORE) go(d, K_EXT_PARKED_DYN(PT_LDS_CORE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
         else go(d, K_EXT_PARKED_DYN(PT_LDS_NONE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
-    } else if (form == PT_FORM_PARKED) PT_BY_MODE(K_EXT_PARKED, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy);
+    } else if (form == PT_FORM_PARKED) { PT_BY_MODE(K_EXT_PARKED, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
     else if (form == PT_FORM_POOLED) PT_GO(k_extend_pooled<PT_LDS_ALL>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
     else if (form == PT_FORM_SWEEP && (c.lacks & PT_SCENE_NO_XF)) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_SWEEP, PT_SCENE_NO_XF>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
     else if (form == PT_FORM_SWEEP) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
@@ -53,5 +53,9 @@ hipError_t allow_lds_extend(uint32_t bytes) {
     allow(reinterpret_cast<const void*>(k_extend_pooled<PT_LDS_ALL>));
     return worst;
 }
+
+#ifdef PT_TIMELINE
+PT_TL_ACCESSOR(pt_debug_timeline_extend)
+#endif
 
 }  // namespace ptk

@@ -31,6 +31,7 @@ void PT_CAT(launch_shade_nl, PT_SHADE_NL)(const LaunchCfg& c, int form, const Sc
     else if (c.fuse) PT_GO(K_SHADE_FUSED, PT_ARGS);   // (the engine asks for it only where this form exists: PT_LDS_ALL, lean, no transforms, pure sweep)
     else if (c.lacks & PT_SCENE_NO_XF) PT_BY_MODE(K_SHADE_LX, PT_ARGS);
     else PT_BY_MODE(K_SHADE_L, PT_ARGS);
+    PT_TL_BUMP(c.stream);
 }
 hipError_t PT_CAT(allow_lds_shade_nl, PT_SHADE_NL)(uint32_t bytes) {
     hipError_t worst = hipSuccess;
@@ -58,6 +59,9 @@ void launch_shade(const LaunchCfg& c, int nl, int form, const SceneArgs& sc, con
     else launch_shade_nl1(c, form, PT_ARGS_FWD);
 }
 hipError_t allow_lds_shade(uint32_t bytes) { hipError_t a = allow_lds_shade_nl1(bytes), b = allow_lds_shade_nl4(bytes); return a != hipSuccess ? a : b; }
+#ifdef PT_TIMELINE
+PT_TL_ACCESSOR(pt_debug_timeline_shade)   // (the one-wavelength forms' records)
+#endif
 #endif
 
 }  // namespace ptk

@@ -11,8 +11,10 @@ namespace ptk {
 #define PT_BY_MODE(K, ...) do { if (c.lds_mode == PT_LDS_ALL) PT_GO(K(PT_LDS_ALL), __VA_ARGS__); else if (c.lds_mode == PT_LDS_CORE) PT_GO(K(PT_LDS_CORE), __VA_ARGS__); \
                                 else PT_GO(K(PT_LDS_NONE), __VA_ARGS__); } while (0)
 #define K_SH_PARKED1(M) k_shadow_parked<M, 1>
-#define K_SH_PARKED1E(M) k_shadow_parked<M, 1, PT_SCENE_NO_LIGHTS>
+#define K_SH_PARKED1S(M) k_shadow_parked<M, 1, 0u, true>
+#define K_SH_PARKED1E(M) k_shadow_parked<M, 1, PT_SCENE_NO_LIGHTS, true>
 #define K_SH_PARKED4(M) k_shadow_parked<M, 4>
+#define K_SH_PARKED4S(M) k_shadow_parked<M, 4, 0u, true>
 #define K_SH_ANY1(M) k_shadow<M, 1, PT_TRAV_ANY>
 #define K_SH_ANY4(M) k_shadow<M, 4, PT_TRAV_ANY>
 #define PT_ARGS sc.blob, sc.blob_words, sc.tex, light_samples, shadow, energy, energy_stride, seg_cap, count_in
@@ -38,12 +40,12 @@ void launch_shadow(const LaunchCfg& c, int form, int nl, bool env, const SceneAr
         if (hero) { PT_DYN_BY_MODE(4); go(plain, k_shadow_sum<4>, light_samples, shadow, energy, energy_stride, seg_cap, count_in); }
         else { PT_DYN_BY_MODE(1); go(plain, k_shadow_sum<1>, light_samples, shadow, energy, energy_stride, seg_cap, count_in); }
     } else if (form == PT_FORM_PARKED) {
-        if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park, c.walk_policy);
+        // (`env`: light samples can pick the environment — the forms that scan axis-parallel rays)
+        if (hero) { if (env) PT_BY_MODE(K_SH_PARKED4S, PT_ARGS, park, c.walk_policy); else PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park, c.walk_policy); }
         else if (c.lacks & PT_SCENE_NO_LIGHTS) PT_BY_MODE(K_SH_PARKED1E, PT_ARGS, park, c.walk_policy);   // (an environment is the scene's only emitter)
+        else if (env) PT_BY_MODE(K_SH_PARKED1S, PT_ARGS, park, c.walk_policy);
         else PT_BY_MODE(K_SH_PARKED1, PT_ARGS, park, c.walk_policy);
-#ifdef PT_TIMELINE
-        hipLaunchKernelGGL(k_tl_bump, dim3(1), dim3(1), 0, c.stream);
-#endif
+        PT_TL_BUMP(c.stream);
     }
     else if (form == PT_FORM_POOLED) {
         if (env) { if (hero) PT_GO((k_shadow_pooled<PT_LDS_ALL, 4, true>), PT_ARGS); else PT_GO((k_shadow_pooled<PT_LDS_ALL, 1, true>), PT_ARGS); }
@@ -62,7 +64,7 @@ hipError_t allow_lds_shadow(uint32_t bytes) {
     hipError_t worst = hipSuccess;
     auto allow = [&](const void* k) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) worst = e; };
 #define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
-    PT_ALLOW_MODES(K_SH_ANY1); PT_ALLOW_MODES(K_SH_ANY4); PT_ALLOW_MODES(K_SH_PARKED1); PT_ALLOW_MODES(K_SH_PARKED4); PT_ALLOW_MODES(K_SH_PARKED1E);
+    PT_ALLOW_MODES(K_SH_ANY1); PT_ALLOW_MODES(K_SH_ANY4); PT_ALLOW_MODES(K_SH_PARKED1); PT_ALLOW_MODES(K_SH_PARKED4); PT_ALLOW_MODES(K_SH_PARKED1E); PT_ALLOW_MODES(K_SH_PARKED1S); PT_ALLOW_MODES(K_SH_PARKED4S);
 #define K_SH_DYN1(M) k_shadow_parked_dyn<M, 1>
 #define K_SH_DYN4(M) k_shadow_parked_dyn<M, 4>
     PT_ALLOW_MODES(K_SH_DYN1); PT_ALLOW_MODES(K_SH_DYN4);
@@ -77,17 +79,13 @@ hipError_t allow_lds_shadow(uint32_t bytes) {
 }
 
 #ifdef PT_TIMELINE
-// (measurement build: the wave records of the launches so far, and the launch counter back to zero)
-extern "C" int pt_debug_timeline(unsigned long long* out, size_t bytes, uint32_t* launches) {
+PT_TL_ACCESSOR(pt_debug_timeline_shadow)
+// (the walks of more than 1500 box tests that pt_device.h recorded in this family's kernels: count, then 12 floats per ray)
+extern "C" int pt_debug_long_walks(float* out, size_t bytes) {
     if (hipDeviceSynchronize() != hipSuccess) return 1;
-    if (hipMemcpyFromSymbol(launches, HIP_SYMBOL(g_tl_launch), sizeof(uint32_t)) != hipSuccess) return 2;
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl), bytes < sizeof(g_tl) ? bytes : sizeof(g_tl)) != hipSuccess) return 3;
-    const uint32_t zero = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tl_launch), &zero, sizeof(zero)) != hipSuccess) return 4;
-    if (bytes > sizeof(g_tl) && hipMemcpyFromSymbol(reinterpret_cast<char*>(out) + sizeof(g_tl), HIP_SYMBOL(ptd::g_tl_rays), sizeof(ptd::g_tl_rays)) != hipSuccess) return 6;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_tl_rays), bytes < sizeof(ptd::g_tl_rays) ? bytes : sizeof(ptd::g_tl_rays)) != hipSuccess) return 2;
     void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(ptd::g_tl_rays)) != hipSuccess || hipMemset(p, 0, sizeof(ptd::g_tl_rays)) != hipSuccess) return 7;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tl)) != hipSuccess || hipMemset(p, 0, sizeof(g_tl)) != hipSuccess) return 5;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(ptd::g_tl_rays)) != hipSuccess || hipMemset(p, 0, sizeof(ptd::g_tl_rays)) != hipSuccess) return 3;
     return 0;
 }
 #endif

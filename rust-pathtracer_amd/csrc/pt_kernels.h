@@ -131,6 +131,34 @@ __device__ __forceinline__ uint32_t fresh_lane_id() {
     return l;
 }
 
+#ifdef PT_TIMELINE
+// (measurement build, tools/wave_timeline.py: when every wave of a kernel family's main kernel began and ended — 100 MHz clock —, how many items
+// its segment held and how much of the family's own unit of work it did; one record per launch, workgroup and wave.  Every family's
+// translation unit has its own copy and its own accessor, PT_TL_ACCESSOR.)
+constexpr uint32_t kTlLaunches = 32, kTlBlocks = 16384;
+static __device__ unsigned long long g_tl[kTlLaunches][kTlBlocks][4][4];
+static __device__ uint32_t g_tl_launch;
+static __global__ void k_tl_bump() { g_tl_launch = g_tl_launch + 1u; }
+#define PT_TL_BEGIN() const unsigned long long tl0 = wall_clock64(); uint32_t tl_work = 0
+#define PT_TL_WORK() (++tl_work)
+#define PT_TL_END(n) do { if (g_tl_launch < kTlLaunches && blockIdx.x < kTlBlocks) { unsigned long long* rec = g_tl[g_tl_launch][blockIdx.x][threadIdx.x >> 6]; \
+    if (lane_id() == 0) { rec[0] = tl0; rec[1] = wall_clock64(); rec[2] = (n); } atomicAdd(&rec[3], (unsigned long long)tl_work); } } while (0)
+#define PT_TL_BUMP(stream) hipLaunchKernelGGL(k_tl_bump, dim3(1), dim3(1), 0, stream)
+#define PT_TL_ACCESSOR(fn) extern "C" int fn(unsigned long long* out, size_t bytes, uint32_t* launches) { \
+    if (hipDeviceSynchronize() != hipSuccess) return 1; \
+    if (hipMemcpyFromSymbol(launches, HIP_SYMBOL(g_tl_launch), sizeof(uint32_t)) != hipSuccess) return 2; \
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl), bytes < sizeof(g_tl) ? bytes : sizeof(g_tl)) != hipSuccess) return 3; \
+    const uint32_t zero = 0; void* p = nullptr; \
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tl_launch), &zero, sizeof(zero)) != hipSuccess) return 4; \
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tl)) != hipSuccess || hipMemset(p, 0, sizeof(g_tl)) != hipSuccess) return 5; \
+    return 0; }
+#else
+#define PT_TL_BEGIN()
+#define PT_TL_WORK()
+#define PT_TL_END(n)
+#define PT_TL_BUMP(stream)
+#endif
+
 // ---- segmented queues -------------------------------------------------------------------------------------------
 // Every queue is cut into gridDim.x segments of `seg_cap` items; workgroup b owns segment b in every kernel of a pass:
 // it reads items [b*seg_cap, b*seg_cap + count_in[b]) and appends its survivors, compacted, to the same segment of the
@@ -207,6 +235,7 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
     const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
     uint32_t st_vertices = 0, st_shadow = 0, st_env = 0;
     const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
+    PT_TL_BEGIN();
     // FULL form (scenes with an environment that light samples can pick): a path that left the scene is a cheap vertex (one MIS-weighted
     // emission), a surface vertex an expensive one (C4: six light samples through the importance map), and a wave that holds both runs the
     // expensive part with the lanes of the cheap ones idle (C4: 38 % of the vertices, lane utilisation 0.60).  So a wave shades the
@@ -274,7 +303,11 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
         uint32_t pos = base + shared_append(out.survives, &lds_counts[0]);
         if (out.survives) store_path<NL>(paths_out, pos, out.next);
         st_vertices += out.vertex_pushed ? 1u : 0u; st_env += out.env_hit ? 1u : 0u; st_shadow += out.shadow_count;
+#ifdef PT_TIMELINE
+        tl_work += out.vertex_pushed ? 1u : 0u;   // (timeline: surface vertices shaded)
+#endif
     }
+    PT_TL_END(n);
     // workgroup totals -> this workgroup's statistics record
     st_vertices = wave_reduce_add(st_vertices); st_shadow = wave_reduce_add(st_shadow); st_env = wave_reduce_add(st_env);
     if (lane_id() == 0) { atomicAdd(&lds_counts[4], st_vertices); atomicAdd(&lds_counts[5], st_shadow); atomicAdd(&lds_counts[6], st_env); }
@@ -545,15 +578,7 @@ constexpr uint32_t kLiveCap = 64u * PT_MAX_LIGHT_SAMPLES + 64u;   // a wave's li
 // `walk_policy` (mesh_walk's: pt_tuning::walk_evict_below | walk_search_below << 8): a resumed wave's walks are left by its last lanes once
 // fewer than walk_evict_below are still walking — they park again with their cursor and go on in a later drain.  Not in the very last drain
 // of a wave, which has nobody left to wait for.
-#ifdef PT_TIMELINE
-// (measurement build, tools/wave_timeline.py: when every wave of k_shadow_parked began and ended, how many items its segment held and how many
-// parked rays it resumed — one record per launch, workgroup and wave)
-constexpr uint32_t kTlLaunches = 32, kTlBlocks = 16384;
-static __device__ unsigned long long g_tl[kTlLaunches][kTlBlocks][4][4];
-static __device__ uint32_t g_tl_launch;
-static __global__ void k_tl_bump() { g_tl_launch = g_tl_launch + 1u; }
-#endif
-template <typename Resume>
+template <bool ALL_LANES, typename Resume>
 __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, bool last, uint32_t walk_policy, Resume&& resume) {
     const uint32_t lane = lane_id();
     for (;;) {
@@ -563,10 +588,12 @@ __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, b
         const uint32_t take = cnt < 64u ? cnt : 64u, first = cnt - take;
         const bool mine = lane < take;
         uint32_t item = 0, ray = 0, kind = 0, cursor = 0; float bound = PT_INF; SweepState st;
+        if (ALL_LANES) sweep_state_init(st, 0);
         if (mine) park_load(pk, first + lane, &item, &st, &ray, &bound, &kind, &cursor);
         __threadfence_block();             // entries are in registers before any lane parks again into these slots
         if (lane == 0) *park_count = first;
-        if (mine) resume(item, st, ray, bound, kind, cursor, last && first == 0u ? walk_policy & ~0xffu : walk_policy);
+        // (ALL_LANES, the forms that scan axis rays: a lane without an entry helps with the scans of the others' — mesh_walk's `alive`)
+        if (ALL_LANES || mine) resume(item, st, ray, bound, kind, cursor, last && first == 0u ? walk_policy & ~0xffu : walk_policy, mine);
     }
 }
 
@@ -591,6 +618,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
         if (parked) park_store(pk, atomicAdd(park_count, 1u), j, st, 0u, PT_INF, 0u, cursor);
         else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, base + j, h); }
     };
+    PT_TL_BEGIN();
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t j = r * blockDim.x + (wave << 6 | fresh_lane_id());
         if (j < n) {
@@ -601,18 +629,24 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
             const TriRay wtr = tri_ray_prepare(o, d);
             settle(j, o, d, st, sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true), 0u);
         }
-        park_drain(pk, park_count, r + 1 == rounds, walk_policy, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t, uint32_t cursor, uint32_t policy) {
-            F3 o, d;
-            ray_of(base + j2, &o, &d);
-            const bool again = sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy);
-            settle(j2, o, d, st, again, cursor);
+        park_drain<false>(pk, park_count, r + 1 == rounds, walk_policy & ~PT_WALK_SCAN_AXIS, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t, uint32_t cursor, uint32_t policy, bool mine) {
+            if (mine) PT_TL_WORK();   // (timeline: parked rays resumed)
+            F3 o = f3(0.0f, 0.0f, 0.0f), d = f3(0.0f, 0.0f, 0.0f);
+            if (mine) ray_of(base + j2, &o, &d);
+            const bool again = sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy, mine);
+            if (mine) settle(j2, o, d, st, again, cursor);
         });
     }
+    PT_TL_END(n);
 }
 
 // (LACKS = PT_SCENE_NO_LIGHTS: the light list is empty — hdri_test — so every light-sample ray is an environment ray: the light pre-pass, the
 // light's record and its emission are compiled out)
-template <int USE_LDS, int NL, uint32_t LACKS = 0u>
+// SCAN: rays parallel to an axis of their mesh are scanned by the whole wave (mesh_scan) — the form for scenes whose light samples can pick the
+// environment: the sample at the pole of the map is such a ray, 1.5 in 10 000 of C4's, each of them 8000 box tests long when walked.  Where light
+// samples only go to lights, and for closest-hit rays (k_extend_parked), an axis-parallel direction is a coincidence of the scene's set-up; those
+// forms walk it like any other ray and do without the scan's registers (96-VGPR k_extend_parked: 6 spilled with it).
+template <int USE_LDS, int NL, uint32_t LACKS = 0u, bool SCAN = false>
 __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                      uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                                      uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ park_all, uint32_t walk_policy) {
@@ -643,21 +677,17 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
         for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
     };
     // (the parked `kind` word: bit 0 = an environment sample, the rest = 1 + the light whose hit bounds the search, sweep_run's known_inst)
-#ifdef PT_TIMELINE
-    const unsigned long long tl0 = wall_clock64();
-    uint32_t tl_resumed = 0;
-#endif
-    auto resume_parked = [&](uint32_t j2, SweepState& st, uint32_t l2, float bound, uint32_t kind, uint32_t cursor, uint32_t policy) {
-#ifdef PT_TIMELINE
-        ++tl_resumed;
-#endif
+    PT_TL_BEGIN();
+    auto resume_parked = [&](uint32_t j2, SweepState& st, uint32_t l2, float bound, uint32_t kind, uint32_t cursor, uint32_t policy, bool mine) {
+        if (mine) PT_TL_WORK();   // (timeline: parked rays resumed)
         ShadowRayT<NL> pr;
-        load_shadow_ray<NL>(shadow, base + j2, l2, &pr);
+        pr.o = f3(0.0f, 0.0f, 0.0f); pr.d = f3(0.0f, 0.0f, 0.0f);
+        if (mine) load_shadow_ray<NL>(shadow, base + j2, l2, &pr);
         const bool env = kOnlyEnv || (kind & 1u) != 0u;
         // a light ray searches with the early stop whenever it has a finite bound (shadow_light_bound)
         const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
-        const bool again = sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound, &cursor, policy);
-        settle(j2, l2, pr, env, bound, st, again, (kind >> 1) - 1u, cursor);
+        const bool again = sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound, &cursor, policy, mine);
+        if (mine) settle(j2, l2, pr, env, bound, st, again, (kind >> 1) - 1u, cursor);
     };
     // The rays that are traced at all — a light sample below the horizon of its surface, or with a zero factor, is not: four in five of
     // C4's — are listed per wave (item and sample number) and traced 64 at a time, so that a step of the wave is 64 live rays and parks at
@@ -705,15 +735,9 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
             }
         }
         __builtin_amdgcn_wave_barrier();
-        park_drain(pk, park_count, r == rounds && live_count == 0u, walk_policy, resume_parked);
+        park_drain<SCAN>(pk, park_count, r == rounds && live_count == 0u, SCAN ? walk_policy : walk_policy & ~PT_WALK_SCAN_AXIS, resume_parked);
     }
-#ifdef PT_TIMELINE
-    if (g_tl_launch < kTlLaunches && blockIdx.x < kTlBlocks) {
-        unsigned long long* rec = g_tl[g_tl_launch][blockIdx.x][wave];
-        if (lane_id() == 0) { rec[0] = tl0; rec[1] = wall_clock64(); rec[2] = n; }
-        atomicAdd(&rec[3], (unsigned long long)tl_resumed);
-    }
-#endif
+    PT_TL_END(n);
     __threadfence_block();
     for (uint32_t r = 0; r < rounds; ++r) {  // pt.rs:349-392, 596: the item's rays summed in order, divided by L
         const uint32_t j = r * blockDim.x + threadIdx.x;
@@ -768,11 +792,11 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked_dyn
         if (parked) park_store(pk, atomicAdd(park_count, 1u), i, st, 0u, PT_INF, 0u, cursor);
         else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, i, h); }
     };
-    auto resume = [&](uint32_t i2, SweepState& st, uint32_t, float, uint32_t, uint32_t cursor, uint32_t policy) {
-        F3 o, d;
-        ray_of(i2, &o, &d);
-        const bool again = sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy);
-        settle(i2, o, d, st, again, cursor);
+    auto resume = [&](uint32_t i2, SweepState& st, uint32_t, float, uint32_t, uint32_t cursor, uint32_t policy, bool mine) {
+        F3 o = f3(0.0f, 0.0f, 0.0f), d = f3(0.0f, 0.0f, 0.0f);
+        if (mine) ray_of(i2, &o, &d);
+        const bool again = sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy, mine);
+        if (mine) settle(i2, o, d, st, again, cursor);
     };
     // one loop, one drain site (the resume code is the bulk of the kernel: two inlined copies cost 25 KB of instruction cache): each turn
     // takes the next 64 items of the current unit — or a new unit, or nothing when the counter has run out — and drains; the last turn
@@ -792,7 +816,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked_dyn
         }
         off += 64u;
         const bool last = !more && off >= cnt;
-        park_drain(pk, park_count, last, walk_policy, resume);
+        park_drain<false>(pk, park_count, last, walk_policy & ~PT_WALK_SCAN_AXIS, resume);
         if (last) break;
     }
 }
@@ -822,13 +846,14 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked_dyn(const 
         shadow_ray_contribution<NL>(s, [&](int k) { return pl_get<NL>(lambda, k); }, ray, env, hit, sh, c);
         for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, c[k]);
     };
-    auto resume = [&](uint32_t item2, SweepState& st, uint32_t l2, float bound, uint32_t kind, uint32_t cursor, uint32_t policy) {   // (`kind`: see k_shadow_parked)
+    auto resume = [&](uint32_t item2, SweepState& st, uint32_t l2, float bound, uint32_t kind, uint32_t cursor, uint32_t policy, bool mine) {   // (`kind`: see k_shadow_parked)
         ShadowRayT<NL> pr;
-        load_shadow_ray<NL>(shadow, item2, l2, &pr);
+        pr.o = f3(0.0f, 0.0f, 0.0f); pr.d = f3(0.0f, 0.0f, 0.0f);
+        if (mine) load_shadow_ray<NL>(shadow, item2, l2, &pr);
         const bool env = (kind & 1u) != 0u;
         const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
-        const bool again = sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound, &cursor, policy);
-        settle(item2, l2, pr, env, bound, st, again, (kind >> 1) - 1u, cursor);
+        const bool again = sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound, &cursor, policy, mine);
+        if (mine) settle(item2, l2, pr, env, bound, st, again, (kind >> 1) - 1u, cursor);
     };
     uint32_t first = 0, cnt = 0, off = 0;   // (one loop, one drain site: see k_extend_parked_dyn)
     bool more = true;
@@ -853,7 +878,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked_dyn(const 
                     settle(item, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound), light, 0u);
                 }
             }
-            park_drain(pk, park_count, last_turn && l + 1 == light_samples, walk_policy, resume);
+            park_drain<false>(pk, park_count, last_turn && l + 1 == light_samples, walk_policy & ~PT_WALK_SCAN_AXIS, resume);
         }
         if (last_turn) break;
     }
