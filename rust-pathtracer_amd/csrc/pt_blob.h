@@ -44,10 +44,12 @@
 #define PT_MESH_LEAF_COUNT 6
 #define PT_MESH_GROUP_OFF 7    /* meshes of more than PT_MESH_GROUP_MIN leaves: per PT_MESH_GROUP consecutive leaves 8 words = the box that holds theirs (min.xyz, 0, max.xyz, flat); 0 = none */
 #ifndef PT_MESH_GROUP
-#define PT_MESH_GROUP 16
+#define PT_MESH_GROUP 6   /* (measured on C3's gem, 302 leaves: k_extend_parked 4400 / 4190 / 3875 / 3605 / 3520 us at 16 / 12 / 8 / 6 / 5 leaves per group) */
 #endif
 #define PT_MESH_GROUP_MIN 96
-#define PT_MESH_SWEEP_MAX 512  /* meshes of at most this many triangles get a leaf list */
+#ifndef PT_MESH_SWEEP_MAX
+#define PT_MESH_SWEEP_MAX 384  /* meshes of at most this many triangles get a leaf list (64 groups, one bit each) */
+#endif
 
 // Instance record (40 words).
 #define PT_INST_WORDS 40

@@ -210,9 +210,13 @@ def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
     for env in ({"PT_AMD_NO_PARK": "1"}, {"PT_AMD_NO_MESH_SWEEP": "1"}, {"PT_AMD_NO_SWEEP": "1"}, {"PT_AMD_NO_LDS": "1"}, {"PT_AMD_NO_CORE_LDS": "1"},
                 {"PT_AMD_BLOCKS_PER_CU": "32"}, {"PT_AMD_PARK_DYNAMIC": "0"}, {"PT_AMD_PARK_DYNAMIC": "1"}, {"PT_AMD_PARK_DYNAMIC": "1", "PT_AMD_PARK_BLOCKS_PER_CU": "1"},
                 {"PT_AMD_LDS_ALL_LIMIT": "65536"}, {"PT_AMD_LDS_ALL_LIMIT": "65536", "PT_AMD_PARK_DYNAMIC": "0"}, {"PT_AMD_LDS_ALL_LIMIT": "4096"},
-                {"PT_AMD_NO_MESH_SWEEP": "1", "PT_AMD_NO_PARK": "1"}):
+                {"PT_AMD_NO_MESH_SWEEP": "1", "PT_AMD_NO_PARK": "1"},
+                {"PT_AMD_WALK_EVICT_BELOW": "1", "PT_AMD_WALK_SEARCH_BELOW": "1"}, {"PT_AMD_WALK_EVICT_BELOW": "64", "PT_AMD_WALK_SEARCH_BELOW": "64"},
+                {"PT_AMD_NO_AXIS_SCAN": "1"}, {"PT_AMD_NO_AXIS_SCAN": "1", "PT_AMD_WALK_EVICT_BELOW": "1", "PT_AMD_WALK_SEARCH_BELOW": "1"}):
         # (the parked kernels with one static segment per workgroup / with units taken from a counter by persistent workgroups; the whole
-        # blob staged in LDS however large — the gem's is 65 KB, staged as its core section by default — / only ever the core section)
+        # blob staged in LDS however large — the gem's is 65 KB, staged as its core section by default — / only ever the core section;
+        # the mesh walks of a resumed wave without eviction and short searches / leaving at every chance; axis-parallel rays walked instead of
+        # scanned by the wave — hdri_c4_small's environment samples at the pole of the map are such rays)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         film, prof = engine.create_scene(b).render(rd)
