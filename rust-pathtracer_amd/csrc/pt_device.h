@@ -947,7 +947,6 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
             static_assert(PT_MESH_SWEEP_MAX <= 512 && PT_MESH_GROUP <= 8, "nine bits per queued leaf, room for a group's leaves below the fill mark");
             unsigned __int128 fifo = 0;
             uint32_t queued = 0;
-            bool over = false;
             for (;;) {
                 if (entered != 0 && queued <= 14u - PT_MESH_GROUP) {
                     const uint32_t g = ctz64(entered);
@@ -986,12 +985,11 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                     if (queued != 0u) {
                         const uint32_t leaf = (uint32_t)fifo & 511u;
                         fifo >>= 9; --queued;
-                        if (triangles(1ull, leaf)) { over = true; queued = 0; entered = 0; fifo = 0; }
+                        if (triangles(1ull, leaf)) { queued = 0; entered = 0; fifo = 0; }   // (an early stop: this lane's search is over)
                     }
                 }
                 if (!PT_WAVE_ANY(entered != 0 || queued != 0u)) break;
             }
-            (void)over;
             return false;
 #else
             while (entered != 0) {
