@@ -1175,6 +1175,73 @@ PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, S
     const TriRay wtr = tri_ray_prepare(o, d);
     return sweep_run<true>(s, o, d, wtr, bound, stop, st, true, known_inst, known_t);
 }
+// ---- the two-level walk, in the parked kernels' protocol (round 3) ------------------------------------------------------------------
+// Scenes without a sweep table (more than 64 instances, or PT_FLAG_NO_SWEEP): the top-level tree is walked lane by lane as in world_hit_walk,
+// but a lane that reaches a mesh instance whose box it hits PARKS there, and the mesh is walked when 64 such rays have collected —
+// mesh_walk with everything the parked kernels give it (full waves, pooled stragglers, short searches, scanned axis rays).  The state is a
+// SweepState whose `hit` word holds the walk's place instead of leaf bits: 1 + the top-level node to visit next, 0 = the search is over
+// (which is also what mesh_walk's early stop leaves there).  Same boxes, same instances, same order as world_hit_walk: the top level in
+// pre-order with the same test and the same culling, every mesh through mesh_walk against the running closest hit.
+PT_HD void top_walk_init(SweepState& st) { sweep_state_init(st, 1ull); }
+// from the state's place on; true = parked at a mesh instance (the place is that instance's leaf; `park_at_mesh` false: meshes in line)
+PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, bool park_at_mesh) {
+    const uint32_t flags = bu(s, PT_HDR_FLAGS);
+    const uint32_t top_off = bu(s, PT_HDR_TOP_NODE_OFF), top_count = bu(s, PT_HDR_TOP_NODE_COUNT), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
+    const bool cull_top = (flags & (PT_FLAG_NO_TOP_CULL | PT_FLAG_NO_CULL)) == 0;
+    RayPrep wr = ray_prepare(o, d);
+    if (flags & PT_FLAG_EXACT_SLAB) wr.fast = false;
+    const bool wr_quick = wr.fast && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f;
+    if (st.hit == 0) return false;
+    uint32_t i = (uint32_t)st.hit - 1u;
+    while (i < top_count) {
+        const F4 a = bf4(s, top_off + i * PT_NODE_WORDS), b = bf4(s, top_off + i * PT_NODE_WORDS + 4);
+        const uint32_t exit_i = PT_NODE_EXIT(pt_f2u(a.w)), shape = pt_f2u(b.w);
+        float entry;
+        const bool box = aabb_hit_node(a, b, wr, wr_quick, &entry) && !(cull_top && !(pt_f2u(a.w) & PT_NODE_NO_CULL) && beyond(entry, __builtin_fminf(st.closest, bound), wr.base));
+        if (shape == PT_NODE_INNER) { i = box ? i + 1 : exit_i; continue; }
+        if (!box) { i = exit_i; continue; }
+        const uint32_t inst = inst_off + shape * PT_INST_WORDS, kind = bu(s, inst + PT_INST_KIND);
+        if (kind == PT_SHAPE_MESH) {
+            if (park_at_mesh) { st.hit = (uint64_t)i + 1ull; return true; }
+            st.hit = (uint64_t)exit_i + 1ull;
+            mesh_walk(s, inst, shape, o, d, bound, stop, st);
+            if (st.hit == 0) return false;   // (an early stop inside the mesh)
+            i = exit_i;
+            continue;
+        }
+        i = exit_i;
+        F3 lo, ld;
+        instance_local_ray(s, inst, o, d, &lo, &ld);
+        Hit h;
+        if (analytic_hit(s, inst, kind, lo, ld, st.closest, &h)) {
+            st.closest = h.t; st.best_inst = shape; st.best_triw = 0;
+            bool over = stop == PT_STOP_ANY;
+            if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
+                const uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+                over = PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : h.material) != PT_TAG_LIGHT;   // something opaque in front of every light
+            }
+            if (over) { st.hit = 0; return false; }
+        }
+    }
+    st.hit = 0;
+    return false;
+}
+// A parked lane: the mesh it stands at (mesh_walk with the wave's policy; true = evicted from it, the place unchanged and `*cursor` where the
+// walk goes on), then the top level from behind that instance (true = parked at the next mesh).
+PT_HD bool top_walk_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, uint32_t* cursor, uint32_t policy, bool alive) {
+    const uint32_t top_off = bu(s, PT_HDR_TOP_NODE_OFF), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
+    const uint32_t at = alive ? (uint32_t)st.hit - 1u : 0u;
+    const F4 a = bf4(s, top_off + at * PT_NODE_WORDS), b = bf4(s, top_off + at * PT_NODE_WORDS + 4);
+    uint32_t shape = pt_f2u(b.w);
+    if (!alive) shape = PT_WAVE_READ(shape, ctz64(PT_WAVE_BALLOT(alive)));   // (a lane that only helps: with the instance of one that has a ray)
+    const uint64_t place = st.hit;
+    st.hit = (uint64_t)PT_NODE_EXIT(pt_f2u(a.w)) + 1ull;
+    if (mesh_walk(s, inst_off + shape * PT_INST_WORDS, shape, o, d, bound, stop, st, cursor, policy, alive)) { st.hit = place; return true; }
+    if (!alive) return false;
+    *cursor = 0u;
+    return top_walk_run(s, o, d, bound, stop, st, true);
+}
+
 PT_HD bool sweep_finish(const SceneView& s, F3 o, F3 d, const SweepState& st, Hit* out) {
     if (st.best_inst == 0xffffffffu) { out->valid = false; return false; }
     hit_record(s, o, d, st.best_inst, st.best_triw, st.bh, out);
@@ -1485,6 +1552,18 @@ template <int TRAV = PT_TRAV_ANY, bool LIGHT_ONLY = false>
 PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_INF, int stop = PT_STOP_NONE, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f) {
     if (TRAV == PT_TRAV_SWEEP) return world_hit_sweep<false, LIGHT_ONLY>(s, o, d, out, bound, stop, known_inst, known_t);
     if (TRAV == PT_TRAV_ANY && scene_uses_sweep(s)) return world_hit_sweep<true, LIGHT_ONLY>(s, o, d, out, bound, stop, known_inst, known_t);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (bu(s, PT_HDR_FLAGS) & PT_FLAG_REPLAY) {
+        // (host emulation: the parked kernels' protocol over the top-level tree, lane by lane — park at every mesh, resume, leave the walk at every chance)
+        SweepState st;
+        top_walk_init(st);
+        uint32_t cursor = 0u;
+        bool parked = top_walk_run(s, o, d, bound, stop, st, true);
+        while (parked) parked = top_walk_resume(s, o, d, bound, stop, st, &cursor, 0x201u | PT_WALK_SCAN_AXIS, true);
+        if (LIGHT_ONLY && st.best_inst != 0xffffffffu && !sweep_best_is_light(s, st)) { out->valid = true; out->material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); return true; }
+        return sweep_finish(s, o, d, st, out);
+    }
+#endif
     return world_hit_walk(s, o, d, out, bound, stop);
 }
 

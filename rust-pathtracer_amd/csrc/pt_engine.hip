@@ -144,6 +144,12 @@ struct pt_scene {
 };
 
 namespace {
+// whether any instance of the flattened scene is a mesh (the parked kernels' scratch is only allocated for scenes that can park)
+bool scene_has_mesh(const std::vector<uint32_t>& blob) {
+    const uint32_t off = blob[PT_HDR_INSTANCE_OFF], n = blob[PT_HDR_INSTANCE_COUNT];
+    for (uint32_t i = 0; i < n; ++i) if (blob[off + i * PT_INST_WORDS + PT_INST_KIND] == (uint32_t)PT_SHAPE_MESH) return true;
+    return false;
+}
 
 std::string g_device_info;
 
@@ -180,7 +186,10 @@ pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples
         b.nl = nlmax;
         HIP_TRY(hipMalloc(&b.counts, sizeof(uint32_t) * 3 * (size_t)grid));
         HIP_TRY(hipMalloc(&b.block_stats, sizeof(unsigned long long) * BS_FIELDS * (size_t)grid));
-        if (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) HIP_TRY(hipMalloc(&b.park, sizeof(uint32_t) * kParkFields * kParkCap * (size_t)grid));
+        // (the parked kernels' scratch: scenes whose sweep table holds walked meshes, and scenes without a sweep table that hold a mesh)
+        const bool no_table = sc->host.blob[PT_HDR_SWEEP_OFF] == 0 || (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP);
+        if ((sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) || (no_table && scene_has_mesh(sc->host.blob)))
+            HIP_TRY(hipMalloc(&b.park, sizeof(uint32_t) * kParkFields * kParkCap * (size_t)grid));
         if (!b.unit_counters) HIP_TRY(hipMalloc(&b.unit_counters, sizeof(uint32_t) * kUnitCounters));
         b.capacity = total; b.light_samples = ls; b.grid = grid;
     }
@@ -250,11 +259,13 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     // the sweep table holds walked meshes: rays that reach one are parked and resumed in full waves (PT_AMD_NO_PARK=1: in line)
     const bool walks = (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) != 0;
     const bool parked = sweep && walks && b.park != nullptr && !(tn.flags & PT_TUNE_NO_PARK);
+    // no sweep table (more than 64 instances, PT_AMD_NO_SWEEP) but meshes: the top-level tree per lane, every mesh parked (top_walk_run, pt_device.h)
+    const bool parked_walk = !sweep && b.park != nullptr && !(tn.flags & PT_TUNE_NO_PARK);
     // PT_AMD_POOL=1: phase 3 of a pure sweep scene pooled per wave (sweep_run_pooled).  Bit-identical, but measured slower than the lane
     // loop on MI355X (C2: k_extend 3155 vs 2475 us, k_shadow 5421 vs 4677 us; DESIGN.md section 5 has the breakdown), so it is not the default.
     const bool pooled = sweep && !walks && mode == PT_LDS_ALL && lds_bytes + pool_lds_bytes() <= kLdsBlobLimitBytes && (tn.flags & PT_TUNE_POOL) != 0;
     // (walked meshes in line under PT_AMD_NO_PARK, and every partly staged or unstaged blob: the run-time choice of PT_FORM_ANY)
-    const int trav_form = parked ? PT_FORM_PARKED : (mode != PT_LDS_ALL || (sweep && walks)) ? PT_FORM_ANY : pooled ? PT_FORM_POOLED : sweep ? PT_FORM_SWEEP : PT_FORM_WALK;
+    const int trav_form = parked ? PT_FORM_PARKED : parked_walk ? PT_FORM_PARKED_WALK : (mode != PT_LDS_ALL || (sweep && walks)) ? PT_FORM_ANY : pooled ? PT_FORM_POOLED : sweep ? PT_FORM_SWEEP : PT_FORM_WALK;
     // The parked kernels take units of work from a counter, a few persistent workgroups per CU, when the whole blob is staged in LDS
     // (C3: k_extend 9175 -> 7880 us, k_shadow 8008 -> 7105, 487 -> 543 Msamples/s: park lists that live across units keep the drains
     // full).  With the mesh in HBM/L2 (C4) the static form wins, 1128 vs 1083 Msamples/s: a wave's parked rays then come from one

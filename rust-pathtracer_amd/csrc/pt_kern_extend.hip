@@ -10,6 +10,7 @@ uint32_t pool_lds_bytes() { return (kBlock / 64) * PT_POOL_WORDS * 4u; }
 #define PT_BY_MODE(K, ...) do { if (c.lds_mode == PT_LDS_ALL) PT_GO(K(PT_LDS_ALL), __VA_ARGS__); else if (c.lds_mode == PT_LDS_CORE) PT_GO(K(PT_LDS_CORE), __VA_ARGS__); \
                                 else PT_GO(K(PT_LDS_NONE), __VA_ARGS__); } while (0)
 #define K_EXT_PARKED(M) k_extend_parked<M>
+#define K_EXT_PARKED_W(M) k_extend_parked<M, 1>
 #define K_EXT_ANY(M) k_extend<M, PT_TRAV_ANY>
 #define K_PROBE(M) k_probe_intersect<M>
 
@@ -29,7 +30,8 @@ void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, Queue path
         if (c.lds_mode == PT_LDS_ALL) go(d, K_EXT_PARKED_DYN(PT_LDS_ALL), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
         else if (c.lds_mode == PT_LDS_CORE) go(d, K_EXT_PARKED_DYN(PT_LDS_CORE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
         else go(d, K_EXT_PARKED_DYN(PT_LDS_NONE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
-    } else if (form == PT_FORM_PARKED) { PT_BY_MODE(K_EXT_PARKED, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
+    } else if (form == PT_FORM_PARKED_WALK) { PT_BY_MODE(K_EXT_PARKED_W, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
+    else if (form == PT_FORM_PARKED) { PT_BY_MODE(K_EXT_PARKED, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
     else if (form == PT_FORM_POOLED) PT_GO(k_extend_pooled<PT_LDS_ALL>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
     else if (form == PT_FORM_SWEEP && (c.lacks & PT_SCENE_NO_XF)) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_SWEEP, PT_SCENE_NO_XF>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
     else if (form == PT_FORM_SWEEP) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
@@ -45,7 +47,7 @@ hipError_t allow_lds_extend(uint32_t bytes) {
     hipError_t worst = hipSuccess;
     auto allow = [&](const void* k) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) worst = e; };
 #define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
-    PT_ALLOW_MODES(K_EXT_ANY); PT_ALLOW_MODES(K_EXT_PARKED); PT_ALLOW_MODES(K_PROBE);
+    PT_ALLOW_MODES(K_EXT_ANY); PT_ALLOW_MODES(K_EXT_PARKED); PT_ALLOW_MODES(K_EXT_PARKED_W); PT_ALLOW_MODES(K_PROBE);
 #define K_EXT_PARKED_DYN2(M) k_extend_parked_dyn<M>
     PT_ALLOW_MODES(K_EXT_PARKED_DYN2);
     allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>));

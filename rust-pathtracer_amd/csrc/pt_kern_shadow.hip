@@ -15,6 +15,8 @@ namespace ptk {
 #define K_SH_PARKED1E(M) k_shadow_parked<M, 1, PT_SCENE_NO_LIGHTS, true>
 #define K_SH_PARKED4(M) k_shadow_parked<M, 4>
 #define K_SH_PARKED4S(M) k_shadow_parked<M, 4, 0u, true>
+#define K_SH_PARKED1W(M) k_shadow_parked<M, 1, 0u, true, 1>
+#define K_SH_PARKED4W(M) k_shadow_parked<M, 4, 0u, true, 1>
 #define K_SH_ANY1(M) k_shadow<M, 1, PT_TRAV_ANY>
 #define K_SH_ANY4(M) k_shadow<M, 4, PT_TRAV_ANY>
 #define PT_ARGS sc.blob, sc.blob_words, sc.tex, light_samples, shadow, energy, energy_stride, seg_cap, count_in
@@ -39,6 +41,9 @@ void launch_shadow(const LaunchCfg& c, int form, int nl, bool env, const SceneAr
         LaunchCfg plain = c; plain.lds_bytes = 0;
         if (hero) { PT_DYN_BY_MODE(4); go(plain, k_shadow_sum<4>, light_samples, shadow, energy, energy_stride, seg_cap, count_in); }
         else { PT_DYN_BY_MODE(1); go(plain, k_shadow_sum<1>, light_samples, shadow, energy, energy_stride, seg_cap, count_in); }
+    } else if (form == PT_FORM_PARKED_WALK) {   // (one general form per wavelength count: with the scan, with the light list)
+        if (hero) PT_BY_MODE(K_SH_PARKED4W, PT_ARGS, park, c.walk_policy); else PT_BY_MODE(K_SH_PARKED1W, PT_ARGS, park, c.walk_policy);
+        PT_TL_BUMP(c.stream);
     } else if (form == PT_FORM_PARKED) {
         // (`env`: light samples can pick the environment — the forms that scan axis-parallel rays)
         if (hero) { if (env) PT_BY_MODE(K_SH_PARKED4S, PT_ARGS, park, c.walk_policy); else PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park, c.walk_policy); }
@@ -64,7 +69,7 @@ hipError_t allow_lds_shadow(uint32_t bytes) {
     hipError_t worst = hipSuccess;
     auto allow = [&](const void* k) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) worst = e; };
 #define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
-    PT_ALLOW_MODES(K_SH_ANY1); PT_ALLOW_MODES(K_SH_ANY4); PT_ALLOW_MODES(K_SH_PARKED1); PT_ALLOW_MODES(K_SH_PARKED4); PT_ALLOW_MODES(K_SH_PARKED1E); PT_ALLOW_MODES(K_SH_PARKED1S); PT_ALLOW_MODES(K_SH_PARKED4S);
+    PT_ALLOW_MODES(K_SH_ANY1); PT_ALLOW_MODES(K_SH_ANY4); PT_ALLOW_MODES(K_SH_PARKED1); PT_ALLOW_MODES(K_SH_PARKED4); PT_ALLOW_MODES(K_SH_PARKED1E); PT_ALLOW_MODES(K_SH_PARKED1S); PT_ALLOW_MODES(K_SH_PARKED4S); PT_ALLOW_MODES(K_SH_PARKED1W); PT_ALLOW_MODES(K_SH_PARKED4W);
 #define K_SH_DYN1(M) k_shadow_parked_dyn<M, 1>
 #define K_SH_DYN4(M) k_shadow_parked_dyn<M, 4>
     PT_ALLOW_MODES(K_SH_DYN1); PT_ALLOW_MODES(K_SH_DYN4);

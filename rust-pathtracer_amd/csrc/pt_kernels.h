@@ -597,7 +597,9 @@ __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, b
     }
 }
 
-template <int USE_LDS>
+// TOP = 1: no sweep table — the top-level tree is walked per lane and a lane parks at every mesh instance it reaches (top_walk_run / top_walk_resume,
+// pt_device.h): the parked kernels' mesh walks for scenes of more than 64 instances.
+template <int USE_LDS, int TOP = 0>
 __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                      Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
                                                                      uint32_t* __restrict__ park_all, uint32_t walk_policy) {
@@ -625,15 +627,21 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
             F3 o, d;
             ray_of(base + j, &o, &d);
             SweepState st;
-            sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
-            const TriRay wtr = tri_ray_prepare(o, d);
-            settle(j, o, d, st, sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true), 0u);
+            bool parks;
+            if (TOP) { top_walk_init(st); parks = top_walk_run(s, o, d, PT_INF, PT_STOP_NONE, st, true); }
+            else {
+                sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
+                const TriRay wtr = tri_ray_prepare(o, d);
+                parks = sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true);
+            }
+            settle(j, o, d, st, parks, 0u);
         }
         park_drain<false>(pk, park_count, r + 1 == rounds, walk_policy & ~PT_WALK_SCAN_AXIS, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t, uint32_t cursor, uint32_t policy, bool mine) {
             if (mine) PT_TL_WORK();   // (timeline: parked rays resumed)
             F3 o = f3(0.0f, 0.0f, 0.0f), d = f3(0.0f, 0.0f, 0.0f);
             if (mine) ray_of(base + j2, &o, &d);
-            const bool again = sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy, mine);
+            const bool again = TOP ? top_walk_resume(s, o, d, PT_INF, PT_STOP_NONE, st, &cursor, policy, mine)
+                                   : sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy, mine);
             if (mine) settle(j2, o, d, st, again, cursor);
         });
     }
@@ -646,7 +654,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
 // environment: the sample at the pole of the map is such a ray, 1.5 in 10 000 of C4's, each of them 8000 box tests long when walked.  Where light
 // samples only go to lights, and for closest-hit rays (k_extend_parked), an axis-parallel direction is a coincidence of the scene's set-up; those
 // forms walk it like any other ray and do without the scan's registers (96-VGPR k_extend_parked: 6 spilled with it).
-template <int USE_LDS, int NL, uint32_t LACKS = 0u, bool SCAN = false>
+template <int USE_LDS, int NL, uint32_t LACKS = 0u, bool SCAN = false, int TOP = 0>
 __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                      uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                                      uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ park_all, uint32_t walk_policy) {
@@ -686,7 +694,8 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
         const bool env = kOnlyEnv || (kind & 1u) != 0u;
         // a light ray searches with the early stop whenever it has a finite bound (shadow_light_bound)
         const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
-        const bool again = sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound, &cursor, policy, mine);
+        const bool again = TOP ? top_walk_resume(s, pr.o, pr.d, bound, stop2, st, &cursor, policy, mine)
+                               : sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound, &cursor, policy, mine);
         if (mine) settle(j2, l2, pr, env, bound, st, again, (kind >> 1) - 1u, cursor);
     };
     // The rays that are traced at all — a light sample below the horizon of its surface, or with a zero factor, is not: four in five of
@@ -726,10 +735,14 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
                 for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
             } else {
                 SweepState st;
-                sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
-                if (PT_PARKED_EXP & 2) { qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, (float)(uint32_t)st.hit); continue; }   // (measurement: up to the masks)
-                const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
-                const bool parks = sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound);
+                bool parks;
+                if (TOP) { top_walk_init(st); parks = top_walk_run(s, ray.o, ray.d, bound, stop, st, true); }
+                else {
+                    sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
+                    if (PT_PARKED_EXP & 2) { qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, (float)(uint32_t)st.hit); continue; }   // (measurement: up to the masks)
+                    const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
+                    parks = sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound);
+                }
                 if ((PT_PARKED_EXP & 4) && parks) { qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, 0.0f); continue; }   // (measurement: parked rays dropped)
                 settle(j, l, ray, env, bound, st, parks, light, 0u);
             }

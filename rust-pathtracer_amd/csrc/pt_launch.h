@@ -10,7 +10,7 @@ namespace ptk {
 
 enum { PT_LDS_NONE = 0, PT_LDS_ALL = 1, PT_LDS_CORE = 2 };                 // what stage_scene copies into LDS
 enum { PT_SHADE_LEAN = 0, PT_SHADE_NO_ENV = 1, PT_SHADE_FULL = 2, PT_SHADE_MEDIUM = 3 };   // k_shade forms (MEDIUM: k_shade_medium, one wavelength)
-enum { PT_FORM_ANY = 0, PT_FORM_WALK = 1, PT_FORM_SWEEP = 2, PT_FORM_POOLED = 3, PT_FORM_PARKED = 4 };  // traversal kernels
+enum { PT_FORM_ANY = 0, PT_FORM_WALK = 1, PT_FORM_SWEEP = 2, PT_FORM_POOLED = 3, PT_FORM_PARKED = 4, PT_FORM_PARKED_WALK = 5 };  // traversal kernels (5: the parked kernels over the top-level tree instead of a sweep table)
 constexpr int kBlock = 256;
 constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // the most LDS a staged blob (or its core section) may take
 // The whole blob is staged only while it leaves the CU its occupancy: six workgroups of 24 KB fit the 160 KB.  Measured (tools/lds_mode.sh):

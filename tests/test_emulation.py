@@ -94,7 +94,8 @@ def test_leaf_sweep_equals_bvh_walk(emu, pkg, monkeypatch, scene):
     big meshes walked from it); the pure BVH walk (flag 16), the exact slab test (2) and no culling (4) must give the same
     bits: hits, films and ray counters.  So must phase 3 as independent unbounded tests + ordered replay (128: the logic of the
     wave-pooled kernels; with 4, the masks are not culled by the bound either; in a table with walked meshes 128 is the parked kernels'
-    protocol instead — park at the mesh, resume, leave the walk after every triangle test and go on from the cursor)."""
+    protocol instead — park at the mesh, resume, leave the walk after every triangle test and go on from the cursor; 144 = 128 + 16: the same
+    protocol over the top-level tree, for scenes without a sweep table)."""
     b = pkg.scene.SCENES[scene]()
     o, d = ps.golden_rays(scene, 4096, 33)
     # axis-parallel directions take the undecided path for every box
@@ -102,10 +103,10 @@ def test_leaf_sweep_equals_bvh_walk(emu, pkg, monkeypatch, scene):
     rd = pkg.api.render_desc(24, 24, 4, 5, light_samples=2)
     results = []
     # (64: big meshes walked instead of swept through their group boxes; 256: the nearest light tested again in phase 3)
-    for flags in ("0", "16", "2", "18", "4", "128", "132", "64", "66", "256", "258", "80", "192", "194"):
+    for flags in ("0", "16", "2", "18", "4", "128", "132", "64", "66", "256", "258", "80", "192", "194", "144", "146", "148"):
         monkeypatch.setenv("PTEMU_FLAGS", flags)
         sc = emu.create_scene(b)
-        assert sc.uses_leaf_sweep() == (flags not in ("16", "18", "80"))
+        assert sc.uses_leaf_sweep() == (flags not in ("16", "18", "80", "144", "146", "148"))
         film, prof = sc.render(rd)
         results.append((sc.intersect(o, d), film, (prof.camera_rays, prof.bounce_rays, prof.shadow_rays, prof.env_hits)))
     for hits, film, counts in results[1:]:
