@@ -199,7 +199,8 @@ def test_known_light_changes_nothing(engine, pkg, monkeypatch, scene, L):
 @pytest.mark.parametrize("scene,L", [("cornell_gem", 2), ("hdri_c4_small", 6), ("mixed_primitives", 3)])
 def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
     """Hybrid scenes (sweep table + walked meshes): parked rays resumed in full waves, walked meshes in line, mesh sweep
-    off, pure BVH walk, core-only / no LDS staging — all the same film bit for bit.  One workgroup per CU makes the
+    off, no sweep table (PT_AMD_NO_SWEEP: the parked kernels over the top-level tree; with PT_AMD_NO_PARK the per-lane two-level walk), core-only / no LDS
+    staging — all the same film bit for bit.  One workgroup per CU makes the
     segments long enough for the park queue to fill and drain several times per launch."""
     b = pkg.scene.SCENES[scene]()
     rd = pkg.api.render_desc(256, 192, 12, 8, light_samples=L, seed=9)
@@ -210,7 +211,7 @@ def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
     for env in ({"PT_AMD_NO_PARK": "1"}, {"PT_AMD_NO_MESH_SWEEP": "1"}, {"PT_AMD_NO_SWEEP": "1"}, {"PT_AMD_NO_LDS": "1"}, {"PT_AMD_NO_CORE_LDS": "1"},
                 {"PT_AMD_BLOCKS_PER_CU": "32"}, {"PT_AMD_PARK_DYNAMIC": "0"}, {"PT_AMD_PARK_DYNAMIC": "1"}, {"PT_AMD_PARK_DYNAMIC": "1", "PT_AMD_PARK_BLOCKS_PER_CU": "1"},
                 {"PT_AMD_LDS_ALL_LIMIT": "65536"}, {"PT_AMD_LDS_ALL_LIMIT": "65536", "PT_AMD_PARK_DYNAMIC": "0"}, {"PT_AMD_LDS_ALL_LIMIT": "4096"},
-                {"PT_AMD_NO_MESH_SWEEP": "1", "PT_AMD_NO_PARK": "1"},
+                {"PT_AMD_NO_MESH_SWEEP": "1", "PT_AMD_NO_PARK": "1"}, {"PT_AMD_NO_SWEEP": "1", "PT_AMD_NO_PARK": "1"}, {"PT_AMD_NO_SWEEP": "1", "PT_AMD_NO_AXIS_SCAN": "1"},
                 {"PT_AMD_WALK_EVICT_BELOW": "1", "PT_AMD_WALK_SEARCH_BELOW": "1"}, {"PT_AMD_WALK_EVICT_BELOW": "64", "PT_AMD_WALK_SEARCH_BELOW": "64"},
                 {"PT_AMD_NO_AXIS_SCAN": "1"}, {"PT_AMD_NO_AXIS_SCAN": "1", "PT_AMD_WALK_EVICT_BELOW": "1", "PT_AMD_WALK_SEARCH_BELOW": "1"}):
         # (the parked kernels with one static segment per workgroup / with units taken from a counter by persistent workgroups; the whole
@@ -222,6 +223,24 @@ def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
         film, prof = engine.create_scene(b).render(rd)
         for k in env:
             monkeypatch.delenv(k) if k != "PT_AMD_BLOCKS_PER_CU" else monkeypatch.setenv(k, "1")
+        assert np.array_equal(base.view(np.uint32), film.view(np.uint32)), env
+        assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits), env
+
+
+@pytest.mark.parametrize("scene,L", [("cornell_gem", 2), ("hdri_small", 3)])
+def test_hero_wavelengths_through_every_parked_form(engine, pkg, monkeypatch, scene, L):
+    """Four wavelengths per path through the parked kernels: the hybrid form, the same with axis-parallel rays walked, the top-level-tree form
+    (PT_AMD_NO_SWEEP) and the per-lane walk (PT_AMD_NO_SWEEP + PT_AMD_NO_PARK) give one film, bit for bit."""
+    b = pkg.scene.SCENES[scene]()
+    rd = pkg.api.render_desc(160, 128, 8, 6, light_samples=L, seed=21, hero_wavelengths=4)
+    monkeypatch.setenv("PT_AMD_BLOCKS_PER_CU", "1")
+    base, pbase = engine.create_scene(b).render(rd)
+    for env in ({"PT_AMD_NO_AXIS_SCAN": "1"}, {"PT_AMD_NO_SWEEP": "1"}, {"PT_AMD_NO_SWEEP": "1", "PT_AMD_NO_PARK": "1"}, {"PT_AMD_NO_PARK": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        film, prof = engine.create_scene(b).render(rd)
+        for k in env:
+            monkeypatch.delenv(k)
         assert np.array_equal(base.view(np.uint32), film.view(np.uint32)), env
         assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits), env
 
