@@ -735,16 +735,19 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
                 for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
             } else {
                 SweepState st;
-                bool parks;
+                bool parks = false;
                 if (TOP) { top_walk_init(st); parks = top_walk_run(s, ray.o, ray.d, bound, stop, st, true); }
                 else {
                     sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
-                    if (PT_PARKED_EXP & 2) { qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, (float)(uint32_t)st.hit); continue; }   // (measurement: up to the masks)
-                    const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
-                    parks = sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound);
+                    if (!(PT_PARKED_EXP & 2)) {
+                        const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
+                        parks = sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound);
+                    }
                 }
-                if ((PT_PARKED_EXP & 4) && parks) { qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, 0.0f); continue; }   // (measurement: parked rays dropped)
-                settle(j, l, ray, env, bound, st, parks, light, 0u);
+                // (measurement variants — no lane may leave the wave's step early, the barrier and the drain below are the whole wave's: 2 = up to the masks, 4 = parked rays dropped)
+                if (PT_PARKED_EXP & 2) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, (float)(uint32_t)st.hit);
+                else if ((PT_PARKED_EXP & 4) && parks) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, 0.0f);
+                else settle(j, l, ray, env, bound, st, parks, light, 0u);
             }
         }
         __builtin_amdgcn_wave_barrier();
