@@ -11,12 +11,10 @@ namespace ptk {
 #define PT_BY_MODE(K, ...) do { if (c.lds_mode == PT_LDS_ALL) PT_GO(K(PT_LDS_ALL), __VA_ARGS__); else if (c.lds_mode == PT_LDS_CORE) PT_GO(K(PT_LDS_CORE), __VA_ARGS__); \
                                 else PT_GO(K(PT_LDS_NONE), __VA_ARGS__); } while (0)
 #define K_SH_PARKED1(M) k_shadow_parked<M, 1>
-#define K_SH_PARKED1S(M) k_shadow_parked<M, 1, 0u, true>
-#define K_SH_PARKED1E(M) k_shadow_parked<M, 1, PT_SCENE_NO_LIGHTS, true>
+#define K_SH_PARKED1E(M) k_shadow_parked<M, 1, PT_SCENE_NO_LIGHTS>
 #define K_SH_PARKED4(M) k_shadow_parked<M, 4>
-#define K_SH_PARKED4S(M) k_shadow_parked<M, 4, 0u, true>
-#define K_SH_PARKED1W(M) k_shadow_parked<M, 1, 0u, true, 1>
-#define K_SH_PARKED4W(M) k_shadow_parked<M, 4, 0u, true, 1>
+#define K_SH_PARKED1W(M) k_shadow_parked<M, 1, 0u, 1>
+#define K_SH_PARKED4W(M) k_shadow_parked<M, 4, 0u, 1>
 #define K_SH_ANY1(M) k_shadow<M, 1, PT_TRAV_ANY>
 #define K_SH_ANY4(M) k_shadow<M, 4, PT_TRAV_ANY>
 #define PT_ARGS sc.blob, sc.blob_words, sc.tex, light_samples, shadow, energy, energy_stride, seg_cap, count_in
@@ -45,10 +43,8 @@ void launch_shadow(const LaunchCfg& c, int form, int nl, bool env, const SceneAr
         if (hero) PT_BY_MODE(K_SH_PARKED4W, PT_ARGS, park, c.walk_policy); else PT_BY_MODE(K_SH_PARKED1W, PT_ARGS, park, c.walk_policy);
         PT_TL_BUMP(c.stream);
     } else if (form == PT_FORM_PARKED) {
-        // (`env`: light samples can pick the environment — the forms that scan axis-parallel rays)
-        if (hero) { if (env) PT_BY_MODE(K_SH_PARKED4S, PT_ARGS, park, c.walk_policy); else PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park, c.walk_policy); }
+        if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park, c.walk_policy);
         else if (c.lacks & PT_SCENE_NO_LIGHTS) PT_BY_MODE(K_SH_PARKED1E, PT_ARGS, park, c.walk_policy);   // (an environment is the scene's only emitter)
-        else if (env) PT_BY_MODE(K_SH_PARKED1S, PT_ARGS, park, c.walk_policy);
         else PT_BY_MODE(K_SH_PARKED1, PT_ARGS, park, c.walk_policy);
         PT_TL_BUMP(c.stream);
     }
@@ -69,7 +65,7 @@ hipError_t allow_lds_shadow(uint32_t bytes) {
     hipError_t worst = hipSuccess;
     auto allow = [&](const void* k) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) worst = e; };
 #define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
-    PT_ALLOW_MODES(K_SH_ANY1); PT_ALLOW_MODES(K_SH_ANY4); PT_ALLOW_MODES(K_SH_PARKED1); PT_ALLOW_MODES(K_SH_PARKED4); PT_ALLOW_MODES(K_SH_PARKED1E); PT_ALLOW_MODES(K_SH_PARKED1S); PT_ALLOW_MODES(K_SH_PARKED4S); PT_ALLOW_MODES(K_SH_PARKED1W); PT_ALLOW_MODES(K_SH_PARKED4W);
+    PT_ALLOW_MODES(K_SH_ANY1); PT_ALLOW_MODES(K_SH_ANY4); PT_ALLOW_MODES(K_SH_PARKED1); PT_ALLOW_MODES(K_SH_PARKED4); PT_ALLOW_MODES(K_SH_PARKED1E); PT_ALLOW_MODES(K_SH_PARKED1W); PT_ALLOW_MODES(K_SH_PARKED4W);
 #define K_SH_DYN1(M) k_shadow_parked_dyn<M, 1>
 #define K_SH_DYN4(M) k_shadow_parked_dyn<M, 4>
     PT_ALLOW_MODES(K_SH_DYN1); PT_ALLOW_MODES(K_SH_DYN4);

@@ -650,11 +650,11 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
 
 // (LACKS = PT_SCENE_NO_LIGHTS: the light list is empty — hdri_test — so every light-sample ray is an environment ray: the light pre-pass, the
 // light's record and its emission are compiled out)
-// SCAN: rays parallel to an axis of their mesh are scanned by the whole wave (mesh_scan) — the form for scenes whose light samples can pick the
-// environment: the sample at the pole of the map is such a ray, 1.5 in 10 000 of C4's, each of them 8000 box tests long when walked.  Where light
-// samples only go to lights, and for closest-hit rays (k_extend_parked), an axis-parallel direction is a coincidence of the scene's set-up; those
-// forms walk it like any other ray and do without the scan's registers (96-VGPR k_extend_parked: 6 spilled with it).
-template <int USE_LDS, int NL, uint32_t LACKS = 0u, bool SCAN = false, int TOP = 0>
+// Rays parallel to an axis of their mesh are scanned by the whole wave (mesh_scan, pt_device.h): the environment sample at the pole of the importance map is such a
+// ray, 1.5 in 10 000 of C4's light samples, each 8000 box tests long when walked.  (The closest-hit kernel, k_extend_parked, walks them: there an axis-parallel
+// direction is a coincidence of the scene's set-up, and the scan's registers cost that 96-VGPR kernel 6 spilled.  Here the form with the scan happens to
+// allocate better than the one without: C3's kernel 4755 -> 4658 us, so every form carries it.)
+template <int USE_LDS, int NL, uint32_t LACKS = 0u, int TOP = 0>
 __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                      uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                                      uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ park_all, uint32_t walk_policy) {
@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
             }
         }
         __builtin_amdgcn_wave_barrier();
-        park_drain<SCAN>(pk, park_count, r == rounds && live_count == 0u, SCAN ? walk_policy : walk_policy & ~PT_WALK_SCAN_AXIS, resume_parked);
+        park_drain<true>(pk, park_count, r == rounds && live_count == 0u, walk_policy, resume_parked);
     }
     PT_TL_END(n);
     __threadfence_block();
