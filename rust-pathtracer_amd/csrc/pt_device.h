@@ -1064,7 +1064,9 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
             F4 a = mf4(s, node_off + i * PT_NODE_WORDS), b = mf4(s, node_off + i * PT_NODE_WORDS + 4);
             uint32_t exit_i = PT_NODE_EXIT(pt_f2u(a.w)), shape = pt_f2u(b.w);
             float entry;
-            bool box = aabb_hit_node(a, b, cr, walk_quick, &entry) && !(cull && beyond(entry, limit, cr.base));
+            // (a ray the filtered test does not take — a zero direction component that was not scanned, magnitudes out of range — goes to the exact test at once:
+            // the per-axis filtered form stays out of this loop)
+            bool box = (walk_quick ? aabb_hit_node(a, b, cr, true, &entry) : aabb_hit_exact(a, b, lo, ld, &entry)) && !(cull && beyond(entry, limit, cr.base));
             if (shape == PT_NODE_INNER) i = box ? i + 1 : exit_i;
             else { i = exit_i; if (box) pending = shape; }
             if (search_below != 0u) { const uint32_t searching = PT_WAVE_ACTIVE(1u); if (searching < search_below && searching < walking) break; }
