@@ -121,7 +121,8 @@ def price(walks, order, **policy):
 rng = np.random.default_rng(1)
 for kernel, kinds in (("k_extend_parked (closest hit)", "C"), ("k_shadow_parked (light + environment rays)", "LE")):
     walks = [segments(s) for s in seqs if s[0] in kinds]
-    if len(walks) < 640:
+    if len(walks) < 128:
+        print("%s: only %d walks traced (a bigger frame: the second argument)" % (kernel, len(walks)))
         continue
     walks = walks[: min(len(walks), 64 * 400)]
     n = len(walks) // 64 * 64
