@@ -13,18 +13,18 @@
 
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
-enum Kind { K_FMA, K_PK_FMA, K_MAX3, K_MIN, K_CMP_CNDMASK, K_RCP, K_FMA64, K_MUL_HI_U32, K_AND_OR, K_MAD_U32_U24, K_MUL_F32_SGPR, K_DS_READ_B128, K_MIX_SALU, K_ADD, K_MUL, K_FMAC, K_FMA_SGPR, K_FMA_LIT, K_MAX, K_CNDMASK, K_CMP, K_MOV, K_LSHL, K_XOR, K_CVT, K_MIX_FMA_MIN, K_BPERMUTE, K_DS_READ_B32_SPREAD, K_READFIRSTLANE, K_COUNT };
+enum Kind { K_FMA, K_PK_FMA, K_MAX3, K_MIN, K_CMP_CNDMASK, K_RCP, K_FMA64, K_MUL_HI_U32, K_AND_OR, K_MAD_U32_U24, K_MUL_F32_SGPR, K_DS_READ_B128, K_MIX_SALU, K_ADD, K_MUL, K_FMAC, K_FMA_SGPR, K_FMA_LIT, K_MAX, K_CNDMASK, K_CMP, K_MOV, K_LSHL, K_XOR, K_CVT, K_MIX_FMA_MIN, K_BPERMUTE, K_DS_READ_B32_SPREAD, K_READFIRSTLANE, K_MAD_U64_U32, K_MUL_LO_U32, K_COUNT };
 static const char* kNames[K_COUNT] = {"v_fma_f32", "v_pk_fma_f32 (2 fma per lane)", "v_max3_f32", "v_min_f32", "v_cmp_lt_f32 + v_cndmask_b32 (pair)", "v_rcp_f32",
                                       "v_fma_f64", "v_mul_hi_u32", "v_and_or_b32", "v_mad_u32_u24", "v_mul_f32 with SGPR operand", "ds_read_b128 (same address: broadcast)",
-                                      "v_fma_f32 + s_add_u32 (1:1)", "v_add_f32", "v_mul_f32", "v_fmac_f32", "v_fma_f32 with SGPR operand", "v_fma_f32 with literal", "v_max_f32", "v_cndmask_b32 (vcc fixed)", "v_cmp_lt_f32 (to vcc)", "v_mov_b32", "v_lshlrev_b32", "v_xor_b32", "v_cvt_f32_u32", "v_fma_f32 + v_min_f32 (1:1; counted as 2)", "ds_bpermute_b32", "ds_read_b32 (lane-strided addresses)", "v_readfirstlane_b32"};
+                                      "v_fma_f32 + s_add_u32 (1:1)", "v_add_f32", "v_mul_f32", "v_fmac_f32", "v_fma_f32 with SGPR operand", "v_fma_f32 with literal", "v_max_f32", "v_cndmask_b32 (vcc fixed)", "v_cmp_lt_f32 (to vcc)", "v_mov_b32", "v_lshlrev_b32", "v_xor_b32", "v_cvt_f32_u32", "v_fma_f32 + v_min_f32 (1:1; counted as 2)", "ds_bpermute_b32", "ds_read_b32 (lane-strided addresses)", "v_readfirstlane_b32", "v_mad_u64_u32 (32x32+64 -> 64)", "v_mul_lo_u32"};
 
 template <int KIND>
 __global__ void __launch_bounds__(256) k_issue(int iters, float seed, float* out, unsigned long long* cycles) {
     __shared__ float4 lds_data[64];
     if (threadIdx.x < 64) lds_data[threadIdx.x] = make_float4(seed, seed, seed, seed);
     __syncthreads();
-    float a[16]; double dd[16]; uint32_t u[16]; float2 p[16];
-    for (int i = 0; i < 16; ++i) { a[i] = seed + (float)i + (float)threadIdx.x; dd[i] = a[i]; u[i] = (uint32_t)(a[i] * 1000.0f); p[i] = make_float2(a[i], a[i] + 1.0f); }
+    float a[16]; double dd[16]; uint32_t u[16]; float2 p[16]; unsigned long long uu[16];
+    for (int i = 0; i < 16; ++i) { a[i] = seed + (float)i + (float)threadIdx.x; dd[i] = a[i]; u[i] = (uint32_t)(a[i] * 1000.0f); uu[i] = u[i]; p[i] = make_float2(a[i], a[i] + 1.0f); }
     float b = seed * 0.5f + 1.0f, c = seed * 0.25f;
     double db = b, dc = c;
     uint32_t sacc = 0;
@@ -151,11 +151,19 @@ __global__ void __launch_bounds__(256) k_issue(int iters, float seed, float* out
 #define X(i) asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sacc) : "v"(u[i]));
             REP16(X) REP16(X)
 #undef X
+        } else if (KIND == K_MAD_U64_U32) {   // (what the compiler makes of Philox's (uint64_t)M * c: one instruction for both halves)
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(uu[i]) : "v"(u[i]), "v"(u[(i + 1) & 15]) : "vcc");
+            REP16(X) REP16(X)
+#undef X
+        } else if (KIND == K_MUL_LO_U32) {
+#define X(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 15]));
+            REP16(X) REP16(X)
+#undef X
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
     float r = 0.0f;
-    for (int i = 0; i < 16; ++i) r += a[i] + (float)dd[i] + (float)u[i] + p[i].x + p[i].y;
+    for (int i = 0; i < 16; ++i) r += a[i] + (float)dd[i] + (float)u[i] + p[i].x + p[i].y + (float)uu[i];
     r += ld[0].x + ld[1].y + ld[2].z + ld[3].w + (float)sacc;
     if (r == 12345.678f) out[0] = r;  // keep everything alive
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
@@ -221,6 +229,8 @@ int main() {
         run<K_BPERMUTE>(cus, w, iters, d_out, d_cycles);
         run<K_DS_READ_B32_SPREAD>(cus, w, iters, d_out, d_cycles);
         run<K_READFIRSTLANE>(cus, w, iters, d_out, d_cycles);
+        run<K_MAD_U64_U32>(cus, w, iters, d_out, d_cycles);
+        run<K_MUL_LO_U32>(cus, w, iters, d_out, d_cycles);
         printf("\n");
     }
     return 0;
