@@ -47,7 +47,7 @@
 #define PT_WAVE_ACTIVE(host_value) (host_value)
 #define PT_WAVE_BALLOT(x) ((x) ? 1ull : 0ull)
 #define PT_WAVE_RANK(mask) 0u
-#define PT_WAVE_READ(x, lane) ((uint32_t)(x))
+#define PT_WAVE_READ(x, lane) ((void)(lane), (uint32_t)(x))
 #endif
 
 // A loop the compiler must keep rolled (the per-wavelength loops of the hero variant: four inlined copies of a curve evaluation cost

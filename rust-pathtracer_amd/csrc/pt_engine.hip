@@ -536,6 +536,7 @@ uint32_t pt_device_count(void) {
     return (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? (uint32_t)n : 0u;
 }
 
+extern "C++" {   // (C++ helpers inside the extern "C" region of the API functions)
 // RCCL, bound on first use: a single-process render pays nothing for it, and the library loads on machines without it.
 namespace {
 struct Rccl {
@@ -564,6 +565,7 @@ Rccl& rccl() {
     return r;
 }
 }  // namespace
+}  // extern "C++"
 
 // dst += src over n float4 pixels: the films of the virtual devices that share one physical device (pt_tuning::multi_virtual)
 __global__ void __launch_bounds__(kBlock) k_film_add(float4* __restrict__ dst, const float4* __restrict__ src, size_t n) {
