@@ -8,6 +8,7 @@ import ctypes as C
 import numpy as np
 
 PT_OK = 0
+PT_ERR_UNSUPPORTED = 4   # pt_status, include/pt_api.h
 TAG_MATERIAL, TAG_LIGHT, TAG_CAMERA = 0, 1, 2
 MATERIAL_NONE = 0xFFFFFFFF
 
@@ -244,6 +245,8 @@ class Library:
 
     def tuning_default(self):
         t = Tuning()
+        if self._tuning_default is None:
+            raise PtError(PT_ERR_UNSUPPORTED, "this library does not export %stuning_default (pt_tuning is the HIP engine's)" % self.prefix)
         self._tuning_default(C.byref(t))
         return t
 
@@ -290,6 +293,8 @@ class Scene:
         self._keep = keep
         handle = C.c_void_p()
         if tuning is not None:
+            if library._scene_create_tuned is None:
+                raise PtError(PT_ERR_UNSUPPORTED, "this library does not export %sscene_create_tuned (pt_tuning is the HIP engine's)" % library.prefix)
             library.check(library._scene_create_tuned(C.byref(desc), C.byref(tuning), C.byref(handle)))
         else:
             library.check(library._scene_create(C.byref(desc), C.byref(handle)))

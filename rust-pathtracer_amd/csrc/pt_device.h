@@ -795,7 +795,9 @@ PT_HD void mesh_scan(const SceneView& s, uint32_t inst, uint32_t node_off, uint3
             m &= m - 1ull;
             const float tsj = pt_u2f(PT_WAVE_READ(pt_f2u(ts), j)), detj = pt_u2f(PT_WAVE_READ(pt_f2u(det), j));
             if (detj < 0.0f ? tsj < *closest * detj : tsj > *closest * detj) continue;   // (beyond the closest hit so far: triangle_outside's second half)
-            *closest = pt_u2f(PT_WAVE_READ(pt_f2u(t), j));
+            const float tj = pt_u2f(PT_WAVE_READ(pt_f2u(t), j));
+            if (tj > bound) continue;   // (behind the light that bounds this search: the walk culls such leaves by min(closest, bound) where it can; the answer — is the closest hit a light — is the same either way, round-3 advisor)
+            *closest = tj;
             *best_triw = PT_WAVE_READ(triw, j);
             if (stop == PT_STOP_ANY) { *stopped = true; return; }
             if (stop == PT_STOP_NONLIGHT && *closest < bound) {
@@ -1168,7 +1170,11 @@ PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, S
     const uint32_t k = alive ? ctz64(st.hit) : 0u;
     const F4 be = bf4(s, bu(s, PT_HDR_SWEEP_BITS_OFF) + k * PT_SWEEP_BIT_WORDS);
     uint32_t inst = pt_f2u(be.x);
-    if (!alive) inst = PT_WAVE_READ(inst, ctz64(PT_WAVE_BALLOT(alive)));   // (mesh_walk: a lane that only helps; some lane of the wave is alive)
+    {   // (mesh_walk: a lane that only helps takes the instance of the first lane that has a ray; some lane of the wave has one.  The broadcast
+        // runs in uniform control flow: a readlane of a lane that is inactive at that point returns an unspecified value.)
+        const uint32_t lead = PT_WAVE_READ(inst, ctz64(PT_WAVE_BALLOT(alive)));
+        inst = alive ? inst : lead;
+    }
     if (mesh_walk(s, inst, pt_f2u(be.w) >> 16, o, d, bound, stop, st, cursor, policy, alive)) return true;
     if (!alive) return false;
     if (cursor != nullptr) *cursor = 0u;
@@ -1235,7 +1241,10 @@ PT_HD bool top_walk_resume(const SceneView& s, F3 o, F3 d, float bound, int stop
     const uint32_t at = alive ? (uint32_t)st.hit - 1u : 0u;
     const F4 a = bf4(s, top_off + at * PT_NODE_WORDS), b = bf4(s, top_off + at * PT_NODE_WORDS + 4);
     uint32_t shape = pt_f2u(b.w);
-    if (!alive) shape = PT_WAVE_READ(shape, ctz64(PT_WAVE_BALLOT(alive)));   // (a lane that only helps: with the instance of one that has a ray)
+    {   // (a lane that only helps: with the instance of the first lane that has a ray — broadcast in uniform control flow, see sweep_resume)
+        const uint32_t lead = PT_WAVE_READ(shape, ctz64(PT_WAVE_BALLOT(alive)));
+        shape = alive ? shape : lead;
+    }
     const uint64_t place = st.hit;
     st.hit = (uint64_t)PT_NODE_EXIT(pt_f2u(a.w)) + 1ull;
     if (mesh_walk(s, inst_off + shape * PT_INST_WORDS, shape, o, d, bound, stop, st, cursor, policy, alive)) { st.hit = place; return true; }

@@ -434,7 +434,10 @@ static pt_status scene_to_device(pt_scene* sc) {
         bool any_xf = false;
         const std::vector<uint32_t>& bl = sc->host.blob;
         for (uint32_t i = 0; i < bl[PT_HDR_INSTANCE_COUNT]; ++i) any_xf = any_xf || (bl[bl[PT_HDR_INSTANCE_OFF] + i * PT_INST_WORDS + PT_INST_FLAGS] & 1u) != 0u;
-        sc->lacks = (tn.flags & PT_TUNE_GENERAL_FORMS) ? 0u : ((any_xf ? 0u : PT_SCENE_NO_XF) | (bl[PT_HDR_LIGHT_COUNT] == 0u ? PT_SCENE_NO_LIGHTS : 0u));
+        // "no lights" = no hit can carry a Light tag: the light list is empty AND no mesh instance overrides its material with a light
+        // (such a mesh is not in the light list, world/mod.rs:45-54, but its hits emit and take no light samples: PT_FLAG_NO_SHADOW_BOUND)
+        const bool no_light_hits = bl[PT_HDR_LIGHT_COUNT] == 0u && !(bl[PT_HDR_FLAGS] & PT_FLAG_NO_SHADOW_BOUND);
+        sc->lacks = (tn.flags & PT_TUNE_GENERAL_FORMS) ? 0u : ((any_xf ? 0u : PT_SCENE_NO_XF) | (no_light_hits ? PT_SCENE_NO_LIGHTS : 0u));
     }
     const bool no_lds = (tn.flags & PT_TUNE_NO_LDS) != 0;
     const uint32_t all_limit = tuned(tn.lds_all_limit, kLdsAllLimitBytes);   // (experiments: the largest blob staged whole)
@@ -485,6 +488,9 @@ pt_status pt_scene_create_tuned(const pt_scene_desc* desc, const pt_tuning* tuni
     for (uint32_t r : tuning->reserved) if (r != 0) return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning::reserved must be 0");
     if (tuning->shade_form > 2 || tuning->park_dynamic < -1 || tuning->park_dynamic > 1 || tuning->multi_virtual > 64 || tuning->walk_evict_below > 64 || tuning->walk_search_below > 64)
         return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning: shade_form in 0..2, park_dynamic in -1..1, multi_virtual, walk_evict_below, walk_search_below <= 64");
+    // the tiled queue index (pt_stages.h qtile) multiplies in 32 bits: capacity <= 2^30; the grids are num_cus * blocks in an int
+    if (tuning->batch_slots > (1u << 30) || tuning->blocks_per_cu > 1024u || tuning->park_blocks_per_cu > 1024u)
+        return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning: batch_slots (PT_AMD_BATCH) <= 2^30, blocks_per_cu and park_blocks_per_cu <= 1024");
     pt_status st = ensure_device();
     if (st != PT_OK) return st;
     pt_scene* sc = new pt_scene();

@@ -233,7 +233,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                 out.add_energy = true;
             }
         }
-    } else if (rp.light_samples > 0) {
+    } else if (rp.light_samples > 0 && PT_MATERIAL_TAG(hit.material) != PT_TAG_LIGHT) {   // (the second test: exactly the vertices shade_wants_item reserved an item for, whatever `lacks` folded above)
         // pt.rs:562-604 -> estimate_direct_illumination_with_loop (pt.rs:333-393)
         uint32_t n_lights = (s.lacks & PT_SCENE_NO_LIGHTS) ? 0u : bu(s, PT_HDR_LIGHT_COUNT);
         float env_p = bf(s, PT_HDR_ENV_PROB);

@@ -753,6 +753,18 @@ def hdri_c4_small():
     return hdri_test(mesh="monkey", hdri_size=(128, 64), importance=(64, 64))
 
 
-SCENES = {"hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
+def hdri_emissive_mesh():
+    """An HDRI environment and a mesh whose *instance* overrides its material with a light (not a reference scene): the mesh is not in the
+    light list (world/mod.rs:45-54 looks at analytic instances' ids and mesh face ids only), so the list is empty — yet its hits carry the
+    Light tag, emit, and take no light samples (pt.rs:512-561).  The kernel forms "without lights" must not be chosen for it."""
+    b = hdri_test(mesh=None, hdri_size=(64, 32), importance=(32, 32))
+    lamp = add_library_material(b, "diffuse_light_flat_x5")
+    p, f, n, mtl = _npz_mesh("gem")
+    m = b.add_mesh(p, f, n, face_materials=api.material_id(api.TAG_MATERIAL, 0))
+    b.add_mesh_instance(m, lamp, transform_from_data(scale=(0.5, 0.5, 0.5), translate=(-0.6, 1.5, -0.1)))
+    return b
+
+
+SCENES = {"hdri_emissive_mesh": hdri_emissive_mesh, "hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
           "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test, "panorama_test": panorama_test, "empty_env": empty_env,
           "big_sphere_light": big_sphere_light, "fog_ball": fog_ball}

@@ -72,6 +72,8 @@ def test_materials_bit_exact(engine, oracle, scene):
     ("cornell_box", 3, 2, 1, 1, {"tile": (64, 64)}),          # film smaller than a tile
     ("white_furnace", 32, 32, 12, 8, {"light_samples": 6}),
     ("hdri_small", 64, 64, 8, 4, {"light_samples": 6}),
+    ("hdri_emissive_mesh", 96, 96, 8, 4, {"light_samples": 3}),     # empty light list, but a mesh instance overridden with a light material (round-3 advisor): its hits emit, take no item
+    ("hdri_emissive_mesh", 64, 64, 6, 4, {"light_samples": 2, "hero_wavelengths": 4}),
     ("cornell_box", 128, 128, 12, 8, {"hero_wavelengths": 4}),      # C5 shape: four wavelengths per path
     ("cornell_gem", 64, 48, 6, 12, {"hero_wavelengths": 4}),
     ("hdri_small", 48, 48, 6, 4, {"hero_wavelengths": 4, "light_samples": 3}),
@@ -245,7 +247,7 @@ def test_hero_wavelengths_through_every_parked_form(engine, pkg, monkeypatch, sc
         assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits), env
 
 
-@pytest.mark.parametrize("scene,L,hero", [("cornell_box", 2, 1), ("cornell_box", 3, 4), ("white_furnace", 6, 1), ("hdri_small", 3, 1)])
+@pytest.mark.parametrize("scene,L,hero", [("cornell_box", 2, 1), ("cornell_box", 3, 4), ("white_furnace", 6, 1), ("hdri_small", 3, 1), ("hdri_emissive_mesh", 3, 1)])
 def test_forms_without_transforms_change_nothing(engine, pkg, monkeypatch, scene, L, hero):
     """A scene in which no instance carries a transform (the Cornell box) runs kernel forms with the matrix paths compiled out
     (PT_SCENE_NO_XF: k_extend / k_shadow in their sweep forms, the lean k_shade).  The general forms (PT_AMD_GENERAL_FORMS=1) give the same
