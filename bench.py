@@ -15,6 +15,15 @@ with one RCCL reduce (disjoint shards, so the sum is a gather) inside the timed 
 
 Prints ONE JSON line on rank 0 with `roofline` (HIP-event time of the dominant kernel, measured inside the timed
 region by the engine) and `cpu_baseline` (the oracle on the host cores, bounded sample).
+
+`--gpus N` is what runs.  Under a launcher (WORLD_SIZE set) it must equal WORLD_SIZE or the run stops with exit code 2.  Without one and
+N > 1, this process — which makes no GPU call and does not import torch — starts the N ranks as fresh child processes
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...  bench.py <the same arguments>`), relays rank
+0's record as its own single line of stdout (everything else the ranks print goes to stderr) and exits with the launcher's code; a
+record whose `n_gpus` / `ranks_seen` is not N is an error (exit code 4), as is a rank without a GPU of its own (`--allow-shared-gpus`
+lets ranks share a device: the one-GPU tests).  For N > 1 the record also carries `strong`: the fixed BASELINE frames (C2: Cornell
+1024 x 1024 x 1024 spp; C4: hdri_test 1024 x 1024 x 2048 spp, L = 6) dealt over the N ranks, one RCCL reduce each, with ms per frame,
+Msamples/s, the reduce's share and the set-up time (`--strong-legs` adds them to a one-GPU run too).
 """
 import argparse
 import importlib
@@ -73,6 +82,49 @@ def algorithmic_bytes(stage, light_samples):
     return 16 * 2                                 # accumulate: film pixel read-modify-write (energy reads are per sample, added below)
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher, N > 1: start the N ranks as fresh children and relay rank 0's record.  This process
+    never touches the GPU (no torch import, no HIP call): the children are the first to initialise it."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    if os.environ.get("PT_BENCH_LAUNCHER"):        # tests: a stand-in for torch.distributed.run (a JSON list; it gets the script and its arguments appended)
+        launcher = json.loads(os.environ["PT_BENCH_LAUNCHER"])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env["PT_BENCH_PARENT"] = str(os.getpid())
+    child = subprocess.Popen(launcher + [os.path.abspath(__file__)] + list(argv), stdout=subprocess.PIPE, env=env, text=True)
+    record = None
+    for line in child.stdout:                      # the ranks' stdout: keep rank 0's record, pass everything else on to stderr
+        text = line.strip()
+        if text.startswith("{") and '"metric"' in text:
+            try:
+                if record is not None:
+                    sys.stderr.write(json.dumps(record) + "\n")
+                record = json.loads(text)
+                continue
+            except ValueError:
+                pass
+        sys.stderr.write(line)
+    code = child.wait()
+    sys.stderr.flush()
+    if code != 0:
+        sys.stderr.write("bench.py: the launcher of %d ranks exited with code %d\n" % (args.gpus, code))
+        return code
+    if record is None:
+        sys.stderr.write("bench.py: %d ranks ran and none printed a record\n" % args.gpus)
+        return 3
+    if record.get("n_gpus") != args.gpus or record.get("ranks_seen") != args.gpus:
+        sys.stderr.write("bench.py: asked for %d GPUs, the record says n_gpus = %r, ranks_seen = %r\n" % (args.gpus, record.get("n_gpus"), record.get("ranks_seen")))
+        return 4
+    record["launched_by"] = "bench.py --gpus %d: parent without GPU calls -> %s" % (args.gpus, " ".join(launcher[1:4] if launcher[0] == sys.executable else launcher[:1]))
+    print(json.dumps(record), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +143,23 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every GPU renders 1/N of the pixels at N x --spp-per-step (per-GPU work fixed); strong: the frame is fixed at --spp-per-step, its tiles dealt over the N GPUs")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl = RCCL) even for one process, so that the film reduce runs through RCCL")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend: nccl = RCCL over xGMI (the product's); gloo only for tests that put two ranks on one GPU, which RCCL refuses")
+    ap.add_argument("--allow-shared-gpus", action="store_true", help="let ranks share a physical GPU (tests on a one-GPU box); by default a rank without a device of its own is an error")
+    ap.add_argument("--strong-legs", action="store_true", help="add the fixed-frame (strong scaling) legs of C2 and C4 to the record also with one GPU (they always run with N > 1)")
+    ap.add_argument("--no-strong-legs", action="store_true", help="skip them")
+    ap.add_argument("--strong-frames", type=int, default=3, help="timed frames per strong-scaling leg (after one warm-up frame)")
+    ap.add_argument("--strong-spp-div", type=int, default=1, help="divide the legs' samples per pixel (C2 1024, C4 2048) by this: tests")
     args = ap.parse_args()
+
+    # ---- how many GPUs: --gpus is what runs.  No launcher and N > 1: be the launcher.  A launcher that disagrees: stop.
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE = %s ranks; refusing to report either number\n" % (args.gpus, env_world))
+        sys.exit(2)
 
     import numpy as np
     import torch
@@ -102,7 +170,11 @@ def main():
     rank, local_rank, world = sharding.rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    device_index = local_rank % max(1, torch.cuda.device_count())  # (a launcher that exposes one GPU per process shows it as device 0)
+    n_devices = torch.cuda.device_count()
+    if local_rank >= n_devices and n_devices != 1 and not args.allow_shared_gpus:
+        # (n_devices == 1 with several ranks: a launcher that exposes one GPU per process shows each its own as device 0 — told apart below by the bus ids)
+        raise SystemExit("bench.py: rank %d (local rank %d) has no GPU of its own: %d device(s) visible, %d ranks (--allow-shared-gpus to share)" % (rank, local_rank, n_devices, world))
+    device_index = local_rank % max(1, n_devices)
     torch.cuda.set_device(device_index)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -110,12 +182,35 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend="gloo")
     n_gpus = world
+    # who is really there: ranks counted by an all-reduce, physical devices by their PCI bus ids (ranks that share one count once)
+    ranks_seen = int(round(sharding.sum_over_ranks([1.0], "cuda")[0]))
+    try:
+        bus_id = int(torch.cuda.get_device_properties(device_index).pci_bus_id) + 256 * int(torch.cuda.get_device_properties(device_index).pci_domain_id)
+    except (AttributeError, TypeError, ValueError):
+        bus_id = device_index
+    if use_dist:
+        ids = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([bus_id], dtype=torch.int64, device="cuda"))
+        physical_gpus = len({int(t.item()) for t in ids})
+    else:
+        physical_gpus = 1
+    if physical_gpus < world and not args.allow_shared_gpus:
+        raise SystemExit("bench.py: %d ranks on %d physical GPU(s) (--allow-shared-gpus to share)" % (world, physical_gpus))
+    try:
+        rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        rccl_version = None
 
     engine = pkg.load()
+    t_create = time.perf_counter()
     builder = pkg.scene.SCENES[args.scene]()
     scene = engine.create_scene(builder)
+    scene_create_ms = 1e3 * (time.perf_counter() - t_create)
 
     W, H, L = args.width, args.height, args.light_samples
     # weak scaling: N x the samples on 1/N of the pixels; strong scaling: the frame's own samples on 1/N of the pixels
@@ -147,6 +242,58 @@ def main():
     sharding.reduce_film(film_total, dst=0)                      # RCCL over xGMI: the only exchange step
     sync()
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, "cuda")
+
+    # ---- the fixed BASELINE frames dealt over the N ranks (strong scaling): after the timed region of `value`, with their own clocks
+    def strong_leg(name, leg_scene, create_ms, spp, max_bounces, min_bounces, light_samples, hero):
+        """One whole frame per step, whatever N is: this rank's tiles of it, then the RCCL reduce.  Per frame: [barrier] render the shard
+        [device sync: this rank's render time] [barrier] reduce [device sync, barrier] — so the reduce is timed free of the wait for the
+        slowest rank, and the ranks' own render times show the load balance of the tile deal."""
+        film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+
+        def frame(k):
+            rd = pkg.api.render_desc(W, H, spp, max_bounces, min_bounces=min_bounces, light_samples=light_samples, seed=1 + k,
+                                     shard=sharding.shard(rank, n_gpus), hero_wavelengths=hero)
+            t = time.perf_counter()
+            prof = leg_scene.render_device(rd, film.data_ptr(), stream)
+            torch.cuda.synchronize()
+            t_render = time.perf_counter() - t
+            if use_dist:
+                dist.barrier()
+            t = time.perf_counter()
+            sharding.reduce_film(film, dst=0)
+            sync()
+            return prof, t_render, time.perf_counter() - t
+
+        sync()
+        t = time.perf_counter()
+        frame(0)                                   # warm-up: queue buffers of this film / light-sample count, first-use work
+        first_ms = 1e3 * sharding.max_over_ranks(time.perf_counter() - t, "cuda")
+        sync()
+        t = time.perf_counter()
+        res = [frame(1 + k) for k in range(args.strong_frames)]
+        total = sharding.max_over_ranks(time.perf_counter() - t, "cuda")
+        render_max = sharding.max_over_ranks(sum(r[1] for r in res), "cuda")
+        render_min = -sharding.max_over_ranks(-sum(r[1] for r in res), "cuda")
+        reduce_s = sharding.max_over_ranks(sum(r[2] for r in res), "cuda")
+        cam = sharding.sum_over_ranks([sum(r[0].camera_rays for r in res)], "cuda")[0]
+        f = float(args.strong_frames)
+        return {"frame": name, "width": W, "height": H, "spp": spp, "max_bounces": max_bounces, "light_samples": light_samples, "n_gpus": n_gpus, "frames": args.strong_frames,
+                "ms_per_frame": 1e3 * total / f, "value": cam / total / 1e6, "unit": "Msamples/s", "samples_per_frame": cam / f,
+                "render_ms_slowest_rank": 1e3 * render_max / f, "render_ms_fastest_rank": 1e3 * render_min / f, "reduce_ms": 1e3 * reduce_s / f,
+                "film_bytes_reduced": W * H * 16, "setup_ms": create_ms + first_ms, "setup": {"scene_create_ms": create_ms, "first_frame_ms": first_ms}}
+
+    strong = None
+    if (world > 1 or args.strong_legs) and not args.no_strong_legs:
+        div = max(1, args.strong_spp_div)
+        c2_scene, c2_ms = (scene, scene_create_ms)
+        if args.scene != "cornell_box":
+            t = time.perf_counter(); c2_scene = engine.create_scene(pkg.scene.SCENES["cornell_box"]()); c2_ms = 1e3 * (time.perf_counter() - t)
+        strong = {"C2": strong_leg("C2: Cornell box, max_bounces 8, L = 2", c2_scene, c2_ms, max(1, 1024 // div), 8, 1, 2, 1)}
+        t = time.perf_counter(); c4_scene = engine.create_scene(pkg.scene.SCENES["hdri_test"]()); c4_ms = 1e3 * (time.perf_counter() - t)
+        strong["C4"] = strong_leg("C4: hdri_test (sphere + monkey mesh under the synthetic HDRI), max_bounces 4, L = 6", c4_scene, c4_ms, max(1, 2048 // div), 4, 1, 6, 1)
+        strong["note"] = ("total work fixed: one BASELINE frame per step, its 32x32 tiles dealt along diagonals over the N ranks, one RCCL reduce of the whole XYZ film per frame; "
+                          "ms_per_frame = wall time barrier to barrier, max over ranks; setup_ms (scene build + upload + first frame's allocations) is outside it, "
+                          "as parsing and BVH build are outside the reference's own window (tiled.rs:294 -> 536)")
 
     # whole-job units: every rank rendered (pixels / N) x (S = spp_per_step x N) samples per step
     shard_pixels = sum(p.stage_items[4] for p in profs) / max(1, len(profs))
@@ -261,9 +408,24 @@ def main():
                                                "source": "data/config.toml:4-8 of the reference (its author's machine, CPU not named)",
                                                "as_Msamples_per_s_at_this_rays_per_sample": REFERENCE_SELF_REPORTED_MRAYS / rays_per_sample if rays_per_sample else None}}
 
+        # ---- the checker next to the number: a smoke-size render of this scene, engine against oracle at the same seed, under the bars the
+        # parity tests use (tests/parity_suite.py: L-inf < 1e-4 flat; a pixel whose own 8 ulp exceed that — values above ~128 — gets those)
+        parity = None
+        if args.cpu_seconds > 0:
+            rd = pkg.api.render_desc(64, 64, 4, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, hero_wavelengths=args.hero)
+            gfilm, gprof = scene.render(rd)
+            ofilm, oprof = oscene.render(rd)
+            ok = np.isfinite(ofilm[..., :3]) & np.isfinite(gfilm[..., :3])
+            d = np.where(ok, np.abs(gfilm[..., :3].astype(np.float64) - ofilm[..., :3].astype(np.float64)), 0.0)
+            parity = {"render": "%s 64x64, 4 spp, max_bounces %d, L = %d, seed 1: HIP engine against the CPU oracle (oracle/ptref.cpp; parity unpinned against the Rust reference)" % (args.scene, args.max_bounces, L),
+                      "film_linf": float(d.max()), "film_rel": float((d / np.maximum(np.abs(ofilm[..., :3]), 1e-6)).max()), "film_linf_bar": 1e-4,
+                      "pixels_over_flat_bar": int((d > 1e-4).any(axis=-1).sum()), "non_finite_mismatch": int((np.isfinite(ofilm) != np.isfinite(gfilm)).sum()),
+                      "counters_equal": (gprof.camera_rays, gprof.bounce_rays, gprof.shadow_rays, gprof.env_hits) == (oprof.camera_rays, oprof.bounce_rays, oprof.shadow_rays, oprof.env_hits)}
+
         out = {
             "metric": metric_name,
-            "value": value, "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "Msamples/s", "n_gpus": n_gpus, "ranks_seen": ranks_seen, "physical_gpus": physical_gpus, "rccl_version": rccl_version, "backend": (args.backend if use_dist else None),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload or ("C2: Cornell box (authored mesh + reference light/camera), %dx%d, PT+NEE, max_bounces=%d, min_bounces=1, "
@@ -279,7 +441,7 @@ def main():
             "rays_per_s": {"segments": counts[2] / elapsed, "shadow": counts[7] / elapsed,
                            "total_Mrays": (counts[2] + counts[7]) / elapsed / 1e6},
             "segments_per_sample": counts[2] / total_samples,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "strong": strong, "parity": parity,
         }
     else:
         out = None

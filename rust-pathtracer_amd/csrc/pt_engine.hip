@@ -263,7 +263,12 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     const bool parked_walk = !sweep && b.park != nullptr && !(tn.flags & PT_TUNE_NO_PARK);
     // PT_AMD_POOL=1: phase 3 of a pure sweep scene pooled per wave (sweep_run_pooled).  Bit-identical, but measured slower than the lane
     // loop on MI355X (C2: k_extend 3155 vs 2475 us, k_shadow 5421 vs 4677 us; DESIGN.md section 5 has the breakdown), so it is not the default.
-    const bool pooled = sweep && !walks && mode == PT_LDS_ALL && lds_bytes + pool_lds_bytes() <= kLdsBlobLimitBytes && (tn.flags & PT_TUNE_POOL) != 0;
+#ifdef PT_EXPERIMENTS
+#define PT_TUNE_EXPERIMENT_POOL (1u << 3)   /* pt_tuning::flags bit the public header leaves unnamed */
+    const bool pooled = sweep && !walks && mode == PT_LDS_ALL && lds_bytes + pool_lds_bytes() <= kLdsBlobLimitBytes && (tn.flags & PT_TUNE_EXPERIMENT_POOL) != 0;
+#else
+    const bool pooled = false;   // (the pooled kernels are not in the product: make EXTRA=-DPT_EXPERIMENTS builds them, PT_AMD_POOL=1 selects them there)
+#endif
     // (walked meshes in line under PT_AMD_NO_PARK, and every partly staged or unstaged blob: the run-time choice of PT_FORM_ANY)
     const int trav_form = parked ? PT_FORM_PARKED : parked_walk ? PT_FORM_PARKED_WALK : (mode != PT_LDS_ALL || (sweep && walks)) ? PT_FORM_ANY : pooled ? PT_FORM_POOLED : sweep ? PT_FORM_SWEEP : PT_FORM_WALK;
     // The parked kernels take units of work from a counter, a few persistent workgroups per CU, when the whole blob is staged in LDS
@@ -461,7 +466,11 @@ void pt_tuning_default(pt_tuning* t) {
     if (!t) return;
     memset(t, 0, sizeof(*t));
     const struct { const char* name; uint32_t bit; } flags[] = {
-        {"PT_AMD_NO_LDS", PT_TUNE_NO_LDS}, {"PT_AMD_NO_CORE_LDS", PT_TUNE_NO_CORE_LDS}, {"PT_AMD_NO_PARK", PT_TUNE_NO_PARK}, {"PT_AMD_POOL", PT_TUNE_POOL},
+        {"PT_AMD_NO_LDS", PT_TUNE_NO_LDS}, {"PT_AMD_NO_CORE_LDS", PT_TUNE_NO_CORE_LDS}, {"PT_AMD_NO_PARK", PT_TUNE_NO_PARK},
+#ifdef PT_EXPERIMENTS
+        {"PT_AMD_POOL", PT_TUNE_EXPERIMENT_POOL},
+#endif
+
         {"PT_AMD_EXACT_SLAB", PT_TUNE_EXACT_SLAB}, {"PT_AMD_NO_CULL", PT_TUNE_NO_CULL}, {"PT_AMD_NO_SWEEP", PT_TUNE_NO_SWEEP}, {"PT_AMD_NO_MESH_SWEEP", PT_TUNE_NO_MESH_SWEEP},
         {"PT_AMD_NO_KNOWN_LIGHT", PT_TUNE_NO_KNOWN_LIGHT}, {"PT_AMD_GENERAL_FORMS", PT_TUNE_GENERAL_FORMS}, {"PT_AMD_NO_FUSE", PT_TUNE_NO_FUSE}, {"PT_AMD_MULTI_RCCL", PT_TUNE_MULTI_RCCL}, {"PT_AMD_NO_AXIS_SCAN", PT_TUNE_NO_AXIS_SCAN}};
     for (const auto& f : flags) if (env_u32(f.name, 0)) t->flags |= f.bit;

@@ -4,7 +4,9 @@
 
 namespace ptk {
 
+#ifdef PT_EXPERIMENTS
 uint32_t pool_lds_bytes() { return (kBlock / 64) * PT_POOL_WORDS * 4u; }
+#endif
 
 #define PT_GO(K, ...) go(c, K, __VA_ARGS__)
 #define PT_BY_MODE(K, ...) do { if (c.lds_mode == PT_LDS_ALL) PT_GO(K(PT_LDS_ALL), __VA_ARGS__); else if (c.lds_mode == PT_LDS_CORE) PT_GO(K(PT_LDS_CORE), __VA_ARGS__); \
@@ -14,6 +16,7 @@ uint32_t pool_lds_bytes() { return (kBlock / 64) * PT_POOL_WORDS * 4u; }
 #define K_EXT_ANY(M) k_extend<M, PT_TRAV_ANY>
 #define K_PROBE(M) k_probe_intersect<M>
 
+// (PT_FORM_POOLED and the k_*_exp measurement variants: builds with EXTRA=-DPT_EXPERIMENTS only — measured slower, profiles/r2_experiments.md)
 // PT_FORM_WALK / SWEEP / POOLED exist for the fully staged blob only (the engine asks for PT_FORM_ANY otherwise)
 void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* count_in, uint32_t* park) {
 #ifdef PT_EXPERIMENTS
@@ -32,7 +35,9 @@ void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, Queue path
         else go(d, K_EXT_PARKED_DYN(PT_LDS_NONE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
     } else if (form == PT_FORM_PARKED_WALK) { PT_BY_MODE(K_EXT_PARKED_W, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
     else if (form == PT_FORM_PARKED) { PT_BY_MODE(K_EXT_PARKED, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
+#ifdef PT_EXPERIMENTS
     else if (form == PT_FORM_POOLED) PT_GO(k_extend_pooled<PT_LDS_ALL>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
+#endif
     else if (form == PT_FORM_SWEEP && (c.lacks & PT_SCENE_NO_XF)) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_SWEEP, PT_SCENE_NO_XF>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
     else if (form == PT_FORM_SWEEP) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
     else if (form == PT_FORM_WALK) PT_GO((k_extend<PT_LDS_ALL, PT_TRAV_WALK>), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
@@ -52,7 +57,9 @@ hipError_t allow_lds_extend(uint32_t bytes) {
     PT_ALLOW_MODES(K_EXT_PARKED_DYN2);
     allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>));
     allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_SWEEP, PT_SCENE_NO_XF>));
+#ifdef PT_EXPERIMENTS
     allow(reinterpret_cast<const void*>(k_extend_pooled<PT_LDS_ALL>));
+#endif
     return worst;
 }
 

@@ -48,10 +48,13 @@ void launch_shadow(const LaunchCfg& c, int form, int nl, bool env, const SceneAr
         else PT_BY_MODE(K_SH_PARKED1, PT_ARGS, park, c.walk_policy);
         PT_TL_BUMP(c.stream);
     }
+#ifdef PT_EXPERIMENTS
     else if (form == PT_FORM_POOLED) {
         if (env) { if (hero) PT_GO((k_shadow_pooled<PT_LDS_ALL, 4, true>), PT_ARGS); else PT_GO((k_shadow_pooled<PT_LDS_ALL, 1, true>), PT_ARGS); }
         else if (hero) PT_GO((k_shadow_pooled<PT_LDS_ALL, 4, false>), PT_ARGS); else PT_GO((k_shadow_pooled<PT_LDS_ALL, 1, false>), PT_ARGS);
-    } else if (form == PT_FORM_SWEEP && (c.lacks & PT_SCENE_NO_XF)) {
+    }
+#endif
+    else if (form == PT_FORM_SWEEP && (c.lacks & PT_SCENE_NO_XF)) {
         if (env) { if (hero) PT_GO((k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, true, PT_SCENE_NO_XF>), PT_ARGS); else PT_GO((k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, true, PT_SCENE_NO_XF>), PT_ARGS); }
         else if (hero) PT_GO((k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, false, PT_SCENE_NO_XF>), PT_ARGS); else PT_GO((k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, false, PT_SCENE_NO_XF>), PT_ARGS);
     } else if (form == PT_FORM_SWEEP) {
@@ -74,8 +77,10 @@ hipError_t allow_lds_shadow(uint32_t bytes) {
     allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, false>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, false>));
     allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, true, PT_SCENE_NO_XF>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, true, PT_SCENE_NO_XF>));
     allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, false, PT_SCENE_NO_XF>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, false, PT_SCENE_NO_XF>));
+#ifdef PT_EXPERIMENTS
     allow(reinterpret_cast<const void*>(k_shadow_pooled<PT_LDS_ALL, 1, false>)); allow(reinterpret_cast<const void*>(k_shadow_pooled<PT_LDS_ALL, 4, false>));
     allow(reinterpret_cast<const void*>(k_shadow_pooled<PT_LDS_ALL, 1, true>)); allow(reinterpret_cast<const void*>(k_shadow_pooled<PT_LDS_ALL, 4, true>));
+#endif
     return worst;
 }
 

@@ -20,7 +20,9 @@ constexpr uint32_t kLdsAllLimitBytes = 24 * 1024;
 constexpr uint32_t kParkCap = 512, kParkFields = 16;
 constexpr uint32_t kWalkEvictBelow = 32, kWalkSearchBelow = 16;   // pt_tuning::walk_evict_below's and walk_search_below's defaults
 enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_MEDIUM_DROPS, BS_FIELDS };  // per-workgroup statistics (Profile counters)
+#ifdef PT_EXPERIMENTS
 uint32_t pool_lds_bytes();  // static LDS of the pooled traversal kernels, on top of the staged blob
+#endif
 
 struct LaunchCfg { int grid; uint32_t lds_bytes; hipStream_t stream; int lds_mode;
                    int dyn_grid = 0; uint32_t* unit_counter = nullptr;   // parked kernels with dynamic units: persistent workgroups and this launch's counter (zeroed)

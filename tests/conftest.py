@@ -30,3 +30,20 @@ def oracle(pkg):
 def engine(pkg):
     """The product: the HIP engine behind the C ABI.  No fallback."""
     return pkg.load()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Which film cases needed the 8-ulp allowance of tests/parity_suite.py (pixels too bright for 1e-4 to be more than their own rounding):
+    printed with every run and left in gpurun_out/ulp_bar.json, so that the tolerance in use is a reported fact."""
+    try:
+        import json
+        import parity_suite
+        log = parity_suite.ULP_BAR_LOG
+        terminalreporter.write_line("film cases that used the 8-ulp allowance: %d%s" % (len(log), "" if log else " (every film within L-inf 1e-4 flat)"))
+        for case, (n, brightest, linf) in sorted(log.items()):
+            terminalreporter.write_line("  %s: %d pixel(s), brightest value %.4g, L-inf %.3g" % (case, n, brightest, linf))
+        out = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out) and log:
+            json.dump({k: {"pixels": v[0], "brightest": v[1], "linf": v[2]} for k, v in log.items()}, open(os.path.join(out, "ulp_bar.json"), "w"), indent=1)
+    except Exception as e:   # a report, never a failure
+        terminalreporter.write_line("ulp-bar report unavailable: %r" % (e,))

@@ -88,7 +88,7 @@ def test_materials_bit_exact(engine, oracle, scene):
     ("hdri_c4_small", 64, 64, 6, 4, {"medium_aware": True, "light_samples": 3}),
 ])
 def test_film_parity(engine, oracle, scene, w, h, spp, mb, kw):
-    ps.render_parity(engine, oracle, scene, w, h, spp, mb, **kw)
+    ps.render_parity(engine, oracle, scene, w, h, spp, mb, flat=(scene, w, spp) == ("cornell_box", 256, 16), **kw)   # (C1: the flat bar)
 
 
 def test_golden_vectors(engine):
@@ -274,22 +274,6 @@ def test_forms_without_transforms_change_nothing(engine, pkg, monkeypatch, scene
         parity_suite.assert_hits_equal(hits, other.intersect(o, d))
 
 
-@pytest.mark.parametrize("scene,L,hero", [("cornell_box", 2, 1), ("mixed_small", 3, 1), ("white_furnace", 6, 1), ("cornell_box", 2, 4)])
-def test_pooled_phase3_changes_nothing(engine, pkg, monkeypatch, scene, L, hero):
-    """Pure sweep scenes: phase 3 pooled per wave (PT_AMD_POOL=1: the candidate triangles of a wave's 64 rays tested 64 at a time, the
-    acceptance replayed per ray in leaf order) gives the film and the counters of the lane-by-lane loop bit for bit.  (It is not the
-    default form: measured slower)"""
-    b = pkg.scene.SCENES[scene]()
-    rd = pkg.api.render_desc(192, 160, 10, 8, light_samples=L, seed=4, hero_wavelengths=hero)
-    base, pbase = engine.create_scene(b).render(rd)
-    monkeypatch.setenv("PT_AMD_POOL", "1")
-    for blocks in ("64", "1"):   # long segments: many rounds per workgroup, pools refilled
-        monkeypatch.setenv("PT_AMD_BLOCKS_PER_CU", blocks)
-        film, prof = engine.create_scene(b).render(rd)
-        assert np.array_equal(base.view(np.uint32), film.view(np.uint32)), blocks
-        assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits)
-
-
 def test_tuning_is_taken_at_scene_creation(engine, pkg, monkeypatch):
     """pt_tuning: the engine's switches as an explicit struct (what a Rust host sets per scene).  pt_scene_create_tuned with a flag set does what
     the variable does through pt_tuning_default; a variable that changes AFTER the scene exists changes nothing (the environment is read once,
@@ -408,7 +392,7 @@ def test_full_size_cornell_properties(engine, oracle, pkg):
     assert np.isfinite(whole).all() and whole.min() >= 0 and (whole[..., 3] == 0).all()
     assert pw.camera_rays == 1024 * 1024 * 2
     full_ref, pref = oracle.create_scene(b).render(rd)
-    ps.check_film(whole, full_ref, pw, pref)
+    ps.check_film(whole, full_ref, pw, pref, flat=True)
     acc = np.zeros_like(whole); rays = 0
     for k in range(4):
         part, pp = sc.render(pkg.api.render_desc(1024, 1024, 2, 8, shard=(k, 4)))
@@ -429,7 +413,8 @@ def test_full_size_cornell_properties(engine, oracle, pkg):
 def test_full_size_baseline_configs(engine, oracle, scene, w, h, mb, kw):
     """The other BASELINE.json configurations at their full film size, 1 spp (C2: 10), against the oracle at matched seeds."""
     kw = dict(kw)
-    ps.render_parity(engine, oracle, scene, w, h, kw.pop("spp", 1), mb, **kw)
+    # north_star's bar as stated: L-inf < 1e-4 on every pixel, flat — no BASELINE configuration may need the 8-ulp allowance for bright pixels
+    ps.render_parity(engine, oracle, scene, w, h, kw.pop("spp", 1), mb, flat=True, **kw)
 
 
 def test_error_behaviour(engine, pkg):

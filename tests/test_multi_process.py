@@ -78,7 +78,7 @@ def test_bench_rccl_path_on_one_gpu(tmp_path):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--spp-per-step", "16", "--cpu-seconds", "0"]
     lines = {}
-    for tag, extra in (("dist", ["--force-dist"]), ("plain", []), ("strong", ["--scaling", "strong"])):
+    for tag, extra in (("dist", ["--force-dist", "--strong-legs", "--strong-spp-div", "64", "--strong-frames", "2"]), ("plain", []), ("strong", ["--scaling", "strong"])):
         r = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert r.stdout.strip().splitlines()[-1].startswith('{"metric"'), r.stdout[-500:]   # the record is the last line of stdout
@@ -86,6 +86,17 @@ def test_bench_rccl_path_on_one_gpu(tmp_path):
     for tag, d in lines.items():
         assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["samples_per_step"] == 1024 * 1024 * 16, tag
     assert lines["dist"]["segments_per_sample"] == lines["plain"]["segments_per_sample"]   # same paths, whoever sums the film
+    for tag, d in lines.items():
+        assert d["ranks_seen"] == 1 and d["physical_gpus"] == 1, tag
+    assert lines["dist"]["backend"] == "nccl" and lines["dist"]["rccl_version"] and lines["plain"]["backend"] is None and lines["plain"]["strong"] is None
+    # the fixed BASELINE frames as a leg of the same record (they always run with N > 1): C2 and C4, each with its clocks
+    st = lines["dist"]["strong"]
+    for leg, spp, L in (("C2", 1024 // 64, 2), ("C4", 2048 // 64, 6)):
+        g = st[leg]
+        assert g["n_gpus"] == 1 and g["frames"] == 2 and g["spp"] == spp and g["light_samples"] == L and g["samples_per_frame"] == 1024 * 1024 * spp, leg
+        assert g["ms_per_frame"] > 0 and abs(g["value"] - g["samples_per_frame"] / (g["ms_per_frame"] * 1e-3) / 1e6) / g["value"] < 1e-6, leg
+        assert 0 < g["reduce_ms"] < g["ms_per_frame"] and g["render_ms_fastest_rank"] <= g["render_ms_slowest_rank"] <= g["ms_per_frame"], leg
+        assert g["setup_ms"] == g["setup"]["scene_create_ms"] + g["setup"]["first_frame_ms"] and g["film_bytes_reduced"] == 1024 * 1024 * 16, leg
     # with one GPU the fixed-frame (strong scaling) run is the weak-scaling run: the same work, the same record but for the mode's name
     assert lines["strong"]["scaling"] == "strong" and lines["plain"]["scaling"] == "weak"
     for key in ("metric", "unit", "n_gpus", "steps", "segments_per_sample", "dtype"):
@@ -146,3 +157,30 @@ def test_two_processes_on_one_gpu_equal_single_process(pkg, tmp_path, scene):
         film, _ = sc.render(pkg.api.render_desc(w, h, 2 * S, 6, light_samples=3, first_sample=k * S, sample_count=S))
         whole += film
     assert np.array_equal(reduced.view(np.uint32), whole.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_launches_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: the parent (no GPU call) starts two ranks with torch.distributed.run and relays
+    rank 0's record — n_gpus 2, ranks_seen 2 (all-reduced), strong-scaling legs included.  This box has one GPU and RCCL refuses two ranks on
+    one device, so the ranks share it (--allow-shared-gpus, physical_gpus says so) and exchange over gloo; without the flag the run must stop."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "256", "--height", "256", "--spp-per-step", "16",
+           "--cpu-seconds", "0", "--backend", "gloo", "--strong-spp-div", "64", "--strong-frames", "2"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode != 0 and r.stdout.strip() == "" and "has no GPU of its own" in r.stderr, r.stderr[-2000:]
+        cmd.append("--allow-shared-gpus")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["physical_gpus"] == min(2, torch.cuda.device_count()) and d["scaling"] == "weak" and "launched_by" in d
+    assert d["config"]["spp_per_step"] == 32 and d["config"]["samples_per_step"] == 256 * 256 * 32          # weak: 1/2 of the pixels at 2 x the samples, per rank
+    for leg, spp in (("C2", 16), ("C4", 32)):
+        g = d["strong"][leg]
+        assert g["n_gpus"] == 2 and g["samples_per_frame"] == 256 * 256 * spp and g["value"] > 0 and g["reduce_ms"] > 0, leg
