@@ -265,7 +265,10 @@ typedef struct pt_tuning {
                                      walking (the rays park again and go on in a later wave); 1 = never, at most 64; 0 = the default */
     uint32_t walk_search_below;   /* PT_AMD_WALK_SEARCH_BELOW: a mesh walk's inner loop (box to box until the lane holds a leaf) ends once fewer lanes than
                                      this are still searching while others hold a leaf; 1 = never, at most 64; 0 = the default */
-    uint32_t reserved[6];         /* must be 0 */
+    uint32_t park_block;          /* PT_AMD_PARK_BLOCK: 512 or 1024 = the parked kernels (scenes with walked meshes, one wavelength per path) run workgroups of that
+                                     many threads that stage the WHOLE blob in LDS — a blob of up to 64 KB, too big to stage at 256 threads per workgroup (the gem
+                                     scene, C3) — while the other kernels keep their staging mode; 0 / 256 = off */
+    uint32_t reserved[5];         /* must be 0 */
 } pt_tuning;
 /* The defaults, overridden by whatever PT_AMD_* variables the environment holds at the time of the call. */
 void pt_tuning_default(pt_tuning* tuning);
@@ -279,7 +282,9 @@ typedef struct pt_profile {      /* Profile (src/profile.rs:2-8) + timing */
                                     [6] = host seconds of the film reduce; [7] spare */
     uint64_t kernel_launches[8];
     uint64_t stage_items[8];     /* work items per stage summed over launches: paths generated, segments extended,
-                                    vertices shaded, light-sample items traced, pixels accumulated */
+                                    vertices shaded, light-sample items traced, pixels accumulated; [5] = tracked mediums a fifth nesting level
+                                    dropped (medium-aware walk; 0 = the walk is the reference's); [6] = threads per workgroup of the parked
+                                    kernels when they ran in their big-workgroup form (pt_tuning::park_block), else 0 */
 } pt_profile;
 
 typedef struct pt_hit {          /* HitRecord (src/hittable.rs:7-16) */
@@ -327,6 +332,12 @@ pt_status pt_bsdf_eval(pt_scene* scene, uint32_t material, size_t n, const float
 pt_status pt_emission(pt_scene* scene, uint32_t material, size_t n, const float* lambda, const float* wi,
                       float* emission);
 pt_status pt_curve_eval(pt_scene* scene, uint32_t curve, size_t n, const float* lambda, float* value);
+/* The first stage of one camera sample — the film jitter of render_sampled (src/renderer/tiled.rs:369-375), the wavelength and the clamp of
+ * PathTracingIntegrator::color (src/integrator/pt.rs:406-414) and Camera::sample_we / get_ray (src/camera/projective_camera.rs:101-120,
+ * panorama_camera.rs:71-95) — for n (pixel id = y * width + x, sample index) pairs of the render `desc` describes (width, height, seed, wavelength
+ * bounds, camera_index): origins and directions as 3 floats each, one wavelength per sample. */
+pt_status pt_camera_samples(pt_scene* scene, const pt_render_desc* desc, size_t n, const uint32_t* pixel, const uint32_t* sample,
+                            float* origins, float* directions, float* lambda);
 
 /* ---- film output stage: output_film (src/renderer/mod.rs:24-80) = tonemap + colour space + files ---- */
 enum { PT_TONEMAP_CLAMP = 0, PT_TONEMAP_REINHARD0 = 1, PT_TONEMAP_REINHARD1 = 2 };      /* src/parsing/tonemap.rs:8-31 */

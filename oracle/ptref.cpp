@@ -1997,6 +1997,27 @@ pt_status ptref_intersect(pt_scene* ps, size_t n, const float* o, const float* d
     return PT_OK;
 }
 
+// tiled.rs:369-375 (jitter) + pt.rs:406-417 (wavelength, clamp, camera.sample_we): the expressions of render_tile and color above
+pt_status ptref_camera_samples(pt_scene* ps, const pt_render_desc* rdp, size_t n, const uint32_t* pixel, const uint32_t* sample, float* origins, float* directions, float* lambda) {
+    if (!ps || !rdp || !pixel || !sample || !origins || !directions || !lambda) { g_error = "null argument"; return PT_ERR_INVALID_ARGUMENT; }
+    const pt_render_desc& rd = *rdp;
+    if (rd.width == 0 || rd.height == 0 || rd.camera_index >= ps->s.cameras.size()) { g_error = "width, height must be positive, camera_index in range"; return PT_ERR_INVALID_ARGUMENT; }
+    const Camera cam = camera_new(ps->s.cameras[rd.camera_index], (float)rd.width / (float)rd.height);
+    for (size_t i = 0; i < n; ++i) {
+        if (pixel[i] >= rd.width * rd.height) { g_error = "pixel id out of range"; return PT_ERR_INVALID_ARGUMENT; }
+        const uint32_t x = pixel[i] % rd.width, y = pixel[i] / rd.width;
+        Sampler smp{rd.seed, pixel[i], sample[i], rd.light_samples};
+        pt_f32x4 fs = smp.film();
+        float cu = ((float)x + fs.x) / (float)rd.width, cv = ((float)y + fs.y) / (float)rd.height;
+        lambda[i] = rd.wavelength_lo + fs.z * (rd.wavelength_hi - rd.wavelength_lo);
+        float fu = pt_clamp(cu, 0.0f, 1.0f - PT_F32_EPSILON), fv = pt_clamp(cv, 0.0f, 1.0f - PT_F32_EPSILON);
+        Ray r = camera_get_ray(cam, smp, fu, fv);
+        origins[3 * i] = r.origin.x; origins[3 * i + 1] = r.origin.y; origins[3 * i + 2] = r.origin.z;
+        directions[3 * i] = r.direction.x; directions[3 * i + 1] = r.direction.y; directions[3 * i + 2] = r.direction.z;
+    }
+    return PT_OK;
+}
+
 pt_status ptref_bsdf_sample(pt_scene* ps, uint32_t material, size_t n, const float* lambda, const float* wi, const float* s2,
                             float* f, float* wo, float* pdf) {
     if (!ps || material >= ps->s.materials.size()) { g_error = "bad material"; return PT_ERR_INVALID_ARGUMENT; }

@@ -131,7 +131,7 @@ class Tuning(C.Structure):
     """pt_tuning: the engine's run-time switches, taken by a scene when it is created."""
     _fields_ = [("flags", C.c_uint32), ("batch_slots", C.c_uint32), ("blocks_per_cu", C.c_uint32), ("park_blocks_per_cu", C.c_uint32),
                 ("park_dynamic", C.c_int32), ("shade_form", C.c_uint32), ("lds_all_limit", C.c_uint32), ("multi_virtual", C.c_uint32),
-                ("walk_evict_below", C.c_uint32), ("walk_search_below", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+                ("walk_evict_below", C.c_uint32), ("walk_search_below", C.c_uint32), ("park_block", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 class OutputDesc(C.Structure):
@@ -165,7 +165,7 @@ assert HIT_DTYPE.itemsize == C.sizeof(Hit)
 
 # every entry point include/pt_api.h declares (without prefix)
 API_FUNCTIONS = ["scene_create", "scene_create_tuned", "tuning_default", "scene_destroy", "last_error", "render", "render_device", "render_multi", "device_count", "intersect",
-                 "bsdf_sample", "bsdf_eval", "emission", "curve_eval", "device_info", "output_film", "write_png", "write_exr", "compare_films"]
+                 "bsdf_sample", "bsdf_eval", "emission", "curve_eval", "camera_samples", "device_info", "output_film", "write_png", "write_exr", "compare_films"]
 
 
 class PtError(RuntimeError):
@@ -217,6 +217,7 @@ class Library:
         self._render_multi = bind("render_multi", C.c_int32, [vp, C.POINTER(RenderDesc), C.c_uint64, fpp, C.POINTER(Profile)], required=False)
         self._device_count = bind("device_count", u32, [], required=False)
         self._intersect = bind("intersect", C.c_int32, [vp, sz, fpp, fpp, C.POINTER(Hit)])
+        self._camera_samples = bind("camera_samples", C.c_int32, [vp, C.POINTER(RenderDesc), sz, C.POINTER(u32), C.POINTER(u32), fpp, fpp, fpp])
         self._bsdf_sample = bind("bsdf_sample", C.c_int32, [vp, u32, sz, fpp, fpp, fpp, fpp, fpp, fpp])
         self._bsdf_eval = bind("bsdf_eval", C.c_int32, [vp, u32, sz, fpp, fpp, fpp, fpp, fpp])
         self._emission = bind("emission", C.c_int32, [vp, u32, sz, fpp, fpp, fpp])
@@ -341,6 +342,16 @@ class Scene:
         self.library.check(self.library._intersect(self.handle, o.shape[0], _fp(o), _fp(d),
                                                    hits.ctypes.data_as(C.POINTER(Hit))))
         return hits
+
+    def camera_samples(self, rd, pixel, sample):
+        """pt_camera_samples: film jitter + wavelength + Camera::get_ray for (pixel id, sample index) pairs of the render `rd`: (origins, directions, lambda)."""
+        pixel = np.ascontiguousarray(pixel, dtype=np.uint32).ravel()
+        sample = np.ascontiguousarray(sample, dtype=np.uint32).ravel()
+        n = pixel.shape[0]
+        o = np.zeros((n, 3), np.float32); d = np.zeros((n, 3), np.float32); lam = np.zeros(n, np.float32)
+        u32p = C.POINTER(C.c_uint32)
+        self.library.check(self.library._camera_samples(self.handle, C.byref(rd), n, pixel.ctypes.data_as(u32p), sample.ctypes.data_as(u32p), _fp(o), _fp(d), _fp(lam)))
+        return o, d, lam
 
     def bsdf_sample(self, material, lam, wi, s2):
         lam = np.ascontiguousarray(lam, dtype=np.float32)

@@ -45,6 +45,16 @@ namespace {
     } while (0)
 
 // mode 0: generate_and_evaluate(lambda, wi, s2) -> f, wo, pdf ; 1: bsdf(lambda, wi, wo) -> f, pdf ; 2: emission(lambda, wi) ; 3: curve(lambda)
+// the first stage of a camera sample as k_generate runs it (stage_generate), for chosen (pixel, sample) pairs: pt_camera_samples
+__global__ void __launch_bounds__(kBlock) k_probe_camera(RenderParams rp, uint32_t n, const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample,
+                                                        float* __restrict__ o, float* __restrict__ d, float* __restrict__ lambda) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const PathVertexT<1> p = stage_generate<1>(rp, sample[i], pixel[i]);
+        o[3 * i] = p.o.x; o[3 * i + 1] = p.o.y; o[3 * i + 2] = p.o.z;
+        d[3 * i] = p.d.x; d[3 * i + 1] = p.d.y; d[3 * i + 2] = p.d.z;
+        lambda[i] = p.lambda;
+    }
+}
 __global__ void __launch_bounds__(kBlock) k_probe_material(const uint32_t* __restrict__ blob, const float* __restrict__ tex, int mode, uint32_t record, uint32_t n,
                                                           const float* __restrict__ lambda, const float* __restrict__ a, const float* __restrict__ b,
                                                           float* __restrict__ f, float* __restrict__ wo, float* __restrict__ pdf) {
@@ -97,7 +107,7 @@ struct DevBuf {
 
 constexpr uint32_t kUnitCounters = 2 * 64 + 2;   // two parked launches per bounce, max_bounces <= 64
 struct DeviceBuffers {
-    uint32_t capacity = 0, light_samples = 0, nl = 0;
+    uint32_t capacity = 0, light_samples = 0, nl = 0, park_block = 0;
     uint32_t *paths_a = nullptr, *paths_b = nullptr, *hits = nullptr, *shadow = nullptr, *pixels = nullptr, *counts = nullptr, *park = nullptr;
     uint32_t* unit_counters = nullptr;   // parked kernels with dynamic units: one counter per launch of a pass (kUnitCounters), zeroed per pass
     float* energy = nullptr;
@@ -168,10 +178,10 @@ uint32_t segment_capacity(uint32_t n, int grid) {
     return (c + 63u) & ~63u;
 }
 
-pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples, size_t n_pixels, int grid, uint32_t nl) {
+pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples, size_t n_pixels, int grid, uint32_t nl, uint32_t park_block) {
     DeviceBuffers& b = sc->buf;
     uint32_t total = segment_capacity(capacity, grid) * (uint32_t)grid;
-    if (b.capacity < total || b.light_samples < light_samples || b.grid != grid || b.nl < nl) {
+    if (b.capacity < total || b.light_samples < light_samples || b.grid != grid || b.nl < nl || b.park_block < park_block) {
         hipFree(b.paths_a); hipFree(b.paths_b); hipFree(b.hits); hipFree(b.shadow); hipFree(b.energy); hipFree(b.counts); hipFree(b.block_stats); hipFree(b.park);
         b.paths_a = b.paths_b = b.hits = b.shadow = b.counts = b.park = nullptr; b.energy = nullptr; b.block_stats = nullptr; b.capacity = 0;
         uint32_t ls = light_samples > b.light_samples ? light_samples : b.light_samples;
@@ -189,7 +199,8 @@ pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples
         // (the parked kernels' scratch: scenes whose sweep table holds walked meshes, and scenes without a sweep table that hold a mesh)
         const bool no_table = sc->host.blob[PT_HDR_SWEEP_OFF] == 0 || (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP);
         if ((sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) || (no_table && scene_has_mesh(sc->host.blob)))
-            HIP_TRY(hipMalloc(&b.park, sizeof(uint32_t) * kParkFields * kParkCap * (size_t)grid));
+            HIP_TRY(hipMalloc(&b.park, sizeof(uint32_t) * kParkFields * (kParkCap / (kBlock / 64)) * (park_block / 64) * (size_t)grid));   // (128 entries per wave)
+        b.park_block = park_block;
         if (!b.unit_counters) HIP_TRY(hipMalloc(&b.unit_counters, sizeof(uint32_t) * kUnitCounters));
         b.capacity = total; b.light_samples = ls; b.grid = grid;
     }
@@ -235,7 +246,9 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     const bool hero = rd.hero_wavelengths == 4;
     if (hero && capacity > (1u << 26)) capacity = 1u << 26;  // 4-wavelength queues are ~1.5x wider: 64 Mi slots ~ 24 GB
     // (the medium-aware walk keeps its two extra path fields where the hero layout keeps the passengers' throughputs)
-    pt_status st = ensure_buffers(sc, capacity, rd.light_samples, pixels.size() ? pixels.size() : 1, grid, (hero || rd.medium_aware) ? 4u : 1u);
+    // the parked kernels in workgroups of 512 / 1024 threads that stage the whole blob (pt_tuning::park_block): static form, one wavelength, a blob that fits
+    const uint32_t park_block = (tn.park_block == 512u || tn.park_block == 1024u) && !hero && sc->blob_words * 4u <= kParkBlobLimitBytes && !(tn.flags & PT_TUNE_NO_LDS) ? tn.park_block : (uint32_t)kBlock;
+    pt_status st = ensure_buffers(sc, capacity, rd.light_samples, pixels.size() ? pixels.size() : 1, grid, (hero || rd.medium_aware) ? 4u : 1u, park_block);
     if (st != PT_OK) return st;
     DeviceBuffers& b = sc->buf;
     if (!pixels.empty()) HIP_TRY(hipMemcpyAsync(b.pixels, pixels.data(), sizeof(uint32_t) * pixels.size(), hipMemcpyHostToDevice, stream));
@@ -276,10 +289,12 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     // full).  With the mesh in HBM/L2 (C4) the static form wins, 1128 vs 1083 Msamples/s: a wave's parked rays then come from one
     // region of the film and walk the same part of the mesh.  PT_AMD_PARK_DYNAMIC=0 / 1 forces either.
     const bool park_dynamic = parked && (tn.park_dynamic < 0 ? mode == PT_LDS_ALL : tn.park_dynamic != 0);
+    const bool park_big = parked && !park_dynamic && park_block != (uint32_t)kBlock && mode != PT_LDS_ALL;
     const int dyn_grid = sc->num_cus * (int)tuned(tn.park_blocks_per_cu, 4);
     LaunchCfg cfg{grid, lds_bytes, stream, mode};
     cfg.dyn_grid = dyn_grid < grid ? dyn_grid : grid;
     cfg.lacks = sc->lacks;
+    if (park_big) { cfg.park_block = (int)park_block; cfg.park_blob_bytes = sc->blob_words * 4u; }
     cfg.walk_policy = (tn.walk_evict_below ? tn.walk_evict_below : kWalkEvictBelow) | (tn.walk_search_below ? tn.walk_search_below : kWalkSearchBelow) << 8
                     | ((tn.flags & PT_TUNE_NO_AXIS_SCAN) ? 0u : PT_WALK_SCAN_AXIS);
     const SceneArgs sargs{sc->d_blob, sc->blob_words, sc->d_tex};
@@ -378,6 +393,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
         for (int i = 0; i < ST_COUNT; ++i) { profile->kernel_seconds[i] = stage_ms[i] * 1e-3; profile->kernel_launches[i] = stage_launches[i]; }
         profile->stage_items[ST_GENERATE] = camera_rays; profile->stage_items[ST_EXTEND] = c[BS_SEGMENTS]; profile->stage_items[ST_SHADE] = c[BS_SEGMENTS];
         profile->stage_items[ST_SHADOW] = c[BS_ITEMS]; profile->stage_items[ST_ACCUMULATE] = accumulated_pixels;
+        profile->stage_items[6] = (uint64_t)cfg.park_block;   // threads per workgroup of the parked kernels when they ran in their big-workgroup form (pt_tuning::park_block), else 0
         profile->stage_items[5] = c[BS_MEDIUM_DROPS];   // the medium-aware walk tracks four nested mediums: what a fifth level lost (0 = the walk is the reference's)
     }
     return PT_OK;
@@ -454,9 +470,10 @@ static pt_status scene_to_device(pt_scene* sc) {
     if (e == hipSuccess) e = hipMemcpy(sc->d_tex, sc->host.tex.data(), sizeof(float) * sc->host.tex.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE, hipGetErrorString(e));
     if (sc->lds_mode != PT_LDS_NONE) {
-        e = allow_lds_extend(kLdsBlobLimitBytes);
+        e = allow_lds_extend(kParkBlobLimitBytes);
         if (e == hipSuccess) e = allow_lds_shade(kLdsBlobLimitBytes);
-        if (e == hipSuccess) e = allow_lds_shadow(kLdsBlobLimitBytes);
+        // (the parked light-sample kernels keep their waves' lists of live rays behind the blob: up to 16 waves x (64 L + 64) words)
+        if (e == hipSuccess) e = allow_lds_shadow(kParkBlobLimitBytes + 16u * (64u * PT_MAX_LIGHT_SAMPLES + 64u) * 4u);
         if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
     }
     return PT_OK;
@@ -484,6 +501,7 @@ void pt_tuning_default(pt_tuning* t) {
     t->multi_virtual = env_u32("PT_AMD_MULTI_VIRTUAL", 0);
     t->walk_evict_below = env_u32("PT_AMD_WALK_EVICT_BELOW", 0);
     t->walk_search_below = env_u32("PT_AMD_WALK_SEARCH_BELOW", 0);
+    t->park_block = env_u32("PT_AMD_PARK_BLOCK", 0);
 }
 
 pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
@@ -495,6 +513,8 @@ pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
 pt_status pt_scene_create_tuned(const pt_scene_desc* desc, const pt_tuning* tuning, pt_scene** out) {
     if (!desc || !out || !tuning) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     for (uint32_t r : tuning->reserved) if (r != 0) return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning::reserved must be 0");
+    if (tuning->park_block != 0 && tuning->park_block != 256 && tuning->park_block != 512 && tuning->park_block != 1024)
+        return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning::park_block (PT_AMD_PARK_BLOCK) must be 0, 256, 512 or 1024");
     if (tuning->shade_form > 2 || tuning->park_dynamic < -1 || tuning->park_dynamic > 1 || tuning->multi_virtual > 64 || tuning->walk_evict_below > 64 || tuning->walk_search_below > 64)
         return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning: shade_form in 0..2, park_dynamic in -1..1, multi_virtual, walk_evict_below, walk_search_below <= 64");
     // the tiled queue index (pt_stages.h qtile) multiplies in 32 bits: capacity <= 2^30; the grids are num_cus * blocks in an int
@@ -740,6 +760,31 @@ pt_status pt_intersect(pt_scene* sc, size_t n, const float* origins, const float
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(hits, dh.p, sizeof(pt_hit) * n, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+pt_status pt_camera_samples(pt_scene* sc, const pt_render_desc* rdp, size_t n, const uint32_t* pixel, const uint32_t* sample, float* origins, float* directions, float* lambda) {
+    if (!sc || !rdp || !pixel || !sample || !origins || !directions || !lambda) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    if (rdp->width == 0 || rdp->height == 0 || rdp->camera_index >= sc->host.cameras.size()) return fail(PT_ERR_INVALID_ARGUMENT, "width, height must be positive, camera_index in range");
+    for (size_t i = 0; i < n; ++i) if (pixel[i] >= rdp->width * rdp->height) return fail(PT_ERR_INVALID_ARGUMENT, "pixel id out of range");
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(sc->device));
+    RenderParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.seed = rdp->seed; rp.width = rdp->width; rp.height = rdp->height;
+    rp.wavelength_lo = rdp->wavelength_lo; rp.wavelength_span = rdp->wavelength_hi - rdp->wavelength_lo;
+    rp.camera = pth::camera_params(sc->host.cameras[rdp->camera_index], (float)rdp->width / (float)rdp->height);
+    rp.chunk_pixels = 1;   // (stage_generate: sample = first_sample + slot / chunk_pixels — the probe hands the sample index in as the slot)
+    DevBuf dp, ds, dor, dd, dl;
+    HIP_TRY(dp.alloc(4 * n)); HIP_TRY(ds.alloc(4 * n)); HIP_TRY(dor.alloc(12 * n)); HIP_TRY(dd.alloc(12 * n)); HIP_TRY(dl.alloc(4 * n));
+    HIP_TRY(hipMemcpy(dp.p, pixel, 4 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ds.p, sample, 4 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_camera, dim3(256), dim3(kBlock), 0, 0, rp, (uint32_t)n, dp.as<uint32_t>(), ds.as<uint32_t>(), dor.as<float>(), dd.as<float>(), dl.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(origins, dor.p, 12 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(directions, dd.p, 12 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lambda, dl.p, 4 * n, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

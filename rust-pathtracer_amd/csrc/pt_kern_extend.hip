@@ -33,7 +33,9 @@ void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, Queue path
         if (c.lds_mode == PT_LDS_ALL) go(d, K_EXT_PARKED_DYN(PT_LDS_ALL), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
         else if (c.lds_mode == PT_LDS_CORE) go(d, K_EXT_PARKED_DYN(PT_LDS_CORE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
         else go(d, K_EXT_PARKED_DYN(PT_LDS_NONE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
-    } else if (form == PT_FORM_PARKED_WALK) { PT_BY_MODE(K_EXT_PARKED_W, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
+    } else if (form == PT_FORM_PARKED && c.park_block == 512) { go_block(c, 512, c.park_blob_bytes, k_extend_parked<PT_LDS_ALL, 0, 512>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
+    else if (form == PT_FORM_PARKED && c.park_block == 1024) { go_block(c, 1024, c.park_blob_bytes, k_extend_parked<PT_LDS_ALL, 0, 1024>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
+    else if (form == PT_FORM_PARKED_WALK) { PT_BY_MODE(K_EXT_PARKED_W, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
     else if (form == PT_FORM_PARKED) { PT_BY_MODE(K_EXT_PARKED, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
 #ifdef PT_EXPERIMENTS
     else if (form == PT_FORM_POOLED) PT_GO(k_extend_pooled<PT_LDS_ALL>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
@@ -55,6 +57,7 @@ hipError_t allow_lds_extend(uint32_t bytes) {
     PT_ALLOW_MODES(K_EXT_ANY); PT_ALLOW_MODES(K_EXT_PARKED); PT_ALLOW_MODES(K_EXT_PARKED_W); PT_ALLOW_MODES(K_PROBE);
 #define K_EXT_PARKED_DYN2(M) k_extend_parked_dyn<M>
     PT_ALLOW_MODES(K_EXT_PARKED_DYN2);
+    allow(reinterpret_cast<const void*>(k_extend_parked<PT_LDS_ALL, 0, 512>)); allow(reinterpret_cast<const void*>(k_extend_parked<PT_LDS_ALL, 0, 1024>));
     allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_SWEEP>));
     allow(reinterpret_cast<const void*>(k_extend<PT_LDS_ALL, PT_TRAV_SWEEP, PT_SCENE_NO_XF>));
 #ifdef PT_EXPERIMENTS

@@ -23,6 +23,16 @@ namespace ptk {
 void launch_shadow(const LaunchCfg& c, int form, int nl, bool env, const SceneArgs& sc, uint32_t light_samples, Queue shadow, float* energy, uint32_t energy_stride,
                    uint32_t seg_cap, const uint32_t* count_in, uint32_t* park, Queue idle_hits) {
     const bool hero = nl == 4;
+    // the static parked forms keep their waves' lists of live rays in dynamic LDS behind the staged blob: block threads, blob bytes -> total bytes, list offset in words
+    auto parked_lds = [&](int block, uint32_t blob_bytes, uint32_t* live_off) {
+        const uint32_t at = (blob_bytes + 15u) & ~15u;
+        *live_off = at / 4u;
+        return at + (uint32_t)(block / 64) * live_cap(light_samples) * 4u;
+    };
+#define PT_PARKED_BY_MODE(K) do { uint32_t live_off; const uint32_t bytes = parked_lds(kBlock, c.lds_bytes, &live_off); \
+        if (c.lds_mode == PT_LDS_ALL) go_block(c, kBlock, bytes, K(PT_LDS_ALL), PT_ARGS, park, c.walk_policy, live_off); \
+        else if (c.lds_mode == PT_LDS_CORE) go_block(c, kBlock, bytes, K(PT_LDS_CORE), PT_ARGS, park, c.walk_policy, live_off); \
+        else go_block(c, kBlock, bytes, K(PT_LDS_NONE), PT_ARGS, park, c.walk_policy, live_off); } while (0)
 #ifdef PT_EXPERIMENTS
     if (const char* v = getenv("PT_AMD_EXP_SHADOW")) {
         const int e = atoi(v);
@@ -40,12 +50,18 @@ void launch_shadow(const LaunchCfg& c, int form, int nl, bool env, const SceneAr
         if (hero) { PT_DYN_BY_MODE(4); go(plain, k_shadow_sum<4>, light_samples, shadow, energy, energy_stride, seg_cap, count_in); }
         else { PT_DYN_BY_MODE(1); go(plain, k_shadow_sum<1>, light_samples, shadow, energy, energy_stride, seg_cap, count_in); }
     } else if (form == PT_FORM_PARKED_WALK) {   // (one general form per wavelength count: with the scan, with the light list)
-        if (hero) PT_BY_MODE(K_SH_PARKED4W, PT_ARGS, park, c.walk_policy); else PT_BY_MODE(K_SH_PARKED1W, PT_ARGS, park, c.walk_policy);
+        if (hero) PT_PARKED_BY_MODE(K_SH_PARKED4W); else PT_PARKED_BY_MODE(K_SH_PARKED1W);
+        PT_TL_BUMP(c.stream);
+    } else if (form == PT_FORM_PARKED && !hero && (c.park_block == 512 || c.park_block == 1024)) {   // (the whole blob staged by bigger workgroups)
+        uint32_t live_off;
+        const uint32_t bytes = parked_lds(c.park_block, c.park_blob_bytes, &live_off);
+        if (c.park_block == 512) go_block(c, 512, bytes, k_shadow_parked<PT_LDS_ALL, 1, 0u, 0, 512>, PT_ARGS, park, c.walk_policy, live_off);
+        else go_block(c, 1024, bytes, k_shadow_parked<PT_LDS_ALL, 1, 0u, 0, 1024>, PT_ARGS, park, c.walk_policy, live_off);
         PT_TL_BUMP(c.stream);
     } else if (form == PT_FORM_PARKED) {
-        if (hero) PT_BY_MODE(K_SH_PARKED4, PT_ARGS, park, c.walk_policy);
-        else if (c.lacks & PT_SCENE_NO_LIGHTS) PT_BY_MODE(K_SH_PARKED1E, PT_ARGS, park, c.walk_policy);   // (an environment is the scene's only emitter)
-        else PT_BY_MODE(K_SH_PARKED1, PT_ARGS, park, c.walk_policy);
+        if (hero) PT_PARKED_BY_MODE(K_SH_PARKED4);
+        else if (c.lacks & PT_SCENE_NO_LIGHTS) PT_PARKED_BY_MODE(K_SH_PARKED1E);   // (an environment is the scene's only emitter)
+        else PT_PARKED_BY_MODE(K_SH_PARKED1);
         PT_TL_BUMP(c.stream);
     }
 #ifdef PT_EXPERIMENTS
@@ -72,6 +88,10 @@ hipError_t allow_lds_shadow(uint32_t bytes) {
 #define K_SH_DYN1(M) k_shadow_parked_dyn<M, 1>
 #define K_SH_DYN4(M) k_shadow_parked_dyn<M, 4>
     PT_ALLOW_MODES(K_SH_DYN1); PT_ALLOW_MODES(K_SH_DYN4);
+    allow(reinterpret_cast<const void*>(k_shadow_parked<PT_LDS_ALL, 1, 0u, 0, 512>)); allow(reinterpret_cast<const void*>(k_shadow_parked<PT_LDS_ALL, 1, 0u, 0, 1024>));
+    { // (the parked forms without a staged blob still keep their live lists in dynamic LDS)
+        allow(reinterpret_cast<const void*>(K_SH_PARKED1(PT_LDS_NONE))); allow(reinterpret_cast<const void*>(K_SH_PARKED4(PT_LDS_NONE))); allow(reinterpret_cast<const void*>(K_SH_PARKED1E(PT_LDS_NONE)));
+        allow(reinterpret_cast<const void*>(K_SH_PARKED1W(PT_LDS_NONE))); allow(reinterpret_cast<const void*>(K_SH_PARKED4W(PT_LDS_NONE))); }
     allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_WALK>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_WALK>));
     allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, true>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, true>));
     allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, false>)); allow(reinterpret_cast<const void*>(k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, false>));

@@ -20,6 +20,9 @@ using namespace ptd;
 
 template <typename K, typename... Args>
 inline void go(const LaunchCfg& c, K kernel, Args... args) { hipLaunchKernelGGL(kernel, dim3(c.grid), dim3(kBlock), c.lds_bytes, c.stream, args...); }
+// (the parked kernels in their bigger workgroups, round 4: `block` threads, `lds_bytes` of dynamic LDS)
+template <typename K, typename... Args>
+inline void go_block(const LaunchCfg& c, int block, uint32_t lds_bytes, K kernel, Args... args) { hipLaunchKernelGGL(kernel, dim3(c.grid), dim3(block), lds_bytes, c.stream, args...); }
 
 // Register budgets: the number of waves per SIMD the compiler must leave room for (1 = no constraint), per kernel form.
 // Measured on MI355X (tools/occupancy_sweep.sh): the traversal kernels are VALU-issue bound and gain from a
@@ -553,12 +556,14 @@ __global__ void __launch_bounds__(kBlock) PT_POOL_OCC k_shadow_exp(const uint32_
 // whenever a wave has 64 rays parked (and at the end) it resumes them together: a full wave, every lane in a mesh walk.  Nothing about a ray's own sequence of tests changes (same leaves, same order, same running closest hit).
 enum { PK_ITEM, PK_HIT_LO, PK_HIT_HI, PK_CLOSEST, PK_BEST_INST, PK_BEST_TRIW, PK_T, PK_B0, PK_B1, PK_B2, PK_RAY, PK_BOUND, PK_KIND, PK_CURSOR };
 static_assert(PK_CURSOR < kParkFields, "a parked entry's fields");
+template <uint32_t kParkCap = ptk::kParkCap>   // (the stride between the fields of a workgroup's entries: 128 per wave)
 __device__ __forceinline__ void park_store(uint32_t* pk, uint32_t e, uint32_t item, const SweepState& st, uint32_t ray, float bound, uint32_t kind, uint32_t cursor) {
     pk[PK_ITEM * kParkCap + e] = item; pk[PK_HIT_LO * kParkCap + e] = (uint32_t)st.hit; pk[PK_HIT_HI * kParkCap + e] = (uint32_t)(st.hit >> 32);
     pk[PK_CLOSEST * kParkCap + e] = pt_f2u(st.closest); pk[PK_BEST_INST * kParkCap + e] = st.best_inst; pk[PK_BEST_TRIW * kParkCap + e] = st.best_triw;
     pk[PK_T * kParkCap + e] = pt_f2u(st.bh.t); pk[PK_B0 * kParkCap + e] = pt_f2u(st.bh.b0); pk[PK_B1 * kParkCap + e] = pt_f2u(st.bh.b1); pk[PK_B2 * kParkCap + e] = pt_f2u(st.bh.b2);
     pk[PK_RAY * kParkCap + e] = ray; pk[PK_BOUND * kParkCap + e] = pt_f2u(bound); pk[PK_KIND * kParkCap + e] = kind; pk[PK_CURSOR * kParkCap + e] = cursor;
 }
+template <uint32_t kParkCap = ptk::kParkCap>
 __device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32_t* item, SweepState* st, uint32_t* ray, float* bound, uint32_t* kind, uint32_t* cursor) {
     *item = pk[PK_ITEM * kParkCap + e]; st->hit = (uint64_t)pk[PK_HIT_LO * kParkCap + e] | (uint64_t)pk[PK_HIT_HI * kParkCap + e] << 32;
     st->closest = pt_u2f(pk[PK_CLOSEST * kParkCap + e]); st->best_inst = pk[PK_BEST_INST * kParkCap + e]; st->best_triw = pk[PK_BEST_TRIW * kParkCap + e];
@@ -574,11 +579,14 @@ __device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32
 #define PT_PARKED_EXP 0   // measurement variants of k_shadow_parked (tools/phase_costs_parked.sh); 0 = the product
 #endif
 constexpr uint32_t kWaveParkCap = kParkCap / (kBlock / 64);
-constexpr uint32_t kLiveCap = 64u * PT_MAX_LIGHT_SAMPLES + 64u;   // a wave's list of live light-sample rays: fewer than 64 left over + the rays of 64 items
+static_assert(kWaveParkCap == 128, "a wave's park list: fewer than 64 entries left over + at most 64 new ones per step");
+// a wave's list of live light-sample rays: fewer than 64 left over + the rays of 64 items — in dynamic LDS behind the staged blob, sized by the
+// render's own light_samples (launch_shadow), so that a big staged blob keeps its two workgroups per CU
+__host__ __device__ constexpr uint32_t live_cap(uint32_t light_samples) { return 64u * light_samples + 64u; }
 // `walk_policy` (mesh_walk's: pt_tuning::walk_evict_below | walk_search_below << 8): a resumed wave's walks are left by its last lanes once
 // fewer than walk_evict_below are still walking — they park again with their cursor and go on in a later drain.  Not in the very last drain
 // of a wave, which has nobody left to wait for.
-template <bool ALL_LANES, typename Resume>
+template <bool ALL_LANES, uint32_t PCAP = ptk::kParkCap, typename Resume>
 __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, bool last, uint32_t walk_policy, Resume&& resume) {
     const uint32_t lane = lane_id();
     for (;;) {
@@ -589,7 +597,7 @@ __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, b
         const bool mine = lane < take;
         uint32_t item = 0, ray = 0, kind = 0, cursor = 0; float bound = PT_INF; SweepState st;
         if (ALL_LANES) sweep_state_init(st, 0);
-        if (mine) park_load(pk, first + lane, &item, &st, &ray, &bound, &kind, &cursor);
+        if (mine) park_load<PCAP>(pk, first + lane, &item, &st, &ray, &bound, &kind, &cursor);
         __threadfence_block();             // entries are in registers before any lane parks again into these slots
         if (lane == 0) *park_count = first;
         // (ALL_LANES, the forms that scan axis rays: a lane without an entry helps with the scans of the others' — mesh_walk's `alive`)
@@ -599,12 +607,17 @@ __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, b
 
 // TOP = 1: no sweep table — the top-level tree is walked per lane and a lane parks at every mesh instance it reaches (top_walk_run / top_walk_resume,
 // pt_device.h): the parked kernels' mesh walks for scenes of more than 64 instances.
-template <int USE_LDS, int TOP = 0>
-__global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
-                                                                     Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
-                                                                     uint32_t* __restrict__ park_all, uint32_t walk_policy) {
+// BLK (round 4): threads per workgroup.  A blob too big to stage whole at 256 threads — the gem scene's 65 KB leaves two workgroups per CU, two waves
+// per SIMD — can be staged whole by workgroups of 512: two of them are sixteen waves per CU, four per SIMD, and the mesh is read by ds_read.  Waves never
+// meet after the staging barrier, so nothing else changes: a wave's park list, its rounds over the segment, its drains.
+template <int USE_LDS, int TOP = 0, int BLK = kBlock>
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlock ? PT_PARK_EXTEND_WAVES : PT_PARK_WAVES)))
+k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
+                uint32_t* __restrict__ park_all, uint32_t walk_policy) {
     extern __shared__ __align__(16) uint32_t lds[];
-    __shared__ uint32_t park_counts[kBlock / 64];
+    __shared__ uint32_t park_counts[BLK / 64];
+    constexpr uint32_t kParkCap = kWaveParkCap * (BLK / 64);   // (shadows ptk::kParkCap: this workgroup's entries per field)
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
     const uint32_t wave = PT_UNIFORM(threadIdx.x >> 6);   // (a scalar: with fresh_lane_id below, threadIdx.x need not stay in a register across the rounds)
     uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap + wave * kWaveParkCap;  // field f of entry e at pk[f * kParkCap + e]
@@ -617,7 +630,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
         *d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
     };
     auto settle = [&](uint32_t j, F3 o, F3 d, const SweepState& st, bool parked, uint32_t cursor) {
-        if (parked) park_store(pk, atomicAdd(park_count, 1u), j, st, 0u, PT_INF, 0u, cursor);
+        if (parked) park_store<kParkCap>(pk, atomicAdd(park_count, 1u), j, st, 0u, PT_INF, 0u, cursor);
         else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, base + j, h); }
     };
     PT_TL_BEGIN();
@@ -636,7 +649,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
             }
             settle(j, o, d, st, parks, 0u);
         }
-        park_drain<false>(pk, park_count, r + 1 == rounds, walk_policy & ~PT_WALK_SCAN_AXIS, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t, uint32_t cursor, uint32_t policy, bool mine) {
+        park_drain<false, kParkCap>(pk, park_count, r + 1 == rounds, walk_policy & ~PT_WALK_SCAN_AXIS, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t, uint32_t cursor, uint32_t policy, bool mine) {
             if (mine) PT_TL_WORK();   // (timeline: parked rays resumed)
             F3 o = f3(0.0f, 0.0f, 0.0f), d = f3(0.0f, 0.0f, 0.0f);
             if (mine) ray_of(base + j2, &o, &d);
@@ -654,12 +667,15 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_EXTEND_OCC k_extend_parked(con
 // ray, 1.5 in 10 000 of C4's light samples, each 8000 box tests long when walked.  (The closest-hit kernel, k_extend_parked, walks them: there an axis-parallel
 // direction is a coincidence of the scene's set-up, and the scan's registers cost that 96-VGPR kernel 6 spilled.  Here the form with the scan happens to
 // allocate better than the one without: C3's kernel 4755 -> 4658 us, so every form carries it.)
-template <int USE_LDS, int NL, uint32_t LACKS = 0u, int TOP = 0>
-__global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+// `live_off`: where in the dynamic LDS, in words, the waves' lists of live rays begin (behind the staged blob; launch_shadow).  BLK: see k_extend_parked.
+template <int USE_LDS, int NL, uint32_t LACKS = 0u, int TOP = 0, int BLK = kBlock>
+__global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                                      uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
-                                                                     uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ park_all, uint32_t walk_policy) {
+                                                                     uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t* __restrict__ park_all, uint32_t walk_policy,
+                                                                     uint32_t live_off) {
     extern __shared__ __align__(16) uint32_t lds[];
-    __shared__ uint32_t park_counts[kBlock / 64];
+    __shared__ uint32_t park_counts[BLK / 64];
+    constexpr uint32_t kParkCap = kWaveParkCap * (BLK / 64);   // (shadows ptk::kParkCap: this workgroup's entries per field)
     SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);
     constexpr bool kOnlyEnv = (LACKS & PT_SCENE_NO_LIGHTS) != 0u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -671,7 +687,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
     // a finished ray leaves its contribution where its factor was; the item's rays are summed in order at the end (an item's
     // rays are parked and resumed by the wave that owns the item, so that sum needs no workgroup barrier either)
     auto settle = [&](uint32_t j, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked, uint32_t light, uint32_t cursor) {
-        if (parked) { park_store(pk, atomicAdd(park_count, 1u), j, st, l, bound, (env ? 1u : 0u) | (light + 1u) << 1, cursor); return; }
+        if (parked) { park_store<kParkCap>(pk, atomicAdd(park_count, 1u), j, st, l, bound, (env ? 1u : 0u) | (light + 1u) << 1, cursor); return; }
         const uint32_t item = base + j;
         float lambda[NL], c[NL];
         for (int k = 0; k < NL; ++k) lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item);
@@ -701,8 +717,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
     // The rays that are traced at all — a light sample below the horizon of its surface, or with a zero factor, is not: four in five of
     // C4's — are listed per wave (item and sample number) and traced 64 at a time, so that a step of the wave is 64 live rays and parks at
     // most one ray per lane.  (One ray of every item per step left the lanes of the dead ones idle: lane utilisation 0.21 on C4.)
-    __shared__ uint32_t live_all[(kBlock / 64) * kLiveCap];
-    uint32_t* live = live_all + wave * kLiveCap;
+    uint32_t* live = lds + live_off + wave * live_cap(light_samples);
     uint32_t live_count = 0;   // (wave-uniform)
     for (uint32_t r = 0;;) {
         const bool flush = r == rounds && live_count > 0u;
@@ -751,7 +766,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked(const uint
             }
         }
         __builtin_amdgcn_wave_barrier();
-        park_drain<true>(pk, park_count, r == rounds && live_count == 0u, walk_policy, resume_parked);
+        park_drain<true, kParkCap>(pk, park_count, r == rounds && live_count == 0u, walk_policy, resume_parked);
     }
     PT_TL_END(n);
     __threadfence_block();

@@ -17,6 +17,9 @@ constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // the most LDS a staged blo
 // the 65 KB blob of C3 staged whole leaves two workgroups per CU, 615 Msamples/s; its 6.7 KB core alone, the mesh read through L1/L2,
 // 752.  C2's 14 KB blob staged whole: 1519; its 7 KB core alone: 1089 (the sweep reads the triangles of the two boxes for every ray).
 constexpr uint32_t kLdsAllLimitBytes = 24 * 1024;
+// The parked kernels in workgroups of 512 / 1024 threads (pt_tuning::park_block) stage the whole blob whatever the other kernels do: two workgroups of
+// 512 per CU are four waves per SIMD, and 2 x (72 KB + the waves' lists of live rays) fit the CU's 160 KB.  The gem scene of C3: 66 256 B.
+constexpr uint32_t kParkBlobLimitBytes = 72 * 1024;
 constexpr uint32_t kParkCap = 512, kParkFields = 16;
 constexpr uint32_t kWalkEvictBelow = 32, kWalkSearchBelow = 16;   // pt_tuning::walk_evict_below's and walk_search_below's defaults
 enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_MEDIUM_DROPS, BS_FIELDS };  // per-workgroup statistics (Profile counters)
@@ -28,6 +31,8 @@ struct LaunchCfg { int grid; uint32_t lds_bytes; hipStream_t stream; int lds_mod
                    int dyn_grid = 0; uint32_t* unit_counter = nullptr;   // parked kernels with dynamic units: persistent workgroups and this launch's counter (zeroed)
                    uint32_t lacks = 0;    // PT_SCENE_* bits of what the scene does not hold: the pure sweep forms and the lean k_shade have forms without it
                    uint32_t walk_policy = 0;   // parked kernels: mesh_walk's policy word (pt_tuning::walk_evict_below | walk_search_below << 8)
+                   int park_block = 0;         // parked kernels, static form, one wavelength: 512 or 1024 = workgroups of that many threads that stage the WHOLE blob
+                   uint32_t park_blob_bytes = 0;   //   (this many bytes of LDS) whatever lds_mode says for the other kernels; 0 = workgroups of kBlock, lds_mode
                    bool fuse = false; };  // k_shade traces its own segments (pure sweep scenes, lean form, no transforms): no k_extend launch, no hit queue
 struct SceneArgs { const uint32_t* blob; uint32_t blob_words; const float* tex; };
 

@@ -516,9 +516,10 @@ def _npz_mesh(name):
     return z["positions"], z["faces"], (n if n.shape[0] else None), str(z["material"])
 
 
-def cornell_gem():
+def cornell_gem(gem_z=-0.7):
     """data/scenes/cornell_box_diamond_gem.toml (C3): env replaced by Constant 0 (its HDRI file is absent and
-    env_sampling_probability = 0)."""
+    env_sampling_probability = 0, SURVEY §8(d)).  `gem_z`: the gem's translation along z — the scene file's -0.7 (culet below the floor);
+    the reference's showcase/moissanite_gem_1080p.png shows an earlier placement with the whole gem above the floor (tests only)."""
     b = SceneBuilder()
     add_library_curves(b, ["flat_zero"])
     b.set_environment_constant(b.curve("flat_zero"), 0.0)
@@ -536,7 +537,7 @@ def cornell_gem():
     b.add_rect((2, 2), (1.0, 0.0, 0.0), "X", True, white)
     p, f, n, mtl = _npz_mesh("brilliant_diamond")
     mesh = b.add_mesh(p, f, n, face_materials=b.material(mtl))
-    b.add_mesh_instance(mesh, gem, transform_from_data(scale=(0.5, 0.5, 0.5), translate=(0.0, 0.0, -0.7)))
+    b.add_mesh_instance(mesh, gem, transform_from_data(scale=(0.5, 0.5, 0.5), translate=(0.0, 0.0, gem_z)))
     b.add_camera((-5.0, 0.0, 0.0), (0.0, 0.0, 0.0), 27.8, focal_distance=5.0, aperture_diameter=0.02)
     return b
 

@@ -171,6 +171,19 @@ pt_status ptemu_intersect(pt_scene* sc, size_t n, const float* o, const float* d
     }
     return PT_OK;
 }
+pt_status ptemu_camera_samples(pt_scene* sc, const pt_render_desc* rd, size_t n, const uint32_t* pixel, const uint32_t* sample, float* o, float* d, float* lambda) {
+    RenderParams rp;
+    std::memset(&rp, 0, sizeof(rp));
+    rp.seed = rd->seed; rp.width = rd->width; rp.height = rd->height;
+    rp.wavelength_lo = rd->wavelength_lo; rp.wavelength_span = rd->wavelength_hi - rd->wavelength_lo;
+    rp.camera = pth::camera_params(sc->host.cameras[rd->camera_index], (float)rd->width / (float)rd->height);
+    rp.chunk_pixels = 1;
+    for (size_t i = 0; i < n; ++i) {
+        const PathVertexT<1> p = stage_generate<1>(rp, sample[i], pixel[i]);
+        o[3 * i] = p.o.x; o[3 * i + 1] = p.o.y; o[3 * i + 2] = p.o.z; d[3 * i] = p.d.x; d[3 * i + 1] = p.d.y; d[3 * i + 2] = p.d.z; lambda[i] = p.lambda;
+    }
+    return PT_OK;
+}
 static uint32_t mat_rec(pt_scene* sc, uint32_t m) { return sc->host.blob[PT_HDR_MATERIAL_OFF] + m * PT_MAT_WORDS; }
 pt_status ptemu_bsdf_sample(pt_scene* sc, uint32_t m, size_t n, const float* lambda, const float* wi, const float* s2, float* f, float* wo, float* pdf) {
     SceneView s{sc->host.blob.data(), sc->host.tex.data(), sc->host.blob.data() + sc->host.blob[PT_HDR_CORE_WORDS]};

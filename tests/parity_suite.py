@@ -67,6 +67,21 @@ def intersect_parity(impl, oracle, scene_name, n=4096, seed=21):
     assert_hits_equal(impl.create_scene(b).intersect(o, d), oracle.create_scene(b).intersect(o, d))
 
 
+def camera_parity(impl, oracle, scene_name, width=97, height=61, n=4096, seed=13, **kw):
+    """The first stage of a camera sample (film jitter, wavelength, clamp, Camera::get_ray: tiled.rs:369-375, pt.rs:406-417, projective_camera.rs:101-120)
+    for random (pixel, sample) pairs: origins, directions and wavelengths bit for bit."""
+    b = pkg().scene.SCENES[scene_name]()
+    rng = np.random.default_rng(seed)
+    pixel = rng.integers(0, width * height, n, dtype=np.uint32)
+    sample = rng.integers(0, 5000, n, dtype=np.uint32)
+    rd = pkg().api.render_desc(width, height, 16, 4, **kw)
+    got, want = impl.create_scene(b).camera_samples(rd, pixel, sample), oracle.create_scene(b).camera_samples(rd, pixel, sample)
+    for g, w, what in zip(got, want, ("origin", "direction", "lambda")):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), (scene_name, what)
+    assert np.all(np.abs(np.linalg.norm(got[1], axis=1) - 1.0) < 1e-6)
+    return got
+
+
 def material_parity(impl, oracle, scene_name, n=2048, seed=9):
     b = pkg().scene.SCENES[scene_name]()
     si, so = impl.create_scene(b), oracle.create_scene(b)

@@ -18,7 +18,7 @@ def declared_functions():
 def test_header_declares_the_boundary():
     names = declared_functions()
     for required in ("pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device", "pt_render_multi", "pt_intersect", "pt_bsdf_sample",
-                     "pt_bsdf_eval", "pt_emission", "pt_curve_eval", "pt_last_error", "pt_device_info"):
+                     "pt_bsdf_eval", "pt_emission", "pt_curve_eval", "pt_camera_samples", "pt_last_error", "pt_device_info"):
         assert required in names
 
 
@@ -104,7 +104,7 @@ def test_tuning_default_reads_the_environment_once(pkg, monkeypatch):
         monkeypatch.delenv(name, raising=False)
     t = lib.tuning_default()
     assert (t.flags, t.batch_slots, t.blocks_per_cu, t.park_blocks_per_cu, t.park_dynamic, t.shade_form, t.lds_all_limit, t.multi_virtual) == (0, 0, 0, 0, -1, 0, 0, 0)
-    assert list(t.reserved) == [0] * 6 and t.walk_evict_below == 0 and t.walk_search_below == 0
+    assert list(t.reserved) == [0] * 5 and t.park_block == 0 and t.walk_evict_below == 0 and t.walk_search_below == 0
     monkeypatch.setenv("PT_AMD_BATCH", "4096"); monkeypatch.setenv("PT_AMD_BLOCKS_PER_CU", "8"); monkeypatch.setenv("PT_AMD_NO_FUSE", "1")
     monkeypatch.setenv("PT_AMD_PARK_DYNAMIC", "0"); monkeypatch.setenv("PT_AMD_MULTI_VIRTUAL", "4"); monkeypatch.setenv("PT_AMD_STAGE_TIMING", "0")
     monkeypatch.setenv("PT_AMD_GENERAL_FORMS", "1")

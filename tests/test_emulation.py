@@ -30,6 +30,11 @@ def test_closest_hits_bit_exact(emu, oracle, scene):
     ps.intersect_parity(emu, oracle, scene)
 
 
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "panorama_test", "hdri_small"])
+def test_camera_samples_bit_exact(emu, oracle, scene):
+    ps.camera_parity(emu, oracle, scene, seed=3, wavelength=(400.0, 700.0))
+
+
 @pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives"])
 def test_materials_bit_exact(emu, oracle, scene):
     ps.material_parity(emu, oracle, scene)

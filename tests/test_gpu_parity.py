@@ -51,6 +51,14 @@ def test_closest_hits_bit_exact(engine, oracle, scene):
     ps.intersect_parity(engine, oracle, scene, n=1 << 16)
 
 
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "panorama_test", "hdri_test", "mixed_primitives"])
+def test_camera_samples_bit_exact(engine, oracle, scene):
+    """Camera trait surface (SURVEY a22 + the head of a1 / a2): thin-lens rays with the aperture rejection loop, panorama rays, jitter and wavelength —
+    the stage k_generate runs, probed through pt_camera_samples against the oracle, bit for bit."""
+    ps.camera_parity(engine, oracle, scene, width=1920, height=1080, n=1 << 16)
+    ps.camera_parity(engine, oracle, scene, width=33, height=21, n=4096, seed=5, wavelength=(555.0, 560.0), camera_index=0)
+
+
 @pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives"])
 def test_materials_bit_exact(engine, oracle, scene):
     ps.material_parity(engine, oracle, scene, n=1 << 14)
@@ -215,7 +223,10 @@ def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
                 {"PT_AMD_LDS_ALL_LIMIT": "65536"}, {"PT_AMD_LDS_ALL_LIMIT": "65536", "PT_AMD_PARK_DYNAMIC": "0"}, {"PT_AMD_LDS_ALL_LIMIT": "4096"},
                 {"PT_AMD_NO_MESH_SWEEP": "1", "PT_AMD_NO_PARK": "1"}, {"PT_AMD_NO_SWEEP": "1", "PT_AMD_NO_PARK": "1"}, {"PT_AMD_NO_SWEEP": "1", "PT_AMD_NO_AXIS_SCAN": "1"},
                 {"PT_AMD_WALK_EVICT_BELOW": "1", "PT_AMD_WALK_SEARCH_BELOW": "1"}, {"PT_AMD_WALK_EVICT_BELOW": "64", "PT_AMD_WALK_SEARCH_BELOW": "64"},
-                {"PT_AMD_NO_AXIS_SCAN": "1"}, {"PT_AMD_NO_AXIS_SCAN": "1", "PT_AMD_WALK_EVICT_BELOW": "1", "PT_AMD_WALK_SEARCH_BELOW": "1"}):
+                {"PT_AMD_NO_AXIS_SCAN": "1"}, {"PT_AMD_NO_AXIS_SCAN": "1", "PT_AMD_WALK_EVICT_BELOW": "1", "PT_AMD_WALK_SEARCH_BELOW": "1"},
+                {"PT_AMD_PARK_BLOCK": "512"}, {"PT_AMD_PARK_BLOCK": "1024"}, {"PT_AMD_PARK_BLOCK": "512", "PT_AMD_BLOCKS_PER_CU": "32"}, {"PT_AMD_PARK_BLOCK": "1024", "PT_AMD_BLOCKS_PER_CU": "8"}):
+        # (PT_AMD_PARK_BLOCK, round 4: the parked kernels in workgroups of 512 / 1024 threads that stage the whole blob — the gem scene's 65 KB — while k_shade keeps
+        # its core-only staging; hdri_c4_small's blob is too big for that and keeps its 256-thread forms)
         # (the parked kernels with one static segment per workgroup / with units taken from a counter by persistent workgroups; the whole
         # blob staged in LDS however large — the gem's is 65 KB, staged as its core section by default — / only ever the core section;
         # the mesh walks of a resumed wave without eviction and short searches / leaving at every chance; axis-parallel rays walked instead of
@@ -227,6 +238,9 @@ def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
             monkeypatch.delenv(k) if k != "PT_AMD_BLOCKS_PER_CU" else monkeypatch.setenv(k, "1")
         assert np.array_equal(base.view(np.uint32), film.view(np.uint32)), env
         assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits), env
+        # (the big-workgroup form really ran where it can — the gem scene's 66 KB blob — and not for hdri_c4_small's 675 KB: never a silent fall-back)
+        if scene != "mixed_primitives":
+            assert prof.stage_items[6] == (int(env.get("PT_AMD_PARK_BLOCK", "0")) if scene == "cornell_gem" else 0), (env, prof.stage_items[6])
 
 
 @pytest.mark.parametrize("scene,L", [("cornell_gem", 2), ("hdri_small", 3)])

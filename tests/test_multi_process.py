@@ -172,7 +172,7 @@ def test_bench_gpus_2_launches_two_ranks(tmp_path):
     import torch
     if torch.cuda.device_count() < 2:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode != 0 and r.stdout.strip() == "" and "has no GPU of its own" in r.stderr, r.stderr[-2000:]
+        assert r.returncode != 0 and r.stdout.strip() == "" and ("has no GPU of its own" in r.stderr or "ranks on 1 physical GPU" in r.stderr), r.stderr[:3000]
         cmd.append("--allow-shared-gpus")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
