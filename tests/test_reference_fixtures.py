@@ -260,3 +260,58 @@ def test_showcase_cornell_box_chromaticities(oracle, pkg):
     # the layout itself: green on the left, red on the right, a warm white in between (as the showcase has it)
     gl, rr, bw = chroma(ours, 0.08, 0.5), chroma(ours, 0.93, 0.5), chroma(ours, 0.5, 0.35)
     assert gl[1] > gl[0] and rr[0] > 0.9 and rr[0] > bw[0] > gl[0]
+
+
+def test_showcase_moissanite_gem_layout(oracle, pkg):
+    """A second loose pin against reference-produced pixels (round-3 verdict, item 7): showcase/moissanite_gem_1080p.png, the look of BASELINE's C3 scene
+    (data/scenes/cornell_box_diamond_gem.toml).  Its lighting cannot be compared — the image shows sharp caustics all over the room, i.e. it was made with
+    the reference's light-tracing / bidirectional integrators and an HDRI behind the open front, neither of which the PT path has — so this test compares
+    what does not depend on the integrator: WHERE things are.  The oracle's own camera (pt_camera_samples: jitter + Camera::get_ray) and its World::hit
+    give an id buffer of the scene at 216 x 216; the showcase, cut by that id buffer, must show
+      * the light's underside at the top centre (x 0.417-0.583, y 0.120-0.153) as the one black quad of a bright ceiling (SharpLight: cos^41, black at
+        grazing angles),
+      * the green wall (y = -1) on the LEFT and the red one (y = +1) on the right, every interior pixel of each dominated by its colour — camera
+        handedness (u = -(v_up x w)), vfov, aspect and the wall materials,
+      * the gem's silhouette: the image's fine structure (luminance spread inside 5 x 5 pixel blocks) is concentrated inside the projected mesh.  With
+        the gem where the scene file puts it today (translate z = -0.7, the culet below the floor) the silhouette does NOT fit; raised to z = -0.35 —
+        culet on the image row 0.815 the showcase shows — it does: the image predates that edit of the file.  Mesh scale 0.5, the 302-triangle
+        brilliant_diamond.obj, transform order and the thin-lens camera are what fit.
+    Loose and geometric; parity stays unpinned."""
+    show = _decode_png(os.path.join(REF, "showcase", "moissanite_gem_1080p.png"))[..., :3].astype(np.float64) / 255.0
+    assert show.shape[:2] == (1080, 1080)
+    lin = np.where(show <= 0.04045, show / 12.92, ((show + 0.055) / 1.055) ** 2.4)
+    N, f = 216, 5
+    rgb = lin.reshape(N, f, N, f, 3).mean(axis=(1, 3))
+    Y = 0.2126 * lin[..., 0] + 0.7152 * lin[..., 1] + 0.0722 * lin[..., 2]
+    Ymean, Yspread = Y.reshape(N, f, N, f).mean(axis=(1, 3)), Y.reshape(N, f, N, f).std(axis=(1, 3))
+
+    def id_buffer(gem_z):
+        sc = oracle.create_scene(pkg.scene.cornell_gem(gem_z=gem_z))
+        o, d, _ = sc.camera_samples(pkg.api.render_desc(N, N, 1, 1), np.arange(N * N, dtype=np.uint32), np.zeros(N * N, np.uint32))
+        hits = sc.intersect(o, d)
+        return np.where(hits["valid"] == 1, hits["instance"].astype(np.int64), -1).reshape(N, N)
+
+    def shrink(mask, r):
+        for _ in range(r):
+            mask = mask & np.roll(mask, 1, 0) & np.roll(mask, -1, 0) & np.roll(mask, 1, 1) & np.roll(mask, -1, 1)
+        return mask
+    LIGHT, CEILING, FLOOR, RED, GREEN, BACK, GEM = range(7)   # instance order of scene.cornell_gem = the scene file's
+    ids = id_buffer(-0.35)
+    assert (ids >= 0).all()                                   # the room fills the frame (vfov 27.8 from x = -5)
+    # the light
+    ys, xs = np.where(ids == LIGHT)
+    assert abs(xs.min() / N - 0.417) < 0.01 and abs((xs.max() + 1) / N - 0.583) < 0.01 and abs(ys.min() / N - 0.120) < 0.01 and abs((ys.max() + 1) / N - 0.153) < 0.01
+    assert Ymean[shrink(ids == LIGHT, 1)].mean() < 0.05 * Ymean[shrink(ids == CEILING, 2)].mean()
+    # the walls
+    g, r = rgb[shrink(ids == GREEN, 2)], rgb[shrink(ids == RED, 2)]
+    assert ((g[:, 1] > g[:, 0]) & (g[:, 1] > g[:, 2])).mean() > 0.97 and ((r[:, 0] > r[:, 1]) & (r[:, 0] > r[:, 2])).mean() > 0.97
+    assert np.where(ids == GREEN)[1].max() < N * 0.17 and np.where(ids == RED)[1].min() > N * 0.83        # green left, red right
+    # the gem
+    def contrast(ids):
+        gem = ids == GEM
+        ring = ~gem & ~shrink(~gem, 6) & (ids == BACK)        # the back wall within six cells of the silhouette
+        return np.median(Yspread[shrink(gem, 1)]) / np.median(Yspread[ring])
+    ys, xs = np.where(ids == GEM)
+    assert abs((ys.max() + 1) / N - 0.815) < 0.01 and abs(xs.min() / N - 0.296) < 0.01 and abs((xs.max() + 1) / N - 0.704) < 0.01
+    assert contrast(ids) > 2.0, contrast(ids)
+    assert contrast(id_buffer(-0.7)) < 1.3                    # (where the scene file puts the gem today: not what the image shows)
