@@ -294,6 +294,9 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     LaunchCfg cfg{grid, lds_bytes, stream, mode};
     cfg.dyn_grid = dyn_grid < grid ? dyn_grid : grid;
     cfg.lacks = sc->lacks;
+#ifdef PT_EXPERIMENTS
+    cfg.live_lists = env_u32("PT_AMD_LIVE_LISTS", 0) != 0;   // (k_shadow_live: a measurement build's kernel, profiles/r4_experiments.md)
+#endif
     if (park_big) { cfg.park_block = (int)park_block; cfg.park_blob_bytes = sc->blob_words * 4u; }
     cfg.walk_policy = (tn.walk_evict_below ? tn.walk_evict_below : kWalkEvictBelow) | (tn.walk_search_below ? tn.walk_search_below : kWalkSearchBelow) << 8
                     | ((tn.flags & PT_TUNE_NO_AXIS_SCAN) ? 0u : PT_WALK_SCAN_AXIS);

@@ -70,6 +70,19 @@ void launch_shadow(const LaunchCfg& c, int form, int nl, bool env, const SceneAr
         else if (hero) PT_GO((k_shadow_pooled<PT_LDS_ALL, 4, false>), PT_ARGS); else PT_GO((k_shadow_pooled<PT_LDS_ALL, 1, false>), PT_ARGS);
     }
 #endif
+#ifdef PT_EXPERIMENTS
+    else if (form == PT_FORM_SWEEP && c.live_lists) {   // (the wave's list: three words per entry behind the blob)
+        const uint32_t at = (c.lds_bytes + 15u) & ~15u, live_off = at / 4u, bytes = at + (uint32_t)(kBlock / 64) * live_cap(light_samples) * 12u;
+#define PT_LIVE(NLv, ENVv, LACKSv) go_block(c, kBlock, bytes, k_shadow_live<PT_LDS_ALL, NLv, PT_TRAV_SWEEP, ENVv, LACKSv>, PT_ARGS, live_off)
+        if (c.lacks & PT_SCENE_NO_XF) {
+            if (env) { if (hero) PT_LIVE(4, true, PT_SCENE_NO_XF); else PT_LIVE(1, true, PT_SCENE_NO_XF); }
+            else if (hero) PT_LIVE(4, false, PT_SCENE_NO_XF); else PT_LIVE(1, false, PT_SCENE_NO_XF);
+        } else {
+            if (env) { if (hero) PT_LIVE(4, true, 0u); else PT_LIVE(1, true, 0u); }
+            else if (hero) PT_LIVE(4, false, 0u); else PT_LIVE(1, false, 0u);
+        }
+    }
+#endif
     else if (form == PT_FORM_SWEEP && (c.lacks & PT_SCENE_NO_XF)) {
         if (env) { if (hero) PT_GO((k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, true, PT_SCENE_NO_XF>), PT_ARGS); else PT_GO((k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, true, PT_SCENE_NO_XF>), PT_ARGS); }
         else if (hero) PT_GO((k_shadow<PT_LDS_ALL, 4, PT_TRAV_SWEEP, false, PT_SCENE_NO_XF>), PT_ARGS); else PT_GO((k_shadow<PT_LDS_ALL, 1, PT_TRAV_SWEEP, false, PT_SCENE_NO_XF>), PT_ARGS);
@@ -88,6 +101,10 @@ hipError_t allow_lds_shadow(uint32_t bytes) {
 #define K_SH_DYN1(M) k_shadow_parked_dyn<M, 1>
 #define K_SH_DYN4(M) k_shadow_parked_dyn<M, 4>
     PT_ALLOW_MODES(K_SH_DYN1); PT_ALLOW_MODES(K_SH_DYN4);
+#ifdef PT_EXPERIMENTS
+#define PT_ALLOW_LIVE(NLv, ENVv) allow(reinterpret_cast<const void*>(k_shadow_live<PT_LDS_ALL, NLv, PT_TRAV_SWEEP, ENVv, 0u>)); allow(reinterpret_cast<const void*>(k_shadow_live<PT_LDS_ALL, NLv, PT_TRAV_SWEEP, ENVv, PT_SCENE_NO_XF>))
+    PT_ALLOW_LIVE(1, true); PT_ALLOW_LIVE(1, false); PT_ALLOW_LIVE(4, true); PT_ALLOW_LIVE(4, false);
+#endif
     allow(reinterpret_cast<const void*>(k_shadow_parked<PT_LDS_ALL, 1, 0u, 0, 512>)); allow(reinterpret_cast<const void*>(k_shadow_parked<PT_LDS_ALL, 1, 0u, 0, 1024>));
     { // (the parked forms without a staged blob still keep their live lists in dynamic LDS)
         allow(reinterpret_cast<const void*>(K_SH_PARKED1(PT_LDS_NONE))); allow(reinterpret_cast<const void*>(K_SH_PARKED4(PT_LDS_NONE))); allow(reinterpret_cast<const void*>(K_SH_PARKED1E(PT_LDS_NONE)));

@@ -84,6 +84,9 @@ inline void go_block(const LaunchCfg& c, int block, uint32_t lds_bytes, K kernel
 #ifndef PT_SHADOW4_SWEEP_WAVES
 #define PT_SHADOW4_SWEEP_WAVES 6
 #endif
+#ifndef PT_SHADOW_LIVE_WAVES
+#define PT_SHADOW_LIVE_WAVES 6   // (k_shadow_live: measured below)
+#endif
 #define PT_SHADOW_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? (NL == 1 ? PT_SHADOW_SWEEP_WAVES : PT_SHADOW4_SWEEP_WAVES) : PT_WALK_WAVES)))
 
 // The lean form of k_shade (closed scenes: nearly every segment ends on a surface) reads the whole hit record at once instead of waiting for its
@@ -93,6 +96,9 @@ inline void go_block(const LaunchCfg& c, int block, uint32_t lds_bytes, K kernel
 #endif
 
 enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_ACCUMULATE, ST_COUNT };
+// a wave's list of live light-sample rays (k_shadow_live, k_shadow_parked): fewer than 64 left over + the rays of 64 items — in dynamic LDS behind the
+// staged blob, sized by the render's own light_samples (launch_shadow), so that the staged blob keeps its workgroups per CU
+__host__ __device__ constexpr uint32_t live_cap(uint32_t light_samples) { return 64u * light_samples + 64u; }
 
 // ------------------------------------------------------------------------------------------------ kernels
 // Every kernel is a persistent grid: blocks stage the scene blob into LDS (when USE_LDS), then walk the queue
@@ -393,6 +399,98 @@ __global__ void __launch_bounds__(kBlock) PT_SHADOW_OCC k_shadow(const uint32_t*
     }
 }
 
+#ifdef PT_EXPERIMENTS
+// MEASURED, NOT FASTER (profiles/r4_experiments.md: C2 k_shadow 3279 us, this kernel 3299 at six waves and 3501 at five; C5 2278 / 2418) — a measurement build's kernel.
+// k_shadow with the rays that are traced at all compacted per wave (round 4).  Of C2's light-sample rays 12 % are dead (factor 0: the sample lies below
+// its surface's horizon) and 19 % of the rest meet no light (a ceiling vertex' ray, offset off the ceiling, starts below the lamp it aims at): in k_shadow,
+// which takes "ray l of every item" per step, their lanes sit idle through the whole search — box tests at a lane utilisation of 0.65 where k_extend's run at
+// 0.93 (tools/phase_util.sh).  Here a wave first LISTS the rays that search: per sample number, the lanes read their item's ray, run the light pre-pass
+// (shadow_light_bound: the nearest light hit bounds the search) and append (item, l, stop, kind | bound | bounding light) to the wave's list in LDS with one
+// ballot; whenever the list holds 64 rays — and at the end — the wave traces 64 of them, every lane busy, and leaves each ray's contribution where its factor
+// was; the item's rays are summed in order at the end as before (pt.rs:349-392).  k_shadow_parked's listing, one step further (it lists before the light
+// pre-pass) and without the parking.  A ray's own search is untouched: same bound, same stop rule, same known light.
+template <int USE_LDS, int NL, int TRAV, bool ENV = true, uint32_t LACKS = 0u>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADOW_LIVE_WAVES))) k_shadow_live(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
+                                                                      uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
+                                                                      uint32_t seg_cap, const uint32_t* __restrict__ count_in, uint32_t live_off) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);
+    const uint32_t cap = live_cap(light_samples);   // entries per wave; field f of entry e at live[f * cap + e]
+    const uint32_t wave = PT_UNIFORM(threadIdx.x >> 6);   // (a scalar: with fresh_lane_id below, threadIdx.x need not stay in a register across the rounds)
+    uint32_t* live = lds + live_off + wave * cap * 3u;
+    const uint32_t base = blockIdx.x * seg_cap, n = PT_UNIFORM(count_in[blockIdx.x]);   // (kBlock, not blockDim.x, below: a division by a run-time value runs on the VALU and takes the loop's scalars with it)
+    const uint32_t rounds = (n + (uint32_t)kBlock - 1) / (uint32_t)kBlock;
+    uint32_t live_count = 0;   // (wave-uniform)
+    for (uint32_t r = 0;;) {
+        const bool flush = r == rounds && live_count > 0u;
+        if (!(live_count >= 64u || flush)) {
+            if (r == rounds) break;
+            const uint32_t j = r * (uint32_t)kBlock + (wave << 6 | fresh_lane_id()), item = base + j;
+            ++r;
+            const uint32_t flags = (ENV && j < n) ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
+            for (uint32_t l = 0; l < light_samples; ++l) {
+                bool searches = false;
+                float bound = PT_INF; int stop = PT_STOP_NONE;
+                uint32_t light = 0xffffffffu;
+                const bool env = ENV && ((flags >> l) & 1u) != 0u;
+                ShadowRayT<NL> ray;
+                if (j < n && load_shadow_ray<NL>(shadow, item, l, &ray)) {
+                    if (env) { stop = shadow_env_stop(s); searches = true; }
+                    else if (shadow_light_bound(s, ray.o, ray.d, &bound, &stop, &light)) searches = true;
+                    else for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);   // (no light on its line: it adds nothing)
+                }
+                const unsigned long long m = __ballot(searches);
+                if (searches) {
+                    const uint32_t e = live_count + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+                    live[e] = j | l << 24 | (env ? 1u << 31 : 0u);
+                    live[cap + e] = pt_f2u(bound); live[2u * cap + e] = light;
+                }
+                live_count += (uint32_t)__popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();   // (the list is the wave's own: its writes are in LDS before any of its lanes reads them)
+            if (r < rounds || live_count >= 64u) continue;
+        }
+        const uint32_t take = live_count < 64u ? live_count : 64u;
+        live_count -= take;
+        if (lane_id() < take) {
+            const uint32_t e = live_count + lane_id(), w = live[e], j = w & 0xffffffu, l = (w >> 24) & 7u, item = base + j;
+            const float bound = pt_u2f(live[cap + e]);
+            const uint32_t light = live[2u * cap + e];
+            const bool env = ENV && (w >> 31) != 0u;
+            // one address per ray — the first field of ray l of the item — held across the search; every field after it is an immediate offset (the sample number
+            // differs from lane to lane here: addresses formed field by field from (item, l) are six 64-bit values the compiler keeps alive through phase 3)
+            uint32_t* const rb = shadow.base + qindex(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields, item);
+            auto rf = [&](uint32_t field) { return pt_u2f(rb[(size_t)field << 6]); };
+            const F3 o = f3(rf(SR_OX), rf(SR_OY), rf(SR_OZ));
+            const F3 d = f3(rf(SR_DX), rf(SR_DY), rf(SR_DZ));
+            // (one wavelength: the factor and the wavelength come with the ray — one exposed load latency per step instead of a second one behind the search)
+            const float factor0 = NL == 1 ? rf(SR_FACTOR) : 0.0f, lambda0 = NL == 1 ? qf(shadow, Layout<NL>::sh_lambda, item) : 0.0f;
+            Hit sh;
+            // (the stop rule is the scene's, not the ray's — what shadow_light_bound / shadow_env_stop said when the ray was listed: wave-uniform for the search)
+            const int stop = env ? shadow_env_stop(s) : shadow_light_stop(s);
+            const bool hit = world_hit<TRAV, true>(s, o, d, &sh, bound, stop, light, bound);
+            float c[NL];
+            shadow_ray_contribution<NL>(s, [&](int k) { return NL == 1 ? lambda0 : qf(shadow, Layout<NL>::sh_lambda + (uint32_t)k, item); },
+                                        [&](int k) { return NL == 1 ? factor0 : rf(SR_FACTOR + (uint32_t)k); }, d, env, hit, sh, c);
+            for (int k = 0; k < NL; ++k) rb[(size_t)(SR_FACTOR + k) << 6] = pt_f2u(c[k]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __threadfence_block();   // (an item's rays were traced by the wave that owns the item: its sums below read what its own lanes wrote)
+    for (uint32_t r = 0; r < rounds; ++r) {  // pt.rs:349-392, 596: the item's rays summed in order, divided by L
+        const uint32_t j = r * (uint32_t)kBlock + (wave << 6 | fresh_lane_id());
+        if (j >= n) continue;
+        const uint32_t item = base + j, slot = qu(shadow, Layout<NL>::sh_slot, item);
+        float lc[NL];
+        for (int k = 0; k < NL; ++k) lc[k] = 0.0f;
+        for (uint32_t l = 0; l < light_samples; ++l)
+            for (int k = 0; k < NL; ++k) lc[k] += qf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item);
+        for (int k = 0; k < NL; ++k) energy[(size_t)k * energy_stride + slot] += lc[k] / (float)light_samples;
+    }
+}
+
+#endif   // PT_EXPERIMENTS (k_shadow_live)
+
 // ------------------------------------------------------------------------------------------------ pooled traversal
 // Pure sweep scenes (every leaf in the table: the Cornell box of C2 / C5).  Phases 1 and 2 per lane as in k_extend / k_shadow; phase
 // 3 for the wave's 64 rays together (sweep_run_pooled, pt_device.h): the candidate triangles of all of them are pooled in LDS and
@@ -580,9 +678,7 @@ __device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32
 #endif
 constexpr uint32_t kWaveParkCap = kParkCap / (kBlock / 64);
 static_assert(kWaveParkCap == 128, "a wave's park list: fewer than 64 entries left over + at most 64 new ones per step");
-// a wave's list of live light-sample rays: fewer than 64 left over + the rays of 64 items — in dynamic LDS behind the staged blob, sized by the
-// render's own light_samples (launch_shadow), so that a big staged blob keeps its two workgroups per CU
-__host__ __device__ constexpr uint32_t live_cap(uint32_t light_samples) { return 64u * light_samples + 64u; }
+
 // `walk_policy` (mesh_walk's: pt_tuning::walk_evict_below | walk_search_below << 8): a resumed wave's walks are left by its last lanes once
 // fewer than walk_evict_below are still walking — they park again with their cursor and go on in a later drain.  Not in the very last drain
 // of a wave, which has nobody left to wait for.
@@ -710,8 +806,13 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
         const bool env = kOnlyEnv || (kind & 1u) != 0u;
         // a light ray searches with the early stop whenever it has a finite bound (shadow_light_bound)
         const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
-        const bool again = TOP ? top_walk_resume(s, pr.o, pr.d, bound, stop2, st, &cursor, policy, mine)
-                               : sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound, &cursor, policy, mine);
+        bool again;
+        if (PT_PARKED_EXP & 8) {   // (measurement: parked rays are stored, loaded and carried on behind their mesh — everything but the mesh walk itself)
+            again = false;
+            if (mine) { st.hit &= st.hit - 1; if (st.hit != 0) { const TriRay wtr = tri_ray_prepare(pr.o, pr.d); again = sweep_run<true>(s, pr.o, pr.d, wtr, bound, stop2, st, true, (kind >> 1) - 1u, bound); } }
+        } else
+        again = TOP ? top_walk_resume(s, pr.o, pr.d, bound, stop2, st, &cursor, policy, mine)
+                    : sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound, &cursor, policy, mine);
         if (mine) settle(j2, l2, pr, env, bound, st, again, (kind >> 1) - 1u, cursor);
     };
     // The rays that are traced at all — a light sample below the horizon of its surface, or with a zero factor, is not: four in five of

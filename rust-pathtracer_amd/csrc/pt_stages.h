@@ -40,6 +40,7 @@ template <int NL> struct Layout {
 struct Queue { uint32_t* base; uint32_t capacity; uint32_t fields; };
 #ifdef PT_QUEUE_SOA
 PT_HD size_t qindex(const Queue& q, uint32_t field, uint32_t i) { return (size_t)field * q.capacity + i; }
+PT_HD size_t qstride(const Queue& q) { return q.capacity; }   // words from one field of an item to the next
 #else
 // Tiles of 64 items: field k of item i at base[((i / 64) * fields + k) * 64 + i % 64].  A wave still reads or writes 256 contiguous bytes per
 // field, and all fields of an item lie within fields * 256 bytes of one address: one 64-bit address per item and queue, the field as the
@@ -47,6 +48,7 @@ PT_HD size_t qindex(const Queue& q, uint32_t field, uint32_t i) { return (size_t
 // (tile < 2^24 since capacity <= 2^30, fields < 2^24: masked operands let the compiler take the full-rate 24-bit multiply)
 PT_HD uint32_t qtile(uint32_t tile, uint32_t fields) { return (tile & 0xffffffu) * (fields & 0xffffffu); }
 PT_HD size_t qindex(const Queue& q, uint32_t field, uint32_t i) { return ((size_t)qtile(i >> 6, q.fields) << 6) + (i & 63u) + ((size_t)field << 6); }
+PT_HD size_t qstride(const Queue&) { return 64; }   // words from one field of an item to the next
 #endif
 PT_HD float qf(const Queue& q, uint32_t field, uint32_t i) { return pt_u2f(q.base[qindex(q, field, i)]); }
 PT_HD uint32_t qu(const Queue& q, uint32_t field, uint32_t i) { return q.base[qindex(q, field, i)]; }
@@ -479,29 +481,37 @@ PT_HD ShadeOutT<1> stage_shade_medium(const SceneView& s, const RenderParams& rp
 }
 
 // queue I/O of one light-sample ray
+// The sample number l is a run-time value (a loop counter, or per lane in the kernels that list their rays): one address is formed for the ray's first
+// field and its other fields are constant offsets from it.  Formed field by field — qindex(q, f0 + field, item) — every field is a 64-bit address of its
+// own ((f0 + field) is a 32-bit sum the compiler may not split), seven of them alive at once in k_shade's light-sample loop.
+template <int NL> PT_HD uint32_t* shadow_ray_base(const Queue& q, uint32_t item, uint32_t l) { return q.base + qindex(q, Layout<NL>::sh_head + l * Layout<NL>::sr_fields, item); }
+PT_HD float rayf(const Queue& q, const uint32_t* rb, uint32_t field) { return pt_u2f(rb[field * qstride(q)]); }
+PT_HD void rayfs(const Queue& q, uint32_t* rb, uint32_t field, float v) { rb[field * qstride(q)] = pt_f2u(v); }
 template <int NL>
 PT_HD void store_shadow_ray(const Queue& q, uint32_t item, uint32_t l, const ShadowRayT<NL>& ray) {
-    uint32_t f0 = Layout<NL>::sh_head + l * Layout<NL>::sr_fields;
-    for (int k = 0; k < NL; ++k) qsf(q, f0 + SR_FACTOR + k, item, ray.factor[k]);
+    uint32_t* const rb = shadow_ray_base<NL>(q, item, l);
+    for (int k = 0; k < NL; ++k) rayfs(q, rb, SR_FACTOR + k, ray.factor[k]);
     if (ray_is_live<NL>(ray)) {
-        qsf(q, f0 + SR_OX, item, ray.o.x); qsf(q, f0 + SR_OY, item, ray.o.y); qsf(q, f0 + SR_OZ, item, ray.o.z);
-        qsf(q, f0 + SR_DX, item, ray.d.x); qsf(q, f0 + SR_DY, item, ray.d.y); qsf(q, f0 + SR_DZ, item, ray.d.z);
+        rayfs(q, rb, SR_OX, ray.o.x); rayfs(q, rb, SR_OY, ray.o.y); rayfs(q, rb, SR_OZ, ray.o.z);
+        rayfs(q, rb, SR_DX, ray.d.x); rayfs(q, rb, SR_DY, ray.d.y); rayfs(q, rb, SR_DZ, ray.d.z);
     }
 }
 // (EAGER: origin and direction are read along with the factors instead of after them — a dead ray's are stale words, unused)
 template <int NL, bool EAGER = false>
 PT_HD bool load_shadow_ray(const Queue& q, uint32_t item, uint32_t l, ShadowRayT<NL>* ray) {
-    uint32_t f0 = Layout<NL>::sh_head + l * Layout<NL>::sr_fields;
-    for (int k = 0; k < NL; ++k) ray->factor[k] = qf(q, f0 + SR_FACTOR + k, item);
+    const uint32_t* const rb = shadow_ray_base<NL>(q, item, l);
+    for (int k = 0; k < NL; ++k) ray->factor[k] = rayf(q, rb, SR_FACTOR + k);
     if (!EAGER && !ray_is_live<NL>(*ray)) return false;
-    ray->o = f3(qf(q, f0 + SR_OX, item), qf(q, f0 + SR_OY, item), qf(q, f0 + SR_OZ, item));
-    ray->d = f3(qf(q, f0 + SR_DX, item), qf(q, f0 + SR_DY, item), qf(q, f0 + SR_DZ, item));
+    ray->o = f3(rayf(q, rb, SR_OX), rayf(q, rb, SR_OY), rayf(q, rb, SR_OZ));
+    ray->d = f3(rayf(q, rb, SR_DX), rayf(q, rb, SR_DY), rayf(q, rb, SR_DZ));
     return ray_is_live<NL>(*ray);
 }
 template <int NL>
 PT_HD void clear_shadow_item(const Queue& q, uint32_t item, uint32_t light_samples) {
-    for (uint32_t l = 0; l < light_samples; ++l)
-        for (int k = 0; k < NL; ++k) qsf(q, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
+    for (uint32_t l = 0; l < light_samples; ++l) {
+        uint32_t* const rb = shadow_ray_base<NL>(q, item, l);
+        for (int k = 0; k < NL; ++k) rayfs(q, rb, SR_FACTOR + k, 0.0f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ shadow
@@ -537,6 +547,7 @@ PT_HD bool shadow_light_bound(const SceneView& s, F3 o, F3 d, float* bound, int*
     *bound = t_light; *stop = PT_STOP_NONLIGHT;
     return t_light < PT_INF;
 }
+PT_HD int shadow_light_stop(const SceneView& s) { return (bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_CULL)) ? PT_STOP_NONE : PT_STOP_NONLIGHT; }   // (the stop rule shadow_light_bound sets)
 PT_HD int shadow_env_stop(const SceneView& s) { return (bu(s, PT_HDR_FLAGS) & PT_FLAG_NO_CULL) ? PT_STOP_NONE : PT_STOP_ANY; }
 // One light-sample ray: a light ray (pt.rs:171-217) or an environment ray (pt.rs:252-330, contributes only if nothing is hit: any hit
 // blocks it, so its search ends at the first one; PT_AMD_NO_CULL keeps the full search).  One search call site for both kinds — a
@@ -548,7 +559,7 @@ PT_HD void stage_shadow_ray(const SceneView& s, LambdaOf&& lambda_of, FactorOf&&
     float bound = PT_INF; int stop = PT_STOP_NONE;
     uint32_t light = 0xffffffffu;   // the light whose hit bounds the search: its test has been run, phase 3 takes the distance (sweep_run)
     if (ENV && env) stop = shadow_env_stop(s);
-    else if (!shadow_light_bound(s, o, d, &bound, &stop, &light)) return;
+    else if (!shadow_light_bound(s, o, d, &bound, &stop, &light)) { PT_STAT(rays_without_light); return; }
     Hit sh;
     bool hit = world_hit<TRAV, true>(s, o, d, &sh, bound, stop, light, bound);
     shadow_ray_contribution<NL>(s, lambda_of, factor_of, d, ENV && env, hit, sh, contribution);
@@ -567,7 +578,8 @@ PT_HD void stage_shadow_item(const SceneView& s, uint32_t light_samples, const Q
     auto lambda_of = [&](int k) { return NL == 1 ? lambda0 : qf(shadow, Layout<NL>::sh_lambda + (uint32_t)k, item); };
     for (uint32_t l = 0; l < light_samples; ++l) {
         ShadowRayT<NL> ray;
-        if (!load_shadow_ray<NL, PT_SHADOW_EAGER && TRAV == PT_TRAV_SWEEP>(shadow, item, l, &ray)) continue;
+        if (!load_shadow_ray<NL, PT_SHADOW_EAGER && TRAV == PT_TRAV_SWEEP>(shadow, item, l, &ray)) { PT_STAT(rays_dead); continue; }
+        PT_STAT(rays_live);
         float c[NL];
         // (hero wavelengths: the factors too are read again when the ray contributes, not held across its search)
         const uint32_t ff = Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR;

@@ -419,6 +419,9 @@ def add_library_material(b, name):
     if name == "sharp_light_fluorescent":
         add_library_curves(b, ["fluorescent_x5", "flat_78"])
         return b.material_sharp_light(name, b.curve("fluorescent_x5"), b.curve("flat_78"), 40.0, api.SIDED_REVERSE)
+    if name == "sharp_light_xenon":
+        add_library_curves(b, ["xenon_x5", "flat_78"])
+        return b.material_sharp_light(name, b.curve("xenon_x5"), b.curve("flat_78"), 100.0, api.SIDED_DUAL)
     if name == "sharp_light":
         add_library_curves(b, ["blackbody_5000k", "flat_78"])
         return b.material_sharp_light(name, b.curve("blackbody_5000k"), b.curve("flat_78"), 400.0, api.SIDED_REVERSE)
@@ -754,6 +757,39 @@ def hdri_c4_small():
     return hdri_test(mesh="monkey", hdri_size=(128, 64), importance=(64, 64))
 
 
+def test_prism(hdri_size=(1024, 512), importance=(1024, 1024)):
+    """data/scenes/test_prism.toml of the reference tree: the rect room of the gem scene, a thin xenon SharpLight (Dual, cos^101), the 836-triangle prism.obj
+    in dispersive glass under a transform stack (scale 0.9, rotate 90 degrees about z, translate), camera inside the room, an HDRI environment with
+    env_sampling_probability 0.1 — its `low_res_hdri` file is absent from the tree, so the synthetic HDRI of C4 stands in.  Transforms AND
+    lights AND environment sampling: the scene class that takes the GENERAL kernel forms (nothing the specialised forms lack is missing here)."""
+    b = SceneBuilder()
+    add_library_curves(b, ["srgb_r", "srgb_g", "srgb_b", "flat_zero"])
+    ts = b.texstack_texture4("synthetic_hdri", [b.curve("srgb_r"), b.curve("srgb_g"), b.curve("srgb_b"), b.curve("flat_zero")], synthetic_hdri(*hdri_size))
+    b.set_environment_hdr(ts, 1.0, importance=importance)
+    b.env_sampling_probability = 0.1
+    light = add_library_material(b, "sharp_light_xenon")
+    white = add_library_material(b, "lambertian_white")
+    red = add_library_material(b, "lambertian_red")
+    green = add_library_material(b, "lambertian_green")
+    glass = add_library_material(b, "ggx_glass_dispersive")
+    b.add_rect((0.7, 0.01), (0.0, 0.0, 0.9), "Z", False, light)
+    b.add_rect((2, 2), (0.0, 0.0, 1.0), "Z", True, white)
+    b.add_rect((2, 2), (0.0, 0.0, -1.0), "Z", True, white)
+    b.add_rect((2, 2), (0.0, 1.0, 0.0), "Y", True, red)
+    b.add_rect((2, 2), (0.0, -1.0, 0.0), "Y", True, green)
+    b.add_rect((2, 2), (1.0, 0.0, 0.0), "X", True, white)
+    p, f, n, mtl = _npz_mesh("prism")
+    mesh = b.add_mesh(p, f, n, face_materials=api.material_id(api.TAG_MATERIAL, 0))
+    b.add_mesh_instance(mesh, glass, transform_from_data(scale=(0.9, 0.9, 0.9), rotate=[((0, 0, 1), 90.0)], translate=(0.0, 0.0, -0.1)))
+    b.add_camera((0.5, 0.0, 0.0), (0.0, 0.0, 0.0), 70.4, focal_distance=0.5, aperture_diameter=0.001)
+    return b
+
+
+def test_prism_small():
+    """test_prism with a small HDRI / importance map, for parity tests."""
+    return test_prism(hdri_size=(64, 32), importance=(32, 32))
+
+
 def hdri_emissive_mesh():
     """An HDRI environment and a mesh whose *instance* overrides its material with a light (not a reference scene): the mesh is not in the
     light list (world/mod.rs:45-54 looks at analytic instances' ids and mesh face ids only), so the list is empty — yet its hits carry the
@@ -766,6 +802,6 @@ def hdri_emissive_mesh():
     return b
 
 
-SCENES = {"hdri_emissive_mesh": hdri_emissive_mesh, "hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
+SCENES = {"test_prism": test_prism, "test_prism_small": test_prism_small, "hdri_emissive_mesh": hdri_emissive_mesh, "hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
           "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test, "panorama_test": panorama_test, "empty_env": empty_env,
           "big_sphere_light": big_sphere_light, "fog_ball": fog_ball}

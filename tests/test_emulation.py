@@ -61,6 +61,7 @@ def test_materials_bit_exact(emu, oracle, scene):
     ("mixed_small", 32, 32, 6, 6, {"hero_wavelengths": 4, "light_samples": 2}),
     ("hdri_small", 32, 32, 8, 4, {"light_samples": 6}),       # C4 shape: HDR environment, importance map, env NEE + MIS
     ("hdri_small", 24, 24, 4, 4, {"light_samples": 8}),       # the most light samples an item can hold
+    ("test_prism_small", 40, 40, 6, 8, {"light_samples": 3}),     # the reference tree's test_prism.toml: transform stack + lights + environment sampling — the general kernel forms
     ("hdri_emissive_mesh", 32, 32, 6, 4, {"light_samples": 3}),   # empty light list, but a mesh instance overridden with a light material: its hits emit
     ("fog_ball", 48, 32, 8, 8, {"medium_aware": True}),       # random_walk_medium — HG fog and Rayleigh haze behind passthrough boundaries, fog in glass
     ("fog_ball", 32, 24, 6, 12, {"medium_aware": True, "light_samples": 3, "min_bounces": 3, "seed": 9}),

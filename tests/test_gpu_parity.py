@@ -80,6 +80,8 @@ def test_materials_bit_exact(engine, oracle, scene):
     ("cornell_box", 3, 2, 1, 1, {"tile": (64, 64)}),          # film smaller than a tile
     ("white_furnace", 32, 32, 12, 8, {"light_samples": 6}),
     ("hdri_small", 64, 64, 8, 4, {"light_samples": 6}),
+    ("test_prism_small", 128, 128, 8, 8, {"light_samples": 3}),     # the reference tree's test_prism.toml (transform stack + lights + environment sampling): the GENERAL kernel forms, off the tuned path
+    ("test_prism_small", 96, 64, 6, 6, {"light_samples": 2, "hero_wavelengths": 4}),
     ("hdri_emissive_mesh", 96, 96, 8, 4, {"light_samples": 3}),     # empty light list, but a mesh instance overridden with a light material (round-3 advisor): its hits emit, take no item
     ("hdri_emissive_mesh", 64, 64, 6, 4, {"light_samples": 2, "hero_wavelengths": 4}),
     ("cornell_box", 128, 128, 12, 8, {"hero_wavelengths": 4}),      # C5 shape: four wavelengths per path
@@ -273,7 +275,8 @@ def test_forms_without_transforms_change_nothing(engine, pkg, monkeypatch, scene
     ref = engine.create_scene(b)
     base, pbase = ref.render(rd)
     hits = ref.intersect(o, d)
-    for env in ({"PT_AMD_GENERAL_FORMS": "1"}, {"PT_AMD_NO_FUSE": "1"}, {"PT_AMD_NO_FUSE": "1", "PT_AMD_BLOCKS_PER_CU": "1"}, {"PT_AMD_BLOCKS_PER_CU": "2"}):
+    for env in ({"PT_AMD_GENERAL_FORMS": "1"}, {"PT_AMD_NO_FUSE": "1"}, {"PT_AMD_NO_FUSE": "1", "PT_AMD_BLOCKS_PER_CU": "1"}, {"PT_AMD_BLOCKS_PER_CU": "2"},
+                {"PT_AMD_BLOCKS_PER_CU": "1", "PT_AMD_GENERAL_FORMS": "1"}):
         # (the fused form — k_shade tracing its own segments, the default for single-wavelength scenes of this kind — against k_extend + k_shade;
         # long segments: many rounds per workgroup)
         for k, v in env.items():
@@ -423,6 +426,7 @@ def test_full_size_cornell_properties(engine, oracle, pkg):
     ("cornell_gem", 1920, 1080, 12, {}),                              # C3
     ("hdri_test", 1024, 1024, 4, {"light_samples": 6}),               # C4
     ("cornell_box", 1024, 1024, 8, {"hero_wavelengths": 4}),          # C5
+    ("test_prism", 1024, 1024, 8, {"light_samples": 2}),              # G1 (round-3 verdict, item 5): a reference-tree scene that takes the general kernel forms
 ])
 def test_full_size_baseline_configs(engine, oracle, scene, w, h, mb, kw):
     """The other BASELINE.json configurations at their full film size, 1 spp (C2: 10), against the oracle at matched seeds."""

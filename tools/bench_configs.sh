@@ -8,7 +8,10 @@ python bench.py --scene hdri_test --max-bounces 4 --light-samples 6 --spp-per-st
   --workload "C4: hdri_test sphere + monkey.obj (ggx_gold), synthetic 1024x512 HDRI, 1024x1024 importance map, env_sampling_probability 0.9, 1024x1024, max_bounces=4, L=6" > $OUT/C4.json 2> $OUT/C4.err
 python bench.py --hero 4 --spp-per-step 60 --steps 3 --warmup 1 --cpu-seconds 10 \
   --workload "C5: Cornell box, hero wavelength (4 wavelengths per path), 1024x1024, max_bounces=8, L=2" > $OUT/C5.json 2> $OUT/C5.err
-for c in C2 C3 C4 C5; do python - <<PY
+# G1: not a BASELINE configuration — the reference tree's data/scenes/test_prism.toml (transformed mesh + lights + environment sampling): the general kernel forms
+python bench.py --scene test_prism --max-bounces 8 --light-samples 2 --spp-per-step 120 --steps 3 --warmup 1 --cpu-seconds 10 \
+  --workload "G1: test_prism.toml (rect room, xenon SharpLight, prism.obj 836 triangles in dispersive glass under a transform stack, synthetic HDRI, env_sampling_probability 0.1), 1024x1024, max_bounces=8, L=2" > $OUT/G1.json 2> $OUT/G1.err
+for c in C2 C3 C4 C5 G1; do python - <<PY
 import json
 try:
     d=json.loads(open("$OUT/$c.json").read().strip().split("\n")[-1])

@@ -7,9 +7,13 @@ SRC=$ROOT/rust-pathtracer_amd/csrc; OBJ=/tmp/pt_variant_$name; mkdir -p $OBJ $RO
 FLAGS="--offload-arch=gfx950 -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -w $*"
 cd $SRC
 pids=()
-for f in pt_engine.hip pt_kern_extend.hip pt_kern_shadow.hip pt_output.hip pt_compare.hip pt_scene_host.cpp pt_plan.cpp; do /opt/rocm/bin/hipcc $FLAGS -c $f -o $OBJ/${f%.*}.o & pids+=($!); done
-/opt/rocm/bin/hipcc $FLAGS -DPT_SHADE_NL=1 -c pt_kern_shade.hip -o $OBJ/pt_kern_shade1.o & pids+=($!)
-/opt/rocm/bin/hipcc $FLAGS -DPT_SHADE_NL=4 -c pt_kern_shade.hip -o $OBJ/pt_kern_shade4.o & pids+=($!)
+# (per-file flags as in the Makefile: the light-sample kernels without machine LICM; VARIANT_SHADOW_FLAGS overrides)
+SHADOW_FLAGS=${VARIANT_SHADOW_FLAGS--mllvm -disable-machine-licm}
+for f in pt_engine.hip pt_kern_extend.hip pt_output.hip pt_compare.hip pt_scene_host.cpp pt_plan.cpp; do /opt/rocm/bin/hipcc $FLAGS -c $f -o $OBJ/${f%.*}.o & pids+=($!); done
+/opt/rocm/bin/hipcc $FLAGS $SHADOW_FLAGS -c pt_kern_shadow.hip -o $OBJ/pt_kern_shadow.o & pids+=($!)
+SHADE_FLAGS=${VARIANT_SHADE_FLAGS--mllvm -disable-machine-licm}
+/opt/rocm/bin/hipcc $FLAGS $SHADE_FLAGS -DPT_SHADE_NL=1 -c pt_kern_shade.hip -o $OBJ/pt_kern_shade1.o & pids+=($!)
+/opt/rocm/bin/hipcc $FLAGS $SHADE_FLAGS -DPT_SHADE_NL=4 -c pt_kern_shade.hip -o $OBJ/pt_kern_shade4.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $ROOT/variants/$name.so $OBJ/*.o
 echo built variants/$name.so

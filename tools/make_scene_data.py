@@ -63,7 +63,7 @@ def meshes():
     om = importlib.util.module_from_spec(spec); spec.loader.exec_module(om)
     outdir = os.path.join(os.path.dirname(OUT), "meshes")
     os.makedirs(outdir, exist_ok=True)
-    for name in ("brilliant_diamond", "monkey", "gem"):
+    for name in ("brilliant_diamond", "monkey", "gem", "prism"):
         models = om.load_obj(f"{REF}/meshes/{name}.obj")
         assert len(models) == 1, (name, len(models))
         p, n, f = models[0].arrays()

@@ -20,7 +20,10 @@ def demangle(names):
 
 
 def usage(source, extra):
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + FLAGS + extra + ["--cuda-device-only", "-c", source, "-o", "/dev/null",
+    # (the Makefile's per-file flags: the light-sample and vertex kernels are built without machine LICM)
+    per_file = ["-mllvm", "-disable-machine-licm"] if os.path.basename(source) in ("pt_kern_shadow.hip", "pt_kern_shade.hip") and "-disable-machine-licm" not in extra and "--licm" not in extra else []
+    extra = [e for e in extra if e != "--licm"]
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + FLAGS + per_file + extra + ["--cuda-device-only", "-c", source, "-o", "/dev/null",
                                                                                  "-Rpass-analysis=kernel-resource-usage"]
     err = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True).stderr
     rows, cur = [], None
