@@ -265,9 +265,10 @@ typedef struct pt_tuning {
                                      walking (the rays park again and go on in a later wave); 1 = never, at most 64; 0 = the default */
     uint32_t walk_search_below;   /* PT_AMD_WALK_SEARCH_BELOW: a mesh walk's inner loop (box to box until the lane holds a leaf) ends once fewer lanes than
                                      this are still searching while others hold a leaf; 1 = never, at most 64; 0 = the default */
-    uint32_t park_block;          /* PT_AMD_PARK_BLOCK: 512 or 1024 = the parked kernels (scenes with walked meshes, one wavelength per path) run workgroups of that
-                                     many threads that stage the WHOLE blob in LDS — a blob of up to 64 KB, too big to stage at 256 threads per workgroup (the gem
-                                     scene, C3) — while the other kernels keep their staging mode; 0 / 256 = off */
+    uint32_t park_block;          /* PT_AMD_PARK_BLOCK: the parked kernels (scenes with walked meshes, one wavelength per path) of a scene whose blob is staged by
+                                     its core only but fits 72 KB (the gem scene, C3: 66 KB) can run workgroups of 512 or 1024 threads that stage the WHOLE blob
+                                     in LDS while the other kernels keep their staging mode.  0 = the measured default (the light-sample kernel at 512, the
+                                     closest-hit kernel at 256), 512 / 1024 = both kernels at that size, 256 = off */
     uint32_t reserved[5];         /* must be 0 */
 } pt_tuning;
 /* The defaults, overridden by whatever PT_AMD_* variables the environment holds at the time of the call. */

@@ -247,7 +247,11 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     if (hero && capacity > (1u << 26)) capacity = 1u << 26;  // 4-wavelength queues are ~1.5x wider: 64 Mi slots ~ 24 GB
     // (the medium-aware walk keeps its two extra path fields where the hero layout keeps the passengers' throughputs)
     // the parked kernels in workgroups of 512 / 1024 threads that stage the whole blob (pt_tuning::park_block): static form, one wavelength, a blob that fits
-    const uint32_t park_block = (tn.park_block == 512u || tn.park_block == 1024u) && !hero && sc->blob_words * 4u <= kParkBlobLimitBytes && !(tn.flags & PT_TUNE_NO_LDS) ? tn.park_block : (uint32_t)kBlock;
+    // 0 = the measured default: the light-sample kernel in workgroups of 512 (C3: -5 %), the closest-hit kernel in its own 256 (at 512 it loses its fifth wave
+    // per SIMD: +14 %); 512 / 1024 = both kernels; 256 = neither (profiles/r4_experiments.md section 1)
+    const bool park_big_ok = !hero && sc->blob_words * 4u <= kParkBlobLimitBytes && sc->lds_mode == PT_LDS_CORE && !(tn.flags & PT_TUNE_NO_LDS);
+    const uint32_t park_block = !park_big_ok ? (uint32_t)kBlock : tn.park_block == 0u ? 512u : tn.park_block;
+    const uint32_t park_block_extend = !park_big_ok || tn.park_block == 0u ? (uint32_t)kBlock : tn.park_block;
     pt_status st = ensure_buffers(sc, capacity, rd.light_samples, pixels.size() ? pixels.size() : 1, grid, (hero || rd.medium_aware) ? 4u : 1u, park_block);
     if (st != PT_OK) return st;
     DeviceBuffers& b = sc->buf;
@@ -297,7 +301,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
 #ifdef PT_EXPERIMENTS
     cfg.live_lists = env_u32("PT_AMD_LIVE_LISTS", 0) != 0;   // (k_shadow_live: a measurement build's kernel, profiles/r4_experiments.md)
 #endif
-    if (park_big) { cfg.park_block = (int)park_block; cfg.park_blob_bytes = sc->blob_words * 4u; }
+    if (park_big) { cfg.park_block = (int)park_block; cfg.park_block_extend = (int)park_block_extend; cfg.park_blob_bytes = sc->blob_words * 4u; }
     cfg.walk_policy = (tn.walk_evict_below ? tn.walk_evict_below : kWalkEvictBelow) | (tn.walk_search_below ? tn.walk_search_below : kWalkSearchBelow) << 8
                     | ((tn.flags & PT_TUNE_NO_AXIS_SCAN) ? 0u : PT_WALK_SCAN_AXIS);
     const SceneArgs sargs{sc->d_blob, sc->blob_words, sc->d_tex};

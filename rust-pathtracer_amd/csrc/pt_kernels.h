@@ -87,7 +87,12 @@ inline void go_block(const LaunchCfg& c, int block, uint32_t lds_bytes, K kernel
 #ifndef PT_SHADOW_LIVE_WAVES
 #define PT_SHADOW_LIVE_WAVES 6   // (k_shadow_live: measured below)
 #endif
-#define PT_SHADOW_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? (NL == 1 ? PT_SHADOW_SWEEP_WAVES : PT_SHADOW4_SWEEP_WAVES) : PT_WALK_WAVES)))
+// (round 4, built without machine LICM: the form without transformed instances — C2's — needs 72 VGPRs and takes EIGHT waves with 7 registers spilled, 32 B of
+// scratch: 3260 -> 3175 us on one box, twice (profiles/r4j_flags.txt); the general form would spill 35 at eight and stays at six)
+#ifndef PT_SHADOW_SWEEP_NOXF_WAVES
+#define PT_SHADOW_SWEEP_NOXF_WAVES 8
+#endif
+#define PT_SHADOW_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? (NL == 1 ? ((LACKS & PT_SCENE_NO_XF) ? PT_SHADOW_SWEEP_NOXF_WAVES : PT_SHADOW_SWEEP_WAVES) : PT_SHADOW4_SWEEP_WAVES) : PT_WALK_WAVES)))
 
 // The lean form of k_shade (closed scenes: nearly every segment ends on a surface) reads the whole hit record at once instead of waiting for its
 // first word to say whether there is a hit (load_hit<EAGER>, pt_stages.h): -1.5 % of the kernel on C2.

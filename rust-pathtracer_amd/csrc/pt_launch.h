@@ -31,7 +31,7 @@ struct LaunchCfg { int grid; uint32_t lds_bytes; hipStream_t stream; int lds_mod
                    int dyn_grid = 0; uint32_t* unit_counter = nullptr;   // parked kernels with dynamic units: persistent workgroups and this launch's counter (zeroed)
                    uint32_t lacks = 0;    // PT_SCENE_* bits of what the scene does not hold: the pure sweep forms and the lean k_shade have forms without it
                    uint32_t walk_policy = 0;   // parked kernels: mesh_walk's policy word (pt_tuning::walk_evict_below | walk_search_below << 8)
-                   int park_block = 0;         // parked kernels, static form, one wavelength: 512 or 1024 = workgroups of that many threads that stage the WHOLE blob
+                   int park_block = 0, park_block_extend = 0;   // parked kernels (light-sample / closest-hit), static form, one wavelength: 512 or 1024 = workgroups of that many threads that stage the WHOLE blob
                    uint32_t park_blob_bytes = 0;   //   (this many bytes of LDS) whatever lds_mode says for the other kernels; 0 = workgroups of kBlock, lds_mode
                    bool live_lists = false;    // measurement builds (-DPT_EXPERIMENTS, PT_AMD_LIVE_LISTS=1): k_shadow's sweep forms list the rays that search per wave (k_shadow_live)
                    bool fuse = false; };  // k_shade traces its own segments (pure sweep scenes, lean form, no transforms): no k_extend launch, no hit queue

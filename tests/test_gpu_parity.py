@@ -220,13 +220,16 @@ def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
     ref_scene = engine.create_scene(b)
     assert ref_scene.uses_leaf_sweep()
     base, pbase = ref_scene.render(rd)
+    # (the default: the gem scene's light-sample kernel in workgroups of 512 with the whole 66 KB blob in LDS; the C4 scene's 675 KB blob never)
+    assert scene == "mixed_primitives" or pbase.stage_items[6] == (512 if scene == "cornell_gem" else 0), pbase.stage_items[6]
     for env in ({"PT_AMD_NO_PARK": "1"}, {"PT_AMD_NO_MESH_SWEEP": "1"}, {"PT_AMD_NO_SWEEP": "1"}, {"PT_AMD_NO_LDS": "1"}, {"PT_AMD_NO_CORE_LDS": "1"},
                 {"PT_AMD_BLOCKS_PER_CU": "32"}, {"PT_AMD_PARK_DYNAMIC": "0"}, {"PT_AMD_PARK_DYNAMIC": "1"}, {"PT_AMD_PARK_DYNAMIC": "1", "PT_AMD_PARK_BLOCKS_PER_CU": "1"},
                 {"PT_AMD_LDS_ALL_LIMIT": "65536"}, {"PT_AMD_LDS_ALL_LIMIT": "65536", "PT_AMD_PARK_DYNAMIC": "0"}, {"PT_AMD_LDS_ALL_LIMIT": "4096"},
                 {"PT_AMD_NO_MESH_SWEEP": "1", "PT_AMD_NO_PARK": "1"}, {"PT_AMD_NO_SWEEP": "1", "PT_AMD_NO_PARK": "1"}, {"PT_AMD_NO_SWEEP": "1", "PT_AMD_NO_AXIS_SCAN": "1"},
                 {"PT_AMD_WALK_EVICT_BELOW": "1", "PT_AMD_WALK_SEARCH_BELOW": "1"}, {"PT_AMD_WALK_EVICT_BELOW": "64", "PT_AMD_WALK_SEARCH_BELOW": "64"},
                 {"PT_AMD_NO_AXIS_SCAN": "1"}, {"PT_AMD_NO_AXIS_SCAN": "1", "PT_AMD_WALK_EVICT_BELOW": "1", "PT_AMD_WALK_SEARCH_BELOW": "1"},
-                {"PT_AMD_PARK_BLOCK": "512"}, {"PT_AMD_PARK_BLOCK": "1024"}, {"PT_AMD_PARK_BLOCK": "512", "PT_AMD_BLOCKS_PER_CU": "32"}, {"PT_AMD_PARK_BLOCK": "1024", "PT_AMD_BLOCKS_PER_CU": "8"}):
+                {"PT_AMD_PARK_BLOCK": "256"}, {"PT_AMD_PARK_BLOCK": "512"}, {"PT_AMD_PARK_BLOCK": "1024"}, {"PT_AMD_PARK_BLOCK": "512", "PT_AMD_BLOCKS_PER_CU": "32"},
+                {"PT_AMD_PARK_BLOCK": "1024", "PT_AMD_BLOCKS_PER_CU": "8"}):
         # (PT_AMD_PARK_BLOCK, round 4: the parked kernels in workgroups of 512 / 1024 threads that stage the whole blob — the gem scene's 65 KB — while k_shade keeps
         # its core-only staging; hdri_c4_small's blob is too big for that and keeps its 256-thread forms)
         # (the parked kernels with one static segment per workgroup / with units taken from a counter by persistent workgroups; the whole
@@ -241,8 +244,8 @@ def test_traversal_forms_change_nothing(engine, pkg, monkeypatch, scene, L):
         assert np.array_equal(base.view(np.uint32), film.view(np.uint32)), env
         assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits), env
         # (the big-workgroup form really ran where it can — the gem scene's 66 KB blob — and not for hdri_c4_small's 675 KB: never a silent fall-back)
-        if scene != "mixed_primitives":
-            assert prof.stage_items[6] == (int(env.get("PT_AMD_PARK_BLOCK", "0")) if scene == "cornell_gem" else 0), (env, prof.stage_items[6])
+        if "PT_AMD_PARK_BLOCK" in env and scene != "mixed_primitives":
+            assert prof.stage_items[6] == (int(env["PT_AMD_PARK_BLOCK"]) % 256 and 0 or (int(env["PT_AMD_PARK_BLOCK"]) if env["PT_AMD_PARK_BLOCK"] != "256" else 0) if scene == "cornell_gem" else 0), (env, prof.stage_items[6])
 
 
 @pytest.mark.parametrize("scene,L", [("cornell_gem", 2), ("hdri_small", 3)])
