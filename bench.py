@@ -446,6 +446,7 @@ def main():
     else:
         out = None
     if use_dist:
+        dist.barrier()   # (rank 0 has just spent its CPU-baseline seconds: the ranks leave together)
         dist.destroy_process_group()
     if out is not None:
         try:   # RCCL's version banner sits in the C library's stdout buffer until exit: push it out first

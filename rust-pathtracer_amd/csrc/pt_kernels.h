@@ -92,7 +92,12 @@ inline void go_block(const LaunchCfg& c, int block, uint32_t lds_bytes, K kernel
 #ifndef PT_SHADOW_SWEEP_NOXF_WAVES
 #define PT_SHADOW_SWEEP_NOXF_WAVES 8
 #endif
-#define PT_SHADOW_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? (NL == 1 ? ((LACKS & PT_SCENE_NO_XF) ? PT_SHADOW_SWEEP_NOXF_WAVES : PT_SHADOW_SWEEP_WAVES) : PT_SHADOW4_SWEEP_WAVES) : PT_WALK_WAVES)))
+// (the hero form likewise: C5 k_shadow 2257 -> 2192 us at eight waves, 32-40 B of scratch; profiles/r4l_hero8.txt)
+#ifndef PT_SHADOW4_SWEEP_NOXF_WAVES
+#define PT_SHADOW4_SWEEP_NOXF_WAVES 8
+#endif
+#define PT_SHADOW_OCC __attribute__((amdgpu_waves_per_eu(TRAV == PT_TRAV_SWEEP ? (NL == 1 ? ((LACKS & PT_SCENE_NO_XF) ? PT_SHADOW_SWEEP_NOXF_WAVES : PT_SHADOW_SWEEP_WAVES) \
+                                                                                           : ((LACKS & PT_SCENE_NO_XF) ? PT_SHADOW4_SWEEP_NOXF_WAVES : PT_SHADOW4_SWEEP_WAVES)) : PT_WALK_WAVES)))
 
 // The lean form of k_shade (closed scenes: nearly every segment ends on a surface) reads the whole hit record at once instead of waiting for its
 // first word to say whether there is a hit (load_hit<EAGER>, pt_stages.h): -1.5 % of the kernel on C2.
@@ -678,6 +683,9 @@ __device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32
 // waves — with no workgroup barrier anywhere: a wave that is deep in a mesh never holds the other three up.  (The first
 // version parked per workgroup with three barriers per drain; rocprofv3 showed the C4 shadow kernel waiting 68 % of its
 // wave cycles at 12 % VALU issue.)
+#ifndef PT_PARKED_EAGER
+#define PT_PARKED_EAGER true
+#endif
 #ifndef PT_PARKED_EXP
 #define PT_PARKED_EXP 0   // measurement variants of k_shadow_parked (tools/phase_costs_parked.sh); 0 = the product
 #endif
@@ -787,11 +795,12 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
     if (lane_id() == 0) *park_count = 0;
     // a finished ray leaves its contribution where its factor was; the item's rays are summed in order at the end (an item's
     // rays are parked and resumed by the wave that owns the item, so that sum needs no workgroup barrier either)
-    auto settle = [&](uint32_t j, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked, uint32_t light, uint32_t cursor) {
+    // (`lambda0`, one wavelength per path: the item's wavelength, read along with the ray — PT_PARKED_EAGER — instead of behind the search)
+    auto settle = [&](uint32_t j, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked, uint32_t light, uint32_t cursor, float lambda0) {
         if (parked) { park_store<kParkCap>(pk, atomicAdd(park_count, 1u), j, st, l, bound, (env ? 1u : 0u) | (light + 1u) << 1, cursor); return; }
         const uint32_t item = base + j;
         float lambda[NL], c[NL];
-        for (int k = 0; k < NL; ++k) lambda[k] = qf(shadow, Layout<NL>::sh_lambda + k, item);
+        for (int k = 0; k < NL; ++k) lambda[k] = (NL == 1 && PT_PARKED_EAGER) ? lambda0 : qf(shadow, Layout<NL>::sh_lambda + k, item);
         Hit sh; sh.valid = false;
         const bool hit = st.best_inst != 0xffffffffu;
         // only a light or nothing at all contributes: the record of an occluder is never read (shadow_ray_contribution)
@@ -807,7 +816,8 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
         if (mine) PT_TL_WORK();   // (timeline: parked rays resumed)
         ShadowRayT<NL> pr;
         pr.o = f3(0.0f, 0.0f, 0.0f); pr.d = f3(0.0f, 0.0f, 0.0f);
-        if (mine) load_shadow_ray<NL>(shadow, base + j2, l2, &pr);
+        if (mine) load_shadow_ray<NL, PT_PARKED_EAGER>(shadow, base + j2, l2, &pr);
+        const float lam0 = (NL == 1 && PT_PARKED_EAGER && mine) ? qf(shadow, Layout<NL>::sh_lambda, base + j2) : 0.0f;
         const bool env = kOnlyEnv || (kind & 1u) != 0u;
         // a light ray searches with the early stop whenever it has a finite bound (shadow_light_bound)
         const int stop2 = env ? shadow_env_stop(s) : (bound < PT_INF ? PT_STOP_NONLIGHT : PT_STOP_NONE);
@@ -818,7 +828,7 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
         } else
         again = TOP ? top_walk_resume(s, pr.o, pr.d, bound, stop2, st, &cursor, policy, mine)
                     : sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound, &cursor, policy, mine);
-        if (mine) settle(j2, l2, pr, env, bound, st, again, (kind >> 1) - 1u, cursor);
+        if (mine) settle(j2, l2, pr, env, bound, st, again, (kind >> 1) - 1u, cursor, lam0);
     };
     // The rays that are traced at all — a light sample below the horizon of its surface, or with a zero factor, is not: four in five of
     // C4's — are listed per wave (item and sample number) and traced 64 at a time, so that a step of the wave is 64 live rays and parks at
@@ -848,7 +858,10 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
         if (lane_id() < take) {
             const uint32_t e = live[live_count + lane_id()], j = e >> 3, l = e & 7u, item = base + j;
             ShadowRayT<NL> ray;
-            load_shadow_ray<NL>(shadow, item, l, &ray);
+            // (a listed ray is live: its origin and direction are read along with its factors, one round trip to memory instead of two in a row — these
+            // kernels run three waves per SIMD, which hide little: round 4, PT_PARKED_EAGER)
+            load_shadow_ray<NL, PT_PARKED_EAGER>(shadow, item, l, &ray);
+            const float lam0 = (NL == 1 && PT_PARKED_EAGER) ? qf(shadow, Layout<NL>::sh_lambda, item) : 0.0f;
             const bool env = kOnlyEnv || ((qu(shadow, Layout<NL>::sh_flags, item) >> l) & 1u) != 0;
             float bound = PT_INF; int stop = shadow_env_stop(s);
             uint32_t light = 0xffffffffu;
@@ -868,7 +881,7 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
                 // (measurement variants — no lane may leave the wave's step early, the barrier and the drain below are the whole wave's: 2 = up to the masks, 4 = parked rays dropped)
                 if (PT_PARKED_EXP & 2) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, (float)(uint32_t)st.hit);
                 else if ((PT_PARKED_EXP & 4) && parks) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, 0.0f);
-                else settle(j, l, ray, env, bound, st, parks, light, 0u);
+                else settle(j, l, ray, env, bound, st, parks, light, 0u, lam0);
             }
         }
         __builtin_amdgcn_wave_barrier();
