@@ -842,6 +842,11 @@ static __device__ float g_tl_rays[1 + 4096 * 12];
 #endif
 // `alive` (the parked kernels' last, partly filled drains): a lane without a ray of its own comes along — with the instance of one that has — to
 // take its share of the scans, and leaves before the walk.
+// SPEC (round 4): speculation — while any lane of the wave still searches for its first leaf, a lane that holds one searches on for its NEXT one (`pending2`)
+// instead of idling; the wave runs its triangle pass when nobody lacks a first leaf.  A lane's leaves keep their order; the box tests of the second search see the
+// closest hit from before the first leaf's triangle test, which only lets through boxes whose triangle cannot be accepted (as in the sweep's FIFO).  A lane evicted
+// while it holds an untested leaf leaves with that leaf's own node in the cursor: the box is tested again on resume.
+template <bool SPEC = false>
 PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, F3 d, float bound, int stop, SweepState& st,
                      uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true) {
     const uint32_t NONE = 0xffffffffu;
@@ -1057,10 +1062,10 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
 #if defined(PT_TIMELINE_RAYS) && defined(__HIP_DEVICE_COMPILE__)
     uint32_t tl_steps = 0;
 #endif
+    uint32_t pending = NONE, pending2 = NONE, pend_node = 0u, pend2_node = 0u;   // (pending2, the node indices: SPEC only)
     for (;;) {
-        uint32_t pending = NONE;
         const uint32_t walking = search_below != 0u ? PT_WAVE_ACTIVE(2u) : 0u;   // (the emulation's lane: "one of two", so every search is cut short)
-        while (i < node_count && pending == NONE) {
+        while (i < node_count && (pending == NONE || (SPEC && pending2 == NONE))) {
             PT_STAT_EVENT(5);
             PT_TL_STEP();
             F4 a = mf4(s, node_off + i * PT_NODE_WORDS), b = mf4(s, node_off + i * PT_NODE_WORDS + 4);
@@ -1070,8 +1075,15 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
             // the per-axis filtered form stays out of this loop)
             bool box = (walk_quick ? aabb_hit_node(a, b, cr, true, &entry) : aabb_hit_exact(a, b, lo, ld, &entry)) && !(cull && beyond(entry, limit, cr.base));
             if (shape == PT_NODE_INNER) i = box ? i + 1 : exit_i;
-            else { i = exit_i; if (box) pending = shape; }
-            if (search_below != 0u) { const uint32_t searching = PT_WAVE_ACTIVE(1u); if (searching < search_below && searching < walking) break; }
+            else {
+                if (box) { if (!SPEC || pending == NONE) { pending = shape; pend_node = i; } else { pending2 = shape; pend2_node = i; } }
+                i = exit_i;
+            }
+            if (SPEC) {
+                // the lanes still without a first leaf (of the lanes in this loop: the others hold two leaves or have no node left)
+                const uint32_t searching = (uint32_t)__builtin_popcountll(PT_WAVE_BALLOT(pending == NONE));
+                if (searching == 0u || (search_below != 0u && searching < search_below && searching < walking)) break;
+            } else if (search_below != 0u) { const uint32_t searching = PT_WAVE_ACTIVE(1u); if (searching < search_below && searching < walking) break; }
         }
         bool over = false;
         if (pending != NONE) {
@@ -1089,11 +1101,12 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                 }
             }
         }
-        if (over || i >= node_count) break;
+        pending = pending2; pend_node = pend2_node; pending2 = NONE;   // (without SPEC: NONE — every turn begins without a leaf)
+        if (over || (i >= node_count && pending == NONE)) break;
         if (evict_below != 0u && PT_WAVE_ACTIVE(0u) < evict_below) { evicted = true; break; }
     }
     PT_TL_DONE();
-    if (evicted) *cursor = i;
+    if (evicted) *cursor = (SPEC && pending != NONE) ? pend_node : i;   // (a leaf held untested: its own node, found again on resume)
     return evicted;
 }
 // Phase 3: the primitive tests of the set bits in pre-order (ties are broken by that order, as in world_hit_walk).  With
@@ -1165,6 +1178,7 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
 }
 // A parked lane: walk the mesh of its lowest set bit, then carry on with phase 3 (it may park again at another walked mesh).  With
 // a `policy` that evicts, the walk may be left unfinished (mesh_walk): true then too, the bit still set and `*cursor` where the walk goes on.
+template <bool SPEC = false>
 PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f,
                         uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true) {
     const uint32_t k = alive ? ctz64(st.hit) : 0u;
@@ -1175,7 +1189,7 @@ PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, S
         const uint32_t lead = PT_WAVE_READ(inst, ctz64(PT_WAVE_BALLOT(alive)));
         inst = alive ? inst : lead;
     }
-    if (mesh_walk(s, inst, pt_f2u(be.w) >> 16, o, d, bound, stop, st, cursor, policy, alive)) return true;
+    if (mesh_walk<SPEC>(s, inst, pt_f2u(be.w) >> 16, o, d, bound, stop, st, cursor, policy, alive)) return true;
     if (!alive) return false;
     if (cursor != nullptr) *cursor = 0u;
     st.hit &= st.hit - 1;   // (zero already after an early stop)
@@ -1236,6 +1250,7 @@ PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, S
 }
 // A parked lane: the mesh it stands at (mesh_walk with the wave's policy; true = evicted from it, the place unchanged and `*cursor` where the
 // walk goes on), then the top level from behind that instance (true = parked at the next mesh).
+template <bool SPEC = false>
 PT_HD bool top_walk_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, uint32_t* cursor, uint32_t policy, bool alive) {
     const uint32_t top_off = bu(s, PT_HDR_TOP_NODE_OFF), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
     const uint32_t at = alive ? (uint32_t)st.hit - 1u : 0u;
@@ -1247,7 +1262,7 @@ PT_HD bool top_walk_resume(const SceneView& s, F3 o, F3 d, float bound, int stop
     }
     const uint64_t place = st.hit;
     st.hit = (uint64_t)PT_NODE_EXIT(pt_f2u(a.w)) + 1ull;
-    if (mesh_walk(s, inst_off + shape * PT_INST_WORDS, shape, o, d, bound, stop, st, cursor, policy, alive)) { st.hit = place; return true; }
+    if (mesh_walk<SPEC>(s, inst_off + shape * PT_INST_WORDS, shape, o, d, bound, stop, st, cursor, policy, alive)) { st.hit = place; return true; }
     if (!alive) return false;
     *cursor = 0u;
     return top_walk_run(s, o, d, bound, stop, st, true);

@@ -683,6 +683,13 @@ __device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32
 // waves — with no workgroup barrier anywhere: a wave that is deep in a mesh never holds the other three up.  (The first
 // version parked per workgroup with three barriers per drain; rocprofv3 showed the C4 shadow kernel waiting 68 % of its
 // wave cycles at 12 % VALU issue.)
+// (mesh_walk's speculation — a lane that holds a leaf searches on for its next one while others still search for their first — per parked kernel family)
+#ifndef PT_WALK_SPEC_SHADOW
+#define PT_WALK_SPEC_SHADOW false
+#endif
+#ifndef PT_WALK_SPEC_EXTEND
+#define PT_WALK_SPEC_EXTEND false
+#endif
 #ifndef PT_PARKED_EAGER
 #define PT_PARKED_EAGER true
 #endif
@@ -762,8 +769,8 @@ k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const fl
             if (mine) PT_TL_WORK();   // (timeline: parked rays resumed)
             F3 o = f3(0.0f, 0.0f, 0.0f), d = f3(0.0f, 0.0f, 0.0f);
             if (mine) ray_of(base + j2, &o, &d);
-            const bool again = TOP ? top_walk_resume(s, o, d, PT_INF, PT_STOP_NONE, st, &cursor, policy, mine)
-                                   : sweep_resume(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy, mine);
+            const bool again = TOP ? top_walk_resume<PT_WALK_SPEC_EXTEND>(s, o, d, PT_INF, PT_STOP_NONE, st, &cursor, policy, mine)
+                                   : sweep_resume<PT_WALK_SPEC_EXTEND>(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy, mine);
             if (mine) settle(j2, o, d, st, again, cursor);
         });
     }
@@ -826,8 +833,8 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
             again = false;
             if (mine) { st.hit &= st.hit - 1; if (st.hit != 0) { const TriRay wtr = tri_ray_prepare(pr.o, pr.d); again = sweep_run<true>(s, pr.o, pr.d, wtr, bound, stop2, st, true, (kind >> 1) - 1u, bound); } }
         } else
-        again = TOP ? top_walk_resume(s, pr.o, pr.d, bound, stop2, st, &cursor, policy, mine)
-                    : sweep_resume(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound, &cursor, policy, mine);
+        again = TOP ? top_walk_resume<PT_WALK_SPEC_SHADOW>(s, pr.o, pr.d, bound, stop2, st, &cursor, policy, mine)
+                    : sweep_resume<PT_WALK_SPEC_SHADOW>(s, pr.o, pr.d, bound, stop2, st, (kind >> 1) - 1u, bound, &cursor, policy, mine);
         if (mine) settle(j2, l2, pr, env, bound, st, again, (kind >> 1) - 1u, cursor, lam0);
     };
     // The rays that are traced at all — a light sample below the horizon of its surface, or with a zero factor, is not: four in five of
