@@ -318,7 +318,10 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     // k_shade that traces its own segments: exists for the pure sweep form of a fully staged, transform-free scene shaded by the lean form.
     // Measured (profiles/r3_experiments.md): C2 +4..5 % (4370 us against 2095 + 2490..2640 per bounce); with four wavelengths per path it
     // loses (C5 996 against 1093 Msamples/s: the traversal then runs at the three waves per SIMD the wide vertex code leaves), so single wavelength only.
-    cfg.fuse = !(tn.flags & PT_TUNE_NO_FUSE) && !hero && trav_form == PT_FORM_SWEEP && shade_form == PT_SHADE_LEAN && (cfg.lacks & PT_SCENE_NO_XF) != 0;
+#ifndef PT_FUSE_HERO
+#define PT_FUSE_HERO 0   /* measured again in round 4 (the hero fused form fits four waves per SIMD since it is built without machine LICM): see below */
+#endif
+    cfg.fuse = !(tn.flags & PT_TUNE_NO_FUSE) && (!hero || PT_FUSE_HERO) && trav_form == PT_FORM_SWEEP && shade_form == PT_SHADE_LEAN && (cfg.lacks & PT_SCENE_NO_XF) != 0;
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
     const bool timing = !(tn.flags & PT_TUNE_NO_STAGE_TIMING);
     double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0};
