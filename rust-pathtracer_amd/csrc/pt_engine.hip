@@ -317,9 +317,9 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
                          : (env_prob != 0.0f || tn.shade_form == 2) ? PT_SHADE_FULL : (has_ggx || tn.shade_form == 1) ? PT_SHADE_NO_ENV : PT_SHADE_LEAN;
     // k_shade that traces its own segments: exists for the pure sweep form of a fully staged, transform-free scene shaded by the lean form.
     // Measured (profiles/r3_experiments.md): C2 +4..5 % (4370 us against 2095 + 2490..2640 per bounce); with four wavelengths per path it
-    // loses (C5 996 against 1093 Msamples/s: the traversal then runs at the three waves per SIMD the wide vertex code leaves), so single wavelength only.
+    // lost in round 3 (C5 996 against 1093 Msamples/s: the traversal then ran at the three waves per SIMD the wide vertex code left) and wins since round 4 (below).
 #ifndef PT_FUSE_HERO
-#define PT_FUSE_HERO 0   /* measured again in round 4 (the hero fused form fits four waves per SIMD since it is built without machine LICM): see below */
+#define PT_FUSE_HERO 1   /* round 4: built without machine LICM the hero fused form needs 111 VGPRs — four waves per SIMD, not three — and wins: C5 1153 -> 1179 (3625 us against 1160 + 2578) */
 #endif
     cfg.fuse = !(tn.flags & PT_TUNE_NO_FUSE) && (!hero || PT_FUSE_HERO) && trav_form == PT_FORM_SWEEP && shade_form == PT_SHADE_LEAN && (cfg.lacks & PT_SCENE_NO_XF) != 0;
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
