@@ -28,7 +28,10 @@ inline void go_block(const LaunchCfg& c, int block, uint32_t lds_bytes, K kernel
 // Measured on MI355X (tools/occupancy_sweep.sh): the traversal kernels are VALU-issue bound and gain from a
 // 5th wave; k_shade is a large body (196 VGPRs unconstrained = 2 waves) that gains from a 3rd wave and loses with a 4th.
 #ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 3
+#define PT_SHADE_WAVES 4   // (round 4: the FULL forms at four waves with 26 registers spilled — C4's k_shade 9252 -> 8560 us, C4 +4.8 %, G1 +1 %: the kernel waits for its table fetches; profiles/r4v_full4.txt)
+#endif
+#ifndef PT_SHADE_MEDIUM_WAVES
+#define PT_SHADE_MEDIUM_WAVES 3
 #endif
 #ifndef PT_SHADE4_WAVES
 #define PT_SHADE4_WAVES 2
@@ -52,7 +55,7 @@ inline void go_block(const LaunchCfg& c, int block, uint32_t lds_bytes, K kernel
 // (forms of k_shade, see the kernel: FULL = PT_SHADE_WAVES / PT_SHADE4_WAVES above; measured with tools/shade_occupancy.sh.  FULL on C4:
 // 11442 us at 3 waves, 14735 at 2, 11869 at 4; NO_ENV on C3: 3564 at 3 or 2, 3902 at 4)
 #ifndef PT_SHADE_NO_ENV_WAVES
-#define PT_SHADE_NO_ENV_WAVES 3
+#define PT_SHADE_NO_ENV_WAVES 4   // (round 4, built without machine LICM: 141 VGPRs of demand; at four waves C3's k_shade 2650 -> 2505 us, profiles/r4t_noenv4.txt; round 2's 156-register form lost at four)
 #endif
 #ifndef PT_SHADE4_NO_ENV_WAVES
 #define PT_SHADE4_NO_ENV_WAVES 3   // 6082 us at 3 waves, 7029 at 2, 6759 unconstrained (C5 before the lean form existed)
@@ -343,7 +346,7 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
 // The medium-aware walk's vertex kernel (stage_shade_medium; pt_render_desc::medium_aware): k_shade with the tracked mediums and the
 // "previous vertex was a medium vertex" flag carried in two more fields of the path record.
 template <int USE_LDS>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE_MEDIUM_WAVES)))
 k_shade_medium(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex, RenderParams rp, uint32_t bounce, const uint32_t* __restrict__ pixels,
                Queue paths_in, Queue hits, Queue paths_out, Queue shadow, float* __restrict__ energy, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
                uint32_t* __restrict__ count_out, uint32_t* __restrict__ shadow_count, unsigned long long* __restrict__ block_stats) {

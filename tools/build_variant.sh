@@ -9,7 +9,8 @@ cd $SRC
 pids=()
 # (per-file flags as in the Makefile: the light-sample kernels without machine LICM; VARIANT_SHADOW_FLAGS overrides)
 SHADOW_FLAGS=${VARIANT_SHADOW_FLAGS--mllvm -disable-machine-licm}
-for f in pt_engine.hip pt_kern_extend.hip pt_output.hip pt_compare.hip pt_scene_host.cpp pt_plan.cpp; do /opt/rocm/bin/hipcc $FLAGS -c $f -o $OBJ/${f%.*}.o & pids+=($!); done
+for f in pt_engine.hip pt_output.hip pt_compare.hip pt_scene_host.cpp pt_plan.cpp; do /opt/rocm/bin/hipcc $FLAGS -c $f -o $OBJ/${f%.*}.o & pids+=($!); done
+/opt/rocm/bin/hipcc $FLAGS ${VARIANT_EXTEND_FLAGS-} -c pt_kern_extend.hip -o $OBJ/pt_kern_extend.o & pids+=($!)
 /opt/rocm/bin/hipcc $FLAGS $SHADOW_FLAGS -c pt_kern_shadow.hip -o $OBJ/pt_kern_shadow.o & pids+=($!)
 SHADE_FLAGS=${VARIANT_SHADE_FLAGS--mllvm -disable-machine-licm}
 /opt/rocm/bin/hipcc $FLAGS $SHADE_FLAGS -DPT_SHADE_NL=1 -c pt_kern_shade.hip -o $OBJ/pt_kern_shade1.o & pids+=($!)
