@@ -1,5 +1,10 @@
 // pt_kern_shade.hip — the vertex kernels (k_shade: 3 staging modes x 1 or 4 wavelengths x 3 forms) and their launcher.
-// PT_SHADE_NL selects the half of the family this translation unit holds (the build compiles the two halves in parallel).
+// PT_SHADE_NL (1 | 4 wavelengths per path) and PT_SHADE_PART (0 = the lean forms, 1 = NO_ENV, FULL, medium) select the quarter of the family this translation unit
+// holds: the build compiles the four side by side, and gives part 1 — the forms of scenes with meshes in L1/L2 and importance-map tables — PT_QUEUE_NT (queue words
+// non-temporal, so that the caches keep what is read again; it does not pay for the lean forms, whose scenes live in LDS).
+#ifndef PT_SHADE_PART
+#error "PT_SHADE_PART must be 0 (lean forms) or 1 (NO_ENV, FULL, medium)"
+#endif
 #include "pt_kernels.h"
 
 namespace ptk {
@@ -18,50 +23,62 @@ namespace ptk {
 #define PT_CAT2(a, b) a##b
 #define PT_CAT(a, b) PT_CAT2(a, b)
 
-void PT_CAT(launch_shade_nl, PT_SHADE_NL)(const LaunchCfg& c, int form, const SceneArgs& sc, const RenderParams& rp, uint32_t bounce, const uint32_t* pixels, Queue paths_in,
+#define PT_PARTNAME(base) PT_CAT(PT_CAT(PT_CAT(base, PT_SHADE_NL), _p), PT_SHADE_PART)
+void PT_PARTNAME(launch_shade_nl)(const LaunchCfg& c, int form, const SceneArgs& sc, const RenderParams& rp, uint32_t bounce, const uint32_t* pixels, Queue paths_in,
                                           Queue hits, Queue paths_out, Queue shadow, float* energy, uint32_t seg_cap, const uint32_t* count_in, uint32_t* count_out,
                                           uint32_t* shadow_count, unsigned long long* block_stats) {
+#if PT_SHADE_PART == 1
 #if PT_SHADE_NL == 1
 #define K_SHADE_M(M) k_shade_medium<M>
     if (form == PT_SHADE_MEDIUM) { PT_BY_MODE(K_SHADE_M, PT_ARGS); return; }
 #endif
     if (form == PT_SHADE_FULL && (c.lacks & PT_SCENE_NO_LIGHTS) && PT_SHADE_NL == 1) PT_BY_MODE(K_SHADE_FE, PT_ARGS);   // (an environment is the scene's only emitter)
     else if (form == PT_SHADE_FULL) PT_BY_MODE(K_SHADE_F, PT_ARGS);
-    else if (form == PT_SHADE_NO_ENV) PT_BY_MODE(K_SHADE_N, PT_ARGS);
-    else if (c.fuse) PT_GO(K_SHADE_FUSED, PT_ARGS);   // (the engine asks for it only where this form exists: PT_LDS_ALL, lean, no transforms, pure sweep)
+    else PT_BY_MODE(K_SHADE_N, PT_ARGS);
+#else
+    (void)form;
+    if (c.fuse) PT_GO(K_SHADE_FUSED, PT_ARGS);   // (the engine asks for it only where this form exists: PT_LDS_ALL, lean, no transforms, pure sweep)
     else if (c.lacks & PT_SCENE_NO_XF) PT_BY_MODE(K_SHADE_LX, PT_ARGS);
     else PT_BY_MODE(K_SHADE_L, PT_ARGS);
+#endif
     PT_TL_BUMP(c.stream);
 }
-hipError_t PT_CAT(allow_lds_shade_nl, PT_SHADE_NL)(uint32_t bytes) {
+hipError_t PT_PARTNAME(allow_lds_shade_nl)(uint32_t bytes) {
     hipError_t worst = hipSuccess;
     auto allow = [&](const void* k) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) worst = e; };
 #define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
+#if PT_SHADE_PART == 0
     allow(reinterpret_cast<const void*>(K_SHADE_FUSED));
-    PT_ALLOW_MODES(K_SHADE_L); PT_ALLOW_MODES(K_SHADE_LX); PT_ALLOW_MODES(K_SHADE_N); PT_ALLOW_MODES(K_SHADE_F);
+    PT_ALLOW_MODES(K_SHADE_L); PT_ALLOW_MODES(K_SHADE_LX);
+#else
+    PT_ALLOW_MODES(K_SHADE_N); PT_ALLOW_MODES(K_SHADE_F);
 #if PT_SHADE_NL == 1
     PT_ALLOW_MODES(K_SHADE_FE);
-#endif
-#if PT_SHADE_NL == 1
     PT_ALLOW_MODES(K_SHADE_M);
+#endif
 #endif
     return worst;
 }
 
-#if PT_SHADE_NL == 1
-void launch_shade_nl4(const LaunchCfg&, int, const SceneArgs&, const RenderParams&, uint32_t, const uint32_t*, Queue, Queue, Queue, Queue, float*, uint32_t, const uint32_t*, uint32_t*,
-                      uint32_t*, unsigned long long*);
-hipError_t allow_lds_shade_nl4(uint32_t);
+#if PT_SHADE_NL == 1 && PT_SHADE_PART == 0
+#define PT_SHADE_SIG const LaunchCfg&, int, const SceneArgs&, const RenderParams&, uint32_t, const uint32_t*, Queue, Queue, Queue, Queue, float*, uint32_t, const uint32_t*, uint32_t*, uint32_t*, unsigned long long*
+void launch_shade_nl1_p1(PT_SHADE_SIG); void launch_shade_nl4_p0(PT_SHADE_SIG); void launch_shade_nl4_p1(PT_SHADE_SIG);
+hipError_t allow_lds_shade_nl1_p1(uint32_t); hipError_t allow_lds_shade_nl4_p0(uint32_t); hipError_t allow_lds_shade_nl4_p1(uint32_t);
 void launch_shade(const LaunchCfg& c, int nl, int form, const SceneArgs& sc, const RenderParams& rp, uint32_t bounce, const uint32_t* pixels, Queue paths_in,
                   Queue hits, Queue paths_out, Queue shadow, float* energy, uint32_t seg_cap, const uint32_t* count_in, uint32_t* count_out,
                   uint32_t* shadow_count, unsigned long long* block_stats) {
-    if (nl == 4) launch_shade_nl4(c, form, PT_ARGS_FWD);
-    else launch_shade_nl1(c, form, PT_ARGS_FWD);
+    const bool lean = form == PT_SHADE_LEAN;
+    if (nl == 4) { if (lean) launch_shade_nl4_p0(c, form, PT_ARGS_FWD); else launch_shade_nl4_p1(c, form, PT_ARGS_FWD); }
+    else if (lean) launch_shade_nl1_p0(c, form, PT_ARGS_FWD); else launch_shade_nl1_p1(c, form, PT_ARGS_FWD);
 }
-hipError_t allow_lds_shade(uint32_t bytes) { hipError_t a = allow_lds_shade_nl1(bytes), b = allow_lds_shade_nl4(bytes); return a != hipSuccess ? a : b; }
-#ifdef PT_TIMELINE
-PT_TL_ACCESSOR(pt_debug_timeline_shade)   // (the one-wavelength forms' records)
+hipError_t allow_lds_shade(uint32_t bytes) {
+    hipError_t r = hipSuccess;
+    for (hipError_t e : {allow_lds_shade_nl1_p0(bytes), allow_lds_shade_nl1_p1(bytes), allow_lds_shade_nl4_p0(bytes), allow_lds_shade_nl4_p1(bytes)}) if (e != hipSuccess) r = e;
+    return r;
+}
 #endif
+#if defined(PT_TIMELINE) && PT_SHADE_NL == 1 && PT_SHADE_PART == 1
+PT_TL_ACCESSOR(pt_debug_timeline_shade)   // (the one-wavelength general forms' records: the scenes the timeline was built for)
 #endif
 
 }  // namespace ptk

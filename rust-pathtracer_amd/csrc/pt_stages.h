@@ -50,10 +50,19 @@ PT_HD uint32_t qtile(uint32_t tile, uint32_t fields) { return (tile & 0xffffffu)
 PT_HD size_t qindex(const Queue& q, uint32_t field, uint32_t i) { return ((size_t)qtile(i >> 6, q.fields) << 6) + (i & 63u) + ((size_t)field << 6); }
 PT_HD size_t qstride(const Queue&) { return 64; }   // words from one field of an item to the next
 #endif
-PT_HD float qf(const Queue& q, uint32_t field, uint32_t i) { return pt_u2f(q.base[qindex(q, field, i)]); }
-PT_HD uint32_t qu(const Queue& q, uint32_t field, uint32_t i) { return q.base[qindex(q, field, i)]; }
-PT_HD void qsf(const Queue& q, uint32_t field, uint32_t i, float v) { q.base[qindex(q, field, i)] = pt_f2u(v); }
-PT_HD void qsu(const Queue& q, uint32_t field, uint32_t i, uint32_t v) { q.base[qindex(q, field, i)] = v; }
+// Queue words are read once by one lane and written once by one lane: streamed.  PT_QUEUE_NT marks their loads and stores non-temporal (the `nt` cache policy: first to be
+// evicted), so that the caches keep what IS read again — mesh nodes and triangles, importance-map rows, texels (measured: DESIGN.md section 6).
+#if defined(PT_QUEUE_NT) && PT_QUEUE_NT && defined(__HIP_DEVICE_COMPILE__)
+#define PT_QLOAD(p) __builtin_nontemporal_load(p)
+#define PT_QSTORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define PT_QLOAD(p) (*(p))
+#define PT_QSTORE(v, p) (*(p) = (v))
+#endif
+PT_HD float qf(const Queue& q, uint32_t field, uint32_t i) { return pt_u2f(PT_QLOAD(&q.base[qindex(q, field, i)])); }
+PT_HD uint32_t qu(const Queue& q, uint32_t field, uint32_t i) { return PT_QLOAD(&q.base[qindex(q, field, i)]); }
+PT_HD void qsf(const Queue& q, uint32_t field, uint32_t i, float v) { PT_QSTORE(pt_f2u(v), &q.base[qindex(q, field, i)]); }
+PT_HD void qsu(const Queue& q, uint32_t field, uint32_t i, uint32_t v) { PT_QSTORE(v, &q.base[qindex(q, field, i)]); }
 
 struct RenderParams {
     uint64_t seed;
@@ -485,8 +494,8 @@ PT_HD ShadeOutT<1> stage_shade_medium(const SceneView& s, const RenderParams& rp
 // field and its other fields are constant offsets from it.  Formed field by field — qindex(q, f0 + field, item) — every field is a 64-bit address of its
 // own ((f0 + field) is a 32-bit sum the compiler may not split), seven of them alive at once in k_shade's light-sample loop.
 template <int NL> PT_HD uint32_t* shadow_ray_base(const Queue& q, uint32_t item, uint32_t l) { return q.base + qindex(q, Layout<NL>::sh_head + l * Layout<NL>::sr_fields, item); }
-PT_HD float rayf(const Queue& q, const uint32_t* rb, uint32_t field) { return pt_u2f(rb[field * qstride(q)]); }
-PT_HD void rayfs(const Queue& q, uint32_t* rb, uint32_t field, float v) { rb[field * qstride(q)] = pt_f2u(v); }
+PT_HD float rayf(const Queue& q, const uint32_t* rb, uint32_t field) { return pt_u2f(PT_QLOAD(&rb[field * qstride(q)])); }
+PT_HD void rayfs(const Queue& q, uint32_t* rb, uint32_t field, float v) { PT_QSTORE(pt_f2u(v), &rb[field * qstride(q)]); }
 template <int NL>
 PT_HD void store_shadow_ray(const Queue& q, uint32_t item, uint32_t l, const ShadowRayT<NL>& ray) {
     uint32_t* const rb = shadow_ray_base<NL>(q, item, l);

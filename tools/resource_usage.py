@@ -23,6 +23,9 @@ def usage(source, extra):
     # (the Makefile's per-file flags: the light-sample and vertex kernels are built without machine LICM)
     per_file = ["-mllvm", "-disable-machine-licm"] if os.path.basename(source) in ("pt_kern_shadow.hip", "pt_kern_shade.hip") and "-disable-machine-licm" not in extra and "--licm" not in extra else []
     extra = [e for e in extra if e != "--licm"]
+    if os.path.basename(source) == "pt_kern_shade.hip" and not any(e.startswith("-DPT_SHADE_PART") for e in extra):
+        # (both parts of the vertex family in one table: the lean forms, then the rest with its PT_QUEUE_NT)
+        return usage(source, extra + ["-DPT_SHADE_PART=0"]) + usage(source, extra + ["-DPT_SHADE_PART=1", "-DPT_QUEUE_NT=1"])
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + FLAGS + per_file + extra + ["--cuda-device-only", "-c", source, "-o", "/dev/null",
                                                                                  "-Rpass-analysis=kernel-resource-usage"]
     err = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True).stderr
