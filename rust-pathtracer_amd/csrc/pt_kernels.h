@@ -693,6 +693,9 @@ __device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32
 #ifndef PT_WALK_SPEC_EXTEND
 #define PT_WALK_SPEC_EXTEND false
 #endif
+#ifndef PT_PARKED_NT_RAY
+#define PT_PARKED_NT_RAY false
+#endif
 #ifndef PT_PARKED_EAGER
 #define PT_PARKED_EAGER true
 #endif
@@ -826,7 +829,7 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
         if (mine) PT_TL_WORK();   // (timeline: parked rays resumed)
         ShadowRayT<NL> pr;
         pr.o = f3(0.0f, 0.0f, 0.0f); pr.d = f3(0.0f, 0.0f, 0.0f);
-        if (mine) load_shadow_ray<NL, PT_PARKED_EAGER>(shadow, base + j2, l2, &pr);
+        if (mine) load_shadow_ray<NL, PT_PARKED_EAGER, PT_PARKED_NT_RAY>(shadow, base + j2, l2, &pr);
         const float lam0 = (NL == 1 && PT_PARKED_EAGER && mine) ? qf(shadow, Layout<NL>::sh_lambda, base + j2) : 0.0f;
         const bool env = kOnlyEnv || (kind & 1u) != 0u;
         // a light ray searches with the early stop whenever it has a finite bound (shadow_light_bound)
@@ -870,7 +873,7 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
             ShadowRayT<NL> ray;
             // (a listed ray is live: its origin and direction are read along with its factors, one round trip to memory instead of two in a row — these
             // kernels run three waves per SIMD, which hide little: round 4, PT_PARKED_EAGER)
-            load_shadow_ray<NL, PT_PARKED_EAGER>(shadow, item, l, &ray);
+            load_shadow_ray<NL, PT_PARKED_EAGER, PT_PARKED_NT_RAY>(shadow, item, l, &ray);
             const float lam0 = (NL == 1 && PT_PARKED_EAGER) ? qf(shadow, Layout<NL>::sh_lambda, item) : 0.0f;
             const bool env = kOnlyEnv || ((qu(shadow, Layout<NL>::sh_flags, item) >> l) & 1u) != 0;
             float bound = PT_INF; int stop = shadow_env_stop(s);

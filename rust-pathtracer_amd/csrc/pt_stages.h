@@ -59,6 +59,12 @@ PT_HD size_t qstride(const Queue&) { return 64; }   // words from one field of a
 #define PT_QLOAD(p) (*(p))
 #define PT_QSTORE(v, p) (*(p) = (v))
 #endif
+// (a load that is non-temporal whatever PT_QUEUE_NT says: a light-sample ray's origin and direction in the parked kernels, read once — PT_PARKED_NT_RAY)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_QLOAD_NT(p) __builtin_nontemporal_load(p)
+#else
+#define PT_QLOAD_NT(p) (*(p))
+#endif
 PT_HD float qf(const Queue& q, uint32_t field, uint32_t i) { return pt_u2f(PT_QLOAD(&q.base[qindex(q, field, i)])); }
 PT_HD uint32_t qu(const Queue& q, uint32_t field, uint32_t i) { return PT_QLOAD(&q.base[qindex(q, field, i)]); }
 PT_HD void qsf(const Queue& q, uint32_t field, uint32_t i, float v) { PT_QSTORE(pt_f2u(v), &q.base[qindex(q, field, i)]); }
@@ -506,13 +512,14 @@ PT_HD void store_shadow_ray(const Queue& q, uint32_t item, uint32_t l, const Sha
     }
 }
 // (EAGER: origin and direction are read along with the factors instead of after them — a dead ray's are stale words, unused)
-template <int NL, bool EAGER = false>
+template <int NL, bool EAGER = false, bool NT_RAY = false>
 PT_HD bool load_shadow_ray(const Queue& q, uint32_t item, uint32_t l, ShadowRayT<NL>* ray) {
     const uint32_t* const rb = shadow_ray_base<NL>(q, item, l);
     for (int k = 0; k < NL; ++k) ray->factor[k] = rayf(q, rb, SR_FACTOR + k);
     if (!EAGER && !ray_is_live<NL>(*ray)) return false;
-    ray->o = f3(rayf(q, rb, SR_OX), rayf(q, rb, SR_OY), rayf(q, rb, SR_OZ));
-    ray->d = f3(rayf(q, rb, SR_DX), rayf(q, rb, SR_DY), rayf(q, rb, SR_DZ));
+    auto rd = [&](uint32_t field) { return NT_RAY ? pt_u2f(PT_QLOAD_NT(&rb[field * qstride(q)])) : rayf(q, rb, field); };
+    ray->o = f3(rd(SR_OX), rd(SR_OY), rd(SR_OZ));
+    ray->d = f3(rd(SR_DX), rd(SR_DY), rd(SR_DZ));
     return ray_is_live<NL>(*ray);
 }
 template <int NL>
