@@ -11,6 +11,8 @@ import ctypes as C
 
 import numpy as np
 
+from util import numerics
+
 F = np.float32
 NORMAL_OFFSET = F(0.001)   # src/lib.rs:48
 TAG_LIGHT = 1
@@ -78,6 +80,14 @@ class Probes:
 
     def emission(self, material, lam, wi):
         return F(self.sc.emission(material & 0xFFFF, f3([lam]), f3(wi)[None])[0])
+
+    def env_emission(self, lam):                                              # environment.rs:60-66: Constant { color, strength }
+        e = self.b.environment
+        assert e.kind == self.pkg.api.ENV_CONSTANT
+        return F(F(self.sc.curve_eval(e.curve, f3([lam]))[0]) * F(e.strength))
+
+    def sincos(self, x):                                                      # the routines of include/pt_numerics.h (the `math` crate's are not vendored)
+        return F(numerics(self.oracle, 0, f3([x]))[0]), F(numerics(self.oracle, 1, f3([x]))[0])
 
     def xyz_bar(self, lam):
         out = (C.c_float * 3)()
@@ -158,14 +168,41 @@ def power_heuristic(a, b):
         return F(F(a * a) / F(F(a * a) + F(b * b)))
 
 
+ENV_PDF = F(F(1.0) / F(4.0 * np.pi))      # environment.rs:124-126 (Constant: the uniform sphere, whatever uv)
+
+
+def uv_to_direction(P, u, v):    # math::misc::uv_to_direction as DESIGN.md §10 reads it (z up)
+    st, ct = P.sincos(F(F(u - F(0.5)) * F(2.0) * F(np.pi)))
+    sp, cp = P.sincos(F(v * F(np.pi)))
+    return f3([F(sp * ct), F(sp * st), cp])
+
+
+def direct_illumination_from_world(P, lam, hit_point, hit_normal, frame, wi, material, throughput, s):   # pt.rs:224-331
+    direction = uv_to_direction(P, s[0], s[1])                                # Constant: uv = the raw sample, environment.rs:301-305
+    wo = frame.to_local(direction)
+    if wo[2] <= 0:                                                            # :243-245
+        return F(0.0)
+    refl, scatter_pdf = P.bsdf(material, lam, wi, wo)
+    o = (f3(hit_point) + f3(hit_normal) * F(NORMAL_OFFSET * signum(direction[2]))).astype(np.float32)   # :256 the WORLD z (kept quirk)
+    if P.hit(o, direction) is not None:
+        return F(0.0)
+    weight = F(1.0) if P.rd.only_direct else F(ENV_PDF / F(ENV_PDF + scatter_pdf))
+    return F(F(F(F(F(throughput * weight) * refl) * P.env_emission(lam)) * F(abs(wo[2]))) * F(F(1.0) / ENV_PDF))   # :316-323
+
+
 def direct_illumination(P, lights, lam, hit_point, hit_normal, frame, wi, material, throughput, pixel, sample, bounce):   # pt.rs:333-393 + 146-218
     rd = P.rd
     total = F(0.0)
-    if not lights:
+    env_p = F(P.b.env_sampling_probability) if lights else F(1.0)            # world/mod.rs:126-134
+    if not lights and env_p == 0:
         return total
     for l in range(rd.light_samples):
         r = P.draw4(pixel, sample, 32 + bounce * (1 + rd.light_samples) + 1 + l)
-        x = r[0]                                                              # choose(0, true, false) with p = 0: the sample unchanged, the lights
+        x = r[0]
+        if x < env_p:                                                         # math::random::choose: the sample rescaled on either side
+            total = F(total + direct_illumination_from_world(P, lam, hit_point, hit_normal, frame, wi, material, throughput, r[1:3]))
+            continue
+        x = F(F(x - env_p) / F(F(1.0) - env_p))
         n = len(lights)
         idx = int(min(max(F(F(n) * x), F(0.0)), F(n - 1)))                    # world/mod.rs:100-124
         rect = lights[idx][1]
@@ -196,13 +233,12 @@ def color(P, lights, pixel, sample):   # pt.rs:397-615
     energy = F(0.0)
     for index in range(1, len(path)):
         prev, v = path[index - 1], path[index]
-        if v.kind == "env":                                                   # :487-511 (constant environment of strength 0: nothing, but through the same arithmetic)
+        if v.kind == "env":                                                   # :487-511
             wo = v.normal
             cos_i = F(abs(dot(prev.normal, wo)))
             with np.errstate(divide="ignore", invalid="ignore"):
-                nee = F(F(F(1.0) / F(4.0 * np.pi)) / cos_i)
-                w = power_heuristic(F(prev.pdf_forward / cos_i), nee)
-            energy = F(energy + F(F(w * v.throughput) * F(0.0)))
+                w = power_heuristic(F(prev.pdf_forward / cos_i), F(ENV_PDF / cos_i))
+            energy = F(energy + F(F(w * v.throughput) * P.env_emission(lam)))
         elif v.kind == "light":                                               # :512-561
             em = P.emission(v.material, lam, v.local_wi)
             if em > 0:
@@ -236,6 +272,63 @@ def render(P, lights):
                     temp = np.zeros(3, np.float32)
             film[y, x, :3] = px / F(rd.spp)
     return film
+
+
+def agree(P, lights, lit):
+    mine = render(P, lights)
+    ref, _ = P.sc.render(P.rd)
+    assert (np.isfinite(ref) == np.isfinite(mine)).all()
+    ok = np.isfinite(ref) & np.isfinite(mine)
+    d = np.abs(np.where(ok, mine - ref, 0.0))[..., :3]
+    assert (ref[..., :3] > 0).mean() > lit, float((ref[..., :3] > 0).mean())
+    assert (d / np.maximum(np.abs(ref[..., :3]), 1e-3)).max() < 2e-5, float((d / np.maximum(np.abs(ref[..., :3]), 1e-3)).max())
+    return ref
+
+
+def sky_and_lamp(pkg):
+    """A rect lamp on the ground, a white and a rough-glass sphere over a floor, under a constant sky sampled half of the time (env_sampling_probability 0.5)."""
+    b = pkg.scene.SceneBuilder()
+    pkg.scene.add_library_curves(b, ["simple_sky_blue"])
+    b.set_environment_constant(b.curve("simple_sky_blue"), 0.5)
+    b.env_sampling_probability = 0.5
+    lamp = pkg.scene.add_library_material(b, "diffuse_light_cornell")
+    white = pkg.scene.add_library_material(b, "lambertian_white")
+    glass = pkg.scene.add_library_material(b, "ggx_glass_rough")
+    b.add_rect((0.5, 0.5), (0.0, 0.0, 0.0), "Z", False, lamp)
+    b.add_rect((6.0, 6.0), (0.0, 0.0, -0.01), "Z", True, white)
+    b.add_sphere(0.35, (0.1, 0.5, 0.6), white)
+    b.add_sphere(0.3, (0.0, -0.45, 0.5), glass)
+    b.add_camera((-3.0, 0.0, 1.2), (0.0, 0.0, 0.4), 35.0, focal_distance=3.0, aperture_diameter=0.01)
+    return b
+
+
+def test_environment_light_samples_agree_with_a_third_reading(pkg, oracle):
+    """estimate_direct_illumination_from_world (pt.rs:224-331), the choice between the sky and the lights (pt.rs:346-358, world/mod.rs:126-134) and the MIS weight of
+    an environment vertex (pt.rs:487-511), for a Constant environment: the white furnace (no light: every sample to the sky) and a scene with both."""
+    b = pkg.scene.white_furnace()
+    for kw in ({}, {"only_direct": True}, {"light_samples": 2, "seed": 4}):
+        agree(Probes(pkg, oracle, b, pkg.api.render_desc(10, 10, 3, 8, **kw)), [], 0.6)
+    b = sky_and_lamp(pkg)
+    lights = [(i, rect_of(b, i)) for i, inst in enumerate(b.instances) if inst.kind == pkg.api.SHAPE_RECT and tag(inst.material) == TAG_LIGHT]
+    assert len(lights) == 1
+    for kw in ({}, {"light_samples": 3, "seed": 11}):
+        agree(Probes(pkg, oracle, b, pkg.api.render_desc(16, 12, 3, 6, **kw)), lights, 0.9)
+
+
+def test_gem_film_agrees_with_a_third_reading(pkg, oracle):
+    """The same estimator over C3's scene: rough-free moissanite (GGX dielectric with dispersion) on a transformed mesh, a SharpLight rect, depth 12."""
+    b = pkg.scene.cornell_gem()
+    lights = [(i, rect_of(b, i)) for i, inst in enumerate(b.instances) if inst.kind == pkg.api.SHAPE_RECT and tag(inst.material) == TAG_LIGHT]
+    assert len(lights) == 1
+    rd = pkg.api.render_desc(14, 14, 4, 12, seed=2)
+    P = Probes(pkg, oracle, b, rd)
+    mine = render(P, lights)
+    ref, _ = P.sc.render(rd)
+    assert (np.isfinite(ref) == np.isfinite(mine)).all()
+    ok = np.isfinite(ref) & np.isfinite(mine)
+    d = np.abs(np.where(ok, mine - ref, 0.0))[..., :3]
+    assert (ref[..., :3] > 0).mean() > 0.3
+    assert (d / np.maximum(np.abs(ref[..., :3]), 1e-3)).max() < 2e-5
 
 
 def test_cornell_film_agrees_with_a_third_reading(pkg, oracle):
