@@ -38,6 +38,7 @@
 #define PT_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* a value every lane of the wave holds */
 #define PT_WAVE_ACTIVE(host_value) ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)))  /* the lanes that execute this line */
 #define PT_WAVE_BALLOT(x) ((unsigned long long)__builtin_amdgcn_ballot_w64(x))
+#define PT_WAVE_MEMBER(mask) (__builtin_amdgcn_inverse_ballot_w64(mask))   /* whether this lane's bit is set in a wave-uniform mask: the mask itself as the lane predicate, no instruction */
 #define PT_WAVE_RANK(mask) ((uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)((mask) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mask), 0u)))  /* set bits of `mask` below this lane */
 #define PT_WAVE_READ(x, lane) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (int)(lane)))   /* lane's value of a 32-bit x, in every lane (a scalar) */
 #else
@@ -46,6 +47,7 @@
 #define PT_UNIFORM(x) (x)
 #define PT_WAVE_ACTIVE(host_value) (host_value)
 #define PT_WAVE_BALLOT(x) ((x) ? 1ull : 0ull)
+#define PT_WAVE_MEMBER(mask) (((mask) & 1ull) != 0ull)
 #define PT_WAVE_RANK(mask) 0u
 #define PT_WAVE_READ(x, lane) ((void)(lane), (uint32_t)(x))
 #endif
@@ -420,6 +422,73 @@ PT_HD void aabb_classify_by(uint32_t code, F4 a, F4 b, const RayPrep& rp, float*
         default: aabb_classify_code<4>(a, b, rp, entry, hit, undecided); break;
     }
 }
+// The decision as two wave masks (the lanes that hit, the lanes too close to call).  A lane predicate that crosses a branch — even a wave-uniform one — is
+// merged by the compiler with three scalar instructions per predicate and path (and-not exec, and exec, or); a ballot is the comparison's own result, and a
+// wave mask crosses control flow as a plain scalar value.  The scalar unit is shared by the four SIMDs of a CU (tools/microbench/salu_issue.hip: 540 G
+// scalar instructions per second for the whole chip, and one scalar instruction among four multiply-adds costs those a third of their rate), so the
+// light-sample kernel's 0.78 scalar instructions per vector one were a bound of their own.
+// Each comparison is balloted by itself (its own result register) and the masks are combined by scalar instructions: the ballot of a compound
+// predicate is compiled as a select and a second comparison.  `undecided` may hold bits of lanes that do not run the test: the caller masks it.
+PT_HD void aabb_wave_thick(F4 a, F4 b, const RayPrep& rp, float* entry, uint64_t* hit, uint64_t* undecided) {
+    PT_STAT(box_tests);
+    float p0 = approx_fma(a.x, rp.r.x, rp.nor.x), q0 = approx_fma(b.x, rp.r.x, rp.nor.x);
+    float p1 = approx_fma(a.y, rp.r.y, rp.nor.y), q1 = approx_fma(b.y, rp.r.y, rp.nor.y);
+    float p2 = approx_fma(a.z, rp.r.z, rp.nor.z), q2 = approx_fma(b.z, rp.r.z, rp.nor.z);
+    float n0 = __builtin_fminf(p0, q0), x0 = __builtin_fmaxf(p0, q0), n1 = __builtin_fminf(p1, q1), x1 = __builtin_fmaxf(p1, q1);
+    float n2 = __builtin_fminf(p2, q2), x2 = __builtin_fmaxf(p2, q2);
+    float lo = slab_entry(n0, n1, n2), hi = slab_exit(x0, x1, x2);
+    float e = approx_fma(PT_SLAB_EPS, lo + pt_abs(hi), rp.base), gap = lo - hi;
+    *entry = lo;
+    const uint64_t H = PT_WAVE_BALLOT(gap < -e), M = PT_WAVE_BALLOT(gap > e);
+    *hit = H; *undecided = ~(H | M);
+}
+PT_HD void aabb_wave_flat(F4 a, F4 b, const RayPrep& rp, float* entry, uint64_t* hit, uint64_t* undecided) {
+    PT_STAT(box_tests);
+    float p0 = approx_fma(a.x, rp.r.x, rp.nor.x), q0 = approx_fma(b.x, rp.r.x, rp.nor.x);
+    float p1 = approx_fma(a.y, rp.r.y, rp.nor.y), q1 = approx_fma(b.y, rp.r.y, rp.nor.y);
+    float p2 = approx_fma(a.z, rp.r.z, rp.nor.z), q2 = approx_fma(b.z, rp.r.z, rp.nor.z);
+    float n0 = __builtin_fminf(p0, q0), x0 = __builtin_fmaxf(p0, q0), n1 = __builtin_fminf(p1, q1), x1 = __builtin_fmaxf(p1, q1);
+    float n2 = __builtin_fminf(p2, q2), x2 = __builtin_fmaxf(p2, q2);
+    float m0 = __builtin_fmaxf(__builtin_fmaxf(n1, n2), 0.0f), m1 = __builtin_fmaxf(__builtin_fmaxf(n0, n2), 0.0f), m2 = __builtin_fmaxf(__builtin_fmaxf(n0, n1), 0.0f);
+    float e0 = approx_fma(PT_SLAB_EPS, m0 + pt_abs(x0), rp.base), e1 = approx_fma(PT_SLAB_EPS, m1 + pt_abs(x1), rp.base), e2 = approx_fma(PT_SLAB_EPS, m2 + pt_abs(x2), rp.base);
+    *entry = __builtin_fmaxf(m0, n0);
+    const uint64_t M = PT_WAVE_BALLOT(m0 > x0 + e0) | PT_WAVE_BALLOT(m1 > x1 + e1) | PT_WAVE_BALLOT(m2 > x2 + e2);
+    const uint64_t H = PT_WAVE_BALLOT(m0 < x0 - e0) & PT_WAVE_BALLOT(m1 < x1 - e1) & PT_WAVE_BALLOT(m2 < x2 - e2) & ~M;
+    *hit = H; *undecided = ~(H | M);
+}
+template <int K>
+PT_HD void aabb_wave_flat1(F4 a, F4 b, const RayPrep& rp, float* entry, uint64_t* hit, uint64_t* undecided) {
+    PT_STAT(box_tests);
+    const float ak = K == 0 ? a.x : (K == 1 ? a.y : a.z), rk = K == 0 ? rp.r.x : (K == 1 ? rp.r.y : rp.r.z), nk = K == 0 ? rp.nor.x : (K == 1 ? rp.nor.y : rp.nor.z);
+    const float ai = K == 0 ? a.y : a.x, bi = K == 0 ? b.y : b.x, ri = K == 0 ? rp.r.y : rp.r.x, ni_ = K == 0 ? rp.nor.y : rp.nor.x;
+    const float al = K == 2 ? a.y : a.z, bl = K == 2 ? b.y : b.z, rl = K == 2 ? rp.r.y : rp.r.z, nl_ = K == 2 ? rp.nor.y : rp.nor.z;
+    const float tk = approx_fma(ak, rk, nk);
+    const float pi = approx_fma(ai, ri, ni_), qi = approx_fma(bi, ri, ni_), pl = approx_fma(al, rl, nl_), ql = approx_fma(bl, rl, nl_);
+    const float n_i = __builtin_fminf(pi, qi), x_i = __builtin_fmaxf(pi, qi), n_l = __builtin_fminf(pl, ql), x_l = __builtin_fmaxf(pl, ql);
+    const float lo = slab_entry(n_i, n_l, n_l), hi = __builtin_fminf(x_i, x_l);
+    const float e = approx_fma(PT_SLAB_EPS, (lo + pt_abs(hi)) + pt_abs(tk), rp.base);
+    const float g1 = lo - tk, g2 = tk - hi;
+    *entry = tk;
+    const uint64_t H = PT_WAVE_BALLOT(g1 < -e) & PT_WAVE_BALLOT(g2 < -e), M = PT_WAVE_BALLOT(g1 > e) | PT_WAVE_BALLOT(g2 > e);
+    *hit = H; *undecided = ~(H | M);
+}
+template <int CODE>
+PT_HD void aabb_classify_wave(F4 a, F4 b, const RayPrep& rp, float* entry, uint64_t* hit, uint64_t* undecided) {
+    if (CODE == 0) aabb_wave_thick(a, b, rp, entry, hit, undecided);
+    else if (CODE == 1) aabb_wave_flat1<0>(a, b, rp, entry, hit, undecided);
+    else if (CODE == 2) aabb_wave_flat1<1>(a, b, rp, entry, hit, undecided);
+    else if (CODE == 3) aabb_wave_flat1<2>(a, b, rp, entry, hit, undecided);
+    else aabb_wave_flat(a, b, rp, entry, hit, undecided);
+}
+PT_HD void aabb_classify_wave_by(uint32_t code, F4 a, F4 b, const RayPrep& rp, float* entry, uint64_t* hit, uint64_t* undecided) {   // `code` wave-uniform
+    switch (code) {
+        case 0: aabb_classify_wave<0>(a, b, rp, entry, hit, undecided); break;
+        case 1: aabb_classify_wave<1>(a, b, rp, entry, hit, undecided); break;
+        case 2: aabb_classify_wave<2>(a, b, rp, entry, hit, undecided); break;
+        case 3: aabb_classify_wave<3>(a, b, rp, entry, hit, undecided); break;
+        default: aabb_classify_wave<4>(a, b, rp, entry, hit, undecided); break;
+    }
+}
 // (the same as one three-way value, for the per-lane loops — BVH walk steps, mesh sweep — whose compiled form is better with it)
 PT_HD int aabb_classify(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry) {
     PT_STAT(box_tests);
@@ -682,37 +751,49 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
     // compiler keeps them in scalar registers) and every mask word costs one select-and-or.
     // An undecided box is rare (0.8 % of the rays meet one): its masks are touched only in the waves where some lane has one — a
     // scalar test of the predicate's ballot instead of four vector instructions per box.
-    auto mark = [&](bool h, bool u, uint32_t mlo, uint32_t mhi) {
-        const uint32_t sh = h ? ~0u : 0u;
-        hit_lo |= sh & mlo; hit_hi |= sh & mhi;
-        if (PT_WAVE_ANY(u)) { PT_KEEP_BRANCH(); const uint32_t su = u ? ~0u : 0u; unc_lo |= su & mlo; unc_hi |= su & mhi; }
+    // The decisions are wave masks (aabb_classify_wave): the lanes whose ray the filter takes (`q`) run the test, the others are undecided at every box;
+    // on the device every lane computes (a lane outside `q` computes on values the filter's bounds do not cover: its bits are masked, nothing reads them).
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr bool every_lane = true;
+#else
+    constexpr bool every_lane = false;   // (the emulation's one lane: the test only where the device's result would be read; PT_STAT counts those)
+#endif
+    const uint64_t q = PT_WAVE_BALLOT(quick), nq = PT_WAVE_BALLOT(!quick);
+    auto mark = [&](uint64_t H, uint64_t U, uint32_t mlo, uint32_t mhi) {
+        const bool hl = PT_WAVE_MEMBER(H);
+        hit_lo |= hl ? mlo : 0u; hit_hi |= hl ? mhi : 0u;
+        if (U != 0ull) { PT_KEEP_BRANCH(); const bool ul = PT_WAVE_MEMBER(U); unc_lo |= ul ? mlo : 0u; unc_hi |= ul ? mhi : 0u; }
     };
     for (uint32_t j = 0; j < count; ++j) {
         const uint32_t e = PT_UNIFORM(sweep + j * PT_SWEEP_INST_WORDS);
         const F4 h0 = bf4(s, e), a = bf4(s, e + 4), b = bf4(s, e + 8);
         const uint32_t kf = PT_UNIFORM(pt_f2u(h0.y));
         float entry = 0.0f;
-        bool ih = false, iu = true;   // (a ray the filter cannot take: every box is undecided)
+        uint64_t ih = 0ull, iu = 0ull;
         // (An untransformed mesh instance's box holds every box of its leaves, so its own test decides nothing — but it lets a wave whose
         // rays all miss the instance skip the leaves: without it C2's k_extend takes 2360 us instead of 2283, k_shadow 4648 instead of 4466.)
-        if (quick) aabb_classify_by((kf >> 11) & 7u, a, b, wr, &entry, &ih, &iu);
-        if (bounded && cull_top && ih && (kf & 0xffu) != PT_SHAPE_SPHERE && beyond(entry, bound, wr.base)) ih = false;
+        if (every_lane || q != 0ull) aabb_classify_wave_by((kf >> 11) & 7u, a, b, wr, &entry, &ih, &iu);
+        ih &= q; iu = (iu & q) | nq;   // (a ray the filter cannot take: every box is undecided)
+        // (`bound` = inf culls nothing: the comparison is false)
+        if (cull_top && (kf & 0xffu) != PT_SHAPE_SPHERE) ih &= ~PT_WAVE_BALLOT(beyond(entry, bound, wr.base));
         mark(ih, iu, pt_f2u(h0.z), pt_f2u(h0.w));
-        const bool inside = ih || iu;
-        if ((kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH && (kf >> 24) != 0u && PT_WAVE_ANY(inside)) {
+        const uint64_t inside = ih | iu;
+        if ((kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH && (kf >> 24) != 0u && inside != 0ull) {
             const uint32_t tl = PT_UNIFORM(pt_f2u(a.w)), tc = kf >> 24;   // the leaves with a box test of their own
             const uint32_t groups = PT_UNIFORM(pt_f2u(bf4(s, e + 12).x));   // the leaves come grouped by the form of their box test
             // the triangle leaves against the instance's ray: the world ray itself unless the instance is transformed (a branch
             // on a wave-uniform flag, not a copy of the prepared ray: 20 registers moved per mesh instance otherwise)
-            auto leaves = [&](const RayPrep& lr, bool lquick) {
+            auto leaves = [&](const RayPrep& lr, uint64_t lq, uint64_t lnq) {
+                const uint64_t qi = lq & inside, nqi = lnq & inside;
                 uint32_t t = 0;
                 auto group = [&](auto code, uint32_t n) {
                     for (const uint32_t end = t + n; t < end; ++t) {
                         const F4 ta = bf4(s, tl + t * PT_SWEEP_TRI_WORDS), tb = bf4(s, tl + t * PT_SWEEP_TRI_WORDS + 4);
-                        bool th = false, tu = true;
-                        if (lquick) aabb_classify_code<decltype(code)::value>(ta, tb, lr, &entry, &th, &tu);
-                        if (bounded && cull_mesh && th && beyond(entry, bound, lr.base)) th = false;
-                        mark(th && inside, tu && inside, pt_f2u(ta.w), pt_f2u(tb.w));
+                        uint64_t th = 0ull, tu = 0ull;
+                        if (every_lane || qi != 0ull) aabb_classify_wave<decltype(code)::value>(ta, tb, lr, &entry, &th, &tu);
+                        th &= qi; tu = (tu & qi) | nqi;
+                        if (cull_mesh) th &= ~PT_WAVE_BALLOT(beyond(entry, bound, lr.base));
+                        mark(th, tu, pt_f2u(ta.w), pt_f2u(tb.w));
                     }
                 };
                 const uint32_t n0 = groups & 0xffu, n1 = (groups >> 8) & 0xffu, n2 = (groups >> 16) & 0xffu, n3 = groups >> 24;
@@ -722,8 +803,9 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
                 F3 lo, ld;
                 instance_local_ray(s, pt_f2u(h0.x), o, d, &lo, &ld);
                 const RayPrep lr = ray_prepare(lo, ld);
-                leaves(lr, lr.fast && !exact && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f);
-            } else leaves(wr, quick);
+                const bool lquick = lr.fast && !exact && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f;
+                leaves(lr, PT_WAVE_BALLOT(lquick), PT_WAVE_BALLOT(!lquick));
+            } else leaves(wr, q, nq);
         }
     }
     uint64_t hit = (uint64_t)hit_lo | (uint64_t)hit_hi << 32, unc = (uint64_t)unc_lo | (uint64_t)unc_hi << 32;
