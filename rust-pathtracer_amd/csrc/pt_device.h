@@ -38,6 +38,7 @@
 #define PT_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* a value every lane of the wave holds */
 #define PT_WAVE_ACTIVE(host_value) ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)))  /* the lanes that execute this line */
 #define PT_WAVE_BALLOT(x) ((unsigned long long)__builtin_amdgcn_ballot_w64(x))
+#define PT_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))   /* the two values exist here, in vector registers: their loads are not sunk past this point */
 #define PT_WAVE_MEMBER(mask) (__builtin_amdgcn_inverse_ballot_w64(mask))   /* whether this lane's bit is set in a wave-uniform mask: the mask itself as the lane predicate, no instruction */
 #define PT_WAVE_RANK(mask) ((uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)((mask) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mask), 0u)))  /* set bits of `mask` below this lane */
 #define PT_WAVE_READ(x, lane) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (int)(lane)))   /* lane's value of a 32-bit x, in every lane (a scalar) */
@@ -47,6 +48,7 @@
 #define PT_UNIFORM(x) (x)
 #define PT_WAVE_ACTIVE(host_value) (host_value)
 #define PT_WAVE_BALLOT(x) ((x) ? 1ull : 0ull)
+#define PT_PIN2(a, b)
 #define PT_WAVE_MEMBER(mask) (((mask) & 1ull) != 0ull)
 #define PT_WAVE_RANK(mask) 0u
 #define PT_WAVE_READ(x, lane) ((void)(lane), (uint32_t)(x))
@@ -359,7 +361,9 @@ PT_HD bool beyond(float entry, float closest, float base) { return entry > close
 #if defined(__HIP_DEVICE_COMPILE__)
 PT_HD float slab_entry(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, 0, %0" : "=&v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 PT_HD float slab_exit(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+PT_HD float pt_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 #else
+PT_HD float pt_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 PT_HD float slab_entry(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a, b), c), 0.0f); }
 PT_HD float slab_exit(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 #endif
@@ -557,6 +561,9 @@ PT_HD TriRay tri_ray_prepare(F3 o, F3 dir) {
 }
 // the test proper, on vertices already translated to the ray origin and permuted (mesh.rs:101-198), in two steps: everything that
 // does not depend on the interval (edge functions with the f64 fallback, sign test, determinant, scaled distance) ...
+// The rejections are written as data flow — one predicate, combined with `&` and `|`, no early return: every divergent `if` costs three scalar instructions
+// (save exec, branch, restore) and a predicate that leaves it three more, and the scalar unit is a bound of these kernels (aabb_classify_wave).  A rejected
+// lane computes a few more products than it needs; it would have idled through them.
 struct TriEdges { float e0, e1, e2, det, ts; };
 PT_HD bool triangle_edges(F3 p0t, F3 p1t, F3 p2t, const TriRay& r, TriEdges* g) {
     PT_STAT(tri_tests);
@@ -566,30 +573,35 @@ PT_HD bool triangle_edges(F3 p0t, F3 p1t, F3 p2t, const TriRay& r, TriEdges* g) 
     float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
     float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
     float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
-    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
-        double a = (double)p2t.x * (double)p1t.y, b = (double)p2t.y * (double)p1t.x;
-        e0 = (float)(b - a);
-        a = (double)p0t.x * (double)p2t.y; b = (double)p0t.y * (double)p2t.x;
-        e1 = (float)(b - a);
-        a = (double)p1t.x * (double)p0t.y; b = (double)p1t.y * (double)p0t.x;
-        e2 = (float)(b - a);
+    const bool zero_edge = (e0 == 0.0f) | (e1 == 0.0f) | (e2 == 0.0f);
+    if (PT_WAVE_ANY(zero_edge)) {   // (rare: a wave-uniform branch around the lanes that need the f64 edge functions)
+        PT_KEEP_BRANCH();
+        if (zero_edge) {
+            double a = (double)p2t.x * (double)p1t.y, b = (double)p2t.y * (double)p1t.x;
+            e0 = (float)(b - a);
+            a = (double)p0t.x * (double)p2t.y; b = (double)p0t.y * (double)p2t.x;
+            e1 = (float)(b - a);
+            a = (double)p1t.x * (double)p0t.y; b = (double)p1t.y * (double)p0t.x;
+            e2 = (float)(b - a);
+        }
     }
-    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+    // some edge function negative and some positive: the minimum and the maximum of the three (a NaN is ignored by both, as by the six comparisons)
+    const bool mixed = (slab_exit(e0, e1, e2) < 0.0f) & (pt_max3(e0, e1, e2) > 0.0f);
     float det = e0 + e1 + e2;
-    if (det == 0.0f) return false;
     p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
     g->e0 = e0; g->e1 = e1; g->e2 = e2; g->det = det;
     g->ts = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
-    return true;
+    return !mixed & (det != 0.0f);
 }
 // ... and the interval test in its scaled form (mesh.rs:150-158): true when (ts, det) lies outside (t0, t1]
 PT_HD bool triangle_outside(float ts, float det, float t0, float t1) {
-    return (det < 0.0f && (ts >= t0 * det || ts < t1 * det)) || (det > 0.0f && (ts <= t0 * det || ts > t1 * det));
+    const float a = t0 * det, b = t1 * det;
+    return ((det < 0.0f) & ((ts >= a) | (ts < b))) | ((det > 0.0f) & ((ts <= a) | (ts > b)));
 }
 PT_HD bool triangle_test_core(F3 p0t, F3 p1t, F3 p2t, const TriRay& r, float t0, float t1, TriHit* out) {
     TriEdges g;
-    if (!triangle_edges(p0t, p1t, p2t, r, &g)) return false;
-    if (triangle_outside(g.ts, g.det, t0, t1)) return false;
+    const bool inside = triangle_edges(p0t, p1t, p2t, r, &g);
+    if (!(inside & !triangle_outside(g.ts, g.det, t0, t1))) return false;
     float inv_det = 1.0f / g.det;
     out->b0 = g.e0 * inv_det; out->b1 = g.e1 * inv_det; out->b2 = g.e2 * inv_det;
     out->t = g.ts * inv_det;
@@ -1220,7 +1232,9 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
             TriHit th;
             F4 q0;
             auto test = [&](const TriRay& tr) {
-                const uint32_t tp = triw + (tr.kz == 0u ? pt_f2u(bp.z) : (tr.kz == 1u ? pt_f2u(bp.w) : 0u));
+                uint32_t off0 = pt_f2u(bp.z), off1 = pt_f2u(bp.w);
+                PT_PIN2(off0, off1);   // (both offsets read, then two selects: the compiler would sink each read into a branch of its own)
+                const uint32_t tp = triw + (tr.kz == 0u ? off0 : (tr.kz == 1u ? off1 : 0u));
                 q0 = mf4(s, tp);
                 const F4 q1 = mf4(s, tp + 4), q2 = mf4(s, tp + 8);
                 return triangle_test_permuted(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th);
@@ -1228,13 +1242,13 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
             bool accepted;
             if (sweep_leaf_transformed(s, kf)) { F3 lo, ld; instance_local_ray(s, inst, o, d, &lo, &ld); const TriRay ltr = tri_ray_prepare(lo, ld); accepted = test(ltr); }
             else accepted = test(wtr);
-            if (accepted) {
-                st.closest = th.t; st.best_inst = kf >> 16; st.best_triw = triw; st.bh = th;
-                if (stop == PT_STOP_ANY) st.hit = 0;
-                else if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
-                    uint32_t im = bu(s, inst + PT_INST_MATERIAL);
-                    if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) st.hit = 0;  // something opaque in front of every light
-                }
+            {   // (selects, not branches: see triangle_edges)
+                const uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+                const bool opaque = PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT;
+                if (accepted) { st.closest = th.t; st.best_inst = kf >> 16; st.best_triw = triw; st.bh = th; }   // (the branch of the test's own division)
+                // PT_STOP_ANY: any hit ends the search; PT_STOP_NONLIGHT: something opaque in front of every light does
+                const bool over = accepted & ((stop == PT_STOP_ANY) | ((stop == PT_STOP_NONLIGHT) & (st.closest < bound) & opaque));
+                st.hit = over ? 0ull : st.hit;
             }
         } else if ((kf >> 16) == known_inst) {
             // rect.rs / disk.rs reject t > t1, sphere.rs accepts t < t1 (the nearer root first; the farther one is beyond it)

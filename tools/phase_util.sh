@@ -28,7 +28,8 @@ base_ext, base_sh = None, None
 def row(name, hi, lo, kern):
     a = c[hi][kern]; b = c[lo][kern] if lo else {k: 0.0 for k in a}
     dt = a["SQ_THREAD_CYCLES_VALU"] - b["SQ_THREAD_CYCLES_VALU"]; da = a["SQ_ACTIVE_INST_VALU"] - b["SQ_ACTIVE_INST_VALU"]; di = a["SQ_INSTS_VALU"] - b["SQ_INSTS_VALU"]
-    print("%-58s VALU instr per launch %9.3g M  lane utilisation %.2f" % (name, di / 1e6, dt / (64.0 * da) if da else float("nan")))
+    ds = a["SQ_INSTS_SALU"] - b["SQ_INSTS_SALU"]
+    print("%-58s VALU instr per launch %9.3g M  lane utilisation %.2f  SALU instr per launch %9.3g M" % (name, di / 1e6, dt / (64.0 * da) if da else float("nan"), ds / 1e6))
 print("k_extend (= the traversal half of the fused k_shade), per launch averages of C2:")
 row("  load + phases 1-2 (22 box tests, masks)", "a", None, "k_extend_exp")
 row("  phase 3 (candidate primitives, lane by lane)", "b", "a", "k_extend_exp")
@@ -45,5 +46,5 @@ for k in ("k_shade", "k_extend", "k_shadow"):
 f = counters("fused")
 for k, v in f.items():
     if k in ("k_shade", "k_shadow"):
-        print("default run (fused) %-10s VALU instr per launch %9.3g M  lane utilisation %.2f" % (k, v["SQ_INSTS_VALU"] / 1e6, v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"])))
+        print("default run (fused) %-10s VALU instr per launch %9.3g M  lane utilisation %.2f  SALU instr per launch %9.3g M" % (k, v["SQ_INSTS_VALU"] / 1e6, v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), v["SQ_INSTS_SALU"] / 1e6))
 PY
