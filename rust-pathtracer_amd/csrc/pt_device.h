@@ -318,9 +318,10 @@ PT_HD RayPrep ray_prepare(F3 o, F3 d) {
     float k = __builtin_fmaxf(__builtin_fmaxf(pt_abs(p.nor.x), pt_abs(p.nor.y)), pt_abs(p.nor.z));
     p.base = PT_SLAB_EPS * k + PT_SLAB_TINY;
     // reciprocals must be finite and the products must not overflow: |d| in (1e-18, 1e18) or exactly 0, finite origin
-    bool okx = (ax == 0.0f) || (ax > 1e-18f && ax < 1e18f), oky = (ay == 0.0f) || (ay > 1e-18f && ay < 1e18f), okz = (az == 0.0f) || (az > 1e-18f && az < 1e18f);
-    bool oko = pt_abs(o.x) < 1e18f && pt_abs(o.y) < 1e18f && pt_abs(o.z) < 1e18f;
-    p.fast = okx && oky && okz && oko;
+    // (`&`, `|`: comparisons combined as data — each `&&` / `||` here was compiled as a branch around the next comparison)
+    bool okx = (ax == 0.0f) | ((ax > 1e-18f) & (ax < 1e18f)), oky = (ay == 0.0f) | ((ay > 1e-18f) & (ay < 1e18f)), okz = (az == 0.0f) | ((az > 1e-18f) & (az < 1e18f));
+    bool oko = (pt_abs(o.x) < 1e18f) & (pt_abs(o.y) < 1e18f) & (pt_abs(o.z) < 1e18f);
+    p.fast = okx & oky & okz & oko;
     return p;
 }
 PT_HD bool aabb_hit(F4 a, F4 b, const RayPrep& rp, float* entry) {
@@ -633,12 +634,13 @@ PT_HD bool analytic_hit(const SceneView& s, uint32_t inst, uint32_t kind, F3 o, 
         uint32_t axis = (flags >> 2) & 3u;
         float s0 = bf(s, inst + PT_INST_SIZE), s1 = bf(s, inst + PT_INST_SIZE + 1);
         F3 to = rect_shuffle(sub(o, origin), axis), td = rect_shuffle(d, axis);
-        if (td.z == 0.0f) return false;
+        // one predicate, no early return (triangle_edges); a ray in the plane divides by zero into an inf or a NaN that the first term rejects
         float t = (-to.z) / td.z;
-        if (t <= 0.0f || t > t1 || t >= PT_INF) return false;
         float xh = to.x + t * td.x, yh = to.y + t * td.y;
         float hx = s0 / 2.0f, hy = s1 / 2.0f;
-        if (xh < -hx || xh > hx || yh < -hy || yh > hy) return false;
+        const bool out_of_range = (td.z == 0.0f) | (t <= 0.0f) | (t > t1) | (t >= PT_INF);
+        const bool off_rect = (xh < -hx) | (xh > hx) | (yh < -hy) | (yh > hy);
+        if (out_of_range | off_rect) return false;
         F3 n = axis_vec(axis);
         if (two_sided && dot(d, n) > 0.0f) n = neg(n);
         out->t = t; out->p = add(o, mul(d, t)); out->u = (xh + hx) / s0; out->v = (yh + hy) / s1;
@@ -666,11 +668,9 @@ PT_HD bool analytic_hit(const SceneView& s, uint32_t inst, uint32_t kind, F3 o, 
     // disk
     float radius = bf(s, inst + PT_INST_RADIUS);
     F3 to = sub(o, origin);
-    if (d.z == 0.0f) return false;
     float t = (-to.z) / d.z;
-    if (t <= 0.0f || t > t1 || t >= PT_INF) return false;
     float xh = to.x + t * d.x, yh = to.y + t * d.y;
-    if (xh * xh + yh * yh > radius * radius) return false;
+    if ((d.z == 0.0f) | (t <= 0.0f) | (t > t1) | (t >= PT_INF) | (xh * xh + yh * yh > radius * radius)) return false;
     F3 n = f3(0, 0, 1);
     if (dot(d, n) > 0.0f && two_sided) n = neg(n);
     out->t = t; out->p = add(o, mul(d, t)); out->u = 0.0f; out->v = 0.0f;
@@ -751,7 +751,7 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
     const bool exact = (flags & PT_FLAG_EXACT_SLAB) != 0;
     const bool cull_top = (flags & (PT_FLAG_NO_TOP_CULL | PT_FLAG_NO_CULL)) == 0, cull_mesh = (flags & PT_FLAG_NO_CULL) == 0;
     const RayPrep wr = ray_prepare(o, d);
-    const bool quick = wr.fast && !exact && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f;
+    const bool quick = wr.fast & !exact & (d.x != 0.0f) & (d.y != 0.0f) & (d.z != 0.0f);
     const bool bounded = bound < PT_INF;
     // the masks are built as 32-bit halves
     uint32_t hit_lo = 0, hit_hi = 0, unc_lo = 0, unc_hi = 0;
@@ -1696,14 +1696,25 @@ PT_HD float nearest_light_hit(const SceneView& s, F3 o, F3 d, uint32_t* which = 
     const uint32_t n = bu(s, PT_HDR_LIGHT_COUNT), lo_ = bu(s, PT_HDR_LIGHT_OFF), ln = bu(s, PT_HDR_LIGHT_NODE_OFF), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
     RayPrep wr = ray_prepare(o, d);
     if (bu(s, PT_HDR_FLAGS) & PT_FLAG_EXACT_SLAB) wr.fast = false;
-    const bool quick = wr.fast && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f;
+    const bool quick = wr.fast & (d.x != 0.0f) & (d.y != 0.0f) & (d.z != 0.0f);
+    const uint64_t q = PT_WAVE_BALLOT(quick), nq = PT_WAVE_BALLOT(!quick);
     float best = PT_INF;
     uint32_t light = 0xffffffffu;
     for (uint32_t k = 0; k < n; ++k) {
         uint32_t node = bu(s, ln + k);
         F4 a = bf4(s, node), b = bf4(s, node + 4);
-        float entry;
-        if (!aabb_hit_uniform_node(a, b, wr, quick, &entry)) continue;
+        // the box decided as wave masks (aabb_classify_wave); the lanes left undecided — and those whose ray the filter does not take — settle it exactly
+        float entry = 0.0f;
+        uint64_t hb = 0ull, ub = 0ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+        aabb_classify_wave_by(PT_UNIFORM(PT_NODE_CODE(pt_f2u(a.w))), a, b, wr, &entry, &hb, &ub);
+#else
+        if (quick) aabb_classify_wave_by(PT_NODE_CODE(pt_f2u(a.w)), a, b, wr, &entry, &hb, &ub);
+#endif
+        hb &= q; ub = (ub & q) | nq;
+        bool inside = PT_WAVE_MEMBER(hb);
+        if (ub != 0ull) { PT_KEEP_BRANCH(); if (PT_WAVE_MEMBER(ub)) { PT_STAT(box_exact); inside = aabb_hit_exact(a, b, o, d, &entry); } }
+        if (!inside) continue;
         uint32_t inst = inst_off + bu(s, lo_ + k) * PT_INST_WORDS;
         F3 l0, l1;
         instance_local_ray(s, inst, o, d, &l0, &l1);
