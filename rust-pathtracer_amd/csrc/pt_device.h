@@ -526,6 +526,36 @@ PT_HD bool aabb_hit_node(F4 a, F4 b, const RayPrep& rp, bool quick, float* entry
     PT_STAT(box_exact);
     return aabb_hit_exact(a, b, rp.o, rp.d, entry);
 }
+// The box test of a walk step as data flow (the lanes of a wave stand on different nodes): the thick form for every lane, the per-axis form on top of it
+// in the waves where some lane stands on a flat node, the exact test in the waves where some lane's decision is too close to call or whose ray the filter
+// does not take — three wave-uniform branches instead of a nest of divergent ones (the scalar unit: aabb_classify_wave).  Decisions are the exact test's.
+PT_HD bool walk_box(F4 a, F4 b, const RayPrep& rp, bool quick, float* entry) {
+    PT_STAT(box_tests);
+    const bool flat = ((pt_f2u(a.w) & PT_NODE_FLAT) != 0u) & quick;
+    const float p0 = approx_fma(a.x, rp.r.x, rp.nor.x), q0 = approx_fma(b.x, rp.r.x, rp.nor.x);
+    const float p1 = approx_fma(a.y, rp.r.y, rp.nor.y), q1 = approx_fma(b.y, rp.r.y, rp.nor.y);
+    const float p2 = approx_fma(a.z, rp.r.z, rp.nor.z), q2 = approx_fma(b.z, rp.r.z, rp.nor.z);
+    const float n0 = __builtin_fminf(p0, q0), x0 = __builtin_fmaxf(p0, q0), n1 = __builtin_fminf(p1, q1), x1 = __builtin_fmaxf(p1, q1);
+    const float n2 = __builtin_fminf(p2, q2), x2 = __builtin_fmaxf(p2, q2);
+    const float lo = slab_entry(n0, n1, n2), hi = slab_exit(x0, x1, x2);
+    const float e = approx_fma(PT_SLAB_EPS, lo + pt_abs(hi), rp.base), gap = lo - hi;
+    float en = lo;
+    bool hit = gap < -e, und = !(gap > e) & !(gap < -e);
+    if (PT_WAVE_ANY(flat)) {
+        const float m0 = __builtin_fmaxf(__builtin_fmaxf(n1, n2), 0.0f), m1 = __builtin_fmaxf(__builtin_fmaxf(n0, n2), 0.0f), m2 = __builtin_fmaxf(__builtin_fmaxf(n0, n1), 0.0f);
+        const float e0 = approx_fma(PT_SLAB_EPS, m0 + pt_abs(x0), rp.base), e1 = approx_fma(PT_SLAB_EPS, m1 + pt_abs(x1), rp.base), e2 = approx_fma(PT_SLAB_EPS, m2 + pt_abs(x2), rp.base);
+        const bool miss = (m0 > x0 + e0) | (m1 > x1 + e1) | (m2 > x2 + e2);
+        const bool hitf = !miss & (m0 < x0 - e0) & (m1 < x1 - e1) & (m2 < x2 - e2);
+        hit = flat ? hitf : hit; und = flat ? !miss & !hitf : und; en = flat ? __builtin_fmaxf(m0, n0) : en;
+    }
+    hit = hit & quick; und = und | !quick;
+    if (PT_WAVE_ANY(und)) {
+        PT_KEEP_BRANCH();
+        if (und) { PT_STAT(box_exact); hit = aabb_hit_exact(a, b, rp.o, rp.d, &en); }
+    }
+    *entry = en;
+    return hit;
+}
 // The same for a node every lane of the wave tests together (the light list of nearest_light_hit): the form the host chose for it.
 PT_HD bool aabb_hit_uniform_node(F4 a, F4 b, const RayPrep& rp, bool quick, float* entry) {
     if (!quick) return aabb_hit(a, b, rp, entry);
@@ -1167,11 +1197,17 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
             float entry;
             // (a ray the filtered test does not take — a zero direction component that was not scanned, magnitudes out of range — goes to the exact test at once:
             // the per-axis filtered form stays out of this loop)
-            bool box = (walk_quick ? aabb_hit_node(a, b, cr, true, &entry) : aabb_hit_exact(a, b, lo, ld, &entry)) && !(cull && beyond(entry, limit, cr.base));
-            if (shape == PT_NODE_INNER) i = box ? i + 1 : exit_i;
-            else {
-                if (box) { if (!SPEC || pending == NONE) { pending = shape; pend_node = i; } else { pending2 = shape; pend2_node = i; } }
-                i = exit_i;
+            const bool box = walk_box(a, b, cr, walk_quick, &entry) & !(cull & beyond(entry, limit, cr.base));
+            if (SPEC) {
+                if (shape == PT_NODE_INNER) i = box ? i + 1 : exit_i;
+                else {
+                    if (box) { if (pending == NONE) { pending = shape; pend_node = i; } else { pending2 = shape; pend2_node = i; } }
+                    i = exit_i;
+                }
+            } else {   // (selects: an inner node entered goes to its first child, anything else to the node's exit; a leaf entered is held)
+                const bool inner = shape == PT_NODE_INNER;
+                pending = (!inner & box) ? shape : pending;
+                i = (inner & box) ? i + 1 : exit_i;
             }
             if (SPEC) {
                 // the lanes still without a first leaf (of the lanes in this loop: the others hold two leaves or have no node left)
@@ -1185,15 +1221,13 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
             uint32_t t = tri_off + pending * PT_TRI_WORDS;
             F4 q0 = mf4(s, t), q1 = mf4(s, t + 4), q2 = mf4(s, t + 8);
             TriHit th;
-            if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
-                st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th;
-                limit = __builtin_fminf(st.closest, bound);
-                if (stop == PT_STOP_ANY) { st.hit = 0; over = true; }
-                else if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
-                    uint32_t im = bu(s, inst + PT_INST_MATERIAL);
-                    if (PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT) { st.hit = 0; over = true; }  // something opaque in front of every light
-                }
-            }
+            const bool accepted = triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th);
+            if (accepted) { st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th; limit = __builtin_fminf(st.closest, bound); }   // (the branch of the test's own division)
+            // PT_STOP_ANY: any hit ends the search; PT_STOP_NONLIGHT: something opaque in front of every light does (selects, as in sweep_run)
+            const uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+            const bool opaque = PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT;
+            over = accepted & ((stop == PT_STOP_ANY) | ((stop == PT_STOP_NONLIGHT) & (st.closest < bound) & opaque));
+            st.hit = over ? 0ull : st.hit;
         }
         pending = pending2; pend_node = pend2_node; pending2 = NONE;   // (without SPEC: NONE — every turn begins without a leaf)
         if (over || (i >= node_count && pending == NONE)) break;
