@@ -444,8 +444,8 @@ PT_HD void aabb_wave_thick(F4 a, F4 b, const RayPrep& rp, float* entry, uint64_t
     float lo = slab_entry(n0, n1, n2), hi = slab_exit(x0, x1, x2);
     float e = approx_fma(PT_SLAB_EPS, lo + pt_abs(hi), rp.base), gap = lo - hi;
     *entry = lo;
-    const uint64_t H = PT_WAVE_BALLOT(gap < -e), M = PT_WAVE_BALLOT(gap > e);
-    *hit = H; *undecided = ~(H | M);
+    const uint64_t H = PT_WAVE_BALLOT(gap < -e), N = PT_WAVE_BALLOT(!(gap > e));   // (N: not a miss — the negated comparison is one instruction)
+    *hit = H; *undecided = N & ~H;
 }
 PT_HD void aabb_wave_flat(F4 a, F4 b, const RayPrep& rp, float* entry, uint64_t* hit, uint64_t* undecided) {
     PT_STAT(box_tests);
@@ -457,9 +457,9 @@ PT_HD void aabb_wave_flat(F4 a, F4 b, const RayPrep& rp, float* entry, uint64_t*
     float m0 = __builtin_fmaxf(__builtin_fmaxf(n1, n2), 0.0f), m1 = __builtin_fmaxf(__builtin_fmaxf(n0, n2), 0.0f), m2 = __builtin_fmaxf(__builtin_fmaxf(n0, n1), 0.0f);
     float e0 = approx_fma(PT_SLAB_EPS, m0 + pt_abs(x0), rp.base), e1 = approx_fma(PT_SLAB_EPS, m1 + pt_abs(x1), rp.base), e2 = approx_fma(PT_SLAB_EPS, m2 + pt_abs(x2), rp.base);
     *entry = __builtin_fmaxf(m0, n0);
-    const uint64_t M = PT_WAVE_BALLOT(m0 > x0 + e0) | PT_WAVE_BALLOT(m1 > x1 + e1) | PT_WAVE_BALLOT(m2 > x2 + e2);
-    const uint64_t H = PT_WAVE_BALLOT(m0 < x0 - e0) & PT_WAVE_BALLOT(m1 < x1 - e1) & PT_WAVE_BALLOT(m2 < x2 - e2) & ~M;
-    *hit = H; *undecided = ~(H | M);
+    const uint64_t N = PT_WAVE_BALLOT(!(m0 > x0 + e0)) & PT_WAVE_BALLOT(!(m1 > x1 + e1)) & PT_WAVE_BALLOT(!(m2 > x2 + e2));
+    const uint64_t H = PT_WAVE_BALLOT(m0 < x0 - e0) & PT_WAVE_BALLOT(m1 < x1 - e1) & PT_WAVE_BALLOT(m2 < x2 - e2) & N;
+    *hit = H; *undecided = N & ~H;
 }
 template <int K>
 PT_HD void aabb_wave_flat1(F4 a, F4 b, const RayPrep& rp, float* entry, uint64_t* hit, uint64_t* undecided) {
@@ -474,8 +474,8 @@ PT_HD void aabb_wave_flat1(F4 a, F4 b, const RayPrep& rp, float* entry, uint64_t
     const float e = approx_fma(PT_SLAB_EPS, (lo + pt_abs(hi)) + pt_abs(tk), rp.base);
     const float g1 = lo - tk, g2 = tk - hi;
     *entry = tk;
-    const uint64_t H = PT_WAVE_BALLOT(g1 < -e) & PT_WAVE_BALLOT(g2 < -e), M = PT_WAVE_BALLOT(g1 > e) | PT_WAVE_BALLOT(g2 > e);
-    *hit = H; *undecided = ~(H | M);
+    const uint64_t H = PT_WAVE_BALLOT(g1 < -e) & PT_WAVE_BALLOT(g2 < -e), N = PT_WAVE_BALLOT(!(g1 > e)) & PT_WAVE_BALLOT(!(g2 > e));
+    *hit = H; *undecided = N & ~H;
 }
 template <int CODE>
 PT_HD void aabb_classify_wave(F4 a, F4 b, const RayPrep& rp, float* entry, uint64_t* hit, uint64_t* undecided) {
@@ -777,7 +777,8 @@ PT_HD void hit_record(const SceneView& s, F3 o, F3 d, uint32_t best_inst, uint32
 PT_HD uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
 // Phases 1 and 2: the mask of leaves whose own box the ray hits (walked mesh instances keep their instance bit).
 PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
-    const uint32_t flags = bu(s, PT_HDR_FLAGS), sweep = bu(s, PT_HDR_SWEEP_OFF), count = bu(s, PT_HDR_SWEEP_COUNT), bits_off = bu(s, PT_HDR_SWEEP_BITS_OFF);
+    // (header words made scalars once: the loop's counter and addresses stay in the scalar unit without a read-first-lane per turn)
+    const uint32_t flags = PT_UNIFORM(bu(s, PT_HDR_FLAGS)), sweep = PT_UNIFORM(bu(s, PT_HDR_SWEEP_OFF)), count = PT_UNIFORM(bu(s, PT_HDR_SWEEP_COUNT)), bits_off = bu(s, PT_HDR_SWEEP_BITS_OFF);
     const bool exact = (flags & PT_FLAG_EXACT_SLAB) != 0;
     const bool cull_top = (flags & (PT_FLAG_NO_TOP_CULL | PT_FLAG_NO_CULL)) == 0, cull_mesh = (flags & PT_FLAG_NO_CULL) == 0;
     const RayPrep wr = ray_prepare(o, d);
@@ -801,6 +802,8 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
     constexpr bool every_lane = false;   // (the emulation's one lane: the test only where the device's result would be read; PT_STAT counts those)
 #endif
     const uint64_t q = PT_WAVE_BALLOT(quick), nq = PT_WAVE_BALLOT(!quick);
+    // beyond(entry, bound, base) with the flag folded into the bound: a search that may not cull compares with +inf (never beyond)
+    const float bound_top = cull_top ? bound : PT_INF, bound_mesh = cull_mesh ? bound : PT_INF;
     auto mark = [&](uint64_t H, uint64_t U, uint32_t mlo, uint32_t mhi) {
         const bool hl = PT_WAVE_MEMBER(H);
         hit_lo |= hl ? mlo : 0u; hit_hi |= hl ? mhi : 0u;
@@ -817,7 +820,7 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
         if (every_lane || q != 0ull) aabb_classify_wave_by((kf >> 11) & 7u, a, b, wr, &entry, &ih, &iu);
         ih &= q; iu = (iu & q) | nq;   // (a ray the filter cannot take: every box is undecided)
         // (`bound` = inf culls nothing: the comparison is false)
-        if (cull_top && (kf & 0xffu) != PT_SHAPE_SPHERE) ih &= ~PT_WAVE_BALLOT(beyond(entry, bound, wr.base));
+        if ((kf & 0xffu) != PT_SHAPE_SPHERE) ih &= ~PT_WAVE_BALLOT(beyond(entry, bound_top, wr.base));
         mark(ih, iu, pt_f2u(h0.z), pt_f2u(h0.w));
         const uint64_t inside = ih | iu;
         if ((kf & (0xffu | PT_SWEEP_WALKED)) == PT_SHAPE_MESH && (kf >> 24) != 0u && inside != 0ull) {
@@ -834,7 +837,7 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
                         uint64_t th = 0ull, tu = 0ull;
                         if (every_lane || qi != 0ull) aabb_classify_wave<decltype(code)::value>(ta, tb, lr, &entry, &th, &tu);
                         th &= qi; tu = (tu & qi) | nqi;
-                        if (cull_mesh) th &= ~PT_WAVE_BALLOT(beyond(entry, bound, lr.base));
+                        th &= ~PT_WAVE_BALLOT(beyond(entry, bound_mesh, lr.base));
                         mark(th, tu, pt_f2u(ta.w), pt_f2u(tb.w));
                     }
                 };
