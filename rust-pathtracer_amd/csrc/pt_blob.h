@@ -140,7 +140,7 @@
 
 // Leaf sweep table (world_hit_sweep).  One mask bit per top-level leaf (instance) and per triangle leaf, numbered in
 // traversal pre-order: instance j gets bit `first`, its triangle leaves first+1 .. first+count.
-// Per instance, in the pre-order of the top-level BVH's leaves (16 words):
+// Per instance (16 words; the mask bits are numbered in the pre-order of the top-level BVH's leaves, the records stand simple ones first, PT_HDR_SWEEP_SIMPLE):
 //   [0] instance record offset, [1] kind | flat << 8 | has_transform << 9 | walked << 10 | form of the box test << 11 (0 thick, 1 / 2 / 3 flat
 //   along x / y / z, 4 flat along several axes) | first mask bit << 16 | tested triangle leaves << 24,
 //   [2..3] the mask its box test sets, [4..6] box min, [7] triangle-leaf list offset, [8..10] box max, [11] triangle-leaf count (all of them),
@@ -165,6 +165,8 @@
 #define PT_HDR_IMAP_ROW_GUIDE 60    /* n + 3 entries per table, entry j = first index whose cmf is >= j / n (pt_device.h sample_cmf) */
 #define PT_HDR_IMAP_STRIDE 66        /* floats between consecutive entries of a pdf or cmf table: 2 = the tables are interleaved, (cmf[k], pdf[k]) pairs — the three or four
                                        values a sample ends on (cmf[k - 1], cmf[k], pdf[k], pdf[k + 1]) then lie on one 128-byte line instead of two */
+#define PT_HDR_SWEEP_SIMPLE 67       /* 2 words: the sweep table begins with the instances whose box test is all there is to do, grouped by the form of the test:
+                                       sizes of the groups 0..3 (8 bits each), then of group 4; the other instances follow (PT_HDR_SWEEP_COUNT counts all) */
 #define PT_HDR_CORE_WORDS 61        /* words of the core section; the mesh-data section follows it */
 #define PT_HDR_SWEEP_MESH_MASK 57  /* 2 words: the bits that stand for mesh instances (no primitive of their own) */
 #define PT_HDR_SWEEP_OWNER_MASK 62 /* 2 words: the bits whose primitive test needs the ray itself (analytic shapes, triangles of transformed

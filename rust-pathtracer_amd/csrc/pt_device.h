@@ -809,7 +809,27 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
         hit_lo |= hl ? mlo : 0u; hit_hi |= hl ? mhi : 0u;
         if (U != 0ull) { PT_KEEP_BRANCH(); const bool ul = PT_WAVE_MEMBER(U); unc_lo |= ul ? mlo : 0u; unc_hi |= ul ? mhi : 0u; }
     };
-    for (uint32_t j = 0; j < count; ++j) {
+    // the instances whose box test is all there is to do (PT_HDR_SWEEP_SIMPLE): one tight loop per form of the test
+    uint32_t first_general = 0u;
+    {
+        uint32_t e = sweep;
+        auto simple = [&](auto code, uint32_t n) {
+            first_general += n;
+            for (; n != 0u; --n, e += PT_SWEEP_INST_WORDS) {
+                const F4 h0 = bf4(s, e), a = bf4(s, e + 4), b = bf4(s, e + 8);
+                float entry = 0.0f;
+                uint64_t ih = 0ull, iu = 0ull;
+                if (every_lane || q != 0ull) aabb_classify_wave<decltype(code)::value>(a, b, wr, &entry, &ih, &iu);
+                ih &= q; iu = (iu & q) | nq;
+                ih &= ~PT_WAVE_BALLOT(beyond(entry, bound_top, wr.base));
+                mark(ih, iu, pt_f2u(h0.z), pt_f2u(h0.w));
+            }
+        };
+        const uint32_t sizes = PT_UNIFORM(bu(s, PT_HDR_SWEEP_SIMPLE));
+        simple(IntC<0>(), sizes & 0xffu); simple(IntC<1>(), (sizes >> 8) & 0xffu); simple(IntC<2>(), (sizes >> 16) & 0xffu); simple(IntC<3>(), sizes >> 24);
+        simple(IntC<4>(), PT_UNIFORM(bu(s, PT_HDR_SWEEP_SIMPLE + 1)));
+    }
+    for (uint32_t j = first_general; j < count; ++j) {
         const uint32_t e = PT_UNIFORM(sweep + j * PT_SWEEP_INST_WORDS);
         const F4 h0 = bf4(s, e), a = bf4(s, e + 4), b = bf4(s, e + 8);
         const uint32_t kf = PT_UNIFORM(pt_f2u(h0.y));

@@ -565,6 +565,35 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                 r[4] = nd[0]; r[5] = nd[1]; r[6] = nd[2]; r[7] = tri_list; r[8] = nd[4]; r[9] = nd[5]; r[10] = nd[6]; r[11] = tri_count;
                 r[12] = group_sizes; r[13] = 0u; r[14] = inst; r[15] = 0u;
             }
+            // The instance records too may stand in any order (their masks carry the leaf order).  Those whose box test is all there is to do — no
+            // triangle leaf with a test of its own: analytic shapes, the walls whose two triangles ride in the instance's mask, walked meshes — come
+            // first, grouped by the form of the test: the sweep runs them through tight loops (pt_device.h sweep_masks), the others through the
+            // general one.  A sphere is never culled (pt_device.h beyond) and stays with the general loop.
+            {
+                std::vector<size_t> perm(order.size());
+                for (size_t j = 0; j < perm.size(); ++j) perm[j] = j;
+                auto simple_code = [&](size_t j) -> uint32_t {   // 0..4: simple with that test form; 5: general
+                    const uint32_t kf = w[sweep_off + j * PT_SWEEP_INST_WORDS + 1];
+                    return ((kf >> 24) == 0u && (kf & 0xffu) != PT_SHAPE_SPHERE) ? ((kf >> 11) & 7u) : 5u;
+                };
+                std::stable_sort(perm.begin(), perm.end(), [&](size_t a2, size_t b2) { return simple_code(a2) < simple_code(b2); });
+                std::vector<uint32_t> block(order.size() * PT_SWEEP_INST_WORDS);
+                std::vector<uint32_t> new_box(order.size());   // old record j -> word offset of its box in the new order
+                uint32_t counts[6] = {0, 0, 0, 0, 0, 0};
+                for (size_t pos = 0; pos < perm.size(); ++pos) {
+                    const size_t j = perm[pos];
+                    for (int q = 0; q < PT_SWEEP_INST_WORDS; ++q) block[pos * PT_SWEEP_INST_WORDS + q] = w[sweep_off + j * PT_SWEEP_INST_WORDS + q];
+                    new_box[j] = sweep_off + (uint32_t)pos * PT_SWEEP_INST_WORDS + 4;
+                    counts[simple_code(j)] += 1;
+                }
+                for (size_t k = 0; k < bits.size() / PT_SWEEP_BIT_WORDS; ++k) {   // the bit table's box references follow the records
+                    uint32_t& bw = bits[k * PT_SWEEP_BIT_WORDS + 2];
+                    if (bw >= sweep_off && bw < sweep_off + order.size() * PT_SWEEP_INST_WORDS) bw = new_box[(bw - sweep_off) / PT_SWEEP_INST_WORDS];
+                }
+                for (size_t q = 0; q < block.size(); ++q) w[sweep_off + q] = block[q];
+                w[PT_HDR_SWEEP_SIMPLE] = counts[0] | counts[1] << 8 | counts[2] << 16 | counts[3] << 24;   // (at most 64 instances)
+                w[PT_HDR_SWEEP_SIMPLE + 1] = counts[4];
+            }
             for (size_t k = 0; k < root_of.size(); ++k)
                 if (root_of[k] != (int)k) {
                     uint64_t m = 1ull << k;
