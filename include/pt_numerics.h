@@ -157,14 +157,11 @@ PT_HD void pt_sincos(float x, float* s_out, float* c_out) {
     float sp = ((-1.9515295891e-4f * r2 + 8.3321608736e-3f) * r2 - 1.6666654611e-1f) * r2 * r + r;
     float cp = ((2.443315711809948e-5f * r2 - 1.388731625493765e-3f) * r2
                 + 4.166664568298827e-2f) * r2 * r2 - 0.5f * r2 + 1.0f;
-    float s, c;
-    switch (k & 3) {
-        case 0: s = sp; c = cp; break;
-        case 1: s = cp; c = -sp; break;
-        case 2: s = -sp; c = -cp; break;
-        default: s = -cp; c = sp; break;
-    }
-    *s_out = s; *c_out = c;
+    /* quadrant k & 3: (sp, cp), (cp, -sp), (-sp, -cp), (-cp, sp) — as selects (a four-way switch on a per-lane value is four divergent branches on the GPU) */
+    const int swap = (k & 1) != 0;
+    const float s0 = swap ? cp : sp, c0 = swap ? sp : cp;
+    *s_out = (k & 2) ? -s0 : s0;
+    *c_out = ((k + 1) & 2) ? -c0 : c0;
 }
 PT_HD float pt_sin(float x) { float s, c; pt_sincos(x, &s, &c); return s; }
 PT_HD float pt_cos(float x) { float s, c; pt_sincos(x, &s, &c); return c; }
@@ -172,10 +169,12 @@ PT_HD float pt_cos(float x) { float s, c; pt_sincos(x, &s, &c); return c; }
 /* ---------------------------------------------------------------- f32 exp
  * Cephes expf: n = round(x*log2 e), two-constant reduction, degree-5
  * polynomial, exact scaling by 2^n (two steps when the result is subnormal). */
-PT_HD float pt_exp(float x) {
-    if (x != x) return x;
-    if (x > 88.72283905206835f) return PT_INF;
-    if (x < -103.9f) return 0.0f;
+/* (These routines are written as data flow: the special cases are selected at the end, over a main path that every argument takes — an out-of-range
+ * one as 0.  On the GPU an early return or an `if` on a per-lane value is a divergent branch, three scalar instructions and more for every value that
+ * leaves it, and the scalar unit is shared by four SIMDs (tools/microbench/salu_issue.hip).  Same results, bit for bit.) */
+PT_HD float pt_exp(float x0) {
+    const int is_nan = x0 != x0, over = x0 > 88.72283905206835f, under = x0 < -103.9f;
+    float x = (is_nan | over | under) ? 0.0f : x0;
     float fn = pt_floor(1.44269504088896341f * x + 0.5f);
     int32_t n = (int32_t)fn;
     x = x - fn * 0.693359375f;
@@ -184,22 +183,26 @@ PT_HD float pt_exp(float x) {
     float p = (((((1.9875691500e-4f * x + 1.3981999507e-3f) * x + 8.3334519073e-3f) * x
                  + 4.1665795894e-2f) * x + 1.6666665459e-1f) * x + 5.0000001201e-1f) * z
               + x + 1.0f;
-    if (n > 127) { p = p * 2.0f; n -= 1; }            /* x close to the overflow threshold */
-    if (n < -126) { p = p * 5.42101086242752217e-20f; n += 64; } /* 2^-64, subnormal result */
-    if (n < -126) return 0.0f;
-    return p * pt_u2f((uint32_t)(n + 127) << 23);
+    const int hi = n > 127;                             /* x close to the overflow threshold */
+    p = hi ? p * 2.0f : p; n = hi ? n - 1 : n;
+    const int sub = n < -126;                           /* 2^-64, subnormal result */
+    p = sub ? p * 5.42101086242752217e-20f : p; n = sub ? n + 64 : n;
+    const int gone = n < -126;
+    float r = p * pt_u2f((uint32_t)((gone ? 0 : n) + 127) << 23);
+    r = (gone | under) ? 0.0f : r;
+    r = over ? PT_INF : r;
+    return is_nan ? x0 : r;
 }
 
 /* ------------------------------------------------------- f64 exp and log
  * Used where the reference computes in f64 (the CIE colour-matching fit,
  * math::misc::gaussian) and for powf, so that the f32 result of pow is
  * accurate to an ulp even for large exponents.  Error below 4e-16 relative. */
-PT_HD double pt_exp64(double x) {
-    if (x != x) return x;
-    if (x > 709.0) return (double)PT_INF;
-    if (x < -745.0) return 0.0;
+PT_HD double pt_exp64(double x0) {
+    const int is_nan = x0 != x0, over = x0 > 709.0, under = x0 < -745.0;
+    const double x = (is_nan | over | under) ? 0.0 : x0;
     double t = x * 1.4426950408889634074 + 0.5;
-    int64_t k = (int64_t)t; if ((double)k > t) k -= 1;
+    int32_t k = (int32_t)t; if ((double)k > t) k -= 1;   /* floor; |t| < 1100 */
     double fk = (double)k;
     double r = x - fk * 6.93147180369123816490e-01;
     r = r - fk * 1.90821492927058770002e-10;
@@ -218,22 +221,29 @@ PT_HD double pt_exp64(double x) {
     p = p * r + 0.5;
     p = p * r + 1.0;
     p = p * r + 1.0;
-    if (k < -1022) { p = p * 5.42101086242752217e-20; k += 64; }
-    if (k < -1022) return 0.0;
-    if (k > 1023) { p = p * 2.0; k -= 1; }
-    return p * pt_u2d((uint64_t)(k + 1023) << 52);
+    const int sub = k < -1022;
+    p = sub ? p * 5.42101086242752217e-20 : p; k = sub ? k + 64 : k;
+    const int gone = k < -1022;
+    const int hi = k > 1023;
+    p = hi ? p * 2.0 : p; k = hi ? k - 1 : k;
+    double v = p * pt_u2d((uint64_t)(uint32_t)((gone ? 0 : k) + 1023) << 52);
+    v = (gone | under) ? 0.0 : v;
+    v = over ? (double)PT_INF : v;
+    return is_nan ? x0 : v;
 }
 
-PT_HD double pt_log64(double x) {
-    if (x != x || x < 0.0) return pt_u2d(0x7ff8000000000000ull);
-    if (x == 0.0) return -(double)PT_INF;
+PT_HD double pt_log64(double x0) {
+    const int bad = (x0 != x0) | (x0 < 0.0), zero = x0 == 0.0;
+    double x = x0;
     uint64_t b = pt_d2u(x);
-    int64_t e = (int64_t)((b >> 52) & 0x7ff);
-    if (e == 0) { x = x * 18014398509481984.0; b = pt_d2u(x); e = (int64_t)((b >> 52) & 0x7ff) - 54; }
-    if (e == 0x7ff) return x;
+    int32_t e = (int32_t)((b >> 52) & 0x7ff);
+    const int tiny = e == 0;                      /* subnormal (or zero: selected away below): scaled by 2^54 */
+    x = tiny ? x * 18014398509481984.0 : x; b = pt_d2u(x); e = tiny ? (int32_t)((b >> 52) & 0x7ff) - 54 : e;
+    const int unbounded = e == 0x7ff;             /* +inf (a NaN is `bad`): returns itself */
     e -= 1023;
     double m = pt_u2d((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull); /* [1,2) */
-    if (m > 1.41421356237309504880) { m = m * 0.5; e += 1; }
+    const int upper = m > 1.41421356237309504880;
+    m = upper ? m * 0.5 : m; e = upper ? e + 1 : e;
     double f = m - 1.0;
     double s = f / (2.0 + f);
     double z = s * s;
@@ -250,7 +260,10 @@ PT_HD double pt_log64(double x) {
     p = p * z + 1.0 / 3.0;
     p = p * z + 1.0;
     double fe = (double)e;
-    return fe * 6.93147180369123816490e-01 + (2.0 * s * p + fe * 1.90821492927058770002e-10);
+    double r = fe * 6.93147180369123816490e-01 + (2.0 * s * p + fe * 1.90821492927058770002e-10);
+    r = unbounded ? x0 : r;
+    r = zero ? -(double)PT_INF : r;
+    return bad ? pt_u2d(0x7ff8000000000000ull) : r;
 }
 
 /* f32::ln and f32::cbrt for the mediums (hg.rs:98, rayleigh.rs:72-75, 104): through the f64 kernels, rounded once. */
@@ -264,11 +277,12 @@ PT_HD float pt_cbrt(float x) {
 
 /* x^y for x >= 0 (the only use is |cos|^n, sharp_light.rs:202-204). */
 PT_HD float pt_pow(float x, float y) {
-    if (x != x || y != y) return x + y;
-    if (y == 0.0f) return 1.0f;
-    if (x == 0.0f) return (y > 0.0f) ? 0.0f : PT_INF;
-    if (x == 1.0f) return 1.0f;
-    return (float)pt_exp64((double)y * pt_log64((double)x));
+    const int is_nan = (x != x) | (y != y);
+    float r = (float)pt_exp64((double)y * pt_log64((double)x));
+    r = (x == 1.0f) ? 1.0f : r;
+    r = (x == 0.0f) ? ((y > 0.0f) ? 0.0f : PT_INF) : r;
+    r = (y == 0.0f) ? 1.0f : r;
+    return is_nan ? x + y : r;
 }
 
 /* ------------------------------------------------------ f32 acos / atan2
@@ -277,32 +291,34 @@ PT_HD float pt_pow(float x, float y) {
 PT_HD float pt_sqrt(float x) { return __builtin_sqrtf(x); }
 
 PT_HD float pt_atan_01(float x) {
-    /* atan on [0, +inf) */
-    float y;
-    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
-    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
-    else { y = 0.0f; }
+    /* atan on [0, +inf): the three ranges as one division, -1 / x, (x - 1) / (x + 1), x / 1 (the last one exact: x itself) */
+    const int far = x > 2.414213562373095f, mid = x > 0.4142135623730950f;
+    float y = far ? 1.5707963267948966f : (mid ? 0.7853981633974483f : 0.0f);
+    const float num = far ? -1.0f : (mid ? x - 1.0f : x), den = far ? x : (mid ? x + 1.0f : 1.0f);
+    x = num / den;
     float z = x * x;
     y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z
               - 3.33329491539e-1f) * z * x + x);
     return y;
 }
 PT_HD float pt_atan2(float y, float x) {
-    if (x != x || y != y) return x + y;
-    if (x == 0.0f && y == 0.0f) return 0.0f;
+    const int is_nan = (x != x) | (y != y), origin = (x == 0.0f) & (y == 0.0f);
     float ax = pt_abs(x), ay = pt_abs(y);
-    float a;
-    if (ax == 0.0f) a = 1.5707963267948966f;
-    else a = pt_atan_01(ay / ax);
-    if (x < 0.0f) a = PT_PI - a;
-    return (y < 0.0f) ? -a : a;
+    /* ax == 0 (and ay != 0): ay / 0 = inf, whose arctangent comes out of pt_atan_01 as pi/2 + (-0) = pi/2, the constant the branch returned */
+    float a = pt_atan_01(ay / ax);
+    a = (x < 0.0f) ? PT_PI - a : a;
+    a = (y < 0.0f) ? -a : a;
+    a = origin ? 0.0f : a;
+    return is_nan ? x + y : a;
 }
 PT_HD float pt_acos(float x) {
-    if (x != x) return x;
-    if (x >= 1.0f) return 0.0f;
-    if (x <= -1.0f) return PT_PI;
-    float s = pt_sqrt((1.0f - x) * (1.0f + x));
-    return pt_atan2(s, x);
+    const int inside = (x < 1.0f) & (x > -1.0f);   /* (a NaN is not: it returns itself below) */
+    const float xs = inside ? x : 0.0f;
+    float s = pt_sqrt((1.0f - xs) * (1.0f + xs));
+    float r = pt_atan2(s, xs);
+    r = (x >= 1.0f) ? 0.0f : r;
+    r = (x <= -1.0f) ? PT_PI : r;
+    return (x != x) ? x : r;
 }
 
 #ifdef __cplusplus
