@@ -41,6 +41,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # whole chip at 5-8 waves per SIMD: v_fma/add/mul/mov/xor issue in 2 cycles, every other VALU instruction (min/max/cmp/cndmask/integer/
 # f64/packed/any with an SGPR operand) in 4.  The kernels here are ~80 % of the second kind.
 VALU_PEAK_4CYCLE, VALU_PEAK_2CYCLE = 600.0, 990.0
+SALU_PEAK = 540.0   # G scalar instructions/s for the whole chip, measured (profiles/r4_salu_issue.txt)
 # the reference's only self-reported figure: 23.9 Mrays/s on 20 threads of an unnamed CPU (/root/reference/data/config.toml:4-8)
 REFERENCE_SELF_REPORTED_MRAYS, REFERENCE_SELF_REPORTED_THREADS = 23.9, 20
 
@@ -360,6 +361,11 @@ def main():
                             "peak_2cycle_class": VALU_PEAK_2CYCLE, "frac_of_4cycle_peak": rate / VALU_PEAK_4CYCLE, "frac_of_2cycle_peak": rate / VALU_PEAK_2CYCLE,
                             "lane_utilization": (sq["SQ_THREAD_CYCLES_VALU"] / (64.0 * sq["SQ_ACTIVE_INST_VALU"])) if sq.get("SQ_ACTIVE_INST_VALU") else None,
                             "instructions_per_wave": sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"] if sq.get("SQ_WAVES") else None,
+                            "scalar_unit": ({"achieved": sq["SQ_INSTS_SALU"] / (summ["kernels"][kname]["total_ms"] * 1e-3) / 1e9, "unit": "G scalar instructions/s",
+                                             "peak": SALU_PEAK, "frac": sq["SQ_INSTS_SALU"] / (summ["kernels"][kname]["total_ms"] * 1e-3) / 1e9 / SALU_PEAK,
+                                             "per_vector_instruction": sq["SQ_INSTS_SALU"] / sq["SQ_INSTS_VALU"],
+                                             "peak_source": "profiles/r4_salu_issue.txt (tools/microbench/salu_issue.hip on MI355X): one scalar unit per CU, shared by its four SIMDs"}
+                                            if sq.get("SQ_INSTS_SALU") else None),
                             "peaks_source": "profiles/r2a_valu_issue.txt (tools/microbench/valu_issue.hip on MI355X): fma/add/mul/mov/xor issue in 2 cycles per "
                                             "wave64, min/max/cmp/cndmask/integer/f64/packed/SGPR-operand instructions in 4", "source": traffic_src}
                 break
