@@ -790,10 +790,9 @@ PT_HD uint64_t sweep_masks(const SceneView& s, F3 o, F3 d, float bound) {
     PT_STAT_RAY(o, d);
     // 1 — the sweep.  `bound` culls leaves that start beyond the distance the caller cares about (shadow rays).
     // A test sets a whole mask: the leaf's bit and the bits of the later leaves of the instance with the very same box (same box,
-    // same ray, same decision; the host folds them into the mask, pt_blob.h).  The decision stays a pair of lane predicates (the
-    // compiler keeps them in scalar registers) and every mask word costs one select-and-or.
+    // same ray, same decision; the host folds them into the mask, pt_blob.h).  Every mask word costs one select-and-or.
     // An undecided box is rare (0.8 % of the rays meet one): its masks are touched only in the waves where some lane has one — a
-    // scalar test of the predicate's ballot instead of four vector instructions per box.
+    // scalar test of the wave mask instead of four vector instructions per box.
     // The decisions are wave masks (aabb_classify_wave): the lanes whose ray the filter takes (`q`) run the test, the others are undecided at every box;
     // on the device every lane computes (a lane outside `q` computes on values the filter's bounds do not cover: its bits are masked, nothing reads them).
 #if defined(__HIP_DEVICE_COMPILE__)
