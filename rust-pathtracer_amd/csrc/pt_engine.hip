@@ -187,14 +187,14 @@ pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples
         uint32_t ls = light_samples > b.light_samples ? light_samples : b.light_samples;
         uint32_t nlmax = nl > b.nl ? nl : b.nl;
         size_t path_fields = nlmax == 4 ? Layout<4>::path_fields : Layout<1>::path_fields;
-        size_t sh_fields = nlmax == 4 ? Layout<4>::shadow_fields(ls ? ls : 1) : Layout<1>::shadow_fields(ls ? ls : 1);
+        size_t sh_fields = nlmax == 4 ? Layout<4>::shadow_queue_fields(ls ? ls : 1) : Layout<1>::shadow_queue_fields(ls ? ls : 1);
         HIP_TRY(hipMalloc(&b.paths_a, sizeof(uint32_t) * path_fields * total));
         HIP_TRY(hipMalloc(&b.paths_b, sizeof(uint32_t) * path_fields * total));
         HIP_TRY(hipMalloc(&b.hits, sizeof(uint32_t) * (size_t)HS_FIELDS * total));
         HIP_TRY(hipMalloc(&b.shadow, sizeof(uint32_t) * sh_fields * total));
         HIP_TRY(hipMalloc(&b.energy, sizeof(float) * (size_t)nlmax * total));
         b.nl = nlmax;
-        HIP_TRY(hipMalloc(&b.counts, sizeof(uint32_t) * 3 * (size_t)grid));
+        HIP_TRY(hipMalloc(&b.counts, sizeof(uint32_t) * 4 * (size_t)grid));   // (live paths x 2, light-sample items, live light-sample items)
         HIP_TRY(hipMalloc(&b.block_stats, sizeof(unsigned long long) * BS_FIELDS * (size_t)grid));
         // (the parked kernels' scratch: scenes whose sweep table holds walked meshes, and scenes without a sweep table that hold a mesh)
         const bool no_table = sc->host.blob[PT_HDR_SWEEP_OFF] == 0 || (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP);
@@ -321,6 +321,10 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
 #ifndef PT_FUSE_HERO
 #define PT_FUSE_HERO 1   /* round 4: built without machine LICM the hero fused form needs 111 VGPRs — four waves per SIMD, not three — and wins: C5 1153 -> 1179 (3625 us against 1160 + 2578) */
 #endif
+    // (the plain light-sample kernel walks the list of live items; the parked forms list their live RAYS themselves, the measurement forms read every item)
+#ifndef PT_EXPERIMENTS
+    rp.live_list = ((trav_form == PT_FORM_SWEEP || trav_form == PT_FORM_WALK || trav_form == PT_FORM_ANY) && shade_form == PT_SHADE_LEAN) ? 1u : 0u;
+#endif
     cfg.fuse = !(tn.flags & PT_TUNE_NO_FUSE) && (!hero || PT_FUSE_HERO) && trav_form == PT_FORM_SWEEP && shade_form == PT_SHADE_LEAN && (cfg.lacks & PT_SCENE_NO_XF) != 0;
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
     const bool timing = !(tn.flags & PT_TUNE_NO_STAGE_TIMING);
@@ -328,10 +332,10 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     uint64_t stage_launches[ST_COUNT] = {0, 0, 0, 0, 0};
     // (a queue's tiles are laid out by the number of fields this render uses, pt_stages.h: the buffers are sized for the widest layout seen)
     const uint32_t path_fields = hero ? Layout<4>::path_fields : (rd.medium_aware ? (uint32_t)PS_FIELDS + 2u : Layout<1>::path_fields);
-    const uint32_t item_fields = hero ? Layout<4>::shadow_fields(rd.light_samples ? rd.light_samples : 1) : Layout<1>::shadow_fields(rd.light_samples ? rd.light_samples : 1);
+    const uint32_t item_fields = hero ? Layout<4>::shadow_queue_fields(rd.light_samples ? rd.light_samples : 1) : Layout<1>::shadow_queue_fields(rd.light_samples ? rd.light_samples : 1);
     Queue qa{b.paths_a, b.capacity, path_fields}, qb{b.paths_b, b.capacity, path_fields}, qh{b.hits, b.capacity, HS_FIELDS}, qs{b.shadow, b.capacity, item_fields};
     uint32_t* live[2] = {b.counts, b.counts + grid};  // per-segment live-path counts, ping-pong with the path queues
-    uint32_t* nshadow = b.counts + 2 * grid;          // per-segment light-sample item counts
+    uint32_t* nshadow = b.counts + 2 * grid;          // per-segment light-sample item counts; behind them (nshadow + grid) the counts of the live ones (Layout::shadow_live_field)
 
     auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipStreamSynchronize(stream));
@@ -375,7 +379,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
             if (park_dynamic) cfg.unit_counter = b.unit_counters + 2 * bounce + 1;
             timed(ST_SHADE, [&] { launch_shade(cfg, hero ? 4 : 1, shade_form, sargs, rp, bounce, d_px, qin, qh, qout, qs, b.energy, seg_cap, cin, cout, nshadow, b.block_stats); });
             if (rd.light_samples > 0)   // (shade_form FULL = the scene can produce environment rays)
-                timed(ST_SHADOW, [&] { launch_shadow(cfg, trav_form, hero ? 4 : 1, shade_form == PT_SHADE_FULL || shade_form == PT_SHADE_MEDIUM, sargs, rd.light_samples, qs, b.energy, b.capacity, seg_cap, nshadow, b.park, qh); });
+                timed(ST_SHADOW, [&] { launch_shadow(cfg, trav_form, hero ? 4 : 1, shade_form == PT_SHADE_FULL || shade_form == PT_SHADE_MEDIUM, sargs, rd.light_samples, qs, b.energy, b.capacity, rp.live_list ? (seg_cap | kShadowListed) : seg_cap, nshadow, b.park, qh); });
         }
         timed(ST_ACCUMULATE, [&] {
             if (hero) hipLaunchKernelGGL(k_accumulate<4>, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, b.energy, d_film);

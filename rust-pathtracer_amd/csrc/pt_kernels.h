@@ -198,6 +198,18 @@ __device__ __forceinline__ uint32_t shared_append(bool flag, uint32_t* lds_head)
     start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
     return start + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
 }
+// Two appends with one wait: both atomics are issued before either result is read.
+__device__ __forceinline__ void shared_append2(bool flag_a, uint32_t* head_a, bool flag_b, uint32_t* head_b, uint32_t* pos_a, uint32_t* pos_b) {
+    const unsigned long long ma = __ballot(flag_a), mb = __ballot(flag_b);
+    uint32_t sa = 0, sb = 0;
+    if (lane_id() == 0) {
+        if (ma != 0ull) sa = atomicAdd(head_a, (uint32_t)__popcll(ma));
+        if (mb != 0ull) sb = atomicAdd(head_b, (uint32_t)__popcll(mb));
+    }
+    sa = (uint32_t)__builtin_amdgcn_readfirstlane((int)sa); sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)sb);
+    const unsigned long long below = (1ull << lane_id()) - 1ull;
+    *pos_a = sa + (uint32_t)__popcll(ma & below); *pos_b = sb + (uint32_t)__popcll(mb & below);
+}
 __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     return v;  // valid in lane 0
@@ -308,11 +320,15 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
         }
         // reserve the light-sample item first, so its rays stream straight from registers to the queue
         uint32_t ipos = base + shared_append(wants_item, &lds_counts[1]);
+        // (the list of live items: built by the lean form — the one the BASELINE Cornell configurations take — when the render's light-sample kernel walks it;
+        // in the other forms the three registers it holds across the vertex code cost more scratch than the list saves: C3 k_shade 2347 -> 2455 us, measured)
+        constexpr bool kLiveList = FORM == PT_SHADE_LEAN;
+        bool item_lives = false;   // some ray of the item has a non-zero factor
         ShadeOutT<NL> out;
         out.survives = false; out.has_item = false; out.vertex_pushed = false; out.env_hit = false; out.shadow_count = 0; out.add_energy = false; out.env_mask = 0;
         if (active) {
             uint32_t pixel = pixels[pv.slot % rp.chunk_pixels];
-            out = stage_shade<NL, FORM == PT_SHADE_FULL, FORM != PT_SHADE_LEAN>(s, rp, bounce, pv, hit, pixel, [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(shadow, ipos, l, ray); });
+            out = stage_shade<NL, FORM == PT_SHADE_FULL, FORM != PT_SHADE_LEAN>(s, rp, bounce, pv, hit, pixel, [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(shadow, ipos, l, ray); if (kLiveList) item_lives = item_lives || ray_is_live<NL>(ray); });
             if (wants_item) {
                 float lam[NL]; lam[0] = pv.lambda;
                 if (NL > 1) hero_lambdas<NL>(rp, pt_draw4(rp.seed, pixel, rp.first_sample + pv.slot / rp.chunk_pixels, PT_DIM_FILM).z, lam);
@@ -322,7 +338,13 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
             }
             if (out.add_energy) for (int k = 0; k < NL; ++k) energy[(size_t)k * rp.energy_stride + pv.slot] += out.energy_add[k];
         }
-        uint32_t pos = base + shared_append(out.survives, &lds_counts[0]);
+        uint32_t pos;
+        if (kLiveList && rp.live_list) {   // the list of the segment's live items (Layout::shadow_live_field), appended with the surviving paths
+            uint32_t lpos;
+            shared_append2(out.survives, &lds_counts[0], item_lives, &lds_counts[2], &pos, &lpos);
+            pos += base;
+            if (item_lives) qsu(shadow, Layout<NL>::shadow_live_field(rp.light_samples), base + lpos, ipos);
+        } else pos = base + shared_append(out.survives, &lds_counts[0]);
         if (out.survives) store_path<NL>(paths_out, pos, out.next);
         st_vertices += out.vertex_pushed ? 1u : 0u; st_env += out.env_hit ? 1u : 0u; st_shadow += out.shadow_count;
 #ifdef PT_TIMELINE
@@ -335,7 +357,7 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
     if (lane_id() == 0) { atomicAdd(&lds_counts[4], st_vertices); atomicAdd(&lds_counts[5], st_shadow); atomicAdd(&lds_counts[6], st_env); }
     __syncthreads();
     if (threadIdx.x == 0) {
-        count_out[blockIdx.x] = lds_counts[0]; shadow_count[blockIdx.x] = lds_counts[1];
+        count_out[blockIdx.x] = lds_counts[0]; shadow_count[blockIdx.x] = lds_counts[1]; shadow_count[gridDim.x + blockIdx.x] = lds_counts[2];
         unsigned long long* bs = block_stats + (size_t)blockIdx.x * BS_FIELDS;
         bs[BS_VERTICES] += lds_counts[4]; bs[BS_SHADOW_RAYS] += lds_counts[5]; bs[BS_ENV_HITS] += lds_counts[6];
         bs[BS_SEGMENTS] += n;
@@ -400,15 +422,21 @@ k_shade_medium(const uint32_t* __restrict__ blob, uint32_t blob_words, const flo
     }
 }
 
+constexpr uint32_t kShadowListed = 0x80000000u;   // (a flag in k_shadow's seg_cap argument: segments are far smaller)
 template <int USE_LDS, int NL, int TRAV, bool ENV = true, uint32_t LACKS = 0u>
 __global__ void __launch_bounds__(kBlock) PT_SHADOW_OCC k_shadow(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                   uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                   uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
     extern __shared__ __align__(16) uint32_t lds[];
     SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);
-    uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
+    // `seg_cap` with its top bit set (kShadowListed; the engine sets it when the vertex kernel built the list): the segment's LIVE items, through their list
+    // (Layout::shadow_live_field; the count behind the items' counts) — an item without a live ray is not read.  Otherwise every item of the segment.
+    const bool listed = (seg_cap & kShadowListed) != 0u;
+    seg_cap &= ~kShadowListed;
+    uint32_t base = blockIdx.x * seg_cap, n = count_in[(listed ? gridDim.x : 0u) + blockIdx.x];
     for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
-        stage_shadow_item<NL, TRAV, ENV>(s, light_samples, shadow, base + j, energy, energy_stride);
+        const uint32_t item = listed ? qu(shadow, Layout<NL>::shadow_live_field(light_samples), base + j) : base + j;
+        stage_shadow_item<NL, TRAV, ENV>(s, light_samples, shadow, item, energy, energy_stride);
     }
 }
 

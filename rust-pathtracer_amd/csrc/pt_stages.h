@@ -35,6 +35,11 @@ template <int NL> struct Layout {
     // light-sample item: slot, lambda[NL], flags (bit l: sub-ray l is an environment sample), then per light sample 6 + NL floats
     static constexpr uint32_t sh_slot = 0, sh_lambda = 1, sh_flags = 1 + NL, sh_head = 2 + NL, sr_fields = 6 + NL;
     static constexpr uint32_t shadow_fields(uint32_t light_samples) { return sh_head + light_samples * sr_fields; }
+    // One more field behind the rays: the LIST of the segment's live items — entry p of the segment holds the position of its p-th item that has a ray with a
+    // non-zero factor.  An item whose rays are all dead (a vertex next to the lamp: every sampled direction below its horizon — 10 % of C2's items) adds 0 to
+    // its slot whether or not it is read: the light-sample kernel walks the list, every lane on a live item, and never touches the others.
+    static constexpr uint32_t shadow_live_field(uint32_t light_samples) { return shadow_fields(light_samples); }
+    static constexpr uint32_t shadow_queue_fields(uint32_t light_samples) { return shadow_fields(light_samples) + 1u; }
 };
 
 struct Queue { uint32_t* base; uint32_t capacity; uint32_t fields; };
@@ -83,6 +88,7 @@ struct RenderParams {
     uint32_t normalize;         // divide by spp when the last phase of a whole render is flushed
     uint32_t energy_stride;     // energy of wavelength k of slot i at energy[k * energy_stride + i]
     uint32_t phase;             // samples per partial sum (10: tiled.rs:347-361; spp: naive.rs:82-103)
+    uint32_t live_list;         // the light-sample kernel of this render walks the list of live items (Layout::shadow_live_field): the vertex kernel builds it
     CameraParams camera;
 };
 
