@@ -238,7 +238,8 @@ enum {
     PT_TUNE_NO_LDS = 1u << 0,          /* PT_AMD_NO_LDS: the blob is read from HBM/L2, nothing staged */
     PT_TUNE_NO_CORE_LDS = 1u << 1,     /* PT_AMD_NO_CORE_LDS: a blob too big to stage whole is not staged by its core either */
     PT_TUNE_NO_PARK = 1u << 2,         /* PT_AMD_NO_PARK: walked meshes of a hybrid scene are walked in line */
-    /* 1u << 3: not a product switch (measurement builds, -DPT_EXPERIMENTS: phase 3 pooled per wave, measured slower — profiles/r2_experiments.md); ignored */
+    PT_TUNE_NO_LIVE_LIST = 1u << 3,    /* PT_AMD_NO_LIVE_LIST: the light-sample kernel reads every item of a segment, not the list of those with a live ray
+                                          (measurement builds, -DPT_EXPERIMENTS, read this bit as their pooled phase 3 instead and build no list) */
     PT_TUNE_EXACT_SLAB = 1u << 4,      /* PT_AMD_EXACT_SLAB: the six-division box test everywhere */
     PT_TUNE_NO_CULL = 1u << 5,         /* PT_AMD_NO_CULL: no culling by the closest hit, no early stop */
     PT_TUNE_NO_SWEEP = 1u << 6,        /* PT_AMD_NO_SWEEP: the BVH walk even where a sweep table exists */

@@ -323,7 +323,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
 #endif
     // (the plain light-sample kernel walks the list of live items; the parked forms list their live RAYS themselves, the measurement forms read every item)
 #ifndef PT_EXPERIMENTS
-    rp.live_list = ((trav_form == PT_FORM_SWEEP || trav_form == PT_FORM_WALK || trav_form == PT_FORM_ANY) && shade_form == PT_SHADE_LEAN) ? 1u : 0u;
+    rp.live_list = ((trav_form == PT_FORM_SWEEP || trav_form == PT_FORM_WALK || trav_form == PT_FORM_ANY) && shade_form == PT_SHADE_LEAN && !(tn.flags & PT_TUNE_NO_LIVE_LIST)) ? 1u : 0u;
 #endif
     cfg.fuse = !(tn.flags & PT_TUNE_NO_FUSE) && (!hero || PT_FUSE_HERO) && trav_form == PT_FORM_SWEEP && shade_form == PT_SHADE_LEAN && (cfg.lacks & PT_SCENE_NO_XF) != 0;
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
@@ -503,7 +503,11 @@ void pt_tuning_default(pt_tuning* t) {
 #endif
 
         {"PT_AMD_EXACT_SLAB", PT_TUNE_EXACT_SLAB}, {"PT_AMD_NO_CULL", PT_TUNE_NO_CULL}, {"PT_AMD_NO_SWEEP", PT_TUNE_NO_SWEEP}, {"PT_AMD_NO_MESH_SWEEP", PT_TUNE_NO_MESH_SWEEP},
-        {"PT_AMD_NO_KNOWN_LIGHT", PT_TUNE_NO_KNOWN_LIGHT}, {"PT_AMD_GENERAL_FORMS", PT_TUNE_GENERAL_FORMS}, {"PT_AMD_NO_FUSE", PT_TUNE_NO_FUSE}, {"PT_AMD_MULTI_RCCL", PT_TUNE_MULTI_RCCL}, {"PT_AMD_NO_AXIS_SCAN", PT_TUNE_NO_AXIS_SCAN}};
+        {"PT_AMD_NO_KNOWN_LIGHT", PT_TUNE_NO_KNOWN_LIGHT}, {"PT_AMD_GENERAL_FORMS", PT_TUNE_GENERAL_FORMS}, {"PT_AMD_NO_FUSE", PT_TUNE_NO_FUSE}, {"PT_AMD_MULTI_RCCL", PT_TUNE_MULTI_RCCL}, {"PT_AMD_NO_AXIS_SCAN", PT_TUNE_NO_AXIS_SCAN},
+#ifndef PT_EXPERIMENTS
+        {"PT_AMD_NO_LIVE_LIST", PT_TUNE_NO_LIVE_LIST},
+#endif
+    };
     for (const auto& f : flags) if (env_u32(f.name, 0)) t->flags |= f.bit;
     if (env_u32("PT_AMD_STAGE_TIMING", 1) == 0) t->flags |= PT_TUNE_NO_STAGE_TIMING;
     t->batch_slots = env_u32("PT_AMD_BATCH", 0);

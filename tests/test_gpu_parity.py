@@ -279,6 +279,7 @@ def test_forms_without_transforms_change_nothing(engine, pkg, monkeypatch, scene
     base, pbase = ref.render(rd)
     hits = ref.intersect(o, d)
     for env in ({"PT_AMD_GENERAL_FORMS": "1"}, {"PT_AMD_NO_FUSE": "1"}, {"PT_AMD_NO_FUSE": "1", "PT_AMD_BLOCKS_PER_CU": "1"}, {"PT_AMD_BLOCKS_PER_CU": "2"},
+                {"PT_AMD_NO_LIVE_LIST": "1"}, {"PT_AMD_NO_LIVE_LIST": "1", "PT_AMD_NO_FUSE": "1"},   # (every light-sample item read, not the list of those with a live ray)
                 {"PT_AMD_BLOCKS_PER_CU": "1", "PT_AMD_GENERAL_FORMS": "1"}):
         # (the fused form — k_shade tracing its own segments, the default for single-wavelength scenes of this kind — against k_extend + k_shade;
         # long segments: many rounds per workgroup)
