@@ -194,6 +194,9 @@ PT_HD bool shade_wants_item(const SceneView& s, const RenderParams& rp, const Hi
 // the whole estimate_direct_illumination_from_world branch is compiled out of the kernel (registers, not results: choose_first with
 // probability 0 leaves the sample as it is).
 // GGX = false: the scene holds no GGX material (material_prepare<false> and friends).
+#ifndef PT_ONE_LIGHT_FORMS
+#define PT_ONE_LIGHT_FORMS (!ENV && !GGX)   /* which vertex forms test their light-sample rays against a scene's only light (below) */
+#endif
 template <int NL, bool ENV = true, bool GGX = true, typename RaySink>
 PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint32_t bounce, const PathVertexT<NL>& pv, const Hit& hit,
                                 uint32_t pixel, RaySink&& sink) {
@@ -264,6 +267,8 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
             F3 hn = normalize(hit.n);  // HitRecord::from(vertex) renormalises (utils.rs:117-134)
             Frame fr2 = frame_from_normal(hn);
             F3 wi2 = to_local(fr2, normalize(sub(pv.prev_p, hit.p)));
+            // (the light-sample rays of a scene with one light are tested against it here — below — unless the scene forbids the light bound)
+            const bool one_light = n_lights == 1u && !(bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_CULL));
             EnvCurves ec[NL];  // the environment's spectral weights at this vertex' wavelengths, for all its light samples
             for (int k = 0; k < NL; ++k) ec[k] = (ENV && env_p > 0.0f) ? env_curves(s, lam[k]) : EnvCurves{{0.0f, 0.0f, 0.0f, 0.0f}, false};
             for (uint32_t l = 0; l < rp.light_samples; ++l) {
@@ -318,6 +323,17 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                         // (the microfacet evaluation is a big body: rolled; the Lambertian one a few instructions: the compiler's choice)
                         if (GGX) { PT_ROLLED for (int k = 1; k < NL; ++k) passenger(k); } else { for (int k = 1; k < NL; ++k) passenger(k); }
                         out.shadow_count += 1;
+                        // The scene's ONLY light: a ray that misses it meets no light at all — the light-sample kernel's search bound (shadow_light_bound:
+                        // nearest_light_hit = +inf) would drop it untraced, with the same test on the same ray.  Found here it makes the ray dead, and an
+                        // item whose rays are all dead is never read (Layout::shadow_live_field).  In the Cornell box that is every vertex on the
+                        // ceiling: its rays start, after the normal offset, BELOW the lamp that hangs 1e-4 under it — 16 % of C2's items.
+                        if (PT_ONE_LIGHT_FORMS && one_light) {
+                            const uint32_t linst = bu(s, PT_HDR_INSTANCE_OFF) + light_id * PT_INST_WORDS;
+                            F3 l0, l1;
+                            instance_local_ray(s, linst, ray.o, ray.d, &l0, &l1);
+                            Hit lh;
+                            if (!analytic_hit(s, linst, bu(s, linst + PT_INST_KIND), l0, l1, PT_INF, &lh)) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
+                        }
                     }
                 }
                 sink(l, ray);
