@@ -353,10 +353,9 @@ PT_HD bool aabb_hit(F4 a, F4 b, const RayPrep& rp, float* entry) {
 // sphere light culled the light; spheres then got a margin of 2e-3, which the second case above still defeats.)
 PT_HD bool beyond(float entry, float closest, float base) { return entry > closest * 1.00001f + base; }
 
-// Three-way form of the filtered test for the leaf sweep: 1 = hit, 0 = miss, 2 = too close to call (the caller settles it
-// with aabb_hit_exact).  Requires rp.fast and no zero direction component.  `flat` (a box of zero thickness, known per leaf
-// on the host) selects the per-axis form above; other boxes use the plain comparison of max entry and min exit, whose
-// approximation error is covered by the same margin.
+// The filtered test classifies: hit, miss, or too close to call (the caller settles it with aabb_hit_exact).  It requires rp.fast and
+// no zero direction component.  A box of zero thickness along some axis (known per box on the host) takes the per-axis form of aabb_hit
+// above; other boxes the plain comparison of max entry and min exit, whose approximation error is covered by the same margin.
 // max(a, b, c, 0) and min(a, b, c) of slab distances: two / one instruction on the device (the compiler's own lowering of the fmaxf
 // chain spends two more on quieting signalling NaNs that arithmetic results cannot be)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -368,65 +367,6 @@ PT_HD float pt_max3(float a, float b, float c) { return __builtin_fmaxf(__builti
 PT_HD float slab_entry(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a, b), c), 0.0f); }
 PT_HD float slab_exit(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 #endif
-PT_HD void aabb_classify2(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry, bool* hit, bool* undecided) {
-    PT_STAT(box_tests);
-    float p0 = approx_fma(a.x, rp.r.x, rp.nor.x), q0 = approx_fma(b.x, rp.r.x, rp.nor.x);
-    float p1 = approx_fma(a.y, rp.r.y, rp.nor.y), q1 = approx_fma(b.y, rp.r.y, rp.nor.y);
-    float p2 = approx_fma(a.z, rp.r.z, rp.nor.z), q2 = approx_fma(b.z, rp.r.z, rp.nor.z);
-    float n0 = __builtin_fminf(p0, q0), x0 = __builtin_fmaxf(p0, q0), n1 = __builtin_fminf(p1, q1), x1 = __builtin_fmaxf(p1, q1);
-    float n2 = __builtin_fminf(p2, q2), x2 = __builtin_fmaxf(p2, q2);
-    if (!flat) {
-        float lo = slab_entry(n0, n1, n2), hi = slab_exit(x0, x1, x2);
-        float e = approx_fma(PT_SLAB_EPS, lo + pt_abs(hi), rp.base), gap = lo - hi;
-        *entry = lo;
-        *hit = gap < -e; *undecided = !(gap > e) && !(gap < -e);
-        return;
-    }
-    float m0 = __builtin_fmaxf(__builtin_fmaxf(n1, n2), 0.0f), m1 = __builtin_fmaxf(__builtin_fmaxf(n0, n2), 0.0f), m2 = __builtin_fmaxf(__builtin_fmaxf(n0, n1), 0.0f);
-    float e0 = approx_fma(PT_SLAB_EPS, m0 + pt_abs(x0), rp.base), e1 = approx_fma(PT_SLAB_EPS, m1 + pt_abs(x1), rp.base), e2 = approx_fma(PT_SLAB_EPS, m2 + pt_abs(x2), rp.base);
-    *entry = __builtin_fmaxf(m0, n0);
-    const bool miss = m0 > x0 + e0 || m1 > x1 + e1 || m2 > x2 + e2;
-    *hit = !miss && (m0 < x0 - e0 && m1 < x1 - e1 && m2 < x2 - e2);
-    *undecided = !miss && !*hit;
-}
-// A box that is flat along exactly one axis K (every axis-aligned wall): both planes of that axis are the same plane, reached at t_K,
-// and AABB::hit's decision — max(entries, 0) <= min(exits) on the quotients it computes — is t_K >= max(n_i, n_l, 0) and
-// t_K <= min(x_i, x_l) for the other two axes i, l (n <= x holds per axis by construction, n_K = x_K = t_K exactly: the same division
-// twice).  Five planes instead of six and two comparisons instead of three pairs; same margin rule as above.
-template <int K>
-PT_HD void aabb_classify_flat1(F4 a, F4 b, const RayPrep& rp, float* entry, bool* hit, bool* undecided) {
-    PT_STAT(box_tests);
-    const float ak = K == 0 ? a.x : (K == 1 ? a.y : a.z), rk = K == 0 ? rp.r.x : (K == 1 ? rp.r.y : rp.r.z), nk = K == 0 ? rp.nor.x : (K == 1 ? rp.nor.y : rp.nor.z);
-    const float ai = K == 0 ? a.y : a.x, bi = K == 0 ? b.y : b.x, ri = K == 0 ? rp.r.y : rp.r.x, ni_ = K == 0 ? rp.nor.y : rp.nor.x;
-    const float al = K == 2 ? a.y : a.z, bl = K == 2 ? b.y : b.z, rl = K == 2 ? rp.r.y : rp.r.z, nl_ = K == 2 ? rp.nor.y : rp.nor.z;
-    const float tk = approx_fma(ak, rk, nk);
-    const float pi = approx_fma(ai, ri, ni_), qi = approx_fma(bi, ri, ni_), pl = approx_fma(al, rl, nl_), ql = approx_fma(bl, rl, nl_);
-    const float n_i = __builtin_fminf(pi, qi), x_i = __builtin_fmaxf(pi, qi), n_l = __builtin_fminf(pl, ql), x_l = __builtin_fmaxf(pl, ql);
-    const float lo = slab_entry(n_i, n_l, n_l), hi = __builtin_fminf(x_i, x_l);
-    const float e = approx_fma(PT_SLAB_EPS, (lo + pt_abs(hi)) + pt_abs(tk), rp.base);
-    const float g1 = lo - tk, g2 = tk - hi;
-    *entry = tk;
-    *hit = g1 < -e && g2 < -e;
-    *undecided = !*hit && !(g1 > e || g2 > e);
-}
-// The form the host chose for a box (pt_scene_host.cpp flat_code): 0 thick, 1..3 flat along one axis, 4 flat along several
-template <int CODE>
-PT_HD void aabb_classify_code(F4 a, F4 b, const RayPrep& rp, float* entry, bool* hit, bool* undecided) {
-    if (CODE == 0) aabb_classify2(a, b, rp, false, entry, hit, undecided);
-    else if (CODE == 1) aabb_classify_flat1<0>(a, b, rp, entry, hit, undecided);
-    else if (CODE == 2) aabb_classify_flat1<1>(a, b, rp, entry, hit, undecided);
-    else if (CODE == 3) aabb_classify_flat1<2>(a, b, rp, entry, hit, undecided);
-    else aabb_classify2(a, b, rp, true, entry, hit, undecided);
-}
-PT_HD void aabb_classify_by(uint32_t code, F4 a, F4 b, const RayPrep& rp, float* entry, bool* hit, bool* undecided) {   // `code` wave-uniform
-    switch (code) {
-        case 0: aabb_classify_code<0>(a, b, rp, entry, hit, undecided); break;
-        case 1: aabb_classify_code<1>(a, b, rp, entry, hit, undecided); break;
-        case 2: aabb_classify_code<2>(a, b, rp, entry, hit, undecided); break;
-        case 3: aabb_classify_code<3>(a, b, rp, entry, hit, undecided); break;
-        default: aabb_classify_code<4>(a, b, rp, entry, hit, undecided); break;
-    }
-}
 // The decision as two wave masks (the lanes that hit, the lanes too close to call).  A lane predicate that crosses a branch — even a wave-uniform one — is
 // merged by the compiler with three scalar instructions per predicate and path (and-not exec, and exec, or); a ballot is the comparison's own result, and a
 // wave mask crosses control flow as a plain scalar value.  The scalar unit is shared by the four SIMDs of a CU (tools/microbench/salu_issue.hip: 540 G
@@ -461,6 +401,11 @@ PT_HD void aabb_wave_flat(F4 a, F4 b, const RayPrep& rp, float* entry, uint64_t*
     const uint64_t H = PT_WAVE_BALLOT(m0 < x0 - e0) & PT_WAVE_BALLOT(m1 < x1 - e1) & PT_WAVE_BALLOT(m2 < x2 - e2) & N;
     *hit = H; *undecided = N & ~H;
 }
+// A box that is flat along exactly one axis K (every axis-aligned wall): both planes of that axis are the same plane, reached at t_K,
+// and AABB::hit's decision — max(entries, 0) <= min(exits) on the quotients it computes — is t_K >= max(n_i, n_l, 0) and
+// t_K <= min(x_i, x_l) for the other two axes i, l (n <= x holds per axis by construction, n_K = x_K = t_K exactly: the same division
+// twice).  Five planes instead of six and two comparisons instead of three pairs; same margin rule as above.
+// The form the host chose for a box (pt_scene_host.cpp flat_code): 0 thick, 1..3 flat along one axis, 4 flat along several (aabb_classify_wave below).
 template <int K>
 PT_HD void aabb_wave_flat1(F4 a, F4 b, const RayPrep& rp, float* entry, uint64_t* hit, uint64_t* undecided) {
     PT_STAT(box_tests);
@@ -555,15 +500,6 @@ PT_HD bool walk_box(F4 a, F4 b, const RayPrep& rp, bool quick, float* entry) {
     }
     *entry = en;
     return hit;
-}
-// The same for a node every lane of the wave tests together (the light list of nearest_light_hit): the form the host chose for it.
-PT_HD bool aabb_hit_uniform_node(F4 a, F4 b, const RayPrep& rp, bool quick, float* entry) {
-    if (!quick) return aabb_hit(a, b, rp, entry);
-    bool h, u;
-    aabb_classify_by(PT_UNIFORM(PT_NODE_CODE(pt_f2u(a.w))), a, b, rp, entry, &h, &u);
-    if (!u) return h;
-    PT_STAT(box_exact);
-    return aabb_hit_exact(a, b, rp.o, rp.d, entry);
 }
 
 // MeshTriangleRef::hit (src/geometry/mesh.rs:67-198), split: the per-ray part (axis permutation and shear constants,
