@@ -645,6 +645,26 @@ def big_sphere_light():
     return b
 
 
+def disk_lamp():
+    """One disk lamp (one-sided, facing down) 1e-4 under a ceiling rect, a floor, a Lambertian ball and a wall (not a reference scene): the lean vertex form of a scene
+    with ONE light of a shape other than a rect — its light-sample rays are tested against the lamp where they are made (pt_stages.h, the one-light test), and the ceiling's
+    vertices, whose rays start below the lamp they aim at, are the case that test exists for."""
+    b = SceneBuilder()
+    add_library_curves(b, ["flat_zero"])
+    b.set_environment_constant(b.curve("flat_zero"), 0.0)
+    b.env_sampling_probability = 0.0
+    light = add_library_material(b, "diffuse_light_flat_x5")
+    white = add_library_material(b, "lambertian_white")
+    red = add_library_material(b, "lambertian_red")
+    b.add_disk(0.25, (0.0, 0.0, 0.9999), False, light)
+    b.add_rect((2.0, 2.0), (0.0, 0.0, 1.0), "Z", True, white)      # ceiling
+    b.add_rect((2.0, 2.0), (0.0, 0.0, 0.0), "Z", True, white)      # floor
+    b.add_rect((2.0, 1.0), (1.0, 0.0, 0.5), "X", True, red)        # back wall
+    b.add_sphere(0.25, (0.2, 0.3, 0.25), white)
+    b.add_camera((-2.4, 0.0, 0.5), (0.0, 0.0, 0.45), 45.0, focal_distance=2.4, aperture_diameter=0.01)
+    return b
+
+
 def fog_ball():
     """The medium-aware walk (pt_render_desc.medium_aware; not a reference scene): a ball of forward-scattering HG fog and one of
     Rayleigh-scattering air behind PassthroughFilter boundaries, a rough glass ball filled with absorbing fog (GGX carries medium ids
@@ -804,4 +824,4 @@ def hdri_emissive_mesh():
 
 SCENES = {"test_prism": test_prism, "test_prism_small": test_prism_small, "hdri_emissive_mesh": hdri_emissive_mesh, "hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
           "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test, "panorama_test": panorama_test, "empty_env": empty_env,
-          "big_sphere_light": big_sphere_light, "fog_ball": fog_ball}
+          "big_sphere_light": big_sphere_light, "disk_lamp": disk_lamp, "fog_ball": fog_ball}

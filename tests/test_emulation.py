@@ -63,6 +63,7 @@ def test_materials_bit_exact(emu, oracle, scene):
     ("hdri_small", 24, 24, 4, 4, {"light_samples": 8}),       # the most light samples an item can hold
     ("test_prism_small", 40, 40, 6, 8, {"light_samples": 3}),     # the reference tree's test_prism.toml: transform stack + lights + environment sampling — the general kernel forms
     ("hdri_emissive_mesh", 32, 32, 6, 4, {"light_samples": 3}),   # empty light list, but a mesh instance overridden with a light material: its hits emit
+    ("disk_lamp", 40, 28, 6, 5, {"light_samples": 2, "seed": 2}),   # one disk lamp: the lean form's light test at the vertex (the ceiling's rays start below the lamp), the list of live items
     ("fog_ball", 48, 32, 8, 8, {"medium_aware": True}),       # random_walk_medium — HG fog and Rayleigh haze behind passthrough boundaries, fog in glass
     ("fog_ball", 32, 24, 6, 12, {"medium_aware": True, "light_samples": 3, "min_bounces": 3, "seed": 9}),
     ("fog_ball", 24, 24, 5, 6, {"medium_aware": True, "light_samples": 0}),

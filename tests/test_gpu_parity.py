@@ -84,6 +84,8 @@ def test_materials_bit_exact(engine, oracle, scene):
     ("test_prism_small", 96, 64, 6, 6, {"light_samples": 2, "hero_wavelengths": 4}),
     ("hdri_emissive_mesh", 96, 96, 8, 4, {"light_samples": 3}),     # empty light list, but a mesh instance overridden with a light material (round-3 advisor): its hits emit, take no item
     ("hdri_emissive_mesh", 64, 64, 6, 4, {"light_samples": 2, "hero_wavelengths": 4}),
+    ("disk_lamp", 160, 112, 8, 5, {"light_samples": 2, "seed": 2}),   # one disk lamp 1e-4 under its ceiling: the lean form tests a light-sample ray against the scene's only light at the vertex, the ceiling's items die there and are not listed
+    ("disk_lamp", 96, 64, 6, 6, {"light_samples": 3, "hero_wavelengths": 4}),
     ("cornell_box", 128, 128, 12, 8, {"hero_wavelengths": 4}),      # C5 shape: four wavelengths per path
     ("cornell_gem", 64, 48, 6, 12, {"hero_wavelengths": 4}),
     ("hdri_small", 48, 48, 6, 4, {"hero_wavelengths": 4, "light_samples": 3}),
