@@ -167,6 +167,7 @@
                                        values a sample ends on (cmf[k - 1], cmf[k], pdf[k], pdf[k + 1]) then lie on one 128-byte line instead of two */
 #define PT_HDR_SWEEP_SIMPLE 67       /* 2 words: the sweep table begins with the instances whose box test is all there is to do, grouped by the form of the test:
                                        sizes of the groups 0..3 (8 bits each), then of group 4; the other instances follow (PT_HDR_SWEEP_COUNT counts all) */
+#define PT_MARG_LDS_MAX_ROWS 2048u   /* importance maps of at most this many rows have their marginal tables staged in LDS by the FULL vertex form (24 KB + guide) */
 #define PT_HDR_CORE_WORDS 61        /* words of the core section; the mesh-data section follows it */
 #define PT_HDR_SWEEP_MESH_MASK 57  /* 2 words: the bits that stand for mesh instances (no primitive of their own) */
 #define PT_HDR_SWEEP_OWNER_MASK 62 /* 2 words: the bits whose primitive test needs the ray itself (analytic shapes, triangles of transformed

@@ -116,6 +116,10 @@ struct SceneView {
     // What the scene is known NOT to hold (PT_SCENE_*): a kernel form sets it from a template constant, and after inlining the branches
     // that depend on it fold away — registers and code size change, results do not (a scene that does hold the thing never gets the form).
     uint32_t lacks = 0u;
+    // The marginal tables of the importance map (interleaved cmf / pdf pairs and their guide) staged in LDS by the FULL vertex form (k_shade, stage_marginal): every
+    // environment sample starts with a search of these 12 KB.  marg_words = 0: not staged (every other kernel, the host): the texture memory's copy is read.
+    const float* marg = nullptr;
+    uint32_t marg_words = 0u, marg_base = 0u, marg_guide = 0u;   // floats staged from tex + marg_base; the guide's offset inside them (0: none)
 };
 #define PT_SCENE_NO_XF 1u   /* no instance carries a transform (the Cornell box): instance_local_ray and the hit record's way back are identities */
 #define PT_SCENE_NO_LIGHTS 2u /* the light list is empty (an environment is the only emitter: hdri_test): no light vertex, no light to sample */
@@ -2237,7 +2241,10 @@ PT_HD void env_sample_uv(const SceneView& s, float sx, float sy, float* u, float
         float mu, row_pdf, mv, column_pdf;
         const uint32_t mg = bu(s, PT_HDR_IMAP_MARG_GUIDE), rg = bu(s, PT_HDR_IMAP_ROW_GUIDE);
         const uint32_t stride = bu(s, PT_HDR_IMAP_STRIDE);
-        sample_cmf(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), s.tex + bu(s, PT_HDR_IMAP_MARG_CMF), rows, sy, &mu, &row_pdf, mg ? s.tex + mg : nullptr, stride);
+        // (two call sites, not one call on selected pointers: each keeps its address space — LDS reads here, global ones there)
+        if (s.marg_words != 0u) sample_cmf(s.marg + (bu(s, PT_HDR_IMAP_MARG_PDF) - s.marg_base), s.marg + (bu(s, PT_HDR_IMAP_MARG_CMF) - s.marg_base), rows, sy, &mu, &row_pdf,
+                                           s.marg_guide ? s.marg + s.marg_guide : nullptr, stride);
+        else sample_cmf(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), s.tex + bu(s, PT_HDR_IMAP_MARG_CMF), rows, sy, &mu, &row_pdf, mg ? s.tex + mg : nullptr, stride);
         uint32_t row = (uint32_t)(mu * (float)rows);
         sample_cmf(s.tex + bu(s, PT_HDR_IMAP_ROW_PDF) + (size_t)row * cols * stride, s.tex + bu(s, PT_HDR_IMAP_ROW_CMF) + (size_t)row * cols * stride, cols, sx, &mv, &column_pdf,
                    rg ? s.tex + rg + (size_t)row * (cols + 3u) : nullptr, stride);

@@ -304,7 +304,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     if (park_big) { cfg.park_block = (int)park_block; cfg.park_block_extend = (int)park_block_extend; cfg.park_blob_bytes = sc->blob_words * 4u; }
     cfg.walk_policy = (tn.walk_evict_below ? tn.walk_evict_below : kWalkEvictBelow) | (tn.walk_search_below ? tn.walk_search_below : kWalkSearchBelow) << 8
                     | ((tn.flags & PT_TUNE_NO_AXIS_SCAN) ? 0u : PT_WALK_SCAN_AXIS);
-    const SceneArgs sargs{sc->d_blob, sc->blob_words, sc->d_tex};
+    const SceneArgs sargs{sc->d_blob, sc->blob_words, sc->d_tex, marginal_lds_bytes(sc->host.blob.data())};
     // light samples can pick the environment only if env_sampling_probability > 0: otherwise k_shade is the form without that branch
     float env_prob; std::memcpy(&env_prob, &sc->host.blob[PT_HDR_ENV_PROB], sizeof env_prob);
     bool has_ggx = false;
@@ -485,7 +485,7 @@ static pt_status scene_to_device(pt_scene* sc) {
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE, hipGetErrorString(e));
     if (sc->lds_mode != PT_LDS_NONE) {
         e = allow_lds_extend(kParkBlobLimitBytes);
-        if (e == hipSuccess) e = allow_lds_shade(kLdsBlobLimitBytes);
+        if (e == hipSuccess) e = allow_lds_shade(kLdsBlobLimitBytes + 32768u);   // (+ the importance map's marginal tables behind the blob, FULL form: up to 2730 rows)
         // (the parked light-sample kernels keep their waves' lists of live rays behind the blob: up to 16 waves x (64 L + 64) words)
         if (e == hipSuccess) e = allow_lds_shadow(kParkBlobLimitBytes + 16u * (64u * PT_MAX_LIGHT_SAMPLES + 64u) * 4u);
         if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));

@@ -32,8 +32,14 @@ void PT_PARTNAME(launch_shade_nl)(const LaunchCfg& c, int form, const SceneArgs&
 #define K_SHADE_M(M) k_shade_medium<M>
     if (form == PT_SHADE_MEDIUM) { PT_BY_MODE(K_SHADE_M, PT_ARGS); return; }
 #endif
-    if (form == PT_SHADE_FULL && (c.lacks & PT_SCENE_NO_LIGHTS) && PT_SHADE_NL == 1) PT_BY_MODE(K_SHADE_FE, PT_ARGS);   // (an environment is the scene's only emitter)
-    else if (form == PT_SHADE_FULL) PT_BY_MODE(K_SHADE_F, PT_ARGS);
+    if (form == PT_SHADE_FULL) {   // (the marginal tables of the importance map behind the blob: stage_marginal)
+        LaunchCfg d = c; d.lds_bytes = ((c.lds_bytes + 15u) & ~15u) + sc.marg_bytes;
+#define PT_GO_D(K, ...) go(d, K, __VA_ARGS__)
+#define PT_BY_MODE_D(K, ...) do { if (c.lds_mode == PT_LDS_ALL) PT_GO_D(K(PT_LDS_ALL), __VA_ARGS__); else if (c.lds_mode == PT_LDS_CORE) PT_GO_D(K(PT_LDS_CORE), __VA_ARGS__); \
+                                  else PT_GO_D(K(PT_LDS_NONE), __VA_ARGS__); } while (0)
+        if ((c.lacks & PT_SCENE_NO_LIGHTS) && PT_SHADE_NL == 1) PT_BY_MODE_D(K_SHADE_FE, PT_ARGS);   // (an environment is the scene's only emitter)
+        else PT_BY_MODE_D(K_SHADE_F, PT_ARGS);
+    }
     else PT_BY_MODE(K_SHADE_N, PT_ARGS);
 #else
     (void)form;
@@ -46,7 +52,7 @@ void PT_PARTNAME(launch_shade_nl)(const LaunchCfg& c, int form, const SceneArgs&
 hipError_t PT_PARTNAME(allow_lds_shade_nl)(uint32_t bytes) {
     hipError_t worst = hipSuccess;
     auto allow = [&](const void* k) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) worst = e; };
-#define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE)))
+#define PT_ALLOW_MODES(K) allow(reinterpret_cast<const void*>(K(PT_LDS_ALL))); allow(reinterpret_cast<const void*>(K(PT_LDS_CORE))); allow(reinterpret_cast<const void*>(K(PT_LDS_NONE)))
 #if PT_SHADE_PART == 0
     allow(reinterpret_cast<const void*>(K_SHADE_FUSED));
     PT_ALLOW_MODES(K_SHADE_L); PT_ALLOW_MODES(K_SHADE_LX);

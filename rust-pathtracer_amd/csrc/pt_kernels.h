@@ -191,6 +191,20 @@ static __global__ void k_tl_bump() { g_tl_launch = g_tl_launch + 1u; }
 // Append without a barrier: one LDS atomic per wave claims the wave's run in the workgroup's segment.  The order of the
 // waves' runs inside the segment then depends on timing, which no result depends on (every queue item is processed on its
 // own; energy and film sums are keyed by slot and pixel).  Measured on k_shade: -6 % against block_append's barrier.
+// The importance map's marginal tables (rows x (cmf, pdf) pairs + the guide of rows + 3 words: 12 KB for 1024 rows) into LDS behind the staged blob.  Only the
+// interleaved layout (PT_HDR_IMAP_STRIDE = 2: one contiguous block) is staged; marginal_lds_bytes (pt_launch.h) is the host's side of this layout.
+template <int USE_LDS>
+__device__ __forceinline__ void stage_marginal(SceneView& s, const uint32_t* __restrict__ blob, uint32_t blob_words, uint32_t* lds) {
+    const uint32_t rows = blob[PT_HDR_IMAP_ROWS], stride = blob[PT_HDR_IMAP_STRIDE];
+    if (blob[PT_HDR_ENV_KIND] != PT_ENV_HDR || rows == 0u || rows > PT_MARG_LDS_MAX_ROWS || stride != 2u) return;
+    const uint32_t used = USE_LDS == PT_LDS_ALL ? blob_words : (USE_LDS == PT_LDS_CORE ? blob[PT_HDR_CORE_WORDS] : 0u);
+    float* dst = reinterpret_cast<float*>(lds + ((used + 3u) & ~3u));
+    const uint32_t a = blob[PT_HDR_IMAP_MARG_PDF], b = blob[PT_HDR_IMAP_MARG_CMF], base = a < b ? a : b, pairs = 2u * rows, mg = blob[PT_HDR_IMAP_MARG_GUIDE];
+    for (uint32_t i = threadIdx.x; i < pairs; i += blockDim.x) dst[i] = s.tex[base + i];
+    if (mg != 0u) for (uint32_t i = threadIdx.x; i < rows + 3u; i += blockDim.x) dst[pairs + i] = s.tex[mg + i];
+    __syncthreads();
+    s.marg = dst; s.marg_words = pairs; s.marg_base = base; s.marg_guide = mg != 0u ? pairs : 0u;
+}
 __device__ __forceinline__ uint32_t shared_append(bool flag, uint32_t* lds_head) {
     unsigned long long mask = __ballot(flag);
     uint32_t start = 0;
@@ -265,6 +279,7 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
     __shared__ uint32_t lds_counts[16];  // [0] path queue head, [1] item queue head, [4..6] statistics
     if (threadIdx.x < 16) lds_counts[threadIdx.x] = 0;
     SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);  // (barrier inside when staging; one below otherwise)
+    if (FORM == PT_SHADE_FULL) stage_marginal<USE_LDS>(s, blob, blob_words, lds);   // (the importance map's marginal tables behind the blob: launch_shade sized the LDS for them)
     if (USE_LDS == PT_LDS_NONE) __syncthreads();
     const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
     uint32_t st_vertices = 0, st_shadow = 0, st_env = 0;

@@ -35,7 +35,13 @@ struct LaunchCfg { int grid; uint32_t lds_bytes; hipStream_t stream; int lds_mod
                    uint32_t park_blob_bytes = 0;   //   (this many bytes of LDS) whatever lds_mode says for the other kernels; 0 = workgroups of kBlock, lds_mode
                    bool live_lists = false;    // measurement builds (-DPT_EXPERIMENTS, PT_AMD_LIVE_LISTS=1): k_shadow's sweep forms list the rays that search per wave (k_shadow_live)
                    bool fuse = false; };  // k_shade traces its own segments (pure sweep scenes, lean form, no transforms): no k_extend launch, no hit queue
-struct SceneArgs { const uint32_t* blob; uint32_t blob_words; const float* tex; };
+struct SceneArgs { const uint32_t* blob; uint32_t blob_words; const float* tex; uint32_t marg_bytes = 0; /* LDS the FULL vertex form takes behind the blob (marginal_lds_bytes) */ };
+// The importance map's marginal tables as k_shade's FULL form stages them (pt_kernels.h stage_marginal): 2 x rows floats + the guide's rows + 3 words, only for the interleaved layout.
+inline uint32_t marginal_lds_bytes(const uint32_t* host_blob) {
+    const uint32_t rows = host_blob[PT_HDR_IMAP_ROWS];
+    if (host_blob[PT_HDR_ENV_KIND] != PT_ENV_HDR || rows == 0u || rows > PT_MARG_LDS_MAX_ROWS || host_blob[PT_HDR_IMAP_STRIDE] != 2u) return 0u;
+    return (2u * rows + (host_blob[PT_HDR_IMAP_MARG_GUIDE] ? rows + 3u : 0u)) * 4u + 16u;
+}
 
 void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, ptd::Queue paths, ptd::Queue hits, uint32_t seg_cap, const uint32_t* count_in, uint32_t* park);
 void launch_shade(const LaunchCfg& c, int nl, int form, const SceneArgs& sc, const ptd::RenderParams& rp, uint32_t bounce, const uint32_t* pixels, ptd::Queue paths_in,
