@@ -2217,7 +2217,9 @@ PT_HD float env_pdf_for(const SceneView& s, float u, float v) {
         float u2, v2; direction_to_uv(nd, &u2, &v2);
         uint32_t row = (uint32_t)(pt_clamp(u2, 0.0f, 1.0f - PT_F32_EPSILON) * (float)rows);
         const uint32_t stride = bu(s, PT_HDR_IMAP_STRIDE);
-        return linear01_nearest(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), rows, u2, stride) *
+        const float marginal_pdf = s.marg_words != 0u ? linear01_nearest(s.marg + (bu(s, PT_HDR_IMAP_MARG_PDF) - s.marg_base), rows, u2, stride)   // (the LDS copy: stage_marginal)
+                                                       : linear01_nearest(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), rows, u2, stride);
+        return marginal_pdf *
                    linear01_nearest(s.tex + bu(s, PT_HDR_IMAP_ROW_PDF) + (size_t)row * cols * stride, cols, v2, stride) *
                    (2.0f * PT_PI * PT_PI * pt_sin(PT_PI * v2) + 0.001f) +
                0.001f;
