@@ -83,34 +83,56 @@ def algorithmic_bytes(stage, light_samples):
     return 16 * 2                                 # accumulate: film pixel read-modify-write (energy reads are per sample, added below)
 
 
+RECORD_MARK = "PT_BENCH_RECORD "   # in front of rank 0's record when a bench.py parent launched the ranks (PT_BENCH_PARENT): the parent relays exactly that line
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher, N > 1: start the N ranks as fresh children and relay rank 0's record.  This process
     never touches the GPU (no torch import, no HIP call): the children are the first to initialise it."""
     import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port)]
-    if os.environ.get("PT_BENCH_LAUNCHER"):        # tests: a stand-in for torch.distributed.run (a JSON list; it gets the script and its arguments appended)
-        launcher = json.loads(os.environ["PT_BENCH_LAUNCHER"])
+    import threading
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     env["PT_BENCH_PARENT"] = str(os.getpid())
-    child = subprocess.Popen(launcher + [os.path.abspath(__file__)] + list(argv), stdout=subprocess.PIPE, env=env, text=True)
-    record = None
-    for line in child.stdout:                      # the ranks' stdout: keep rank 0's record, pass everything else on to stderr
-        text = line.strip()
-        if text.startswith("{") and '"metric"' in text:
-            try:
-                if record is not None:
-                    sys.stderr.write(json.dumps(record) + "\n")
-                record = json.loads(text)
-                continue
-            except ValueError:
-                pass
-        sys.stderr.write(line)
-    code = child.wait()
+    # The master port is found by bind-and-close, which another process can win before the launcher binds it again (round-4 advisor): a launcher that
+    # fails on "address already in use" is started again on a new port, three times at most.  Rank 0 marks its record (RECORD_MARK: it sees PT_BENCH_PARENT),
+    # so nothing else a rank prints — RCCL's banner, a stray line of JSON — can be taken for it.
+    for attempt in range(3):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port)]
+        if os.environ.get("PT_BENCH_LAUNCHER"):        # tests: a stand-in for torch.distributed.run (a JSON list; it gets the script and its arguments appended)
+            launcher = json.loads(os.environ["PT_BENCH_LAUNCHER"])
+        child = subprocess.Popen(launcher + [os.path.abspath(__file__)] + list(argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
+        port_taken = []
+
+        def relay_stderr(stream=child.stderr, seen=port_taken):
+            for line in stream:
+                if "EADDRINUSE" in line or "ddress already in use" in line:
+                    seen.append(line)
+                sys.stderr.write(line)
+        relay = threading.Thread(target=relay_stderr, daemon=True)
+        relay.start()
+        record = None
+        for line in child.stdout:                      # the ranks' stdout: keep rank 0's record, pass everything else on to stderr
+            text = line.strip()
+            if text.startswith(RECORD_MARK):
+                try:
+                    if record is not None:
+                        sys.stderr.write(json.dumps(record) + "\n")
+                    record = json.loads(text[len(RECORD_MARK):])
+                    continue
+                except ValueError:
+                    pass
+            sys.stderr.write(line)
+        code = child.wait()
+        relay.join(timeout=10)
+        if code != 0 and record is None and port_taken and attempt < 2:
+            sys.stderr.write("bench.py: port %d was taken before the launcher could bind it; starting the ranks again\n" % port)
+            continue
+        break
     sys.stderr.flush()
     if code != 0:
         sys.stderr.write("bench.py: the launcher of %d ranks exited with code %d\n" % (args.gpus, code))
@@ -461,7 +483,7 @@ def main():
         except OSError:
             pass
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)   # the last line of stdout, after anything RCCL had to say
+        print((RECORD_MARK if os.environ.get("PT_BENCH_PARENT") else "") + json.dumps(out), flush=True)   # the last line of stdout, after anything RCCL had to say
 
 
 if __name__ == "__main__":

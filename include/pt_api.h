@@ -238,8 +238,7 @@ enum {
     PT_TUNE_NO_LDS = 1u << 0,          /* PT_AMD_NO_LDS: the blob is read from HBM/L2, nothing staged */
     PT_TUNE_NO_CORE_LDS = 1u << 1,     /* PT_AMD_NO_CORE_LDS: a blob too big to stage whole is not staged by its core either */
     PT_TUNE_NO_PARK = 1u << 2,         /* PT_AMD_NO_PARK: walked meshes of a hybrid scene are walked in line */
-    PT_TUNE_NO_LIVE_LIST = 1u << 3,    /* PT_AMD_NO_LIVE_LIST: the light-sample kernel reads every item of a segment, not the list of those with a live ray
-                                          (measurement builds, -DPT_EXPERIMENTS, read this bit as their pooled phase 3 instead and build no list) */
+    PT_TUNE_NO_LIVE_LIST = 1u << 3,    /* PT_AMD_NO_LIVE_LIST: the light-sample kernel reads every item of a segment, not the list of those with a live ray */
     PT_TUNE_EXACT_SLAB = 1u << 4,      /* PT_AMD_EXACT_SLAB: the six-division box test everywhere */
     PT_TUNE_NO_CULL = 1u << 5,         /* PT_AMD_NO_CULL: no culling by the closest hit, no early stop */
     PT_TUNE_NO_SWEEP = 1u << 6,        /* PT_AMD_NO_SWEEP: the BVH walk even where a sweep table exists */
@@ -249,6 +248,8 @@ enum {
     PT_TUNE_NO_FUSE = 1u << 10,        /* PT_AMD_NO_FUSE: k_extend + k_shade as two launches even where the fused form (k_shade tracing its own segments) exists */
     PT_TUNE_NO_STAGE_TIMING = 1u << 11,/* PT_AMD_STAGE_TIMING=0: no HIP events around the launches (pt_profile::kernel_seconds stay 0) */
     PT_TUNE_MULTI_RCCL = 1u << 12,     /* PT_AMD_MULTI_RCCL: pt_render_multi takes the RCCL reduce even for one device */
+    PT_TUNE_NO_ONE_LIGHT = 1u << 14,   /* PT_AMD_NO_ONE_LIGHT: in a scene with ONE light the lean vertex kernel does not run that light's shape test on its light-sample rays
+                                          (by default a ray that misses the only light is dead where it is made and its item, if no ray of it lives, never read) */
     PT_TUNE_NO_AXIS_SCAN = 1u << 13    /* PT_AMD_NO_AXIS_SCAN: the parked kernels walk a ray that is parallel to an axis of its mesh like any other (by default the
                                           whole wave scans the mesh's leaves for it: such a ray passes most boxes, AABB::hit ignoring the axes its direction is zero along) */
 };
@@ -270,7 +271,10 @@ typedef struct pt_tuning {
                                      its core only but fits 72 KB (the gem scene, C3: 66 KB) can run workgroups of 512 or 1024 threads that stage the WHOLE blob
                                      in LDS while the other kernels keep their staging mode.  0 = the measured default (the light-sample kernel at 512, the
                                      closest-hit kernel at 256), 512 / 1024 = both kernels at that size, 256 = off */
-    uint32_t reserved[5];         /* must be 0 */
+    uint32_t light_prepass_max;   /* PT_AMD_LIGHT_PREPASS_MAX: a light-sample ray aimed at a light is bounded by the nearest hit among ALL lights before it is traced (one box
+                                     test per light and ray: it buys the early stop at the first occluder).  A scene with more lights than this traces such a ray as a
+                                     plain closest-hit search instead (test_bokeh.toml: 82 lights).  0 = the default (16); 0xffffffff = always bound */
+    uint32_t reserved[4];         /* must be 0 */
 } pt_tuning;
 /* The defaults, overridden by whatever PT_AMD_* variables the environment holds at the time of the call. */
 void pt_tuning_default(pt_tuning* tuning);

@@ -124,14 +124,14 @@ class Profile(C.Structure):
 
 # pt_tuning flags (include/pt_api.h)
 TUNE_NO_LDS, TUNE_NO_CORE_LDS, TUNE_NO_PARK, TUNE_NO_LIVE_LIST, TUNE_EXACT_SLAB, TUNE_NO_CULL, TUNE_NO_SWEEP, TUNE_NO_MESH_SWEEP, TUNE_NO_KNOWN_LIGHT, \
-    TUNE_GENERAL_FORMS, TUNE_NO_FUSE, TUNE_NO_STAGE_TIMING, TUNE_MULTI_RCCL, TUNE_NO_AXIS_SCAN = (1 << i for i in range(14))
+    TUNE_GENERAL_FORMS, TUNE_NO_FUSE, TUNE_NO_STAGE_TIMING, TUNE_MULTI_RCCL, TUNE_NO_AXIS_SCAN, TUNE_NO_ONE_LIGHT = (1 << i for i in range(15))
 
 
 class Tuning(C.Structure):
     """pt_tuning: the engine's run-time switches, taken by a scene when it is created."""
     _fields_ = [("flags", C.c_uint32), ("batch_slots", C.c_uint32), ("blocks_per_cu", C.c_uint32), ("park_blocks_per_cu", C.c_uint32),
                 ("park_dynamic", C.c_int32), ("shade_form", C.c_uint32), ("lds_all_limit", C.c_uint32), ("multi_virtual", C.c_uint32),
-                ("walk_evict_below", C.c_uint32), ("walk_search_below", C.c_uint32), ("park_block", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("walk_evict_below", C.c_uint32), ("walk_search_below", C.c_uint32), ("park_block", C.c_uint32), ("light_prepass_max", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
 class OutputDesc(C.Structure):

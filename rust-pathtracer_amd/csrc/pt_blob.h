@@ -135,6 +135,9 @@
 #define PT_FLAG_NO_MESH_SWEEP 64u  /* diagnostics (PT_AMD_NO_MESH_SWEEP=1): walk every mesh BVH */
 #define PT_FLAG_NO_SWEEP 16u      /* diagnostics (PT_AMD_NO_SWEEP=1): always walk the BVHs */
 #define PT_FLAG_NO_KNOWN_LIGHT 256u /* diagnostics (PT_AMD_NO_KNOWN_LIGHT=1): phase 3 tests the nearest light again instead of taking the light pre-pass' distance */
+#define PT_FLAG_NO_ONE_LIGHT 512u /* diagnostics (PT_AMD_NO_ONE_LIGHT=1): the lean vertex kernel does not test a light-sample ray against the scene's only light (stage_shade) */
+#define PT_FLAG_NO_LIGHT_PREPASS 1024u /* the light list is long (pt_tuning::light_prepass_max): a light-sample ray is traced as a plain closest-hit search, without the
+                                         pre-pass over every light's box that bounds it (nearest_light_hit is linear in the lights: 82 box tests per ray in test_bokeh.toml) */
 #define PT_FLAG_REPLAY 128u       /* diagnostics (host emulation): phase 3 of the sweep as unbounded tests + ordered replay (the pooled form's logic) */
 #define PT_FLAG_NO_TOP_CULL 1u   /* a Disk instance exists: its reference box (radius/2, disk.rs:24-28) does not contain it */
 
@@ -167,6 +170,10 @@
                                        values a sample ends on (cmf[k - 1], cmf[k], pdf[k], pdf[k + 1]) then lie on one 128-byte line instead of two */
 #define PT_HDR_SWEEP_SIMPLE 67       /* 2 words: the sweep table begins with the instances whose box test is all there is to do, grouped by the form of the test:
                                        sizes of the groups 0..3 (8 bits each), then of group 4; the other instances follow (PT_HDR_SWEEP_COUNT counts all) */
+/* ... and only while blob + tables leave the FULL vertex form its four workgroups per CU (four waves per SIMD, 160 KB of LDS: 40 KB each); a bigger staged
+   blob keeps the tables in L2 rather than lose a workgroup per CU silently (round-4 advisor).  stage_marginal (device) and marginal_lds_bytes (host) share the rule. */
+#define PT_SHADE_LDS_BUDGET 40960u
+#define PT_MARG_LDS_BYTES(rows, has_guide) ((2u * (rows) + ((has_guide) ? (rows) + 3u : 0u)) * 4u + 16u)
 #define PT_MARG_LDS_MAX_ROWS 2048u   /* importance maps of at most this many rows have their marginal tables staged in LDS by the FULL vertex form (24 KB + guide) */
 #define PT_HDR_CORE_WORDS 61        /* words of the core section; the mesh-data section follows it */
 #define PT_HDR_SWEEP_MESH_MASK 57  /* 2 words: the bits that stand for mesh instances (no primitive of their own) */

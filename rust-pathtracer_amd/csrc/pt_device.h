@@ -20,6 +20,12 @@
 #include "../../include/pt_numerics.h"
 #include "pt_blob.h"
 
+// Predicates in this header are combined with `&` and `|` ON PURPOSE: `&&` / `||` of comparisons compile to a branch around the next comparison — three scalar
+// instructions each on a unit the kernels were bound by ("The scalar unit").  No operand has a side effect, so the two spellings mean the same.
+#if defined(__clang__)
+#pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
+#endif
+
 // Optional instrumentation for host-side experiments (tools/traversal_stats.cpp); compiled out everywhere else.
 #ifndef PT_STAT
 #define PT_STAT(counter)
@@ -1685,6 +1691,14 @@ PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_
     return world_hit_walk(s, o, d, out, bound, stop);
 }
 
+// One light's own shape test on a world ray against the unbounded interval: what nearest_light_hit runs per light whose box passes, and what the lean
+// vertex kernel runs on a light-sample ray of a scene with one light (stage_shade) — ONE helper, so the two cannot drift apart (round-4 advisor).
+PT_HD bool light_shape_hit(const SceneView& s, uint32_t inst, F3 o, F3 d, Hit* h) {
+    F3 l0, l1;
+    instance_local_ray(s, inst, o, d, &l0, &l1);
+    return analytic_hit(s, inst, bu(s, inst + PT_INST_KIND), l0, l1, PT_INF, h);
+}
+
 // Nearest hit among the light instances that the reference's walk would test for this ray (an instance is tested iff
 // its own leaf box passes AABB::hit; ancestor boxes contain it, and the slab test is monotone under rounding, so they
 // pass too).  Returns +inf if no light is hit.  Same arithmetic as the walk, so the distance is the one the walk finds.
@@ -1711,11 +1725,8 @@ PT_HD float nearest_light_hit(const SceneView& s, F3 o, F3 d, uint32_t* which = 
         bool inside = PT_WAVE_MEMBER(hb);
         if (ub != 0ull) { PT_KEEP_BRANCH(); if (PT_WAVE_MEMBER(ub)) { PT_STAT(box_exact); inside = aabb_hit_exact(a, b, o, d, &entry); } }
         if (!inside) continue;
-        uint32_t inst = inst_off + bu(s, lo_ + k) * PT_INST_WORDS;
-        F3 l0, l1;
-        instance_local_ray(s, inst, o, d, &l0, &l1);
         Hit h;
-        if (analytic_hit(s, inst, bu(s, inst + PT_INST_KIND), l0, l1, PT_INF, &h) && h.t < best) { best = h.t; light = bu(s, lo_ + k); }
+        if (light_shape_hit(s, inst_off + bu(s, lo_ + k) * PT_INST_WORDS, o, d, &h) && h.t < best) { best = h.t; light = bu(s, lo_ + k); }
     }
     if (which != nullptr) *which = light;   // (the instance that gave the distance; 0xffffffff: none)
     return best;

@@ -281,7 +281,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     // PT_AMD_POOL=1: phase 3 of a pure sweep scene pooled per wave (sweep_run_pooled).  Bit-identical, but measured slower than the lane
     // loop on MI355X (C2: k_extend 3155 vs 2475 us, k_shadow 5421 vs 4677 us; DESIGN.md section 5 has the breakdown), so it is not the default.
 #ifdef PT_EXPERIMENTS
-#define PT_TUNE_EXPERIMENT_POOL (1u << 3)   /* pt_tuning::flags bit the public header leaves unnamed */
+#define PT_TUNE_EXPERIMENT_POOL (1u << 31)   /* a pt_tuning::flags bit of its own, unnamed in the public header (round-4 advisor: bit 3 means PT_TUNE_NO_LIVE_LIST in every build) */
     const bool pooled = sweep && !walks && mode == PT_LDS_ALL && lds_bytes + pool_lds_bytes() <= kLdsBlobLimitBytes && (tn.flags & PT_TUNE_EXPERIMENT_POOL) != 0;
 #else
     const bool pooled = false;   // (the pooled kernels are not in the product: make EXTRA=-DPT_EXPERIMENTS builds them, PT_AMD_POOL=1 selects them there)
@@ -304,7 +304,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     if (park_big) { cfg.park_block = (int)park_block; cfg.park_block_extend = (int)park_block_extend; cfg.park_blob_bytes = sc->blob_words * 4u; }
     cfg.walk_policy = (tn.walk_evict_below ? tn.walk_evict_below : kWalkEvictBelow) | (tn.walk_search_below ? tn.walk_search_below : kWalkSearchBelow) << 8
                     | ((tn.flags & PT_TUNE_NO_AXIS_SCAN) ? 0u : PT_WALK_SCAN_AXIS);
-    const SceneArgs sargs{sc->d_blob, sc->blob_words, sc->d_tex, marginal_lds_bytes(sc->host.blob.data())};
+    const SceneArgs sargs{sc->d_blob, sc->blob_words, sc->d_tex, marginal_lds_bytes(sc->host.blob.data(), lds_bytes)};
     // light samples can pick the environment only if env_sampling_probability > 0: otherwise k_shade is the form without that branch
     float env_prob; std::memcpy(&env_prob, &sc->host.blob[PT_HDR_ENV_PROB], sizeof env_prob);
     bool has_ggx = false;
@@ -322,8 +322,10 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
 #define PT_FUSE_HERO 1   /* round 4: built without machine LICM the hero fused form needs 111 VGPRs — four waves per SIMD, not three — and wins: C5 1153 -> 1179 (3625 us against 1160 + 2578) */
 #endif
     // (the plain light-sample kernel walks the list of live items; the parked forms list their live RAYS themselves, the measurement forms read every item)
-#ifndef PT_EXPERIMENTS
     rp.live_list = ((trav_form == PT_FORM_SWEEP || trav_form == PT_FORM_WALK || trav_form == PT_FORM_ANY) && shade_form == PT_SHADE_LEAN && !(tn.flags & PT_TUNE_NO_LIVE_LIST)) ? 1u : 0u;
+#ifdef PT_EXPERIMENTS
+    // a measurement build runs the shipped kernel pair unless one of its own forms is asked for: those read every item of a segment
+    if (cfg.live_lists || getenv("PT_AMD_EXP_SHADOW")) rp.live_list = 0u;
 #endif
     cfg.fuse = !(tn.flags & PT_TUNE_NO_FUSE) && (!hero || PT_FUSE_HERO) && trav_form == PT_FORM_SWEEP && shade_form == PT_SHADE_LEAN && (cfg.lacks & PT_SCENE_NO_XF) != 0;
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
@@ -464,6 +466,8 @@ static pt_status scene_to_device(pt_scene* sc) {
     if (tn.flags & PT_TUNE_NO_SWEEP) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_SWEEP;
     if (tn.flags & PT_TUNE_NO_MESH_SWEEP) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_MESH_SWEEP;
     if (tn.flags & PT_TUNE_NO_KNOWN_LIGHT) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_KNOWN_LIGHT;
+    if (tn.flags & PT_TUNE_NO_ONE_LIGHT) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_ONE_LIGHT;
+    if (sc->host.blob[PT_HDR_LIGHT_COUNT] > tuned(tn.light_prepass_max, kLightPrepassMax)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_LIGHT_PREPASS;
     sc->blob_words = (uint32_t)sc->host.blob.size();
     {   // no instance carries a transform (the Cornell box): the forms without the matrix paths (PT_AMD_GENERAL_FORMS=1 keeps the general ones)
         bool any_xf = false;
@@ -485,7 +489,7 @@ static pt_status scene_to_device(pt_scene* sc) {
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE, hipGetErrorString(e));
     if (sc->lds_mode != PT_LDS_NONE) {
         e = allow_lds_extend(kParkBlobLimitBytes);
-        if (e == hipSuccess) e = allow_lds_shade(kLdsBlobLimitBytes + 32768u);   // (+ the importance map's marginal tables behind the blob, FULL form: up to 2730 rows)
+        if (e == hipSuccess) e = allow_lds_shade(kLdsBlobLimitBytes > PT_SHADE_LDS_BUDGET ? kLdsBlobLimitBytes : PT_SHADE_LDS_BUDGET);   // (the FULL form's marginal tables ride behind the blob only within PT_SHADE_LDS_BUDGET)
         // (the parked light-sample kernels keep their waves' lists of live rays behind the blob: up to 16 waves x (64 L + 64) words)
         if (e == hipSuccess) e = allow_lds_shadow(kParkBlobLimitBytes + 16u * (64u * PT_MAX_LIGHT_SAMPLES + 64u) * 4u);
         if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
@@ -503,10 +507,8 @@ void pt_tuning_default(pt_tuning* t) {
 #endif
 
         {"PT_AMD_EXACT_SLAB", PT_TUNE_EXACT_SLAB}, {"PT_AMD_NO_CULL", PT_TUNE_NO_CULL}, {"PT_AMD_NO_SWEEP", PT_TUNE_NO_SWEEP}, {"PT_AMD_NO_MESH_SWEEP", PT_TUNE_NO_MESH_SWEEP},
-        {"PT_AMD_NO_KNOWN_LIGHT", PT_TUNE_NO_KNOWN_LIGHT}, {"PT_AMD_GENERAL_FORMS", PT_TUNE_GENERAL_FORMS}, {"PT_AMD_NO_FUSE", PT_TUNE_NO_FUSE}, {"PT_AMD_MULTI_RCCL", PT_TUNE_MULTI_RCCL}, {"PT_AMD_NO_AXIS_SCAN", PT_TUNE_NO_AXIS_SCAN},
-#ifndef PT_EXPERIMENTS
+        {"PT_AMD_NO_KNOWN_LIGHT", PT_TUNE_NO_KNOWN_LIGHT}, {"PT_AMD_GENERAL_FORMS", PT_TUNE_GENERAL_FORMS}, {"PT_AMD_NO_FUSE", PT_TUNE_NO_FUSE}, {"PT_AMD_MULTI_RCCL", PT_TUNE_MULTI_RCCL}, {"PT_AMD_NO_AXIS_SCAN", PT_TUNE_NO_AXIS_SCAN}, {"PT_AMD_NO_ONE_LIGHT", PT_TUNE_NO_ONE_LIGHT},
         {"PT_AMD_NO_LIVE_LIST", PT_TUNE_NO_LIVE_LIST},
-#endif
     };
     for (const auto& f : flags) if (env_u32(f.name, 0)) t->flags |= f.bit;
     if (env_u32("PT_AMD_STAGE_TIMING", 1) == 0) t->flags |= PT_TUNE_NO_STAGE_TIMING;
@@ -520,6 +522,7 @@ void pt_tuning_default(pt_tuning* t) {
     t->walk_evict_below = env_u32("PT_AMD_WALK_EVICT_BELOW", 0);
     t->walk_search_below = env_u32("PT_AMD_WALK_SEARCH_BELOW", 0);
     t->park_block = env_u32("PT_AMD_PARK_BLOCK", 0);
+    t->light_prepass_max = env_u32("PT_AMD_LIGHT_PREPASS_MAX", 0);
 }
 
 pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
@@ -784,7 +787,11 @@ pt_status pt_intersect(pt_scene* sc, size_t n, const float* origins, const float
 pt_status pt_camera_samples(pt_scene* sc, const pt_render_desc* rdp, size_t n, const uint32_t* pixel, const uint32_t* sample, float* origins, float* directions, float* lambda) {
     if (!sc || !rdp || !pixel || !sample || !origins || !directions || !lambda) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     if (rdp->width == 0 || rdp->height == 0 || rdp->camera_index >= sc->host.cameras.size()) return fail(PT_ERR_INVALID_ARGUMENT, "width, height must be positive, camera_index in range");
-    for (size_t i = 0; i < n; ++i) if (pixel[i] >= rdp->width * rdp->height) return fail(PT_ERR_INVALID_ARGUMENT, "pixel id out of range");
+    if (!(rdp->wavelength_hi >= rdp->wavelength_lo)) return fail(PT_ERR_INVALID_ARGUMENT, "wavelength_hi must not be below wavelength_lo");
+    if (n > 0xffffffffull) return fail(PT_ERR_INVALID_ARGUMENT, "at most 2^32 - 1 samples per call");
+    const uint64_t n_pixels = (uint64_t)rdp->width * (uint64_t)rdp->height;   // (64-bit: a 32-bit product wraps for big films and lets ids through)
+    if (n_pixels > 0xffffffffull) return fail(PT_ERR_INVALID_ARGUMENT, "width x height must fit a 32-bit pixel id");
+    for (size_t i = 0; i < n; ++i) if ((uint64_t)pixel[i] >= n_pixels) return fail(PT_ERR_INVALID_ARGUMENT, "pixel id out of range");
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(sc->device));
     RenderParams rp;

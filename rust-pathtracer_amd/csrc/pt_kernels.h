@@ -198,6 +198,7 @@ __device__ __forceinline__ void stage_marginal(SceneView& s, const uint32_t* __r
     const uint32_t rows = blob[PT_HDR_IMAP_ROWS], stride = blob[PT_HDR_IMAP_STRIDE];
     if (blob[PT_HDR_ENV_KIND] != PT_ENV_HDR || rows == 0u || rows > PT_MARG_LDS_MAX_ROWS || stride != 2u) return;
     const uint32_t used = USE_LDS == PT_LDS_ALL ? blob_words : (USE_LDS == PT_LDS_CORE ? blob[PT_HDR_CORE_WORDS] : 0u);
+    if (((used + 3u) & ~3u) * 4u + PT_MARG_LDS_BYTES(rows, blob[PT_HDR_IMAP_MARG_GUIDE] != 0u) > PT_SHADE_LDS_BUDGET) return;   // (marginal_lds_bytes gave 0: nothing was reserved)
     float* dst = reinterpret_cast<float*>(lds + ((used + 3u) & ~3u));
     const uint32_t a = blob[PT_HDR_IMAP_MARG_PDF], b = blob[PT_HDR_IMAP_MARG_CMF], base = a < b ? a : b, pairs = 2u * rows, mg = blob[PT_HDR_IMAP_MARG_GUIDE];
     for (uint32_t i = threadIdx.x; i < pairs; i += blockDim.x) dst[i] = s.tex[base + i];

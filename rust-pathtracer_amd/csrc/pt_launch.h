@@ -21,6 +21,7 @@ constexpr uint32_t kLdsAllLimitBytes = 24 * 1024;
 // 512 per CU are four waves per SIMD, and 2 x (72 KB + the waves' lists of live rays) fit the CU's 160 KB.  The gem scene of C3: 66 256 B.
 constexpr uint32_t kParkBlobLimitBytes = 72 * 1024;
 constexpr uint32_t kParkCap = 512, kParkFields = 16;
+constexpr uint32_t kLightPrepassMax = 16;   // pt_tuning::light_prepass_max's default: the most lights whose boxes a light-sample ray tests one by one for its bound
 constexpr uint32_t kWalkEvictBelow = 32, kWalkSearchBelow = 16;   // pt_tuning::walk_evict_below's and walk_search_below's defaults
 enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_MEDIUM_DROPS, BS_FIELDS };  // per-workgroup statistics (Profile counters)
 #ifdef PT_EXPERIMENTS
@@ -37,10 +38,12 @@ struct LaunchCfg { int grid; uint32_t lds_bytes; hipStream_t stream; int lds_mod
                    bool fuse = false; };  // k_shade traces its own segments (pure sweep scenes, lean form, no transforms): no k_extend launch, no hit queue
 struct SceneArgs { const uint32_t* blob; uint32_t blob_words; const float* tex; uint32_t marg_bytes = 0; /* LDS the FULL vertex form takes behind the blob (marginal_lds_bytes) */ };
 // The importance map's marginal tables as k_shade's FULL form stages them (pt_kernels.h stage_marginal): 2 x rows floats + the guide's rows + 3 words, only for the interleaved layout.
-inline uint32_t marginal_lds_bytes(const uint32_t* host_blob) {
+// `staged_bytes`: what the kernel stages of the blob (all of it, its core, nothing).  0 = the tables stay in L2 (no importance map, too many rows, or no room: PT_SHADE_LDS_BUDGET).
+inline uint32_t marginal_lds_bytes(const uint32_t* host_blob, uint32_t staged_bytes) {
     const uint32_t rows = host_blob[PT_HDR_IMAP_ROWS];
     if (host_blob[PT_HDR_ENV_KIND] != PT_ENV_HDR || rows == 0u || rows > PT_MARG_LDS_MAX_ROWS || host_blob[PT_HDR_IMAP_STRIDE] != 2u) return 0u;
-    return (2u * rows + (host_blob[PT_HDR_IMAP_MARG_GUIDE] ? rows + 3u : 0u)) * 4u + 16u;
+    const uint32_t bytes = PT_MARG_LDS_BYTES(rows, host_blob[PT_HDR_IMAP_MARG_GUIDE] != 0u);
+    return ((staged_bytes + 15u) & ~15u) + bytes <= PT_SHADE_LDS_BUDGET ? bytes : 0u;
 }
 
 void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, ptd::Queue paths, ptd::Queue hits, uint32_t seg_cap, const uint32_t* count_in, uint32_t* park);

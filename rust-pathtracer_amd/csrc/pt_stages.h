@@ -268,7 +268,8 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
             Frame fr2 = frame_from_normal(hn);
             F3 wi2 = to_local(fr2, normalize(sub(pv.prev_p, hit.p)));
             // (the light-sample rays of a scene with one light are tested against it here — below — unless the scene forbids the light bound)
-            const bool one_light = n_lights == 1u && !(bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_CULL));
+            // (the shortcut below is legal exactly where shadow_light_bound takes its bound from nearest_light_hit: the same flags)
+            const bool one_light = n_lights == 1u && !(bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_LIGHT_PREPASS | PT_FLAG_NO_CULL | PT_FLAG_NO_ONE_LIGHT));
             EnvCurves ec[NL];  // the environment's spectral weights at this vertex' wavelengths, for all its light samples
             for (int k = 0; k < NL; ++k) ec[k] = (ENV && env_p > 0.0f) ? env_curves(s, lam[k]) : EnvCurves{{0.0f, 0.0f, 0.0f, 0.0f}, false};
             for (uint32_t l = 0; l < rp.light_samples; ++l) {
@@ -328,11 +329,10 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                         // item whose rays are all dead is never read (Layout::shadow_live_field).  In the Cornell box that is every vertex on the
                         // ceiling: its rays start, after the normal offset, BELOW the lamp that hangs 1e-4 under it — 16 % of C2's items.
                         if (PT_ONE_LIGHT_FORMS && one_light) {
-                            const uint32_t linst = bu(s, PT_HDR_INSTANCE_OFF) + light_id * PT_INST_WORDS;
-                            F3 l0, l1;
-                            instance_local_ray(s, linst, ray.o, ray.d, &l0, &l1);
+                            // (light_shape_hit: the very call nearest_light_hit makes per light — it kills a SUBSET of what the light-sample kernel
+                            // would drop, which runs the light's box test first; PT_AMD_NO_ONE_LIGHT switches this off and the GPU tests compare the two)
                             Hit lh;
-                            if (!analytic_hit(s, linst, bu(s, linst + PT_INST_KIND), l0, l1, PT_INF, &lh)) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
+                            if (!light_shape_hit(s, bu(s, PT_HDR_INSTANCE_OFF) + light_id * PT_INST_WORDS, ray.o, ray.d, &lh)) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
                         }
                     }
                 }
@@ -579,13 +579,13 @@ PT_HD void shadow_ray_contribution(const SceneView& s, LambdaOf&& lambda_of, con
 // when the scene forbids the shortcut.  Returns false when the ray cannot contribute.
 PT_HD bool shadow_light_bound(const SceneView& s, F3 o, F3 d, float* bound, int* stop, uint32_t* light = nullptr) {
     if (light != nullptr) *light = 0xffffffffu;
-    if (bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_CULL)) { *bound = PT_INF; *stop = PT_STOP_NONE; return true; }
+    if (bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_LIGHT_PREPASS | PT_FLAG_NO_CULL)) { *bound = PT_INF; *stop = PT_STOP_NONE; return true; }
     float t_light = nearest_light_hit(s, o, d, light);
     if (light != nullptr && (bu(s, PT_HDR_FLAGS) & PT_FLAG_NO_KNOWN_LIGHT)) *light = 0xffffffffu;
     *bound = t_light; *stop = PT_STOP_NONLIGHT;
     return t_light < PT_INF;
 }
-PT_HD int shadow_light_stop(const SceneView& s) { return (bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_CULL)) ? PT_STOP_NONE : PT_STOP_NONLIGHT; }   // (the stop rule shadow_light_bound sets)
+PT_HD int shadow_light_stop(const SceneView& s) { return (bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_LIGHT_PREPASS | PT_FLAG_NO_CULL)) ? PT_STOP_NONE : PT_STOP_NONLIGHT; }   // (the stop rule shadow_light_bound sets)
 PT_HD int shadow_env_stop(const SceneView& s) { return (bu(s, PT_HDR_FLAGS) & PT_FLAG_NO_CULL) ? PT_STOP_NONE : PT_STOP_ANY; }
 // One light-sample ray: a light ray (pt.rs:171-217) or an environment ray (pt.rs:252-330, contributes only if nothing is hit: any hit
 // blocks it, so its search ends at the first one; PT_AMD_NO_CULL keeps the full search).  One search call site for both kinds — a

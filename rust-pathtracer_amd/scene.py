@@ -413,6 +413,9 @@ def add_library_material(b, name):
     if name == "diffuse_light_cornell":
         add_library_curves(b, ["cornell_light", "flat_78"])
         return b.material_diffuse_light(name, b.curve("cornell_light"), b.curve("flat_78"), api.SIDED_REVERSE)
+    if name == "diffuse_light":                 # data/lib_materials.toml:306-310
+        add_library_curves(b, ["blackbody_5000k", "flat_78"])
+        return b.material_diffuse_light(name, b.curve("blackbody_5000k"), b.curve("flat_78"), api.SIDED_DUAL)
     if name == "diffuse_light_flat_x5":
         add_library_curves(b, ["E5", "flat_78"])
         return b.material_diffuse_light(name, b.curve("E5"), b.curve("flat_78"), api.SIDED_DUAL)
@@ -810,6 +813,52 @@ def test_prism_small():
     return test_prism(hdri_size=(64, 32), importance=(32, 32))
 
 
+def test_bokeh(hdri_size=(1024, 512), importance=(1024, 1024), lights_per_row=41):
+    """data/scenes/test_bokeh.toml of the reference tree (G2): two rows of 41 sphere lights of radius 0.01 (`diffuse_light`: blackbody 5000 K, Dual) at x = -0.5 / +0.5,
+    y = -20 .. 20, z = 0, seen through a wide thin lens (aperture_diameter 0.1, focal_distance 5) under an HDRI of strength 0.1 with env_sampling_probability 0.5 —
+    its `autumn_park_8k` file is absent from the tree, so the synthetic HDRI of C4 stands in.  82 instances > 64: no leaf-sweep table, so every ray takes
+    the TOP-LEVEL BVH WALK (src/accelerator/lbvh.rs:172-213, mod.rs:86-178) and a light sample picks one of 82 lights (world/mod.rs:100-124).  The scene file's
+    Bladed aperture is sampled as circular."""
+    b = SceneBuilder()
+    add_library_curves(b, ["srgb_r", "srgb_g", "srgb_b", "flat_zero"])
+    ts = b.texstack_texture4("synthetic_hdri", [b.curve("srgb_r"), b.curve("srgb_g"), b.curve("srgb_b"), b.curve("flat_zero")], synthetic_hdri(*hdri_size))
+    b.set_environment_hdr(ts, 0.1, importance=importance)
+    b.env_sampling_probability = 0.5
+    light = add_library_material(b, "diffuse_light")
+    half = lights_per_row // 2
+    for x in (-0.5, 0.5):                       # file order: the x = -0.5 row first, y ascending
+        for k in range(-half, half + 1):
+            b.add_sphere(0.01, (x, float(k), 0.0), light)
+    b.add_camera((0.0, -5.0, 0.5), (0.0, 0.0, 0.2), 45.0, focal_distance=5.0, aperture_diameter=0.1)
+    return b
+
+
+def test_bokeh_small():
+    """test_bokeh with a small HDRI / importance map, for parity tests (still 82 instances: the top-level walk)."""
+    return test_bokeh(hdri_size=(64, 32), importance=(32, 32))
+
+
+def test_bokeh_floor(hdri_size=(1024, 512), importance=(1024, 1024)):
+    """NOT a reference scene: test_bokeh with a white Lambertian floor 0.05 under the lights and three non-emissive spheres on it.  In test_bokeh itself every
+    surface is a light — a light vertex takes no light samples (pt.rs:512-561), so its renders never trace a light-sample ray; with the floor the 82-entry
+    light list is sampled at every floor vertex and the light-sample rays take the top-level walk too (G2F of DESIGN section 6)."""
+    b = test_bokeh(hdri_size, importance)
+    cam = b.cameras.pop()
+    white = add_library_material(b, "lambertian_white")
+    glass = add_library_material(b, "ggx_glass_rough")
+    gold = add_library_material(b, "ggx_gold")
+    b.add_rect((60.0, 60.0), (0.0, 0.0, -0.05), "Z", True, white)
+    b.add_sphere(0.15, (0.0, -1.0, 0.1), glass)
+    b.add_sphere(0.12, (-0.3, 0.5, 0.07), gold)
+    b.add_sphere(0.10, (0.35, 1.5, 0.05), white)
+    b.cameras.append(cam)
+    return b
+
+
+def test_bokeh_floor_small():
+    return test_bokeh_floor(hdri_size=(64, 32), importance=(32, 32))
+
+
 def hdri_emissive_mesh():
     """An HDRI environment and a mesh whose *instance* overrides its material with a light (not a reference scene): the mesh is not in the
     light list (world/mod.rs:45-54 looks at analytic instances' ids and mesh face ids only), so the list is empty — yet its hits carry the
@@ -822,6 +871,6 @@ def hdri_emissive_mesh():
     return b
 
 
-SCENES = {"test_prism": test_prism, "test_prism_small": test_prism_small, "hdri_emissive_mesh": hdri_emissive_mesh, "hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
+SCENES = {"test_bokeh_floor": test_bokeh_floor, "test_bokeh_floor_small": test_bokeh_floor_small, "test_bokeh": test_bokeh, "test_bokeh_small": test_bokeh_small, "test_prism": test_prism, "test_prism_small": test_prism_small, "hdri_emissive_mesh": hdri_emissive_mesh, "hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
           "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test, "panorama_test": panorama_test, "empty_env": empty_env,
           "big_sphere_light": big_sphere_light, "disk_lamp": disk_lamp, "fog_ball": fog_ball}

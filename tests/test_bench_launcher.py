@@ -27,8 +27,15 @@ if mode == "fail":
     sys.exit(7)
 if mode == "silent":
     sys.exit(0)
+if mode == "port":   # the launcher lost the race for its master port the first time
+    marker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "port_lost_once")
+    if not os.path.exists(marker):
+        open(marker, "w").close()
+        sys.stderr.write("RuntimeError: The server socket has failed to listen on any local network address. port: 29500, useIpv6: false, code: -98, name: EADDRINUSE\n")
+        sys.exit(1)
 rec = {"metric": "Msamples/s", "value": 123.0, "n_gpus": n if mode != "lies" else 1, "ranks_seen": n if mode != "half" else n - 1, "steps": 2}
-print(json.dumps(rec))
+print(json.dumps({"metric": "a line of JSON that is not the record", "n_gpus": 1}))
+print("PT_BENCH_RECORD " + json.dumps(rec))   # (rank 0 marks its record for a bench.py parent)
 print("trailing noise")
 '''
 
@@ -49,8 +56,15 @@ def test_parent_relays_one_record(tmp_path):
     assert len(lines) == 1, r.stdout                        # ONE line of stdout: the record
     d = json.loads(lines[0])
     assert d["n_gpus"] == 4 and d["ranks_seen"] == 4 and d["value"] == 123.0 and "launched_by" in d
-    for noise in ("RCCL version", "{not a record}", "trailing noise", "rank noise"):
+    for noise in ("RCCL version", "{not a record}", "trailing noise", "rank noise", "a line of JSON that is not the record"):
         assert noise in r.stderr and noise not in r.stdout   # everything else the ranks said: stderr
+
+
+def test_parent_starts_again_when_the_master_port_was_taken(tmp_path):
+    """The parent finds a free port by bind-and-close; a launcher that then fails with EADDRINUSE is started again on another port."""
+    r = run_parent(tmp_path, "port")
+    assert r.returncode == 0, r.stderr
+    assert "starting the ranks again" in r.stderr and json.loads(r.stdout.strip())["ranks_seen"] == 4
 
 
 @pytest.mark.parametrize("mode,code", [("lies", 4), ("half", 4), ("fail", 7), ("silent", 3)])

@@ -61,6 +61,8 @@ def test_materials_bit_exact(emu, oracle, scene):
     ("mixed_small", 32, 32, 6, 6, {"hero_wavelengths": 4, "light_samples": 2}),
     ("hdri_small", 32, 32, 8, 4, {"light_samples": 6}),       # C4 shape: HDR environment, importance map, env NEE + MIS
     ("hdri_small", 24, 24, 4, 4, {"light_samples": 8}),       # the most light samples an item can hold
+    ("test_bokeh_small", 48, 48, 6, 8, {"light_samples": 2}),      # G2: 82 instances, no sweep table — the top-level walk
+    ("test_bokeh_floor_small", 48, 40, 6, 8, {"light_samples": 3}),
     ("test_prism_small", 40, 40, 6, 8, {"light_samples": 3}),     # the reference tree's test_prism.toml: transform stack + lights + environment sampling — the general kernel forms
     ("hdri_emissive_mesh", 32, 32, 6, 4, {"light_samples": 3}),   # empty light list, but a mesh instance overridden with a light material: its hits emit
     ("disk_lamp", 40, 28, 6, 5, {"light_samples": 2, "seed": 2}),   # one disk lamp: the lean form's light test at the vertex (the ceiling's rays start below the lamp), the list of live items
@@ -121,6 +123,23 @@ def test_leaf_sweep_equals_bvh_walk(emu, pkg, monkeypatch, scene):
         ps.assert_hits_equal(hits, results[0][0])
         assert np.array_equal(film.view(np.uint32), results[0][1].view(np.uint32))
         assert counts == results[0][2]
+
+
+@pytest.mark.parametrize("scene,L,hero", [("test_bokeh_floor_small", 3, 1), ("test_bokeh_floor_small", 2, 4), ("mixed_primitives", 3, 1), ("cornell_box", 2, 1), ("test_prism_small", 2, 1)])
+def test_light_prepass_changes_nothing(emu, pkg, monkeypatch, scene, L, hero):
+    """A light-sample ray is bounded by the nearest hit among all lights before it is traced (few lights: the early stop at the first occluder) or traced as a
+    plain closest-hit search (blob flag 1024 = PT_FLAG_NO_LIGHT_PREPASS, what a scene with more lights than pt_tuning::light_prepass_max gets): the same film
+    and counters, with and without the sweep table (16) and the parked protocol (144)."""
+    b = pkg.scene.SCENES[scene]()
+    rd = pkg.api.render_desc(40, 32, 6, 6, light_samples=L, seed=11, hero_wavelengths=hero)
+    results = []
+    for flags in ("0", "1024", "1040", "1168"):
+        monkeypatch.setenv("PTEMU_FLAGS", flags)
+        film, prof = emu.create_scene(b).render(rd)
+        results.append((film, (prof.camera_rays, prof.bounce_rays, prof.shadow_rays, prof.env_hits)))
+    for film, counts in results[1:]:
+        assert np.array_equal(film.view(np.uint32), results[0][0].view(np.uint32))
+        assert counts == results[0][1]
 
 
 def test_reference_known_answers_on_the_lane_logic(emu, oracle, pkg):
