@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--light-samples", type=int, default=2)
     ap.add_argument("--scene", default="cornell_box")
     ap.add_argument("--min-bounces", type=int, default=1)
+    ap.add_argument("--env-sampling-probability", type=float, default=None, help="override the scene's env_sampling_probability (as the reference's config file can)")
     ap.add_argument("--hero", type=int, default=1, help="wavelengths per path: 1, or 4 for the hero-wavelength variant (C5)")
     ap.add_argument("--workload", default=None, help="label for config.workload (default: derived from the arguments)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline (0 = skip)")
@@ -232,6 +233,8 @@ def main():
     engine = pkg.load()
     t_create = time.perf_counter()
     builder = pkg.scene.SCENES[args.scene]()
+    if args.env_sampling_probability is not None:   # (the config file's override of the scene's value: TOMLConfig::env_sampling_probability, src/parsing/config.rs:125-130)
+        builder.env_sampling_probability = args.env_sampling_probability
     scene = engine.create_scene(builder)
     scene_create_ms = 1e3 * (time.perf_counter() - t_create)
 
@@ -358,7 +361,7 @@ def main():
         # (profiles/<tag>_summary.json, tools/profile_gpu.sh): (2 x FETCH_SIZE + WRITE_SIZE) KiB — FETCH_SIZE reads 1/2 of a
         # coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact (calibrated on k_generate's 68 B/item).
         # Only a profile taken on exactly this workload counts (every key below must match); otherwise the fields stay null.
-        workload_key = {"scene": args.scene, "width": W, "height": H, "max_bounces": args.max_bounces, "min_bounces": args.min_bounces,
+        workload_key = {**({"env_sampling_probability": args.env_sampling_probability} if args.env_sampling_probability is not None else {}), "scene": args.scene, "width": W, "height": H, "max_bounces": args.max_bounces, "min_bounces": args.min_bounces,
                         "light_samples": L, "hero": args.hero, "spp_per_step": S, "n_gpus": n_gpus}
         traffic, traffic_src, valu = None, None, None
         try:

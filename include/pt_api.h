@@ -274,7 +274,10 @@ typedef struct pt_tuning {
     uint32_t light_prepass_max;   /* PT_AMD_LIGHT_PREPASS_MAX: a light-sample ray aimed at a light is bounded by the nearest hit among ALL lights before it is traced (one box
                                      test per light and ray: it buys the early stop at the first occluder).  A scene with more lights than this traces such a ray as a
                                      plain closest-hit search instead (test_bokeh.toml: 82 lights).  0 = the default (16); 0xffffffff = always bound */
-    uint32_t reserved[4];         /* must be 0 */
+    uint32_t top_evict_below;     /* PT_AMD_TOP_EVICT_BELOW: scenes without a sweep table (more than 64 instances) walk the top-level tree lane by lane; once fewer lanes
+                                     of a wave than this are still walking, those leave with their place, are parked like a ray at a mesh and go on in a later wave of 64
+                                     such rays.  1 = never, at most 64; 0 = the default (32 for a scene of more than 64 instances without a mesh, else never) */
+    uint32_t reserved[3];         /* must be 0 */
 } pt_tuning;
 /* The defaults, overridden by whatever PT_AMD_* variables the environment holds at the time of the call. */
 void pt_tuning_default(pt_tuning* tuning);

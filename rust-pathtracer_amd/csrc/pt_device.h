@@ -1303,67 +1303,92 @@ PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, S
 // (which is also what mesh_walk's early stop leaves there).  Same boxes, same instances, same order as world_hit_walk: the top level in
 // pre-order with the same test and the same culling, every mesh through mesh_walk against the running closest hit.
 PT_HD void top_walk_init(SweepState& st) { sweep_state_init(st, 1ull); }
-// from the state's place on; true = parked at a mesh instance (the place is that instance's leaf; `park_at_mesh` false: meshes in line)
-PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, bool park_at_mesh) {
+// A ray's place in a parked entry's cursor word when it was EVICTED from the top-level walk (below) rather than parked at a mesh: no mesh walk to finish first.
+#define PT_TOP_EVICTED 0xffffffffu
+#ifndef PT_TOP_WALK_BOX
+#define PT_TOP_WALK_BOX 1   /* the box test of a top-level step as data flow (walk_box, the mesh walk's) instead of the per-lane nest of aabb_hit_node: round 5 */
+#endif
+// from the state's place on; true = parked: at a mesh instance (the place is that instance's leaf; `park_at_mesh` false: meshes in line; *evicted false), or —
+// round 5 — EVICTED (*evicted true, the place is the next node): the walks of a wave's 64 rays differ in length by an order of magnitude (test_bokeh.toml + a floor:
+// 32 steps on average, 124 for the slowest lane of a wave), so once fewer than `evict_below` lanes of the wave are still walking, those leave with their place,
+// are parked like a ray at a mesh and go on in a later wave of 64 such rays (the mesh walk's policy, mesh_walk: pt_tuning::walk_evict_below).  A ray's own
+// sequence of tests is the same; the emulation's one lane leaves at every chance.  0 = never.
+PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, bool park_at_mesh, uint32_t evict_below = 0u, bool* evicted = nullptr) {
     const uint32_t flags = bu(s, PT_HDR_FLAGS);
     const uint32_t top_off = bu(s, PT_HDR_TOP_NODE_OFF), top_count = bu(s, PT_HDR_TOP_NODE_COUNT), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
     const bool cull_top = (flags & (PT_FLAG_NO_TOP_CULL | PT_FLAG_NO_CULL)) == 0;
     RayPrep wr = ray_prepare(o, d);
     if (flags & PT_FLAG_EXACT_SLAB) wr.fast = false;
     const bool wr_quick = wr.fast && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f;
+    if (evicted != nullptr) *evicted = false;
     if (st.hit == 0) return false;
     uint32_t i = (uint32_t)st.hit - 1u;
     while (i < top_count) {
         const F4 a = bf4(s, top_off + i * PT_NODE_WORDS), b = bf4(s, top_off + i * PT_NODE_WORDS + 4);
         const uint32_t exit_i = PT_NODE_EXIT(pt_f2u(a.w)), shape = pt_f2u(b.w);
         float entry;
+#if PT_TOP_WALK_BOX
+        const bool box = walk_box(a, b, wr, wr_quick, &entry) & !(cull_top & !(pt_f2u(a.w) & PT_NODE_NO_CULL) & beyond(entry, __builtin_fminf(st.closest, bound), wr.base));
+#else
         const bool box = aabb_hit_node(a, b, wr, wr_quick, &entry) && !(cull_top && !(pt_f2u(a.w) & PT_NODE_NO_CULL) && beyond(entry, __builtin_fminf(st.closest, bound), wr.base));
-        if (shape == PT_NODE_INNER) { i = box ? i + 1 : exit_i; continue; }
-        if (!box) { i = exit_i; continue; }
-        const uint32_t inst = inst_off + shape * PT_INST_WORDS, kind = bu(s, inst + PT_INST_KIND);
-        if (kind == PT_SHAPE_MESH) {
-            if (park_at_mesh) { st.hit = (uint64_t)i + 1ull; return true; }
-            st.hit = (uint64_t)exit_i + 1ull;
-            mesh_walk(s, inst, shape, o, d, bound, stop, st);
-            if (st.hit == 0) return false;   // (an early stop inside the mesh)
-            i = exit_i;
-            continue;
-        }
-        i = exit_i;
-        F3 lo, ld;
-        instance_local_ray(s, inst, o, d, &lo, &ld);
-        Hit h;
-        if (analytic_hit(s, inst, kind, lo, ld, st.closest, &h)) {
-            st.closest = h.t; st.best_inst = shape; st.best_triw = 0;
-            bool over = stop == PT_STOP_ANY;
-            if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
-                const uint32_t im = bu(s, inst + PT_INST_MATERIAL);
-                over = PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : h.material) != PT_TAG_LIGHT;   // something opaque in front of every light
+#endif
+        if (shape == PT_NODE_INNER || !box) i = (shape == PT_NODE_INNER && box) ? i + 1 : exit_i;
+        else {
+            const uint32_t inst = inst_off + shape * PT_INST_WORDS, kind = bu(s, inst + PT_INST_KIND);
+            if (kind == PT_SHAPE_MESH) {
+                if (park_at_mesh) { st.hit = (uint64_t)i + 1ull; return true; }
+                st.hit = (uint64_t)exit_i + 1ull;
+                mesh_walk(s, inst, shape, o, d, bound, stop, st);
+                if (st.hit == 0) return false;   // (an early stop inside the mesh)
+                i = exit_i;
+            } else {
+                i = exit_i;
+                F3 lo, ld;
+                instance_local_ray(s, inst, o, d, &lo, &ld);
+                Hit h;
+                if (analytic_hit(s, inst, kind, lo, ld, st.closest, &h)) {
+                    st.closest = h.t; st.best_inst = shape; st.best_triw = 0;
+                    bool over = stop == PT_STOP_ANY;
+                    if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
+                        const uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+                        over = PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : h.material) != PT_TAG_LIGHT;   // something opaque in front of every light
+                    }
+                    if (over) { st.hit = 0; return false; }
+                }
             }
-            if (over) { st.hit = 0; return false; }
         }
+        // (behind a step, so that a resumed ray always moves on; a ray on its last node is not worth a parked entry)
+        if (evict_below != 0u && i < top_count && PT_WAVE_ACTIVE(0u) < evict_below) { st.hit = (uint64_t)i + 1ull; *evicted = true; return true; }
     }
     st.hit = 0;
     return false;
 }
 // A parked lane: the mesh it stands at (mesh_walk with the wave's policy; true = evicted from it, the place unchanged and `*cursor` where the
-// walk goes on), then the top level from behind that instance (true = parked at the next mesh).
+// walk goes on), then the top level from behind that instance (true = parked at the next mesh, or evicted from the top-level walk: *cursor = PT_TOP_EVICTED,
+// and such a ray has no mesh to finish when it is resumed).
 template <bool SPEC = false>
 PT_HD bool top_walk_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, uint32_t* cursor, uint32_t policy, bool alive) {
     const uint32_t top_off = bu(s, PT_HDR_TOP_NODE_OFF), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
-    const uint32_t at = alive ? (uint32_t)st.hit - 1u : 0u;
-    const F4 a = bf4(s, top_off + at * PT_NODE_WORDS), b = bf4(s, top_off + at * PT_NODE_WORDS + 4);
-    uint32_t shape = pt_f2u(b.w);
-    {   // (a lane that only helps: with the instance of the first lane that has a ray — broadcast in uniform control flow, see sweep_resume)
-        const uint32_t lead = PT_WAVE_READ(shape, ctz64(PT_WAVE_BALLOT(alive)));
-        shape = alive ? shape : lead;
+    const bool at_mesh = alive && *cursor != PT_TOP_EVICTED;
+    const uint64_t mesh_lanes = PT_WAVE_BALLOT(at_mesh);
+    if (mesh_lanes != 0ull) {   // (wave-uniform: a wave of rays that were all evicted from the top level — every wave of a scene without meshes — has no mesh walk)
+        const uint32_t at = at_mesh ? (uint32_t)st.hit - 1u : 0u;
+        const F4 a = bf4(s, top_off + at * PT_NODE_WORDS), b = bf4(s, top_off + at * PT_NODE_WORDS + 4);
+        uint32_t shape = pt_f2u(b.w);
+        {   // (a lane that only helps: with the instance of the first lane that stands at a mesh — broadcast in uniform control flow, see sweep_resume)
+            const uint32_t lead = PT_WAVE_READ(shape, ctz64(mesh_lanes));
+            shape = at_mesh ? shape : lead;
+        }
+        const uint64_t place = st.hit;
+        if (at_mesh) st.hit = (uint64_t)PT_NODE_EXIT(pt_f2u(a.w)) + 1ull;
+        if (mesh_walk<SPEC>(s, inst_off + shape * PT_INST_WORDS, shape, o, d, bound, stop, st, cursor, policy, at_mesh)) { st.hit = place; return true; }
     }
-    const uint64_t place = st.hit;
-    st.hit = (uint64_t)PT_NODE_EXIT(pt_f2u(a.w)) + 1ull;
-    if (mesh_walk<SPEC>(s, inst_off + shape * PT_INST_WORDS, shape, o, d, bound, stop, st, cursor, policy, alive)) { st.hit = place; return true; }
     if (!alive) return false;
     *cursor = 0u;
-    return top_walk_run(s, o, d, bound, stop, st, true);
+    bool evicted = false;
+    const bool parked = top_walk_run(s, o, d, bound, stop, st, true, (policy >> 24) & 0xffu, &evicted);
+    if (evicted) *cursor = PT_TOP_EVICTED;
+    return parked;
 }
 
 PT_HD bool sweep_finish(const SceneView& s, F3 o, F3 d, const SweepState& st, Hit* out) {
@@ -1682,8 +1707,10 @@ PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_
         SweepState st;
         top_walk_init(st);
         uint32_t cursor = 0u;
-        bool parked = top_walk_run(s, o, d, bound, stop, st, true);
-        while (parked) parked = top_walk_resume(s, o, d, bound, stop, st, &cursor, 0x201u | PT_WALK_SCAN_AXIS, true);
+        bool evicted = false;
+        bool parked = top_walk_run(s, o, d, bound, stop, st, true, 1u, &evicted);   // (evict_below 1 against the emulation's 0 active lanes: the ray leaves after every step)
+        if (evicted) cursor = PT_TOP_EVICTED;
+        while (parked) parked = top_walk_resume(s, o, d, bound, stop, st, &cursor, 0x01000201u | PT_WALK_SCAN_AXIS, true);
         if (LIGHT_ONLY && st.best_inst != 0xffffffffu && !sweep_best_is_light(s, st)) { out->valid = true; out->material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); return true; }
         return sweep_finish(s, o, d, st, out);
     }

@@ -154,7 +154,7 @@ struct pt_scene {
 };
 
 namespace {
-// whether any instance of the flattened scene is a mesh (the parked kernels' scratch is only allocated for scenes that can park)
+// whether any instance of the flattened scene is a mesh (a scene without one never parks at a mesh: its top-level walks are the ones worth leaving early)
 bool scene_has_mesh(const std::vector<uint32_t>& blob) {
     const uint32_t off = blob[PT_HDR_INSTANCE_OFF], n = blob[PT_HDR_INSTANCE_COUNT];
     for (uint32_t i = 0; i < n; ++i) if (blob[off + i * PT_INST_WORDS + PT_INST_KIND] == (uint32_t)PT_SHAPE_MESH) return true;
@@ -196,9 +196,11 @@ pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples
         b.nl = nlmax;
         HIP_TRY(hipMalloc(&b.counts, sizeof(uint32_t) * 4 * (size_t)grid));   // (live paths x 2, light-sample items, live light-sample items)
         HIP_TRY(hipMalloc(&b.block_stats, sizeof(unsigned long long) * BS_FIELDS * (size_t)grid));
-        // (the parked kernels' scratch: scenes whose sweep table holds walked meshes, and scenes without a sweep table that hold a mesh)
+        // (the parked kernels' scratch: scenes whose sweep table holds walked meshes, and every scene without a sweep table — with or without a mesh: the parked
+        // kernels over the top-level tree list their live rays and run at five / four waves per SIMD, and beat the per-lane walk kernels even where no ray ever
+        // parks: test_bokeh.toml + a floor, k_extend 1265 -> 693 us, k_shadow 5948 -> 2887 us, profiles/r5_experiments.md section 1)
         const bool no_table = sc->host.blob[PT_HDR_SWEEP_OFF] == 0 || (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP);
-        if ((sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) || (no_table && scene_has_mesh(sc->host.blob)))
+        if ((sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) || no_table)
             HIP_TRY(hipMalloc(&b.park, sizeof(uint32_t) * kParkFields * (kParkCap / (kBlock / 64)) * (park_block / 64) * (size_t)grid));   // (128 entries per wave)
         b.park_block = park_block;
         if (!b.unit_counters) HIP_TRY(hipMalloc(&b.unit_counters, sizeof(uint32_t) * kUnitCounters));
@@ -276,7 +278,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     // the sweep table holds walked meshes: rays that reach one are parked and resumed in full waves (PT_AMD_NO_PARK=1: in line)
     const bool walks = (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS) != 0;
     const bool parked = sweep && walks && b.park != nullptr && !(tn.flags & PT_TUNE_NO_PARK);
-    // no sweep table (more than 64 instances, PT_AMD_NO_SWEEP) but meshes: the top-level tree per lane, every mesh parked (top_walk_run, pt_device.h)
+    // no sweep table (more than 64 instances, PT_AMD_NO_SWEEP): the top-level tree per lane, every mesh parked (top_walk_run, pt_device.h)
     const bool parked_walk = !sweep && b.park != nullptr && !(tn.flags & PT_TUNE_NO_PARK);
     // PT_AMD_POOL=1: phase 3 of a pure sweep scene pooled per wave (sweep_run_pooled).  Bit-identical, but measured slower than the lane
     // loop on MI355X (C2: k_extend 3155 vs 2475 us, k_shadow 5421 vs 4677 us; DESIGN.md section 5 has the breakdown), so it is not the default.
@@ -302,8 +304,16 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     cfg.live_lists = env_u32("PT_AMD_LIVE_LISTS", 0) != 0;   // (k_shadow_live: a measurement build's kernel, profiles/r4_experiments.md)
 #endif
     if (park_big) { cfg.park_block = (int)park_block; cfg.park_block_extend = (int)park_block_extend; cfg.park_blob_bytes = sc->blob_words * 4u; }
+    // The top-level walk is left early by a wave's last lanes (top_walk_run) where that walk is long and nothing else thins the wave out: a tree of more than 64
+    // instances — the scenes that have no sweep table by themselves — without a mesh (test_bokeh.toml + a floor: k_shadow_parked 2900 -> 2320 us at 32, 2430 at 16 and
+    // at 48).  With a mesh in the scene the lanes of a wave PARK at it, the wave thins out although its rays are not done, and evicting the rest only adds park
+    // traffic: the same scene with the gem standing on the floor 1337 -> 1260 Msamples/s at 32 (1341 at 16); a small scene forced off its table (PT_AMD_NO_SWEEP:
+    // thirteen instances in the gem scene, ten nodes per walk) lost 15 % (profiles/r5_experiments.md section 2).
+    const uint32_t top_evict = tn.top_evict_below ? tn.top_evict_below
+                             : (sc->host.blob[PT_HDR_INSTANCE_COUNT] > PT_SWEEP_MAX_BITS && !scene_has_mesh(sc->host.blob) ? kTopEvictBelow : 1u);
     cfg.walk_policy = (tn.walk_evict_below ? tn.walk_evict_below : kWalkEvictBelow) | (tn.walk_search_below ? tn.walk_search_below : kWalkSearchBelow) << 8
-                    | ((tn.flags & PT_TUNE_NO_AXIS_SCAN) ? 0u : PT_WALK_SCAN_AXIS);
+                    | ((tn.flags & PT_TUNE_NO_AXIS_SCAN) ? 0u : PT_WALK_SCAN_AXIS)
+                    | (top_evict <= 1u ? 0u : top_evict << 24);   // (1 = never: 0 in the policy word)
     const SceneArgs sargs{sc->d_blob, sc->blob_words, sc->d_tex, marginal_lds_bytes(sc->host.blob.data(), lds_bytes)};
     // light samples can pick the environment only if env_sampling_probability > 0: otherwise k_shade is the form without that branch
     float env_prob; std::memcpy(&env_prob, &sc->host.blob[PT_HDR_ENV_PROB], sizeof env_prob);
@@ -523,6 +533,7 @@ void pt_tuning_default(pt_tuning* t) {
     t->walk_search_below = env_u32("PT_AMD_WALK_SEARCH_BELOW", 0);
     t->park_block = env_u32("PT_AMD_PARK_BLOCK", 0);
     t->light_prepass_max = env_u32("PT_AMD_LIGHT_PREPASS_MAX", 0);
+    t->top_evict_below = env_u32("PT_AMD_TOP_EVICT_BELOW", 0);
 }
 
 pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
@@ -536,8 +547,8 @@ pt_status pt_scene_create_tuned(const pt_scene_desc* desc, const pt_tuning* tuni
     for (uint32_t r : tuning->reserved) if (r != 0) return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning::reserved must be 0");
     if (tuning->park_block != 0 && tuning->park_block != 256 && tuning->park_block != 512 && tuning->park_block != 1024)
         return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning::park_block (PT_AMD_PARK_BLOCK) must be 0, 256, 512 or 1024");
-    if (tuning->shade_form > 2 || tuning->park_dynamic < -1 || tuning->park_dynamic > 1 || tuning->multi_virtual > 64 || tuning->walk_evict_below > 64 || tuning->walk_search_below > 64)
-        return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning: shade_form in 0..2, park_dynamic in -1..1, multi_virtual, walk_evict_below, walk_search_below <= 64");
+    if (tuning->shade_form > 2 || tuning->park_dynamic < -1 || tuning->park_dynamic > 1 || tuning->multi_virtual > 64 || tuning->walk_evict_below > 64 || tuning->walk_search_below > 64 || tuning->top_evict_below > 64)
+        return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning: shade_form in 0..2, park_dynamic in -1..1, multi_virtual, walk_evict_below, walk_search_below, top_evict_below <= 64");
     // the tiled queue index (pt_stages.h qtile) multiplies in 32 bits: capacity <= 2^30; the grids are num_cus * blocks in an int
     if (tuning->batch_slots > (1u << 30) || tuning->blocks_per_cu > 1024u || tuning->park_blocks_per_cu > 1024u)
         return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning: batch_slots (PT_AMD_BATCH) <= 2^30, blocks_per_cu and park_blocks_per_cu <= 1024");

@@ -767,7 +767,7 @@ __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, b
         __threadfence_block();             // entries are in registers before any lane parks again into these slots
         if (lane == 0) *park_count = first;
         // (ALL_LANES, the forms that scan axis rays: a lane without an entry helps with the scans of the others' — mesh_walk's `alive`)
-        if (ALL_LANES || mine) resume(item, st, ray, bound, kind, cursor, last && first == 0u ? walk_policy & ~0xffu : walk_policy, mine);
+        if (ALL_LANES || mine) resume(item, st, ray, bound, kind, cursor, last && first == 0u ? walk_policy & ~0xff0000ffu : walk_policy, mine);   // (the very last drain: neither the mesh walks nor the top-level walks are left early)
     }
 }
 
@@ -806,14 +806,14 @@ k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const fl
             F3 o, d;
             ray_of(base + j, &o, &d);
             SweepState st;
-            bool parks;
-            if (TOP) { top_walk_init(st); parks = top_walk_run(s, o, d, PT_INF, PT_STOP_NONE, st, true); }
+            bool parks, evicted = false;
+            if (TOP) { top_walk_init(st); parks = top_walk_run(s, o, d, PT_INF, PT_STOP_NONE, st, true, (walk_policy >> 24) & 0xffu, &evicted); }
             else {
                 sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
                 const TriRay wtr = tri_ray_prepare(o, d);
                 parks = sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true);
             }
-            settle(j, o, d, st, parks, 0u);
+            settle(j, o, d, st, parks, evicted ? PT_TOP_EVICTED : 0u);
         }
         park_drain<false, kParkCap>(pk, park_count, r + 1 == rounds, walk_policy & ~PT_WALK_SCAN_AXIS, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t, uint32_t cursor, uint32_t policy, bool mine) {
             if (mine) PT_TL_WORK();   // (timeline: parked rays resumed)
@@ -926,8 +926,8 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
                 for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR + k, item, 0.0f);
             } else {
                 SweepState st;
-                bool parks = false;
-                if (TOP) { top_walk_init(st); parks = top_walk_run(s, ray.o, ray.d, bound, stop, st, true); }
+                bool parks = false, evicted = false;
+                if (TOP) { top_walk_init(st); parks = top_walk_run(s, ray.o, ray.d, bound, stop, st, true, (walk_policy >> 24) & 0xffu, &evicted); }
                 else {
                     sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
                     if (!(PT_PARKED_EXP & 2)) {
@@ -938,7 +938,7 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
                 // (measurement variants — no lane may leave the wave's step early, the barrier and the drain below are the whole wave's: 2 = up to the masks, 4 = parked rays dropped)
                 if (PT_PARKED_EXP & 2) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, (float)(uint32_t)st.hit);
                 else if ((PT_PARKED_EXP & 4) && parks) qsf(shadow, Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR, item, 0.0f);
-                else settle(j, l, ray, env, bound, st, parks, light, 0u, lam0);
+                else settle(j, l, ray, env, bound, st, parks, light, evicted ? PT_TOP_EVICTED : 0u, lam0);
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -855,6 +855,23 @@ def test_bokeh_floor(hdri_size=(1024, 512), importance=(1024, 1024)):
     return b
 
 
+def test_bokeh_floor_gem(hdri_size=(1024, 512), importance=(1024, 1024)):
+    """NOT a reference scene: test_bokeh_floor with the brilliant-cut gem (302 triangles, moissanite) standing on the floor — more than 64 instances AND a mesh: the top-level
+    walk parks at the mesh, the parked kernels walk it in full waves (top_walk_run / top_walk_resume), and the wave's last top-level walkers are evicted."""
+    b = test_bokeh_floor(hdri_size, importance)
+    cam = b.cameras.pop()
+    gem = add_library_material(b, "ggx_moissanite")
+    p, f, n, mtl = _npz_mesh("gem")
+    m = b.add_mesh(p, f, n, face_materials=api.material_id(api.TAG_MATERIAL, 0))
+    b.add_mesh_instance(m, gem, transform_from_data(scale=(0.5, 0.5, 0.5), translate=(0.1, -2.0, 0.2)))
+    b.cameras.append(cam)
+    return b
+
+
+def test_bokeh_floor_gem_small():
+    return test_bokeh_floor_gem(hdri_size=(64, 32), importance=(32, 32))
+
+
 def test_bokeh_floor_small():
     return test_bokeh_floor(hdri_size=(64, 32), importance=(32, 32))
 
@@ -871,6 +888,6 @@ def hdri_emissive_mesh():
     return b
 
 
-SCENES = {"test_bokeh_floor": test_bokeh_floor, "test_bokeh_floor_small": test_bokeh_floor_small, "test_bokeh": test_bokeh, "test_bokeh_small": test_bokeh_small, "test_prism": test_prism, "test_prism_small": test_prism_small, "hdri_emissive_mesh": hdri_emissive_mesh, "hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
+SCENES = {"test_bokeh_floor_gem": test_bokeh_floor_gem, "test_bokeh_floor_gem_small": test_bokeh_floor_gem_small, "test_bokeh_floor": test_bokeh_floor, "test_bokeh_floor_small": test_bokeh_floor_small, "test_bokeh": test_bokeh, "test_bokeh_small": test_bokeh_small, "test_prism": test_prism, "test_prism_small": test_prism_small, "hdri_emissive_mesh": hdri_emissive_mesh, "hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
           "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test, "panorama_test": panorama_test, "empty_env": empty_env,
           "big_sphere_light": big_sphere_light, "disk_lamp": disk_lamp, "fog_ball": fog_ball}

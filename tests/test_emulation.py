@@ -63,6 +63,7 @@ def test_materials_bit_exact(emu, oracle, scene):
     ("hdri_small", 24, 24, 4, 4, {"light_samples": 8}),       # the most light samples an item can hold
     ("test_bokeh_small", 48, 48, 6, 8, {"light_samples": 2}),      # G2: 82 instances, no sweep table — the top-level walk
     ("test_bokeh_floor_small", 48, 40, 6, 8, {"light_samples": 3}),
+    ("test_bokeh_floor_gem_small", 48, 40, 6, 8, {"light_samples": 2}),   # ... and a mesh: parked at the mesh, evicted from the top-level walk
     ("test_prism_small", 40, 40, 6, 8, {"light_samples": 3}),     # the reference tree's test_prism.toml: transform stack + lights + environment sampling — the general kernel forms
     ("hdri_emissive_mesh", 32, 32, 6, 4, {"light_samples": 3}),   # empty light list, but a mesh instance overridden with a light material: its hits emit
     ("disk_lamp", 40, 28, 6, 5, {"light_samples": 2, "seed": 2}),   # one disk lamp: the lean form's light test at the vertex (the ceiling's rays start below the lamp), the list of live items

@@ -85,6 +85,8 @@ def test_materials_bit_exact(engine, oracle, scene):
     ("test_bokeh_small", 128, 128, 8, 8, {"light_samples": 2}),      # G2, the reference tree's test_bokeh.toml: 82 sphere lights > 64 instances = no sweep table, the top-level BVH walk
     ("test_bokeh_floor_small", 128, 96, 8, 8, {"light_samples": 3}),  # ... with a floor under the lights: the 82-entry light list sampled, light-sample rays through the top-level walk
     ("test_bokeh_floor_small", 96, 64, 6, 6, {"light_samples": 2, "hero_wavelengths": 4}),
+    ("test_bokeh_floor_gem_small", 128, 96, 8, 8, {"light_samples": 2}),  # ... and a mesh: rays park at the mesh AND are evicted from the top-level walk
+    ("test_bokeh_floor_gem_small", 96, 64, 6, 6, {"light_samples": 3, "hero_wavelengths": 4}),
     ("hdri_emissive_mesh", 96, 96, 8, 4, {"light_samples": 3}),     # empty light list, but a mesh instance overridden with a light material (round-3 advisor): its hits emit, take no item
     ("hdri_emissive_mesh", 64, 64, 6, 4, {"light_samples": 2, "hero_wavelengths": 4}),
     ("disk_lamp", 160, 112, 8, 5, {"light_samples": 2, "seed": 2}),   # one disk lamp 1e-4 under its ceiling: the lean form tests a light-sample ray against the scene's only light at the vertex, the ceiling's items die there and are not listed
@@ -344,7 +346,7 @@ def test_tuning_is_taken_at_scene_creation(engine, pkg, monkeypatch):
     assert p3.kernel_launches[1] > 0
     monkeypatch.delenv("PT_AMD_NO_FUSE")
     bad = engine.tuning_default()
-    bad.reserved[3] = 1
+    bad.reserved[2] = 1
     with pytest.raises(pkg.api.PtError):
         engine.create_scene(b, bad)
     bad = engine.tuning_default()
@@ -456,6 +458,29 @@ def test_full_size_cornell_properties(engine, oracle, pkg):
     down = whole[..., 1].reshape(64, 16, 64, 16).mean(axis=(1, 3))
     rel = abs(down.mean() - ref[..., 1].mean()) / ref[..., 1].mean()
     assert rel < 0.05, rel
+
+
+def test_c4_frame_dealt_over_eight_shards(engine, pkg):
+    """BASELINE.json's 8-GPU configuration as eight shards on one device: the C4 scene at 1024 x 1024, its 32 x 32 tiles dealt along diagonals over shard = (k, 8)
+    (PT_TILE_SHARD, include/pt_api.h; the split of src/renderer/tiled.rs:190-277 into independent tile sets).  The eight partial films are disjoint, their sum is the
+    one-device film bit for bit, the counters add up, and no shard gets more than 1/8 of the tiles + one per diagonal's remainder."""
+    sc = engine.create_scene(pkg.scene.hdri_test())
+    whole, pw = sc.render(pkg.api.render_desc(1024, 1024, 2, 4, light_samples=6, seed=8))
+    acc = np.zeros_like(whole)
+    covered = np.zeros(whole.shape[:2], np.int32)
+    rays = [0, 0, 0]
+    for k in range(8):
+        part, pp = sc.render(pkg.api.render_desc(1024, 1024, 2, 4, light_samples=6, seed=8, shard=(k, 8)))
+        owned = (part != 0).any(axis=2)
+        tiles = owned.reshape(32, 32, 32, 32).any(axis=(1, 3))          # which 32 x 32 tiles this shard touched
+        assert 120 <= tiles.sum() <= 136, (k, tiles.sum())               # 1024 tiles over 8 shards: 128 each, give or take the diagonals' ends
+        covered += owned
+        acc += part
+        rays[0] += pp.bounce_rays; rays[1] += pp.shadow_rays; rays[2] += pp.env_hits
+        assert pp.camera_rays == 2 * 1024 * 1024 // 8
+    assert covered.max() == 1                                            # disjoint
+    assert np.array_equal(acc.view(np.uint32), whole.view(np.uint32))
+    assert tuple(rays) == (pw.bounce_rays, pw.shadow_rays, pw.env_hits)
 
 
 @pytest.mark.parametrize("scene,w,h,mb,kw", [

@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-struct Stats { unsigned long long box_tests, box_exact, tri_tests, instance_tests; };
+struct Stats { unsigned long long box_tests, box_exact, tri_tests, instance_tests, rays_without_light, rays_dead, rays_live; };
 static Stats g_stats;
 // trace: per ray, list of rounds; each round = (steps, leaf kind 0 none / 3 tri / 4 inst)
 struct Round { int steps; int leaf; };
