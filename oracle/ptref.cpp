@@ -2156,6 +2156,27 @@ void ptref_numerics(int which, size_t n, const float* x, const float* y, float* 
         }
     }
 }
+// The restated `math`-crate helpers on their own (tests/test_pin.py: the pin kit compares them with numbers a maintainer prints from the real crate).
+// which: 0 uv_to_direction(in[0], in[1]) -> 3; 1 direction_to_uv(in[0..3]) -> 2; 2 power_heuristic(a, b) -> 1; 3 power_heuristic_generic(a, b) -> 1;
+// 4 random_cosine_direction(u, v) -> 3; 5 random_on_unit_sphere(x, y) -> 3; 6 random_in_unit_disk(x, y) -> 3; 7 TangentFrame::from_normal(in[0..3]).to_world(in[3..6]) -> 3;
+// 8 ... .to_local(in[3..6]) -> 3; 9 Sample1D::choose(x = in[0], split = in[1], 1, 2) -> (rescaled x, choice)
+void ptref_math_probe(int which, const float* in, float* out) {
+    V3 r = v3(0.0f, 0.0f, 0.0f);
+    switch (which) {
+        case 0: r = uv_to_direction(in[0], in[1]); break;
+        case 1: direction_to_uv(v3(in[0], in[1], in[2]), &out[0], &out[1]); return;
+        case 2: out[0] = power_heuristic(in[0], in[1]); return;
+        case 3: out[0] = power_heuristic_generic(in[0], in[1]); return;
+        case 4: r = random_cosine_direction(in[0], in[1]); break;
+        case 5: r = random_on_unit_sphere(in[0], in[1]); break;
+        case 6: r = random_in_unit_disk(in[0], in[1]); break;
+        case 7: r = to_world(frame_from_normal(v3(in[0], in[1], in[2])), v3(in[3], in[4], in[5])); break;
+        case 8: r = to_local(frame_from_normal(v3(in[0], in[1], in[2])), v3(in[3], in[4], in[5])); break;
+        case 9: { float x = in[0]; out[1] = (float)choose<int>(x, in[1], 1, 2); out[0] = x; return; }
+        default: break;
+    }
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
 void ptref_draw4(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t dim, float* out4) {
     pt_f32x4 r = pt_draw4(seed, pixel, sample, dim); out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w;
 }

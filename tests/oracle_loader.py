@@ -28,6 +28,8 @@ def load(pkg):
     L.ptref_xyz_bar.argtypes = [C.c_float, C.POINTER(C.c_float)]
     L.ptref_numerics.restype = None
     L.ptref_numerics.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ptref_math_probe.restype = None
+    L.ptref_math_probe.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ptref_draw4.restype = None
     L.ptref_draw4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
     L.ptref_philox.restype = None
