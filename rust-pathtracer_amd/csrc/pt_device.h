@@ -26,6 +26,10 @@
 #pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
 #endif
 
+#ifndef PT_GROUP_WALK_BOX
+#define PT_GROUP_WALK_BOX 1   /* the grouped mesh sweep's per-lane leaf boxes through walk_box (round 5); 0 = aabb_classify + a loop over the undecided */
+#endif
+
 // Optional instrumentation for host-side experiments (tools/traversal_stats.cpp); compiled out everywhere else.
 #ifndef PT_STAT
 #define PT_STAT(counter)
@@ -1051,7 +1055,21 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                     const uint32_t g = ctz64(entered);
                     entered &= entered - 1;
                     const uint32_t first = g * PT_MESH_GROUP, chunk = leaf_count - first < PT_MESH_GROUP ? leaf_count - first : PT_MESH_GROUP;
-                    uint32_t hit = 0, unc = 0;
+                    uint32_t hit = 0;
+#if PT_GROUP_WALK_BOX
+                    // (round 5: the leaf boxes of an entered group through the walk's data-flow test — the lanes stand on different leaves, as in a walk step: the thick form
+                    // for every lane, the flat form and the exact test under wave-uniform branches — instead of aabb_classify's per-lane nest and a loop over the undecided)
+                    for (uint32_t t = 0; t < PT_MESH_GROUP; ++t) {
+                        if (t >= chunk) break;
+                        const uint32_t e = leaf_off + (first + t) * 8u;
+                        F4 ta = mf4(s, e), tb = mf4(s, e + 4);
+                        ta.w = pt_u2f(pt_f2u(tb.w) != 0u ? PT_NODE_FLAT : 0u);   // (a leaf-list entry keeps its "flat" flag in [7]; walk_box reads it where a node keeps it)
+                        float entry = 0.0f;
+                        const bool box = walk_box(ta, tb, cr, quick, &entry) & !(cull & beyond(entry, limit, cr.base));
+                        hit |= box ? 1u << t : 0u;
+                    }
+#else
+                    uint32_t unc = 0;
                     for (uint32_t t = 0; t < PT_MESH_GROUP; ++t) {
                         if (t >= chunk) break;
                         const uint32_t e = leaf_off + (first + t) * 8u;
@@ -1069,6 +1087,7 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                         PT_STAT(box_exact);
                         if (aabb_hit_exact(mf4(s, e), mf4(s, e + 4), lo, ld, &entry)) hit |= 1u << k;
                     }
+#endif
                     while (hit != 0u) {
                         const uint32_t k = (uint32_t)__builtin_ctz(hit);
                         hit &= hit - 1u;

@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(RenderParams rp, const uint
         uint32_t slot = base + j;
         uint32_t pixel = pixels[slot % rp.chunk_pixels];
         PathVertexT<NL> p = stage_generate<NL>(rp, slot, pixel);
-        store_path<NL>(paths, slot, p);
+        if (PT_CAMERA_RECORD && rp.camera_record) store_path_camera<NL>(paths, slot, p); else store_path<NL>(paths, slot, p);
         for (int k = 0; k < NL; ++k) energy[(size_t)k * rp.energy_stride + slot] = 0.0f;
     }
     if (threadIdx.x == 0) count_out[blockIdx.x] = cnt;
@@ -325,11 +325,13 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
                 const F3 o = f3(qf(paths_in, PS_OX, i), qf(paths_in, PS_OY, i), qf(paths_in, PS_OZ, i));
                 const F3 d = f3(qf(paths_in, PS_DX, i), qf(paths_in, PS_DY, i), qf(paths_in, PS_DZ, i));
                 world_hit<FUSE_TRAV == PT_NO_FUSE ? PT_TRAV_ANY : FUSE_TRAV>(s, o, d, &hit);
-                pv = load_path<NL>(paths_in, i);
+                pv = load_path<NL>(paths_in, i, bounce == 0u);
             } else {
                 // (the path record first: its sixteen loads are in flight while the hit record's first word — which decides whether the rest
                 // is read at all — comes back; the other order leaves that latency exposed: k_shade 2506 -> 2893 us on C2)
-                pv = load_path<NL>(paths_in, i);
+                // (the camera vertex' lean record, pt_stages.h — not in the NO_ENV form: the branch costs that form, at its register budget, 7 %: C3 k_shade 2377 -> 2540 us,
+                // so a render that takes it has k_generate write the full record, RenderParams::camera_record)
+                pv = load_path<NL>(paths_in, i, FORM != PT_SHADE_NO_ENV && bounce == 0u);
                 hit = load_hit<PT_SHADE_EAGER && FORM == PT_SHADE_LEAN>(hits, i);
             }
             wants_item = shade_wants_item(s, rp, hit);
@@ -711,19 +713,38 @@ __global__ void __launch_bounds__(kBlock) PT_POOL_OCC k_shadow_exp(const uint32_
 // whenever a wave has 64 rays parked (and at the end) it resumes them together: a full wave, every lane in a mesh walk.  Nothing about a ray's own sequence of tests changes (same leaves, same order, same running closest hit).
 enum { PK_ITEM, PK_HIT_LO, PK_HIT_HI, PK_CLOSEST, PK_BEST_INST, PK_BEST_TRIW, PK_T, PK_B0, PK_B1, PK_B2, PK_RAY, PK_BOUND, PK_KIND, PK_CURSOR };
 static_assert(PK_CURSOR < kParkFields, "a parked entry's fields");
-template <uint32_t kParkCap = ptk::kParkCap>   // (the stride between the fields of a workgroup's entries: 128 per wave)
-__device__ __forceinline__ void park_store(uint32_t* pk, uint32_t e, uint32_t item, const SweepState& st, uint32_t ray, float bound, uint32_t kind, uint32_t cursor) {
+// REC (round 5: the round-4 verdict's "compacted park record", built instead of priced): which fields an entry carries.  PK_FULL = all fourteen; PK_SEGMENT = a path segment's
+// (k_extend_parked: no ray number, bound or kind — constants there): eleven; PK_LIGHT_RAY = a light-sample ray's whose closest hit's barycentrics nobody will read
+// (only a light's record is ever built, shadow_ray_contribution, and a light is an analytic shape unless a mesh instance is overridden with one —
+// `with_bh`, wave-uniform, says whether this scene has such a mesh): ten.
+enum { PK_FULL = 0, PK_SEGMENT = 1, PK_LIGHT_RAY = 2 };
+#ifndef PT_PARK_SEGMENT_REC
+#define PT_PARK_SEGMENT_REC PK_FULL   /* k_extend_parked's record: PK_SEGMENT measured +0.7 % on C3 (3210 -> 3234 us: the kernel allocates worse), equal on C4 and G1 — not taken */
+#endif
+#ifndef PT_PARK_COMPACT
+#define PT_PARK_COMPACT 1   /* 0: every kernel stores and loads every field (the record of rounds 2-4) */
+#endif
+template <uint32_t kParkCap = ptk::kParkCap, int REC = PK_FULL>   // (kParkCap: the stride between the fields of a workgroup's entries: 128 per wave)
+__device__ __forceinline__ void park_store(uint32_t* pk, uint32_t e, uint32_t item, const SweepState& st, uint32_t ray, float bound, uint32_t kind, uint32_t cursor, bool with_bh = true) {
     pk[PK_ITEM * kParkCap + e] = item; pk[PK_HIT_LO * kParkCap + e] = (uint32_t)st.hit; pk[PK_HIT_HI * kParkCap + e] = (uint32_t)(st.hit >> 32);
     pk[PK_CLOSEST * kParkCap + e] = pt_f2u(st.closest); pk[PK_BEST_INST * kParkCap + e] = st.best_inst; pk[PK_BEST_TRIW * kParkCap + e] = st.best_triw;
-    pk[PK_T * kParkCap + e] = pt_f2u(st.bh.t); pk[PK_B0 * kParkCap + e] = pt_f2u(st.bh.b0); pk[PK_B1 * kParkCap + e] = pt_f2u(st.bh.b1); pk[PK_B2 * kParkCap + e] = pt_f2u(st.bh.b2);
-    pk[PK_RAY * kParkCap + e] = ray; pk[PK_BOUND * kParkCap + e] = pt_f2u(bound); pk[PK_KIND * kParkCap + e] = kind; pk[PK_CURSOR * kParkCap + e] = cursor;
+    if (!PT_PARK_COMPACT || REC != PK_LIGHT_RAY || with_bh) {
+        pk[PK_T * kParkCap + e] = pt_f2u(st.bh.t); pk[PK_B0 * kParkCap + e] = pt_f2u(st.bh.b0); pk[PK_B1 * kParkCap + e] = pt_f2u(st.bh.b1); pk[PK_B2 * kParkCap + e] = pt_f2u(st.bh.b2);
+    }
+    if (!PT_PARK_COMPACT || REC != PK_SEGMENT) { pk[PK_RAY * kParkCap + e] = ray; pk[PK_BOUND * kParkCap + e] = pt_f2u(bound); pk[PK_KIND * kParkCap + e] = kind; }
+    pk[PK_CURSOR * kParkCap + e] = cursor;
 }
-template <uint32_t kParkCap = ptk::kParkCap>
-__device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32_t* item, SweepState* st, uint32_t* ray, float* bound, uint32_t* kind, uint32_t* cursor) {
+template <uint32_t kParkCap = ptk::kParkCap, int REC = PK_FULL>
+__device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32_t* item, SweepState* st, uint32_t* ray, float* bound, uint32_t* kind, uint32_t* cursor, bool with_bh = true) {
     *item = pk[PK_ITEM * kParkCap + e]; st->hit = (uint64_t)pk[PK_HIT_LO * kParkCap + e] | (uint64_t)pk[PK_HIT_HI * kParkCap + e] << 32;
     st->closest = pt_u2f(pk[PK_CLOSEST * kParkCap + e]); st->best_inst = pk[PK_BEST_INST * kParkCap + e]; st->best_triw = pk[PK_BEST_TRIW * kParkCap + e];
-    st->bh.t = pt_u2f(pk[PK_T * kParkCap + e]); st->bh.b0 = pt_u2f(pk[PK_B0 * kParkCap + e]); st->bh.b1 = pt_u2f(pk[PK_B1 * kParkCap + e]); st->bh.b2 = pt_u2f(pk[PK_B2 * kParkCap + e]);
-    *ray = pk[PK_RAY * kParkCap + e]; *bound = pt_u2f(pk[PK_BOUND * kParkCap + e]); *kind = pk[PK_KIND * kParkCap + e]; *cursor = pk[PK_CURSOR * kParkCap + e];
+    st->bh.t = 0.0f; st->bh.b0 = st->bh.b1 = st->bh.b2 = 0.0f;
+    if (!PT_PARK_COMPACT || REC != PK_LIGHT_RAY || with_bh) {
+        st->bh.t = pt_u2f(pk[PK_T * kParkCap + e]); st->bh.b0 = pt_u2f(pk[PK_B0 * kParkCap + e]); st->bh.b1 = pt_u2f(pk[PK_B1 * kParkCap + e]); st->bh.b2 = pt_u2f(pk[PK_B2 * kParkCap + e]);
+    }
+    *ray = 0u; *bound = PT_INF; *kind = 0u;
+    if (!PT_PARK_COMPACT || REC != PK_SEGMENT) { *ray = pk[PK_RAY * kParkCap + e]; *bound = pt_u2f(pk[PK_BOUND * kParkCap + e]); *kind = pk[PK_KIND * kParkCap + e]; }
+    *cursor = pk[PK_CURSOR * kParkCap + e];
 }
 // The resume loop shared by both kernels, per WAVE: every wave of the workgroup parks into its own quarter of the scratch
 // region (128 entries: fewer than 64 left over + at most 64 new per step) and resumes 64 parked rays at a time — full
@@ -752,8 +773,8 @@ static_assert(kWaveParkCap == 128, "a wave's park list: fewer than 64 entries le
 // `walk_policy` (mesh_walk's: pt_tuning::walk_evict_below | walk_search_below << 8): a resumed wave's walks are left by its last lanes once
 // fewer than walk_evict_below are still walking — they park again with their cursor and go on in a later drain.  Not in the very last drain
 // of a wave, which has nobody left to wait for.
-template <bool ALL_LANES, uint32_t PCAP = ptk::kParkCap, typename Resume>
-__device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, bool last, uint32_t walk_policy, Resume&& resume) {
+template <bool ALL_LANES, uint32_t PCAP = ptk::kParkCap, int REC = PK_FULL, typename Resume>
+__device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, bool last, uint32_t walk_policy, Resume&& resume, bool with_bh = true) {
     const uint32_t lane = lane_id();
     for (;;) {
         __threadfence_block();             // this wave's parked entries are visible to its other lanes
@@ -763,7 +784,7 @@ __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, b
         const bool mine = lane < take;
         uint32_t item = 0, ray = 0, kind = 0, cursor = 0; float bound = PT_INF; SweepState st;
         if (ALL_LANES) sweep_state_init(st, 0);
-        if (mine) park_load<PCAP>(pk, first + lane, &item, &st, &ray, &bound, &kind, &cursor);
+        if (mine) park_load<PCAP, REC>(pk, first + lane, &item, &st, &ray, &bound, &kind, &cursor, with_bh);
         __threadfence_block();             // entries are in registers before any lane parks again into these slots
         if (lane == 0) *park_count = first;
         // (ALL_LANES, the forms that scan axis rays: a lane without an entry helps with the scans of the others' — mesh_walk's `alive`)
@@ -796,7 +817,7 @@ k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const fl
         *d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
     };
     auto settle = [&](uint32_t j, F3 o, F3 d, const SweepState& st, bool parked, uint32_t cursor) {
-        if (parked) park_store<kParkCap>(pk, atomicAdd(park_count, 1u), j, st, 0u, PT_INF, 0u, cursor);
+        if (parked) park_store<kParkCap, PT_PARK_SEGMENT_REC>(pk, atomicAdd(park_count, 1u), j, st, 0u, PT_INF, 0u, cursor);
         else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, base + j, h); }
     };
     PT_TL_BEGIN();
@@ -815,7 +836,7 @@ k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const fl
             }
             settle(j, o, d, st, parks, evicted ? PT_TOP_EVICTED : 0u);
         }
-        park_drain<false, kParkCap>(pk, park_count, r + 1 == rounds, walk_policy & ~PT_WALK_SCAN_AXIS, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t, uint32_t cursor, uint32_t policy, bool mine) {
+        park_drain<false, kParkCap, PT_PARK_SEGMENT_REC>(pk, park_count, r + 1 == rounds, walk_policy & ~PT_WALK_SCAN_AXIS, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t, uint32_t cursor, uint32_t policy, bool mine) {
             if (mine) PT_TL_WORK();   // (timeline: parked rays resumed)
             F3 o = f3(0.0f, 0.0f, 0.0f), d = f3(0.0f, 0.0f, 0.0f);
             if (mine) ray_of(base + j2, &o, &d);
@@ -844,6 +865,8 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
     constexpr uint32_t kParkCap = kWaveParkCap * (BLK / 64);   // (shadows ptk::kParkCap: this workgroup's entries per field)
     SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);
     constexpr bool kOnlyEnv = (LACKS & PT_SCENE_NO_LIGHTS) != 0u;
+    // (a parked light-sample ray carries its closest hit's barycentrics only where a triangle can be a light: a mesh instance overridden with a light material)
+    const bool with_bh = (PT_UNIFORM(bu(s, PT_HDR_FLAGS)) & PT_FLAG_NO_SHADOW_BOUND) != 0u;
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap + wave * kWaveParkCap;
     uint32_t* park_count = &park_counts[wave];
@@ -854,7 +877,7 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
     // rays are parked and resumed by the wave that owns the item, so that sum needs no workgroup barrier either)
     // (`lambda0`, one wavelength per path: the item's wavelength, read along with the ray — PT_PARKED_EAGER — instead of behind the search)
     auto settle = [&](uint32_t j, uint32_t l, const ShadowRayT<NL>& ray, bool env, float bound, const SweepState& st, bool parked, uint32_t light, uint32_t cursor, float lambda0) {
-        if (parked) { park_store<kParkCap>(pk, atomicAdd(park_count, 1u), j, st, l, bound, (env ? 1u : 0u) | (light + 1u) << 1, cursor); return; }
+        if (parked) { park_store<kParkCap, PK_LIGHT_RAY>(pk, atomicAdd(park_count, 1u), j, st, l, bound, (env ? 1u : 0u) | (light + 1u) << 1, cursor, with_bh); return; }
         const uint32_t item = base + j;
         float lambda[NL], c[NL];
         for (int k = 0; k < NL; ++k) lambda[k] = (NL == 1 && PT_PARKED_EAGER) ? lambda0 : qf(shadow, Layout<NL>::sh_lambda + k, item);
@@ -942,7 +965,7 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
             }
         }
         __builtin_amdgcn_wave_barrier();
-        park_drain<true, kParkCap>(pk, park_count, r == rounds && live_count == 0u, walk_policy, resume_parked);
+        park_drain<true, kParkCap, PK_LIGHT_RAY>(pk, park_count, r == rounds && live_count == 0u, walk_policy, resume_parked, with_bh);
     }
     PT_TL_END(n);
     __threadfence_block();

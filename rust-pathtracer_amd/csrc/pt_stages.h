@@ -88,6 +88,7 @@ struct RenderParams {
     uint32_t normalize;         // divide by spp when the last phase of a whole render is flushed
     uint32_t energy_stride;     // energy of wavelength k of slot i at energy[k * energy_stride + i]
     uint32_t phase;             // samples per partial sum (10: tiled.rs:347-361; spp: naive.rs:82-103)
+    uint32_t camera_record;     // k_generate writes the camera vertex' lean record (store_path_camera): the render's vertex kernel rebuilds the rest at bounce 0
     uint32_t live_list;         // the light-sample kernel of this render walks the list of live items (Layout::shadow_live_field): the vertex kernel builds it
     CameraParams camera;
 };
@@ -116,6 +117,30 @@ PT_HD PathVertexT<NL> load_path(const Queue& q, uint32_t i) {
     for (int k = 1; k < NL; ++k) p.beta[k] = qf(q, PS_FIELDS + k - 1, i);
     p.prev_n = f3(qf(q, PS_PNX, i), qf(q, PS_PNY, i), qf(q, PS_PNZ, i));
     p.prev_p = f3(qf(q, PS_PPX, i), qf(q, PS_PPY, i), qf(q, PS_PPZ, i));
+    return p;
+}
+// The camera vertex' record (round 5): of the sixteen words stage_generate fills, nine are functions of the other seven and of the item's index — throughput 1, slot = the
+// index (k_generate stores slot s at index s), previous pdf 100, previous normal = the direction, previous point = the origin (pt.rs:430-446).  k_generate writes the ray and the
+// wavelength alone (28 of 64 bytes: it is bound by those writes, 5.7 TB/s) and the first bounce's vertex kernel rebuilds the rest instead of reading it: the same values.
+#ifndef PT_CAMERA_RECORD
+#define PT_CAMERA_RECORD 1   /* 0: the full record written and read at every bounce (rounds 1-4) */
+#endif
+template <int NL>
+PT_HD void store_path_camera(const Queue& q, uint32_t i, const PathVertexT<NL>& p) {
+    qsf(q, PS_OX, i, p.o.x); qsf(q, PS_OY, i, p.o.y); qsf(q, PS_OZ, i, p.o.z);
+    qsf(q, PS_DX, i, p.d.x); qsf(q, PS_DY, i, p.d.y); qsf(q, PS_DZ, i, p.d.z);
+    qsf(q, PS_LAMBDA, i, p.lambda);
+}
+// `first`: the launch shades camera vertices (bounce 0, wave-uniform)
+template <int NL>
+PT_HD PathVertexT<NL> load_path(const Queue& q, uint32_t i, bool first) {
+    if (!(PT_CAMERA_RECORD && first)) return load_path<NL>(q, i);
+    PathVertexT<NL> p;
+    p.o = f3(qf(q, PS_OX, i), qf(q, PS_OY, i), qf(q, PS_OZ, i));
+    p.d = f3(qf(q, PS_DX, i), qf(q, PS_DY, i), qf(q, PS_DZ, i));
+    p.lambda = qf(q, PS_LAMBDA, i);
+    for (int k = 0; k < NL; ++k) p.beta[k] = 1.0f;
+    p.slot = i; p.prev_pdf = 100.0f; p.prev_n = p.d; p.prev_p = p.o;
     return p;
 }
 template <int NL>

@@ -66,6 +66,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
     rp.phase = rd.phase_samples;
     rp.energy_stride = capacity;
     rp.camera = pth::camera_params(sc->host.cameras[rd.camera_index], (float)rd.width / (float)rd.height);
+    rp.camera_record = rd.medium_aware ? 0u : 1u;   // (the camera vertex' lean record, pt_stages.h: the engine takes it in the lean and full vertex forms; here wherever the plain walk runs)
     typedef Layout<NL> LY;
     const size_t cap64 = ((size_t)capacity + 63u) & ~(size_t)63u;   // queues are tiled by 64 items (pt_stages.h)
     std::vector<uint32_t> pa((size_t)(LY::path_fields + 2) * cap64), pb((size_t)(LY::path_fields + 2) * cap64), ph((size_t)HS_FIELDS * cap64),
@@ -79,7 +80,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
         const uint32_t* px = pixels.data() + pass.pixel_begin;
         uint32_t n = pass.pixel_count * pass.sample_count;
         camera_rays += n;
-        for (uint32_t i = 0; i < n; ++i) { store_path<NL>(qa, i, stage_generate<NL>(rp, i, px[i % rp.chunk_pixels])); for (int k = 0; k < NL; ++k) energy[(size_t)k * capacity + i] = 0.0f; }
+        for (uint32_t i = 0; i < n; ++i) { if (PT_CAMERA_RECORD && rp.camera_record) store_path_camera<NL>(qa, i, stage_generate<NL>(rp, i, px[i % rp.chunk_pixels])); else store_path<NL>(qa, i, stage_generate<NL>(rp, i, px[i % rp.chunk_pixels])); for (int k = 0; k < NL; ++k) energy[(size_t)k * capacity + i] = 0.0f; }
         uint32_t live = n;
         bool has_ggx = false;
         for (uint32_t i = 0; i < bu(s, PT_HDR_MATERIAL_COUNT); ++i) {
@@ -97,7 +98,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
             }
             uint32_t next = 0, items = 0;
             for (uint32_t i = 0; i < live; ++i) {
-                PathVertexT<NL> pv = load_path<NL>(qin, i);
+                PathVertexT<NL> pv = load_path<NL>(qin, i, rp.camera_record != 0u && bounce == 0u);
                 Hit hit = load_hit(qh, i);
                 bool wants = shade_wants_item(s, rp, hit);   // (the medium-aware walk overrides this below)
                 uint32_t ipos = items;
