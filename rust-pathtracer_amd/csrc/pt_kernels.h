@@ -123,6 +123,9 @@ __host__ __device__ constexpr uint32_t live_cap(uint32_t light_samples) { return
 #define PT_EXP_LACKS 0u   /* register-pressure experiments in the build container only (tools/isa_pressure.py on one kernel): what that kernel is compiled to
                              assume the scene lacks, whatever its template says.  Never for a library that renders: a scene holding the thing would be wrong. */
 #endif
+#ifndef PT_EMPTY_SEGMENT_EXIT
+#define PT_EMPTY_SEGMENT_EXIT 1   /* a workgroup whose segment is empty returns before it stages the scene (round 5); 0 = stages it, then finds nothing to do */
+#endif
 template <int USE_LDS, uint32_t LACKS = 0u>
 __device__ __forceinline__ SceneView stage_scene(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* tex, uint32_t* lds) {
     SceneView s;
@@ -252,6 +255,7 @@ template <int USE_LDS, int TRAV, uint32_t LACKS = 0u>
 __global__ void __launch_bounds__(kBlock) PT_TRAV_OCC k_extend(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                                                   Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
     extern __shared__ __align__(16) uint32_t lds[];
+    if (PT_EMPTY_SEGMENT_EXIT && count_in[blockIdx.x] == 0u) return;   // (an empty segment: nothing to stage the scene for — the deep bounces of an open scene are mostly such launches)
     SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);
     uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
     for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
@@ -278,6 +282,10 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
                                                  uint32_t* __restrict__ shadow_count, unsigned long long* __restrict__ block_stats) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ uint32_t lds_counts[16];  // [0] path queue head, [1] item queue head, [4..6] statistics
+    if (PT_EMPTY_SEGMENT_EXIT && count_in[blockIdx.x] == 0u) {   // (an empty segment leaves empty segments: no scene staged, no barrier met)
+        if (threadIdx.x == 0) { count_out[blockIdx.x] = 0u; shadow_count[blockIdx.x] = 0u; shadow_count[gridDim.x + blockIdx.x] = 0u; }
+        return;
+    }
     if (threadIdx.x < 16) lds_counts[threadIdx.x] = 0;
     SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);  // (barrier inside when staging; one below otherwise)
     if (FORM == PT_SHADE_FULL) stage_marginal<USE_LDS>(s, blob, blob_words, lds);   // (the importance map's marginal tables behind the blob: launch_shade sized the LDS for them)
@@ -392,6 +400,10 @@ k_shade_medium(const uint32_t* __restrict__ blob, uint32_t blob_words, const flo
                uint32_t* __restrict__ count_out, uint32_t* __restrict__ shadow_count, unsigned long long* __restrict__ block_stats) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ uint32_t lds_counts[16];
+    if (PT_EMPTY_SEGMENT_EXIT && count_in[blockIdx.x] == 0u) {
+        if (threadIdx.x == 0) { count_out[blockIdx.x] = 0u; shadow_count[blockIdx.x] = 0u; shadow_count[gridDim.x + blockIdx.x] = 0u; }
+        return;
+    }
     if (threadIdx.x < 16) lds_counts[threadIdx.x] = 0;
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
     if (USE_LDS == PT_LDS_NONE) __syncthreads();
@@ -446,6 +458,7 @@ __global__ void __launch_bounds__(kBlock) PT_SHADOW_OCC k_shadow(const uint32_t*
                                                   uint32_t light_samples, Queue shadow, float* __restrict__ energy, uint32_t energy_stride,
                                                   uint32_t seg_cap, const uint32_t* __restrict__ count_in) {
     extern __shared__ __align__(16) uint32_t lds[];
+    if (PT_EMPTY_SEGMENT_EXIT && count_in[((seg_cap & kShadowListed) != 0u ? gridDim.x : 0u) + blockIdx.x] == 0u) return;
     SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);
     // `seg_cap` with its top bit set (kShadowListed; the engine sets it when the vertex kernel built the list): the segment's LIVE items, through their list
     // (Layout::shadow_live_field; the count behind the items' counts) — an item without a live ray is not read.  Otherwise every item of the segment.
@@ -805,6 +818,7 @@ k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const fl
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ uint32_t park_counts[BLK / 64];
     constexpr uint32_t kParkCap = kWaveParkCap * (BLK / 64);   // (shadows ptk::kParkCap: this workgroup's entries per field)
+    if (PT_EMPTY_SEGMENT_EXIT && count_in[blockIdx.x] == 0u) return;
     SceneView s = stage_scene<USE_LDS>(blob, blob_words, tex, lds);
     const uint32_t wave = PT_UNIFORM(threadIdx.x >> 6);   // (a scalar: with fresh_lane_id below, threadIdx.x need not stay in a register across the rounds)
     uint32_t* pk = park_all + (size_t)blockIdx.x * kParkFields * kParkCap + wave * kWaveParkCap;  // field f of entry e at pk[f * kParkCap + e]
@@ -863,6 +877,7 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ uint32_t park_counts[BLK / 64];
     constexpr uint32_t kParkCap = kWaveParkCap * (BLK / 64);   // (shadows ptk::kParkCap: this workgroup's entries per field)
+    if (PT_EMPTY_SEGMENT_EXIT && count_in[blockIdx.x] == 0u) return;
     SceneView s = stage_scene<USE_LDS, LACKS>(blob, blob_words, tex, lds);
     constexpr bool kOnlyEnv = (LACKS & PT_SCENE_NO_LIGHTS) != 0u;
     // (a parked light-sample ray carries its closest hit's barycentrics only where a triangle can be a light: a mesh instance overridden with a light material)
