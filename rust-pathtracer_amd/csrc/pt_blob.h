@@ -34,7 +34,7 @@
 
 // Mesh record (8 words): node_off (float4 units... all offsets are WORD offsets), node_count, tri_off, normal_off
 // (0 = none), face_count, leaf list, group boxes
-#define PT_MESH_WORDS 8
+#define PT_MESH_WORDS 16
 #define PT_MESH_NODE_OFF 0
 #define PT_MESH_NODE_COUNT 1
 #define PT_MESH_TRI_OFF 2
@@ -43,6 +43,14 @@
 #define PT_MESH_LEAF_OFF 5     /* leaf list for mesh_sweep (0 = none): per leaf in pre-order 8 words = min.xyz, triangle word offset, max.xyz, flat */
 #define PT_MESH_LEAF_COUNT 6
 #define PT_MESH_GROUP_OFF 7    /* meshes of more than PT_MESH_GROUP_MIN leaves: per PT_MESH_GROUP consecutive leaves 8 words = the box that holds theirs (min.xyz, 0, max.xyz, flat); 0 = none */
+/* A CLOSED mesh's inner sphere (round 5; mesh_surely_blocks, pt_device.h): centre [8..10] and radius [11] of a ball that lies strictly inside the surface (every
+   edge shared by exactly two triangles, the centre at odd crossing parity, the radius 0.98 x the distance to the nearest triangle), in the mesh's own space; [12] the
+   length of the bounding box's diagonal.  A ray that passes through the ball and leaves the box before its bound MUST cross the surface in between — the watertight
+   triangle test cannot miss a crossing of a closed surface — so a light-sample ray's search can end there: "something opaque in front of the light", without a walk.
+   Radius 0: no such ball (an open mesh, a light among its faces, no inside point found). */
+#define PT_MESH_INNER_C 8
+#define PT_MESH_INNER_R 11
+#define PT_MESH_REACH 12
 #ifndef PT_MESH_GROUP
 #define PT_MESH_GROUP 6   /* (measured on C3's gem, 302 leaves: k_extend_parked 4400 / 4190 / 3875 / 3605 / 3520 us at 16 / 12 / 8 / 6 / 5 leaves per group) */
 #endif

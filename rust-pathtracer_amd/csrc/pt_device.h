@@ -1224,6 +1224,31 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
     if (evicted) *cursor = (SPEC && pending != NONE) ? pend_node : i;   // (a leaf held untested: its own node, found again on resume)
     return evicted;
 }
+// A light-sample ray's search may end at a CLOSED mesh without looking at a triangle (round 5; pt_blob.h PT_MESH_INNER_*): if the ray passes through the mesh's
+// inner ball at tca > 0 and is beyond the mesh's bounding box — farther from that inside point than the box's diagonal — before `bound`, it crosses the surface in
+// between, and the reference's watertight triangle test (mesh.rs:67-198, restated in triangle_test) reports a hit there: a non-light hit in front of every light,
+// which is all such a search wants to know (PT_STOP_NONLIGHT, PT_STOP_ANY: the callers read "a light or not", never the occluder's record).  The ball was shrunk by
+// 2 % on the host; the test runs in the instance's own space with the un-normalised direction, t is the world ray's parameter.
+#ifndef PT_INNER_BALL
+#define PT_INNER_BALL 1
+#endif
+// (which searches try it: the light rays — bounded, PT_STOP_NONLIGHT: C3 k_shadow_parked 3783 -> 3558 us.  Environment rays too (PT_STOP_ANY) was measured on C4, whose
+// light samples are all of that kind: k_shadow_parked 2904 -> 2929 us — a ray that leaves the monkey's surface for the sky seldom passes through its inside)
+#define PT_INNER_BALL_STOP PT_STOP_NONLIGHT
+PT_HD bool mesh_surely_blocks(const SceneView& s, uint32_t inst, F3 o, F3 d, float bound) {
+    if (!PT_INNER_BALL) return false;
+    const uint32_t mesh = bu(s, inst + PT_INST_MESH);
+    const float r = bf(s, mesh + PT_MESH_INNER_R);
+    const uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+    if (!(r > 0.0f) || (im != PT_MATERIAL_NONE && PT_MATERIAL_TAG(im) == PT_TAG_LIGHT)) return false;
+    F3 lo, ld;
+    instance_local_ray(s, inst, o, d, &lo, &ld);
+    const F3 oc = sub(f3(bf(s, mesh + PT_MESH_INNER_C), bf(s, mesh + PT_MESH_INNER_C + 1), bf(s, mesh + PT_MESH_INNER_C + 2)), lo);
+    const float dd = dot(ld, ld), tca = dot(oc, ld) / dd;
+    const F3 q = sub(oc, mul(ld, tca));
+    return (dot(q, q) < r * r) & (tca > 0.0f) & (tca + 1.01f * bf(s, mesh + PT_MESH_REACH) / pt_sqrt(dd) < bound);
+}
+
 // Phase 3: the primitive tests of the set bits in pre-order (ties are broken by that order, as in world_hit_walk).  With
 // `park_at_walked` the loop returns true when the next bit is a walked mesh instance, leaving the bit set: the caller
 // parks the state and resumes with sweep_resume; otherwise walked meshes are walked in line.
@@ -1239,6 +1264,10 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
         const F4 be = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS);
         const uint32_t inst = pt_f2u(be.x), triw = pt_f2u(be.y), kf = pt_f2u(be.w);
         if (WALKS && (kf & PT_SWEEP_WALKED)) {  // WALKS = false: the table is known to hold no walked mesh (pure sweep kernels)
+            if (stop == PT_INNER_BALL_STOP && mesh_surely_blocks(s, inst, o, d, __builtin_fminf(bound, st.closest))) {   // (no walk: the mesh is closed and the ray goes through its inside)
+                st.closest = 0.0f; st.best_inst = kf >> 16; st.best_triw = 0u; st.hit = 0;
+                return false;
+            }
             if (park_at_walked) return true;
             st.hit &= st.hit - 1;
             mesh_walk(s, inst, kf >> 16, o, d, bound, stop, st);
@@ -1355,6 +1384,7 @@ PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, S
         else {
             const uint32_t inst = inst_off + shape * PT_INST_WORDS, kind = bu(s, inst + PT_INST_KIND);
             if (kind == PT_SHAPE_MESH) {
+                // (mesh_surely_blocks is not tried here: in the top-level walk's kernels it cost 2 % — G2FG k_shadow_parked 5896 -> 6022 us — even where no ray could take it)
                 if (park_at_mesh) { st.hit = (uint64_t)i + 1ull; return true; }
                 st.hit = (uint64_t)exit_i + 1ull;
                 mesh_walk(s, inst, shape, o, d, bound, stop, st);

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace pth {
@@ -110,6 +112,99 @@ struct BvhBuilder {
         emit(li, lb); emit(ri, rb);
     }
 };
+
+
+// ---- a closed mesh's inner sphere (pt_blob.h PT_MESH_INNER_*), all in f64 -------------------------------------------------------------
+// Closed = every undirected edge (vertices compared by POSITION: OBJ files repeat vertices along seams) belongs to exactly two triangles.  The centre is the point
+// of a 9 x 9 x 9 grid over the bounding box that is farthest from the surface among those at odd crossing parity along three axis rays (all three must agree);
+// the radius 0.98 x its distance to the nearest triangle.  Any failure — an open edge, a degenerate triangle, rays that disagree, a ball smaller than 2 % of the
+// box — and the mesh simply has no ball.
+struct D3 { double x, y, z; };
+static inline D3 d3(const float* p) { return D3{p[0], p[1], p[2]}; }
+static inline D3 dsub(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline double ddot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline D3 dcross(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// squared distance from p to triangle abc (Ericson, Real-Time Collision Detection 5.1.5)
+static double point_triangle_dist2(D3 p, D3 a, D3 b, D3 c) {
+    const D3 ab = dsub(b, a), ac = dsub(c, a), ap = dsub(p, a);
+    const double d1 = ddot(ab, ap), d2 = ddot(ac, ap);
+    auto len2 = [](D3 v) { return ddot(v, v); };
+    if (d1 <= 0 && d2 <= 0) return len2(ap);
+    const D3 bp = dsub(p, b); const double d3_ = ddot(ab, bp), d4 = ddot(ac, bp);
+    if (d3_ >= 0 && d4 <= d3_) return len2(bp);
+    const double vc = d1 * d4 - d3_ * d2;
+    if (vc <= 0 && d1 >= 0 && d3_ <= 0) { const double v = d1 / (d1 - d3_); return len2(dsub(ap, D3{ab.x * v, ab.y * v, ab.z * v})); }
+    const D3 cp = dsub(p, c); const double d5 = ddot(ab, cp), d6 = ddot(ac, cp);
+    if (d6 >= 0 && d5 <= d6) return len2(cp);
+    const double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { const double w = d2 / (d2 - d6); return len2(dsub(ap, D3{ac.x * w, ac.y * w, ac.z * w})); }
+    const double va = d3_ * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3_) >= 0 && (d5 - d6) >= 0) { const double w = (d4 - d3_) / ((d4 - d3_) + (d5 - d6)); const D3 bc = dsub(c, b); return len2(dsub(bp, D3{bc.x * w, bc.y * w, bc.z * w})); }
+    const double denom = 1.0 / (va + vb + vc), v = vb * denom, w = vc * denom;
+    return len2(dsub(ap, D3{ab.x * v + ac.x * w, ab.y * v + ac.y * w, ab.z * v + ac.z * w}));
+}
+// crossings of the ray p + t e_axis, t > 0, with the triangles; -1 if the ray passes within 1e-9 (relative) of an edge or vertex (the caller drops the point)
+static int axis_crossings(D3 p, int axis, const float* V, const uint32_t* ix, uint32_t faces, double scale) {
+    const int u = (axis + 1) % 3, v = (axis + 2) % 3;
+    auto comp = [](D3 q, int k) { return k == 0 ? q.x : (k == 1 ? q.y : q.z); };
+    int n = 0;
+    for (uint32_t f = 0; f < faces; ++f) {
+        const D3 a = d3(V + 3 * ix[3 * f]), b = d3(V + 3 * ix[3 * f + 1]), c = d3(V + 3 * ix[3 * f + 2]);
+        const double pu = comp(p, u), pv = comp(p, v);
+        const double au = comp(a, u) - pu, av = comp(a, v) - pv, bu_ = comp(b, u) - pu, bv = comp(b, v) - pv, cu = comp(c, u) - pu, cv = comp(c, v) - pv;
+        const double e0 = bu_ * cv - bv * cu, e1 = cu * av - cv * au, e2 = au * bv - av * bu_;   // 2D edge functions of the projection
+        const double eps = 1e-9 * scale * scale;
+        const int pos = (e0 > eps) + (e1 > eps) + (e2 > eps), neg = (e0 < -eps) + (e1 < -eps) + (e2 < -eps);
+        if (pos == 3 || neg == 3) {                       // strictly inside the projected triangle: the ray's line crosses the triangle's plane there
+            const double det = e0 + e1 + e2;
+            const double t = (e0 * (comp(a, axis) - comp(p, axis)) + e1 * (comp(b, axis) - comp(p, axis)) + e2 * (comp(c, axis) - comp(p, axis))) / det;
+            if (std::fabs(t) < 1e-9 * scale) return -1;
+            if (t > 0) ++n;
+        } else if (!(pos > 0 && neg > 0)) return -1;      // on, or too close to, an edge, a vertex, or the line of a triangle seen edge-on: this point is not used
+    }
+    return n;
+}
+static bool inner_sphere(const float* V, uint32_t vertex_count, const uint32_t* ix, uint32_t faces, const Box& mb, float* centre, float* radius) {
+    // closedness: edges keyed by the BIT PATTERNS of their end points' positions
+    struct Key { uint32_t a[3], b[3]; bool operator<(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) < 0; } };
+    auto pos = [&](uint32_t v, uint32_t* out) { for (int k = 0; k < 3; ++k) { float x = V[3 * v + k]; if (x == 0.0f) x = 0.0f; std::memcpy(&out[k], &x, 4); } };   // (-0 = +0)
+    std::vector<Key> edges; edges.reserve((size_t)faces * 3);
+    for (uint32_t f = 0; f < faces; ++f)
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t v0 = ix[3 * f + k], v1 = ix[3 * f + (k + 1) % 3];
+            if (v0 >= vertex_count || v1 >= vertex_count) return false;
+            Key e; pos(v0, e.a); pos(v1, e.b);
+            if (std::memcmp(e.a, e.b, 12) == 0) return false;                    // a degenerate edge
+            if (std::memcmp(e.a, e.b, 12) > 0) { uint32_t t[3]; std::memcpy(t, e.a, 12); std::memcpy(e.a, e.b, 12); std::memcpy(e.b, t, 12); }
+            edges.push_back(e);
+        }
+    std::sort(edges.begin(), edges.end());
+    for (size_t i = 0; i < edges.size();) {
+        size_t j = i; while (j < edges.size() && std::memcmp(&edges[j], &edges[i], sizeof(Key)) == 0) ++j;
+        if (j - i != 2) return false;
+        i = j;
+    }
+    const double sx = (double)mb.mx[0] - mb.mn[0], sy = (double)mb.mx[1] - mb.mn[1], sz = (double)mb.mx[2] - mb.mn[2];
+    const double scale = std::fmax(sx, std::fmax(sy, sz));
+    if (!(scale > 0) || !(sx > 0 && sy > 0 && sz > 0)) return false;
+    const int G = 9;
+    double best_r2 = 0; D3 best{0, 0, 0};
+    for (int gx = 0; gx < G; ++gx) for (int gy = 0; gy < G; ++gy) for (int gz = 0; gz < G; ++gz) {
+        // (grid points at irrational-ish offsets, so that axis rays do not run along the seams of symmetric models)
+        const D3 p{mb.mn[0] + sx * (gx + 0.5137) / G, mb.mn[1] + sy * (gy + 0.4871) / G, mb.mn[2] + sz * (gz + 0.5063) / G};
+        double r2 = INFINITY;
+        for (uint32_t f = 0; f < faces && r2 > best_r2; ++f)
+            r2 = std::fmin(r2, point_triangle_dist2(p, d3(V + 3 * ix[3 * f]), d3(V + 3 * ix[3 * f + 1]), d3(V + 3 * ix[3 * f + 2])));
+        if (!(r2 > best_r2)) continue;
+        bool inside = true;
+        for (int axis = 0; axis < 3 && inside; ++axis) { const int n = axis_crossings(p, axis, V, ix, faces, scale); inside = n > 0 && (n & 1) == 1; }
+        if (inside) { best_r2 = r2; best = p; }
+    }
+    const double r = 0.98 * std::sqrt(best_r2);
+    if (!(r > 0.02 * scale)) return false;
+    centre[0] = (float)best.x; centre[1] = (float)best.y; centre[2] = (float)best.z; *radius = (float)(r * 0.9999);
+    return true;
+}
 
 void pad16(std::vector<uint32_t>& w) { while (w.size() % 4) w.push_back(0); }
 
@@ -366,6 +461,16 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
         }
         mesh_off[mi] = (uint32_t)w.size();
         uint32_t rec[PT_MESH_WORDS] = {node_off, (uint32_t)(nodes.size() / PT_NODE_WORDS), tri_off, normal_off, m.face_count, leaf_off, leaf_count, group_off};
+        for (int k = 8; k < PT_MESH_WORDS; ++k) rec[k] = 0u;
+        {   // the inner sphere of a closed mesh without light faces (pt_blob.h PT_MESH_INNER_*)
+            float c[3] = {0.0f, 0.0f, 0.0f}, r = 0.0f;
+            if (mesh_light_faces[mi] == 0 && m.face_count >= 4 && m.face_count <= 200000 && inner_sphere(V, m.vertex_count, d.indices + m.index_offset, m.face_count, mb, c, &r)) {
+                rec[PT_MESH_INNER_C] = fbits(c[0]); rec[PT_MESH_INNER_C + 1] = fbits(c[1]); rec[PT_MESH_INNER_C + 2] = fbits(c[2]); rec[PT_MESH_INNER_R] = fbits(r);
+            }
+            if (getenv("PT_AMD_HOST_VERBOSE")) fprintf(stderr, "mesh %u: %u faces, inner ball centre (%g, %g, %g) radius %g (0 = none)\n", mi, m.face_count, c[0], c[1], c[2], r);
+            const double dx = (double)mb.mx[0] - mb.mn[0], dy = (double)mb.mx[1] - mb.mn[1], dz = (double)mb.mx[2] - mb.mn[2];
+            rec[PT_MESH_REACH] = fbits((float)(std::sqrt(dx * dx + dy * dy + dz * dz) * 1.0001));
+        }
         w.insert(w.end(), rec, rec + PT_MESH_WORDS);
     }
 
