@@ -200,6 +200,27 @@ static bool inner_sphere(const float* V, uint32_t vertex_count, const uint32_t* 
         for (int axis = 0; axis < 3 && inside; ++axis) { const int n = axis_crossings(p, axis, V, ix, faces, scale); inside = n > 0 && (n & 1) == 1; }
         if (inside) { best_r2 = r2; best = p; }
     }
+    if (!(best_r2 > 0)) return false;
+    // refine the centre: a pattern search from the best grid point (the distance field has no other structure to use), steps from a grid cell down to 1e-4 of the box.
+    // A step is taken only to a point that is farther from the surface; it cannot leave the inside: the segment to it stays within the old ball.
+    auto dist2 = [&](D3 p, double stop_below) {
+        double r2 = INFINITY;
+        for (uint32_t f = 0; f < faces && r2 > stop_below; ++f) r2 = std::fmin(r2, point_triangle_dist2(p, d3(V + 3 * ix[3 * f]), d3(V + 3 * ix[3 * f + 1]), d3(V + 3 * ix[3 * f + 2])));
+        return r2;
+    };
+    for (double step = scale / G; step > 1e-4 * scale; step *= 0.5) {
+        for (int tries = 0; tries < 64; ++tries) {
+            bool moved = false;
+            for (int k = 0; k < 6; ++k) {
+                const double s1 = (k & 1) ? -step : step;
+                if (!(step < std::sqrt(best_r2))) break;      // (the new centre must lie inside the present ball)
+                D3 q = best; if (k / 2 == 0) q.x += s1; else if (k / 2 == 1) q.y += s1; else q.z += s1;
+                const double r2 = dist2(q, best_r2);
+                if (r2 > best_r2) { best_r2 = r2; best = q; moved = true; }
+            }
+            if (!moved) break;
+        }
+    }
     const double r = 0.98 * std::sqrt(best_r2);
     if (!(r > 0.02 * scale)) return false;
     centre[0] = (float)best.x; centre[1] = (float)best.y; centre[2] = (float)best.z; *radius = (float)(r * 0.9999);
