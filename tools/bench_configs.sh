@@ -11,7 +11,13 @@ python bench.py --hero 4 --spp-per-step 60 --steps 3 --warmup 1 --cpu-seconds 10
 # G1: not a BASELINE configuration — the reference tree's data/scenes/test_prism.toml (transformed mesh + lights + environment sampling): the general kernel forms
 python bench.py --scene test_prism --max-bounces 8 --light-samples 2 --spp-per-step 120 --steps 3 --warmup 1 --cpu-seconds 10 \
   --workload "G1: test_prism.toml (rect room, xenon SharpLight, prism.obj 836 triangles in dispersive glass under a transform stack, synthetic HDRI, env_sampling_probability 0.1), 1024x1024, max_bounces=8, L=2" > $OUT/G1.json 2> $OUT/G1.err
-for c in C2 C3 C4 C5 G1; do python - <<PY
+# G2: the reference tree's data/scenes/test_bokeh.toml — 82 sphere lights, more than 64 instances: no sweep table, the top-level BVH walk (round-4 verdict, item 1); G2F: the same with a floor
+# (not a reference scene: in G2 every surface is a light and no light-sample ray is ever traced; with the floor the 82-entry light list is sampled)
+python bench.py --scene test_bokeh --max-bounces 8 --light-samples 2 --spp-per-step 120 --steps 3 --warmup 1 --cpu-seconds 10 \
+  --workload "G2: test_bokeh.toml (82 sphere lights of radius 0.01 = no sweep table: the top-level BVH walk; synthetic HDRI strength 0.1, env_sampling_probability 0.5, thin lens 0.1), 1024x1024, max_bounces=8, L=2" > $OUT/G2.json 2> $OUT/G2.err
+python bench.py --scene test_bokeh_floor --max-bounces 8 --light-samples 2 --spp-per-step 120 --steps 3 --warmup 1 --cpu-seconds 10 \
+  --workload "G2F: test_bokeh.toml + a Lambertian floor and three spheres (not a reference scene: the 82-entry light list sampled, light-sample rays through the top-level walk), 1024x1024, max_bounces=8, L=2" > $OUT/G2F.json 2> $OUT/G2F.err
+for c in C2 C3 C4 C5 G1 G2 G2F; do python - <<PY
 import json
 try:
     d=json.loads(open("$OUT/$c.json").read().strip().split("\n")[-1])
