@@ -293,7 +293,8 @@ typedef struct pt_profile {      /* Profile (src/profile.rs:2-8) + timing */
     uint64_t stage_items[8];     /* work items per stage summed over launches: paths generated, segments extended,
                                     vertices shaded, light-sample items traced, pixels accumulated; [5] = tracked mediums a fifth nesting level
                                     dropped (medium-aware walk; 0 = the walk is the reference's); [6] = threads per workgroup of the parked
-                                    kernels when they ran in their big-workgroup form (pt_tuning::park_block), else 0 */
+                                    kernels when they ran in their big-workgroup form (pt_tuning::park_block), else 0; [7] = 1 when the camera
+                                    vertices went through the path queue as lean records (ray + wavelength: 28 of 64 bytes), else 0 */
 } pt_profile;
 
 typedef struct pt_hit {          /* HitRecord (src/hittable.rs:7-16) */

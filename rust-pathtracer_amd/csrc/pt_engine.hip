@@ -421,6 +421,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
         profile->stage_items[ST_GENERATE] = camera_rays; profile->stage_items[ST_EXTEND] = c[BS_SEGMENTS]; profile->stage_items[ST_SHADE] = c[BS_SEGMENTS];
         profile->stage_items[ST_SHADOW] = c[BS_ITEMS]; profile->stage_items[ST_ACCUMULATE] = accumulated_pixels;
         profile->stage_items[6] = (uint64_t)cfg.park_block;   // threads per workgroup of the parked kernels when they ran in their big-workgroup form (pt_tuning::park_block), else 0
+        profile->stage_items[7] = rp.camera_record;     // 1: k_generate wrote the camera vertex' lean record (7 of 16 words) and the first bounce's vertex kernel rebuilt the rest
         profile->stage_items[5] = c[BS_MEDIUM_DROPS];   // the medium-aware walk tracks four nested mediums: what a fifth level lost (0 = the walk is the reference's)
     }
     return PT_OK;
