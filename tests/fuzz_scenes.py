@@ -76,6 +76,17 @@ def random_scene(seed):
                 b.add_sphere(float(rng.uniform(0.05, 0.25)), o3, material(light_ok=False), transform() if rng.random() < 0.2 else None)
             else:
                 b.add_rect(tuple(rng.uniform(0.1, 0.5, 2).tolist()), o3, "XYZ"[rng.integers(3)], True, material(light_ok=False))
+    if seed >= 600000:  # (a seed space of its own, round 5) the scene class of data/scenes/test_bokeh.toml: MANY small lights — more than pt_tuning::light_prepass_max, so that
+        # light-sample rays are plain closest-hit searches — in rows a ray can graze (long, uneven top-level walks: the eviction of a wave's last walkers), more than 64 instances
+        rng4 = np.random.default_rng(seed + 1357)
+        if rng4.random() < 0.6:
+            rows = int(rng4.integers(1, 4)); per = int(rng4.integers(16, 46))
+            z0 = float(rng4.uniform(-1.3, 0.5))
+            for r in range(rows):
+                x0 = float(rng4.uniform(-1.0, 1.0)); radius = float(rng4.choice([0.01, 0.03, 0.08]))
+                for k in range(per):
+                    lit = rng4.random() < 0.8
+                    b.add_sphere(radius, (x0, -4.0 + 8.0 * k / per, z0), lights[int(rng4.integers(len(lights)))] if lit else mats[int(rng4.integers(len(mats)))])
     if rng.random() < 0.3:  # a bigger mesh: the sweep table can no longer inline every triangle (walked mesh, parked rays)
         p, f, n, _ = S._npz_mesh("gem")
         mesh = b.add_mesh(p, f, n, face_materials=api.material_id(api.TAG_MATERIAL, mats[0] & 0xFFFF))
