@@ -1361,7 +1361,19 @@ PT_HD void top_walk_init(SweepState& st) { sweep_state_init(st, 1ull); }
 // 32 steps on average, 124 for the slowest lane of a wave), so once fewer than `evict_below` lanes of the wave are still walking, those leave with their place,
 // are parked like a ray at a mesh and go on in a later wave of 64 such rays (the mesh walk's policy, mesh_walk: pt_tuning::walk_evict_below).  A ray's own
 // sequence of tests is the same; the emulation's one lane leaves at every chance.  0 = never.
-PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, bool park_at_mesh, uint32_t evict_below = 0u, bool* evicted = nullptr) {
+// The loop is a while-while (round 5, second step; PT_TOP_WHILE_WHILE=0 builds the single loop it replaces): box steps until the lane HOLDS a leaf whose box it
+// hits, then the wave's leaf tests together.  In the single loop every step that found ANY lane a leaf ran the shape test — a square root and two divisions for a
+// sphere, ~100 instructions — for that lane alone: with 64 lanes at one leaf per sixteen steps that is nearly every step (G2F: lane utilisation 0.38, 15 000 vector
+// instructions per wave).  `search_below`: the inner loop ends once fewer lanes than this are still searching while others hold a leaf (the mesh walk's rule).
+#ifndef PT_TOP_WHILE_WHILE
+#define PT_TOP_WHILE_WHILE 1
+#endif
+// (the mesh walk's early end of the inner loop LOSES here — G2F k_shadow_parked 2313 us with the single loop, 2267 as a pure while-while, 3200 at 16 and 3660 at 32: a lane that
+// leaves the search early only waits through the others' leaf tests and searches on — so the kernels pass 0; the emulation's one lane passes 1 and leaves at every step)
+#define PT_TOP_SEARCH_BELOW 0u
+PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, bool park_at_mesh, uint32_t evict_below = 0u, bool* evicted = nullptr,
+                        uint32_t search_below = 0u) {
+    const uint32_t NONE = 0xffffffffu;
     const uint32_t flags = bu(s, PT_HDR_FLAGS);
     const uint32_t top_off = bu(s, PT_HDR_TOP_NODE_OFF), top_count = bu(s, PT_HDR_TOP_NODE_COUNT), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
     const bool cull_top = (flags & (PT_FLAG_NO_TOP_CULL | PT_FLAG_NO_CULL)) == 0;
@@ -1371,6 +1383,48 @@ PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, S
     if (evicted != nullptr) *evicted = false;
     if (st.hit == 0) return false;
     uint32_t i = (uint32_t)st.hit - 1u;
+#if PT_TOP_WHILE_WHILE
+    for (;;) {
+        // 1 — box steps only, every lane that is still searching; a lane that holds a leaf waits for the others (or for `search_below`)
+        uint32_t pending = NONE, pend_node = 0u;
+        while (pending == NONE && i < top_count) {
+            const F4 a = bf4(s, top_off + i * PT_NODE_WORDS), b = bf4(s, top_off + i * PT_NODE_WORDS + 4);
+            const uint32_t exit_i = PT_NODE_EXIT(pt_f2u(a.w)), shape = pt_f2u(b.w);
+            float entry;
+            const bool box = walk_box(a, b, wr, wr_quick, &entry) & !(cull_top & !(pt_f2u(a.w) & PT_NODE_NO_CULL) & beyond(entry, __builtin_fminf(st.closest, bound), wr.base));
+            const bool inner = shape == PT_NODE_INNER;
+            pend_node = i;
+            pending = (!inner & box) ? shape : NONE;
+            i = (inner & box) ? i + 1u : exit_i;
+            if (search_below != 0u && PT_WAVE_ACTIVE(0u) < search_below) break;
+        }
+        if (pending == NONE) { if (i >= top_count) break; continue; }   // (done — or the inner loop was left early: search on)
+        // 2 — the leaf this lane holds
+        const uint32_t inst = inst_off + pending * PT_INST_WORDS, kind = bu(s, inst + PT_INST_KIND);
+        if (kind == PT_SHAPE_MESH) {
+            // (mesh_surely_blocks is not tried here: in the top-level walk's kernels it cost 2 % — G2FG k_shadow_parked 5896 -> 6022 us — even where no ray could take it)
+            if (park_at_mesh) { st.hit = (uint64_t)pend_node + 1ull; return true; }
+            st.hit = (uint64_t)i + 1ull;
+            mesh_walk(s, inst, pending, o, d, bound, stop, st);
+            if (st.hit == 0) return false;   // (an early stop inside the mesh)
+        } else {
+            F3 lo, ld;
+            instance_local_ray(s, inst, o, d, &lo, &ld);
+            Hit h;
+            if (analytic_hit(s, inst, kind, lo, ld, st.closest, &h)) {
+                st.closest = h.t; st.best_inst = pending; st.best_triw = 0;
+                bool over = stop == PT_STOP_ANY;
+                if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
+                    const uint32_t im = bu(s, inst + PT_INST_MATERIAL);
+                    over = PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : h.material) != PT_TAG_LIGHT;   // something opaque in front of every light
+                }
+                if (over) { st.hit = 0; return false; }
+            }
+        }
+        // (behind a leaf, so that a resumed ray always moves on; a ray on its last node is not worth a parked entry)
+        if (evict_below != 0u && i < top_count && PT_WAVE_ACTIVE(0u) < evict_below) { st.hit = (uint64_t)i + 1ull; *evicted = true; return true; }
+    }
+#else
     while (i < top_count) {
         const F4 a = bf4(s, top_off + i * PT_NODE_WORDS), b = bf4(s, top_off + i * PT_NODE_WORDS + 4);
         const uint32_t exit_i = PT_NODE_EXIT(pt_f2u(a.w)), shape = pt_f2u(b.w);
@@ -1384,7 +1438,6 @@ PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, S
         else {
             const uint32_t inst = inst_off + shape * PT_INST_WORDS, kind = bu(s, inst + PT_INST_KIND);
             if (kind == PT_SHAPE_MESH) {
-                // (mesh_surely_blocks is not tried here: in the top-level walk's kernels it cost 2 % — G2FG k_shadow_parked 5896 -> 6022 us — even where no ray could take it)
                 if (park_at_mesh) { st.hit = (uint64_t)i + 1ull; return true; }
                 st.hit = (uint64_t)exit_i + 1ull;
                 mesh_walk(s, inst, shape, o, d, bound, stop, st);
@@ -1409,6 +1462,7 @@ PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, S
         // (behind a step, so that a resumed ray always moves on; a ray on its last node is not worth a parked entry)
         if (evict_below != 0u && i < top_count && PT_WAVE_ACTIVE(0u) < evict_below) { st.hit = (uint64_t)i + 1ull; *evicted = true; return true; }
     }
+#endif
     st.hit = 0;
     return false;
 }
@@ -1435,7 +1489,7 @@ PT_HD bool top_walk_resume(const SceneView& s, F3 o, F3 d, float bound, int stop
     if (!alive) return false;
     *cursor = 0u;
     bool evicted = false;
-    const bool parked = top_walk_run(s, o, d, bound, stop, st, true, (policy >> 24) & 0xffu, &evicted);
+    const bool parked = top_walk_run(s, o, d, bound, stop, st, true, (policy >> 24) & 0xffu, &evicted, (policy >> 8) & 0xffu ? PT_TOP_SEARCH_BELOW : 0u);
     if (evicted) *cursor = PT_TOP_EVICTED;
     return parked;
 }
@@ -1757,7 +1811,7 @@ PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_
         top_walk_init(st);
         uint32_t cursor = 0u;
         bool evicted = false;
-        bool parked = top_walk_run(s, o, d, bound, stop, st, true, 1u, &evicted);   // (evict_below 1 against the emulation's 0 active lanes: the ray leaves after every step)
+        bool parked = top_walk_run(s, o, d, bound, stop, st, true, 1u, &evicted, 1u);   // (evict_below / search_below 1 against the emulation's 0 active lanes: the ray leaves at every chance)
         if (evicted) cursor = PT_TOP_EVICTED;
         while (parked) parked = top_walk_resume(s, o, d, bound, stop, st, &cursor, 0x01000201u | PT_WALK_SCAN_AXIS, true);
         if (LIGHT_ONLY && st.best_inst != 0xffffffffu && !sweep_best_is_light(s, st)) { out->valid = true; out->material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); return true; }
