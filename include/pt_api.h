@@ -276,7 +276,7 @@ typedef struct pt_tuning {
                                      plain closest-hit search instead (test_bokeh.toml: 82 lights).  0 = the default (16); 0xffffffff = always bound */
     uint32_t top_evict_below;     /* PT_AMD_TOP_EVICT_BELOW: scenes without a sweep table (more than 64 instances) walk the top-level tree lane by lane; once fewer lanes
                                      of a wave than this are still walking, those leave with their place, are parked like a ray at a mesh and go on in a later wave of 64
-                                     such rays.  1 = never, at most 64; 0 = the default (32 for a scene of more than 64 instances without a mesh, else never) */
+                                     such rays.  1 = never, at most 64; 0 = the default (48 for a scene of more than 64 instances without a mesh, else never) */
     uint32_t reserved[3];         /* must be 0 */
 } pt_tuning;
 /* The defaults, overridden by whatever PT_AMD_* variables the environment holds at the time of the call. */

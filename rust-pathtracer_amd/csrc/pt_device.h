@@ -1371,6 +1371,11 @@ PT_HD void top_walk_init(SweepState& st) { sweep_state_init(st, 1ull); }
 // (the mesh walk's early end of the inner loop LOSES here — G2F k_shadow_parked 2313 us with the single loop, 2267 as a pure while-while, 3200 at 16 and 3660 at 32: a lane that
 // leaves the search early only waits through the others' leaf tests and searches on — so the kernels pass 0; the emulation's one lane passes 1 and leaves at every step)
 #define PT_TOP_SEARCH_BELOW 0u
+// (an eviction check INSIDE the search loop — most of G2F's light rays never hold a leaf and so never reach the check behind a leaf test — was measured and lost badly: the
+// second exit from the inner loop costs the loop itself, k_shadow_parked 2545 -> 3675 us with eviction off, 2235 -> 2266 at 32: profiles/r5_experiments.md section 10)
+#ifndef PT_TOP_EVICT_IN_SEARCH
+#define PT_TOP_EVICT_IN_SEARCH 0
+#endif
 PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, bool park_at_mesh, uint32_t evict_below = 0u, bool* evicted = nullptr,
                         uint32_t search_below = 0u) {
     const uint32_t NONE = 0xffffffffu;
@@ -1396,7 +1401,12 @@ PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, S
             pend_node = i;
             pending = (!inner & box) ? shape : NONE;
             i = (inner & box) ? i + 1u : exit_i;
-            if (search_below != 0u && PT_WAVE_ACTIVE(0u) < search_below) break;
+#if !defined(__HIP_DEVICE_COMPILE__)
+            if (search_below != 0u && PT_WAVE_ACTIVE(0u) < search_below) break;   // (the emulation only: PT_TOP_SEARCH_BELOW — no scalar compare-and-branch per step in the kernels)
+#endif
+            // (the wave's last searchers leave from inside the search too: most of G2F's light rays never hold a leaf — 2.2 leaf rounds in a wave's 61 steps — and would never
+            // reach the check behind a leaf test, below)
+            if (PT_TOP_EVICT_IN_SEARCH && evict_below != 0u && pending == NONE && i < top_count && PT_WAVE_ACTIVE(0u) < evict_below) { st.hit = (uint64_t)i + 1ull; *evicted = true; return true; }
         }
         if (pending == NONE) { if (i >= top_count) break; continue; }   // (done — or the inner loop was left early: search on)
         // 2 — the leaf this lane holds
