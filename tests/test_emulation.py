@@ -143,6 +143,58 @@ def test_light_prepass_changes_nothing(emu, pkg, monkeypatch, scene, L, hero):
         assert counts == results[0][1]
 
 
+def _inner_ball(emu, b):
+    sc = emu.create_scene(b)
+    w = [int(sc.library._debug_scene_info(sc.handle, k)) for k in range(8, 13)]
+    f = np.array(w, np.uint32).view(np.float32)
+    return f[:3].astype(np.float64), float(f[3]), float(f[4])
+
+
+@pytest.mark.parametrize("mesh", ["brilliant_diamond", "monkey", "prism", "gem"])
+def test_closed_meshes_get_an_inner_ball(emu, pkg, mesh):
+    """mesh_surely_blocks (pt_device.h) rests on what the host found: a ball strictly INSIDE a closed mesh.  Checked here with arithmetic of its own (numpy, f64): the surface is
+    closed (every undirected edge, by position, in exactly two triangles), every triangle is farther from the centre than the radius, and the centre is inside — an odd
+    number of crossings along seven random rays."""
+    p, f, n, mtl = pkg.scene._npz_mesh(mesh)
+    p = np.asarray(p, np.float64).reshape(-1, 3); f = np.asarray(f).reshape(-1, 3)
+    b = pkg.scene.hdri_test(mesh=None, hdri_size=(16, 8), importance=(0, 0))
+    m = b.add_mesh(p.astype(np.float32), f, None, face_materials=pkg.api.material_id(pkg.api.TAG_MATERIAL, 0))
+    b.add_mesh_instance(m, None, None)
+    c, r, reach = _inner_ball(emu, b)
+    assert r > 0.02 * (p.max(0) - p.min(0)).max(), (mesh, r)
+    assert abs(reach - np.linalg.norm(p.max(0) - p.min(0))) < 1e-3 * reach
+    tri = p.astype(np.float32).astype(np.float64)[f]                      # the vertices as the engine holds them
+    rng = np.random.default_rng(5)
+    for _ in range(7):   # crossing parity along random directions (independent of the faces' orientation: the authored test mesh mixes windings): odd = inside
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        e1, e2 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+        pv = np.cross(d, e2); det = np.einsum("ij,ij->i", e1, pv)
+        ok = np.abs(det) > 1e-14
+        tv = c - tri[:, 0]
+        u = np.einsum("ij,ij->i", tv, pv) / np.where(ok, det, 1.0)
+        qv = np.cross(tv, e1)
+        v = (qv @ d) / np.where(ok, det, 1.0)
+        t = np.einsum("ij,ij->i", e2, qv) / np.where(ok, det, 1.0)
+        assert not (ok & ((np.abs(u) < 1e-9) | (np.abs(v) < 1e-9) | (np.abs(1 - u - v) < 1e-9)) & (t > 0)).any()   # (no crossing through an edge with these seeds)
+        crossings = int((ok & (u > 0) & (v > 0) & (u + v < 1) & (t > 0)).sum())
+        assert crossings % 2 == 1, (mesh, crossings)
+    # distance from the centre to every triangle: not below r / 0.98 (the host's shrink), checked through dense samples of each triangle (barycentric grid) — an upper bound of the true distance
+    g = np.array([(i, j, 12 - i - j) for i in range(13) for j in range(13 - i)], np.float64) / 12.0
+    pts = np.einsum("gk,tkx->tgx", g, tri).reshape(-1, 3)
+    assert np.linalg.norm(pts - c, axis=1).min() >= r / 0.98 * (1.0 - 1e-4), (mesh, r)
+
+
+def test_an_open_mesh_gets_no_inner_ball(emu, pkg):
+    """One triangle missing: three edges with a single triangle — no inside to speak of.  (A mesh with a light among its faces cannot be created at all, mesh.rs:213-232; a
+    mesh INSTANCE overridden with a light keeps its ball and mesh_surely_blocks looks at the instance's material: scene.hdri_emissive_mesh in the film cases.)"""
+    p, f, n, mtl = pkg.scene._npz_mesh("gem")
+    f = np.asarray(f).reshape(-1, 3)
+    b = pkg.scene.hdri_test(mesh=None, hdri_size=(16, 8), importance=(0, 0))
+    m = b.add_mesh(p, f[:-1], None, face_materials=pkg.api.material_id(pkg.api.TAG_MATERIAL, 0))
+    b.add_mesh_instance(m, None, None)
+    assert _inner_ball(emu, b)[1] == 0.0
+
+
 def test_reference_known_answers_on_the_lane_logic(emu, oracle, pkg):
     """The reference's own known-answer tests for the path, which tests/test_oracle.py runs on the oracle, on the
     engine's lane logic; tests/test_gpu_parity.py runs the same list on the GPU."""
