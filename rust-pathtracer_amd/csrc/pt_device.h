@@ -1230,7 +1230,7 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
 // which is all such a search wants to know (PT_STOP_NONLIGHT, PT_STOP_ANY: the callers read "a light or not", never the occluder's record).  The ball was shrunk by
 // 2 % on the host; the test runs in the instance's own space with the un-normalised direction, t is the world ray's parameter.
 #ifndef PT_INNER_BALL
-#define PT_INNER_BALL 1
+#define PT_INNER_BALL 2   /* 0: never; 1: the first ball alone; 2: the further balls too (PT_MESH_MORE_*) */
 #endif
 // (which searches try it: the light rays — bounded, PT_STOP_NONLIGHT: C3 k_shadow_parked 3783 -> 3558 us.  Environment rays too (PT_STOP_ANY) was measured on C4, whose
 // light samples are all of that kind: k_shadow_parked 2904 -> 2929 us — a ray that leaves the monkey's surface for the sky seldom passes through its inside)
@@ -1243,10 +1243,20 @@ PT_HD bool mesh_surely_blocks(const SceneView& s, uint32_t inst, F3 o, F3 d, flo
     if (!(r > 0.0f) || (im != PT_MATERIAL_NONE && PT_MATERIAL_TAG(im) == PT_TAG_LIGHT)) return false;
     F3 lo, ld;
     instance_local_ray(s, inst, o, d, &lo, &ld);
-    const F3 oc = sub(f3(bf(s, mesh + PT_MESH_INNER_C), bf(s, mesh + PT_MESH_INNER_C + 1), bf(s, mesh + PT_MESH_INNER_C + 2)), lo);
-    const float dd = dot(ld, ld), tca = dot(oc, ld) / dd;
-    const F3 q = sub(oc, mul(ld, tca));
-    return (dot(q, q) < r * r) & (tca > 0.0f) & (tca + 1.01f * bf(s, mesh + PT_MESH_REACH) / pt_sqrt(dd) < bound);
+    const float dd = dot(ld, ld), far = 1.01f * bf(s, mesh + PT_MESH_REACH) / pt_sqrt(dd);
+    auto through = [&](F3 c, float rr) {
+        const F3 oc = sub(c, lo);
+        const float tca = dot(oc, ld) / dd;
+        const F3 q = sub(oc, mul(ld, tca));
+        return (dot(q, q) < rr * rr) & (tca > 0.0f) & (tca + far < bound);
+    };
+    bool blocks = through(f3(bf(s, mesh + PT_MESH_INNER_C), bf(s, mesh + PT_MESH_INNER_C + 1), bf(s, mesh + PT_MESH_INNER_C + 2)), r);
+#if PT_INNER_BALL > 1
+    // (the further balls: a ball is an inside point of its own — the same argument; the loop's addresses are the wave's when the rays stand at the same mesh)
+    const uint32_t more = bu(s, mesh + PT_MESH_MORE_OFF), n = bu(s, mesh + PT_MESH_MORE_COUNT);
+    for (uint32_t k = 0; k < n; ++k) { const F4 b = bf4(s, more + 4u * k); blocks = blocks | through(f3(b.x, b.y, b.z), b.w); }
+#endif
+    return blocks;
 }
 
 // Phase 3: the primitive tests of the set bits in pre-order (ties are broken by that order, as in world_hit_walk).  With

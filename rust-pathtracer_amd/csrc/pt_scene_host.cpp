@@ -164,7 +164,7 @@ static int axis_crossings(D3 p, int axis, const float* V, const uint32_t* ix, ui
     }
     return n;
 }
-static bool inner_sphere(const float* V, uint32_t vertex_count, const uint32_t* ix, uint32_t faces, const Box& mb, float* centre, float* radius) {
+static bool inner_sphere(const float* V, uint32_t vertex_count, const uint32_t* ix, uint32_t faces, const Box& mb, float* centre, float* radius, std::vector<float>* more = nullptr) {
     // closedness: edges keyed by the BIT PATTERNS of their end points' positions
     struct Key { uint32_t a[3], b[3]; bool operator<(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) < 0; } };
     auto pos = [&](uint32_t v, uint32_t* out) { for (int k = 0; k < 3; ++k) { float x = V[3 * v + k]; if (x == 0.0f) x = 0.0f; std::memcpy(&out[k], &x, 4); } };   // (-0 = +0)
@@ -189,16 +189,22 @@ static bool inner_sphere(const float* V, uint32_t vertex_count, const uint32_t* 
     if (!(scale > 0) || !(sx > 0 && sy > 0 && sz > 0)) return false;
     const int G = 9;
     double best_r2 = 0; D3 best{0, 0, 0};
+    struct Cand { D3 p; double r2; };
+    std::vector<Cand> inside_points;   // (every inside grid point with its distance: the candidates of the further balls, below)
+    const bool want_more = more != nullptr && faces <= 20000;
     for (int gx = 0; gx < G; ++gx) for (int gy = 0; gy < G; ++gy) for (int gz = 0; gz < G; ++gz) {
         // (grid points at irrational-ish offsets, so that axis rays do not run along the seams of symmetric models)
         const D3 p{mb.mn[0] + sx * (gx + 0.5137) / G, mb.mn[1] + sy * (gy + 0.4871) / G, mb.mn[2] + sz * (gz + 0.5063) / G};
         double r2 = INFINITY;
-        for (uint32_t f = 0; f < faces && r2 > best_r2; ++f)
+        const double stop_below = want_more ? 0.0 : best_r2;
+        for (uint32_t f = 0; f < faces && r2 > stop_below; ++f)
             r2 = std::fmin(r2, point_triangle_dist2(p, d3(V + 3 * ix[3 * f]), d3(V + 3 * ix[3 * f + 1]), d3(V + 3 * ix[3 * f + 2])));
-        if (!(r2 > best_r2)) continue;
+        if (!(r2 > (want_more ? 1e-6 * scale * scale : best_r2))) continue;
         bool inside = true;
         for (int axis = 0; axis < 3 && inside; ++axis) { const int n = axis_crossings(p, axis, V, ix, faces, scale); inside = n > 0 && (n & 1) == 1; }
-        if (inside) { best_r2 = r2; best = p; }
+        if (!inside) continue;
+        if (want_more) inside_points.push_back(Cand{p, r2});
+        if (r2 > best_r2) { best_r2 = r2; best = p; }
     }
     if (!(best_r2 > 0)) return false;
     // refine the centre: a pattern search from the best grid point (the distance field has no other structure to use), steps from a grid cell down to 1e-4 of the box.
@@ -224,6 +230,24 @@ static bool inner_sphere(const float* V, uint32_t vertex_count, const uint32_t* 
     const double r = 0.98 * std::sqrt(best_r2);
     if (!(r > 0.02 * scale)) return false;
     centre[0] = (float)best.x; centre[1] = (float)best.y; centre[2] = (float)best.z; *radius = (float)(r * 0.9999);
+    // Further balls (at most PT_MESH_MORE_BALLS): greedily the inside grid point farthest from the surface whose CENTRE lies outside every ball taken so far — a
+    // ball somewhere else in the body — as long as it is at least a quarter of the first one's radius.  (What they buy was priced on C3's rays before it was built:
+    // the first ball catches 24 % of the blocked rays that enter the gem's box, eight balls 58 %.)
+    if (want_more) {
+        std::vector<D3> centres{best}; std::vector<double> radii{r};
+        while (centres.size() < 1 + PT_MESH_MORE_BALLS) {
+            const Cand* pick = nullptr;
+            for (const Cand& c : inside_points) {
+                bool outside_all = true;
+                for (size_t k = 0; k < centres.size() && outside_all; ++k) { const D3 dd = dsub(c.p, centres[k]); outside_all = ddot(dd, dd) > radii[k] * radii[k]; }
+                if (outside_all && (pick == nullptr || c.r2 > pick->r2)) pick = &c;
+            }
+            if (pick == nullptr || !(0.98 * std::sqrt(pick->r2) >= 0.25 * r)) break;
+            const double rr = 0.98 * std::sqrt(pick->r2);
+            centres.push_back(pick->p); radii.push_back(rr);
+            more->push_back((float)pick->p.x); more->push_back((float)pick->p.y); more->push_back((float)pick->p.z); more->push_back((float)(rr * 0.9999));
+        }
+    }
     return true;
 }
 
@@ -485,8 +509,15 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
         for (int k = 8; k < PT_MESH_WORDS; ++k) rec[k] = 0u;
         {   // the inner sphere of a closed mesh without light faces (pt_blob.h PT_MESH_INNER_*)
             float c[3] = {0.0f, 0.0f, 0.0f}, r = 0.0f;
-            if (mesh_light_faces[mi] == 0 && m.face_count >= 4 && m.face_count <= 200000 && inner_sphere(V, m.vertex_count, d.indices + m.index_offset, m.face_count, mb, c, &r)) {
+            std::vector<float> more;
+            if (mesh_light_faces[mi] == 0 && m.face_count >= 4 && m.face_count <= 200000 && inner_sphere(V, m.vertex_count, d.indices + m.index_offset, m.face_count, mb, c, &r, &more)) {
                 rec[PT_MESH_INNER_C] = fbits(c[0]); rec[PT_MESH_INNER_C + 1] = fbits(c[1]); rec[PT_MESH_INNER_C + 2] = fbits(c[2]); rec[PT_MESH_INNER_R] = fbits(r);
+                if (!more.empty()) {   // (in the core section, in front of the record: four words a ball)
+                    pad16(w);
+                    rec[PT_MESH_MORE_OFF] = (uint32_t)w.size(); rec[PT_MESH_MORE_COUNT] = (uint32_t)(more.size() / 4);
+                    for (float x : more) w.push_back(fbits(x));
+                    mesh_off[mi] = (uint32_t)w.size();
+                }
             }
             if (getenv("PT_AMD_HOST_VERBOSE")) fprintf(stderr, "mesh %u: %u faces, inner ball centre (%g, %g, %g) radius %g (0 = none)\n", mi, m.face_count, c[0], c[1], c[2], r);
             const double dx = (double)mb.mx[0] - mb.mn[0], dy = (double)mb.mx[1] - mb.mn[1], dz = (double)mb.mx[2] - mb.mn[2];
