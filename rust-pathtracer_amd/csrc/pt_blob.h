@@ -53,7 +53,12 @@
 #define PT_MESH_REACH 12
 #define PT_MESH_MORE_OFF 13      /* further inner balls of the mesh (core section; four words each: centre, radius), 0 = none */
 #define PT_MESH_MORE_COUNT 14
+#ifndef PT_MESH_MORE_BALLS
 #define PT_MESH_MORE_BALLS 7u
+#endif
+#ifndef PT_MESH_MORE_MIN
+#define PT_MESH_MORE_MIN 0.25   /* a further ball is at least this fraction of the first one's radius */
+#endif
 #ifndef PT_MESH_GROUP
 #define PT_MESH_GROUP 6   /* (measured on C3's gem, 302 leaves: k_extend_parked 4400 / 4190 / 3875 / 3605 / 3520 us at 16 / 12 / 8 / 6 / 5 leaves per group) */
 #endif

@@ -242,7 +242,7 @@ static bool inner_sphere(const float* V, uint32_t vertex_count, const uint32_t* 
                 for (size_t k = 0; k < centres.size() && outside_all; ++k) { const D3 dd = dsub(c.p, centres[k]); outside_all = ddot(dd, dd) > radii[k] * radii[k]; }
                 if (outside_all && (pick == nullptr || c.r2 > pick->r2)) pick = &c;
             }
-            if (pick == nullptr || !(0.98 * std::sqrt(pick->r2) >= 0.25 * r)) break;
+            if (pick == nullptr || !(0.98 * std::sqrt(pick->r2) >= PT_MESH_MORE_MIN * r)) break;
             const double rr = 0.98 * std::sqrt(pick->r2);
             centres.push_back(pick->p); radii.push_back(rr);
             more->push_back((float)pick->p.x); more->push_back((float)pick->p.y); more->push_back((float)pick->p.z); more->push_back((float)(rr * 0.9999));

@@ -1,6 +1,6 @@
 #!/bin/bash
-OUT=gpurun_out/r5t_balls.txt; : > $OUT
+OUT=gpurun_out/r5t3_balls.txt; : > $OUT
 C3="--scene cornell_gem --width 1920 --height 1080 --max-bounces 12 --spp-per-step 60"
 G1="--scene test_prism --max-bounces 8 --light-samples 2 --spp-per-step 120"
-bash tools/ab_libs.sh "variants/balls1.so variants/balls2.so" -- $C3 ";;" $G1 >> $OUT 2>&1
+bash tools/ab_libs.sh "variants/b03.so variants/b05.so variants/b07.so variants/b10.so" -- $C3 ";;" $G1 >> $OUT 2>&1
 cat $OUT
