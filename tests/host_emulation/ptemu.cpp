@@ -34,7 +34,8 @@ uint32_t ptemu_debug_scene_info(pt_scene* sc, int what) {
     const std::vector<uint32_t>& w = sc->host.blob;
     if (what == 0) return (uint32_t)w.size() * 4u;          // bytes of the blob
     if (what == 7) return w[PT_HDR_CORE_WORDS] * 4u;        // bytes of its core section
-    if (what >= 8 && what <= 12) {   // the inner ball of the first mesh instance's mesh (pt_blob.h PT_MESH_INNER_*): 8..10 centre, 11 radius, 12 reach — float bits; 0 = no mesh
+    if (what >= 1000000) return (size_t)(what - 1000000) < w.size() ? w[(size_t)(what - 1000000)] : 0u;   // a word of the blob
+    if (what >= 8 && what <= 14) {   // the inner ball of the first mesh instance's mesh (pt_blob.h PT_MESH_INNER_*): 8..10 centre, 11 radius, 12 reach — float bits —, 13 / 14 the further balls' list (blob word offset, count); 0 = no mesh
         for (uint32_t i = 0; i < w[PT_HDR_INSTANCE_COUNT]; ++i) {
             const uint32_t inst = w[PT_HDR_INSTANCE_OFF] + i * PT_INST_WORDS;
             if (w[inst + PT_INST_KIND] == (uint32_t)PT_SHAPE_MESH) return w[w[inst + PT_INST_MESH] + (uint32_t)what];

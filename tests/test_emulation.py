@@ -143,11 +143,16 @@ def test_light_prepass_changes_nothing(emu, pkg, monkeypatch, scene, L, hero):
         assert counts == results[0][1]
 
 
-def _inner_ball(emu, b):
+def _inner_ball(emu, b, every=False):
     sc = emu.create_scene(b)
-    w = [int(sc.library._debug_scene_info(sc.handle, k)) for k in range(8, 13)]
-    f = np.array(w, np.uint32).view(np.float32)
-    return f[:3].astype(np.float64), float(f[3]), float(f[4])
+    info = lambda k: int(sc.library._debug_scene_info(sc.handle, k))
+    f = np.array([info(k) for k in range(8, 13)], np.uint32).view(np.float32)
+    balls = [(f[:3].astype(np.float64), float(f[3]))]
+    off, count = info(13), info(14)
+    for k in range(count):   # the further balls (pt_blob.h PT_MESH_MORE_*)
+        q = np.array([info(1000000 + off + 4 * k + j) for j in range(4)], np.uint32).view(np.float32)
+        balls.append((q[:3].astype(np.float64), float(q[3])))
+    return (balls, float(f[4])) if every else (balls[0][0], balls[0][1], float(f[4]))
 
 
 @pytest.mark.parametrize("mesh", ["brilliant_diamond", "monkey", "prism", "gem"])
@@ -160,28 +165,31 @@ def test_closed_meshes_get_an_inner_ball(emu, pkg, mesh):
     b = pkg.scene.hdri_test(mesh=None, hdri_size=(16, 8), importance=(0, 0))
     m = b.add_mesh(p.astype(np.float32), f, None, face_materials=pkg.api.material_id(pkg.api.TAG_MATERIAL, 0))
     b.add_mesh_instance(m, None, None)
-    c, r, reach = _inner_ball(emu, b)
-    assert r > 0.02 * (p.max(0) - p.min(0)).max(), (mesh, r)
+    balls, reach = _inner_ball(emu, b, every=True)
+    assert balls[0][1] > 0.02 * (p.max(0) - p.min(0)).max(), (mesh, balls[0][1])
+    assert 1 <= len(balls) <= 8 and all(r >= 0.25 * 0.98 * balls[0][1] for _, r in balls), [r for _, r in balls]
     assert abs(reach - np.linalg.norm(p.max(0) - p.min(0))) < 1e-3 * reach
     tri = p.astype(np.float32).astype(np.float64)[f]                      # the vertices as the engine holds them
-    rng = np.random.default_rng(5)
-    for _ in range(7):   # crossing parity along random directions (independent of the faces' orientation: the authored test mesh mixes windings): odd = inside
-        d = rng.normal(size=3); d /= np.linalg.norm(d)
-        e1, e2 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
-        pv = np.cross(d, e2); det = np.einsum("ij,ij->i", e1, pv)
-        ok = np.abs(det) > 1e-14
-        tv = c - tri[:, 0]
-        u = np.einsum("ij,ij->i", tv, pv) / np.where(ok, det, 1.0)
-        qv = np.cross(tv, e1)
-        v = (qv @ d) / np.where(ok, det, 1.0)
-        t = np.einsum("ij,ij->i", e2, qv) / np.where(ok, det, 1.0)
-        assert not (ok & ((np.abs(u) < 1e-9) | (np.abs(v) < 1e-9) | (np.abs(1 - u - v) < 1e-9)) & (t > 0)).any()   # (no crossing through an edge with these seeds)
-        crossings = int((ok & (u > 0) & (v > 0) & (u + v < 1) & (t > 0)).sum())
-        assert crossings % 2 == 1, (mesh, crossings)
-    # distance from the centre to every triangle: not below r / 0.98 (the host's shrink), checked through dense samples of each triangle (barycentric grid) — an upper bound of the true distance
     g = np.array([(i, j, 12 - i - j) for i in range(13) for j in range(13 - i)], np.float64) / 12.0
-    pts = np.einsum("gk,tkx->tgx", g, tri).reshape(-1, 3)
-    assert np.linalg.norm(pts - c, axis=1).min() >= r / 0.98 * (1.0 - 1e-4), (mesh, r)
+    pts = np.einsum("gk,tkx->tgx", g, tri).reshape(-1, 3)                 # dense samples of every triangle
+    rng = np.random.default_rng(5)
+    for c, r in balls:
+        for _ in range(7):   # crossing parity along random directions (independent of the faces' orientation: the authored test mesh mixes windings): odd = inside
+            d = rng.normal(size=3); d /= np.linalg.norm(d)
+            e1, e2 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+            pv = np.cross(d, e2); det = np.einsum("ij,ij->i", e1, pv)
+            ok = np.abs(det) > 1e-14
+            tv = c - tri[:, 0]
+            u = np.einsum("ij,ij->i", tv, pv) / np.where(ok, det, 1.0)
+            qv = np.cross(tv, e1)
+            v = (qv @ d) / np.where(ok, det, 1.0)
+            t = np.einsum("ij,ij->i", e2, qv) / np.where(ok, det, 1.0)
+            crossings = int((ok & (u > 0) & (v > 0) & (u + v < 1) & (t > 0)).sum())
+            assert crossings % 2 == 1, (mesh, crossings)
+        # no triangle comes closer to the centre than r / 0.98 (the host's shrink): the samples' distances bound the true distance from above
+        assert np.linalg.norm(pts - c, axis=1).min() >= r / 0.98 * (1.0 - 1e-4), (mesh, r)
+    for i, (ci, ri) in enumerate(balls):   # a further ball's centre lies outside the balls before it: a ball somewhere else in the body
+        assert all(np.linalg.norm(ci - cj) > rj * 0.999 for cj, rj in balls[:i])
 
 
 def test_an_open_mesh_gets_no_inner_ball(emu, pkg):
