@@ -1235,6 +1235,9 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
 // (which searches try it: the light rays — bounded, PT_STOP_NONLIGHT: C3 k_shadow_parked 3783 -> 3558 us.  Environment rays too (PT_STOP_ANY) was measured on C4, whose
 // light samples are all of that kind: k_shadow_parked 2904 -> 2929 us — a ray that leaves the monkey's surface for the sky seldom passes through its inside)
 #define PT_INNER_BALL_STOP PT_STOP_NONLIGHT
+#ifndef PT_INNER_BALL_ANY
+#define PT_INNER_BALL_ANY 0   /* 1: environment rays (PT_STOP_ANY) try the balls too */
+#endif
 PT_HD bool mesh_surely_blocks(const SceneView& s, uint32_t inst, F3 o, F3 d, float bound) {
     if (!PT_INNER_BALL) return false;
     const uint32_t mesh = bu(s, inst + PT_INST_MESH);
@@ -1274,7 +1277,7 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
         const F4 be = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS);
         const uint32_t inst = pt_f2u(be.x), triw = pt_f2u(be.y), kf = pt_f2u(be.w);
         if (WALKS && (kf & PT_SWEEP_WALKED)) {  // WALKS = false: the table is known to hold no walked mesh (pure sweep kernels)
-            if (stop == PT_INNER_BALL_STOP && mesh_surely_blocks(s, inst, o, d, __builtin_fminf(bound, st.closest))) {   // (no walk: the mesh is closed and the ray goes through its inside)
+            if ((stop == PT_INNER_BALL_STOP || (PT_INNER_BALL_ANY && stop == PT_STOP_ANY)) && mesh_surely_blocks(s, inst, o, d, __builtin_fminf(bound, st.closest))) {   // (no walk: the mesh is closed and the ray goes through its inside)
                 st.closest = 0.0f; st.best_inst = kf >> 16; st.best_triw = 0u; st.hit = 0;
                 return false;
             }
