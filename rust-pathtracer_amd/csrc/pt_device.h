@@ -1262,6 +1262,52 @@ PT_HD bool mesh_surely_blocks(const SceneView& s, uint32_t inst, F3 o, F3 d, flo
     return blocks;
 }
 
+// A ray that enters a mesh's bounding box may still miss the mesh by a wide margin — the box's corners are empty (round 5; pt_blob.h PT_MESH_DOP_*).  The host keeps the
+// mesh's extent along ten more directions (face and body diagonals: with the box a 26-DOP), widened by 1e-3 of each slab's width; a ray whose segment (0, limit) lies
+// outside one of those slabs passes no triangle within 1e-3 of the mesh's size — forty times what the arithmetic of this test and of the triangle test can move anything —
+// so every triangle test the reference would run on it fails: the mesh is skipped, no park, no walk.  In the instance's own space, un-normalised direction (t is the world
+// ray's).  For every kind of search (a skipped mesh has no hit to offer to any of them).
+#ifndef PT_MESH_DOP
+#define PT_MESH_DOP 1   /* 0: never; 1: the six face diagonals; 2: the four body diagonals too (measured: the four more cost every kernel more than they skip) */
+#endif
+// Which searches try it, per kernel family (a translation unit each).  The closest-hit kernels: every ray (k_extend_parked -3 % on C3 and G1, -4 % on C4).  The light-sample
+// kernels (PT_MESH_DOP_ONLY_ANY, set by pt_kern_shadow.hip): environment rays only (C4 k_shadow_parked -7 %) — a bounded light ray that crosses a corner of the box leaves
+// the BVH after a node or two anyway, and the ten slabs cost its kernel more than those walks (C3 +3 %, G1 +3 %, G2FG +3 %).
+#ifndef PT_MESH_DOP_ONLY_ANY
+#define PT_MESH_DOP_ONLY_ANY 0
+#endif
+#define PT_MESH_DOP_TRIES(stop) (!PT_MESH_DOP_ONLY_ANY || (stop) == PT_STOP_ANY)
+#ifndef PT_MESH_DOP_TOP
+#define PT_MESH_DOP_TOP 1   /* the top-level walk's kernels try it too */
+#endif
+PT_HD bool mesh_surely_missed(const SceneView& s, uint32_t inst, F3 o, F3 d, float limit) {
+    if (!PT_MESH_DOP) return false;
+    const uint32_t dop = bu(s, bu(s, inst + PT_INST_MESH) + PT_MESH_DOP_OFF);
+    if (dop == 0u) return false;
+    F3 lo, ld;
+    instance_local_ray(s, inst, o, d, &lo, &ld);
+    const float far = bf(s, dop + 2u * PT_MESH_DOP_DIRS);
+    float t0 = 0.0f, t1 = limit;
+    bool apart = false, trusted = true;
+    auto slab = [&](uint32_t k, float so, float sd) {   // the ray's coordinate along direction k: so + t sd
+        const float L = bf(s, dop + 2u * k), H = bf(s, dop + 2u * k + 1u);
+        const bool flat = sd == 0.0f;
+        const float r = fast_rcp(flat ? 1.0f : sd);
+        const float ta = (L - so) * r, tb = (H - so) * r;
+        t0 = __builtin_fmaxf(t0, flat ? t0 : __builtin_fminf(ta, tb));
+        t1 = __builtin_fminf(t1, flat ? t1 : __builtin_fmaxf(ta, tb));
+        apart = apart | (flat & ((so < L) | (so > H)));
+        trusted = trusted & (pt_abs(so) < far);
+    };
+    slab(0, lo.x + lo.y, ld.x + ld.y); slab(1, lo.x - lo.y, ld.x - ld.y); slab(2, lo.x + lo.z, ld.x + ld.z); slab(3, lo.x - lo.z, ld.x - ld.z);
+    slab(4, lo.y + lo.z, ld.y + ld.z); slab(5, lo.y - lo.z, ld.y - ld.z);
+#if PT_MESH_DOP > 1
+    slab(6, lo.x + lo.y + lo.z, ld.x + ld.y + ld.z); slab(7, lo.x + lo.y - lo.z, ld.x + ld.y - ld.z);
+    slab(8, lo.x - lo.y + lo.z, ld.x - ld.y + ld.z); slab(9, lo.x - lo.y - lo.z, ld.x - ld.y - ld.z);
+#endif
+    return trusted & (apart | (t0 > t1));
+}
+
 // Phase 3: the primitive tests of the set bits in pre-order (ties are broken by that order, as in world_hit_walk).  With
 // `park_at_walked` the loop returns true when the next bit is a walked mesh instance, leaving the bit set: the caller
 // parks the state and resumes with sweep_resume; otherwise walked meshes are walked in line.
@@ -1281,6 +1327,7 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
                 st.closest = 0.0f; st.best_inst = kf >> 16; st.best_triw = 0u; st.hit = 0;
                 return false;
             }
+            if (PT_MESH_DOP_TRIES(stop) && mesh_surely_missed(s, inst, o, d, __builtin_fminf(bound, st.closest))) { st.hit &= st.hit - 1; continue; }   // (through a corner of the mesh's box: nothing to walk for)
             if (park_at_walked) return true;
             st.hit &= st.hit - 1;
             mesh_walk(s, inst, kf >> 16, o, d, bound, stop, st);
@@ -1426,6 +1473,7 @@ PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, S
         const uint32_t inst = inst_off + pending * PT_INST_WORDS, kind = bu(s, inst + PT_INST_KIND);
         if (kind == PT_SHAPE_MESH) {
             // (mesh_surely_blocks is not tried here: in the top-level walk's kernels it cost 2 % — G2FG k_shadow_parked 5896 -> 6022 us — even where no ray could take it)
+            if (PT_MESH_DOP_TOP && PT_MESH_DOP_TRIES(stop) && mesh_surely_missed(s, inst, o, d, __builtin_fminf(bound, st.closest))) continue;
             if (park_at_mesh) { st.hit = (uint64_t)pend_node + 1ull; return true; }
             st.hit = (uint64_t)i + 1ull;
             mesh_walk(s, inst, pending, o, d, bound, stop, st);

@@ -1,4 +1,5 @@
 // pt_kern_shadow.hip — the light-sample kernels (k_shadow in its traversal forms) and their launcher.
+#define PT_MESH_DOP_ONLY_ANY 1   /* (pt_device.h mesh_surely_missed: in this family only the environment rays try a mesh's extra slabs) */
 #include <cstdlib>
 #ifdef PT_TIMELINE
 #define PT_TIMELINE_RAYS   // (measurement build: pt_device.h records the long walks of this family's kernels)

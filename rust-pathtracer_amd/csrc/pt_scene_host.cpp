@@ -522,6 +522,28 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
             if (getenv("PT_AMD_HOST_VERBOSE")) fprintf(stderr, "mesh %u: %u faces, inner ball centre (%g, %g, %g) radius %g (0 = none)\n", mi, m.face_count, c[0], c[1], c[2], r);
             const double dx = (double)mb.mx[0] - mb.mn[0], dy = (double)mb.mx[1] - mb.mn[1], dz = (double)mb.mx[2] - mb.mn[2];
             rec[PT_MESH_REACH] = fbits((float)(std::sqrt(dx * dx + dy * dy + dz * dz) * 1.0001));
+            {   // the slabs of the 26-DOP beyond the box (pt_blob.h PT_MESH_DOP_*): every vertex, f64, widened by 1e-3 of the slab's width and rounded outward
+                static const int dirs[PT_MESH_DOP_DIRS][3] = {{1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}};
+                pad16(w);
+                const uint32_t dop_off = (uint32_t)w.size();
+                double big = 0.0;
+                for (int k = 0; k < PT_MESH_DOP_DIRS; ++k) {
+                    double lo = INFINITY, hi = -INFINITY;
+                    for (uint32_t v = 0; v < m.vertex_count; ++v) {
+                        const double x = (double)dirs[k][0] * V[3 * v] + (double)dirs[k][1] * V[3 * v + 1] + (double)dirs[k][2] * V[3 * v + 2];
+                        lo = std::fmin(lo, x); hi = std::fmax(hi, x);
+                    }
+                    const double margin = 1e-3 * (hi - lo) + 1e-30;
+                    const float flo = std::nextafterf((float)(lo - margin), -INFINITY), fhi = std::nextafterf((float)(hi + margin), INFINITY);
+                    w.push_back(fbits(flo)); w.push_back(fbits(fhi));
+                    big = std::fmax(big, std::fmax(std::fabs(lo), std::fabs(hi)) + (hi - lo));
+                }
+                w.push_back(fbits((float)(100.0 * big)));   // `far`: an origin whose n . o is beyond it leaves a rounding error of the size of the margin — such a ray is walked
+                const bool finite = std::isfinite(big) && big > 0.0;
+                rec[PT_MESH_DOP_OFF] = finite ? dop_off : 0u;
+                pad16(w);
+                mesh_off[mi] = (uint32_t)w.size();
+            }
         }
         w.insert(w.end(), rec, rec + PT_MESH_WORDS);
     }
