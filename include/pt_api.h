@@ -277,7 +277,10 @@ typedef struct pt_tuning {
     uint32_t top_evict_below;     /* PT_AMD_TOP_EVICT_BELOW: scenes without a sweep table (more than 64 instances) walk the top-level tree lane by lane; once fewer lanes
                                      of a wave than this are still walking, those leave with their place, are parked like a ray at a mesh and go on in a later wave of 64
                                      such rays.  1 = never, at most 64; 0 = the default (48 for a scene of more than 64 instances without a mesh, else never) */
-    uint32_t reserved[3];         /* must be 0 */
+    uint32_t group_evict_below;   /* PT_AMD_GROUP_EVICT_BELOW: the grouped sweep of a walked mesh of up to 384 triangles (the closest-hit kernel of a scene with ONE such mesh): a
+                                     ray enters 5.7 of the gem's 51 groups on average and a wave waits for its busiest lane; once fewer lanes than this still have a group to
+                                     do they leave with their groups and go on in a later wave of 64 such rays.  1 = never, at most 64; 0 = the default */
+    uint32_t reserved[2];         /* must be 0 */
 } pt_tuning;
 /* The defaults, overridden by whatever PT_AMD_* variables the environment holds at the time of the call. */
 void pt_tuning_default(pt_tuning* tuning);

@@ -131,7 +131,7 @@ class Tuning(C.Structure):
     """pt_tuning: the engine's run-time switches, taken by a scene when it is created."""
     _fields_ = [("flags", C.c_uint32), ("batch_slots", C.c_uint32), ("blocks_per_cu", C.c_uint32), ("park_blocks_per_cu", C.c_uint32),
                 ("park_dynamic", C.c_int32), ("shade_form", C.c_uint32), ("lds_all_limit", C.c_uint32), ("multi_virtual", C.c_uint32),
-                ("walk_evict_below", C.c_uint32), ("walk_search_below", C.c_uint32), ("park_block", C.c_uint32), ("light_prepass_max", C.c_uint32), ("top_evict_below", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("walk_evict_below", C.c_uint32), ("walk_search_below", C.c_uint32), ("park_block", C.c_uint32), ("light_prepass_max", C.c_uint32), ("top_evict_below", C.c_uint32), ("group_evict_below", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 class OutputDesc(C.Structure):

@@ -942,15 +942,20 @@ static __device__ float g_tl_rays[1 + 4096 * 12];
 // instead of idling; the wave runs its triangle pass when nobody lacks a first leaf.  A lane's leaves keep their order; the box tests of the second search see the
 // closest hit from before the first leaf's triangle test, which only lets through boxes whose triangle cannot be accepted (as in the sweep's FIFO).  A lane evicted
 // while it holds an untested leaf leaves with that leaf's own node in the cursor: the box is tested again on resume.
+// GROUPS (round 5: the round-4 verdict's "entered-group loop without eviction"): in the grouped sweep a lane's ray enters 5.7 groups on average and a wave waits for the lane with
+// the most — lane utilisation 0.38.  Once fewer lanes than `(policy >> 17) & 0x7f` still have a group to do, those drain their triangle queues and LEAVE: cursor = PT_GROUPS_EVICTED,
+// `*aux` = the mask of their groups still to do (the caller parks both: two words an entry of a path segment has to spare); a later wave of 64 such rays goes straight to its groups.
+#define PT_GROUPS_EVICTED 0xfffffffeu
 template <bool SPEC = false>
 PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, F3 d, float bound, int stop, SweepState& st,
-                     uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true) {
+                     uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true, uint64_t* aux = nullptr) {
     const uint32_t NONE = 0xffffffffu;
     const uint32_t flags = bu(s, PT_HDR_FLAGS);
     const bool cull = (flags & PT_FLAG_NO_CULL) == 0;
     F3 lo, ld;
     instance_local_ray(s, inst, o, d, &lo, &ld);
-    const uint32_t begin_at = cursor != nullptr ? *cursor : 0u;   // (a ray that was evicted from a walk goes on walking — and so does its whole wave)
+    const bool regroup = cursor != nullptr && *cursor == PT_GROUPS_EVICTED;   // (evicted from the grouped sweep's group loop: its groups still to do came along in *aux)
+    const uint32_t begin_at = (cursor != nullptr && !regroup) ? *cursor : 0u;   // (a ray that was evicted from a walk goes on walking — and so does its whole wave)
     if (policy & PT_WALK_SCAN_AXIS) {
         // rays parallel to an axis of the mesh: one after the other, the whole wave on each (mesh_scan).  Before this lane's own constants
         // are made: the scan works on the broadcast ray's, and the two sets need not be held at once.
@@ -1040,6 +1045,8 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                 if (ct == 1 && cull && beyond(entry, limit, cr.base)) ct = 0;
                 entered |= ct != 0 ? 1ull << g : 0ull;
             }
+            if (regroup) entered = *aux;   // (a resumed ray's own groups; the box tests above were the fresh rays' — the loop's addresses are the wave's)
+            const uint32_t group_evict = aux != nullptr ? (policy >> 17) & 0x7fu : 0u;
 #if PT_SWEEP_FIFO
             // The leaves of the entered groups, per lane — but a lane's triangle tests do not follow its box tests at once: the leaves whose box
             // passed wait in a queue of the lane's own (fourteen 9-bit leaf numbers in two words), and the wave runs a round of triangle tests — one
@@ -1107,6 +1114,18 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                     }
                 }
                 if (!PT_WAVE_ANY(entered != 0 || queued != 0u)) break;
+                if (group_evict != 0u) {
+                    const uint32_t busy = (uint32_t)__builtin_popcountll(PT_WAVE_BALLOT(entered != 0 || queued != 0u));
+                    if (busy < group_evict) {   // (wave-uniform) the last lanes: their queued triangles, then out with the groups they have left
+                        while (queued != 0u) {
+                            const uint32_t leaf = (uint32_t)fifo & 511u;
+                            fifo >>= 9; --queued;
+                            if (triangles(1ull, leaf)) { queued = 0; entered = 0; fifo = 0; }
+                        }
+                        if (entered != 0) { *cursor = PT_GROUPS_EVICTED; *aux = entered; return true; }
+                        break;
+                    }
+                }
             }
             return false;
 #else
@@ -1386,7 +1405,7 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
 // a `policy` that evicts, the walk may be left unfinished (mesh_walk): true then too, the bit still set and `*cursor` where the walk goes on.
 template <bool SPEC = false>
 PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f,
-                        uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true) {
+                        uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true, uint64_t* aux = nullptr) {
     const uint32_t k = alive ? ctz64(st.hit) : 0u;
     const F4 be = bf4(s, bu(s, PT_HDR_SWEEP_BITS_OFF) + k * PT_SWEEP_BIT_WORDS);
     uint32_t inst = pt_f2u(be.x);
@@ -1395,7 +1414,7 @@ PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, S
         const uint32_t lead = PT_WAVE_READ(inst, ctz64(PT_WAVE_BALLOT(alive)));
         inst = alive ? inst : lead;
     }
-    if (mesh_walk<SPEC>(s, inst, pt_f2u(be.w) >> 16, o, d, bound, stop, st, cursor, policy, alive)) return true;
+    if (mesh_walk<SPEC>(s, inst, pt_f2u(be.w) >> 16, o, d, bound, stop, st, cursor, policy, alive, aux)) return true;
     if (!alive) return false;
     if (cursor != nullptr) *cursor = 0u;
     st.hit &= st.hit - 1;   // (zero already after an early stop)
@@ -1758,7 +1777,8 @@ PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound
         // the parked kernels' protocol, lane by lane: park at a walked mesh, resume, and leave the walk at every chance (mesh_walk's eviction)
         uint32_t cursor = 0u;
         bool parked = sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, true, known_inst, known_t);
-        while (parked) parked = sweep_resume(s, o, d, bound, stop, st, known_inst, known_t, &cursor, 0x201u | PT_WALK_SCAN_AXIS);
+        uint64_t aux = 0ull;   // (the grouped sweep's group loop too is left at every chance: 2 << 17 against the emulation's one busy lane)
+        while (parked) parked = sweep_resume(s, o, d, bound, stop, st, known_inst, known_t, &cursor, 0x201u | PT_WALK_SCAN_AXIS | (2u << 17), true, &aux);
     } else
 #endif
     sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, false, known_inst, known_t);

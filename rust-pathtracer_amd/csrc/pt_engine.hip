@@ -311,9 +311,19 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     // thirteen instances in the gem scene, ten nodes per walk) lost 15 % (profiles/r5_experiments.md section 2).
     const uint32_t top_evict = tn.top_evict_below ? tn.top_evict_below
                              : (sc->host.blob[PT_HDR_INSTANCE_COUNT] > PT_SWEEP_MAX_BITS && !scene_has_mesh(sc->host.blob) ? kTopEvictBelow : 1u);
+    // The grouped mesh sweep's group loop is left by a wave's last lanes (mesh_walk, GROUPS) where every parked ray of the closest-hit kernel stands in the SAME mesh — one
+    // walked mesh in the table: a resumed wave is then always one the grouped sweep takes, and a ray that comes back with groups to do is never walked from the top.
+    uint32_t group_evict = 1u;
+    {
+        const std::vector<uint32_t>& bl = sc->host.blob;
+        uint32_t walked = 0;
+        if (sweep) for (uint32_t j = 0; j < bl[PT_HDR_SWEEP_COUNT]; ++j) walked += (bl[bl[PT_HDR_SWEEP_OFF] + j * PT_SWEEP_INST_WORDS + 1] & PT_SWEEP_WALKED) ? 1u : 0u;
+        if (parked && walked == 1u) group_evict = tn.group_evict_below ? tn.group_evict_below : kGroupEvictBelow;
+    }
     cfg.walk_policy = (tn.walk_evict_below ? tn.walk_evict_below : kWalkEvictBelow) | (tn.walk_search_below ? tn.walk_search_below : kWalkSearchBelow) << 8
                     | ((tn.flags & PT_TUNE_NO_AXIS_SCAN) ? 0u : PT_WALK_SCAN_AXIS)
-                    | (top_evict <= 1u ? 0u : top_evict << 24);   // (1 = never: 0 in the policy word)
+                    | (top_evict <= 1u ? 0u : top_evict << 24)   // (1 = never: 0 in the policy word)
+                    | (group_evict <= 1u ? 0u : group_evict << 17);
     const SceneArgs sargs{sc->d_blob, sc->blob_words, sc->d_tex, marginal_lds_bytes(sc->host.blob.data(), lds_bytes)};
     // light samples can pick the environment only if env_sampling_probability > 0: otherwise k_shade is the form without that branch
     float env_prob; std::memcpy(&env_prob, &sc->host.blob[PT_HDR_ENV_PROB], sizeof env_prob);
@@ -536,6 +546,7 @@ void pt_tuning_default(pt_tuning* t) {
     t->park_block = env_u32("PT_AMD_PARK_BLOCK", 0);
     t->light_prepass_max = env_u32("PT_AMD_LIGHT_PREPASS_MAX", 0);
     t->top_evict_below = env_u32("PT_AMD_TOP_EVICT_BELOW", 0);
+    t->group_evict_below = env_u32("PT_AMD_GROUP_EVICT_BELOW", 0);
 }
 
 pt_status pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
@@ -549,8 +560,8 @@ pt_status pt_scene_create_tuned(const pt_scene_desc* desc, const pt_tuning* tuni
     for (uint32_t r : tuning->reserved) if (r != 0) return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning::reserved must be 0");
     if (tuning->park_block != 0 && tuning->park_block != 256 && tuning->park_block != 512 && tuning->park_block != 1024)
         return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning::park_block (PT_AMD_PARK_BLOCK) must be 0, 256, 512 or 1024");
-    if (tuning->shade_form > 2 || tuning->park_dynamic < -1 || tuning->park_dynamic > 1 || tuning->multi_virtual > 64 || tuning->walk_evict_below > 64 || tuning->walk_search_below > 64 || tuning->top_evict_below > 64)
-        return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning: shade_form in 0..2, park_dynamic in -1..1, multi_virtual, walk_evict_below, walk_search_below, top_evict_below <= 64");
+    if (tuning->shade_form > 2 || tuning->park_dynamic < -1 || tuning->park_dynamic > 1 || tuning->multi_virtual > 64 || tuning->walk_evict_below > 64 || tuning->walk_search_below > 64 || tuning->top_evict_below > 64 || tuning->group_evict_below > 64)
+        return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning: shade_form in 0..2, park_dynamic in -1..1, multi_virtual, walk_evict_below, walk_search_below, top_evict_below, group_evict_below <= 64");
     // the tiled queue index (pt_stages.h qtile) multiplies in 32 bits: capacity <= 2^30; the grids are num_cus * blocks in an int
     if (tuning->batch_slots > (1u << 30) || tuning->blocks_per_cu > 1024u || tuning->park_blocks_per_cu > 1024u)
         return fail(PT_ERR_INVALID_ARGUMENT, "pt_tuning: batch_slots (PT_AMD_BATCH) <= 2^30, blocks_per_cu and park_blocks_per_cu <= 1024");

@@ -801,7 +801,7 @@ __device__ __forceinline__ void park_drain(uint32_t* pk, uint32_t* park_count, b
         __threadfence_block();             // entries are in registers before any lane parks again into these slots
         if (lane == 0) *park_count = first;
         // (ALL_LANES, the forms that scan axis rays: a lane without an entry helps with the scans of the others' — mesh_walk's `alive`)
-        if (ALL_LANES || mine) resume(item, st, ray, bound, kind, cursor, last && first == 0u ? walk_policy & ~0xff0000ffu : walk_policy, mine);   // (the very last drain: neither the mesh walks nor the top-level walks are left early)
+        if (ALL_LANES || mine) resume(item, st, ray, bound, kind, cursor, last && first == 0u ? walk_policy & ~0xfffe00ffu : walk_policy, mine);   // (the very last drain: neither the mesh walks, nor the grouped sweep's group loops, nor the top-level walks are left early)
     }
 }
 
@@ -830,8 +830,9 @@ k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const fl
         *o = f3(qf(paths, PS_OX, i), qf(paths, PS_OY, i), qf(paths, PS_OZ, i));
         *d = f3(qf(paths, PS_DX, i), qf(paths, PS_DY, i), qf(paths, PS_DZ, i));
     };
-    auto settle = [&](uint32_t j, F3 o, F3 d, const SweepState& st, bool parked, uint32_t cursor) {
-        if (parked) park_store<kParkCap, PT_PARK_SEGMENT_REC>(pk, atomicAdd(park_count, 1u), j, st, 0u, PT_INF, 0u, cursor);
+    // (`aux`: the groups a ray evicted from the grouped mesh sweep has still to do, mesh_walk — in the two words of an entry that a path segment has to spare: ray number and kind)
+    auto settle = [&](uint32_t j, F3 o, F3 d, const SweepState& st, bool parked, uint32_t cursor, uint64_t aux = 0ull) {
+        if (parked) park_store<kParkCap, PT_PARK_SEGMENT_REC>(pk, atomicAdd(park_count, 1u), j, st, (uint32_t)aux, PT_INF, (uint32_t)(aux >> 32), cursor);
         else { Hit h; sweep_finish(s, o, d, st, &h); store_hit(hits, base + j, h); }
     };
     PT_TL_BEGIN();
@@ -850,13 +851,14 @@ k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const fl
             }
             settle(j, o, d, st, parks, evicted ? PT_TOP_EVICTED : 0u);
         }
-        park_drain<false, kParkCap, PT_PARK_SEGMENT_REC>(pk, park_count, r + 1 == rounds, walk_policy & ~PT_WALK_SCAN_AXIS, [&](uint32_t j2, SweepState& st, uint32_t, float, uint32_t, uint32_t cursor, uint32_t policy, bool mine) {
+        park_drain<false, kParkCap, PT_PARK_SEGMENT_REC>(pk, park_count, r + 1 == rounds, walk_policy & ~PT_WALK_SCAN_AXIS, [&](uint32_t j2, SweepState& st, uint32_t aux_lo, float, uint32_t aux_hi, uint32_t cursor, uint32_t policy, bool mine) {
             if (mine) PT_TL_WORK();   // (timeline: parked rays resumed)
             F3 o = f3(0.0f, 0.0f, 0.0f), d = f3(0.0f, 0.0f, 0.0f);
             if (mine) ray_of(base + j2, &o, &d);
+            uint64_t aux = (uint64_t)aux_lo | (uint64_t)aux_hi << 32;
             const bool again = TOP ? top_walk_resume<PT_WALK_SPEC_EXTEND>(s, o, d, PT_INF, PT_STOP_NONE, st, &cursor, policy, mine)
-                                   : sweep_resume<PT_WALK_SPEC_EXTEND>(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy, mine);
-            if (mine) settle(j2, o, d, st, again, cursor);
+                                   : sweep_resume<PT_WALK_SPEC_EXTEND>(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy, mine, &aux);
+            if (mine) settle(j2, o, d, st, again, cursor, aux);
         });
     }
     PT_TL_END(n);

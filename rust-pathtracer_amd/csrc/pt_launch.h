@@ -22,6 +22,7 @@ constexpr uint32_t kLdsAllLimitBytes = 24 * 1024;
 constexpr uint32_t kParkBlobLimitBytes = 72 * 1024;
 constexpr uint32_t kParkCap = 512, kParkFields = 16;
 constexpr uint32_t kLightPrepassMax = 16;   // pt_tuning::light_prepass_max's default: the most lights whose boxes a light-sample ray tests one by one for its bound
+constexpr uint32_t kGroupEvictBelow = 32;   // pt_tuning::group_evict_below's default (1 = never)
 constexpr uint32_t kTopEvictBelow = 48;   // pt_tuning::top_evict_below's default (1 = never); the check runs behind a leaf test of the while-while walk: G2F k_shadow_parked 2545 (never) / 2314 (16) / 2235 (32) / 2126 (40) / 2108 us (48)
 constexpr uint32_t kWalkEvictBelow = 32, kWalkSearchBelow = 16;   // pt_tuning::walk_evict_below's and walk_search_below's defaults
 enum { BS_VERTICES, BS_SHADOW_RAYS, BS_ENV_HITS, BS_SEGMENTS, BS_ITEMS, BS_MEDIUM_DROPS, BS_FIELDS };  // per-workgroup statistics (Profile counters)

@@ -104,7 +104,7 @@ def test_tuning_default_reads_the_environment_once(pkg, monkeypatch):
         monkeypatch.delenv(name, raising=False)
     t = lib.tuning_default()
     assert (t.flags, t.batch_slots, t.blocks_per_cu, t.park_blocks_per_cu, t.park_dynamic, t.shade_form, t.lds_all_limit, t.multi_virtual) == (0, 0, 0, 0, -1, 0, 0, 0)
-    assert list(t.reserved) == [0] * 3 and t.top_evict_below == 0 and t.light_prepass_max == 0 and t.park_block == 0 and t.walk_evict_below == 0 and t.walk_search_below == 0
+    assert list(t.reserved) == [0] * 2 and t.group_evict_below == 0 and t.top_evict_below == 0 and t.light_prepass_max == 0 and t.park_block == 0 and t.walk_evict_below == 0 and t.walk_search_below == 0
     monkeypatch.setenv("PT_AMD_BATCH", "4096"); monkeypatch.setenv("PT_AMD_BLOCKS_PER_CU", "8"); monkeypatch.setenv("PT_AMD_NO_FUSE", "1")
     monkeypatch.setenv("PT_AMD_PARK_DYNAMIC", "0"); monkeypatch.setenv("PT_AMD_MULTI_VIRTUAL", "4"); monkeypatch.setenv("PT_AMD_STAGE_TIMING", "0")
     monkeypatch.setenv("PT_AMD_GENERAL_FORMS", "1")

@@ -346,7 +346,7 @@ def test_tuning_is_taken_at_scene_creation(engine, pkg, monkeypatch):
     assert p3.kernel_launches[1] > 0
     monkeypatch.delenv("PT_AMD_NO_FUSE")
     bad = engine.tuning_default()
-    bad.reserved[2] = 1
+    bad.reserved[1] = 1
     with pytest.raises(pkg.api.PtError):
         engine.create_scene(b, bad)
     bad = engine.tuning_default()
