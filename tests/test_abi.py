@@ -108,6 +108,11 @@ def test_tuning_default_reads_the_environment_once(pkg, monkeypatch):
     monkeypatch.setenv("PT_AMD_BATCH", "4096"); monkeypatch.setenv("PT_AMD_BLOCKS_PER_CU", "8"); monkeypatch.setenv("PT_AMD_NO_FUSE", "1")
     monkeypatch.setenv("PT_AMD_PARK_DYNAMIC", "0"); monkeypatch.setenv("PT_AMD_MULTI_VIRTUAL", "4"); monkeypatch.setenv("PT_AMD_STAGE_TIMING", "0")
     monkeypatch.setenv("PT_AMD_GENERAL_FORMS", "1")
+    monkeypatch.setenv("PT_AMD_LIGHT_PREPASS_MAX", "5"); monkeypatch.setenv("PT_AMD_TOP_EVICT_BELOW", "24"); monkeypatch.setenv("PT_AMD_GROUP_EVICT_BELOW", "40")
+    monkeypatch.setenv("PT_AMD_NO_ONE_LIGHT", "1")
     t = lib.tuning_default()
     assert (t.batch_slots, t.blocks_per_cu, t.park_dynamic, t.multi_virtual) == (4096, 8, 0, 4)
+    assert (t.light_prepass_max, t.top_evict_below, t.group_evict_below) == (5, 24, 40)     # (round 5's fields)
+    assert t.flags & pkg.api.TUNE_NO_ONE_LIGHT
+    t.flags &= ~pkg.api.TUNE_NO_ONE_LIGHT
     assert t.flags == pkg.api.TUNE_NO_FUSE | pkg.api.TUNE_NO_STAGE_TIMING | pkg.api.TUNE_GENERAL_FORMS
