@@ -1270,7 +1270,8 @@ PT_HD bool mesh_surely_blocks(const SceneView& s, uint32_t inst, F3 o, F3 d, flo
         const F3 oc = sub(c, lo);
         const float tca = dot(oc, ld) / dd;
         const F3 q = sub(oc, mul(ld, tca));
-        return (dot(q, q) < rr * rr) & (tca > 0.0f) & (tca + far < bound);
+        // (the ball was shrunk by 2 %: the f32 distance of the ray from its centre is right to 1e-6 |oc|, i.e. to a twentieth of that margin for an origin within 1000 radii — farther origins make no claim)
+        return (dot(q, q) < rr * rr) & (tca > 0.0f) & (tca + far < bound) & (dot(oc, oc) < 1e6f * rr * rr);
     };
     bool blocks = through(f3(bf(s, mesh + PT_MESH_INNER_C), bf(s, mesh + PT_MESH_INNER_C + 1), bf(s, mesh + PT_MESH_INNER_C + 2)), r);
 #if PT_INNER_BALL > 1
@@ -1299,24 +1300,29 @@ PT_HD bool mesh_surely_blocks(const SceneView& s, uint32_t inst, F3 o, F3 d, flo
 #ifndef PT_MESH_DOP_TOP
 #define PT_MESH_DOP_TOP 1   /* the top-level walk's kernels try it too */
 #endif
+// Error budget (f32, u = 6e-8): a direction's coordinate of the origin, so = a sum of two or three components, is off by <= 2u L1(o); of the direction, sd, by <= 2u L1(d).  A slab is
+// used only if |sd| >= 4e-3 L1(d) — then t = (L - so) / sd (a reciprocal and a product: 3u more) is right to 3e-5 of itself — and only if the origin lies within eight slab widths of
+// both planes — then the ray's position along the direction at that t is right to 8 w 3e-5 + 2u L1(o) < 3e-4 w (the host refuses a mesh that lies more than 500 of its own widths
+// from its origin: `far` = 0).  The slabs are widened by 1e-3 w on the host.  A direction the ray runs exactly along (sd == 0) separates iff the origin is outside the slab.
 PT_HD bool mesh_surely_missed(const SceneView& s, uint32_t inst, F3 o, F3 d, float limit) {
     if (!PT_MESH_DOP) return false;
     const uint32_t dop = bu(s, bu(s, inst + PT_INST_MESH) + PT_MESH_DOP_OFF);
     if (dop == 0u) return false;
     F3 lo, ld;
     instance_local_ray(s, inst, o, d, &lo, &ld);
-    const float far = bf(s, dop + 2u * PT_MESH_DOP_DIRS);
+    const float dmin = 4e-3f * (pt_abs(ld.x) + pt_abs(ld.y) + pt_abs(ld.z));
     float t0 = 0.0f, t1 = limit;
-    bool apart = false, trusted = true;
+    bool apart = false;
     auto slab = [&](uint32_t k, float so, float sd) {   // the ray's coordinate along direction k: so + t sd
         const float L = bf(s, dop + 2u * k), H = bf(s, dop + 2u * k + 1u);
+        const float a = L - so, b = H - so, w8 = 8.0f * (H - L);
         const bool flat = sd == 0.0f;
-        const float r = fast_rcp(flat ? 1.0f : sd);
-        const float ta = (L - so) * r, tb = (H - so) * r;
-        t0 = __builtin_fmaxf(t0, flat ? t0 : __builtin_fminf(ta, tb));
-        t1 = __builtin_fminf(t1, flat ? t1 : __builtin_fmaxf(ta, tb));
-        apart = apart | (flat & ((so < L) | (so > H)));
-        trusted = trusted & (pt_abs(so) < far);
+        const bool usable = (pt_abs(sd) >= dmin) & (pt_abs(a) < w8) & (pt_abs(b) < w8);
+        const float r = fast_rcp(usable ? sd : 1.0f);
+        const float ta = a * r, tb = b * r;
+        t0 = __builtin_fmaxf(t0, usable ? __builtin_fminf(ta, tb) : t0);
+        t1 = __builtin_fminf(t1, usable ? __builtin_fmaxf(ta, tb) : t1);
+        apart = apart | (flat & ((a > 0.0f) | (b < 0.0f)) & (pt_abs(a) < w8) & (pt_abs(b) < w8));
     };
     slab(0, lo.x + lo.y, ld.x + ld.y); slab(1, lo.x - lo.y, ld.x - ld.y); slab(2, lo.x + lo.z, ld.x + ld.z); slab(3, lo.x - lo.z, ld.x - ld.z);
     slab(4, lo.y + lo.z, ld.y + ld.z); slab(5, lo.y - lo.z, ld.y - ld.z);
@@ -1324,7 +1330,7 @@ PT_HD bool mesh_surely_missed(const SceneView& s, uint32_t inst, F3 o, F3 d, flo
     slab(6, lo.x + lo.y + lo.z, ld.x + ld.y + ld.z); slab(7, lo.x + lo.y - lo.z, ld.x + ld.y - ld.z);
     slab(8, lo.x - lo.y + lo.z, ld.x - ld.y + ld.z); slab(9, lo.x - lo.y - lo.z, ld.x - ld.y - ld.z);
 #endif
-    return trusted & (apart | (t0 > t1));
+    return apart | (t0 > t1);
 }
 
 // Phase 3: the primitive tests of the set bits in pre-order (ties are broken by that order, as in world_hit_walk).  With

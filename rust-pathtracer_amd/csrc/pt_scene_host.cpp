@@ -526,20 +526,20 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
                 static const int dirs[PT_MESH_DOP_DIRS][3] = {{1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}};
                 pad16(w);
                 const uint32_t dop_off = (uint32_t)w.size();
-                double big = 0.0;
+                bool centred = true;   // (no slab lies more than 500 of its own widths from the mesh's origin: mesh_surely_missed's error budget)
                 for (int k = 0; k < PT_MESH_DOP_DIRS; ++k) {
                     double lo = INFINITY, hi = -INFINITY;
                     for (uint32_t v = 0; v < m.vertex_count; ++v) {
                         const double x = (double)dirs[k][0] * V[3 * v] + (double)dirs[k][1] * V[3 * v + 1] + (double)dirs[k][2] * V[3 * v + 2];
                         lo = std::fmin(lo, x); hi = std::fmax(hi, x);
                     }
-                    const double margin = 1e-3 * (hi - lo) + 1e-30;
+                    const double margin = 1e-3 * (hi - lo);
                     const float flo = std::nextafterf((float)(lo - margin), -INFINITY), fhi = std::nextafterf((float)(hi + margin), INFINITY);
                     w.push_back(fbits(flo)); w.push_back(fbits(fhi));
-                    big = std::fmax(big, std::fmax(std::fabs(lo), std::fabs(hi)) + (hi - lo));
+                    centred = centred && std::isfinite(lo) && std::isfinite(hi) && hi > lo && std::fmax(std::fabs(lo), std::fabs(hi)) <= 500.0 * (hi - lo);
                 }
-                w.push_back(fbits((float)(100.0 * big)));   // `far`: an origin whose n . o is beyond it leaves a rounding error of the size of the margin — such a ray is walked
-                const bool finite = std::isfinite(big) && big > 0.0;
+                w.push_back(0u);
+                const bool finite = centred;
                 rec[PT_MESH_DOP_OFF] = finite ? dop_off : 0u;
                 pad16(w);
                 mesh_off[mi] = (uint32_t)w.size();
