@@ -1297,6 +1297,9 @@ PT_HD bool mesh_surely_blocks(const SceneView& s, uint32_t inst, F3 o, F3 d, flo
 #define PT_MESH_DOP_ONLY_ANY 0
 #endif
 #define PT_MESH_DOP_TRIES(stop) (!PT_MESH_DOP_ONLY_ANY || (stop) == PT_STOP_ANY)
+#ifndef PT_MESH_DOP_SLABS
+#define PT_MESH_DOP_SLABS 6   /* how many of the six face-diagonal slabs are tried (2, 4, 6) */
+#endif
 #ifndef PT_MESH_DOP_TOP
 #define PT_MESH_DOP_TOP 1   /* the top-level walk's kernels try it too */
 #endif
@@ -1324,8 +1327,13 @@ PT_HD bool mesh_surely_missed(const SceneView& s, uint32_t inst, F3 o, F3 d, flo
         t1 = __builtin_fminf(t1, usable ? __builtin_fmaxf(ta, tb) : t1);
         apart = apart | (flat & ((a > 0.0f) | (b < 0.0f)) & (pt_abs(a) < w8) & (pt_abs(b) < w8));
     };
-    slab(0, lo.x + lo.y, ld.x + ld.y); slab(1, lo.x - lo.y, ld.x - ld.y); slab(2, lo.x + lo.z, ld.x + ld.z); slab(3, lo.x - lo.z, ld.x - ld.z);
+    slab(0, lo.x + lo.y, ld.x + ld.y); slab(1, lo.x - lo.y, ld.x - ld.y);
+#if PT_MESH_DOP_SLABS > 2
+    slab(2, lo.x + lo.z, ld.x + ld.z); slab(3, lo.x - lo.z, ld.x - ld.z);
+#endif
+#if PT_MESH_DOP_SLABS > 4
     slab(4, lo.y + lo.z, ld.y + ld.z); slab(5, lo.y - lo.z, ld.y - ld.z);
+#endif
 #if PT_MESH_DOP > 1
     slab(6, lo.x + lo.y + lo.z, ld.x + ld.y + ld.z); slab(7, lo.x + lo.y - lo.z, ld.x + ld.y - ld.z);
     slab(8, lo.x - lo.y + lo.z, ld.x - ld.y + ld.z); slab(9, lo.x - lo.y - lo.z, ld.x - ld.y - ld.z);

@@ -1,0 +1,7 @@
+#!/bin/bash
+OUT=gpurun_out/r5y_slabs.txt; : > $OUT
+C3="--scene cornell_gem --width 1920 --height 1080 --max-bounces 12 --spp-per-step 60"
+C4="--scene hdri_test --max-bounces 4 --light-samples 6 --spp-per-step 120"
+G1="--scene test_prism --max-bounces 8 --light-samples 2 --spp-per-step 120"
+bash tools/ab_libs.sh "variants/slabs2.so variants/slabs4.so variants/slabs6.so" -- $C3 ";;" $C4 ";;" $G1 >> $OUT 2>&1
+cat $OUT
