@@ -26,6 +26,9 @@
 #pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
 #endif
 
+#ifndef PT_GROUP_WAVE_MASKS
+#define PT_GROUP_WAVE_MASKS 0   /* 1 = the grouped mesh sweep's group boxes decided as wave masks (round 5 experiment 14: C3 k_extend_parked -1.8 %, frame within noise; off) */
+#endif
 #ifndef PT_GROUP_WALK_BOX
 #define PT_GROUP_WALK_BOX 1   /* the grouped mesh sweep's per-lane leaf boxes through walk_box (round 5); 0 = aabb_classify + a loop over the undecided */
 #endif
@@ -1037,6 +1040,27 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
             const uint32_t groups = (leaf_count + PT_MESH_GROUP - 1u) / PT_MESH_GROUP;
             static_assert((PT_MESH_SWEEP_MAX + PT_MESH_GROUP - 1) / PT_MESH_GROUP <= 64 && PT_MESH_GROUP <= 32, "one bit per group, one per leaf of a group");
             uint64_t entered = 0;
+#if PT_GROUP_WAVE_MASKS && defined(__HIP_DEVICE_COMPILE__)
+            {   // (round 5: the group boxes — every lane the same box — decided as wave masks, as the leaf sweep's boxes are: aabb_classify_wave; a group counts as entered when its
+                // box is hit OR too close to call, as below)
+                const uint64_t q = PT_WAVE_BALLOT(quick), nq = PT_WAVE_BALLOT(!quick);
+                const float lim = cull ? limit : PT_INF;
+                uint32_t ent_lo = 0u, ent_hi = 0u;
+                for (uint32_t g = 0; g < groups; ++g) {
+                    const uint32_t e = PT_UNIFORM(group_off + g * 8u);
+                    const F4 ga = mf4(s, e), gb = mf4(s, e + 4);
+                    float entry = 0.0f;
+                    uint64_t ih = 0ull, iu = 0ull;
+                    if (PT_UNIFORM(pt_f2u(gb.w)) != 0u) aabb_classify_wave<4>(ga, gb, cr, &entry, &ih, &iu); else aabb_classify_wave<0>(ga, gb, cr, &entry, &ih, &iu);
+                    ih &= q; iu = (iu & q) | nq;
+                    ih &= ~PT_WAVE_BALLOT(beyond(entry, lim, cr.base));
+                    const bool in = PT_WAVE_MEMBER(ih | iu);
+                    const uint32_t m = 1u << (g & 31u);
+                    if (g < 32u) ent_lo |= in ? m : 0u; else ent_hi |= in ? m : 0u;
+                }
+                entered = (uint64_t)ent_lo | (uint64_t)ent_hi << 32;
+            }
+#else
             for (uint32_t g = 0; g < groups; ++g) {
                 const uint32_t e = PT_UNIFORM(group_off + g * 8u);
                 const F4 ga = mf4(s, e), gb = mf4(s, e + 4);
@@ -1045,6 +1069,7 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                 if (ct == 1 && cull && beyond(entry, limit, cr.base)) ct = 0;
                 entered |= ct != 0 ? 1ull << g : 0ull;
             }
+#endif
             if (regroup) entered = *aux;   // (a resumed ray's own groups; the box tests above were the fresh rays' — the loop's addresses are the wave's)
             const uint32_t group_evict = aux != nullptr ? (policy >> 17) & 0x7fu : 0u;
 #if PT_SWEEP_FIFO
