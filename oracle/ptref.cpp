@@ -2152,6 +2152,9 @@ void ptref_numerics(int which, size_t n, const float* x, const float* y, float* 
             case 5: out[i] = pt_atan2(x[i], y[i]); break;
             case 6: out[i] = (float)pt_exp64((double)x[i]); break;
             case 7: out[i] = (float)pt_log64((double)x[i]); break;
+            case 11: out[i] = x_bar(x[i]); break;   /* the colour-matching fit, x = angstrom (the engine's cheaper evaluation is compared over every f32 of its range) */
+            case 12: out[i] = y_bar(x[i]); break;
+            case 13: out[i] = z_bar(x[i]); break;
             default: out[i] = 0.0f;
         }
     }

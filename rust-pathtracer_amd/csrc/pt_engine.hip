@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(kBlock) k_probe_numerics(int which, uint32_t n
             case 8: r = x[i] / y[i]; break;
             case 9: r = pt_sqrt(x[i]); break;
             case 10: r = x[i] * y[i] + x[i]; break;  // must NOT be contracted to an fma
+            case 11: case 12: case 13: { float c[3]; ptd::xyz_bar(x[i], &c[0], &c[1], &c[2]); r = c[which - 11]; break; }   // x = angstrom
             default: r = 0.0f;
         }
         out[i] = r;

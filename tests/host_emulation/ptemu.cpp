@@ -55,6 +55,14 @@ uint32_t ptemu_debug_scene_info(pt_scene* sc, int what) {
     return 0;
 }
 
+// the colour-matching fit as the kernels evaluate it (contract = 0) and as the numeric contract defines it (1), for n wavelengths in angstrom: 3 floats each
+void ptemu_xyz_bar(size_t n, const float* angstrom, int contract, float* out) {
+    for (size_t i = 0; i < n; ++i) {
+        if (contract) xyz_bar_contract(angstrom[i], &out[3 * i], &out[3 * i + 1], &out[3 * i + 2]);
+        else xyz_bar(angstrom[i], &out[3 * i], &out[3 * i + 1], &out[3 * i + 2]);
+    }
+}
+
 }  // extern "C"
 template <int NL>
 static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, pt_profile* profile) {

@@ -46,6 +46,25 @@ def test_device_arithmetic_matches_x86(engine, oracle):
         assert np.array_equal(dev(10, x, y).view(np.uint32), ((x * y).astype(np.float32) + x).view(np.uint32))  # not fused
 
 
+def test_colour_matching_fit_for_every_wavelength(engine, oracle):
+    """k_accumulate's cheaper evaluation of the CIE fit (csrc/pt_device.h: gaussian64_fast) on the device against the oracle's, for every f32 of the range it is
+    used in (10 027 009 wavelengths x 3 outputs), and the contract's form outside the range."""
+    from test_xyz_bar import FAST_LO, FAST_HI, every_f32, oracle_xyz
+    fn = engine.lib.pt_debug_numerics
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    rng = np.random.default_rng(5)
+    outside = np.concatenate([every_f32(3599.0, 3600.0)[:-1], every_f32(8000.0, 8001.0)[1:], rng.uniform(0.0, 3600.0, 20000).astype(np.float32),
+                              rng.uniform(8000.0, 30000.0, 20000).astype(np.float32)])
+    for xs in list(np.array_split(every_f32(FAST_LO, FAST_HI), 4)) + [outside]:
+        xs = np.ascontiguousarray(xs); y = np.zeros_like(xs)
+        want = oracle_xyz(oracle, xs)
+        for c in range(3):
+            out = np.zeros_like(xs)
+            engine.check(fn(11 + c, xs.size, fptr(xs), fptr(y), fptr(out)))
+            assert np.array_equal(out.view(np.uint32), np.ascontiguousarray(want[:, c]).view(np.uint32)), c
+
+
 @pytest.mark.parametrize("scene", ["cornell_box", "cornell_gem", "mixed_primitives", "mixed_small", "white_furnace", "hdri_small", "hdri_c4_small"])
 def test_closest_hits_bit_exact(engine, oracle, scene):
     ps.intersect_parity(engine, oracle, scene, n=1 << 16)
