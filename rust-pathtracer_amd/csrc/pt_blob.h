@@ -109,8 +109,14 @@
 #define PT_MED_IOR 4
 #define PT_MED_CORRECTIVE 5
 
-// Curve record (8 words): kind, mode, p0, p1, data_off (word offset), data_count, pad, pad
+// Curve record (8 words): kind, mode, p0, p1, data_off (word offset), data_count, cell table, 1 / cell width
 #define PT_CURVE_WORDS 8
+// (round 5) a tabulated curve of 8..255 sorted knots: word 6 = (cells - 1) << 24 | word offset of its cell table (a byte per cell, four to a word: the number of
+// knots in lower cells), word 7 = cells / (last knot - first knot) as f32; word 6 = 0: no table, the binary search
+#define PT_CURVE_GRID 6
+#define PT_CURVE_GRID_INV 7
+#define PT_CURVE_GRID_MIN_KNOTS 8u
+#define PT_BLOB_LDS_ALL_BYTES 24576u   /* the largest blob the kernels stage whole in LDS (pt_launch.h kLdsAllLimitBytes) */
 // Texstack record: layer_count, then per layer 8 words: kind, curve0..3 (word offsets), width, height, texel offset (floats, into texture memory)
 #define PT_LAYER_WORDS 8
 

@@ -26,6 +26,9 @@
 #pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
 #endif
 
+#ifndef PT_CURVE_CELLS
+#define PT_CURVE_CELLS 1   /* tabulated curves: the knot index from the curve's cell table (round 5); 0 = the binary search everywhere */
+#endif
 #ifndef PT_GROUP_WAVE_MASKS
 #define PT_GROUP_WAVE_MASKS 0   /* 1 = the grouped mesh sweep's group boxes decided as wave masks (round 5 experiment 14: C3 k_extend_parked -1.8 %, frame within noise; off) */
 #endif
@@ -217,6 +220,16 @@ PT_HD float curve_eval(const SceneView& s, uint32_t c, float lambda) {
         }
         case PT_CURVE_TABULATED: {
             uint32_t lo = 0, hi = n;
+            const uint32_t grid = PT_CURVE_CELLS ? bu(s, c + PT_CURVE_GRID) : 0u;
+            if (grid != 0u) {
+                // the first knot that is not below lambda — the binary search's answer — found from the cell table (pt_scene_host.cpp): every knot in a lower cell
+                // is below lambda, the walk passes the knots of lambda's own cell
+                const float fi = (lambda - bf(s, d)) * bf(s, c + PT_CURVE_GRID_INV);
+                const float top = (float)(grid >> 24);
+                const uint32_t g = fi >= 0.0f ? (uint32_t)(fi < top ? fi : top) : 0u;
+                lo = (bu(s, (grid & 0xffffffu) + (g >> 2)) >> ((g & 3u) * 8u)) & 0xffu;
+                while (lo < n && bf(s, d + 2 * lo) < lambda) ++lo;
+            } else
             while (lo < hi) {
                 uint32_t mid = lo + (hi - lo) / 2;
                 if (bf(s, d + 2 * mid) < lambda) lo = mid + 1; else hi = mid;

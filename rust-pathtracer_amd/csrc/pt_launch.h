@@ -16,7 +16,7 @@ constexpr uint32_t kLdsBlobLimitBytes = 64 * 1024;  // the most LDS a staged blo
 // The whole blob is staged only while it leaves the CU its occupancy: six workgroups of 24 KB fit the 160 KB.  Measured (tools/lds_mode.sh):
 // the 65 KB blob of C3 staged whole leaves two workgroups per CU, 615 Msamples/s; its 6.7 KB core alone, the mesh read through L1/L2,
 // 752.  C2's 14 KB blob staged whole: 1519; its 7 KB core alone: 1089 (the sweep reads the triangles of the two boxes for every ray).
-constexpr uint32_t kLdsAllLimitBytes = 24 * 1024;
+constexpr uint32_t kLdsAllLimitBytes = PT_BLOB_LDS_ALL_BYTES;
 // The parked kernels in workgroups of 512 / 1024 threads (pt_tuning::park_block) stage the whole blob whatever the other kernels do: two workgroups of
 // 512 per CU are four waves per SIMD, and 2 x (72 KB + the waves' lists of live rays) fit the CU's 160 KB.  The gem scene of C3: 66 256 B.
 constexpr uint32_t kParkBlobLimitBytes = 72 * 1024;

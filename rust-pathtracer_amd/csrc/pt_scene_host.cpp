@@ -259,8 +259,22 @@ void xf_point(const float* m, const float* p, float* o) {
 
 }  // namespace
 
+static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::string* err, bool curve_tables, uint32_t* curve_table_words);
+// The curves' cell tables are an accelerator, and a scene that fits the LDS whole without them and not with them is better off without (the kernels of a scene staged
+// whole never touch global memory for scene data: G2F at 24.3 KB): built again without the tables then.
 bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
+    uint32_t table_words = 0;
+    if (!build_host_scene_with(d, hs, err, true, &table_words)) return false;
+    const size_t bytes = hs->blob.size() * 4;
+    if (table_words != 0 && bytes > PT_BLOB_LDS_ALL_BYTES && bytes - 4u * table_words <= PT_BLOB_LDS_ALL_BYTES) {
+        *hs = HostScene();
+        return build_host_scene_with(d, hs, err, false, &table_words);
+    }
+    return true;
+}
+static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::string* err, bool curve_tables, uint32_t* curve_table_words) {
     auto fail = [&](const char* m) { *err = m; return false; };
+    *curve_table_words = 0;
     if (d.material_count == 0 || !d.materials) return fail("scene needs at least the error material (index 0)");
     if (d.camera_count == 0 || !d.cameras) return fail("scene has no camera");
     if (d.environment.kind != PT_ENV_CONSTANT && d.environment.kind != PT_ENV_SUN && d.environment.kind != PT_ENV_HDR) return fail("unknown environment kind");
@@ -329,8 +343,35 @@ bool build_host_scene(const pt_scene_desc& d, HostScene* hs, std::string* err) {
         uint32_t off = (uint32_t)w.size();
         bool has = c.kind == PT_CURVE_LINEAR || c.kind == PT_CURVE_TABULATED || c.kind == PT_CURVE_EXPONENTIAL || c.kind == PT_CURVE_INV_EXPONENTIAL;
         if (has) for (uint32_t k = 0; k < c.data_count * per; ++k) w.push_back(fbits(d.curve_data[c.data_offset + k]));
+        // A tabulated curve's cell table (round 5; pt_blob.h PT_CURVE_GRID): the knot range in G equal cells, per cell the number of knots in lower cells — a lower
+        // bound of the binary search's answer for every wavelength of the cell (cell() is monotone), from which curve_eval walks up: the same index, one or two knot
+        // reads instead of log2 n.  cell() here is curve_grid_cell's arithmetic (pt_device.h), operation for operation.
+        uint32_t grid_word = 0, inv_bits = 0;
+        if (curve_tables && c.kind == PT_CURVE_TABULATED && c.data_count >= PT_CURVE_GRID_MIN_KNOTS && c.data_count <= 255u) {
+            const float* kd = d.curve_data + c.data_offset;
+            const uint32_t n = c.data_count;
+            bool sorted = true;
+            for (uint32_t k = 0; k < n; ++k) sorted = sorted && std::isfinite(kd[2 * k]) && (k == 0 || kd[2 * k] >= kd[2 * (k - 1)]);
+            uint32_t cells = 16; while (cells < n) cells *= 2;
+            const float x0 = kd[0], width = kd[2 * (n - 1)] - x0;
+            const float inv = (float)cells / width;
+            if (sorted && width > 0.0f && std::isfinite(inv) && inv > 0.0f) {
+                const float top = (float)(cells - 1);
+                std::vector<uint32_t> below(cells + 1, 0);   // below[g] = knots in cells < g
+                for (uint32_t k = 0; k < n; ++k) {
+                    const float fi = (kd[2 * k] - x0) * inv;
+                    const uint32_t g = fi >= 0.0f ? (uint32_t)(fi < top ? fi : top) : 0u;
+                    below[g + 1] += 1;
+                }
+                for (uint32_t g = 0; g < cells; ++g) below[g + 1] += below[g];
+                const uint32_t toff = (uint32_t)w.size();
+                for (uint32_t g = 0; g < cells; g += 4) w.push_back(below[g] | below[g + 1] << 8 | below[g + 2] << 16 | below[g + 3] << 24);
+                grid_word = toff | (cells - 1) << 24; inv_bits = fbits(inv); *curve_table_words += cells / 4;
+            }
+        }
         uint32_t* r = &w[curve_off[i]];
         r[0] = (uint32_t)c.kind; r[1] = (uint32_t)c.mode; r[2] = fbits(c.p0); r[3] = fbits(c.p1); r[4] = off; r[5] = has ? c.data_count : 0;
+        r[PT_CURVE_GRID] = grid_word; r[PT_CURVE_GRID_INV] = inv_bits;
     }
     w[PT_HDR_CURVE_OFF] = d.curve_count ? curve_off[0] : 0; w[PT_HDR_CURVE_COUNT] = d.curve_count;
     hs->curve_offsets = curve_off;

@@ -98,6 +98,60 @@ def material_parity(impl, oracle, scene_name, n=2048, seed=9):
         assert np.array_equal(si.curve_eval(c, lam2).view(np.uint32), so.curve_eval(c, lam2).view(np.uint32)), c
 
 
+def curve_table_parity(impl, oracle, seed=21):
+    """Tabulated curves (math::curves::Curve::Tabulated, evaluate: the first knot not below lambda, then the cubic between its neighbours) — the engine finds the knot
+    from a per-curve cell table (csrc/pt_scene_host.cpp, pt_device.h curve_eval), the oracle by the binary search: the same value for every wavelength, at the knots,
+    an ulp either side of them, at the cells' edges, outside the table, and for tables the engine builds no cell table for (fewer than 8 or more than 255 knots, unsorted)."""
+    P = pkg()
+    b = P.scene.SCENES["cornell_box"]()
+    P.scene.add_library_curves(b, ["cornell_white", "cornell_green", "cornell_red", "cornell_light", "gold_n", "gold_k", "copper_n", "copper_k", "srgb_r", "srgb_g", "srgb_b"])
+    rng = np.random.default_rng(seed)
+    tables = {}
+    for name in ("cornell_white", "gold_n", "copper_k", "srgb_b"):
+        tables[name] = None
+    def add(name, xs, mode=None):
+        xs = np.asarray(xs, dtype=np.float32)
+        ys = rng.uniform(0.0, 2.0, xs.size).astype(np.float32)
+        kw = {} if mode is None else {"mode": mode}
+        b.curve_tabulated(name, [float(x) for x in xs], [float(y) for y in ys], **kw)
+        tables[name] = xs
+    add("t_uniform_8", np.linspace(380, 780, 8))
+    add("t_seven", np.linspace(380, 780, 7))                                         # below the minimum: binary search
+    add("t_255", np.sort(rng.uniform(300, 900, 255)))
+    add("t_256", np.sort(rng.uniform(300, 900, 256)))                                # too many for a byte per cell: binary search
+    add("t_clustered", np.sort(np.concatenate([rng.uniform(549.9, 550.1, 60), rng.uniform(350, 800, 40)])))   # many knots in one cell
+    add("t_duplicates", np.sort(np.repeat(rng.uniform(400, 700, 30), 3)))            # equal neighbours: the first of them
+    add("t_ulp_steps", np.float32(500.0) + np.arange(40, dtype=np.float32) * np.float32(2 ** -14 * 4))   # knots a few ulps apart
+    add("t_wide", np.sort(np.concatenate([[1e-3, 1e7], rng.uniform(100, 2000, 50)])))
+    add("t_negative", np.linspace(-300, 900, 33))
+    add("t_linear", np.sort(rng.uniform(380, 780, 64)), mode=P.api.INTERP_LINEAR)
+    add("t_nearest", np.sort(rng.uniform(380, 780, 64)), mode=P.api.INTERP_NEAREST)
+    un = rng.uniform(380, 780, 40); un[[3, 17]] = un[[17, 3]]
+    add("t_unsorted", un)                                                            # not a valid table: whatever the binary search makes of it
+    si, so = impl.create_scene(b), oracle.create_scene(b)
+    special = np.array([0.0, -1.0, 1e-30, 379.99, 380.0, 780.0, 780.01, 1e9, 3e38, np.inf, -np.inf, np.nan], dtype=np.float32)
+    for name, c in b.curve_names.items():
+        xs = tables.get(name)
+        lam = [special, rng.uniform(300, 900, 20000).astype(np.float32), np.linspace(360, 800, 4401).astype(np.float32)]
+        if xs is None and name in tables:      # a library table: its knots from the scene
+            cr = b.curves[c]
+            xs = np.asarray(b.curve_data[cr.data_offset:cr.data_offset + 2 * cr.data_count:2], dtype=np.float32)
+        if xs is not None:
+            near = [xs]
+            for k in (1, 2, 3):
+                up, down = xs.copy(), xs.copy()
+                for _ in range(k): up, down = np.nextafter(up, np.float32(np.inf)), np.nextafter(down, np.float32(-np.inf))
+                near += [up, down]
+            lo, hi = float(xs.min()), float(xs.max())
+            edges = (lo + (hi - lo) * np.arange(0, 257) / 256.0).astype(np.float32)      # cell edges of every table size divide these
+            lam += near + [edges, np.nextafter(edges, np.float32(np.inf)), np.nextafter(edges, np.float32(-np.inf)), rng.uniform(lo - 1, hi + 1, 20000).astype(np.float32)]
+        lam = np.ascontiguousarray(np.concatenate(lam).astype(np.float32))
+        with np.errstate(all="ignore"):
+            got, want = si.curve_eval(c, lam), so.curve_eval(c, lam)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (name, lam[~same][:5], got[~same][:5], want[~same][:5])
+
+
 ULP_BAR_LOG = {}   # test id -> metrics of the film cases whose pixels needed the 8-ulp allowance (reported at the end of the GPU run, conftest.py)
 
 

@@ -40,6 +40,10 @@ def test_materials_bit_exact(emu, oracle, scene):
     ps.material_parity(emu, oracle, scene)
 
 
+def test_tabulated_curves_through_their_cell_tables(emu, oracle):
+    ps.curve_table_parity(emu, oracle)
+
+
 @pytest.mark.parametrize("scene,w,h,spp,mb,kw", [
     ("cornell_box", 48, 40, 13, 4, {}),                       # C1 shape at reduced size; spp not a multiple of 10
     ("cornell_box", 33, 21, 4, 8, {"tile": (16, 16)}),        # remnant tiles (tiled.rs:236-277)

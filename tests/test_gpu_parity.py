@@ -46,6 +46,10 @@ def test_device_arithmetic_matches_x86(engine, oracle):
         assert np.array_equal(dev(10, x, y).view(np.uint32), ((x * y).astype(np.float32) + x).view(np.uint32))  # not fused
 
 
+def test_tabulated_curves_through_their_cell_tables(engine, oracle):
+    ps.curve_table_parity(engine, oracle)
+
+
 def test_colour_matching_fit_for_every_wavelength(engine, oracle):
     """k_accumulate's cheaper evaluation of the CIE fit (csrc/pt_device.h: gaussian64_fast) on the device against the oracle's, for every f32 of the range it is
     used in (10 027 009 wavelengths x 3 outputs), and the contract's form outside the range."""
