@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
             out = stage_shade<NL, FORM == PT_SHADE_FULL, FORM != PT_SHADE_LEAN>(s, rp, bounce, pv, hit, pixel, [&](uint32_t l, const ShadowRayT<NL>& ray) { store_shadow_ray<NL>(shadow, ipos, l, ray); if (kLiveList) item_lives = item_lives || ray_is_live<NL>(ray); });
             if (wants_item) {
                 float lam[NL]; lam[0] = pv.lambda;
-                if (NL > 1) hero_lambdas<NL>(rp, pt_draw4(rp.seed, pixel, rp.first_sample + pv.slot / rp.chunk_pixels, PT_DIM_FILM).z, lam);
+                if (NL > 1) hero_lambdas<NL>(rp, pv.lambda, lam);
                 qsu(shadow, Layout<NL>::sh_slot, ipos, pv.slot); qsu(shadow, Layout<NL>::sh_flags, ipos, out.env_mask);
                 for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_lambda + k, ipos, lam[k]);
                 if (!out.has_item) clear_shadow_item<NL>(shadow, ipos, rp.light_samples);  // vertex dropped (NaN pdf, utils.rs:261-263)

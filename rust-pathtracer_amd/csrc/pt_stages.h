@@ -180,7 +180,9 @@ PT_HD PathVertexT<NL> stage_generate(const RenderParams& rp, uint32_t slot, uint
     pt_f32x4 fs = pt_draw4(rp.seed, pixel, sample, PT_DIM_FILM);
     float cu = ((float)x + fs.x) / (float)rp.width, cv = ((float)y + fs.y) / (float)rp.height;  // box filter, tiled.rs:372-375
     PathVertexT<NL> p;
-    p.lambda = rp.wavelength_lo + fs.z * rp.wavelength_span;                                     // pt.rs:406
+    // pt.rs:406.  (round 5) A hero-wavelength path carries the wavelength SAMPLE instead — its four wavelengths are functions of it (hero_lambdas), and a vertex that
+    // holds it need not draw the film block again for them (a Philox draw per vertex: C5 k_shade).
+    p.lambda = NL > 1 ? fs.z : rp.wavelength_lo + fs.z * rp.wavelength_span;
     float fu = pt_clamp(cu, 0.0f, 1.0f - PT_F32_EPSILON), fv = pt_clamp(cv, 0.0f, 1.0f - PT_F32_EPSILON);  // pt.rs:411-414
     camera_ray(rp.camera, rp.seed, pixel, sample, fu, fv, &p.o, &p.d);
     for (int k = 0; k < NL; ++k) p.beta[k] = 1.0f;
@@ -233,7 +235,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     bool prev_is_camera = bounce == 0;
     float lam[NL];
     lam[0] = pv.lambda;
-    if (NL > 1) hero_lambdas<NL>(rp, pt_draw4(rp.seed, pixel, sample, PT_DIM_FILM).z, lam);
+    if (NL > 1) hero_lambdas<NL>(rp, pv.lambda, lam);   // (the record holds the wavelength sample, stage_generate)
     const float lambda = lam[0];
     if (!hit.valid) {
         // environment vertex (utils.rs:344-372) and its MIS-weighted emission (pt.rs:487-511)
@@ -383,7 +385,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     out.next.o = add(hit.p, mul(mul(hit.n, 0.001f), pt_signum(wo.z)));
     out.next.d = normalize(to_world(frame, wo));
     for (int k = 0; k < NL; ++k) out.next.beta[k] = beta[k];
-    out.next.lambda = lambda; out.next.slot = pv.slot;
+    out.next.lambda = pv.lambda; out.next.slot = pv.slot;
     out.next.prev_pdf = pdf_forward; out.next.prev_n = hit.n; out.next.prev_p = hit.p;
     return out;
 }
