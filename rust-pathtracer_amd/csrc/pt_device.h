@@ -2451,22 +2451,36 @@ PT_HD void sample_cmf(const float* pdf, const float* cmf, uint32_t n, float x, f
     c = pt_clamp(c, 0.0f, 1.0f - PT_F32_EPSILON);
     *coord = c; *p = linear01_nearest(pdf, n, c, stride);
 }
-PT_HD float env_emission(const SceneView& s, float u, float v, float lambda) {
+// What the emission and the pdf of an environment direction both start from, computed once per (u, v) (round 5: a vertex that left the scene took the direction of
+// its (u, v) and — under an HDR map — that direction's texture coordinates twice, once for the pdf and once for the emission; a light sample took the direction once for
+// its ray and again for its emission.  The same operations on the same values, made once: 2 sincos + atan2 + acos per environment vertex, 2 sincos per environment sample.)
+struct EnvPoint { F3 dir; float u2, v2; };
+PT_HD EnvPoint env_point_of(const SceneView& s, F3 dir) {   // dir = uv_to_direction(u, v)
+    EnvPoint e; e.dir = dir; e.u2 = 0.0f; e.v2 = 0.0f;
+    if (bu(s, PT_HDR_ENV_KIND) == PT_ENV_HDR) {
+        // HDR (environment.rs:84-96): direction -> rotation.to_local -> equirect uv
+        F3 nd = xf_vec(s, PT_HDR_ENV_REVERSE, dir);
+        direction_to_uv(nd, &e.u2, &e.v2);
+    }
+    return e;
+}
+PT_HD EnvPoint env_point(const SceneView& s, float u, float v) {
+    if (bu(s, PT_HDR_ENV_KIND) == PT_ENV_CONSTANT) { EnvPoint e; e.dir = f3(0, 0, 0); e.u2 = 0.0f; e.v2 = 0.0f; return e; }   // (nothing of it is read)
+    return env_point_of(s, uv_to_direction(u, v));
+}
+PT_HD float env_emission(const SceneView& s, const EnvPoint& e, float lambda) {
     uint32_t kind = bu(s, PT_HDR_ENV_KIND);
     float strength = bf(s, PT_HDR_ENV_STRENGTH);
     if (kind == PT_ENV_CONSTANT) return curve_eval(s, bu(s, PT_HDR_ENV_CURVE), lambda) * strength;
     if (kind == PT_ENV_SUN) {
-        F3 dir = uv_to_direction(u, v);
         F3 sd = bf3(s, PT_HDR_ENV_SUN_DIR);
-        float c = dot(sd, dir), sn = pt_sqrt(1.0f - c * c);
+        float c = dot(sd, e.dir), sn = pt_sqrt(1.0f - c * c);
         if (pt_abs(sn) < pt_sin(bf(s, PT_HDR_ENV_ANGULAR) / 2.0f) && c > 0.0f) return curve_eval(s, bu(s, PT_HDR_ENV_CURVE), lambda) * strength;
         return 0.0f;
     }
-    // HDR (environment.rs:84-96): direction -> rotation.to_local -> equirect uv -> TexStack
-    F3 nd = xf_vec(s, PT_HDR_ENV_REVERSE, uv_to_direction(u, v));
-    float u2, v2; direction_to_uv(nd, &u2, &v2);
-    return texstack_eval(s, bu(s, PT_HDR_ENV_TEXSTACK), lambda, u2, v2) * strength;
+    return texstack_eval(s, bu(s, PT_HDR_ENV_TEXSTACK), lambda, e.u2, e.v2) * strength;   // -> TexStack
 }
+PT_HD float env_emission(const SceneView& s, float u, float v, float lambda) { return env_emission(s, env_point(s, u, v), lambda); }
 // The same for the light samples of one vertex: an HDR environment of one layer (every HDRI of the reference's scene files)
 // evaluates its curves once per vertex and wavelength instead of once per light sample.
 struct EnvCurves { LayerCurves c; bool cached; };
@@ -2478,27 +2492,23 @@ PT_HD EnvCurves env_curves(const SceneView& s, float lambda) {
     e.c = layer_curves(s, ts + 1, lambda); e.cached = true;
     return e;
 }
-PT_HD float env_emission(const SceneView& s, float u, float v, float lambda, const EnvCurves& ec) {
-    if (!ec.cached) return env_emission(s, u, v, lambda);
-    F3 nd = xf_vec(s, PT_HDR_ENV_REVERSE, uv_to_direction(u, v));
-    float u2, v2; direction_to_uv(nd, &u2, &v2);
-    return (0.0f + layer_eval(s, bu(s, PT_HDR_ENV_TEXSTACK) + 1, ec.c, u2, v2)) * bf(s, PT_HDR_ENV_STRENGTH);
+PT_HD float env_emission(const SceneView& s, const EnvPoint& e, float lambda, const EnvCurves& ec) {
+    if (!ec.cached) return env_emission(s, e, lambda);
+    return (0.0f + layer_eval(s, bu(s, PT_HDR_ENV_TEXSTACK) + 1, ec.c, e.u2, e.v2)) * bf(s, PT_HDR_ENV_STRENGTH);
 }
-PT_HD float env_pdf_for(const SceneView& s, float u, float v) {
+PT_HD float env_pdf_for(const SceneView& s, const EnvPoint& e) {
     uint32_t kind = bu(s, PT_HDR_ENV_KIND);
     if (kind == PT_ENV_SUN) {
-        F3 dir = uv_to_direction(u, v);
         F3 sd = bf3(s, PT_HDR_ENV_SUN_DIR);
         float ad = bf(s, PT_HDR_ENV_ANGULAR);
-        float c = dot(sd, dir), sn = pt_sqrt(1.0f - c * c);
+        float c = dot(sd, e.dir), sn = pt_sqrt(1.0f - c * c);
         if (pt_abs(sn) < pt_sin(ad / 2.0f) && c > 0.0f) return 1.0f / (2.0f * PT_PI * (1.0f - pt_cos(ad)));
         return 0.0f;
     }
     uint32_t rows = bu(s, PT_HDR_IMAP_ROWS);
     if (kind == PT_ENV_HDR && rows > 0) {  // environment.rs:221-253
         uint32_t cols = bu(s, PT_HDR_IMAP_COLS);
-        F3 nd = xf_vec(s, PT_HDR_ENV_REVERSE, uv_to_direction(u, v));
-        float u2, v2; direction_to_uv(nd, &u2, &v2);
+        const float u2 = e.u2, v2 = e.v2;
         uint32_t row = (uint32_t)(pt_clamp(u2, 0.0f, 1.0f - PT_F32_EPSILON) * (float)rows);
         const uint32_t stride = bu(s, PT_HDR_IMAP_STRIDE);
         const float marginal_pdf = s.marg_words != 0u ? linear01_nearest(s.marg + (bu(s, PT_HDR_IMAP_MARG_PDF) - s.marg_base), rows, u2, stride)   // (the LDS copy: stage_marginal)
@@ -2510,6 +2520,7 @@ PT_HD float env_pdf_for(const SceneView& s, float u, float v) {
     }
     return 1.0f / (4.0f * PT_PI);
 }
+PT_HD float env_pdf_for(const SceneView& s, float u, float v) { return env_pdf_for(s, env_point(s, u, v)); }
 PT_HD void env_sample_uv(const SceneView& s, float sx, float sy, float* u, float* v, float* pdf) {
     uint32_t kind = bu(s, PT_HDR_ENV_KIND);
     if (kind == PT_ENV_SUN) {

@@ -243,10 +243,11 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
         float u = 0.0f, v = 0.0f;
         if (bu(s, PT_HDR_ENV_KIND) != PT_ENV_CONSTANT) direction_to_uv(wo, &u, &v);
         float cos_i = pt_abs(dot(pv.prev_n, wo));
-        float nee_psa_pdf = env_pdf_for(s, u, v) / pt_abs(cos_i);
+        const EnvPoint ep = env_point(s, u, v);   // (the direction of (u, v) and its texture coordinates: once for the pdf and the emission)
+        float nee_psa_pdf = env_pdf_for(s, ep) / pt_abs(cos_i);
         float bsdf_psa_pdf = pv.prev_pdf / pt_abs(cos_i);
         float weight = (bsdf_psa_pdf * bsdf_psa_pdf) / (bsdf_psa_pdf * bsdf_psa_pdf + nee_psa_pdf * nee_psa_pdf);
-        PT_ROLLED for (int k = 0; k < NL; ++k) pl_set<NL>(out.energy_add, k, weight * pl_get<NL>(pv.beta, k) * env_emission(s, u, v, pl_get<NL>(lam, k)));
+        PT_ROLLED for (int k = 0; k < NL; ++k) pl_set<NL>(out.energy_add, k, weight * pl_get<NL>(pv.beta, k) * env_emission(s, ep, pl_get<NL>(lam, k)));
         out.add_energy = true;
         out.vertex_pushed = true; out.env_hit = true;
         return out;
@@ -312,15 +313,16 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                     F3 direction = uv_to_direction(eu, ev);
                     F3 local_wo = to_local(fr2, direction);
                     if (local_wo.z > 0.0f) {
+                        const EnvPoint ep = env_point_of(s, direction);   // (the sample's emission starts from the same direction: not taken twice)
                         float refl, spdf;
                         material_bsdf_p<GGX>(me0, wi2, local_wo, &refl, &spdf);
                         float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + spdf);
                         ray.o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(direction.z)));
                         ray.d = direction;
-                        ray.factor[0] = pv.beta[0] * weight * refl * env_emission(s, eu, ev, lambda, ec[0]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
+                        ray.factor[0] = pv.beta[0] * weight * refl * env_emission(s, ep, lambda, ec[0]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
                         for (int k = 1; k < NL; ++k) {   // (hero wavelengths under an environment that light samples pick: no BASELINE configuration; unrolled)
                             float rk, pk; material_bsdf_p<GGX>(material_at<NL>(me, k), wi2, local_wo, &rk, &pk);
-                            ray.factor[k] = pv.beta[k] * weight * rk * env_emission(s, eu, ev, lam[k], ec[k]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
+                            ray.factor[k] = pv.beta[k] * weight * rk * env_emission(s, ep, lam[k], ec[k]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
                         }
                         out.shadow_count += 1;
                         // a contribution of exactly 0 adds 0 whether or not the ray is occluded: not traced
@@ -421,10 +423,11 @@ PT_HD ShadeOutT<1> stage_shade_medium(const SceneView& s, const RenderParams& rp
             float u = 0.0f, v = 0.0f;
             if (bu(s, PT_HDR_ENV_KIND) != PT_ENV_CONSTANT) direction_to_uv(wo, &u, &v);
             float cos_i = pt_abs(dot(pv.prev_n, wo));
-            float nee_psa_pdf = env_pdf_for(s, u, v) / pt_abs(cos_i);
+            const EnvPoint ep = env_point(s, u, v);
+            float nee_psa_pdf = env_pdf_for(s, ep) / pt_abs(cos_i);
             float bsdf_psa_pdf = pv.prev_pdf / pt_abs(cos_i);
             float weight = (bsdf_psa_pdf * bsdf_psa_pdf) / (bsdf_psa_pdf * bsdf_psa_pdf + nee_psa_pdf * nee_psa_pdf);
-            out.energy_add[0] = weight * pv.beta[0] * env_emission(s, u, v, lambda);
+            out.energy_add[0] = weight * pv.beta[0] * env_emission(s, ep, lambda);
             out.add_energy = true; out.env_hit = true;
         }
         return out;
@@ -497,12 +500,13 @@ PT_HD ShadeOutT<1> stage_shade_medium(const SceneView& s, const RenderParams& rp
                     const F3 direction = uv_to_direction(eu, ev);
                     const F3 local_wo = to_local(fr2, direction);
                     if (local_wo.z > 0.0f) {
+                        const EnvPoint ep = env_point_of(s, direction);
                         float refl, spdf;
                         material_bsdf_p(mev, wi2, local_wo, &refl, &spdf);
                         const float weight = rp.only_direct ? 1.0f : light_pdf / (light_pdf + spdf);
                         ray.o = add(hit.p, mul(mul(hn, 0.001f), pt_signum(direction.z)));
                         ray.d = direction;
-                        ray.factor[0] = pv.beta[0] * weight * refl * env_emission(s, eu, ev, lambda, ec) * pt_abs(local_wo.z) * (1.0f / light_pdf);
+                        ray.factor[0] = pv.beta[0] * weight * refl * env_emission(s, ep, lambda, ec) * pt_abs(local_wo.z) * (1.0f / light_pdf);
                         out.shadow_count += 1;
                         if (ray_is_live<1>(ray)) out.env_mask |= 1u << l;
                     }
