@@ -73,7 +73,7 @@ def algorithmic_bytes(stage, light_samples):
     producer; DESIGN.md 'Algorithmic bytes').  4-byte fields."""
     path, hit = 16 * 4, 11 * 4
     if stage == "generate":
-        return path + 4 + 4                       # write path state + zero energy, read pixel id (the lean camera record, 7 words for 16, is taken off below where a render used it)
+        return path + 4 + 4 + 4                   # write path state + zero energy + the wavelength sample k_accumulate reads, read pixel id (the lean camera record, 7 words for 16, is taken off below where a render used it)
     if stage == "extend":
         return 6 * 4 + hit                        # read ray (o, d), write hit record
     if stage == "shade":
@@ -347,7 +347,7 @@ def main():
         if fused:
             per_item[2] -= 11 * 4                       # no hit record to read (and k_extend's 24 + 44 B per segment are not moved at all)
         kbytes = [per_item[i] * kitems[i] for i in range(5)]
-        kbytes[4] += 4 * sum(p.camera_rays for p in profs)          # accumulate also reads one energy per sample
+        kbytes[4] += 8 * sum(p.camera_rays for p in profs)          # accumulate also reads one energy and one wavelength sample per sample
         camera_record = all(p.stage_items[7] == 1 for p in profs)    # the camera vertex' lean record: 7 of the 16 words written by k_generate, read at bounce 0
         if camera_record:
             lean = 9 * 4 * sum(p.camera_rays for p in profs)

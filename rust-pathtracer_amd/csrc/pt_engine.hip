@@ -193,7 +193,7 @@ pt_status ensure_buffers(pt_scene* sc, uint32_t capacity, uint32_t light_samples
         HIP_TRY(hipMalloc(&b.paths_b, sizeof(uint32_t) * path_fields * total));
         HIP_TRY(hipMalloc(&b.hits, sizeof(uint32_t) * (size_t)HS_FIELDS * total));
         HIP_TRY(hipMalloc(&b.shadow, sizeof(uint32_t) * sh_fields * total));
-        HIP_TRY(hipMalloc(&b.energy, sizeof(float) * (size_t)nlmax * total));
+        HIP_TRY(hipMalloc(&b.energy, sizeof(float) * (size_t)(nlmax + 1u) * total));   // (+ the plane of wavelength samples, PT_STORED_WAVELENGTH)
         b.nl = nlmax;
         HIP_TRY(hipMalloc(&b.counts, sizeof(uint32_t) * 4 * (size_t)grid));   // (live paths x 2, light-sample items, live light-sample items)
         HIP_TRY(hipMalloc(&b.block_stats, sizeof(unsigned long long) * BS_FIELDS * (size_t)grid));

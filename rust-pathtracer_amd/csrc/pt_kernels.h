@@ -243,9 +243,11 @@ __global__ void __launch_bounds__(kBlock) k_generate(RenderParams rp, const uint
     for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x) {
         uint32_t slot = base + j;
         uint32_t pixel = pixels[slot % rp.chunk_pixels];
-        PathVertexT<NL> p = stage_generate<NL>(rp, slot, pixel);
+        float u = 0.0f;
+        PathVertexT<NL> p = stage_generate<NL>(rp, slot, pixel, &u);
         if (PT_CAMERA_RECORD && rp.camera_record) store_path_camera<NL>(paths, slot, p); else store_path<NL>(paths, slot, p);
         for (int k = 0; k < NL; ++k) energy[(size_t)k * rp.energy_stride + slot] = 0.0f;
+        if (PT_STORED_WAVELENGTH) energy[(size_t)NL * rp.energy_stride + slot] = u;   // (the plane behind the energies: k_accumulate's wavelength sample)
     }
     if (threadIdx.x == 0) count_out[blockIdx.x] = cnt;
 }

@@ -122,6 +122,9 @@ PT_HD PathVertexT<NL> load_path(const Queue& q, uint32_t i) {
 // The camera vertex' record (round 5): of the sixteen words stage_generate fills, nine are functions of the other seven and of the item's index — throughput 1, slot = the
 // index (k_generate stores slot s at index s), previous pdf 100, previous normal = the direction, previous point = the origin (pt.rs:430-446).  k_generate writes the ray and the
 // wavelength alone (28 of 64 bytes: it is bound by those writes, 5.7 TB/s) and the first bounce's vertex kernel rebuilds the rest instead of reading it: the same values.
+#ifndef PT_STORED_WAVELENGTH
+#define PT_STORED_WAVELENGTH 1   /* k_generate leaves each sample's wavelength sample behind the energy planes and k_accumulate reads it (round 5); 0: k_accumulate draws it again */
+#endif
 #ifndef PT_CAMERA_RECORD
 #define PT_CAMERA_RECORD 1   /* 0: the full record written and read at every bounce (rounds 1-4) */
 #endif
@@ -173,7 +176,7 @@ PT_HD Hit load_hit(const Queue& q, uint32_t i) {
 
 // ------------------------------------------------------------------------------------------------ generate
 template <int NL>
-PT_HD PathVertexT<NL> stage_generate(const RenderParams& rp, uint32_t slot, uint32_t pixel) {
+PT_HD PathVertexT<NL> stage_generate(const RenderParams& rp, uint32_t slot, uint32_t pixel, float* wavelength_sample = nullptr) {
     uint32_t s_local = slot / rp.chunk_pixels;
     uint32_t sample = rp.first_sample + s_local;
     uint32_t x = pixel % rp.width, y = pixel / rp.width;
@@ -183,6 +186,7 @@ PT_HD PathVertexT<NL> stage_generate(const RenderParams& rp, uint32_t slot, uint
     // pt.rs:406.  (round 5) A hero-wavelength path carries the wavelength SAMPLE instead — its four wavelengths are functions of it (hero_lambdas), and a vertex that
     // holds it need not draw the film block again for them (a Philox draw per vertex: C5 k_shade).
     p.lambda = NL > 1 ? fs.z : rp.wavelength_lo + fs.z * rp.wavelength_span;
+    if (wavelength_sample != nullptr) *wavelength_sample = fs.z;
     float fu = pt_clamp(cu, 0.0f, 1.0f - PT_F32_EPSILON), fv = pt_clamp(cv, 0.0f, 1.0f - PT_F32_EPSILON);  // pt.rs:411-414
     camera_ray(rp.camera, rp.seed, pixel, sample, fu, fv, &p.o, &p.d);
     for (int k = 0; k < NL; ++k) p.beta[k] = 1.0f;
@@ -669,9 +673,11 @@ PT_HD void stage_accumulate_pixel(const RenderParams& rp, const float* energy, u
     for (uint32_t s_local = 0; s_local < rp.pass_samples; ++s_local) {
         uint32_t sample = rp.first_sample + s_local;
         size_t slot = (size_t)s_local * rp.chunk_pixels + p;
-        pt_f32x4 fs = pt_draw4(rp.seed, pixel, sample, PT_DIM_FILM);
+        // (round 5) the sample's wavelength sample u as k_generate left it in the plane behind the energies (PT_STORED_WAVELENGTH) — not the film block's Philox draw again,
+        // which was 40 % of this loop; hero_lambdas(u)[0] is stage_generate's own expression for the wavelength
         float lam[NL];
-        hero_lambdas<NL>(rp, fs.z, lam);
+        if (PT_STORED_WAVELENGTH) hero_lambdas<NL>(rp, energy[(size_t)NL * rp.energy_stride + slot], lam);
+        else hero_lambdas<NL>(rp, pt_draw4(rp.seed, pixel, sample, PT_DIM_FILM).z, lam);
         if (NL == 1) {
             float e = energy[slot];
             float xb, yb, zb;

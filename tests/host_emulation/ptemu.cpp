@@ -87,7 +87,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
     const size_t cap64 = ((size_t)capacity + 63u) & ~(size_t)63u;   // queues are tiled by 64 items (pt_stages.h)
     std::vector<uint32_t> pa((size_t)(LY::path_fields + 2) * cap64), pb((size_t)(LY::path_fields + 2) * cap64), ph((size_t)HS_FIELDS * cap64),
         psh((size_t)LY::shadow_fields(PT_MAX_LIGHT_SAMPLES) * cap64);
-    std::vector<float> energy((size_t)NL * capacity);
+    std::vector<float> energy((size_t)(NL + 1) * capacity);   // (+ the plane of wavelength samples, PT_STORED_WAVELENGTH)
     Queue qa{pa.data(), capacity, LY::path_fields + 2}, qb{pb.data(), capacity, LY::path_fields + 2}, qh{ph.data(), capacity, HS_FIELDS}, qs{psh.data(), capacity, LY::shadow_fields(PT_MAX_LIGHT_SAMPLES)};
     uint64_t bounce_rays = 0, shadow_rays = 0, env_hits = 0, camera_rays = 0, medium_drops = 0;
     uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
@@ -96,7 +96,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
         const uint32_t* px = pixels.data() + pass.pixel_begin;
         uint32_t n = pass.pixel_count * pass.sample_count;
         camera_rays += n;
-        for (uint32_t i = 0; i < n; ++i) { if (PT_CAMERA_RECORD && rp.camera_record) store_path_camera<NL>(qa, i, stage_generate<NL>(rp, i, px[i % rp.chunk_pixels])); else store_path<NL>(qa, i, stage_generate<NL>(rp, i, px[i % rp.chunk_pixels])); for (int k = 0; k < NL; ++k) energy[(size_t)k * capacity + i] = 0.0f; }
+        for (uint32_t i = 0; i < n; ++i) { float u = 0.0f; const PathVertexT<NL> pg = stage_generate<NL>(rp, i, px[i % rp.chunk_pixels], &u); if (PT_CAMERA_RECORD && rp.camera_record) store_path_camera<NL>(qa, i, pg); else store_path<NL>(qa, i, pg); for (int k = 0; k < NL; ++k) energy[(size_t)k * capacity + i] = 0.0f; energy[(size_t)NL * capacity + i] = u; }
         uint32_t live = n;
         bool has_ggx = false;
         for (uint32_t i = 0; i < bu(s, PT_HDR_MATERIAL_COUNT); ++i) {
