@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--min-bounces", type=int, default=1)
     ap.add_argument("--env-sampling-probability", type=float, default=None, help="override the scene's env_sampling_probability (as the reference's config file can)")
     ap.add_argument("--hero", type=int, default=1, help="wavelengths per path: 1, or 4 for the hero-wavelength variant (C5)")
+    ap.add_argument("--medium-aware", action="store_true", help="the medium-aware walk (RenderSettings of the reference's PT integrator with mediums: src/integrator/utils.rs:708-1103; scene fog_ball)")
     ap.add_argument("--workload", default=None, help="label for config.workload (default: derived from the arguments)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline (0 = skip)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -249,7 +250,7 @@ def main():
 
     def step(k):
         rd = pkg.api.render_desc(W, H, total_spp, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1,
-                                 shard=sharding.shard(rank, n_gpus), first_sample=k * S, sample_count=S, hero_wavelengths=args.hero)
+                                 shard=sharding.shard(rank, n_gpus), first_sample=k * S, sample_count=S, hero_wavelengths=args.hero, medium_aware=args.medium_aware)
         prof = scene.render_device(rd, film_step.data_ptr(), stream)
         film_total.add_(film_step)
         return prof
@@ -367,7 +368,7 @@ def main():
         # coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact (calibrated on k_generate's 68 B/item).
         # Only a profile taken on exactly this workload counts (every key below must match); otherwise the fields stay null.
         workload_key = {**({"env_sampling_probability": args.env_sampling_probability} if args.env_sampling_probability is not None else {}), "scene": args.scene, "width": W, "height": H, "max_bounces": args.max_bounces, "min_bounces": args.min_bounces,
-                        "light_samples": L, "hero": args.hero, "spp_per_step": S, "n_gpus": n_gpus}
+                        "light_samples": L, "hero": args.hero, "spp_per_step": S, "n_gpus": n_gpus, **({"medium_aware": True} if args.medium_aware else {})}
         traffic, traffic_src, valu = None, None, None
         try:
             import glob
@@ -427,12 +428,12 @@ def main():
                 t = time.perf_counter(); _, pr = oracle_loader.render_mt(oracle, oscene, rd, cores); return pr, time.perf_counter() - t
             # calibrate on ~1 s of work, then a bounded sample: every 32x32 tile of the film (the thread pool takes them from one
             # queue) at as many samples per pixel as the budget buys — at least 4 tiles per thread of ~1 s each, so the tail is short
-            pp, dt = orender(pkg.api.render_desc(W, H, 1, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, shard=(0, 4), hero_wavelengths=args.hero))
+            pp, dt = orender(pkg.api.render_desc(W, H, 1, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, shard=(0, 4), hero_wavelengths=args.hero, medium_aware=args.medium_aware))
             rate = pp.camera_rays / dt
-            pp, dt = orender(pkg.api.render_desc(W, H, max(1, min(16, int(rate * 2.0 / (W * H)))), args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, hero_wavelengths=args.hero))
+            pp, dt = orender(pkg.api.render_desc(W, H, max(1, min(16, int(rate * 2.0 / (W * H)))), args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, hero_wavelengths=args.hero, medium_aware=args.medium_aware))
             rate = pp.camera_rays / dt
             spp = max(1, int(rate * args.cpu_seconds / (W * H)))
-            pc, dt = orender(pkg.api.render_desc(W, H, spp, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, hero_wavelengths=args.hero))
+            pc, dt = orender(pkg.api.render_desc(W, H, spp, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, hero_wavelengths=args.hero, medium_aware=args.medium_aware))
             rays_per_sample = (pc.bounce_rays + pc.shadow_rays) / max(1, pc.camera_rays)
             cpu = {"value": pc.camera_rays / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
                    "sample": "oracle (C++ restatement of the reference PT path, std::thread over a queue of 32x32 tiles) on %d host threads (os.cpu_count() = %d, "
@@ -448,7 +449,7 @@ def main():
         # parity tests use (tests/parity_suite.py: L-inf < 1e-4 flat; a pixel whose own 8 ulp exceed that — values above ~128 — gets those)
         parity = None
         if args.cpu_seconds > 0:
-            rd = pkg.api.render_desc(64, 64, 4, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, hero_wavelengths=args.hero)
+            rd = pkg.api.render_desc(64, 64, 4, args.max_bounces, min_bounces=args.min_bounces, light_samples=L, seed=1, hero_wavelengths=args.hero, medium_aware=args.medium_aware)
             gfilm, gprof = scene.render(rd)
             ofilm, oprof = oscene.render(rd)
             ok = np.isfinite(ofilm[..., :3]) & np.isfinite(gfilm[..., :3])
