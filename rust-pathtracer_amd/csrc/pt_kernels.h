@@ -30,6 +30,9 @@ inline void go_block(const LaunchCfg& c, int block, uint32_t lds_bytes, K kernel
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 4   // (round 4: the FULL forms at four waves with 26 registers spilled — C4's k_shade 9252 -> 8560 us, C4 +4.8 %, G1 +1 %: the kernel waits for its table fetches; profiles/r4v_full4.txt)
 #endif
+#ifndef PT_MEDIUM_SPLIT
+#define PT_MEDIUM_SPLIT 1   /* k_shade_medium shades its surface vertices in waves of their own (round 5); 0: every vertex where its item lies */
+#endif
 #ifndef PT_SHADE_MEDIUM_WAVES
 #define PT_SHADE_MEDIUM_WAVES 3
 #endif
@@ -412,30 +415,63 @@ k_shade_medium(const uint32_t* __restrict__ blob, uint32_t blob_words, const flo
     const uint32_t base = blockIdx.x * seg_cap, n = count_in[blockIdx.x];
     uint32_t st_vertices = 0, st_shadow = 0, st_env = 0, st_drops = 0;
     const uint32_t rounds = (n + blockDim.x - 1) / blockDim.x;
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t j = r * blockDim.x + threadIdx.x, i = base + j;
-        const bool active = j < n;
+    // (round 5) The split by vertex kind that k_shade's FULL form has, behind the free-flight step: a wave first takes its 64 items through stage_medium_flight —
+    // environment vertices and medium vertices (a phase-function sample) are finished there — and keeps the SURFACE vertices (material, light samples: the expensive
+    // kind) with the throughput their segment left in a list of its own, shading them 64 at a time whenever the list holds that many, and what is left at the end.
+    // The kinds shared waves at a lane utilisation of 0.36 (profiles/r5z_F4_summary.json).  No vertex' result depends on when it is shaded; a light-sample item is
+    // reserved when its surface vertex is shaded (a vertex that scattered in a medium first used to reserve one and clear it).
+    __shared__ uint32_t later[PT_MEDIUM_SPLIT ? kBlock * 2 : 1];
+    __shared__ float later_beta[PT_MEDIUM_SPLIT ? kBlock * 2 : 1];
+    uint32_t* my_later = later + (PT_MEDIUM_SPLIT ? (threadIdx.x >> 6) * 128u : 0u);
+    float* my_beta = later_beta + (PT_MEDIUM_SPLIT ? (threadIdx.x >> 6) * 128u : 0u);
+    uint32_t later_count = 0;   // (wave-uniform)
+    for (uint32_t r = 0;;) {
+        uint32_t i = 0;
+        bool active = false, resumed = false;
+        float beta_in = 0.0f;
+        if (PT_MEDIUM_SPLIT && (later_count >= 64u || (r == rounds && later_count > 0u))) {
+            const uint32_t take = later_count < 64u ? later_count : 64u;
+            later_count -= take;
+            active = lane_id() < take; resumed = true;
+            if (active) { i = my_later[later_count + lane_id()]; beta_in = my_beta[later_count + lane_id()]; }
+        } else if (r < rounds) {
+            const uint32_t j = r * blockDim.x + threadIdx.x;
+            ++r;
+            active = j < n; i = base + j;
+        } else break;
         PathVertexT<1> pv; Hit hit; hit.valid = false;
         MediumState ms{0u, 0u}, ms_next{0u, 0u};
-        bool wants_item = false;
         if (active) {
             pv = load_path<1>(paths_in, i);
             hit = load_hit(hits, i);
             if (bounce != 0) { ms.mediums = qu(paths_in, PS_MEDIUMS, i); ms.prev_medium = qu(paths_in, PS_PREV_MEDIUM, i); }   // (the camera starts in vacuum)
-            wants_item = shade_medium_wants_item(s, rp, hit, ms);
         }
-        const uint32_t ipos = base + shared_append(wants_item, &lds_counts[1]);
         ShadeOutT<1> out;
-        out.survives = false; out.has_item = false; out.vertex_pushed = false; out.env_hit = false; out.shadow_count = 0; out.add_energy = false; out.env_mask = 0;
-        if (active) {
-            const uint32_t pixel = pixels[pv.slot % rp.chunk_pixels];
-            out = stage_shade_medium(s, rp, bounce, pv, hit, pixel, ms, &ms_next, [&](uint32_t l, const ShadowRayT<1>& ray) { store_shadow_ray<1>(shadow, ipos, l, ray); });
-            if (wants_item) {
-                qsu(shadow, Layout<1>::sh_slot, ipos, pv.slot); qsu(shadow, Layout<1>::sh_flags, ipos, out.env_mask);
-                qsf(shadow, Layout<1>::sh_lambda, ipos, pv.lambda);
-                if (!out.has_item) clear_shadow_item<1>(shadow, ipos, rp.light_samples);   // a medium vertex, or a surface vertex that was never pushed
+        shade_out_clear(&out);
+        if (PT_MEDIUM_SPLIT && !resumed) {
+            bool surface = false; float beta = 0.0f;
+            if (active) surface = stage_medium_flight(s, rp, bounce, pv, hit, pixels[pv.slot % rp.chunk_pixels], ms, &ms_next, &out, &beta);
+            const unsigned long long m = __ballot(surface);
+            if (surface) { const uint32_t e = later_count + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull)); my_later[e] = i; my_beta[e] = beta; }
+            later_count += (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();   // (the list is the wave's own: its writes are in LDS before any of its lanes reads them)
+            if (active && out.add_energy) energy[pv.slot] += out.energy_add[0];
+        } else {
+            // the surface vertices of the list (or, without the split, every vertex in one step)
+            const bool wants_item = active && shade_medium_wants_item(s, rp, hit, ms);
+            const uint32_t ipos = base + shared_append(wants_item, &lds_counts[1]);
+            if (active) {
+                const uint32_t pixel = pixels[pv.slot % rp.chunk_pixels];
+                auto sink = [&](uint32_t l, const ShadowRayT<1>& ray) { store_shadow_ray<1>(shadow, ipos, l, ray); };
+                if (PT_MEDIUM_SPLIT) out = stage_medium_surface(s, rp, bounce, pv, hit, pixel, ms, beta_in, &ms_next, sink);
+                else out = stage_shade_medium(s, rp, bounce, pv, hit, pixel, ms, &ms_next, sink);
+                if (wants_item) {
+                    qsu(shadow, Layout<1>::sh_slot, ipos, pv.slot); qsu(shadow, Layout<1>::sh_flags, ipos, out.env_mask);
+                    qsf(shadow, Layout<1>::sh_lambda, ipos, pv.lambda);
+                    if (!out.has_item) clear_shadow_item<1>(shadow, ipos, rp.light_samples);   // a surface vertex that was never pushed (or, without the split, a medium vertex)
+                }
+                if (out.add_energy) energy[pv.slot] += out.energy_add[0];
             }
-            if (out.add_energy) energy[pv.slot] += out.energy_add[0];
         }
         const uint32_t pos = base + shared_append(out.survives, &lds_counts[0]);
         if (out.survives) { store_path<1>(paths_out, pos, out.next); qsu(paths_out, PS_MEDIUMS, pos, ms_next.mediums); qsu(paths_out, PS_PREV_MEDIUM, pos, ms_next.prev_medium); }

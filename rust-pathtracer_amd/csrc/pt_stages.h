@@ -410,13 +410,18 @@ struct MediumState { uint32_t mediums, prev_medium; uint32_t dropped = 0u; };   
 PT_HD bool shade_medium_wants_item(const SceneView& s, const RenderParams& rp, const Hit& hit, const MediumState& ms) {
     return ms.prev_medium == 0u && shade_wants_item(s, rp, hit);
 }
-template <typename RaySink>
-PT_HD ShadeOutT<1> stage_shade_medium(const SceneView& s, const RenderParams& rp, uint32_t bounce, const PathVertexT<1>& pv, const Hit& hit,
-                                      uint32_t pixel, const MediumState& ms, MediumState* ms_out, RaySink&& sink) {
-    ShadeOutT<1> out;
-    out.survives = false; out.add_energy = false; out.vertex_pushed = false; out.env_hit = false;
-    out.shadow_count = 0; out.env_mask = 0; out.has_item = false; out.energy_add[0] = 0.0f;
-    *ms_out = ms;
+// In two steps (round 5, for the kernel: k_shade_medium runs the second for whole waves of surface vertices): stage_medium_flight — the environment vertex, or the free
+// flights through the tracked mediums and, when one of them scatters in front of the hit, the medium vertex; it returns true when the vertex is the SURFACE hit, with the
+// throughput the segment's attenuation left — and stage_medium_surface, the surface vertex from there.  stage_shade_medium is the two in sequence.
+PT_HD void shade_out_clear(ShadeOutT<1>* out) {
+    out->survives = false; out->add_energy = false; out->vertex_pushed = false; out->env_hit = false;
+    out->shadow_count = 0; out->env_mask = 0; out->has_item = false; out->energy_add[0] = 0.0f;
+}
+PT_HD bool stage_medium_flight(const SceneView& s, const RenderParams& rp, uint32_t bounce, const PathVertexT<1>& pv, const Hit& hit,
+                               uint32_t pixel, const MediumState& ms, MediumState* ms_out, ShadeOutT<1>* out_p, float* beta_out) {
+    ShadeOutT<1>& out = *out_p;
+    shade_out_clear(&out);
+    *ms_out = ms; *beta_out = 0.0f;
     const uint32_t sample = rp.first_sample + pv.slot / rp.chunk_pixels;
     const float lambda = pv.lambda;
     const bool more = bounce + 1 < (rp.only_direct ? 1u : rp.max_bounces);
@@ -434,7 +439,7 @@ PT_HD ShadeOutT<1> stage_shade_medium(const SceneView& s, const RenderParams& rp
             out.energy_add[0] = weight * pv.beta[0] * env_emission(s, ep, lambda);
             out.add_energy = true; out.env_hit = true;
         }
-        return out;
+        return false;
     }
     // the nearest scattering event of the tracked mediums in front of the hit (utils.rs:766-793), then the segment's attenuation (:794-806)
     MediumEval me[4];
@@ -467,8 +472,20 @@ PT_HD ShadeOutT<1> stage_shade_medium(const SceneView& s, const RenderParams& rp
         out.survives = more;
         out.next.o = medium_point; out.next.d = wo; out.next.beta[0] = beta; out.next.lambda = lambda; out.next.slot = pv.slot;
         out.next.prev_pdf = phase; out.next.prev_n = wo; out.next.prev_p = medium_point;
-        return out;
+        return false;
     }
+    *beta_out = beta;
+    return true;
+}
+template <typename RaySink>
+PT_HD ShadeOutT<1> stage_medium_surface(const SceneView& s, const RenderParams& rp, uint32_t bounce, const PathVertexT<1>& pv, const Hit& hit,
+                                        uint32_t pixel, const MediumState& ms, float beta, MediumState* ms_out, RaySink&& sink) {
+    ShadeOutT<1> out;
+    shade_out_clear(&out);
+    *ms_out = ms;
+    const uint32_t sample = rp.first_sample + pv.slot / rp.chunk_pixels;
+    const float lambda = pv.lambda;
+    const bool more = bounce + 1 < (rp.only_direct ? 1u : rp.max_bounces);
     const Frame frame = frame_from_normal(hit.n);
     const F3 wi = normalize(to_local(frame, neg(pv.d)));
     if (PT_MATERIAL_TAG(hit.material) == PT_TAG_CAMERA) return out;
@@ -550,6 +567,13 @@ PT_HD ShadeOutT<1> stage_shade_medium(const SceneView& s, const RenderParams& rp
     out.next.beta[0] = beta; out.next.lambda = lambda; out.next.slot = pv.slot;
     out.next.prev_pdf = pdf_forward; out.next.prev_n = hit.n; out.next.prev_p = hit.p;
     return out;
+}
+template <typename RaySink>
+PT_HD ShadeOutT<1> stage_shade_medium(const SceneView& s, const RenderParams& rp, uint32_t bounce, const PathVertexT<1>& pv, const Hit& hit,
+                                      uint32_t pixel, const MediumState& ms, MediumState* ms_out, RaySink&& sink) {
+    ShadeOutT<1> out; float beta;
+    if (!stage_medium_flight(s, rp, bounce, pv, hit, pixel, ms, ms_out, &out, &beta)) return out;
+    return stage_medium_surface(s, rp, bounce, pv, hit, pixel, ms, beta, ms_out, sink);
 }
 
 // queue I/O of one light-sample ray
