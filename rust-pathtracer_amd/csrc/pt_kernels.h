@@ -31,7 +31,7 @@ inline void go_block(const LaunchCfg& c, int block, uint32_t lds_bytes, K kernel
 #define PT_SHADE_WAVES 4   // (round 4: the FULL forms at four waves with 26 registers spilled — C4's k_shade 9252 -> 8560 us, C4 +4.8 %, G1 +1 %: the kernel waits for its table fetches; profiles/r4v_full4.txt)
 #endif
 #ifndef PT_MEDIUM_SPLIT
-#define PT_MEDIUM_SPLIT 1   /* k_shade_medium shades its surface vertices in waves of their own (round 5); 0: every vertex where its item lies */
+#define PT_MEDIUM_SPLIT 1   /* k_shade_medium: 1 = its surface vertices in waves of their own (round 5); 2 = and its free flights (measured slower: 4437 -> 5103 us); 0 = every vertex where its item lies */
 #endif
 #ifndef PT_SHADE_MEDIUM_WAVES
 #define PT_SHADE_MEDIUM_WAVES 3
@@ -420,20 +420,35 @@ k_shade_medium(const uint32_t* __restrict__ blob, uint32_t blob_words, const flo
     // kind) with the throughput their segment left in a list of its own, shading them 64 at a time whenever the list holds that many, and what is left at the end.
     // The kinds shared waves at a lane utilisation of 0.36 (profiles/r5z_F4_summary.json).  No vertex' result depends on when it is shaded; a light-sample item is
     // reserved when its surface vertex is shaded (a vertex that scattered in a medium first used to reserve one and clear it).
-    __shared__ uint32_t later[PT_MEDIUM_SPLIT ? kBlock * 2 : 1];
-    __shared__ float later_beta[PT_MEDIUM_SPLIT ? kBlock * 2 : 1];
-    uint32_t* my_later = later + (PT_MEDIUM_SPLIT ? (threadIdx.x >> 6) * 128u : 0u);
-    float* my_beta = later_beta + (PT_MEDIUM_SPLIT ? (threadIdx.x >> 6) * 128u : 0u);
-    uint32_t later_count = 0;   // (wave-uniform)
+    // (PT_MEDIUM_SPLIT 2 — built, bit-identical, slower, not the default: a second list in front of it.  Whether a path tracks a medium at all is in its record: a fresh round only SORTS its 64 items —
+    // an environment vertex is finished there, a hit without a tracked medium goes to the surface list with its throughput as it is (the attenuation of no medium is
+    // the factor 1.0 twice: the same bits), a hit behind tracked mediums to the flight list — and the free flights, too, run for whole waves: stage_medium_flight for 64
+    // of those, its medium vertices finished, its surface vertices passed on.  A wave drains the surface list first, then the flight list, then takes fresh items: either
+    // list holds fewer than 64 entries when something is added to it, and a step adds at most 64.)
+    constexpr bool kSplit = PT_MEDIUM_SPLIT != 0, kSort = PT_MEDIUM_SPLIT == 2;
+    __shared__ uint32_t later[kSplit ? kBlock * 2 : 1];
+    __shared__ float later_beta[kSplit ? kBlock * 2 : 1];
+    __shared__ uint32_t flights[kSort ? kBlock * 2 : 1];
+    uint32_t* my_later = later + (kSplit ? (threadIdx.x >> 6) * 128u : 0u);
+    float* my_beta = later_beta + (kSplit ? (threadIdx.x >> 6) * 128u : 0u);
+    uint32_t* my_flights = flights + (kSort ? (threadIdx.x >> 6) * 128u : 0u);
+    uint32_t later_count = 0, flight_count = 0;   // (wave-uniform)
+    enum { FRESH, FLIGHT, SURFACE };
     for (uint32_t r = 0;;) {
         uint32_t i = 0;
-        bool active = false, resumed = false;
+        bool active = false;
+        int mode = FRESH;   // (wave-uniform)
         float beta_in = 0.0f;
-        if (PT_MEDIUM_SPLIT && (later_count >= 64u || (r == rounds && later_count > 0u))) {
+        if (kSplit && (later_count >= 64u || (r == rounds && flight_count == 0u && later_count > 0u))) {
             const uint32_t take = later_count < 64u ? later_count : 64u;
             later_count -= take;
-            active = lane_id() < take; resumed = true;
+            active = lane_id() < take; mode = SURFACE;
             if (active) { i = my_later[later_count + lane_id()]; beta_in = my_beta[later_count + lane_id()]; }
+        } else if (kSort && (flight_count >= 64u || (r == rounds && flight_count > 0u))) {
+            const uint32_t take = flight_count < 64u ? flight_count : 64u;
+            flight_count -= take;
+            active = lane_id() < take; mode = FLIGHT;
+            if (active) i = my_flights[flight_count + lane_id()];
         } else if (r < rounds) {
             const uint32_t j = r * blockDim.x + threadIdx.x;
             ++r;
@@ -441,29 +456,49 @@ k_shade_medium(const uint32_t* __restrict__ blob, uint32_t blob_words, const flo
         } else break;
         PathVertexT<1> pv; Hit hit; hit.valid = false;
         MediumState ms{0u, 0u}, ms_next{0u, 0u};
-        if (active) {
+        ShadeOutT<1> out;
+        shade_out_clear(&out);
+        auto append = [&](bool flag, uint32_t* list, uint32_t* count, float* betas, float beta) {   // the wave's own list: one ballot
+            const unsigned long long m = __ballot(flag);
+            if (flag) { const uint32_t e = *count + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull)); list[e] = i; if (betas != nullptr) betas[e] = beta; }
+            *count += (uint32_t)__popcll(m);
+        };
+        auto load_item = [&] {
             pv = load_path<1>(paths_in, i);
             hit = load_hit(hits, i);
             if (bounce != 0) { ms.mediums = qu(paths_in, PS_MEDIUMS, i); ms.prev_medium = qu(paths_in, PS_PREV_MEDIUM, i); }   // (the camera starts in vacuum)
-        }
-        ShadeOutT<1> out;
-        shade_out_clear(&out);
-        if (PT_MEDIUM_SPLIT && !resumed) {
+        };
+        if (kSort && mode == FRESH) {
+            // sort: the first word of the hit record and the tracked mediums say which kind the item is
+            const bool hits_something = active && qf(hits, HS_T, i) >= 0.0f;
+            const bool tracks = hits_something && bounce != 0 && qu(paths_in, PS_MEDIUMS, i) != 0u;
+            const bool leaves = active && !hits_something;
+            if (leaves) {   // the environment vertex
+                load_item();
+                float beta;
+                stage_medium_flight(s, rp, bounce, pv, hit, pixels[pv.slot % rp.chunk_pixels], ms, &ms_next, &out, &beta);
+                if (out.add_energy) energy[pv.slot] += out.energy_add[0];
+            }
+            append(tracks, my_flights, &flight_count, nullptr, 0.0f);
+            append(hits_something && !tracks, my_later, &later_count, my_beta, hits_something && !tracks ? qf(paths_in, PS_BETA, i) : 0.0f);
+            __builtin_amdgcn_wave_barrier();   // (the lists are the wave's own: their writes are in LDS before any of its lanes reads them)
+        } else if (kSplit && mode != SURFACE) {
+            // the free flights (PT_MEDIUM_SPLIT 1: of a fresh round's items; 2: of 64 items that track a medium)
+            if (active) load_item();
             bool surface = false; float beta = 0.0f;
             if (active) surface = stage_medium_flight(s, rp, bounce, pv, hit, pixels[pv.slot % rp.chunk_pixels], ms, &ms_next, &out, &beta);
-            const unsigned long long m = __ballot(surface);
-            if (surface) { const uint32_t e = later_count + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull)); my_later[e] = i; my_beta[e] = beta; }
-            later_count += (uint32_t)__popcll(m);
-            __builtin_amdgcn_wave_barrier();   // (the list is the wave's own: its writes are in LDS before any of its lanes reads them)
+            append(surface, my_later, &later_count, my_beta, beta);
+            __builtin_amdgcn_wave_barrier();
             if (active && out.add_energy) energy[pv.slot] += out.energy_add[0];
         } else {
             // the surface vertices of the list (or, without the split, every vertex in one step)
+            if (active) load_item();
             const bool wants_item = active && shade_medium_wants_item(s, rp, hit, ms);
             const uint32_t ipos = base + shared_append(wants_item, &lds_counts[1]);
             if (active) {
                 const uint32_t pixel = pixels[pv.slot % rp.chunk_pixels];
                 auto sink = [&](uint32_t l, const ShadowRayT<1>& ray) { store_shadow_ray<1>(shadow, ipos, l, ray); };
-                if (PT_MEDIUM_SPLIT) out = stage_medium_surface(s, rp, bounce, pv, hit, pixel, ms, beta_in, &ms_next, sink);
+                if (kSplit) out = stage_medium_surface(s, rp, bounce, pv, hit, pixel, ms, beta_in, &ms_next, sink);
                 else out = stage_shade_medium(s, rp, bounce, pv, hit, pixel, ms, &ms_next, sink);
                 if (wants_item) {
                     qsu(shadow, Layout<1>::sh_slot, ipos, pv.slot); qsu(shadow, Layout<1>::sh_flags, ipos, out.env_mask);
