@@ -348,7 +348,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     // a measurement build runs the shipped kernel pair unless one of its own forms is asked for: those read every item of a segment
     if (cfg.live_lists || getenv("PT_AMD_EXP_SHADOW")) rp.live_list = 0u;
 #endif
-    rp.camera_record = (shade_form == PT_SHADE_LEAN || shade_form == PT_SHADE_FULL) ? 1u : 0u;   // (the forms whose bounce-0 launch rebuilds the camera vertex: k_shade, pt_kernels.h)
+    rp.camera_record = (shade_form == PT_SHADE_LEAN || shade_form == PT_SHADE_FULL || shade_form == PT_SHADE_MEDIUM) ? 1u : 0u;   // (the forms whose bounce-0 launch rebuilds the camera vertex: k_shade, pt_kernels.h)
     cfg.fuse = !(tn.flags & PT_TUNE_NO_FUSE) && (!hero || PT_FUSE_HERO) && trav_form == PT_FORM_SWEEP && shade_form == PT_SHADE_LEAN && (cfg.lacks & PT_SCENE_NO_XF) != 0;
     const uint32_t bounce_limit = rd.only_direct ? 1u : rd.max_bounces;
     const bool timing = !(tn.flags & PT_TUNE_NO_STAGE_TIMING);

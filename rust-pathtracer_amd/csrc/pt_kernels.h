@@ -464,7 +464,7 @@ k_shade_medium(const uint32_t* __restrict__ blob, uint32_t blob_words, const flo
             *count += (uint32_t)__popcll(m);
         };
         auto load_item = [&] {
-            pv = load_path<1>(paths_in, i);
+            pv = load_path<1>(paths_in, i, rp.camera_record != 0u && bounce == 0u);   // (the camera vertex' lean record, pt_stages.h)
             hit = load_hit(hits, i);
             if (bounce != 0) { ms.mediums = qu(paths_in, PS_MEDIUMS, i); ms.prev_medium = qu(paths_in, PS_PREV_MEDIUM, i); }   // (the camera starts in vacuum)
         };

@@ -82,7 +82,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
     rp.phase = rd.phase_samples;
     rp.energy_stride = capacity;
     rp.camera = pth::camera_params(sc->host.cameras[rd.camera_index], (float)rd.width / (float)rd.height);
-    rp.camera_record = rd.medium_aware ? 0u : 1u;   // (the camera vertex' lean record, pt_stages.h: the engine takes it in the lean and full vertex forms; here wherever the plain walk runs)
+    rp.camera_record = 1u;   // (the camera vertex' lean record, pt_stages.h: the engine takes it in the lean and full vertex forms; here wherever the plain walk runs)
     typedef Layout<NL> LY;
     const size_t cap64 = ((size_t)capacity + 63u) & ~(size_t)63u;   // queues are tiled by 64 items (pt_stages.h)
     std::vector<uint32_t> pa((size_t)(LY::path_fields + 2) * cap64), pb((size_t)(LY::path_fields + 2) * cap64), ph((size_t)HS_FIELDS * cap64),
