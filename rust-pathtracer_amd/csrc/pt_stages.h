@@ -442,31 +442,41 @@ PT_HD bool stage_medium_flight(const SceneView& s, const RenderParams& rp, uint3
         return false;
     }
     // the nearest scattering event of the tracked mediums in front of the hit (utils.rs:766-793), then the segment's attenuation (:794-806)
+    // (the four slots as unrolled, guarded steps: every index is a constant, so the mediums' values and the flight samples stay in registers — as a run-time-indexed
+    // array they were 80 bytes of stack per lane; the scattering medium's values are kept where they are chosen instead of being looked up again)
     MediumEval me[4];
     uint32_t n_tracked = 0;
-    for (; n_tracked < 4u && ((ms.mediums >> (8u * n_tracked)) & 0xffu) != 0u; ++n_tracked)
-        me[n_tracked] = medium_prepare(s, medium_record(s, (ms.mediums >> (8u * n_tracked)) & 0xffu), lambda);
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t id = (ms.mediums >> (8u * k)) & 0xffu;
+        if (n_tracked == k && id != 0u) { me[k] = medium_prepare(s, medium_record(s, id), lambda); n_tracked = k + 1u; }
+    }
     float medium_time = hit.t; F3 medium_point = hit.p; uint32_t medium_slot = 4u;
     float hero_weight = 1.0f, hero_tr = 1.0f;
+    MediumEval scattering = {0u, 0.0f, 0.0f, 0.0f};
     if (n_tracked != 0u) {
         const pt_f32x4 fd = pt_draw4_tagged(rp.seed, pixel, sample, bounce, PT_TAG_MEDIUM_DISTANCE);
         const float flight[4] = {fd.x, fd.y, fd.z, fd.w};
-        for (uint32_t k = 0; k < n_tracked; ++k) {
-            F3 p; float w;
-            medium_sample(me[k], pv.o, pv.d, flight[k], &p, &w);
-            const float t = norm(sub(p, pv.o));
-            if (t < medium_time) { medium_time = t; medium_point = p; hero_weight = w; hero_tr = medium_tr(me[k], pv.o, p); medium_slot = k; }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (k < n_tracked) {
+                F3 p; float w;
+                medium_sample(me[k], pv.o, pv.d, flight[k], &p, &w);
+                const float t = norm(sub(p, pv.o));
+                if (t < medium_time) { medium_time = t; medium_point = p; hero_weight = w; hero_tr = medium_tr(me[k], pv.o, p); medium_slot = k; scattering = me[k]; }
+            }
         }
     }
     float beta = pv.beta[0] * hero_weight;
     float combined = 1.0f;
-    for (uint32_t k = 0; k < n_tracked; ++k) combined *= medium_tr(me[k], pv.o, medium_point);
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) if (k < n_tracked) combined *= medium_tr(me[k], pv.o, medium_point);
     beta *= combined / hero_tr;
     if (medium_slot != 4u) {
         // Vertex::Medium (utils.rs:1031-1066): a new direction from the phase function, the throughput untouched
         const pt_f32x4 ph = pt_draw4_tagged(rp.seed, pixel, sample, bounce, PT_TAG_MEDIUM_PHASE);
         float phase;
-        const F3 wo = medium_sample_p(me[medium_slot], neg(pv.d), ph.x, ph.y, &phase);
+        const F3 wo = medium_sample_p(scattering, neg(pv.d), ph.x, ph.y, &phase);
         out.vertex_pushed = true;
         ms_out->prev_medium = 1u;
         out.survives = more;
