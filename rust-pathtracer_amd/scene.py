@@ -385,6 +385,11 @@ def add_library_curves(b, names):
         elif n == "flat_one": b.curve_flat(n, 1.0)
         elif n == "flat_78": b.curve_flat(n, 0.78)
         elif n == "E5": b.curve_flat(n, 5.0)
+        elif n == "E10": b.curve_flat(n, 10.0)
+        elif n == "D65": b.curve_tabulated(n, sp["tabulated"][n]["x"], sp["tabulated"][n]["y"])   # data/lib_curves.toml:1-5 (TabulatedCSV, column 1, Cubic)
+        elif n == "540THz": b.curve_simple_spike(n, 555.17, 1.0, 1.0, 1.0)                         # data/lib_curves.toml:23-28
+        elif n == "simple_blue": b.curve_simple_spike(n, 450.0, 50.0, 50.0, 0.55)                 # data/lib_curves.toml:91-96
+        elif n == "simple_yellow": b.curve_simple_spike(n, 600.0, 50.0, 50.0, 0.55)               # data/lib_curves.toml:107-112
         elif n == "air_ior": b.curve_cauchy(n, 1.0002724293, 1.64748969205)
         elif n in ("cornell_white", "cornell_green", "cornell_red", "cornell_light", "srgb_r", "srgb_g", "srgb_b"):
             b.curve_tabulated(n, sp["tabulated"][n]["x"], sp["tabulated"][n]["y"])
@@ -406,7 +411,8 @@ def add_library_material(b, name):
     if name in b.material_ids:
         return b.material_ids[name]
     if name.startswith("lambertian_"):
-        curve = {"lambertian_white": "cornell_white", "lambertian_green": "cornell_green", "lambertian_red": "cornell_red"}[name]
+        curve = {"lambertian_white": "cornell_white", "lambertian_green": "cornell_green", "lambertian_red": "cornell_red",
+                 "lambertian_blue": "simple_blue", "lambertian_yellow": "simple_yellow"}[name]   # data/lib_textures.toml:36-60
         add_library_curves(b, [curve])
         ts = b.texstack_texture1(name, b.curve(curve))  # Texture1 over single_pixel.png (1x1 white -> factor 1.0)
         return b.material_lambertian(name, ts)
@@ -419,6 +425,16 @@ def add_library_material(b, name):
     if name == "diffuse_light_flat_x5":
         add_library_curves(b, ["E5", "flat_78"])
         return b.material_diffuse_light(name, b.curve("E5"), b.curve("flat_78"), api.SIDED_DUAL)
+    if name == "diffuse_light_flat_x10":        # data/lib_materials.toml:279-283
+        add_library_curves(b, ["E10", "flat_78"])
+        return b.material_diffuse_light(name, b.curve("E10"), b.curve("flat_78"), api.SIDED_DUAL)
+    if name == "diffuse_540THz":                # data/lib_materials.toml:313-317 (the candela's monochromatic source)
+        add_library_curves(b, ["540THz", "flat_zero"])
+        return b.material_diffuse_light(name, b.curve("540THz"), b.curve("flat_zero"), api.SIDED_DUAL)
+    if name == "ggx_air_glass":                 # data/lib_materials.toml:40-49: air inside, glass outside (the inner surface of a hollow ball)
+        add_library_curves(b, ["air_ior", "flat_zero"])
+        eta_o = b.curve_cauchy(name + ".eta_o", 1.4, 4500.0)
+        return b.material_ggx(name, 0.0004, b.curve("air_ior"), eta_o, b.curve("flat_zero"))
     if name == "sharp_light_fluorescent":
         add_library_curves(b, ["fluorescent_x5", "flat_78"])
         return b.material_sharp_light(name, b.curve("fluorescent_x5"), b.curve("flat_78"), 40.0, api.SIDED_REVERSE)
@@ -888,6 +904,164 @@ def hdri_emissive_mesh():
     return b
 
 
+
+# =================================================================== the reference tree's self-contained scene files
+# data/scenes/*.toml of the reference that need nothing the tree does not hold (no OBJ, no HDRI): the same instances, materials,
+# environment and camera, value for value (tests/test_reference_fixtures.py renders the reference's own file and the builder on the
+# oracle and compares the films bit for bit where /root/reference exists; the GPU tier renders the builders on the engine).
+def _room(b, light=None, front=False):
+    """The 2 x 2 x 2 room of the reference's cornell_box_* / test_blackbox scene files: two-sided rects, white ceiling, floor and back,
+    red at y = +1, green at y = -1 (and a white wall behind the camera when `front`)."""
+    white = add_library_material(b, "lambertian_white")
+    red = add_library_material(b, "lambertian_red")
+    green = add_library_material(b, "lambertian_green")
+    b.add_rect((2, 2), (0.0, 0.0, 1.0), "Z", True, white)
+    b.add_rect((2, 2), (0.0, 0.0, -1.0), "Z", True, white)
+    b.add_rect((2, 2), (0.0, 1.0, 0.0), "Y", True, red)
+    b.add_rect((2, 2), (0.0, -1.0, 0.0), "Y", True, green)
+    b.add_rect((2, 2), (1.0, 0.0, 0.0), "X", True, white)
+    if front:
+        b.add_rect((2, 2), (-1.0, 0.0, 0.0), "X", True, white)
+
+
+def _dark_sun(b):
+    """environment = Sun of strength 0 towards +z, colour D65, never sampled (test_lighting_north, test_nee_sphere, test_sampling_methods)."""
+    add_library_curves(b, ["D65"])
+    b.set_environment_sun(b.curve("D65"), 0.0, 0.0565, (0.0, 0.0, 1.0))
+    b.env_sampling_probability = 0.0
+
+
+def ref_candela_calibration():
+    """data/scenes/candela_calibration.toml: a unit sphere that emits the 540 THz spike, seen from x = -5 (rendered by
+    data/config_test_candela_calibration.toml with wavelength_bounds [555, 560] and only_direct)."""
+    b = SceneBuilder()
+    add_library_curves(b, ["D65"])
+    b.set_environment_constant(b.curve("D65"), 0.0)
+    b.env_sampling_probability = 0.0
+    b.add_sphere(1.0, (0.0, 0.0, 0.0), add_library_material(b, "diffuse_540THz"))
+    b.add_camera((-5.0, 0.0, 0.0), (0.0, 0.0, 0.0), 27.8, focal_distance=5.0, aperture_diameter=0.02)
+    return b
+
+
+def ref_cornell_box_parallel_prism():
+    """data/scenes/cornell_box_parallel_prism.toml (its prism instance is commented out in the file): the room under a Sun environment
+    sampled with probability 0.5 and a narrow two-sided sharp light under the ceiling."""
+    b = SceneBuilder()
+    add_library_curves(b, ["D65"])
+    b.set_environment_sun(b.curve("D65"), 0.4, 0.0565, (1.0, 0.0, 1.0))
+    b.env_sampling_probability = 0.5
+    b.add_rect((0.4, 0.1), (0.0, 0.8, 0.9), "Z", True, add_library_material(b, "sharp_light"))
+    _room(b)
+    b.add_camera((-5.0, 0.0, 0.0), (0.0, 0.0, 0.0), 27.8, focal_distance=5.0, aperture_diameter=0.02)
+    return b
+
+
+def ref_cornell_box_single_orb_caustic():
+    """data/scenes/cornell_box_single_orb_caustic.toml: the room, a one-sided sharp light (cos^401) and a dispersive glass ball."""
+    b = SceneBuilder()
+    add_library_curves(b, ["D65"])
+    b.set_environment_constant(b.curve("D65"), 0.0)
+    b.env_sampling_probability = 0.0
+    b.add_rect((0.2, 0.2), (0.0, 0.0, 0.9), "Z", False, add_library_material(b, "sharp_light"))
+    _room(b)
+    b.add_sphere(0.3, (0.1, 0.1, -0.15), add_library_material(b, "ggx_glass_dispersive"))
+    b.add_camera((-5.0, 0.0, 0.0), (0.0, 0.0, 0.0), 27.8, focal_distance=5.0, aperture_diameter=0.02)
+    return b
+
+
+def ref_test_blackbox():
+    """data/scenes/test_blackbox.toml: the closed room seen from inside, no light in it, a D65 sky of strength 1 outside and
+    env_sampling_probability 1 — every light sample is an environment sample, and every one of them is blocked."""
+    b = SceneBuilder()
+    add_library_curves(b, ["D65"])
+    b.set_environment_constant(b.curve("D65"), 1.0)
+    b.env_sampling_probability = 1.0
+    _room(b, front=True)
+    b.add_camera((0.5, 0.0, 0.0), (0.0, 0.0, 0.0), 70.4, focal_distance=0.5, aperture_diameter=0.001)
+    return b
+
+
+def ref_test_lighting_north():
+    """data/scenes/test_lighting_north.toml: a lamp at z = 10 over a white unit sphere — with the Cornell box's camera, which sits INSIDE the sphere."""
+    b = SceneBuilder()
+    _dark_sun(b)
+    b.add_rect((0.5, 0.5), (0.0, 0.0, 10.0), "Z", True, add_library_material(b, "diffuse_light_flat_x10"))
+    b.add_sphere(1.0, (0.0, 0.0, 0.0), add_library_material(b, "lambertian_white"))
+    b.add_camera((-0.8, 0.278, 0.273), (0.0, 0.278, 0.273), 37.8, focal_distance=1.1, aperture_diameter=0.01)
+    return b
+
+
+def ref_test_nee_sphere():
+    """data/scenes/test_nee_sphere.toml: a sphere LIGHT of radius 5 (Sphere::sample / psa_pdf, src/geometry/sphere.rs:95-152) over six
+    Lambertian balls, a floor and a wall."""
+    b = SceneBuilder()
+    _dark_sun(b)
+    b.add_sphere(5.0, (3.0, -6.0, 8.0), add_library_material(b, "diffuse_light_flat_x10"))
+    white = add_library_material(b, "lambertian_white")
+    for y in (-2.3, 0.0, 2.3):
+        b.add_sphere(1.0, (5.0, y, 0.0), white)
+    for y, m in ((-1.4, "lambertian_red"), (0.0, "lambertian_green"), (1.4, "lambertian_blue")):
+        b.add_sphere(0.4, (3.5, y, -0.6), add_library_material(b, m))
+    b.add_rect((40, 40), (0.0, 0.0, -1.0), "Z", True, white)
+    b.add_rect((20, 20), (16.0, 0.0, 0.0), "X", True, white)
+    b.add_camera((0.5, 0.0, 0.0), (0.0, 0.0, 0.0), 70.4, focal_distance=0.5, aperture_diameter=0.001)
+    return b
+
+
+def ref_test_rtiow_scene_2():
+    """data/scenes/test_rtiow_scene_2.toml: a hollow glass ball (ggx_glass outside, ggx_air_glass inside at radius 0.48), a blue and a
+    gold ball on a yellow floor under a sphere light and a sky-blue constant environment that is never sampled (probability 0)."""
+    b = SceneBuilder()
+    add_library_curves(b, ["simple_sky_blue"])
+    b.set_environment_constant(b.curve("simple_sky_blue"), 1.0)
+    b.env_sampling_probability = 0.0
+    b.add_sphere(5.0, (3.0, -6.0, 8.0), add_library_material(b, "diffuse_light_flat_x10"))
+    b.add_sphere(0.5, (3.5, -1.0, 0.0), add_library_material(b, "ggx_glass"))
+    b.add_sphere(0.48, (3.5, -1.0, 0.0), add_library_material(b, "ggx_air_glass"))
+    b.add_sphere(0.5, (3.5, 0.0, 0.0), add_library_material(b, "lambertian_blue"))
+    b.add_sphere(0.5, (3.5, 1.0, 0.0), add_library_material(b, "ggx_gold"))
+    b.add_rect((40, 40), (0.0, 0.0, -0.5), "Z", True, add_library_material(b, "lambertian_yellow"))
+    b.add_camera((0.5, 0.0, 0.0), (0.0, 0.0, 0.0), 70.4, focal_distance=0.5, aperture_diameter=0.001)
+    return b
+
+
+def ref_test_sampling_methods():
+    """data/scenes/test_sampling_methods.toml: two rect lamps of different size either side of a white ball on a floor (two entries in the light list)."""
+    b = SceneBuilder()
+    _dark_sun(b)
+    lamp = add_library_material(b, "diffuse_light_flat_x10")
+    b.add_rect((1, 1), (0.0, 2.0, 0.5), "Y", True, lamp)
+    b.add_rect((0.5, 0.5), (0.0, -1.0, 0.5), "Y", True, lamp)
+    white = add_library_material(b, "lambertian_white")
+    b.add_sphere(0.5, (0.0, 0.0, 0.5), white)
+    b.add_rect((10, 10), (0.0, 0.0, 0.0), "Z", True, white)
+    b.add_camera((0.5, 0.0, 0.0), (0.0, 0.0, 0.0), 70.4, focal_distance=0.5, aperture_diameter=0.001)
+    return b
+
+
+def ref_sun_test():
+    """data/scenes/sun_test.toml of the REFERENCE tree (this repository's own data/scenes/sun_test.toml is `sun_test` above): no light but
+    the Sun environment (strength 0.4, D65, towards (1, 0, 1)), sampled with probability 0.5; eight balls — dispersive glass, gold, copper,
+    red — on a floor."""
+    b = SceneBuilder()
+    add_library_curves(b, ["D65"])
+    b.set_environment_sun(b.curve("D65"), 0.4, 0.0565, (1.0, 0.0, 1.0))
+    b.env_sampling_probability = 0.5
+    b.add_rect((20, 20), (0.0, 10.0, -1.0), "Z", True, add_library_material(b, "lambertian_white"))
+    for side in (1.0, -1.0):
+        for x, y, m in ((-0.6, 0.3, "ggx_glass_dispersive"), (-0.6, 0.8, "ggx_gold"), (0.6, 0.3, "ggx_copper"), (0.6, 0.8, "lambertian_red")):
+            b.add_sphere(0.2, (x, side * y, -0.8), add_library_material(b, m))
+    b.add_camera((-5.0, 0.0, 0.4), (0.0, 0.0, -0.7), 16.2, focal_distance=5.0, aperture_diameter=0.001)
+    return b
+
+
+REFERENCE_TREE_SCENES = {"candela_calibration": ref_candela_calibration, "cornell_box_parallel_prism": ref_cornell_box_parallel_prism,
+                         "cornell_box_single_orb_caustic": ref_cornell_box_single_orb_caustic, "sun_test": ref_sun_test, "test_blackbox": ref_test_blackbox,
+                         "test_lighting_north": ref_test_lighting_north, "test_nee_sphere": ref_test_nee_sphere, "test_rtiow_scene_2": ref_test_rtiow_scene_2,
+                         "test_sampling_methods": ref_test_sampling_methods}   # file name in the reference's data/scenes -> builder
+
+
 SCENES = {"test_bokeh_floor_gem": test_bokeh_floor_gem, "test_bokeh_floor_gem_small": test_bokeh_floor_gem_small, "test_bokeh_floor": test_bokeh_floor, "test_bokeh_floor_small": test_bokeh_floor_small, "test_bokeh": test_bokeh, "test_bokeh_small": test_bokeh_small, "test_prism": test_prism, "test_prism_small": test_prism_small, "hdri_emissive_mesh": hdri_emissive_mesh, "hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
           "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test, "panorama_test": panorama_test, "empty_env": empty_env,
           "big_sphere_light": big_sphere_light, "disk_lamp": disk_lamp, "fog_ball": fog_ball}
+SCENES.update({"ref_" + name: fn for name, fn in REFERENCE_TREE_SCENES.items()})

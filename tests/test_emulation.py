@@ -76,6 +76,15 @@ def test_tabulated_curves_through_their_cell_tables(emu, oracle):
     ("fog_ball", 24, 24, 5, 6, {"medium_aware": True, "light_samples": 0}),
     ("cornell_box", 32, 32, 6, 6, {"medium_aware": True}),    # no medium in the scene: the medium-aware walk's own vertex rules (a light vertex adds nothing)
     ("mixed_small", 32, 32, 6, 6, {"medium_aware": True, "light_samples": 3}),
+    # the reference tree's self-contained scene files (pkg.scene.REFERENCE_TREE_SCENES; the GPU tier renders all nine, with and without hero wavelengths)
+    ("ref_candela_calibration", 32, 32, 20, 12, {"wavelength": (555.0, 560.0), "only_direct": True, "light_samples": 1, "min_bounces": 2}),
+    ("ref_cornell_box_single_orb_caustic", 40, 32, 8, 8, {}),
+    ("ref_sun_test", 40, 32, 8, 8, {}),
+    ("ref_test_blackbox", 32, 32, 6, 6, {}),
+    ("ref_test_nee_sphere", 40, 32, 8, 8, {}),
+    ("ref_test_rtiow_scene_2", 40, 32, 8, 8, {"hero_wavelengths": 4}),
+    ("ref_test_sampling_methods", 40, 32, 8, 8, {}),
+    ("cornell_box", 12, 12, 1024, 8, {}),                     # C2's sample count: 102 phases of ten and one of four per pixel (the GPU tier: 128 x 128)
 ])
 def test_film_parity(emu, oracle, scene, w, h, spp, mb, kw):
     ps.render_parity(emu, oracle, scene, w, h, spp, mb, **kw)

@@ -227,6 +227,29 @@ def test_reference_scenes_that_load_render_on_the_oracle(sfmod, oracle, pkg, nam
     assert lit or name in ("cornell_box_parallel_prism", "cornell_box_single_orb_caustic", "test_lighting_north"), name
 
 
+@pytest.mark.parametrize("name", sorted(SCENES_THAT_LOAD))
+def test_reference_scene_builders_are_the_reference_scene_files(sfmod, oracle, pkg, name):
+    """The GPU tier renders the reference tree's self-contained scenes from scene builders (pkg.scene.REFERENCE_TREE_SCENES — /root/reference does not
+    exist on the GPU box).  Here, where it does: the reference's OWN scene file through the C++ front end and the builder give the oracle the same
+    film bit for bit and the same counters — the builders are those scenes, value for value."""
+    builders = dict(pkg.scene.REFERENCE_TREE_SCENES, white_furnace=pkg.scene.white_furnace)
+    assert sorted(builders) == sorted(SCENES_THAT_LOAD)
+    config = sfmod.Config(os.path.join(os.path.dirname(pkg.__file__), "data", "config_cornell_c1.toml"))
+    sfmod.set_root(REF)
+    try:
+        sf = sfmod.SceneFile(os.path.join(REF, "data", "scenes", name + ".toml"), config)
+    finally:
+        sfmod.set_root()
+    b = builders[name]()
+    assert sf.desc.instance_count == len(b.instances) and sf.desc.env_sampling_probability == np.float32(b.env_sampling_probability)
+    kw = {"wavelength": (555.0, 560.0), "only_direct": True, "light_samples": 1} if name == "candela_calibration" else {"light_samples": 2}
+    rd = pkg.api.render_desc(40, 32, 6, 6, seed=3, **kw)
+    film_f, prof_f = oracle.create_scene(sf).render(rd)
+    film_b, prof_b = oracle.create_scene(b).render(rd)
+    assert np.array_equal(film_f.view(np.uint32), film_b.view(np.uint32))
+    assert (prof_f.camera_rays, prof_f.bounce_rays, prof_f.shadow_rays, prof_f.env_hits) == (prof_b.camera_rays, prof_b.bounce_rays, prof_b.shadow_rays, prof_b.env_hits)
+
+
 def test_showcase_cornell_box_chromaticities(oracle, pkg):
     """A loose STATISTICAL pin of the oracle against the only pixels in the tree that the reference itself produced:
     showcase/cornell_box_1080p.png.  Its render settings are unknown (exposure, tone mapper, sample count, the author's own cornell_box.obj),

@@ -44,6 +44,7 @@ def main():
     tab.update(csv_columns(f"{REF}/curves/csv/gold.csv", {"gold_n": 1, "gold_k": 2}))          # wavelength in micrometres
     tab.update(csv_columns(f"{REF}/curves/csv/copper-mcpeak.csv", {"copper_n": 1, "copper_k": 2}))
     tab.update(csv_columns(f"{REF}/curves/basis/simple-spectral-srgb-1931.csv", {"srgb_r": 1, "srgb_g": 2, "srgb_b": 3}))
+    tab.update(csv_columns(f"{REF}/curves/csv/D65.csv", {"D65": 1}))                           # CIE standard illuminant D65, 1 nm, 300-830 nm (lib_curves.toml:1-5)
     lin = {"fluorescent": spectra(f"{REF}/curves/spectra/fluorescent.spectra"),
            "xenon_lamp": spectra(f"{REF}/curves/spectra/xenon_lamp.spectra")}
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
