@@ -250,6 +250,8 @@ enum {
     PT_TUNE_MULTI_RCCL = 1u << 12,     /* PT_AMD_MULTI_RCCL: pt_render_multi takes the RCCL reduce even for one device */
     PT_TUNE_NO_ONE_LIGHT = 1u << 14,   /* PT_AMD_NO_ONE_LIGHT: in a scene with ONE light the lean vertex kernel does not run that light's shape test on its light-sample rays
                                           (by default a ray that misses the only light is dead where it is made and its item, if no ray of it lives, never read) */
+    PT_TUNE_NO_CONVEX = 1u << 15,      /* PT_AMD_NO_CONVEX: no use of the host's convex-body certificates (a light-sample ray that leaves a closed convex mesh instance inward is
+                                          dead where it is made, one that leaves it outward does not park at that mesh again: pt_blob.h PT_INST_CONVEX_*, round 6) */
     PT_TUNE_NO_AXIS_SCAN = 1u << 13    /* PT_AMD_NO_AXIS_SCAN: the parked kernels walk a ray that is parallel to an axis of its mesh like any other (by default the
                                           whole wave scans the mesh's leaves for it: such a ray passes most boxes, AABB::hit ignoring the axes its direction is zero along) */
 };
@@ -288,7 +290,8 @@ void pt_tuning_default(pt_tuning* tuning);
 typedef struct pt_profile {      /* Profile (src/profile.rs:2-8) + timing */
     uint64_t bounce_rays, shadow_rays, light_rays, camera_rays, env_hits;
     double seconds;              /* render loop only: the window of src/renderer/tiled.rs:294 -> :536 */
-    double kernel_seconds[8];    /* HIP-event time per stage: generate, extend, shade, shadow, accumulate; pt_render_multi adds
+    double kernel_seconds[8];    /* HIP-event time per stage: generate, extend, shade, shadow, accumulate (one event per launch boundary: a launch's time includes
+                                    the few microseconds of gap in front of it; the stream's non-kernel work — memsets — is charged to no stage); pt_render_multi adds
                                     [5] = host seconds spent on set-up before the render window (replicas, streams, device films,
                                     communicator: paid by the first call with a device set and film size, cached on the scene after),
                                     [6] = host seconds of the film reduce; [7] spare */

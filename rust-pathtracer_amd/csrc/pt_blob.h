@@ -15,7 +15,7 @@
 #define PT_BLOB_H
 #include <stdint.h>
 
-#define PT_BLOB_MAGIC 0x50544231u /* "PTB1" */
+#define PT_BLOB_MAGIC 0x50544232u /* "PTB2": mesh records of 16 words, curve records with cell tables, instance records with their sweep-table bits (round 6) */
 #define PT_NODE_INNER 0xffffffffu
 #define PT_NODE_FLAT 0x80000000u  /* in the exit word [3]: the box has zero thickness along an axis */
 #define PT_NODE_NO_CULL 0x40000000u /* in the exit word: the subtree holds a sphere, whose computed hit distance can fall short of its box by more
@@ -31,6 +31,11 @@
 
 // Triangle: three float4: (p0.xyz, bits(material)), (p1.xyz, 0), (p2.xyz, 0); optional normals: three float4.
 #define PT_TRI_WORDS 12
+#define PT_TRI_FLAGS 11       /* the third vertex' spare word: bit 0 = PT_TRI_IN_SAFE */
+#define PT_TRI_IN_SAFE 1u     /* the host certified (PT_INST_CONVEX_IN, below): a point of this face moved 1e-3 inward lies inside its closed convex body.  hit_record hands the bit on: */
+#define PT_TRI_IN_SAFE_INNER 2u /* ... certified for the points of the face whose barycentric coordinates are all >= PT_TRI_INNER_BARY (a face at a sharp edge: a strip along that edge is not safe) */
+#define PT_TRI_INNER_BARY 0.015625f
+#define PT_HIT_IN_SAFE 0x80000000u /* ... in the hit's instance word (Hit::instance; instances are numbered below 2^31) */
 
 // Mesh record (8 words): node_off (float4 units... all offsets are WORD offsets), node_count, tri_off, normal_off
 // (0 = none), face_count, leaf list, group boxes
@@ -76,12 +81,26 @@
 // Instance record (40 words).
 #define PT_INST_WORDS 40
 #define PT_INST_KIND 0
-#define PT_INST_FLAGS 1      /* bit0 has_transform, bit1 two_sided, bits 2-3 axis */
+#define PT_INST_FLAGS 1      /* bit0 has_transform, bit1 two_sided, bits 2-3 axis, bits 4-5 PT_INST_CONVEX_* */
+/* A mesh instance the host has CERTIFIED (pt_scene_host.cpp convex_certificate, f64, in world space) as a closed convex body whose hit normals are its faces' own
+   (round 6; stage_shade, pt_stages.h).  A light-sample ray is made at a surface point p, offset by 1e-3 along the hit normal to the side it leaves on (pt.rs:176, 256):
+   CONVEX_OUT: a ray that leaves such a body OUTWARD (n . d > 0.02) starts 1e-3 outside the supporting plane of the face it left and moves away from it — the whole body lies
+     behind that plane (to within 2e-4, checked), so no triangle of this instance can be hit: the light-sample kernel drops the instance from the ray's leaf mask
+     (PT_INST_SWEEP_MASK) — no park, no walk.  (Optional: a traversal form that ignores the mark walks the mesh and finds nothing.)
+   CONVEX_IN: a ray that leaves it INWARD starts at least 1e-4 inside every face plane (checked for every face), and every light lies outside the body's box (checked): the
+     ray must cross the closed surface before it can meet a light, the reference's closest hit is that crossing (or something else in front of it — in any case no light,
+     pt.rs:177-189), the sample contributes 0: the ray is dead where it is made (counted, never traced). */
+#define PT_INST_CONVEX_OUT 16u
+#define PT_INST_CONVEX_IN 32u
+#ifndef PT_CONVEX_OUT_COS
+#define PT_CONVEX_OUT_COS 0.02f
+#endif   /* an outward ray is marked only above this cosine to the hit normal (the normal may differ from the face's by 0.0045 rad, checked) */
 #define PT_INST_MATERIAL 2   /* packed MaterialId or PT_MATERIAL_NONE */
 #define PT_INST_MESH 3       /* word offset of the mesh record */
 #define PT_INST_ORIGIN 4     /* 3 floats */
 #define PT_INST_RADIUS 7
 #define PT_INST_SIZE 8       /* 2 floats */
+#define PT_INST_SWEEP_MASK 10 /* 2 words: the instance's bits in the leaf sweep table (its own and its triangle leaves'); 0 = no table */
 #define PT_INST_FORWARD 16   /* 12 floats: rows 0..2 of the 4x4 */
 #define PT_INST_REVERSE 28   /* 12 floats */
 
@@ -166,6 +185,7 @@
 #define PT_FLAG_NO_ONE_LIGHT 512u /* diagnostics (PT_AMD_NO_ONE_LIGHT=1): the lean vertex kernel does not test a light-sample ray against the scene's only light (stage_shade) */
 #define PT_FLAG_NO_LIGHT_PREPASS 1024u /* the light list is long (pt_tuning::light_prepass_max): a light-sample ray is traced as a plain closest-hit search, without the
                                          pre-pass over every light's box that bounds it (nearest_light_hit is linear in the lights: 82 box tests per ray in test_bokeh.toml) */
+#define PT_FLAG_CONVEX 2048u      /* some instance carries a PT_INST_CONVEX_* certificate (the vertex code looks at instance flags only then) */
 #define PT_FLAG_REPLAY 128u       /* diagnostics (host emulation): phase 3 of the sweep as unbounded tests + ordered replay (the pooled form's logic) */
 #define PT_FLAG_NO_TOP_CULL 1u   /* a Disk instance exists: its reference box (radius/2, disk.rs:24-28) does not contain it */
 

@@ -46,6 +46,10 @@
 #ifndef PT_STAT_RAY
 #define PT_STAT_RAY(o, d)
 #endif
+#ifndef PT_STAT_WALK
+#define PT_STAT_WALK(lo, ld, bound, closest, stop)   /* a mesh walk begins (tools/light_walks.cpp): the ray in the instance's own space, its bound, the closest hit so far */
+#define PT_STAT_WALK_END(over)                       /* ... and ends: whether the search is over (an early stop) */
+#endif
 
 // Wave-level helpers: device code sees the wave, the host emulation one lane at a time.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -697,10 +701,16 @@ PT_HD void hit_record(const SceneView& s, F3 o, F3 d, uint32_t best_inst, uint32
     F3 lo, ld;
     instance_local_ray(s, inst, o, d, &lo, &ld);
     Hit h;
+    uint32_t in_safe = 0u;   // PT_HIT_IN_SAFE: the triangle's PT_TRI_IN_SAFE (pt_blob.h), handed to the vertex code in the instance word
     if (triw != 0u) {
         uint32_t mesh = bu(s, inst + PT_INST_MESH);
         uint32_t normal_off = bu(s, mesh + PT_MESH_NORMAL_OFF);
         F4 q0 = mf4(s, triw), q1 = mf4(s, triw + 4), q2 = mf4(s, triw + 8);
+        {   // (bit 0: the whole face; bit 1: its inside, away from the edges by PT_TRI_INNER_BARY)
+            const uint32_t tf = pt_f2u(q2.w);
+            const bool inner = __builtin_fminf(__builtin_fminf(bh.b0, bh.b1), bh.b2) >= PT_TRI_INNER_BARY;
+            in_safe = ((tf | (inner ? tf >> 1 : 0u)) & 1u) << 31;
+        }
         F3 p0 = f3(q0.x, q0.y, q0.z), p1 = f3(q1.x, q1.y, q1.z), p2 = f3(q2.x, q2.y, q2.z);
         if (normal_off != 0) {
             uint32_t nn = normal_off + (triw - bu(s, mesh + PT_MESH_TRI_OFF));
@@ -723,7 +733,7 @@ PT_HD void hit_record(const SceneView& s, F3 o, F3 d, uint32_t best_inst, uint32
         h.n = normalize(xf_vec_transposed(s, inst + PT_INST_REVERSE, h.n));
         h.p = xf_point(s, inst + PT_INST_FORWARD, h.p);
     }
-    h.instance = best_inst;
+    h.instance = best_inst | in_safe;
     uint32_t m = bu(s, inst + PT_INST_MATERIAL);
     if (m != PT_MATERIAL_NONE) h.material = m;
     h.valid = true;
@@ -1015,6 +1025,7 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
     const uint32_t node_off = bu(s, mesh + PT_MESH_NODE_OFF), node_count = bu(s, mesh + PT_MESH_NODE_COUNT), tri_off = bu(s, mesh + PT_MESH_TRI_OFF);
     float limit = __builtin_fminf(st.closest, bound);
     const uint32_t leaf_off = bu(s, mesh + PT_MESH_LEAF_OFF);
+    PT_STAT_WALK(lo, ld, bound, st.closest, stop);
     // (bounded searches — light rays, which also stop at the first opaque hit — prune so much of the tree that the walk wins; measured
     // again with the group boxes below: C3 k_shadow_parked 5730 us through the grouped sweep, 5635 through the walk)
     // The mesh sweep reads its leaf list with wave-uniform addresses: every lane that takes it must be in the same mesh.  A table
@@ -1278,6 +1289,7 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
         if (evict_below != 0u && PT_WAVE_ACTIVE(0u) < evict_below) { evicted = true; break; }
     }
     PT_TL_DONE();
+    PT_STAT_WALK_END(st.hit == 0ull);
     if (evicted) *cursor = (SPEC && pending != NONE) ? pend_node : i;   // (a leaf held untested: its own node, found again on resume)
     return evicted;
 }
@@ -1352,18 +1364,22 @@ PT_HD bool mesh_surely_missed(const SceneView& s, uint32_t inst, F3 o, F3 d, flo
     F3 lo, ld;
     instance_local_ray(s, inst, o, d, &lo, &ld);
     const float dmin = 4e-3f * (pt_abs(ld.x) + pt_abs(ld.y) + pt_abs(ld.z));
+    // (round-5 advisor: `so` is a sum or difference of the origin's components — small for an origin far away along the slab's own plane, while its rounding error is
+    // 2u L1(o) whatever the sum comes to; the budget above wants that below 3e-4 w: a slab is used only by an origin within 250 of its own eight-width window, L1(o) < 2000 w)
+    const float l1o = pt_abs(lo.x) + pt_abs(lo.y) + pt_abs(lo.z);
     float t0 = 0.0f, t1 = limit;
     bool apart = false;
     auto slab = [&](uint32_t k, float so, float sd) {   // the ray's coordinate along direction k: so + t sd
         const float L = bf(s, dop + 2u * k), H = bf(s, dop + 2u * k + 1u);
         const float a = L - so, b = H - so, w8 = 8.0f * (H - L);
         const bool flat = sd == 0.0f;
-        const bool usable = (pt_abs(sd) >= dmin) & (pt_abs(a) < w8) & (pt_abs(b) < w8);
+        const bool near = (pt_abs(a) < w8) & (pt_abs(b) < w8) & (l1o < 250.0f * w8);
+        const bool usable = (pt_abs(sd) >= dmin) & near;
         const float r = fast_rcp(usable ? sd : 1.0f);
         const float ta = a * r, tb = b * r;
         t0 = __builtin_fmaxf(t0, usable ? __builtin_fminf(ta, tb) : t0);
         t1 = __builtin_fminf(t1, usable ? __builtin_fmaxf(ta, tb) : t1);
-        apart = apart | (flat & ((a > 0.0f) | (b < 0.0f)) & (pt_abs(a) < w8) & (pt_abs(b) < w8));
+        apart = apart | (flat & ((a > 0.0f) | (b < 0.0f)) & near);
     };
     slab(0, lo.x + lo.y, ld.x + ld.y); slab(1, lo.x - lo.y, ld.x - ld.y);
 #if PT_MESH_DOP_SLABS > 2
@@ -1816,10 +1832,17 @@ PT_HD bool sweep_best_is_light(const SceneView& s, const SweepState& st) {
 }
 // LIGHT_ONLY (light-sample rays): only a light's record is ever read (shadow_ray_contribution) — of any other closest hit the caller
 // learns that it exists and that it is no light, and the record (a triangle's vertices, barycentric point and normal) is not built.
+// The leaf-mask bits of an instance (its own and its triangle leaves'): what a ray that cannot hit the instance — a light-sample ray that left a certified convex body
+// outward, pt_blob.h PT_INST_CONVEX_OUT — drops from its mask before phase 3.
+PT_HD uint64_t sweep_instance_mask(const SceneView& s, uint32_t instance) {
+    const uint32_t io = bu(s, PT_HDR_INSTANCE_OFF) + instance * PT_INST_WORDS;
+    return (uint64_t)bu(s, io + PT_INST_SWEEP_MASK) | (uint64_t)bu(s, io + PT_INST_SWEEP_MASK + 1) << 32;
+}
 template <bool WALKS = true, bool LIGHT_ONLY = false>
-PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, int stop, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f) {
+PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, int stop, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f, uint32_t skip_inst = 0xffffffffu) {
     SweepState st;
     sweep_state_init(st, sweep_masks(s, o, d, bound));
+    if (WALKS && skip_inst != 0xffffffffu) st.hit &= ~sweep_instance_mask(s, skip_inst);
     const TriRay wtr = tri_ray_prepare(o, d);
 #if !defined(__HIP_DEVICE_COMPILE__)
     if ((bu(s, PT_HDR_FLAGS) & (PT_FLAG_REPLAY | PT_FLAG_SWEEP_WALKS)) == PT_FLAG_REPLAY) { sweep_run_replay(s, o, d, wtr, st); return sweep_finish(s, o, d, st, out); }
@@ -1944,9 +1967,10 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
 #define PT_TRAV_SWEEP 2
 PT_HD bool scene_uses_sweep(const SceneView& s) { return bu(s, PT_HDR_SWEEP_OFF) != 0u && !(bu(s, PT_HDR_FLAGS) & PT_FLAG_NO_SWEEP); }
 template <int TRAV = PT_TRAV_ANY, bool LIGHT_ONLY = false>
-PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_INF, int stop = PT_STOP_NONE, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f) {
+PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_INF, int stop = PT_STOP_NONE, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f,
+                     uint32_t skip_inst = 0xffffffffu) {   // (skip_inst: an instance the ray is known not to hit — optional knowledge: the walk forms do not use it)
     if (TRAV == PT_TRAV_SWEEP) return world_hit_sweep<false, LIGHT_ONLY>(s, o, d, out, bound, stop, known_inst, known_t);
-    if (TRAV == PT_TRAV_ANY && scene_uses_sweep(s)) return world_hit_sweep<true, LIGHT_ONLY>(s, o, d, out, bound, stop, known_inst, known_t);
+    if (TRAV == PT_TRAV_ANY && scene_uses_sweep(s)) return world_hit_sweep<true, LIGHT_ONLY>(s, o, d, out, bound, stop, known_inst, known_t, skip_inst);
 #if !defined(__HIP_DEVICE_COMPILE__)
     if (bu(s, PT_HDR_FLAGS) & PT_FLAG_REPLAY) {
         // (host emulation: the parked kernels' protocol over the top-level tree, lane by lane — park at every mesh, resume, leave the walk at every chance)

@@ -391,7 +391,11 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
         uint32_t seg_cap = segment_capacity(n, grid);
         camera_rays += n;
         const uint32_t* d_px = b.pixels + pass.pixel_begin;
-        if (park_dynamic) HIP_TRY(hipMemsetAsync(b.unit_counters, 0, sizeof(uint32_t) * kUnitCounters, stream));
+        if (park_dynamic) {
+            HIP_TRY(hipMemsetAsync(b.unit_counters, 0, sizeof(uint32_t) * kUnitCounters, stream));
+            // (round-5 advisor) an event of its own behind the stream's non-kernel work, charged to no stage: k_generate's time begins here, not at the end of the previous pass
+            if (events_ok) { events_ok = event_at(event_stage.size() + 1); if (events_ok) event_stage.push_back(-1); }
+        }
         timed(ST_GENERATE, [&] {
             if (hero) hipLaunchKernelGGL(k_generate<4>, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, qa, b.energy, n, seg_cap, live[0]);
             else hipLaunchKernelGGL(k_generate<1>, dim3(grid), dim3(kBlock), 0, stream, rp, d_px, qa, b.energy, n, seg_cap, live[0]);
@@ -417,7 +421,7 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     auto t1 = std::chrono::steady_clock::now();
     for (size_t k = 0; k < event_stage.size(); ++k) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, sc->events[k], sc->events[k + 1]) == hipSuccess) stage_ms[event_stage[k]] += ms;
+        if (event_stage[k] >= 0 && hipEventElapsedTime(&ms, sc->events[k], sc->events[k + 1]) == hipSuccess) stage_ms[event_stage[k]] += ms;
     }
     if (profile) {
         memset(profile, 0, sizeof(*profile));
@@ -492,6 +496,7 @@ static pt_status scene_to_device(pt_scene* sc) {
     if (tn.flags & PT_TUNE_NO_MESH_SWEEP) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_MESH_SWEEP;
     if (tn.flags & PT_TUNE_NO_KNOWN_LIGHT) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_KNOWN_LIGHT;
     if (tn.flags & PT_TUNE_NO_ONE_LIGHT) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_ONE_LIGHT;
+    if (tn.flags & PT_TUNE_NO_CONVEX) sc->host.blob[PT_HDR_FLAGS] &= ~PT_FLAG_CONVEX;   // (the vertex code looks at an instance's certificate only under this flag, and only it makes marks)
     if (sc->host.blob[PT_HDR_LIGHT_COUNT] > tuned(tn.light_prepass_max, kLightPrepassMax)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_LIGHT_PREPASS;
     sc->blob_words = (uint32_t)sc->host.blob.size();
     {   // no instance carries a transform (the Cornell box): the forms without the matrix paths (PT_AMD_GENERAL_FORMS=1 keeps the general ones)
@@ -532,7 +537,7 @@ void pt_tuning_default(pt_tuning* t) {
 #endif
 
         {"PT_AMD_EXACT_SLAB", PT_TUNE_EXACT_SLAB}, {"PT_AMD_NO_CULL", PT_TUNE_NO_CULL}, {"PT_AMD_NO_SWEEP", PT_TUNE_NO_SWEEP}, {"PT_AMD_NO_MESH_SWEEP", PT_TUNE_NO_MESH_SWEEP},
-        {"PT_AMD_NO_KNOWN_LIGHT", PT_TUNE_NO_KNOWN_LIGHT}, {"PT_AMD_GENERAL_FORMS", PT_TUNE_GENERAL_FORMS}, {"PT_AMD_NO_FUSE", PT_TUNE_NO_FUSE}, {"PT_AMD_MULTI_RCCL", PT_TUNE_MULTI_RCCL}, {"PT_AMD_NO_AXIS_SCAN", PT_TUNE_NO_AXIS_SCAN}, {"PT_AMD_NO_ONE_LIGHT", PT_TUNE_NO_ONE_LIGHT},
+        {"PT_AMD_NO_KNOWN_LIGHT", PT_TUNE_NO_KNOWN_LIGHT}, {"PT_AMD_GENERAL_FORMS", PT_TUNE_GENERAL_FORMS}, {"PT_AMD_NO_FUSE", PT_TUNE_NO_FUSE}, {"PT_AMD_MULTI_RCCL", PT_TUNE_MULTI_RCCL}, {"PT_AMD_NO_AXIS_SCAN", PT_TUNE_NO_AXIS_SCAN}, {"PT_AMD_NO_ONE_LIGHT", PT_TUNE_NO_ONE_LIGHT}, {"PT_AMD_NO_CONVEX", PT_TUNE_NO_CONVEX},
         {"PT_AMD_NO_LIVE_LIST", PT_TUNE_NO_LIVE_LIST},
     };
     for (const auto& f : flags) if (env_u32(f.name, 0)) t->flags |= f.bit;

@@ -5,6 +5,8 @@
 #ifndef PT_SHADE_PART
 #error "PT_SHADE_PART must be 0 (lean forms) or 1 (NO_ENV, FULL, medium)"
 #endif
+#include <cstdio>
+#include <cstdlib>
 #include "pt_kernels.h"
 
 namespace ptk {
@@ -74,6 +76,9 @@ void launch_shade(const LaunchCfg& c, int nl, int form, const SceneArgs& sc, con
                   Queue hits, Queue paths_out, Queue shadow, float* energy, uint32_t seg_cap, const uint32_t* count_in, uint32_t* count_out,
                   uint32_t* shadow_count, unsigned long long* block_stats) {
     const bool lean = form == PT_SHADE_LEAN;
+    // (round-5 advisor) k_generate writes the camera vertex' lean record when rp.camera_record is set; k_shade's forms read it at bounce 0 by their FORM alone (the uniform branch
+    // on rp.camera_record costs the NO_ENV form 7 %, pt_kernels.h).  The two sides must agree: a FORM / camera_record pairing that does not would read nine stale words per path.
+    if ((rp.camera_record != 0u) != (form != PT_SHADE_NO_ENV)) { fprintf(stderr, "launch_shade: form %d launched with camera_record = %u\n", form, rp.camera_record); abort(); }
     if (nl == 4) { if (lean) launch_shade_nl4_p0(c, form, PT_ARGS_FWD); else launch_shade_nl4_p1(c, form, PT_ARGS_FWD); }
     else if (lean) launch_shade_nl1_p0(c, form, PT_ARGS_FWD); else launch_shade_nl1_p1(c, form, PT_ARGS_FWD);
 }

@@ -850,6 +850,9 @@ __device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32
 #ifndef PT_PARKED_EAGER
 #define PT_PARKED_EAGER true
 #endif
+#ifndef PT_CONVEX_SKIP
+#define PT_CONVEX_SKIP 1   /* the parked light-sample kernel honours the mark "cannot hit its instance again" (round 6); 0 = ignores it: the mesh is walked and nothing found */
+#endif
 #ifndef PT_PARKED_EXP
 #define PT_PARKED_EXP 0   // measurement variants of k_shadow_parked (tools/phase_costs_parked.sh); 0 = the product
 #endif
@@ -1032,7 +1035,10 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
             // kernels run three waves per SIMD, which hide little: round 4, PT_PARKED_EAGER)
             load_shadow_ray<NL, PT_PARKED_EAGER, PT_PARKED_NT_RAY>(shadow, item, l, &ray);
             const float lam0 = (NL == 1 && PT_PARKED_EAGER) ? qf(shadow, Layout<NL>::sh_lambda, item) : 0.0f;
-            const bool env = kOnlyEnv || ((qu(shadow, Layout<NL>::sh_flags, item) >> l) & 1u) != 0;
+            // (the item's flag word: bit l = an environment sample; bit 8 + l = the ray left a certified convex body outward and cannot hit that instance, word >> 16, again:
+            // pt_blob.h PT_INST_CONVEX_OUT — its bits leave the ray's leaf mask, so the ray neither parks at that mesh nor walks it)
+            const uint32_t iflags = kOnlyEnv ? 0u : qu(shadow, Layout<NL>::sh_flags, item);
+            const bool env = kOnlyEnv || ((iflags >> l) & 1u) != 0;
             float bound = PT_INF; int stop = shadow_env_stop(s);
             uint32_t light = 0xffffffffu;
             if (!env && !shadow_light_bound(s, ray.o, ray.d, &bound, &stop, &light)) {
@@ -1043,6 +1049,7 @@ __global__ void __launch_bounds__(BLK) PT_PARK_OCC k_shadow_parked(const uint32_
                 if (TOP) { top_walk_init(st); parks = top_walk_run(s, ray.o, ray.d, bound, stop, st, true, (walk_policy >> 24) & 0xffu, &evicted); }
                 else {
                     sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
+                    if (PT_CONVEX_SKIP && ((iflags >> (8u + l)) & 1u) != 0u) st.hit &= ~sweep_instance_mask(s, iflags >> 16);
                     if (!(PT_PARKED_EXP & 2)) {
                         const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
                         parks = sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound);
@@ -1194,6 +1201,7 @@ __global__ void __launch_bounds__(kBlock) PT_PARK_OCC k_shadow_parked_dyn(const 
                 } else {
                     SweepState st;
                     sweep_state_init(st, sweep_masks(s, ray.o, ray.d, bound));
+                    if (PT_CONVEX_SKIP && ((flags >> (8u + l)) & 1u) != 0u) st.hit &= ~sweep_instance_mask(s, flags >> 16);   // (see k_shadow_parked)
                     const TriRay wtr = tri_ray_prepare(ray.o, ray.d);
                     settle(item, l, ray, env, bound, st, sweep_run(s, ray.o, ray.d, wtr, bound, stop, st, true, light, bound), light, 0u);
                 }
@@ -1245,7 +1253,7 @@ __global__ void __launch_bounds__(kBlock) k_probe_intersect(const uint32_t* __re
         if (ok) {
             r.valid = 1; r.t = h.t; r.point[0] = h.p.x; r.point[1] = h.p.y; r.point[2] = h.p.z;
             r.normal[0] = h.n.x; r.normal[1] = h.n.y; r.normal[2] = h.n.z; r.uv[0] = h.u; r.uv[1] = h.v;
-            r.material = h.material; r.instance = h.instance;
+            r.material = h.material; r.instance = h.instance & ~PT_HIT_IN_SAFE;
         }
         out[i] = r;
     }

@@ -164,26 +164,126 @@ static int axis_crossings(D3 p, int axis, const float* V, const uint32_t* ix, ui
     }
     return n;
 }
-static bool inner_sphere(const float* V, uint32_t vertex_count, const uint32_t* ix, uint32_t faces, const Box& mb, float* centre, float* radius, std::vector<float>* more = nullptr) {
-    // closedness: edges keyed by the BIT PATTERNS of their end points' positions
+// Closed = every undirected edge (end points compared by the BIT PATTERNS of their positions) belongs to exactly two triangles, and no triangle is degenerate:
+// not an edge of length 0 and — round-5 advisor — not a sliver either.  A T-junction filled with a zero-area triangle (three distinct collinear vertices) still pairs
+// every edge twice, but the watertight triangle test is watertight only across edges computed from the SAME vertex pair (mesh.rs:67-198): through such a junction a ray
+// can meet the det == 0 triangle alone and pass.  "Closed" is what the shortcuts below argue from, so such a mesh is not closed.
+static bool mesh_is_closed(const float* V, uint32_t vertex_count, const uint32_t* ix, uint32_t faces, const Box& mb) {
     struct Key { uint32_t a[3], b[3]; bool operator<(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) < 0; } };
     auto pos = [&](uint32_t v, uint32_t* out) { for (int k = 0; k < 3; ++k) { float x = V[3 * v + k]; if (x == 0.0f) x = 0.0f; std::memcpy(&out[k], &x, 4); } };   // (-0 = +0)
+    const double ex = (double)mb.mx[0] - mb.mn[0], ey = (double)mb.mx[1] - mb.mn[1], ez = (double)mb.mx[2] - mb.mn[2];
+    const double extent = std::fmax(ex, std::fmax(ey, ez));
     std::vector<Key> edges; edges.reserve((size_t)faces * 3);
-    for (uint32_t f = 0; f < faces; ++f)
+    for (uint32_t f = 0; f < faces; ++f) {
+        for (int k = 0; k < 3; ++k) if (ix[3 * f + k] >= vertex_count) return false;
+        const D3 a = d3(V + 3 * ix[3 * f]), b = d3(V + 3 * ix[3 * f + 1]), c = d3(V + 3 * ix[3 * f + 2]);
+        const D3 n = dcross(dsub(b, a), dsub(c, a));
+        if (!(std::sqrt(ddot(n, n)) > 1e-10 * extent * extent)) return false;     // twice the area: a sliver (or NaN)
         for (int k = 0; k < 3; ++k) {
             const uint32_t v0 = ix[3 * f + k], v1 = ix[3 * f + (k + 1) % 3];
-            if (v0 >= vertex_count || v1 >= vertex_count) return false;
             Key e; pos(v0, e.a); pos(v1, e.b);
             if (std::memcmp(e.a, e.b, 12) == 0) return false;                    // a degenerate edge
             if (std::memcmp(e.a, e.b, 12) > 0) { uint32_t t[3]; std::memcpy(t, e.a, 12); std::memcpy(e.a, e.b, 12); std::memcpy(e.b, t, 12); }
             edges.push_back(e);
         }
+    }
     std::sort(edges.begin(), edges.end());
     for (size_t i = 0; i < edges.size();) {
         size_t j = i; while (j < edges.size() && std::memcmp(&edges[j], &edges[i], sizeof(Key)) == 0) ++j;
         if (j - i != 2) return false;
         i = j;
     }
+    return true;
+}
+
+// ---- a CONVEX closed mesh instance (pt_blob.h PT_INST_CONVEX_*), certified in f64 in WORLD space ---------------------------------------------------------------------
+// What stage_shade argues from when it marks a light-sample ray that leaves such an instance (outward: the instance cannot be hit again; inward: nothing but this
+// instance's own surface — or something inside it — can be the closest hit, and no light is inside).  Every number the argument uses is checked here, for the vertices
+// as the engine sees them (f32 positions through the instance's f32 forward matrix) and the normals as hit_record makes them (vertex normals, or the face normal, through
+// the transposed reverse matrix):
+//   closed (above); at most 4096 faces; world coordinates within 64 (one f32 ulp there is 4e-6: a hundred times below the margins);
+//   every face's hit normals lie within 0.0045 rad of the face's own outward normal;
+//   CONVEX, OUT: no vertex lies more than 2e-4 above any face's plane (the gem's facets are planar to 1e-4) and some vertex lies 1e-2 below it;
+//   IN, face by face: the face's three corners, moved 1e-3 against the face normal (where pt.rs:176 puts an inward ray's origin), lie at least 1e-4 below EVERY face plane —
+//   so does every point of the face (the planes' half-spaces are convex); such a face's triangle carries PT_TRI_IN_SAFE and hit_record hands it on in the hit's instance word;
+//   and the world box of every light-tagged instance is disjoint from this instance's (both widened by 1e-3).
+static uint32_t convex_certificate(const float* V, uint32_t vertex_count, const uint32_t* ix, uint32_t faces, const float* N, const pt_instance& in, const Box& wbox,
+                                   const std::vector<Box>& light_boxes, std::vector<char>* in_safe) {
+    if (faces < 4 || faces > 4096 || vertex_count > 3 * 4096) return 0u;
+    auto world = [&](const float* p) {
+        if (!in.has_transform) return D3{p[0], p[1], p[2]};
+        const float* m = in.forward;
+        return D3{(double)m[0] * p[0] + (double)m[1] * p[1] + (double)m[2] * p[2] + m[3], (double)m[4] * p[0] + (double)m[5] * p[1] + (double)m[6] * p[2] + m[7],
+                  (double)m[8] * p[0] + (double)m[9] * p[1] + (double)m[10] * p[2] + m[11]};
+    };
+    auto world_normal = [&](D3 n) {   // hit_record: normalize(reverse^T n)
+        if (in.has_transform) { const float* r = in.reverse; n = D3{r[0] * n.x + r[4] * n.y + r[8] * n.z, r[1] * n.x + r[5] * n.y + r[9] * n.z, r[2] * n.x + r[6] * n.y + r[10] * n.z}; }
+        const double l = std::sqrt(ddot(n, n));
+        return D3{n.x / l, n.y / l, n.z / l};
+    };
+    std::vector<D3> W(vertex_count);
+    for (uint32_t v = 0; v < vertex_count; ++v) {
+        W[v] = world(V + 3 * v);
+        if (!(std::fabs(W[v].x) <= 64.0 && std::fabs(W[v].y) <= 64.0 && std::fabs(W[v].z) <= 64.0)) return 0u;
+    }
+    const double kCos = 0.99999, kSlack = 2e-4, kThick = 1e-2, kOffset = 1e-3, kInside = 1e-4;
+    std::vector<D3> fn(faces); std::vector<double> fd(faces);
+    for (uint32_t f = 0; f < faces; ++f) {
+        const D3 a = W[ix[3 * f]], b = W[ix[3 * f + 1]], c = W[ix[3 * f + 2]];
+        D3 g = dcross(dsub(b, a), dsub(c, a));
+        const double l = std::sqrt(ddot(g, g));
+        if (!(l > 0)) return 0u;
+        g = D3{g.x / l, g.y / l, g.z / l};
+        // the hit normals of this face, as hit_record makes them (local: the vertex normals, or cross(p0 - p2, p1 - p2))
+        D3 local[3]; int count = 0;
+        if (N != nullptr) for (int k = 0; k < 3; ++k) local[count++] = d3(N + 3 * ix[3 * f + k]);
+        else { const D3 p0 = d3(V + 3 * ix[3 * f]), p1 = d3(V + 3 * ix[3 * f + 1]), p2 = d3(V + 3 * ix[3 * f + 2]); local[count++] = dcross(dsub(p0, p2), dsub(p1, p2)); }
+        const D3 first = world_normal(local[0]);
+        if (ddot(first, g) < 0) g = D3{-g.x, -g.y, -g.z};   // (the face's plane normal on the side the hit normals point to: it must turn out to be the OUTWARD side, below)
+        for (int k = 0; k < count; ++k) if (!(ddot(world_normal(local[k]), g) >= kCos)) return 0u;
+        fn[f] = g; fd[f] = ddot(g, a);
+    }
+    for (uint32_t f = 0; f < faces; ++f) {
+        double hi = -INFINITY, lo = INFINITY;
+        for (uint32_t v = 0; v < vertex_count; ++v) { const double sd = ddot(fn[f], W[v]) - fd[f]; hi = std::fmax(hi, sd); lo = std::fmin(lo, sd); }
+        if (!(hi <= kSlack && lo <= -kThick)) return 0u;   // not convex (or the normals point inward, or the body is a sliver)
+    }
+    uint32_t flags = PT_INST_CONVEX_OUT;
+    // IN is a property of a FACE (a sharp edge — the brilliant cut has 64 faces at edges of 97 degrees — puts the corner of one face, moved inward, OUTSIDE the next
+    // face's plane): `in_safe[f]`, and the instance takes the flag when any of its faces is safe
+    bool inside_ok = false;
+    in_safe->assign(faces, 0);   // (0 none, 1 the whole face, 2 its inside only)
+    for (uint32_t f = 0; f < faces; ++f) {
+        bool ok = true;
+        for (int k = 0; k < 3 && ok; ++k) {
+            const D3 p = W[ix[3 * f + k]], q = D3{p.x - kOffset * fn[f].x, p.y - kOffset * fn[f].y, p.z - kOffset * fn[f].z};
+            for (uint32_t g = 0; g < faces; ++g) if (!(ddot(fn[g], q) - fd[g] <= -kInside)) { ok = false; break; }
+        }
+        if (!ok) {   // the face without a strip of PT_TRI_INNER_BARY along its edges (hit_record tests the hit's barycentric coordinates): the corners of that inner triangle
+            ok = true;
+            const double e = PT_TRI_INNER_BARY * 0.98;   // (the device compares f32 barycentrics: a margin for their rounding)
+            for (int k = 0; k < 3 && ok; ++k) {
+                const D3 a = W[ix[3 * f + k]], b = W[ix[3 * f + (k + 1) % 3]], c = W[ix[3 * f + (k + 2) % 3]];
+                const D3 p = D3{(1 - 2 * e) * a.x + e * b.x + e * c.x, (1 - 2 * e) * a.y + e * b.y + e * c.y, (1 - 2 * e) * a.z + e * b.z + e * c.z};
+                const D3 q = D3{p.x - kOffset * fn[f].x, p.y - kOffset * fn[f].y, p.z - kOffset * fn[f].z};
+                for (uint32_t g = 0; g < faces; ++g) if (!(ddot(fn[g], q) - fd[g] <= -kInside)) { ok = false; break; }
+            }
+            (*in_safe)[f] = ok ? 2 : 0;
+        } else (*in_safe)[f] = 1;
+        inside_ok = inside_ok || ok;
+    }
+    bool lights_clear = true;
+    for (const Box& lb : light_boxes) {
+        bool apart = false;
+        for (int k = 0; k < 3; ++k) apart = apart || (double)lb.mn[k] - 1e-3 > (double)wbox.mx[k] + 1e-3 || (double)lb.mx[k] + 1e-3 < (double)wbox.mn[k] - 1e-3;
+        lights_clear = lights_clear && apart;
+    }
+    if (inside_ok && lights_clear) flags |= PT_INST_CONVEX_IN;
+    return flags;
+}
+
+static bool inner_sphere(const float* V, uint32_t vertex_count, const uint32_t* ix, uint32_t faces, const Box& mb, float* centre, float* radius, std::vector<float>* more = nullptr) {
+    if (!mesh_is_closed(V, vertex_count, ix, faces, mb)) return false;
     const double sx = (double)mb.mx[0] - mb.mn[0], sy = (double)mb.mx[1] - mb.mn[1], sz = (double)mb.mx[2] - mb.mn[2];
     const double scale = std::fmax(sx, std::fmax(sy, sz));
     if (!(scale > 0) || !(sx > 0 && sy > 0 && sz > 0)) return false;
@@ -355,7 +455,7 @@ static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::st
             uint32_t cells = 16; while (cells < n) cells *= 2;
             const float x0 = kd[0], width = kd[2 * (n - 1)] - x0;
             const float inv = (float)cells / width;
-            if (sorted && width > 0.0f && std::isfinite(inv) && inv > 0.0f) {
+            if (sorted && width > 0.0f && std::isfinite(inv) && inv > 0.0f && w.size() < (1u << 24)) {   // (the table's word offset rides in 24 bits of the record's grid word: a core section beyond 64 MB keeps the binary search)
                 const float top = (float)(cells - 1);
                 std::vector<uint32_t> below(cells + 1, 0);   // below[g] = knots in cells < g
                 for (uint32_t k = 0; k < n; ++k) {
@@ -650,6 +750,52 @@ static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::st
         }
     }
     for (uint32_t l : lights) if (d.instances[l].kind == PT_SHAPE_MESH) return fail("mesh lights cannot be sampled (todo!() in the reference, mesh.rs:213-232)");
+    {   // convex closed mesh instances (pt_blob.h PT_INST_CONVEX_*): certified once per instance, in world space
+        auto lightish = [&](uint32_t i) {   // can a hit on instance i carry a Light tag
+            const pt_instance& in = d.instances[i];
+            if (in.material != PT_MATERIAL_NONE) return PT_MATERIAL_TAG(in.material) == PT_TAG_LIGHT;
+            return in.kind == PT_SHAPE_MESH && mesh_light_faces[in.mesh] != 0;
+        };
+        std::vector<Box> light_boxes;
+        for (uint32_t i = 0; i < d.instance_count; ++i) if (lightish(i)) light_boxes.push_back(ibox[i]);
+        std::vector<int> mesh_closed(d.mesh_count, -1);
+        std::vector<std::vector<char>> mesh_in_safe(d.mesh_count);
+        bool any = false;
+        for (uint32_t i = 0; i < d.instance_count && i < 65536u; ++i) {   // (the mark a ray carries names its instance in 16 bits)
+            const pt_instance& in = d.instances[i];
+            if (in.kind != PT_SHAPE_MESH || lightish(i)) continue;
+            const pt_mesh& m = d.meshes[in.mesh];
+            const float* V = d.vertices + 3 * (size_t)m.vertex_offset;
+            const uint32_t* ix = d.indices + m.index_offset;
+            if (m.face_count > 4096) continue;
+            if (mesh_closed[in.mesh] < 0) mesh_closed[in.mesh] = mesh_is_closed(V, m.vertex_count, ix, m.face_count, mesh_box[in.mesh]) ? 1 : 0;
+            if (!mesh_closed[in.mesh]) continue;
+            std::vector<char> in_safe;
+            uint32_t cf = convex_certificate(V, m.vertex_count, ix, m.face_count, m.normal_offset >= 0 ? d.normals + 3 * (size_t)m.normal_offset : nullptr, in, ibox[i], light_boxes, &in_safe);
+            if (cf & PT_INST_CONVEX_IN) {
+                // a triangle is IN-safe when it is for EVERY instance of its mesh that takes the flag (the mark rides in the mesh's triangle record)
+                if (mesh_in_safe[in.mesh].empty()) mesh_in_safe[in.mesh] = in_safe;
+                else for (uint32_t f = 0; f < m.face_count; ++f) {   // (0 none, 1 the whole face, 2 its inside only: the weaker of the two claims)
+                    const char a = mesh_in_safe[in.mesh][f], b = in_safe[f];
+                    mesh_in_safe[in.mesh][f] = (a == 0 || b == 0) ? 0 : (a == 1 && b == 1 ? 1 : 2);
+                }
+            }
+            if (getenv("PT_AMD_HOST_VERBOSE")) fprintf(stderr, "instance %u: mesh %d, convex certificate %s%s\n", i, in.mesh, (cf & PT_INST_CONVEX_OUT) ? "OUT " : "none", (cf & PT_INST_CONVEX_IN) ? "IN" : "");
+            w[w[PT_HDR_INSTANCE_OFF] + i * PT_INST_WORDS + PT_INST_FLAGS] |= cf;
+            any = any || cf != 0u;
+        }
+        if (any) w[PT_HDR_FLAGS] |= PT_FLAG_CONVEX;
+        for (uint32_t mi = 0; mi < d.mesh_count; ++mi) {   // PT_TRI_IN_SAFE into the triangle records, and into their permuted copies
+            if (mesh_in_safe[mi].empty()) continue;
+            const uint32_t tri_off = w[mesh_off[mi] + PT_MESH_TRI_OFF];
+            for (uint32_t f = 0; f < d.meshes[mi].face_count; ++f) {
+                if (!mesh_in_safe[mi][f]) continue;
+                const uint32_t bit = mesh_in_safe[mi][f] == 1 ? PT_TRI_IN_SAFE : PT_TRI_IN_SAFE_INNER;
+                md[tri_off + (size_t)f * PT_TRI_WORDS + PT_TRI_FLAGS] |= bit;
+                if (mesh_perm0[mi] != 0u) { md[tri_off + mesh_perm0[mi] + (size_t)f * PT_TRI_WORDS + PT_TRI_FLAGS] |= bit; md[tri_off + mesh_perm1[mi] + (size_t)f * PT_TRI_WORDS + PT_TRI_FLAGS] |= bit; }
+            }
+        }
+    }
 
     // top-level BVH over instances
     pad16(w);
@@ -780,6 +926,10 @@ static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::st
                     for (size_t q = 0; q < block.size(); ++q) w[tri_list + q] = block[q];
                 }
                 uint64_t own_mask = mask_of(first_bit);
+                {   // the instance's bits, all of them, in its own record (PT_INST_SWEEP_MASK: what a ray that may skip the instance drops from its leaf mask)
+                    const uint64_t all = (bit >= 64u ? ~0ull : (1ull << bit) - 1ull) & ~((1ull << first_bit) - 1ull);
+                    w[rec_off + PT_INST_SWEEP_MASK] = (uint32_t)all; w[rec_off + PT_INST_SWEEP_MASK + 1] = (uint32_t)(all >> 32);
+                }
                 uint32_t* r = &w[e];
                 r[0] = rec_off; r[1] = kf | first_bit << 16 | (uint32_t)leaders.size() << 24; r[2] = (uint32_t)own_mask; r[3] = (uint32_t)(own_mask >> 32);
                 r[4] = nd[0]; r[5] = nd[1]; r[6] = nd[2]; r[7] = tri_list; r[8] = nd[4]; r[9] = nd[5]; r[10] = nd[6]; r[11] = tri_count;
@@ -931,7 +1081,7 @@ static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::st
     }
     w[PT_HDR_WORLD_RADIUS] = fbits(radius);
     {
-        uint32_t flags = w[PT_HDR_FLAGS] & PT_FLAG_SWEEP_WALKS;
+        uint32_t flags = w[PT_HDR_FLAGS] & (PT_FLAG_SWEEP_WALKS | PT_FLAG_CONVEX);
         for (uint32_t i = 0; i < d.instance_count; ++i) {
             const pt_instance& in = d.instances[i];
             if (in.kind == PT_SHAPE_DISK) flags |= PT_FLAG_NO_TOP_CULL;

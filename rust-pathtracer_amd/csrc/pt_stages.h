@@ -207,7 +207,7 @@ struct ShadeOutT {
     bool vertex_pushed;     // counts towards Profile::bounce_rays
     bool env_hit;
     uint32_t shadow_count;  // valid sub-rays (Profile::shadow_rays)
-    uint32_t env_mask;      // bit l: sub-ray l is an environment sample
+    uint32_t env_mask;      // the item's flag word: bit l: sub-ray l is an environment sample; bit 8 + l: sub-ray l cannot hit instance (word >> 16) again (PT_INST_CONVEX_OUT)
     bool has_item;
 };
 
@@ -282,7 +282,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                 out.add_energy = true;
             } else if (!rp.only_direct) {
                 F3 nee_dir = normalize(sub(hit.p, pv.prev_p));
-                uint32_t inst = bu(s, PT_HDR_INSTANCE_OFF) + hit.instance * PT_INST_WORDS;
+                uint32_t inst = bu(s, PT_HDR_INSTANCE_OFF) + (hit.instance & ~PT_HIT_IN_SAFE) * PT_INST_WORDS;
                 float pdfh = light_psa_pdf(s, inst, dot(pv.prev_n, nee_dir), dot(hit.n, nee_dir), pv.prev_p, hit.p);
                 float a = pv.prev_pdf;
                 float weight = (a * a) / (a * a + pdfh * pdfh);
@@ -304,6 +304,9 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
             const bool one_light = n_lights == 1u && !(bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_LIGHT_PREPASS | PT_FLAG_NO_CULL | PT_FLAG_NO_ONE_LIGHT));
             EnvCurves ec[NL];  // the environment's spectral weights at this vertex' wavelengths, for all its light samples
             for (int k = 0; k < NL; ++k) ec[k] = (ENV && env_p > 0.0f) ? env_curves(s, lam[k]) : EnvCurves{{0.0f, 0.0f, 0.0f, 0.0f}, false};
+            // (round 6) the vertex lies on an instance the host certified convex and closed (pt_blob.h PT_INST_CONVEX_*): its outward light-sample rays are marked
+            // "cannot hit this instance again" (ShadeOutT::env_mask, bits 8.. and 16..), its inward light rays are dead here.  A scene without such an instance: one scalar test.
+            const uint32_t convex = (bu(s, PT_HDR_FLAGS) & PT_FLAG_CONVEX) ? bu(s, bu(s, PT_HDR_INSTANCE_OFF) + (hit.instance & ~PT_HIT_IN_SAFE) * PT_INST_WORDS + PT_INST_FLAGS) & (PT_INST_CONVEX_OUT | PT_INST_CONVEX_IN) : 0u;
             for (uint32_t l = 0; l < rp.light_samples; ++l) {
                 ShadowRayT<NL> ray; ray.o = f3(0, 0, 0); ray.d = f3(0, 0, 0);
                 for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
@@ -329,6 +332,13 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                             ray.factor[k] = pv.beta[k] * weight * rk * env_emission(s, ep, lam[k], ec[k]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
                         }
                         out.shadow_count += 1;
+                        if (convex != 0u) {
+                            // An environment ray always LEAVES on the normal's side (local_wo.z > 0) but starts on the side of the WORLD z of its direction (pt.rs:256, a kept
+                            // quirk): with direction.z < 0 it starts 1e-3 INSIDE a certified body and must cross its closed surface — any hit blocks an environment ray
+                            // (pt.rs:300-330): dead here; with direction.z > 0 it starts outside and cannot hit the body again.
+                            if ((convex & PT_INST_CONVEX_IN) && (hit.instance & PT_HIT_IN_SAFE) && direction.z < 0.0f) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
+                            if ((convex & PT_INST_CONVEX_OUT) && local_wo.z > PT_CONVEX_OUT_COS && direction.z > 0.0f) out.env_mask |= 0x100u << l;
+                        }
                         // a contribution of exactly 0 adds 0 whether or not the ray is occluded: not traced
                         if (ray_is_live<NL>(ray)) out.env_mask |= 1u << l;
                     }
@@ -357,6 +367,11 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                         // (the microfacet evaluation is a big body: rolled; the Lambertian one a few instructions: the compiler's choice)
                         if (GGX) { PT_ROLLED for (int k = 1; k < NL; ++k) passenger(k); } else { for (int k = 1; k < NL; ++k) passenger(k); }
                         out.shadow_count += 1;
+                        if (convex != 0u) {
+                            // inward from a certified body: the reference's closest hit is the body's own surface, or something inside it — no light (pt.rs:177-189): the sample adds 0
+                            if ((convex & PT_INST_CONVEX_IN) && (hit.instance & PT_HIT_IN_SAFE) && bsdf_wo.z < 0.0f) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
+                            if ((convex & PT_INST_CONVEX_OUT) && bsdf_wo.z > PT_CONVEX_OUT_COS) out.env_mask |= 0x100u << l;
+                        }
                         // The scene's ONLY light: a ray that misses it meets no light at all — the light-sample kernel's search bound (shadow_light_bound:
                         // nearest_light_hit = +inf) would drop it untraced, with the same test on the same ray.  Found here it makes the ray dead, and an
                         // item whose rays are all dead is never read (Layout::shadow_live_field).  In the Cornell box that is every vertex on the
@@ -371,6 +386,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                 }
                 sink(l, ray);
             }
+            if (out.env_mask & 0xff00u) out.env_mask |= hit.instance << 16;   // (PT_HIT_IN_SAFE falls off the top)   // (the instance the marked rays may skip; certified instances are numbered below 65536)
             out.has_item = true;
         }
     }
@@ -661,14 +677,14 @@ PT_HD int shadow_env_stop(const SceneView& s) { return (bu(s, PT_HDR_FLAGS) & PT
 // wave whose lanes hold both kinds traces them together.  ENV = false: the caller knows the scene produces no environment rays
 // (env_sampling_probability = 0) and that half is compiled out.
 template <int NL, int TRAV = PT_TRAV_ANY, bool ENV = true, typename LambdaOf, typename FactorOf>
-PT_HD void stage_shadow_ray(const SceneView& s, LambdaOf&& lambda_of, FactorOf&& factor_of, F3 o, F3 d, bool env, float (&contribution)[NL]) {
+PT_HD void stage_shadow_ray(const SceneView& s, LambdaOf&& lambda_of, FactorOf&& factor_of, F3 o, F3 d, bool env, float (&contribution)[NL], uint32_t skip_inst = 0xffffffffu) {
     for (int k = 0; k < NL; ++k) contribution[k] = 0.0f;
     float bound = PT_INF; int stop = PT_STOP_NONE;
     uint32_t light = 0xffffffffu;   // the light whose hit bounds the search: its test has been run, phase 3 takes the distance (sweep_run)
     if (ENV && env) stop = shadow_env_stop(s);
     else if (!shadow_light_bound(s, o, d, &bound, &stop, &light)) { PT_STAT(rays_without_light); return; }
     Hit sh;
-    bool hit = world_hit<TRAV, true>(s, o, d, &sh, bound, stop, light, bound);
+    bool hit = world_hit<TRAV, true>(s, o, d, &sh, bound, stop, light, bound, skip_inst);
     shadow_ray_contribution<NL>(s, lambda_of, factor_of, d, ENV && env, hit, sh, contribution);
 }
 // (PT_SHADOW_EAGER true: the pure sweep form reads a ray's origin and direction along with its factor — measured: k_shadow 3525 -> 3600 us on C2, not used)
@@ -678,7 +694,9 @@ PT_HD void stage_shadow_ray(const SceneView& s, LambdaOf&& lambda_of, FactorOf&&
 // One light-sample item: L rays, summed in order, divided by L (pt.rs:349-392, 596)
 template <int NL, int TRAV = PT_TRAV_ANY, bool ENV = true>
 PT_HD void stage_shadow_item(const SceneView& s, uint32_t light_samples, const Queue& shadow, uint32_t item, float* energy, uint32_t energy_stride) {
-    uint32_t slot = qu(shadow, Layout<NL>::sh_slot, item), flags = ENV ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
+    // (the pure sweep kernels' tables hold no walked mesh: a mark "cannot hit its instance again" — bit 8 + l, PT_INST_CONVEX_OUT — would save them a triangle leaf or two; not read there)
+    const bool marks = TRAV != PT_TRAV_SWEEP && (bu(s, PT_HDR_FLAGS) & PT_FLAG_CONVEX) != 0u;
+    uint32_t slot = qu(shadow, Layout<NL>::sh_slot, item), flags = (ENV || marks) ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
     float lambda0 = 0.0f, lc[NL];
     if (NL == 1) lambda0 = qf(shadow, Layout<NL>::sh_lambda, item);
     for (int k = 0; k < NL; ++k) lc[k] = 0.0f;
@@ -691,7 +709,7 @@ PT_HD void stage_shadow_item(const SceneView& s, uint32_t light_samples, const Q
         // (hero wavelengths: the factors too are read again when the ray contributes, not held across its search)
         const uint32_t ff = Layout<NL>::sh_head + l * Layout<NL>::sr_fields + SR_FACTOR;
         auto factor_of = [&](int k) { return NL == 1 ? ray.factor[0] : qf(shadow, ff + (uint32_t)k, item); };
-        stage_shadow_ray<NL, TRAV, ENV>(s, lambda_of, factor_of, ray.o, ray.d, ((flags >> l) & 1u) != 0u, c);
+        stage_shadow_ray<NL, TRAV, ENV>(s, lambda_of, factor_of, ray.o, ray.d, ENV && ((flags >> l) & 1u) != 0u, c, (marks && ((flags >> (8u + l)) & 1u) != 0u) ? flags >> 16 : 0xffffffffu);
         for (int k = 0; k < NL; ++k) lc[k] += c[k];
     }
     for (int k = 0; k < NL; ++k) energy[(size_t)k * energy_stride + slot] += lc[k] / (float)light_samples;

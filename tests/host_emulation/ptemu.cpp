@@ -26,6 +26,7 @@ pt_status ptemu_scene_create(const pt_scene_desc* d, pt_scene** out) {
     // the engine's diagnostic switches (pt_engine.hip: PT_AMD_EXACT_SLAB / NO_CULL / NO_SWEEP), as one flag word
     const char* f = getenv("PTEMU_FLAGS");
     if (f) sc->host.blob[PT_HDR_FLAGS] |= (uint32_t)strtoul(f, nullptr, 0);
+    if (getenv("PTEMU_NO_CONVEX")) sc->host.blob[PT_HDR_FLAGS] &= ~PT_FLAG_CONVEX;   // (pt_engine.hip: PT_TUNE_NO_CONVEX)
     *out = sc;
     return PT_OK;
 }
@@ -39,6 +40,18 @@ uint32_t ptemu_debug_scene_info(pt_scene* sc, int what) {
         for (uint32_t i = 0; i < w[PT_HDR_INSTANCE_COUNT]; ++i) {
             const uint32_t inst = w[PT_HDR_INSTANCE_OFF] + i * PT_INST_WORDS;
             if (w[inst + PT_INST_KIND] == (uint32_t)PT_SHAPE_MESH) return w[w[inst + PT_INST_MESH] + (uint32_t)what];
+        }
+        return 0;
+    }
+    if (what >= 15 && what <= 17) {   // the first mesh instance's record flags (15: PT_INST_CONVEX_* among them) and how many of its mesh's triangles carry PT_TRI_IN_SAFE (16) / PT_TRI_IN_SAFE_INNER (17)
+        for (uint32_t i = 0; i < w[PT_HDR_INSTANCE_COUNT]; ++i) {
+            const uint32_t inst = w[PT_HDR_INSTANCE_OFF] + i * PT_INST_WORDS;
+            if (w[inst + PT_INST_KIND] != (uint32_t)PT_SHAPE_MESH) continue;
+            if (what == 15) return w[inst + PT_INST_FLAGS];
+            const uint32_t mesh = w[inst + PT_INST_MESH], tri = w[PT_HDR_CORE_WORDS] + w[mesh + PT_MESH_TRI_OFF];
+            uint32_t n = 0;
+            for (uint32_t f = 0; f < w[mesh + PT_MESH_FACE_COUNT]; ++f) n += (w[tri + f * PT_TRI_WORDS + PT_TRI_FLAGS] & (what == 16 ? PT_TRI_IN_SAFE : PT_TRI_IN_SAFE_INNER)) ? 1u : 0u;
+            return n;
         }
         return 0;
     }
@@ -182,7 +195,7 @@ pt_status ptemu_intersect(pt_scene* sc, size_t n, const float* o, const float* d
         Hit h; pt_hit r; std::memset(&r, 0, sizeof(r));
         if (world_hit(s, f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), &h)) {
             r.valid = 1; r.t = h.t; r.point[0] = h.p.x; r.point[1] = h.p.y; r.point[2] = h.p.z; r.normal[0] = h.n.x; r.normal[1] = h.n.y; r.normal[2] = h.n.z;
-            r.uv[0] = h.u; r.uv[1] = h.v; r.material = h.material; r.instance = h.instance;
+            r.uv[0] = h.u; r.uv[1] = h.v; r.material = h.material; r.instance = h.instance & ~PT_HIT_IN_SAFE;
         }
         hits[i] = r;
     }

@@ -216,6 +216,105 @@ def test_an_open_mesh_gets_no_inner_ball(emu, pkg):
     assert _inner_ball(emu, b)[1] == 0.0
 
 
+def _cube(split_edge=False):
+    """A closed unit cube of 12 triangles, outward winding.  `split_edge`: the edge (0,0,0)-(1,0,0) carries a T-junction — the bottom face's triangle along it is cut
+    in two at the edge's midpoint while the front face's keeps the whole edge, and the gap is "filled" with a zero-area triangle: every undirected edge is still in
+    exactly two triangles."""
+    p = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+    f = [(0, 2, 1), (0, 3, 2), (4, 5, 6), (4, 6, 7), (0, 1, 5), (0, 5, 4), (1, 2, 6), (1, 6, 5), (2, 3, 7), (2, 7, 6), (3, 0, 4), (3, 4, 7)]
+    if split_edge:
+        p.append((0.5, 0, 0))                                  # 8: the midpoint
+        f[0:1] = [(0, 2, 8), (8, 2, 1)]                         # the bottom triangle (0, 2, 1) cut at the midpoint
+        f.append((0, 8, 1))                                     # the sliver between the two halves and the front face's whole edge
+    return np.asarray(p, np.float32), np.asarray(f, np.uint32)
+
+
+def _mesh_scene(pkg, p, f, n=None, transform=None, light_at=(0.0, 0.0, 3.0), sky=False):
+    b = pkg.scene.SceneBuilder()
+    pkg.scene.add_library_curves(b, ["flat_zero", "flat_one"])
+    b.set_environment_constant(b.curve("flat_one" if sky else "flat_zero"), 1.0 if sky else 0.0)
+    b.env_sampling_probability = 0.5 if sky else 0.0
+    lamp = pkg.scene.add_library_material(b, "diffuse_light_flat_x5")
+    white = pkg.scene.add_library_material(b, "lambertian_white")
+    glass = pkg.scene.add_library_material(b, "ggx_glass_rough")
+    b.add_rect((1.0, 1.0), light_at, "Z", True, lamp)
+    b.add_rect((12, 12), (0.0, 0.0, -2.0), "Z", True, white)
+    m = b.add_mesh(p, f, n, face_materials=pkg.api.material_id(pkg.api.TAG_MATERIAL, 0))
+    b.add_mesh_instance(m, glass, transform)
+    b.add_camera((-6.0, 0.5, 1.0), (0.5, 0.5, 0.5), 30.0)
+    return b
+
+
+def test_a_sliver_at_a_t_junction_is_not_closed(emu, pkg):
+    """Round-5 advisor: a T-junction filled with a zero-area triangle pairs every edge twice, but the watertight triangle test is watertight only across edges computed from
+    the SAME vertex pair — a ray can pass through such a junction.  Such a mesh is not "closed": no inner ball, no convex certificate; the plain cube has both."""
+    CONVEX = 16 | 32
+    for split, closed in ((False, True), (True, False)):
+        p, f = _cube(split)
+        sc = emu.create_scene(_mesh_scene(pkg, p, f))
+        info = lambda k: int(sc.library._debug_scene_info(sc.handle, k))
+        radius = float(np.array([info(11)], np.uint32).view(np.float32)[0])
+        assert (radius > 0.0) == closed and ((info(15) & CONVEX) != 0) == closed, (split, radius, info(15))
+
+
+def test_convex_certificates(emu, pkg):
+    """pt_blob.h PT_INST_CONVEX_*: which instances the host certifies, checked against what the scenes are.  The brilliant cut in the Cornell room: OUT and IN, 238 faces safe
+    all over and 64 (those at its 97-degree edges) safe away from their edges; with a lamp inside its bounding box: OUT only; a cube: OUT, and IN for the inside of its faces
+    only (at a 90-degree edge a point moved inward along one face lies ON the next face's plane); scaled unevenly and rotated: still convex, still certified; the monkey (not
+    convex), a smooth-shaded gem (hit normals are not the faces'), a cube seen inside out (normals inward): nothing."""
+    OUT, IN = 16, 32
+    def flags(b):
+        sc = emu.create_scene(b)
+        info = lambda k: int(sc.library._debug_scene_info(sc.handle, k))
+        return info(15) & (OUT | IN), info(16), info(17)
+    assert flags(pkg.scene.cornell_gem()) == (OUT | IN, 238, 64)
+    lamp_inside = pkg.scene.cornell_gem()
+    lamp_inside.add_rect((0.05, 0.05), (0.45, 0.45, -0.55), "Z", True, lamp_inside.material("sharp_light_fluorescent"))   # in a corner of the gem's box, outside the gem
+    assert flags(lamp_inside)[0] == OUT
+    p, f = _cube()
+    assert flags(_mesh_scene(pkg, p, f)) == (OUT | IN, 0, 12)
+    xf = pkg.scene.transform_from_data(scale=(0.5, 2.0, 1.25), rotate=[((0.3, 1.0, 0.2), 37.0)], translate=(0.2, -0.4, 0.1))
+    assert flags(_mesh_scene(pkg, p, f, transform=xf)) == (OUT | IN, 0, 12)
+    assert flags(_mesh_scene(pkg, p, f[:, ::-1].copy()))[0] == 0                        # inside out
+    assert flags(_mesh_scene(pkg, p, f, light_at=(0.5, 0.5, 1.0005)))[0] == OUT          # a lamp 5e-4 above the cube: its box touches the cube's
+    pm, fm, nm, _ = pkg.scene._npz_mesh("monkey")
+    assert flags(_mesh_scene(pkg, pm, fm))[0] == 0
+    pg, fg, ng, _ = pkg.scene._npz_mesh("gem")
+    assert ng is not None and flags(_mesh_scene(pkg, pg, fg, ng))[0] == 0               # smooth shading normals
+    # the certificate's geometry once more, with arithmetic of its own (numpy, f64), for the gem as the scene places it: convex within the slack, the safe faces really safe
+    pd, fd, nd, _ = pkg.scene._npz_mesh("brilliant_diamond")
+    P = pd.astype(np.float64) * 0.5 + np.array([0.0, 0.0, -0.7]); F = np.asarray(fd)
+    a, b_, c = P[F[:, 0]], P[F[:, 1]], P[F[:, 2]]
+    n = np.cross(b_ - a, c - a); n /= np.linalg.norm(n, axis=1)[:, None]
+    d = (n * a).sum(1)
+    assert (P @ n.T - d[None, :]).max() <= 2e-4
+    Q = P[F] - 1e-3 * n[:, None, :]                       # every corner of every face, moved inward
+    inside = ((Q.reshape(-1, 3) @ n.T - d[None, :]).max(axis=1) <= -1e-4).reshape(-1, 3).all(axis=1)
+    assert int(inside.sum()) == 238
+
+
+@pytest.mark.parametrize("case", ["cornell_gem", "cornell_gem_hero", "cube", "cube_transformed", "cube_lamp_close", "cube_sky", "cube_sky_hero"])
+def test_convex_certificates_change_nothing(emu, oracle, pkg, monkeypatch, case):
+    """A light-sample ray that leaves a certified body inward is dead where it is made, one that leaves it outward drops the body from its leaf mask (stage_shade,
+    world_hit_sweep): with the certificates ignored (PTEMU_NO_CONVEX = pt_tuning's PT_TUNE_NO_CONVEX) the film and the counters are the same bit for bit — and both are the oracle's."""
+    p, f = _cube()
+    xf = pkg.scene.transform_from_data(scale=(0.5, 2.0, 1.25), rotate=[((0.3, 1.0, 0.2), 37.0)], translate=(0.2, -0.4, 0.1))
+    b = {"cornell_gem": pkg.scene.cornell_gem, "cornell_gem_hero": pkg.scene.cornell_gem, "cube": lambda: _mesh_scene(pkg, p, f),
+         "cube_transformed": lambda: _mesh_scene(pkg, p, f, transform=xf), "cube_lamp_close": lambda: _mesh_scene(pkg, p, f, light_at=(0.5, 0.5, 1.2)),
+         # (environment rays: they leave on the normal's side but START on the side of their direction's WORLD z — pt.rs:256 —, so half of them start inside the body)
+         "cube_sky": lambda: _mesh_scene(pkg, p, f, transform=xf, sky=True), "cube_sky_hero": lambda: _mesh_scene(pkg, p, f, sky=True)}[case]()
+    rd = pkg.api.render_desc(48, 40, 8, 10, light_samples=3, seed=12, hero_wavelengths=4 if case.endswith("hero") else 1)
+    with_cert, pw = emu.create_scene(b).render(rd)
+    monkeypatch.setenv("PTEMU_NO_CONVEX", "1")
+    without, po = emu.create_scene(b).render(rd)
+    monkeypatch.delenv("PTEMU_NO_CONVEX")
+    assert np.array_equal(with_cert.view(np.uint32), without.view(np.uint32))
+    assert (pw.bounce_rays, pw.shadow_rays, pw.env_hits) == (po.bounce_rays, po.shadow_rays, po.env_hits)
+    ref, pr = oracle.create_scene(b).render(rd)
+    ps.check_film(with_cert, ref, pw, pr)
+    assert with_cert[..., :3].max() > 0.0
+
+
 def test_reference_known_answers_on_the_lane_logic(emu, oracle, pkg):
     """The reference's own known-answer tests for the path, which tests/test_oracle.py runs on the oracle, on the
     engine's lane logic; tests/test_gpu_parity.py runs the same list on the GPU."""

@@ -404,6 +404,36 @@ def test_forms_without_transforms_change_nothing(engine, pkg, monkeypatch, scene
         parity_suite.assert_hits_equal(hits, other.intersect(o, d))
 
 
+@pytest.mark.parametrize("case", ["cornell_gem", "cornell_gem_hero", "fuzz_49682", "fuzz_100003", "cube_sky"])
+def test_convex_certificates_change_nothing(engine, oracle, pkg, monkeypatch, case):
+    """Round 6 (pt_blob.h PT_INST_CONVEX_*): a light-sample ray that leaves a certified closed convex mesh instance inward is dead where it is made, one that leaves it outward
+    drops the instance from its leaf mask and never parks at it.  With the certificates ignored (PT_AMD_NO_CONVEX = PT_TUNE_NO_CONVEX) — and through the other traversal
+    forms, which do not use the marks — the film and the counters are the same bit for bit, and they are the oracle's.  fuzz_49682: octahedra under a sky that light samples
+    pick (an environment ray starts on the side of its direction's world z, pt.rs:256: half of the outward ones start INSIDE the body — the case that caught the first version)."""
+    import fuzz_scenes
+    from test_emulation import _cube, _mesh_scene
+    if case.startswith("fuzz_"):
+        b = fuzz_scenes.random_scene(int(case[5:]))
+    elif case == "cube_sky":
+        p, f = _cube()
+        b = _mesh_scene(pkg, p, f, transform=pkg.scene.transform_from_data(scale=(0.5, 2.0, 1.25), rotate=[((0.3, 1.0, 0.2), 37.0)], translate=(0.2, -0.4, 0.1)), sky=True)
+    else:
+        b = pkg.scene.cornell_gem()
+    rd = pkg.api.render_desc(192, 160, 10, 10, light_samples=3, seed=12, hero_wavelengths=4 if case.endswith("hero") else 1)
+    monkeypatch.setenv("PT_AMD_BLOCKS_PER_CU", "2")   # (segments long enough for the park lists to fill)
+    base, pbase = engine.create_scene(b).render(rd)
+    for env in ({"PT_AMD_NO_CONVEX": "1"}, {"PT_AMD_NO_SWEEP": "1"}, {"PT_AMD_NO_PARK": "1"}, {"PT_AMD_NO_CONVEX": "1", "PT_AMD_NO_SWEEP": "1"}, {"PT_AMD_PARK_DYNAMIC": "1", "PT_AMD_LDS_ALL_LIMIT": "98304"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        film, prof = engine.create_scene(b).render(rd)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(base.view(np.uint32), film.view(np.uint32)), env
+        assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits), env
+    ref, rprof = oracle.create_scene(b).render(rd)
+    ps.check_film(base, ref, pbase, rprof)
+
+
 def test_tuning_is_taken_at_scene_creation(engine, pkg, monkeypatch):
     """pt_tuning: the engine's switches as an explicit struct (what a Rust host sets per scene).  pt_scene_create_tuned with a flag set does what
     the variable does through pt_tuning_default; a variable that changes AFTER the scene exists changes nothing (the environment is read once,

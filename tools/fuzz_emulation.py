@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Differential soak on the CPU: the emulated lane logic (tests/host_emulation) vs the oracle over seeded random scenes (tests/fuzz_scenes.py) — what tools/fuzz_soak.py does
+on the GPU, for the build container.  usage: tools/fuzz_emulation.py <first seed> <count> [width height spp] [PTEMU_FLAGS]"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fuzz_scenes  # noqa: E402
+import oracle_loader  # noqa: E402
+import parity_suite as ps  # noqa: E402
+
+pkg = importlib.import_module("rust-pathtracer_amd")
+first, count = int(sys.argv[1]), int(sys.argv[2])
+W, H, SPP = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (40, 32, 3)
+if len(sys.argv) > 6:
+    os.environ["PTEMU_FLAGS"] = sys.argv[6]
+emu = pkg.api.Library(os.path.join(ROOT, "tests", "host_emulation", "libptemu.so"), "ptemu_", optional=("render_device", "device_info"))
+oracle = oracle_loader.load(pkg)
+bad = []
+for seed in range(first, first + count):
+    try:
+        b = fuzz_scenes.random_scene(seed)
+        o, d = fuzz_scenes.random_rays(seed, 1 << 11)
+        se, so = emu.create_scene(b), oracle.create_scene(b)
+        ps.assert_hits_equal(se.intersect(o, d), so.intersect(o, d))
+        rd = pkg.api.render_desc(W, H, SPP, 6, light_samples=int(1 + seed % 3), seed=seed, hero_wavelengths=4 if seed % 5 == 0 and not fuzz_scenes.medium_aware(seed) else 1, medium_aware=fuzz_scenes.medium_aware(seed))
+        film, prof = se.render(rd)
+        ref, rprof = so.render(rd)
+        ps.check_film(film, ref, prof, rprof)
+    except Exception as e:  # noqa: BLE001
+        bad.append((seed, repr(e)[:200]))
+print("seeds", first, "..", first + count - 1, "failures:", len(bad), bad[:5])
+sys.exit(1 if bad else 0)
