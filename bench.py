@@ -304,7 +304,30 @@ def main():
         reduce_s = sharding.max_over_ranks(sum(r[2] for r in res), "cuda")
         cam = sharding.sum_over_ranks([sum(r[0].camera_rays for r in res)], "cuda")[0]
         f = float(args.strong_frames)
-        return {"frame": name, "width": W, "height": H, "spp": spp, "max_bounces": max_bounces, "light_samples": light_samples, "n_gpus": n_gpus, "frames": args.strong_frames,
+        # ---- SURVEY 8(e)'s claim, checked by the record itself (round-5 verdict, item 4): "the reduced film of N ranks is bit-identical to the 1-GPU film".  A small frame of
+        # the leg's own settings (256 x 256, or the film if smaller): every rank renders its tiles of it, one reduce into rank 0 — the leg's own code path — and rank 0 ALSO
+        # renders the whole frame alone; the two films are compared bit for bit on the device.  After the leg's clocks.
+        cw, ch = min(W, 256), min(H, 256)
+        small = torch.zeros((ch, cw, 4), dtype=torch.float32, device="cuda")
+        rd_s = pkg.api.render_desc(cw, ch, spp, max_bounces, min_bounces=min_bounces, light_samples=light_samples, seed=99, shard=sharding.shard(rank, n_gpus), hero_wavelengths=hero)
+        prof_s = leg_scene.render_device(rd_s, small.data_ptr(), stream)
+        torch.cuda.synchronize()
+        sharding.reduce_film(small, dst=0)
+        sync()
+        rays = sharding.sum_over_ranks([prof_s.camera_rays, prof_s.bounce_rays, prof_s.shadow_rays], "cuda")
+        check = None
+        if rank == 0:
+            alone = torch.zeros_like(small)
+            prof_a = leg_scene.render_device(pkg.api.render_desc(cw, ch, spp, max_bounces, min_bounces=min_bounces, light_samples=light_samples, seed=99, hero_wavelengths=hero), alone.data_ptr(), stream)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(small.view(torch.int32), alone.view(torch.int32)))
+            check = {"film_equals_one_rank": same and [int(x) for x in rays] == [prof_a.camera_rays, prof_a.bounce_rays, prof_a.shadow_rays],
+                     "width": cw, "height": ch, "spp": spp, "ranks": n_gpus, "films_bitwise_equal": same,
+                     "counters_n_ranks": [int(x) for x in rays], "counters_one_rank": [prof_a.camera_rays, prof_a.bounce_rays, prof_a.shadow_rays],
+                     "max_abs_difference": float((small - alone).abs().max().item()), "film_max": float(alone.max().item())}
+        sync()
+        return {"frame": name, "film_equals_one_rank": check["film_equals_one_rank"] if check else None, "one_rank_check": check,
+                "rccl_ranks": (dist.get_world_size() if use_dist else 1), "backend": (args.backend if use_dist else None), "width": W, "height": H, "spp": spp, "max_bounces": max_bounces, "light_samples": light_samples, "n_gpus": n_gpus, "frames": args.strong_frames,
                 "ms_per_frame": 1e3 * total / f, "value": cam / total / 1e6, "unit": "Msamples/s", "samples_per_frame": cam / f,
                 "render_ms_slowest_rank": 1e3 * render_max / f, "render_ms_fastest_rank": 1e3 * render_min / f, "reduce_ms": 1e3 * reduce_s / f,
                 "film_bytes_reduced": W * H * 16, "setup_ms": create_ms + first_ms, "setup": {"scene_create_ms": create_ms, "first_frame_ms": first_ms}}
@@ -320,7 +343,8 @@ def main():
         strong["C4"] = strong_leg("C4: hdri_test (sphere + monkey mesh under the synthetic HDRI), max_bounces 4, L = 6", c4_scene, c4_ms, max(1, 2048 // div), 4, 1, 6, 1)
         strong["note"] = ("total work fixed: one BASELINE frame per step, its 32x32 tiles dealt along diagonals over the N ranks, one RCCL reduce of the whole XYZ film per frame; "
                           "ms_per_frame = wall time barrier to barrier, max over ranks; setup_ms (scene build + upload + first frame's allocations) is outside it, "
-                          "as parsing and BVH build are outside the reference's own window (tiled.rs:294 -> 536)")
+                          "as parsing and BVH build are outside the reference's own window (tiled.rs:294 -> 536); film_equals_one_rank: a 256 x 256 frame of the leg's settings rendered by the N ranks "
+                          "and reduced, and by rank 0 alone — films compared bit for bit, counters summed over the ranks (SURVEY 8(e): the shards are disjoint, the sum is a gather)")
 
     # whole-job units: every rank rendered (pixels / N) x (S = spp_per_step x N) samples per step
     shard_pixels = sum(p.stage_items[4] for p in profs) / max(1, len(profs))

@@ -223,6 +223,9 @@
 #define PT_SHADE_LDS_BUDGET 40960u
 #define PT_MARG_LDS_BYTES(rows, has_guide) ((2u * (rows) + ((has_guide) ? (rows) + 3u : 0u)) * 4u + 16u)
 #define PT_MARG_LDS_MAX_ROWS 2048u   /* importance maps of at most this many rows have their marginal tables staged in LDS by the FULL vertex form (24 KB + guide) */
+#define PT_HDR_CONVEX_INST 69        /* 1 + the id of the scene's ONLY instance with PT_INST_CONVEX_OUT (0: none, or several): a path segment that leaves it outward carries a mark
+                                       — the sign of its record's previous-pdf word, which every reader squares — and the parked closest-hit kernel drops the instance from that
+                                       ray's leaf mask, as the light-sample kernel does for marked light rays */
 #define PT_HDR_CORE_WORDS 61        /* words of the core section; the mesh-data section follows it */
 #define PT_HDR_SWEEP_MESH_MASK 57  /* 2 words: the bits that stand for mesh instances (no primitive of their own) */
 #define PT_HDR_SWEEP_OWNER_MASK 62 /* 2 words: the bits whose primitive test needs the ray itself (analytic shapes, triangles of transformed

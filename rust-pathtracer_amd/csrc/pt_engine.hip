@@ -405,6 +405,9 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
             uint32_t *cin = live[bounce & 1], *cout = live[(bounce + 1) & 1];
             // kernel variant = staging mode (PT_LDS_*) x traversal form x wavelengths per path (pt_launch.h)
             if (park_dynamic) cfg.unit_counter = b.unit_counters + 2 * bounce;
+            // (a marked path segment — it left the scene's one certified convex body outward — skips that instance: records the vertex kernel wrote, so from bounce 1 on; never
+            // in the medium-aware walk, whose vertex code makes no marks)
+            cfg.path_marks = (bounce > 0 && !rd.medium_aware && (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_CONVEX)) ? sc->host.blob[PT_HDR_CONVEX_INST] : 0u;
             if (!cfg.fuse) timed(ST_EXTEND, [&] { launch_extend(cfg, trav_form, sargs, qin, qh, seg_cap, cin, b.park); });
             if (park_dynamic) cfg.unit_counter = b.unit_counters + 2 * bounce + 1;
             timed(ST_SHADE, [&] { launch_shade(cfg, hero ? 4 : 1, shade_form, sargs, rp, bounce, d_px, qin, qh, qout, qs, b.energy, seg_cap, cin, cout, nshadow, b.block_stats); });

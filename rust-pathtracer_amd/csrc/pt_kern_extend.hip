@@ -33,10 +33,10 @@ void launch_extend(const LaunchCfg& c, int form, const SceneArgs& sc, Queue path
         if (c.lds_mode == PT_LDS_ALL) go(d, K_EXT_PARKED_DYN(PT_LDS_ALL), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
         else if (c.lds_mode == PT_LDS_CORE) go(d, K_EXT_PARKED_DYN(PT_LDS_CORE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
         else go(d, K_EXT_PARKED_DYN(PT_LDS_NONE), sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, (uint32_t)c.grid, c.unit_counter, c.walk_policy);
-    } else if (form == PT_FORM_PARKED && c.park_block_extend == 512) { go_block(c, 512, c.park_blob_bytes, k_extend_parked<PT_LDS_ALL, 0, 512>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
-    else if (form == PT_FORM_PARKED && c.park_block_extend == 1024) { go_block(c, 1024, c.park_blob_bytes, k_extend_parked<PT_LDS_ALL, 0, 1024>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
-    else if (form == PT_FORM_PARKED_WALK) { PT_BY_MODE(K_EXT_PARKED_W, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
-    else if (form == PT_FORM_PARKED) { PT_BY_MODE(K_EXT_PARKED, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy); PT_TL_BUMP(c.stream); }
+    } else if (form == PT_FORM_PARKED && c.park_block_extend == 512) { go_block(c, 512, c.park_blob_bytes, k_extend_parked<PT_LDS_ALL, 0, 512>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy, c.path_marks); PT_TL_BUMP(c.stream); }
+    else if (form == PT_FORM_PARKED && c.park_block_extend == 1024) { go_block(c, 1024, c.park_blob_bytes, k_extend_parked<PT_LDS_ALL, 0, 1024>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy, c.path_marks); PT_TL_BUMP(c.stream); }
+    else if (form == PT_FORM_PARKED_WALK) { PT_BY_MODE(K_EXT_PARKED_W, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy, 0u); PT_TL_BUMP(c.stream); }
+    else if (form == PT_FORM_PARKED) { PT_BY_MODE(K_EXT_PARKED, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in, park, c.walk_policy, c.path_marks); PT_TL_BUMP(c.stream); }
 #ifdef PT_EXPERIMENTS
     else if (form == PT_FORM_POOLED) PT_GO(k_extend_pooled<PT_LDS_ALL>, sc.blob, sc.blob_words, sc.tex, paths, hits, seg_cap, count_in);
 #endif

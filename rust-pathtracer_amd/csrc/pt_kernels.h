@@ -797,6 +797,9 @@ __global__ void __launch_bounds__(kBlock) PT_POOL_OCC k_shadow_exp(const uint32_
 // the ones that do are scattered over the waves, so walking the mesh in line would leave a wave waiting for a handful of
 // lanes.  Instead a lane that reaches a walked-mesh bit *parks* its sweep state in the workgroup's scratch region, and
 // whenever a wave has 64 rays parked (and at the end) it resumes them together: a full wave, every lane in a mesh walk.  Nothing about a ray's own sequence of tests changes (same leaves, same order, same running closest hit).
+#ifndef PT_CONVEX_SKIP
+#define PT_CONVEX_SKIP 1   /* the parked kernels honour the mark "cannot hit its instance again" (round 6); 0 = ignore it: the mesh is walked and nothing found */
+#endif
 enum { PK_ITEM, PK_HIT_LO, PK_HIT_HI, PK_CLOSEST, PK_BEST_INST, PK_BEST_TRIW, PK_T, PK_B0, PK_B1, PK_B2, PK_RAY, PK_BOUND, PK_KIND, PK_CURSOR };
 static_assert(PK_CURSOR < kParkFields, "a parked entry's fields");
 // REC (round 5: the round-4 verdict's "compacted park record", built instead of priced): which fields an entry carries.  PK_FULL = all fourteen; PK_SEGMENT = a path segment's
@@ -850,9 +853,6 @@ __device__ __forceinline__ void park_load(const uint32_t* pk, uint32_t e, uint32
 #ifndef PT_PARKED_EAGER
 #define PT_PARKED_EAGER true
 #endif
-#ifndef PT_CONVEX_SKIP
-#define PT_CONVEX_SKIP 1   /* the parked light-sample kernel honours the mark "cannot hit its instance again" (round 6); 0 = ignores it: the mesh is walked and nothing found */
-#endif
 #ifndef PT_PARKED_EXP
 #define PT_PARKED_EXP 0   // measurement variants of k_shadow_parked (tools/phase_costs_parked.sh); 0 = the product
 #endif
@@ -890,7 +890,9 @@ template <int USE_LDS, int TOP = 0, int BLK = kBlock>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlock ? PT_PARK_EXTEND_WAVES : PT_PARK_WAVES)))
 k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const float* __restrict__ tex,
                 Queue paths, Queue hits, uint32_t seg_cap, const uint32_t* __restrict__ count_in,
-                uint32_t* __restrict__ park_all, uint32_t walk_policy) {
+                uint32_t* __restrict__ park_all, uint32_t walk_policy, uint32_t path_marks) {
+    // `path_marks`: 1 + the instance a MARKED segment cannot hit (PT_HDR_CONVEX_INST; the mark is the sign of the record's previous-pdf word, written by the vertex kernel —
+    // so never at bounce 0, whose records k_generate wrote: the engine passes 0 there, and for a scene without such an instance)
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ uint32_t park_counts[BLK / 64];
     constexpr uint32_t kParkCap = kWaveParkCap * (BLK / 64);   // (shadows ptk::kParkCap: this workgroup's entries per field)
@@ -922,6 +924,7 @@ k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const fl
             if (TOP) { top_walk_init(st); parks = top_walk_run(s, o, d, PT_INF, PT_STOP_NONE, st, true, (walk_policy >> 24) & 0xffu, &evicted); }
             else {
                 sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
+                if (PT_CONVEX_SKIP && path_marks != 0u && qf(paths, PS_PREV_PDF, base + j) < 0.0f) st.hit &= ~sweep_instance_mask(s, path_marks - 1u);
                 const TriRay wtr = tri_ray_prepare(o, d);
                 parks = sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true);
             }

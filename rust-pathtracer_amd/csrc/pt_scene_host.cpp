@@ -785,6 +785,11 @@ static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::st
             any = any || cf != 0u;
         }
         if (any) w[PT_HDR_FLAGS] |= PT_FLAG_CONVEX;
+        {   // PT_HDR_CONVEX_INST: the only OUT-certified instance, if there is exactly one
+            uint32_t count = 0, which = 0;
+            for (uint32_t i = 0; i < d.instance_count; ++i) if (w[w[PT_HDR_INSTANCE_OFF] + i * PT_INST_WORDS + PT_INST_FLAGS] & PT_INST_CONVEX_OUT) { ++count; which = i; }
+            w[PT_HDR_CONVEX_INST] = count == 1 ? which + 1u : 0u;
+        }
         for (uint32_t mi = 0; mi < d.mesh_count; ++mi) {   // PT_TRI_IN_SAFE into the triangle records, and into their permuted copies
             if (mesh_in_safe[mi].empty()) continue;
             const uint32_t tri_off = w[mesh_off[mi] + PT_MESH_TRI_OFF];

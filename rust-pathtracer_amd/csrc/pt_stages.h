@@ -113,7 +113,7 @@ PT_HD PathVertexT<NL> load_path(const Queue& q, uint32_t i) {
     PathVertexT<NL> p;
     p.o = f3(qf(q, PS_OX, i), qf(q, PS_OY, i), qf(q, PS_OZ, i));
     p.d = f3(qf(q, PS_DX, i), qf(q, PS_DY, i), qf(q, PS_DZ, i));
-    p.beta[0] = qf(q, PS_BETA, i); p.lambda = qf(q, PS_LAMBDA, i); p.slot = qu(q, PS_SLOT, i); p.prev_pdf = qf(q, PS_PREV_PDF, i);
+    p.beta[0] = qf(q, PS_BETA, i); p.lambda = qf(q, PS_LAMBDA, i); p.slot = qu(q, PS_SLOT, i); p.prev_pdf = pt_abs(qf(q, PS_PREV_PDF, i));   // (its sign is a mark for the closest-hit kernel: PT_HDR_CONVEX_INST)
     for (int k = 1; k < NL; ++k) p.beta[k] = qf(q, PS_FIELDS + k - 1, i);
     p.prev_n = f3(qf(q, PS_PNX, i), qf(q, PS_PNY, i), qf(q, PS_PNZ, i));
     p.prev_p = f3(qf(q, PS_PPX, i), qf(q, PS_PPY, i), qf(q, PS_PPZ, i));
@@ -260,6 +260,10 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     F3 wi = normalize(to_local(frame, neg(pv.d)));
     uint32_t m = material_record(s, hit.material);
     bool is_light = !(s.lacks & PT_SCENE_NO_LIGHTS) && PT_MATERIAL_TAG(hit.material) == PT_TAG_LIGHT;
+    // (round 6) the vertex lies on an instance the host certified convex and closed (pt_blob.h PT_INST_CONVEX_*): its outward light-sample rays are marked
+    // "cannot hit this instance again" (ShadeOutT::env_mask, bits 8.. and 16..), its inward light rays are dead here, and so is marked the path's next segment if it
+    // leaves outward.  A scene without such an instance: one scalar test.
+    const uint32_t convex = (bu(s, PT_HDR_FLAGS) & PT_FLAG_CONVEX) ? bu(s, bu(s, PT_HDR_INSTANCE_OFF) + (hit.instance & ~PT_HIT_IN_SAFE) * PT_INST_WORDS + PT_INST_FLAGS) & (PT_INST_CONVEX_OUT | PT_INST_CONVEX_IN) : 0u;
     pt_f32x4 r = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples));
     float f, pdf; F3 wo;
     // (per-wavelength loops stay rolled, their arrays in registers: pl_get / pl_set, pt_device.h)
@@ -304,9 +308,6 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
             const bool one_light = n_lights == 1u && !(bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_SHADOW_BOUND | PT_FLAG_NO_LIGHT_PREPASS | PT_FLAG_NO_CULL | PT_FLAG_NO_ONE_LIGHT));
             EnvCurves ec[NL];  // the environment's spectral weights at this vertex' wavelengths, for all its light samples
             for (int k = 0; k < NL; ++k) ec[k] = (ENV && env_p > 0.0f) ? env_curves(s, lam[k]) : EnvCurves{{0.0f, 0.0f, 0.0f, 0.0f}, false};
-            // (round 6) the vertex lies on an instance the host certified convex and closed (pt_blob.h PT_INST_CONVEX_*): its outward light-sample rays are marked
-            // "cannot hit this instance again" (ShadeOutT::env_mask, bits 8.. and 16..), its inward light rays are dead here.  A scene without such an instance: one scalar test.
-            const uint32_t convex = (bu(s, PT_HDR_FLAGS) & PT_FLAG_CONVEX) ? bu(s, bu(s, PT_HDR_INSTANCE_OFF) + (hit.instance & ~PT_HIT_IN_SAFE) * PT_INST_WORDS + PT_INST_FLAGS) & (PT_INST_CONVEX_OUT | PT_INST_CONVEX_IN) : 0u;
             for (uint32_t l = 0; l < rp.light_samples; ++l) {
                 ShadowRayT<NL> ray; ray.o = f3(0, 0, 0); ray.d = f3(0, 0, 0);
                 for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
@@ -409,6 +410,9 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     for (int k = 0; k < NL; ++k) out.next.beta[k] = beta[k];
     out.next.lambda = pv.lambda; out.next.slot = pv.slot;
     out.next.prev_pdf = pdf_forward; out.next.prev_n = hit.n; out.next.prev_p = hit.p;
+    // The next segment leaves the scene's one certified convex body outward (it starts 1e-3 outside the face it left, hit.n being that face's normal, and moves away): it
+    // cannot hit that instance again.  Marked in the sign of the previous-pdf word — every reader takes its magnitude (load_path) — for the parked closest-hit kernel.
+    if ((convex & PT_INST_CONVEX_OUT) && wo.z > PT_CONVEX_OUT_COS && bu(s, PT_HDR_CONVEX_INST) == (hit.instance & ~PT_HIT_IN_SAFE) + 1u) out.next.prev_pdf = -pdf_forward;
     return out;
 }
 

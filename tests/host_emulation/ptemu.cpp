@@ -122,7 +122,10 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
             Queue qin = (bounce & 1) ? qb : qa, qout = (bounce & 1) ? qa : qb;
             for (uint32_t i = 0; i < live; ++i) {
                 Hit h;
-                world_hit(s, f3(qf(qin, PS_OX, i), qf(qin, PS_OY, i), qf(qin, PS_OZ, i)), f3(qf(qin, PS_DX, i), qf(qin, PS_DY, i), qf(qin, PS_DZ, i)), &h);
+                // (k_extend_parked's path_marks: a marked segment — the sign of its previous-pdf word, from bounce 1 on — cannot hit the scene's one certified convex body)
+                const bool marked = bounce > 0 && !rd.medium_aware && (bu(s, PT_HDR_FLAGS) & PT_FLAG_CONVEX) && bu(s, PT_HDR_CONVEX_INST) != 0u && qf(qin, PS_PREV_PDF, i) < 0.0f;
+                world_hit(s, f3(qf(qin, PS_OX, i), qf(qin, PS_OY, i), qf(qin, PS_OZ, i)), f3(qf(qin, PS_DX, i), qf(qin, PS_DY, i), qf(qin, PS_DZ, i)), &h, PT_INF, PT_STOP_NONE, 0xffffffffu, 0.0f,
+                          marked ? bu(s, PT_HDR_CONVEX_INST) - 1u : 0xffffffffu);
                 store_hit(qh, i, h);
             }
             uint32_t next = 0, items = 0;

@@ -102,6 +102,7 @@ def test_bench_rccl_path_on_one_gpu(tmp_path):
         assert g["ms_per_frame"] > 0 and abs(g["value"] - g["samples_per_frame"] / (g["ms_per_frame"] * 1e-3) / 1e6) / g["value"] < 1e-6, leg
         assert 0 < g["reduce_ms"] < g["ms_per_frame"] and g["render_ms_fastest_rank"] <= g["render_ms_slowest_rank"] <= g["ms_per_frame"], leg
         assert g["setup_ms"] == g["setup"]["scene_create_ms"] + g["setup"]["first_frame_ms"] and g["film_bytes_reduced"] == 1024 * 1024 * 16, leg
+        assert g["film_equals_one_rank"] is True and g["one_rank_check"]["ranks"] == 1 and g["rccl_ranks"] == 1 and g["backend"] == "nccl", leg
     # with one GPU the fixed-frame (strong scaling) run is the weak-scaling run: the same work, the same record but for the mode's name
     assert lines["strong"]["scaling"] == "strong" and lines["plain"]["scaling"] == "weak"
     for key in ("metric", "unit", "n_gpus", "steps", "segments_per_sample", "dtype"):
@@ -198,3 +199,7 @@ def test_bench_gpus_n_launches_n_ranks(tmp_path, n):
         g = d["strong"][leg]
         assert g["n_gpus"] == n and g["samples_per_frame"] == 256 * 256 * spp and g["value"] > 0 and g["reduce_ms"] > 0, leg
         assert g["render_ms_slowest_rank"] >= g["render_ms_fastest_rank"] > 0, leg
+        # the record checks SURVEY 8(e)'s claim itself: the n ranks' reduced film of a small frame against rank 0's own render of it, bit for bit, counters summed
+        c = g["one_rank_check"]
+        assert g["film_equals_one_rank"] is True and c["films_bitwise_equal"] and c["ranks"] == n and g["rccl_ranks"] == n, (leg, c)
+        assert c["counters_n_ranks"] == c["counters_one_rank"] and c["counters_one_rank"][0] == 256 * 256 * spp and c["film_max"] > 0.0 and c["max_abs_difference"] == 0.0, (leg, c)
