@@ -271,8 +271,9 @@ typedef struct pt_tuning {
                                      this are still searching while others hold a leaf; 1 = never, at most 64; 0 = the default */
     uint32_t park_block;          /* PT_AMD_PARK_BLOCK: the parked kernels (scenes with walked meshes, one wavelength per path) of a scene whose blob is staged by
                                      its core only but fits 72 KB (the gem scene, C3: 66 KB) can run workgroups of 512 or 1024 threads that stage the WHOLE blob
-                                     in LDS while the other kernels keep their staging mode.  0 = the measured default (the light-sample kernel at 512, the
-                                     closest-hit kernel at 256), 512 / 1024 = both kernels at that size, 256 = off */
+                                     in LDS while the other kernels keep their staging mode.  0 = the measured default (the light-sample kernel at 512 — at 256 in a
+                                     scene with a certified convex body, whose light rays seldom reach the mesh —, the closest-hit kernel at 256), 512 / 1024 = both kernels
+                                     at that size, 256 = off */
     uint32_t light_prepass_max;   /* PT_AMD_LIGHT_PREPASS_MAX: a light-sample ray aimed at a light is bounded by the nearest hit among ALL lights before it is traced (one box
                                      test per light and ray: it buys the early stop at the first occluder).  A scene with more lights than this traces such a ray as a
                                      plain closest-hit search instead (test_bokeh.toml: 82 lights).  0 = the default (16); 0xffffffff = always bound */

@@ -281,6 +281,9 @@ PT_HD float layer_eval(const SceneView& s, uint32_t l, const LayerCurves& c, flo
     uint32_t kind = bu(s, l), w = bu(s, l + 5), h = bu(s, l + 6), toff = bu(s, l + 7);
     float cu = pt_clamp(u, 0.0f, 1.0f - PT_F32_EPSILON), cv = pt_clamp(v, 0.0f, 1.0f - PT_F32_EPSILON);
     uint32_t x = (uint32_t)(cu * (float)w), y = (uint32_t)(cv * (float)h);
+#if defined(PT_EXP_TABLE_FOLD)
+    if (h >= 64u * PT_EXP_TABLE_FOLD) y %= h / PT_EXP_TABLE_FOLD;   // (a TIMING experiment, never the product: see env_sample_uv)
+#endif
     uint32_t idx = y * w + x;
     if (kind == PT_TEXTURE1) return c.c0 * s.tex[toff + idx];
     const float* t = s.tex + toff + 4u * idx;
@@ -2534,6 +2537,9 @@ PT_HD float env_pdf_for(const SceneView& s, const EnvPoint& e) {
         uint32_t cols = bu(s, PT_HDR_IMAP_COLS);
         const float u2 = e.u2, v2 = e.v2;
         uint32_t row = (uint32_t)(pt_clamp(u2, 0.0f, 1.0f - PT_F32_EPSILON) * (float)rows);
+#if defined(PT_EXP_TABLE_FOLD)
+        row %= rows / PT_EXP_TABLE_FOLD;
+#endif
         const uint32_t stride = bu(s, PT_HDR_IMAP_STRIDE);
         const float marginal_pdf = s.marg_words != 0u ? linear01_nearest(s.marg + (bu(s, PT_HDR_IMAP_MARG_PDF) - s.marg_base), rows, u2, stride)   // (the LDS copy: stage_marginal)
                                                        : linear01_nearest(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), rows, u2, stride);
@@ -2567,6 +2573,12 @@ PT_HD void env_sample_uv(const SceneView& s, float sx, float sy, float* u, float
                                            s.marg_guide ? s.marg + s.marg_guide : nullptr, stride);
         else sample_cmf(s.tex + bu(s, PT_HDR_IMAP_MARG_PDF), s.tex + bu(s, PT_HDR_IMAP_MARG_CMF), rows, sy, &mu, &row_pdf, mg ? s.tex + mg : nullptr, stride);
         uint32_t row = (uint32_t)(mu * (float)rows);
+#if defined(PT_EXP_TABLE_FOLD)
+        // A TIMING experiment (round 6, profiles/r6_experiments.md; never the product — the results are wrong): the importance map's row tables and the environment's texels
+        // folded onto 1 / PT_EXP_TABLE_FOLD of their rows.  The same instructions and the same number of reads from a working set that much smaller: what the FULL vertex form
+        // would take if its table reads hit L2 — the ceiling of anything that reorders the searches (band passes) without removing them.
+        row %= rows / PT_EXP_TABLE_FOLD;
+#endif
         sample_cmf(s.tex + bu(s, PT_HDR_IMAP_ROW_PDF) + (size_t)row * cols * stride, s.tex + bu(s, PT_HDR_IMAP_ROW_CMF) + (size_t)row * cols * stride, cols, sx, &mv, &column_pdf,
                    rg ? s.tex + rg + (size_t)row * (cols + 3u) : nullptr, stride);
         F3 new_wo = xf_vec(s, PT_HDR_ENV_FORWARD, uv_to_direction(mu, mv));

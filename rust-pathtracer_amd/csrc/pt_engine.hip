@@ -253,7 +253,10 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
     // 0 = the measured default: the light-sample kernel in workgroups of 512 (C3: -5 %), the closest-hit kernel in its own 256 (at 512 it loses its fifth wave
     // per SIMD: +14 %); 512 / 1024 = both kernels; 256 = neither (profiles/r4_experiments.md section 1)
     const bool park_big_ok = !hero && sc->blob_words * 4u <= kParkBlobLimitBytes && sc->lds_mode == PT_LDS_CORE && !(tn.flags & PT_TUNE_NO_LDS);
-    const uint32_t park_block = !park_big_ok ? (uint32_t)kBlock : tn.park_block == 0u ? 512u : tn.park_block;
+    // (round 6: in a scene with a certified convex body — PT_FLAG_CONVEX, the gem of C3 — nine in ten of the light rays that used to walk the mesh no longer reach it, and the
+    // light-sample kernel is better off in workgroups of 256 that stage the core alone, twice the workgroups per CU: C3 k_shadow_parked 2339 -> 2083 us, profiles/r6d_ab_park.txt)
+    const bool few_walks = (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_CONVEX) != 0u;
+    const uint32_t park_block = !park_big_ok ? (uint32_t)kBlock : tn.park_block == 0u ? (few_walks ? (uint32_t)kBlock : 512u) : tn.park_block;
     const uint32_t park_block_extend = !park_big_ok || tn.park_block == 0u ? (uint32_t)kBlock : tn.park_block;
     pt_status st = ensure_buffers(sc, capacity, rd.light_samples, pixels.size() ? pixels.size() : 1, grid, (hero || rd.medium_aware) ? 4u : 1u, park_block);
     if (st != PT_OK) return st;
