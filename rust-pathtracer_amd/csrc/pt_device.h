@@ -1404,10 +1404,21 @@ PT_HD bool mesh_surely_missed(const SceneView& s, uint32_t inst, F3 o, F3 d, flo
 // `known_inst`, `known_t`: an instance whose test the caller has run on this very ray already (the nearest light of a light-sample ray,
 // nearest_light_hit) and the distance it found: the leaf takes that distance through the interval rule of its shape instead of running
 // the test again — the same number through the same comparison.
+// PT_SWEEP_ENTRY_REJECT (round 6, EXPERIMENT, off; round-5 verdict item 6 "the entry-distance reject actually built and measured"): phase 1 culls a leaf by the search's
+// bound only — the masks do not keep the boxes' entry distances — so phase 3 tests every triangle whose box the ray passes, however far behind the closest hit found
+// meanwhile.  With this switch a triangle leaf's box is tested AGAIN once a hit is known (the walk form's rule: beyond(entry, closest)), and the triangle skipped when its box
+// begins behind that hit.  Measured on C2: profiles/r6_experiments.md section 4.
+#ifndef PT_SWEEP_ENTRY_REJECT
+#define PT_SWEEP_ENTRY_REJECT 0
+#endif
 template <bool WALKS = true>
 PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bound, int stop, SweepState& st, bool park_at_walked,
                      uint32_t known_inst = 0xffffffffu, float known_t = 0.0f) {
     const uint32_t bits_off = bu(s, PT_HDR_SWEEP_BITS_OFF);
+#if PT_SWEEP_ENTRY_REJECT
+    const RayPrep erp = ray_prepare(o, d);
+    const bool erp_ok = erp.fast & (d.x != 0.0f) & (d.y != 0.0f) & (d.z != 0.0f) & !(bu(s, PT_HDR_FLAGS) & (PT_FLAG_NO_CULL | PT_FLAG_EXACT_SLAB));
+#endif
     while (st.hit != 0) {
         const uint32_t k = ctz64(st.hit);
         const F4 be = bf4(s, bits_off + k * PT_SWEEP_BIT_WORDS);
@@ -1440,6 +1451,16 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
                 return triangle_test_permuted(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th);
             };
             bool accepted;
+#if PT_SWEEP_ENTRY_REJECT
+            if (erp_ok && st.closest < PT_INF && !sweep_leaf_transformed(s, kf)) {
+                const uint32_t box = pt_f2u(be.z);
+                const F4 ba = bf4(s, box), bb = bf4(s, box + 4);
+                const float n0 = __builtin_fminf(approx_fma(ba.x, erp.r.x, erp.nor.x), approx_fma(bb.x, erp.r.x, erp.nor.x));
+                const float n1 = __builtin_fminf(approx_fma(ba.y, erp.r.y, erp.nor.y), approx_fma(bb.y, erp.r.y, erp.nor.y));
+                const float n2 = __builtin_fminf(approx_fma(ba.z, erp.r.z, erp.nor.z), approx_fma(bb.z, erp.r.z, erp.nor.z));
+                if (beyond(slab_entry(n0, n1, n2), st.closest, erp.base)) continue;   // (the box begins behind the closest hit: its triangle cannot be accepted)
+            }
+#endif
             if (sweep_leaf_transformed(s, kf)) { F3 lo, ld; instance_local_ray(s, inst, o, d, &lo, &ld); const TriRay ltr = tri_ray_prepare(lo, ld); accepted = test(ltr); }
             else accepted = test(wtr);
             {   // (selects, not branches: see triangle_edges)

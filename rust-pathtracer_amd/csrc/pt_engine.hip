@@ -886,7 +886,9 @@ pt_status pt_debug_numerics(int which, size_t n, const float* x, const float* y,
 uint32_t pt_debug_scene_info(pt_scene* sc, int what) {
     switch (what) { case 0: return sc->blob_words * 4; case 1: return (uint32_t)sc->lds_mode; case 2: return sc->host.light_count; case 3: return (uint32_t)sc->num_cus;
                     case 4: return sc->host.blob[PT_HDR_SWEEP_OFF] != 0 && !(sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP) ? 1u : 0u;
-                    case 7: return sc->host.blob[PT_HDR_CORE_WORDS] * 4; default: return 0; }
+                    case 7: return sc->host.blob[PT_HDR_CORE_WORDS] * 4;
+                    case 8: return (uint32_t)(sc->host.tex.size() > 0xffffffffull ? 0xffffffffull : sc->host.tex.size());   // words of texels + importance-map tables (read through L2, never staged)
+                    default: return 0; }
 }
 
 }  // extern "C"

@@ -19,6 +19,9 @@ timeout 900 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU
 echo "sq rc=$?" >> "$OUT/bench_sq.log"
 timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_sq2.log" 2>&1
 echo "sq2 rc=$?" >> "$OUT/bench_sq2.log"
+# (round 6) L2 hits and misses per kernel, a pass of its own: what the FETCH_SIZE excess of a scene with big tables is made of (bench.py roofline.l2)
+timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$OUT/pmc_tcc" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_tcc.log" 2>&1
+echo "tcc rc=$?" >> "$OUT/bench_tcc.log"
 cd "$ROOT" && python3 tools/summarize_profile.py "$OUT" "$TAG" > "$OUT/summary.log" 2>&1
 find "$OUT" -name "*.csv" -size +20M -delete
 ls -R "$OUT" | head -50

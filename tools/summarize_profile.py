@@ -109,10 +109,19 @@ def main():
             dv["valu_instructions_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
         derived[k] = dv
     summary["derived"] = derived
+    # L2 (TCC) hits and misses per launch, when the pass was made: <tag>_tcc.txt, one line per kernel (the format of profiles/r5z_C4_tcc.txt, which bench.py reads)
+    tcc = defaultdict(lambda: defaultdict(list))
+    for r in counter_rows(os.path.join(out_dir, "pmc_tcc")):
+        tcc[short(r.get("Kernel_Name", ""))][r.get("Counter_Name")].append(float(r["Counter_Value"]))
+    tcc_lines = ["%s %s launches %d" % (k, {c: "%.4g" % (sum(v) / len(v)) for c, v in sorted(cs.items())}, max(len(v) for v in cs.values())) for k, cs in sorted(tcc.items()) if k.startswith("k_")]
+    if tcc_lines:
+        with open(os.path.join(prof, "%s_tcc.txt" % tag), "w") as fh:
+            fh.write("\n".join(tcc_lines) + "\n")
+        summary["TCC"] = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in tcc.items() if k.startswith("k_")}
     with open(os.path.join(prof, "%s_summary.json" % tag), "w") as fh:
         json.dump(summary, fh, indent=1, sort_keys=True)
     # a copy next to the raw output: gpurun brings gpurun_out/ back, not profiles/
-    for name in ("%s_summary.json" % tag, "%s_kernel_stats.csv" % tag, "%s_rocprofv3_kernel_stats.csv" % tag):
+    for name in ("%s_summary.json" % tag, "%s_kernel_stats.csv" % tag, "%s_rocprofv3_kernel_stats.csv" % tag, "%s_tcc.txt" % tag):
         try:
             with open(os.path.join(prof, name)) as src, open(os.path.join(out_dir, name), "w") as dst:
                 dst.write(src.read())
