@@ -54,6 +54,7 @@
 // Wave-level helpers: device code sees the wave, the host emulation one lane at a time.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PT_KEEP_BRANCH() asm volatile("" ::: "memory")   /* inside a rarely taken block: the compiler must not turn it into selects */
+#define PT_KEEP_BRANCH_NOFENCE() asm volatile("")   /* the same for a block that IS taken often: no memory clobber, the loads and stores around it schedule freely */
 #define PT_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
 #define PT_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))  /* a value every lane of the wave holds */
 #define PT_WAVE_ACTIVE(host_value) ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)))  /* the lanes that execute this line */
@@ -64,6 +65,7 @@
 #define PT_WAVE_READ(x, lane) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (int)(lane)))   /* lane's value of a 32-bit x, in every lane (a scalar) */
 #else
 #define PT_KEEP_BRANCH()
+#define PT_KEEP_BRANCH_NOFENCE()
 #define PT_WAVE_ANY(x) (x)
 #define PT_UNIFORM(x) (x)
 #define PT_WAVE_ACTIVE(host_value) (host_value)
@@ -140,10 +142,22 @@ struct SceneView {
     // environment sample starts with a search of these 12 KB.  marg_words = 0: not staged (every other kernel, the host): the texture memory's copy is read.
     const float* marg = nullptr;
     uint32_t marg_words = 0u, marg_base = 0u, marg_guide = 0u;   // floats staged from tex + marg_base; the guide's offset inside them (0: none)
+    // PT_FLAG_CONVEX of the header (round 6: some instance carries a convex-body certificate), read ONCE per kernel from the blob's HBM copy through the kernel's scalar
+    // argument (stage_scene): a scalar register, so that the certificate code in hit_record and stage_shade stands behind scalar branches and costs a scene without
+    // certificates no vector instruction (measured before this: 2-4 % of the vertex kernels of every such scene, profiles/r6g_ab_r5.txt).
+    uint32_t certs = 0u;
 };
 #define PT_SCENE_NO_XF 1u   /* no instance carries a transform (the Cornell box): instance_local_ray and the hit record's way back are identities */
 #define PT_SCENE_NO_LIGHTS 2u /* the light list is empty (an environment is the only emitter: hdri_test): no light vertex, no light to sample */
+#define PT_SCENE_NO_CERTS 4u  /* no instance carries a convex-body certificate (PT_FLAG_CONVEX clear): the certificate code of hit_record and stage_shade is compiled out.  Every
+                                 vertex-kernel form has this bit but the two made for such scenes (k_shade NO_ENV / FULL "with certificates", pt_kern_shade.hip) — measured: with the
+                                 code present behind scalar branches the fused and lean forms still lost 2 % (registers, layout: profiles/r6h_ab_r5b.txt) */
 PT_HD uint32_t bu(const SceneView& s, uint32_t off) { return s.w[off]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+PT_HD bool scene_has_certificates(const SceneView& s) { return !(s.lacks & PT_SCENE_NO_CERTS) && s.certs != 0u; }
+#else
+PT_HD bool scene_has_certificates(const SceneView& s) { return (s.w[21] & 2048u) != 0u; }   // (the host emulation builds its views by hand: PT_HDR_FLAGS & PT_FLAG_CONVEX, pt_blob.h)
+#endif
 PT_HD float bf(const SceneView& s, uint32_t off) { return pt_u2f(s.w[off]); }
 PT_HD F4 bf4(const SceneView& s, uint32_t off) { return *reinterpret_cast<const F4*>(s.w + off); }
 PT_HD F3 bf3(const SceneView& s, uint32_t off) { return f3(bf(s, off), bf(s, off + 1), bf(s, off + 2)); }
@@ -709,7 +723,8 @@ PT_HD void hit_record(const SceneView& s, F3 o, F3 d, uint32_t best_inst, uint32
         uint32_t mesh = bu(s, inst + PT_INST_MESH);
         uint32_t normal_off = bu(s, mesh + PT_MESH_NORMAL_OFF);
         F4 q0 = mf4(s, triw), q1 = mf4(s, triw + 4), q2 = mf4(s, triw + 8);
-        {   // (bit 0: the whole face; bit 1: its inside, away from the edges by PT_TRI_INNER_BARY)
+        if (scene_has_certificates(s)) {   // (a scalar branch; bit 0: the whole face; bit 1: its inside, away from the edges by PT_TRI_INNER_BARY)
+            PT_KEEP_BRANCH_NOFENCE();
             const uint32_t tf = pt_f2u(q2.w);
             const bool inner = __builtin_fminf(__builtin_fminf(bh.b0, bh.b1), bh.b2) >= PT_TRI_INNER_BARY;
             in_safe = ((tf | (inner ? tf >> 1 : 0u)) & 1u) << 31;

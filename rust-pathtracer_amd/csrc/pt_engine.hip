@@ -337,8 +337,11 @@ pt_status render_impl(pt_scene* sc, const pt_render_desc* rdp, float* d_film, hi
         has_ggx = has_ggx || kind == PT_MATERIAL_GGX || kind == PT_MATERIAL_PASSTHROUGH;
     }
     // (a PassthroughFilter lives in the forms that hold the GGX code)
+    // (a scene with a convex-body certificate takes at least the NO_ENV form: the lean and fused forms are compiled without the certificate code, pt_kern_shade.hip)
+    const bool certs = !rd.medium_aware && (sc->host.blob[PT_HDR_FLAGS] & PT_FLAG_CONVEX) != 0u;
     const int shade_form = rd.medium_aware ? PT_SHADE_MEDIUM
-                         : (env_prob != 0.0f || tn.shade_form == 2) ? PT_SHADE_FULL : (has_ggx || tn.shade_form == 1) ? PT_SHADE_NO_ENV : PT_SHADE_LEAN;
+                         : (env_prob != 0.0f || tn.shade_form == 2) ? PT_SHADE_FULL : (has_ggx || certs || tn.shade_form == 1) ? PT_SHADE_NO_ENV : PT_SHADE_LEAN;
+    cfg.certs = certs;
     // k_shade that traces its own segments: exists for the pure sweep form of a fully staged, transform-free scene shaded by the lean form.
     // Measured (profiles/r3_experiments.md): C2 +4..5 % (4370 us against 2095 + 2490..2640 per bounce); with four wavelengths per path it
     // lost in round 3 (C5 996 against 1093 Msamples/s: the traversal then ran at the three waves per SIMD the wide vertex code left) and wins since round 4 (below).

@@ -14,12 +14,16 @@ namespace ptk {
 #define PT_GO(K, ...) go(c, K, __VA_ARGS__)
 #define PT_BY_MODE(K, ...) do { if (c.lds_mode == PT_LDS_ALL) PT_GO(K(PT_LDS_ALL), __VA_ARGS__); else if (c.lds_mode == PT_LDS_CORE) PT_GO(K(PT_LDS_CORE), __VA_ARGS__); \
                                 else PT_GO(K(PT_LDS_NONE), __VA_ARGS__); } while (0)
-#define K_SHADE_L(M) k_shade<M, PT_SHADE_NL, PT_SHADE_LEAN>
-#define K_SHADE_LX(M) k_shade<M, PT_SHADE_NL, PT_SHADE_LEAN, PT_SCENE_NO_XF>
-#define K_SHADE_FUSED k_shade<PT_LDS_ALL, PT_SHADE_NL, PT_SHADE_LEAN, PT_SCENE_NO_XF, PT_TRAV_SWEEP>
-#define K_SHADE_N(M) k_shade<M, PT_SHADE_NL, PT_SHADE_NO_ENV>
-#define K_SHADE_F(M) k_shade<M, PT_SHADE_NL, PT_SHADE_FULL>
-#define K_SHADE_FE(M) k_shade<M, PT_SHADE_NL, PT_SHADE_FULL, PT_SCENE_NO_LIGHTS>
+// (PT_SCENE_NO_CERTS: the certificate code compiled out — every form but the two a scene WITH a convex-body certificate takes, K_SHADE_NC / K_SHADE_FC: the engine gives such a
+// scene at least the NO_ENV form, never the lean, fused or light-free ones)
+#define K_SHADE_L(M) k_shade<M, PT_SHADE_NL, PT_SHADE_LEAN, PT_SCENE_NO_CERTS>
+#define K_SHADE_LX(M) k_shade<M, PT_SHADE_NL, PT_SHADE_LEAN, PT_SCENE_NO_XF | PT_SCENE_NO_CERTS>
+#define K_SHADE_FUSED k_shade<PT_LDS_ALL, PT_SHADE_NL, PT_SHADE_LEAN, PT_SCENE_NO_XF | PT_SCENE_NO_CERTS, PT_TRAV_SWEEP>
+#define K_SHADE_N(M) k_shade<M, PT_SHADE_NL, PT_SHADE_NO_ENV, PT_SCENE_NO_CERTS>
+#define K_SHADE_F(M) k_shade<M, PT_SHADE_NL, PT_SHADE_FULL, PT_SCENE_NO_CERTS>
+#define K_SHADE_FE(M) k_shade<M, PT_SHADE_NL, PT_SHADE_FULL, PT_SCENE_NO_LIGHTS | PT_SCENE_NO_CERTS>
+#define K_SHADE_NC(M) k_shade<M, PT_SHADE_NL, PT_SHADE_NO_ENV>
+#define K_SHADE_FC(M) k_shade<M, PT_SHADE_NL, PT_SHADE_FULL>
 #define PT_ARGS sc.blob, sc.blob_words, sc.tex, rp, bounce, pixels, paths_in, hits, paths_out, shadow, energy, seg_cap, count_in, count_out, shadow_count, block_stats
 #define PT_ARGS_FWD sc, rp, bounce, pixels, paths_in, hits, paths_out, shadow, energy, seg_cap, count_in, count_out, shadow_count, block_stats
 #define PT_CAT2(a, b) a##b
@@ -39,9 +43,11 @@ void PT_PARTNAME(launch_shade_nl)(const LaunchCfg& c, int form, const SceneArgs&
 #define PT_GO_D(K, ...) go(d, K, __VA_ARGS__)
 #define PT_BY_MODE_D(K, ...) do { if (c.lds_mode == PT_LDS_ALL) PT_GO_D(K(PT_LDS_ALL), __VA_ARGS__); else if (c.lds_mode == PT_LDS_CORE) PT_GO_D(K(PT_LDS_CORE), __VA_ARGS__); \
                                   else PT_GO_D(K(PT_LDS_NONE), __VA_ARGS__); } while (0)
-        if ((c.lacks & PT_SCENE_NO_LIGHTS) && PT_SHADE_NL == 1) PT_BY_MODE_D(K_SHADE_FE, PT_ARGS);   // (an environment is the scene's only emitter)
+        if (c.certs) PT_BY_MODE_D(K_SHADE_FC, PT_ARGS);
+        else if ((c.lacks & PT_SCENE_NO_LIGHTS) && PT_SHADE_NL == 1) PT_BY_MODE_D(K_SHADE_FE, PT_ARGS);   // (an environment is the scene's only emitter)
         else PT_BY_MODE_D(K_SHADE_F, PT_ARGS);
     }
+    else if (c.certs) PT_BY_MODE(K_SHADE_NC, PT_ARGS);
     else PT_BY_MODE(K_SHADE_N, PT_ARGS);
 #else
     (void)form;
@@ -59,7 +65,7 @@ hipError_t PT_PARTNAME(allow_lds_shade_nl)(uint32_t bytes) {
     allow(reinterpret_cast<const void*>(K_SHADE_FUSED));
     PT_ALLOW_MODES(K_SHADE_L); PT_ALLOW_MODES(K_SHADE_LX);
 #else
-    PT_ALLOW_MODES(K_SHADE_N); PT_ALLOW_MODES(K_SHADE_F);
+    PT_ALLOW_MODES(K_SHADE_N); PT_ALLOW_MODES(K_SHADE_F); PT_ALLOW_MODES(K_SHADE_NC); PT_ALLOW_MODES(K_SHADE_FC);
 #if PT_SHADE_NL == 1
     PT_ALLOW_MODES(K_SHADE_FE);
     PT_ALLOW_MODES(K_SHADE_M);
@@ -78,6 +84,7 @@ void launch_shade(const LaunchCfg& c, int nl, int form, const SceneArgs& sc, con
     const bool lean = form == PT_SHADE_LEAN;
     // (round-5 advisor) k_generate writes the camera vertex' lean record when rp.camera_record is set; k_shade's forms read it at bounce 0 by their FORM alone (the uniform branch
     // on rp.camera_record costs the NO_ENV form 7 %, pt_kernels.h).  The two sides must agree: a FORM / camera_record pairing that does not would read nine stale words per path.
+    if (c.certs && form == PT_SHADE_LEAN) { fprintf(stderr, "launch_shade: a scene with convex-body certificates takes the NO_ENV or FULL form\n"); abort(); }
     if ((rp.camera_record != 0u) != (form != PT_SHADE_NO_ENV)) { fprintf(stderr, "launch_shade: form %d launched with camera_record = %u\n", form, rp.camera_record); abort(); }
     if (nl == 4) { if (lean) launch_shade_nl4_p0(c, form, PT_ARGS_FWD); else launch_shade_nl4_p1(c, form, PT_ARGS_FWD); }
     else if (lean) launch_shade_nl1_p0(c, form, PT_ARGS_FWD); else launch_shade_nl1_p1(c, form, PT_ARGS_FWD);

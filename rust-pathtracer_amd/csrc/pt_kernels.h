@@ -134,6 +134,7 @@ __device__ __forceinline__ SceneView stage_scene(const uint32_t* __restrict__ bl
     SceneView s;
     s.tex = tex;
     s.lacks = LACKS | PT_EXP_LACKS;
+    s.certs = blob[PT_HDR_FLAGS] & PT_FLAG_CONVEX;   // (a scalar load of a kernel argument's target: SceneView::certs)
     const uint32_t core_words = blob[PT_HDR_CORE_WORDS];
     if (USE_LDS != PT_LDS_NONE) {
         const uint32_t words = USE_LDS == PT_LDS_ALL ? blob_words : core_words;

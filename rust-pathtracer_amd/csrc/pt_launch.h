@@ -37,6 +37,7 @@ struct LaunchCfg { int grid; uint32_t lds_bytes; hipStream_t stream; int lds_mod
                    int park_block = 0, park_block_extend = 0;   // parked kernels (light-sample / closest-hit), static form, one wavelength: 512 or 1024 = workgroups of that many threads that stage the WHOLE blob
                    uint32_t park_blob_bytes = 0;   //   (this many bytes of LDS) whatever lds_mode says for the other kernels; 0 = workgroups of kBlock, lds_mode
                    bool live_lists = false;    // measurement builds (-DPT_EXPERIMENTS, PT_AMD_LIVE_LISTS=1): k_shadow's sweep forms list the rays that search per wave (k_shadow_live)
+                   bool certs = false;         // the scene holds a convex-body certificate (blob PT_FLAG_CONVEX): the vertex forms that carry the certificate code
                    uint32_t path_marks = 0;    // k_extend_parked: 1 + the instance a marked path segment cannot hit (blob PT_HDR_CONVEX_INST), 0 at bounce 0 and for scenes without one
                    bool fuse = false; };  // k_shade traces its own segments (pure sweep scenes, lean form, no transforms): no k_extend launch, no hit queue
 struct SceneArgs { const uint32_t* blob; uint32_t blob_words; const float* tex; uint32_t marg_bytes = 0; /* LDS the FULL vertex form takes behind the blob (marginal_lds_bytes) */ };

@@ -113,7 +113,8 @@ PT_HD PathVertexT<NL> load_path(const Queue& q, uint32_t i) {
     PathVertexT<NL> p;
     p.o = f3(qf(q, PS_OX, i), qf(q, PS_OY, i), qf(q, PS_OZ, i));
     p.d = f3(qf(q, PS_DX, i), qf(q, PS_DY, i), qf(q, PS_DZ, i));
-    p.beta[0] = qf(q, PS_BETA, i); p.lambda = qf(q, PS_LAMBDA, i); p.slot = qu(q, PS_SLOT, i); p.prev_pdf = pt_abs(qf(q, PS_PREV_PDF, i));   // (its sign is a mark for the closest-hit kernel: PT_HDR_CONVEX_INST)
+    p.beta[0] = qf(q, PS_BETA, i); p.lambda = qf(q, PS_LAMBDA, i); p.slot = qu(q, PS_SLOT, i); p.prev_pdf = qf(q, PS_PREV_PDF, i);   // (its SIGN is a mark for the closest-hit kernel, PT_HDR_CONVEX_INST: every reader below squares the value — the MIS weights of a light or
+                                                                                                                  // environment vertex — so the sign never reaches a result; taking the magnitude here cost the fused form an instruction it does not need)
     for (int k = 1; k < NL; ++k) p.beta[k] = qf(q, PS_FIELDS + k - 1, i);
     p.prev_n = f3(qf(q, PS_PNX, i), qf(q, PS_PNY, i), qf(q, PS_PNZ, i));
     p.prev_p = f3(qf(q, PS_PPX, i), qf(q, PS_PPY, i), qf(q, PS_PPZ, i));
@@ -263,7 +264,9 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     // (round 6) the vertex lies on an instance the host certified convex and closed (pt_blob.h PT_INST_CONVEX_*): its outward light-sample rays are marked
     // "cannot hit this instance again" (ShadeOutT::env_mask, bits 8.. and 16..), its inward light rays are dead here, and so is marked the path's next segment if it
     // leaves outward.  A scene without such an instance: one scalar test.
-    const uint32_t convex = (bu(s, PT_HDR_FLAGS) & PT_FLAG_CONVEX) ? bu(s, bu(s, PT_HDR_INSTANCE_OFF) + (hit.instance & ~PT_HIT_IN_SAFE) * PT_INST_WORDS + PT_INST_FLAGS) & (PT_INST_CONVEX_OUT | PT_INST_CONVEX_IN) : 0u;
+    const bool certs = scene_has_certificates(s);   // (wave-uniform, a scalar: everything the certificates add stands behind it)
+    uint32_t convex = 0u;
+    if (certs) { PT_KEEP_BRANCH_NOFENCE(); convex = bu(s, bu(s, PT_HDR_INSTANCE_OFF) + (hit.instance & ~PT_HIT_IN_SAFE) * PT_INST_WORDS + PT_INST_FLAGS) & (PT_INST_CONVEX_OUT | PT_INST_CONVEX_IN); }
     pt_f32x4 r = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples));
     float f, pdf; F3 wo;
     // (per-wavelength loops stay rolled, their arrays in registers: pl_get / pl_set, pt_device.h)
@@ -333,7 +336,8 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                             ray.factor[k] = pv.beta[k] * weight * rk * env_emission(s, ep, lam[k], ec[k]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
                         }
                         out.shadow_count += 1;
-                        if (convex != 0u) {
+                        if (certs && convex != 0u) {
+                            PT_KEEP_BRANCH_NOFENCE();
                             // An environment ray always LEAVES on the normal's side (local_wo.z > 0) but starts on the side of the WORLD z of its direction (pt.rs:256, a kept
                             // quirk): with direction.z < 0 it starts 1e-3 INSIDE a certified body and must cross its closed surface — any hit blocks an environment ray
                             // (pt.rs:300-330): dead here; with direction.z > 0 it starts outside and cannot hit the body again.
@@ -368,7 +372,8 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                         // (the microfacet evaluation is a big body: rolled; the Lambertian one a few instructions: the compiler's choice)
                         if (GGX) { PT_ROLLED for (int k = 1; k < NL; ++k) passenger(k); } else { for (int k = 1; k < NL; ++k) passenger(k); }
                         out.shadow_count += 1;
-                        if (convex != 0u) {
+                        if (certs && convex != 0u) {
+                            PT_KEEP_BRANCH_NOFENCE();
                             // inward from a certified body: the reference's closest hit is the body's own surface, or something inside it — no light (pt.rs:177-189): the sample adds 0
                             if ((convex & PT_INST_CONVEX_IN) && (hit.instance & PT_HIT_IN_SAFE) && bsdf_wo.z < 0.0f) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
                             if ((convex & PT_INST_CONVEX_OUT) && bsdf_wo.z > PT_CONVEX_OUT_COS) out.env_mask |= 0x100u << l;
@@ -387,7 +392,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                 }
                 sink(l, ray);
             }
-            if (out.env_mask & 0xff00u) out.env_mask |= hit.instance << 16;   // (PT_HIT_IN_SAFE falls off the top)   // (the instance the marked rays may skip; certified instances are numbered below 65536)
+            if (certs && (out.env_mask & 0xff00u)) out.env_mask |= hit.instance << 16;   // (PT_HIT_IN_SAFE falls off the top)   // (the instance the marked rays may skip; certified instances are numbered below 65536)
             out.has_item = true;
         }
     }
@@ -412,7 +417,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     out.next.prev_pdf = pdf_forward; out.next.prev_n = hit.n; out.next.prev_p = hit.p;
     // The next segment leaves the scene's one certified convex body outward (it starts 1e-3 outside the face it left, hit.n being that face's normal, and moves away): it
     // cannot hit that instance again.  Marked in the sign of the previous-pdf word — every reader takes its magnitude (load_path) — for the parked closest-hit kernel.
-    if ((convex & PT_INST_CONVEX_OUT) && wo.z > PT_CONVEX_OUT_COS && bu(s, PT_HDR_CONVEX_INST) == (hit.instance & ~PT_HIT_IN_SAFE) + 1u) out.next.prev_pdf = -pdf_forward;
+    if (certs && (convex & PT_INST_CONVEX_OUT) && wo.z > PT_CONVEX_OUT_COS && bu(s, PT_HDR_CONVEX_INST) == (hit.instance & ~PT_HIT_IN_SAFE) + 1u) out.next.prev_pdf = -pdf_forward;
     return out;
 }
 
@@ -699,7 +704,7 @@ PT_HD void stage_shadow_ray(const SceneView& s, LambdaOf&& lambda_of, FactorOf&&
 template <int NL, int TRAV = PT_TRAV_ANY, bool ENV = true>
 PT_HD void stage_shadow_item(const SceneView& s, uint32_t light_samples, const Queue& shadow, uint32_t item, float* energy, uint32_t energy_stride) {
     // (the pure sweep kernels' tables hold no walked mesh: a mark "cannot hit its instance again" — bit 8 + l, PT_INST_CONVEX_OUT — would save them a triangle leaf or two; not read there)
-    const bool marks = TRAV != PT_TRAV_SWEEP && (bu(s, PT_HDR_FLAGS) & PT_FLAG_CONVEX) != 0u;
+    const bool marks = TRAV != PT_TRAV_SWEEP && scene_has_certificates(s);
     uint32_t slot = qu(shadow, Layout<NL>::sh_slot, item), flags = (ENV || marks) ? qu(shadow, Layout<NL>::sh_flags, item) : 0u;
     float lambda0 = 0.0f, lc[NL];
     if (NL == 1) lambda0 = qf(shadow, Layout<NL>::sh_lambda, item);
