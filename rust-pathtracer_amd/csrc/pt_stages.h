@@ -265,8 +265,16 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     // "cannot hit this instance again" (ShadeOutT::env_mask, bits 8.. and 16..), its inward light rays are dead here, and so is marked the path's next segment if it
     // leaves outward.  A scene without such an instance: one scalar test.
     const bool certs = scene_has_certificates(s);   // (wave-uniform, a scalar: everything the certificates add stands behind it)
-    uint32_t convex = 0u;
-    if (certs) { PT_KEEP_BRANCH_NOFENCE(); convex = bu(s, bu(s, PT_HDR_INSTANCE_OFF) + (hit.instance & ~PT_HIT_IN_SAFE) * PT_INST_WORDS + PT_INST_FLAGS) & (PT_INST_CONVEX_OUT | PT_INST_CONVEX_IN); }
+    // (three lane predicates made here, so that neither the instance's flag word nor the hit's instance word stays alive through the sampling code below: the NO_ENV form
+    // runs at its register cap)
+    bool cv_out = false, cv_in = false, cv_path = false;   // outward rays are marked; inward light rays from this face are dead; the path's next segment is marked too
+    if (certs) {
+        PT_KEEP_BRANCH_NOFENCE();
+        const uint32_t cf = bu(s, bu(s, PT_HDR_INSTANCE_OFF) + (hit.instance & ~PT_HIT_IN_SAFE) * PT_INST_WORDS + PT_INST_FLAGS);
+        cv_out = (cf & PT_INST_CONVEX_OUT) != 0u;
+        cv_in = (cf & PT_INST_CONVEX_IN) != 0u && (hit.instance & PT_HIT_IN_SAFE) != 0u;
+        cv_path = cv_out && bu(s, PT_HDR_CONVEX_INST) == (hit.instance & ~PT_HIT_IN_SAFE) + 1u;
+    }
     pt_f32x4 r = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples));
     float f, pdf; F3 wo;
     // (per-wavelength loops stay rolled, their arrays in registers: pl_get / pl_set, pt_device.h)
@@ -336,13 +344,13 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                             ray.factor[k] = pv.beta[k] * weight * rk * env_emission(s, ep, lam[k], ec[k]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
                         }
                         out.shadow_count += 1;
-                        if (certs && convex != 0u) {
+                        if (certs && (cv_out | cv_in)) {
                             PT_KEEP_BRANCH_NOFENCE();
                             // An environment ray always LEAVES on the normal's side (local_wo.z > 0) but starts on the side of the WORLD z of its direction (pt.rs:256, a kept
                             // quirk): with direction.z < 0 it starts 1e-3 INSIDE a certified body and must cross its closed surface — any hit blocks an environment ray
                             // (pt.rs:300-330): dead here; with direction.z > 0 it starts outside and cannot hit the body again.
-                            if ((convex & PT_INST_CONVEX_IN) && (hit.instance & PT_HIT_IN_SAFE) && direction.z < 0.0f) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
-                            if ((convex & PT_INST_CONVEX_OUT) && local_wo.z > PT_CONVEX_OUT_COS && direction.z > 0.0f) out.env_mask |= 0x100u << l;
+                            if (cv_in && direction.z < 0.0f) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
+                            if (cv_out && local_wo.z > PT_CONVEX_OUT_COS && direction.z > 0.0f) out.env_mask |= 0x100u << l;
                         }
                         // a contribution of exactly 0 adds 0 whether or not the ray is occluded: not traced
                         if (ray_is_live<NL>(ray)) out.env_mask |= 1u << l;
@@ -372,11 +380,11 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                         // (the microfacet evaluation is a big body: rolled; the Lambertian one a few instructions: the compiler's choice)
                         if (GGX) { PT_ROLLED for (int k = 1; k < NL; ++k) passenger(k); } else { for (int k = 1; k < NL; ++k) passenger(k); }
                         out.shadow_count += 1;
-                        if (certs && convex != 0u) {
+                        if (certs && (cv_out | cv_in)) {
                             PT_KEEP_BRANCH_NOFENCE();
                             // inward from a certified body: the reference's closest hit is the body's own surface, or something inside it — no light (pt.rs:177-189): the sample adds 0
-                            if ((convex & PT_INST_CONVEX_IN) && (hit.instance & PT_HIT_IN_SAFE) && bsdf_wo.z < 0.0f) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
-                            if ((convex & PT_INST_CONVEX_OUT) && bsdf_wo.z > PT_CONVEX_OUT_COS) out.env_mask |= 0x100u << l;
+                            if (cv_in && bsdf_wo.z < 0.0f) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
+                            if (cv_out && bsdf_wo.z > PT_CONVEX_OUT_COS) out.env_mask |= 0x100u << l;
                         }
                         // The scene's ONLY light: a ray that misses it meets no light at all — the light-sample kernel's search bound (shadow_light_bound:
                         // nearest_light_hit = +inf) would drop it untraced, with the same test on the same ray.  Found here it makes the ray dead, and an
@@ -417,7 +425,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     out.next.prev_pdf = pdf_forward; out.next.prev_n = hit.n; out.next.prev_p = hit.p;
     // The next segment leaves the scene's one certified convex body outward (it starts 1e-3 outside the face it left, hit.n being that face's normal, and moves away): it
     // cannot hit that instance again.  Marked in the sign of the previous-pdf word — every reader takes its magnitude (load_path) — for the parked closest-hit kernel.
-    if (certs && (convex & PT_INST_CONVEX_OUT) && wo.z > PT_CONVEX_OUT_COS && bu(s, PT_HDR_CONVEX_INST) == (hit.instance & ~PT_HIT_IN_SAFE) + 1u) out.next.prev_pdf = -pdf_forward;
+    if (certs && cv_path && wo.z > PT_CONVEX_OUT_COS) out.next.prev_pdf = -pdf_forward;
     return out;
 }
 
