@@ -31,11 +31,17 @@
 
 // Triangle: three float4: (p0.xyz, bits(material)), (p1.xyz, 0), (p2.xyz, 0); optional normals: three float4.
 #define PT_TRI_WORDS 12
-#define PT_TRI_FLAGS 11       /* the third vertex' spare word: bit 0 = PT_TRI_IN_SAFE */
-#define PT_TRI_IN_SAFE 1u     /* the host certified (PT_INST_CONVEX_IN, below): a point of this face moved 1e-3 inward lies inside its closed convex body.  hit_record hands the bit on: */
-#define PT_TRI_IN_SAFE_INNER 2u /* ... certified for the points of the face whose barycentric coordinates are all >= PT_TRI_INNER_BARY (a face at a sharp edge: a strip along that edge is not safe) */
+#define PT_TRI_FLAGS 11       /* the third vertex' spare word: the face's part of its instance's convex-body certificate (PT_INST_CONVEX_*, below; 0 = none) */
+#define PT_TRI_IN_SAFE 1u     /* bit 0: a point of this face moved 1e-3 inward along any of the face's hit normals lies inside its closed convex body */
+#define PT_TRI_IN_SAFE_INNER 2u /* bit 1: ... certified for the points of the face whose barycentric coordinates are all >= PT_TRI_INNER_BARY (a face at a sharp edge: a strip along that edge is not safe) */
 #define PT_TRI_INNER_BARY 0.015625f
-#define PT_HIT_IN_SAFE 0x80000000u /* ... in the hit's instance word (Hit::instance; instances are numbered below 2^31) */
+#define PT_TRI_OUT_SHIFT 2    /* bits 2..16: the face's OUTWARD threshold in units of 2^-15, rounded up: 0.02 + the sine of the largest angle between the face's own normal and its hit
+                                 normals (vertex normals: a smooth-shaded mesh).  A ray that leaves a point of this face with n . d above it — n the hit normal — moves away from
+                                 the face's plane, behind which the whole body lies.  0 = no such claim for this face. */
+/* hit_record hands both on in the hit's instance word (Hit::instance) — only in a scene with a certificate, whose instances are numbered below 65536: */
+#define PT_HIT_IN_SAFE 0x80000000u   /* bit 31: this hit may take the inward claim (PT_TRI_IN_SAFE, or _INNER and its barycentrics allow it) */
+#define PT_HIT_OUT_SHIFT 16          /* bits 16..30: the face's outward threshold */
+#define PT_HIT_INDEX_MASK 0xffffu
 
 // Mesh record (8 words): node_off (float4 units... all offsets are WORD offsets), node_count, tri_off, normal_off
 // (0 = none), face_count, leaf list, group boxes
@@ -84,17 +90,14 @@
 #define PT_INST_FLAGS 1      /* bit0 has_transform, bit1 two_sided, bits 2-3 axis, bits 4-5 PT_INST_CONVEX_* */
 /* A mesh instance the host has CERTIFIED (pt_scene_host.cpp convex_certificate, f64, in world space) as a closed convex body whose hit normals are its faces' own
    (round 6; stage_shade, pt_stages.h).  A light-sample ray is made at a surface point p, offset by 1e-3 along the hit normal to the side it leaves on (pt.rs:176, 256):
-   CONVEX_OUT: a ray that leaves such a body OUTWARD (n . d > 0.02) starts 1e-3 outside the supporting plane of the face it left and moves away from it — the whole body lies
-     behind that plane (to within 2e-4, checked), so no triangle of this instance can be hit: the light-sample kernel drops the instance from the ray's leaf mask
-     (PT_INST_SWEEP_MASK) — no park, no walk.  (Optional: a traversal form that ignores the mark walks the mesh and finds nothing.)
+   CONVEX_OUT: a ray that leaves such a body OUTWARD (n . d above the face's threshold, PT_TRI_OUT_SHIFT) starts outside the supporting plane of the face it left and moves
+     away from it — the whole body lies behind that plane (to within 2e-4, checked), so no triangle of this instance can be hit: the light-sample kernel drops the instance from
+     the ray's leaf mask (PT_INST_SWEEP_MASK) — no park, no walk.  (Optional: a traversal form that ignores the mark walks the mesh and finds nothing.)
    CONVEX_IN: a ray that leaves it INWARD starts at least 1e-4 inside every face plane (checked for every face), and every light lies outside the body's box (checked): the
      ray must cross the closed surface before it can meet a light, the reference's closest hit is that crossing (or something else in front of it — in any case no light,
      pt.rs:177-189), the sample contributes 0: the ray is dead where it is made (counted, never traced). */
 #define PT_INST_CONVEX_OUT 16u
 #define PT_INST_CONVEX_IN 32u
-#ifndef PT_CONVEX_OUT_COS
-#define PT_CONVEX_OUT_COS 0.02f
-#endif   /* an outward ray is marked only above this cosine to the hit normal (the normal may differ from the face's by 0.0045 rad, checked) */
 #define PT_INST_MATERIAL 2   /* packed MaterialId or PT_MATERIAL_NONE */
 #define PT_INST_MESH 3       /* word offset of the mesh record */
 #define PT_INST_ORIGIN 4     /* 3 floats */

@@ -158,6 +158,8 @@ PT_HD bool scene_has_certificates(const SceneView& s) { return !(s.lacks & PT_SC
 #else
 PT_HD bool scene_has_certificates(const SceneView& s) { return (s.w[21] & 2048u) != 0u; }   // (the host emulation builds its views by hand: PT_HDR_FLAGS & PT_FLAG_CONVEX, pt_blob.h)
 #endif
+// The instance a hit lies on: in a scene with certificates the hit's instance word also carries its face's claims (hit_record)
+PT_HD uint32_t hit_instance_index(const SceneView& s, uint32_t instance_word) { return scene_has_certificates(s) ? instance_word & PT_HIT_INDEX_MASK : instance_word; }
 PT_HD float bf(const SceneView& s, uint32_t off) { return pt_u2f(s.w[off]); }
 PT_HD F4 bf4(const SceneView& s, uint32_t off) { return *reinterpret_cast<const F4*>(s.w + off); }
 PT_HD F3 bf3(const SceneView& s, uint32_t off) { return f3(bf(s, off), bf(s, off + 1), bf(s, off + 2)); }
@@ -718,16 +720,16 @@ PT_HD void hit_record(const SceneView& s, F3 o, F3 d, uint32_t best_inst, uint32
     F3 lo, ld;
     instance_local_ray(s, inst, o, d, &lo, &ld);
     Hit h;
-    uint32_t in_safe = 0u;   // PT_HIT_IN_SAFE: the triangle's PT_TRI_IN_SAFE (pt_blob.h), handed to the vertex code in the instance word
+    uint32_t in_safe = 0u;   // PT_HIT_IN_SAFE and the outward threshold of the face (pt_blob.h PT_TRI_FLAGS), handed to the vertex code in the instance word
     if (triw != 0u) {
         uint32_t mesh = bu(s, inst + PT_INST_MESH);
         uint32_t normal_off = bu(s, mesh + PT_MESH_NORMAL_OFF);
         F4 q0 = mf4(s, triw), q1 = mf4(s, triw + 4), q2 = mf4(s, triw + 8);
-        if (scene_has_certificates(s)) {   // (a scalar branch; bit 0: the whole face; bit 1: its inside, away from the edges by PT_TRI_INNER_BARY)
-            PT_KEEP_BRANCH_NOFENCE();
+        if (scene_has_certificates(s)) {   // (a scalar branch.  The face's flag word, pt_blob.h PT_TRI_FLAGS: bit 0 the inward claim for the whole face, bit 1 for its inside,
+            PT_KEEP_BRANCH_NOFENCE();      // away from the edges by PT_TRI_INNER_BARY; bits 2.. the outward threshold, handed on as it is)
             const uint32_t tf = pt_f2u(q2.w);
             const bool inner = __builtin_fminf(__builtin_fminf(bh.b0, bh.b1), bh.b2) >= PT_TRI_INNER_BARY;
-            in_safe = ((tf | (inner ? tf >> 1 : 0u)) & 1u) << 31;
+            in_safe = ((tf | (inner ? tf >> 1 : 0u)) & 1u) << 31 | ((tf >> PT_TRI_OUT_SHIFT) & 0x7fffu) << PT_HIT_OUT_SHIFT;
         }
         F3 p0 = f3(q0.x, q0.y, q0.z), p1 = f3(q1.x, q1.y, q1.z), p2 = f3(q2.x, q2.y, q2.z);
         if (normal_off != 0) {

@@ -1257,7 +1257,7 @@ __global__ void __launch_bounds__(kBlock) k_probe_intersect(const uint32_t* __re
         if (ok) {
             r.valid = 1; r.t = h.t; r.point[0] = h.p.x; r.point[1] = h.p.y; r.point[2] = h.p.z;
             r.normal[0] = h.n.x; r.normal[1] = h.n.y; r.normal[2] = h.n.z; r.uv[0] = h.u; r.uv[1] = h.v;
-            r.material = h.material; r.instance = h.instance & ~PT_HIT_IN_SAFE;
+            r.material = h.material; r.instance = hit_instance_index(s, h.instance);
         }
         out[i] = r;
     }

@@ -202,13 +202,15 @@ static bool mesh_is_closed(const float* V, uint32_t vertex_count, const uint32_t
 // as the engine sees them (f32 positions through the instance's f32 forward matrix) and the normals as hit_record makes them (vertex normals, or the face normal, through
 // the transposed reverse matrix):
 //   closed (above); at most 4096 faces; world coordinates within 64 (one f32 ulp there is 4e-6: a hundred times below the margins);
-//   every face's hit normals lie within 0.0045 rad of the face's own outward normal;
-//   CONVEX, OUT: no vertex lies more than 2e-4 above any face's plane (the gem's facets are planar to 1e-4) and some vertex lies 1e-2 below it;
+//   every face's hit normals lie on its outward side; per face: the largest angle delta between the face's own normal and its hit normals (0 for a flat-shaded face), faces
+//   with cos(delta) < 0.5 taking no claim;
+//   CONVEX: no vertex lies more than 2e-4 above any face's plane (the gem's facets are planar to 1e-4) and some vertex lies 1e-2 below it;
+//   OUT, face by face: the threshold 0.02 + sin(delta) a direction's cosine to the hit normal must exceed (PT_TRI_OUT_SHIFT);
 //   IN, face by face: the face's three corners, moved 1e-3 against the face normal (where pt.rs:176 puts an inward ray's origin), lie at least 1e-4 below EVERY face plane —
 //   so does every point of the face (the planes' half-spaces are convex); such a face's triangle carries PT_TRI_IN_SAFE and hit_record hands it on in the hit's instance word;
 //   and the world box of every light-tagged instance is disjoint from this instance's (both widened by 1e-3).
 static uint32_t convex_certificate(const float* V, uint32_t vertex_count, const uint32_t* ix, uint32_t faces, const float* N, const pt_instance& in, const Box& wbox,
-                                   const std::vector<Box>& light_boxes, std::vector<char>* in_safe) {
+                                   const std::vector<Box>& light_boxes, std::vector<uint32_t>* face_flags) {
     if (faces < 4 || faces > 4096 || vertex_count > 3 * 4096) return 0u;
     auto world = [&](const float* p) {
         if (!in.has_transform) return D3{p[0], p[1], p[2]};
@@ -226,8 +228,8 @@ static uint32_t convex_certificate(const float* V, uint32_t vertex_count, const 
         W[v] = world(V + 3 * v);
         if (!(std::fabs(W[v].x) <= 64.0 && std::fabs(W[v].y) <= 64.0 && std::fabs(W[v].z) <= 64.0)) return 0u;
     }
-    const double kCos = 0.99999, kSlack = 2e-4, kThick = 1e-2, kOffset = 1e-3, kInside = 1e-4;
-    std::vector<D3> fn(faces); std::vector<double> fd(faces);
+    const double kSlack = 2e-4, kThick = 1e-2, kOffset = 1e-3, kInside = 1e-4, kMinCos = 0.5;
+    std::vector<D3> fn(faces); std::vector<double> fd(faces), fsin(faces), fcos(faces);   // per face: the plane, and the sine / cosine of the largest angle between its normal and its hit normals
     for (uint32_t f = 0; f < faces; ++f) {
         const D3 a = W[ix[3 * f]], b = W[ix[3 * f + 1]], c = W[ix[3 * f + 2]];
         D3 g = dcross(dsub(b, a), dsub(c, a));
@@ -240,24 +242,43 @@ static uint32_t convex_certificate(const float* V, uint32_t vertex_count, const 
         else { const D3 p0 = d3(V + 3 * ix[3 * f]), p1 = d3(V + 3 * ix[3 * f + 1]), p2 = d3(V + 3 * ix[3 * f + 2]); local[count++] = dcross(dsub(p0, p2), dsub(p1, p2)); }
         const D3 first = world_normal(local[0]);
         if (ddot(first, g) < 0) g = D3{-g.x, -g.y, -g.z};   // (the face's plane normal on the side the hit normals point to: it must turn out to be the OUTWARD side, below)
-        for (int k = 0; k < count; ++k) if (!(ddot(world_normal(local[k]), g) >= kCos)) return 0u;
-        fn[f] = g; fd[f] = ddot(g, a);
+        // a hit's normal is normalize(sum b_i n_i), b_i >= 0: no farther from the face's normal than the farthest n_i (a flat-shaded face: the face's own, rounding apart)
+        double cmin = 1.0;
+        for (int k = 0; k < count; ++k) cmin = std::fmin(cmin, ddot(world_normal(local[k]), g));
+        if (!(cmin > 0.0)) return 0u;                        // a hit normal on the other side of its own face
+        fn[f] = g; fd[f] = ddot(g, a); fcos[f] = cmin; fsin[f] = std::sqrt(std::fmax(0.0, 1.0 - cmin * cmin));
     }
     for (uint32_t f = 0; f < faces; ++f) {
         double hi = -INFINITY, lo = INFINITY;
         for (uint32_t v = 0; v < vertex_count; ++v) { const double sd = ddot(fn[f], W[v]) - fd[f]; hi = std::fmax(hi, sd); lo = std::fmin(lo, sd); }
         if (!(hi <= kSlack && lo <= -kThick)) return 0u;   // not convex (or the normals point inward, or the body is a sliver)
     }
+    // OUT, face by face: the origin p + 1e-3 n (n a hit normal) lies 1e-3 cos(delta) above the face's plane — at least 5e-4: above the slack — and a direction with
+    // n . d > sin(delta) has angle(d, face normal) <= angle(d, n) + delta < 90 degrees: it moves away from the plane.  The threshold rides in the triangle's flag word in
+    // units of 2^-15, rounded up, + 0.02 (rounding of n . d in f32, of a normal's length: 1e-6).
+    face_flags->assign(faces, 0u);
+    bool any_out = false;
+    for (uint32_t f = 0; f < faces; ++f) {
+        if (!(fcos[f] >= kMinCos)) continue;
+        const uint32_t tq = (uint32_t)std::ceil((fsin[f] + 0.02) * 32768.0);
+        if (tq == 0u || tq > 32767u) continue;
+        (*face_flags)[f] = tq << PT_TRI_OUT_SHIFT;
+        any_out = true;
+    }
+    if (!any_out) return 0u;
     uint32_t flags = PT_INST_CONVEX_OUT;
     // IN is a property of a FACE (a sharp edge — the brilliant cut has 64 faces at edges of 97 degrees — puts the corner of one face, moved inward, OUTSIDE the next
     // face's plane): `in_safe[f]`, and the instance takes the flag when any of its faces is safe
+    // (the origin is p - 1e-3 n with n within delta of the face's normal: it lies within 1e-3 * 2 sin(delta / 2) of p - 1e-3 n_f, so that point must clear every plane by that much more)
     bool inside_ok = false;
-    in_safe->assign(faces, 0);   // (0 none, 1 the whole face, 2 its inside only)
+    std::vector<char> in_safe(faces, 0);   // (0 none, 1 the whole face, 2 its inside only)
     for (uint32_t f = 0; f < faces; ++f) {
+        if (!(fcos[f] >= kMinCos)) continue;
+        const double need = kInside + kOffset * std::sqrt(std::fmax(0.0, 2.0 - 2.0 * fcos[f]));   // 2 sin(delta / 2) = sqrt(2 - 2 cos delta)
         bool ok = true;
         for (int k = 0; k < 3 && ok; ++k) {
             const D3 p = W[ix[3 * f + k]], q = D3{p.x - kOffset * fn[f].x, p.y - kOffset * fn[f].y, p.z - kOffset * fn[f].z};
-            for (uint32_t g = 0; g < faces; ++g) if (!(ddot(fn[g], q) - fd[g] <= -kInside)) { ok = false; break; }
+            for (uint32_t g = 0; g < faces; ++g) if (!(ddot(fn[g], q) - fd[g] <= -need)) { ok = false; break; }
         }
         if (!ok) {   // the face without a strip of PT_TRI_INNER_BARY along its edges (hit_record tests the hit's barycentric coordinates): the corners of that inner triangle
             ok = true;
@@ -266,10 +287,10 @@ static uint32_t convex_certificate(const float* V, uint32_t vertex_count, const 
                 const D3 a = W[ix[3 * f + k]], b = W[ix[3 * f + (k + 1) % 3]], c = W[ix[3 * f + (k + 2) % 3]];
                 const D3 p = D3{(1 - 2 * e) * a.x + e * b.x + e * c.x, (1 - 2 * e) * a.y + e * b.y + e * c.y, (1 - 2 * e) * a.z + e * b.z + e * c.z};
                 const D3 q = D3{p.x - kOffset * fn[f].x, p.y - kOffset * fn[f].y, p.z - kOffset * fn[f].z};
-                for (uint32_t g = 0; g < faces; ++g) if (!(ddot(fn[g], q) - fd[g] <= -kInside)) { ok = false; break; }
+                for (uint32_t g = 0; g < faces; ++g) if (!(ddot(fn[g], q) - fd[g] <= -need)) { ok = false; break; }
             }
-            (*in_safe)[f] = ok ? 2 : 0;
-        } else (*in_safe)[f] = 1;
+            in_safe[f] = ok ? 2 : 0;
+        } else in_safe[f] = 1;
         inside_ok = inside_ok || ok;
     }
     bool lights_clear = true;
@@ -278,7 +299,10 @@ static uint32_t convex_certificate(const float* V, uint32_t vertex_count, const 
         for (int k = 0; k < 3; ++k) apart = apart || (double)lb.mn[k] - 1e-3 > (double)wbox.mx[k] + 1e-3 || (double)lb.mx[k] + 1e-3 < (double)wbox.mn[k] - 1e-3;
         lights_clear = lights_clear && apart;
     }
-    if (inside_ok && lights_clear) flags |= PT_INST_CONVEX_IN;
+    if (inside_ok && lights_clear) {
+        flags |= PT_INST_CONVEX_IN;
+        for (uint32_t f = 0; f < faces; ++f) (*face_flags)[f] |= in_safe[f] == 1 ? PT_TRI_IN_SAFE : (in_safe[f] == 2 ? PT_TRI_IN_SAFE_INNER : 0u);
+    }
     return flags;
 }
 
@@ -759,9 +783,9 @@ static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::st
         std::vector<Box> light_boxes;
         for (uint32_t i = 0; i < d.instance_count; ++i) if (lightish(i)) light_boxes.push_back(ibox[i]);
         std::vector<int> mesh_closed(d.mesh_count, -1);
-        std::vector<std::vector<char>> mesh_in_safe(d.mesh_count);
+        std::vector<std::vector<uint32_t>> mesh_face_flags(d.mesh_count);
         bool any = false;
-        for (uint32_t i = 0; i < d.instance_count && i < 65536u; ++i) {   // (the mark a ray carries names its instance in 16 bits)
+        for (uint32_t i = 0; i < d.instance_count && d.instance_count <= 65536u; ++i) {   // (a hit's instance word and the mark a ray carries name the instance in 16 bits: a scene of more instances takes no certificate)
             const pt_instance& in = d.instances[i];
             if (in.kind != PT_SHAPE_MESH || lightish(i)) continue;
             const pt_mesh& m = d.meshes[in.mesh];
@@ -770,14 +794,18 @@ static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::st
             if (m.face_count > 4096) continue;
             if (mesh_closed[in.mesh] < 0) mesh_closed[in.mesh] = mesh_is_closed(V, m.vertex_count, ix, m.face_count, mesh_box[in.mesh]) ? 1 : 0;
             if (!mesh_closed[in.mesh]) continue;
-            std::vector<char> in_safe;
-            uint32_t cf = convex_certificate(V, m.vertex_count, ix, m.face_count, m.normal_offset >= 0 ? d.normals + 3 * (size_t)m.normal_offset : nullptr, in, ibox[i], light_boxes, &in_safe);
-            if (cf & PT_INST_CONVEX_IN) {
-                // a triangle is IN-safe when it is for EVERY instance of its mesh that takes the flag (the mark rides in the mesh's triangle record)
-                if (mesh_in_safe[in.mesh].empty()) mesh_in_safe[in.mesh] = in_safe;
-                else for (uint32_t f = 0; f < m.face_count; ++f) {   // (0 none, 1 the whole face, 2 its inside only: the weaker of the two claims)
-                    const char a = mesh_in_safe[in.mesh][f], b = in_safe[f];
-                    mesh_in_safe[in.mesh][f] = (a == 0 || b == 0) ? 0 : (a == 1 && b == 1 ? 1 : 2);
+            std::vector<uint32_t> face_flags;
+            uint32_t cf = convex_certificate(V, m.vertex_count, ix, m.face_count, m.normal_offset >= 0 ? d.normals + 3 * (size_t)m.normal_offset : nullptr, in, ibox[i], light_boxes, &face_flags);
+            if (cf != 0u) {
+                // The faces' flag words ride in the MESH's triangle records: with several certified instances of one mesh a face keeps the weaker of their claims (the larger
+                // outward threshold — 0, "none", being the largest —, the weaker inward flag: whole face > inside only > none).
+                std::vector<uint32_t>& mf = mesh_face_flags[in.mesh];
+                if (mf.empty()) mf = face_flags;
+                else for (uint32_t f = 0; f < m.face_count; ++f) {
+                    const uint32_t ta = mf[f] >> PT_TRI_OUT_SHIFT, tb = face_flags[f] >> PT_TRI_OUT_SHIFT, t = (ta == 0u || tb == 0u) ? 0u : (ta > tb ? ta : tb);
+                    const uint32_t ia = mf[f] & 3u, ib = face_flags[f] & 3u;
+                    const uint32_t in_bits = (ia == 0u || ib == 0u) ? 0u : ((ia == PT_TRI_IN_SAFE && ib == PT_TRI_IN_SAFE) ? PT_TRI_IN_SAFE : PT_TRI_IN_SAFE_INNER);
+                    mf[f] = t << PT_TRI_OUT_SHIFT | in_bits;
                 }
             }
             if (getenv("PT_AMD_HOST_VERBOSE")) fprintf(stderr, "instance %u: mesh %d, convex certificate %s%s\n", i, in.mesh, (cf & PT_INST_CONVEX_OUT) ? "OUT " : "none", (cf & PT_INST_CONVEX_IN) ? "IN" : "");
@@ -790,14 +818,13 @@ static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::st
             for (uint32_t i = 0; i < d.instance_count; ++i) if (w[w[PT_HDR_INSTANCE_OFF] + i * PT_INST_WORDS + PT_INST_FLAGS] & PT_INST_CONVEX_OUT) { ++count; which = i; }
             w[PT_HDR_CONVEX_INST] = count == 1 ? which + 1u : 0u;
         }
-        for (uint32_t mi = 0; mi < d.mesh_count; ++mi) {   // PT_TRI_IN_SAFE into the triangle records, and into their permuted copies
-            if (mesh_in_safe[mi].empty()) continue;
+        for (uint32_t mi = 0; mi < d.mesh_count; ++mi) {   // the faces' flag words (PT_TRI_FLAGS) into the triangle records, and into their permuted copies
+            if (mesh_face_flags[mi].empty()) continue;
             const uint32_t tri_off = w[mesh_off[mi] + PT_MESH_TRI_OFF];
             for (uint32_t f = 0; f < d.meshes[mi].face_count; ++f) {
-                if (!mesh_in_safe[mi][f]) continue;
-                const uint32_t bit = mesh_in_safe[mi][f] == 1 ? PT_TRI_IN_SAFE : PT_TRI_IN_SAFE_INNER;
-                md[tri_off + (size_t)f * PT_TRI_WORDS + PT_TRI_FLAGS] |= bit;
-                if (mesh_perm0[mi] != 0u) { md[tri_off + mesh_perm0[mi] + (size_t)f * PT_TRI_WORDS + PT_TRI_FLAGS] |= bit; md[tri_off + mesh_perm1[mi] + (size_t)f * PT_TRI_WORDS + PT_TRI_FLAGS] |= bit; }
+                const uint32_t word = mesh_face_flags[mi][f];
+                md[tri_off + (size_t)f * PT_TRI_WORDS + PT_TRI_FLAGS] = word;
+                if (mesh_perm0[mi] != 0u) { md[tri_off + mesh_perm0[mi] + (size_t)f * PT_TRI_WORDS + PT_TRI_FLAGS] = word; md[tri_off + mesh_perm1[mi] + (size_t)f * PT_TRI_WORDS + PT_TRI_FLAGS] = word; }
             }
         }
     }

@@ -268,12 +268,15 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     // (three lane predicates made here, so that neither the instance's flag word nor the hit's instance word stays alive through the sampling code below: the NO_ENV form
     // runs at its register cap)
     bool cv_out = false, cv_in = false, cv_path = false;   // outward rays are marked; inward light rays from this face are dead; the path's next segment is marked too
+    float cv_tau = 2.0f;                                    // the face's outward threshold: a direction's cosine to the hit normal must exceed it
     if (certs) {
         PT_KEEP_BRANCH_NOFENCE();
-        const uint32_t cf = bu(s, bu(s, PT_HDR_INSTANCE_OFF) + (hit.instance & ~PT_HIT_IN_SAFE) * PT_INST_WORDS + PT_INST_FLAGS);
-        cv_out = (cf & PT_INST_CONVEX_OUT) != 0u;
+        const uint32_t id = hit.instance & PT_HIT_INDEX_MASK, tq = (hit.instance >> PT_HIT_OUT_SHIFT) & 0x7fffu;
+        const uint32_t cf = bu(s, bu(s, PT_HDR_INSTANCE_OFF) + id * PT_INST_WORDS + PT_INST_FLAGS);
+        cv_out = (cf & PT_INST_CONVEX_OUT) != 0u && tq != 0u;
+        cv_tau = (float)tq * (1.0f / 32768.0f);
         cv_in = (cf & PT_INST_CONVEX_IN) != 0u && (hit.instance & PT_HIT_IN_SAFE) != 0u;
-        cv_path = cv_out && bu(s, PT_HDR_CONVEX_INST) == (hit.instance & ~PT_HIT_IN_SAFE) + 1u;
+        cv_path = cv_out && bu(s, PT_HDR_CONVEX_INST) == id + 1u;
     }
     pt_f32x4 r = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples));
     float f, pdf; F3 wo;
@@ -297,7 +300,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                 out.add_energy = true;
             } else if (!rp.only_direct) {
                 F3 nee_dir = normalize(sub(hit.p, pv.prev_p));
-                uint32_t inst = bu(s, PT_HDR_INSTANCE_OFF) + (hit.instance & ~PT_HIT_IN_SAFE) * PT_INST_WORDS;
+                uint32_t inst = bu(s, PT_HDR_INSTANCE_OFF) + hit_instance_index(s, hit.instance) * PT_INST_WORDS;
                 float pdfh = light_psa_pdf(s, inst, dot(pv.prev_n, nee_dir), dot(hit.n, nee_dir), pv.prev_p, hit.p);
                 float a = pv.prev_pdf;
                 float weight = (a * a) / (a * a + pdfh * pdfh);
@@ -350,7 +353,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                             // quirk): with direction.z < 0 it starts 1e-3 INSIDE a certified body and must cross its closed surface — any hit blocks an environment ray
                             // (pt.rs:300-330): dead here; with direction.z > 0 it starts outside and cannot hit the body again.
                             if (cv_in && direction.z < 0.0f) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
-                            if (cv_out && local_wo.z > PT_CONVEX_OUT_COS && direction.z > 0.0f) out.env_mask |= 0x100u << l;
+                            if (cv_out && local_wo.z > cv_tau && direction.z > 0.0f) out.env_mask |= 0x100u << l;
                         }
                         // a contribution of exactly 0 adds 0 whether or not the ray is occluded: not traced
                         if (ray_is_live<NL>(ray)) out.env_mask |= 1u << l;
@@ -384,7 +387,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                             PT_KEEP_BRANCH_NOFENCE();
                             // inward from a certified body: the reference's closest hit is the body's own surface, or something inside it — no light (pt.rs:177-189): the sample adds 0
                             if (cv_in && bsdf_wo.z < 0.0f) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
-                            if (cv_out && bsdf_wo.z > PT_CONVEX_OUT_COS) out.env_mask |= 0x100u << l;
+                            if (cv_out && bsdf_wo.z > cv_tau) out.env_mask |= 0x100u << l;
                         }
                         // The scene's ONLY light: a ray that misses it meets no light at all — the light-sample kernel's search bound (shadow_light_bound:
                         // nearest_light_hit = +inf) would drop it untraced, with the same test on the same ray.  Found here it makes the ray dead, and an
@@ -400,7 +403,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                 }
                 sink(l, ray);
             }
-            if (certs && (out.env_mask & 0xff00u)) out.env_mask |= hit.instance << 16;   // (PT_HIT_IN_SAFE falls off the top)   // (the instance the marked rays may skip; certified instances are numbered below 65536)
+            if (certs && (out.env_mask & 0xff00u)) out.env_mask |= hit.instance << 16;   // (the hit's face claims fall off the top: the instance's index is its low 16 bits)   // (the instance the marked rays may skip; certified instances are numbered below 65536)
             out.has_item = true;
         }
     }
@@ -425,7 +428,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     out.next.prev_pdf = pdf_forward; out.next.prev_n = hit.n; out.next.prev_p = hit.p;
     // The next segment leaves the scene's one certified convex body outward (it starts 1e-3 outside the face it left, hit.n being that face's normal, and moves away): it
     // cannot hit that instance again.  Marked in the sign of the previous-pdf word — every reader takes its magnitude (load_path) — for the parked closest-hit kernel.
-    if (certs && cv_path && wo.z > PT_CONVEX_OUT_COS) out.next.prev_pdf = -pdf_forward;
+    if (certs && cv_path && wo.z > cv_tau) out.next.prev_pdf = -pdf_forward;
     return out;
 }
 

@@ -198,7 +198,7 @@ pt_status ptemu_intersect(pt_scene* sc, size_t n, const float* o, const float* d
         Hit h; pt_hit r; std::memset(&r, 0, sizeof(r));
         if (world_hit(s, f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), &h)) {
             r.valid = 1; r.t = h.t; r.point[0] = h.p.x; r.point[1] = h.p.y; r.point[2] = h.p.z; r.normal[0] = h.n.x; r.normal[1] = h.n.y; r.normal[2] = h.n.z;
-            r.uv[0] = h.u; r.uv[1] = h.v; r.material = h.material; r.instance = h.instance & ~PT_HIT_IN_SAFE;
+            r.uv[0] = h.u; r.uv[1] = h.v; r.material = h.material; r.instance = hit_instance_index(s, h.instance);
         }
         hits[i] = r;
     }

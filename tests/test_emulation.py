@@ -280,7 +280,12 @@ def test_convex_certificates(emu, pkg):
     pm, fm, nm, _ = pkg.scene._npz_mesh("monkey")
     assert flags(_mesh_scene(pkg, pm, fm))[0] == 0
     pg, fg, ng, _ = pkg.scene._npz_mesh("gem")
-    assert ng is not None and flags(_mesh_scene(pkg, pg, fg, ng))[0] == 0               # smooth shading normals
+    assert ng is not None and flags(_mesh_scene(pkg, pg, fg, ng))[0] == 0               # (the 64-triangle gem is not convex)
+    # a SMOOTH-shaded convex body (the reference tree's prism.obj: 836 triangles, vertex normals up to 47 degrees off their faces): certified face by face, each face with
+    # its own outward threshold (0.02 + the sine of its normals' largest deviation) and an inward margin that grows with it
+    pp, fp, npr, _ = pkg.scene._npz_mesh("prism")
+    got = flags(_mesh_scene(pkg, pp, fp, npr, transform=pkg.scene.transform_from_data(scale=(3.0, 3.0, 3.0))))
+    assert got[0] == (OUT | IN) and got[1] + got[2] > 600, got
     # the certificate's geometry once more, with arithmetic of its own (numpy, f64), for the gem as the scene places it: convex within the slack, the safe faces really safe
     pd, fd, nd, _ = pkg.scene._npz_mesh("brilliant_diamond")
     P = pd.astype(np.float64) * 0.5 + np.array([0.0, 0.0, -0.7]); F = np.asarray(fd)
@@ -293,7 +298,7 @@ def test_convex_certificates(emu, pkg):
     assert int(inside.sum()) == 238
 
 
-@pytest.mark.parametrize("case", ["cornell_gem", "cornell_gem_hero", "cube", "cube_transformed", "cube_lamp_close", "cube_sky", "cube_sky_hero"])
+@pytest.mark.parametrize("case", ["cornell_gem", "cornell_gem_hero", "cube", "cube_transformed", "cube_lamp_close", "cube_sky", "cube_sky_hero", "prism_smooth", "prism_smooth_sky"])
 def test_convex_certificates_change_nothing(emu, oracle, pkg, monkeypatch, case):
     """A light-sample ray that leaves a certified body inward is dead where it is made, one that leaves it outward drops the body from its leaf mask (stage_shade,
     world_hit_sweep): with the certificates ignored (PTEMU_NO_CONVEX = pt_tuning's PT_TUNE_NO_CONVEX) the film and the counters are the same bit for bit — and both are the oracle's."""
@@ -302,7 +307,10 @@ def test_convex_certificates_change_nothing(emu, oracle, pkg, monkeypatch, case)
     b = {"cornell_gem": pkg.scene.cornell_gem, "cornell_gem_hero": pkg.scene.cornell_gem, "cube": lambda: _mesh_scene(pkg, p, f),
          "cube_transformed": lambda: _mesh_scene(pkg, p, f, transform=xf), "cube_lamp_close": lambda: _mesh_scene(pkg, p, f, light_at=(0.5, 0.5, 1.2)),
          # (environment rays: they leave on the normal's side but START on the side of their direction's WORLD z — pt.rs:256 —, so half of them start inside the body)
-         "cube_sky": lambda: _mesh_scene(pkg, p, f, transform=xf, sky=True), "cube_sky_hero": lambda: _mesh_scene(pkg, p, f, sky=True)}[case]()
+         "cube_sky": lambda: _mesh_scene(pkg, p, f, transform=xf, sky=True), "cube_sky_hero": lambda: _mesh_scene(pkg, p, f, sky=True),
+         # (a smooth-shaded convex body: the hit normals are up to 47 degrees off their faces, every face has its own outward threshold)
+         "prism_smooth": lambda: _mesh_scene(pkg, *pkg.scene._npz_mesh("prism")[:3], transform=pkg.scene.transform_from_data(scale=(3.0, 3.0, 3.0), rotate=[((0, 0, 1), 90.0)])),
+         "prism_smooth_sky": lambda: _mesh_scene(pkg, *pkg.scene._npz_mesh("prism")[:3], transform=pkg.scene.transform_from_data(scale=(2.0, 3.0, 2.5)), sky=True)}[case]()
     rd = pkg.api.render_desc(48, 40, 8, 10, light_samples=3, seed=12, hero_wavelengths=4 if case.endswith("hero") else 1)
     with_cert, pw = emu.create_scene(b).render(rd)
     monkeypatch.setenv("PTEMU_NO_CONVEX", "1")

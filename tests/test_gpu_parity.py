@@ -410,7 +410,7 @@ def test_forms_without_transforms_change_nothing(engine, pkg, monkeypatch, scene
         parity_suite.assert_hits_equal(hits, other.intersect(o, d))
 
 
-@pytest.mark.parametrize("case", ["cornell_gem", "cornell_gem_hero", "fuzz_49682", "fuzz_100003", "cube_sky"])
+@pytest.mark.parametrize("case", ["cornell_gem", "cornell_gem_hero", "fuzz_49682", "fuzz_100003", "cube_sky", "prism_smooth_sky", "test_prism_small"])
 def test_convex_certificates_change_nothing(engine, oracle, pkg, monkeypatch, case):
     """Round 6 (pt_blob.h PT_INST_CONVEX_*): a light-sample ray that leaves a certified closed convex mesh instance inward is dead where it is made, one that leaves it outward
     drops the instance from its leaf mask and never parks at it.  With the certificates ignored (PT_AMD_NO_CONVEX = PT_TUNE_NO_CONVEX) — and through the other traversal
@@ -423,6 +423,10 @@ def test_convex_certificates_change_nothing(engine, oracle, pkg, monkeypatch, ca
     elif case == "cube_sky":
         p, f = _cube()
         b = _mesh_scene(pkg, p, f, transform=pkg.scene.transform_from_data(scale=(0.5, 2.0, 1.25), rotate=[((0.3, 1.0, 0.2), 37.0)], translate=(0.2, -0.4, 0.1)), sky=True)
+    elif case == "prism_smooth_sky":   # (a smooth-shaded convex body: every face with its own outward threshold)
+        b = _mesh_scene(pkg, *pkg.scene._npz_mesh("prism")[:3], transform=pkg.scene.transform_from_data(scale=(2.0, 3.0, 2.5)), sky=True)
+    elif case == "test_prism_small":   # (G1's scene: the reference tree's test_prism.toml)
+        b = pkg.scene.test_prism_small()
     else:
         b = pkg.scene.cornell_gem()
     rd = pkg.api.render_desc(192, 160, 10, 10, light_samples=3, seed=12, hero_wavelengths=4 if case.endswith("hero") else 1)
