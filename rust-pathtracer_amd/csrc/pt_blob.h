@@ -226,6 +226,10 @@
 #define PT_SHADE_LDS_BUDGET 40960u
 #define PT_MARG_LDS_BYTES(rows, has_guide) ((2u * (rows) + ((has_guide) ? (rows) + 3u : 0u)) * 4u + 16u)
 #define PT_MARG_LDS_MAX_ROWS 2048u   /* importance maps of at most this many rows have their marginal tables staged in LDS by the FULL vertex form (24 KB + guide) */
+#define PT_SPHERE_CULL_K 5.4e-3   /* 3.5 x 1.55e-3: see beyond_sphere, pt_device.h */
+#define PT_HDR_TOP_MARGIN 70         /* word offset of one float per top-level BVH node (0 = none; round 6): 0 for a node that holds no sphere — it is culled by the closest hit
+                                       with the plain margin —, else the constant part of the margin a node that holds spheres is culled with (PT_SPHERE_CULL_K, pt_device.h:
+                                       3.5 r_max + K (diagonal + r_max), r_max the largest radius below the node); +inf = never (a transformed sphere below it) */
 #define PT_HDR_CONVEX_INST 69        /* 1 + the id of the scene's ONLY instance with PT_INST_CONVEX_OUT (0: none, or several): a path segment that leaves it outward carries a mark
                                        — the sign of its record's previous-pdf word, which every reader squares — and the parked closest-hit kernel drops the instance from that
                                        ray's leaf mask, as the light-sample kernel does for marked light rays */

@@ -405,6 +405,18 @@ PT_HD bool aabb_hit(F4 a, F4 b, const RayPrep& rp, float* entry) {
 // (History: every box had margin 1e-5 until the GPU soak met a grazing ray — fuzz seed 101684, a light-sample ray bounded by its own
 // sphere light culled the light; spheres then got a margin of 2e-3, which the second case above still defeats.)
 PT_HD bool beyond(float entry, float closest, float base) { return entry > closest * 1.00001f + base; }
+// ... and since round 6 a box that holds UNTRANSFORMED spheres is culled too, by a margin CERTIFIED from the quadratic's error (the round-5 verdict's item 3; before, a scene of
+// many sphere lights — test_bokeh.toml — walked its top-level tree without any culling by the closest hit).  With u = 2^-24, D the distance from the ray's origin to a sphere's
+// centre, r its radius: oc . d, oc . oc - r^2 and the discriminant b^2 - a c are each right to a few u (D + r)^2, so the computed root t solves a quadratic whose value AT t is
+// off by F <= 40 u (D + r)^2: the computed hit point lies within eta = sqrt(F) = 1.55e-3 (D + r) of the sphere, hence inside the sphere's box grown by eta.  A ray the reference
+// tests against the sphere enters the sphere's own box (its box test passed), and between entering the grown box and the box itself it travels at most the grown box's diagonal,
+// 2 sqrt(3) (r + eta) <= 3.5 (r + eta): computed t >= box entry - 3.5 (r + eta).  An ancestor's entry is no later, and D <= entry + diagonal of the ancestor's box.  So a node
+// whose entry distance exceeds the closest hit by m0 + K entry, m0 = 3.5 r_max + K (diagonal + r_max), K = 3.5 x 1.55e-3 = 5.4e-3 (PT_SPHERE_CULL_K), holds no sphere whose
+// computed hit would be accepted.  m0 comes from the host per top-level node (pt_blob.h PT_HDR_TOP_MARGIN): 0 = no sphere below the node (the plain rule), +inf = never.
+// (scene.big_sphere_light — radius 20 000 — gets m0 = 70 000: never culled in practice, as before.)
+PT_HD bool beyond_sphere(float entry, float closest, float base, float m0) {
+    return (m0 != 0.0f ? entry * (1.0f - (float)PT_SPHERE_CULL_K) : entry) > closest * 1.00001f + base + m0;
+}
 
 // The filtered test classifies: hit, miss, or too close to call (the caller settles it with aabb_hit_exact).  It requires rp.fast and
 // no zero direction component.  A box of zero thickness along some axis (known per box on the host) takes the per-axis form of aabb_hit
@@ -1556,6 +1568,9 @@ PT_HD void top_walk_init(SweepState& st) { sweep_state_init(st, 1ull); }
 #ifndef PT_TOP_WHILE_WHILE
 #define PT_TOP_WHILE_WHILE 1
 #endif
+#ifndef PT_SPHERE_CULL
+#define PT_SPHERE_CULL 1   /* top-level nodes that hold untransformed spheres are culled by the closest hit with their certified margin (beyond_sphere, round 6); 0 = never, as before */
+#endif
 // (the mesh walk's early end of the inner loop LOSES here — G2F k_shadow_parked 2313 us with the single loop, 2267 as a pure while-while, 3200 at 16 and 3660 at 32: a lane that
 // leaves the search early only waits through the others' leaf tests and searches on — so the kernels pass 0; the emulation's one lane passes 1 and leaves at every step)
 #define PT_TOP_SEARCH_BELOW 0u
@@ -1570,6 +1585,7 @@ PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, S
     const uint32_t flags = bu(s, PT_HDR_FLAGS);
     const uint32_t top_off = bu(s, PT_HDR_TOP_NODE_OFF), top_count = bu(s, PT_HDR_TOP_NODE_COUNT), inst_off = bu(s, PT_HDR_INSTANCE_OFF);
     const bool cull_top = (flags & (PT_FLAG_NO_TOP_CULL | PT_FLAG_NO_CULL)) == 0;
+    const uint32_t margin_off = PT_SPHERE_CULL ? bu(s, PT_HDR_TOP_MARGIN) : 0u;   // (the sphere nodes' certified margins, beyond_sphere; 0: the scene holds no sphere)
     RayPrep wr = ray_prepare(o, d);
     if (flags & PT_FLAG_EXACT_SLAB) wr.fast = false;
     const bool wr_quick = wr.fast && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f;
@@ -1584,7 +1600,9 @@ PT_HD bool top_walk_run(const SceneView& s, F3 o, F3 d, float bound, int stop, S
             const F4 a = bf4(s, top_off + i * PT_NODE_WORDS), b = bf4(s, top_off + i * PT_NODE_WORDS + 4);
             const uint32_t exit_i = PT_NODE_EXIT(pt_f2u(a.w)), shape = pt_f2u(b.w);
             float entry;
-            const bool box = walk_box(a, b, wr, wr_quick, &entry) & !(cull_top & !(pt_f2u(a.w) & PT_NODE_NO_CULL) & beyond(entry, __builtin_fminf(st.closest, bound), wr.base));
+            bool box = walk_box(a, b, wr, wr_quick, &entry);
+            if (margin_off != 0u) box = box & !(cull_top & beyond_sphere(entry, __builtin_fminf(st.closest, bound), wr.base, bf(s, margin_off + i)));   // (wave-uniform: a scene with spheres)
+            else box = box & !(cull_top & !(pt_f2u(a.w) & PT_NODE_NO_CULL) & beyond(entry, __builtin_fminf(st.closest, bound), wr.base));
             const bool inner = shape == PT_NODE_INNER;
             pend_node = i;
             pending = (!inner & box) ? shape : NONE;
@@ -1917,6 +1935,7 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
     bool cr_quick = wr_quick;  // (of the ray the current level is walked with)
     uint32_t node_off = top_off, node_count = top_count, i = 0;
     uint32_t level_inst = NONE, top_resume = 0, tri_off = 0;
+    const uint32_t walk_margin_off = PT_SPHERE_CULL ? bu(s, PT_HDR_TOP_MARGIN) : 0u;
     // `bound`: the caller knows that no hit beyond it can matter (shadow rays: the nearest light hit, see
     // stage_shadow_light); `limit` = min(closest, bound) drives the culling, `closest` keeps the reference's meaning.
     float closest = PT_INF, limit = bound;
@@ -1944,7 +1963,11 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
             F4 a = *reinterpret_cast<const F4*>(nb), b = *reinterpret_cast<const F4*>(nb + 4);
             uint32_t exit_i = PT_NODE_EXIT(pt_f2u(a.w)), shape = pt_f2u(b.w);
             float entry;
-            bool box = aabb_hit_node(a, b, cr, cr_quick, &entry) && !((level_inst != NONE ? cull_mesh : cull_top) && !(pt_f2u(a.w) & PT_NODE_NO_CULL) && beyond(entry, limit, cr.base));
+            bool box = aabb_hit_node(a, b, cr, cr_quick, &entry);
+            if (box) {
+                if (level_inst == NONE && walk_margin_off != 0u) box = !(cull_top && beyond_sphere(entry, limit, cr.base, bf(s, walk_margin_off + i)));   // (a top-level node of a scene with spheres)
+                else box = !((level_inst != NONE ? cull_mesh : cull_top) && !(pt_f2u(a.w) & PT_NODE_NO_CULL) && beyond(entry, limit, cr.base));
+            }
             if (shape == PT_NODE_INNER) { i = box ? i + 1 : exit_i; }
             else { i = exit_i; if (box) pending = shape; }
         }

@@ -42,6 +42,8 @@ struct BvhBuilder {
     uint32_t base;               // first node's index (0)
     std::vector<uint32_t> leaf_of_shape;  // node index of each shape's leaf
     std::vector<char> no_cull;            // per shape (empty = none): its computed hit distance may fall short of its box (spheres): nodes holding one are never culled
+    std::vector<float> sphere_radius;     // per shape (empty = none): > 0 an untransformed sphere's radius, +inf a sphere that must never be culled (transformed), 0 no sphere
+    std::vector<float> node_margin;       // out, per node (filled when sphere_radius is given): pt_blob.h PT_HDR_TOP_MARGIN
     explicit BvhBuilder(const std::vector<Box>& s, std::vector<uint32_t>& o) : shapes(s), out(o), base(0), leaf_of_shape(s.size(), 0) {}
 
     uint32_t node_count() const { return (uint32_t)(out.size() / PT_NODE_WORDS); }
@@ -100,6 +102,14 @@ struct BvhBuilder {
         out[at + 0] = fbits(b.mn[0]); out[at + 1] = fbits(b.mn[1]); out[at + 2] = fbits(b.mn[2]); out[at + 3] = node_count() | (flat ? PT_NODE_FLAT : 0u) | (keep ? PT_NODE_NO_CULL : 0u) | code << 27;
         out[at + 4] = fbits(b.mx[0]); out[at + 5] = fbits(b.mx[1]); out[at + 6] = fbits(b.mx[2]); out[at + 7] = leaf ? idx[0] : PT_NODE_INNER;
         if (leaf) leaf_of_shape[idx[0]] = (uint32_t)(at / PT_NODE_WORDS);
+        if (!sphere_radius.empty()) {
+            float rmax = 0.0f;
+            for (uint32_t i : idx) rmax = std::fmax(rmax, sphere_radius[i]);
+            const double dx = (double)b.mx[0] - b.mn[0], dy = (double)b.mx[1] - b.mn[1], dz = (double)b.mx[2] - b.mn[2];
+            const double m0 = 3.5 * rmax + PT_SPHERE_CULL_K * (std::sqrt(dx * dx + dy * dy + dz * dz) + rmax);
+            if (node_margin.size() < at / PT_NODE_WORDS + 1) node_margin.resize(at / PT_NODE_WORDS + 1, 0.0f);
+            node_margin[at / PT_NODE_WORDS] = rmax > 0.0f ? std::nextafterf((float)m0, INFINITY) : 0.0f;   // (inf stays inf)
+        }
     }
 
     void build() {
@@ -836,11 +846,24 @@ static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::st
         std::vector<uint32_t> nodes; BvhBuilder bb(ibox, nodes);
         bb.no_cull.assign(d.instance_count, 0);
         for (uint32_t i = 0; i < d.instance_count; ++i) bb.no_cull[i] = d.instances[i].kind == PT_SHAPE_SPHERE;
+        bb.sphere_radius.assign(d.instance_count, 0.0f);
+        for (uint32_t i = 0; i < d.instance_count; ++i)
+            if (d.instances[i].kind == PT_SHAPE_SPHERE) bb.sphere_radius[i] = d.instances[i].has_transform ? INFINITY : d.instances[i].radius;
         bb.build();
         w[PT_HDR_TOP_NODE_OFF] = (uint32_t)w.size(); w[PT_HDR_TOP_NODE_COUNT] = (uint32_t)(nodes.size() / PT_NODE_WORDS);
         uint32_t top = (uint32_t)w.size();
         w.insert(w.end(), nodes.begin(), nodes.end());
         pad16(w);
+        {   // PT_HDR_TOP_MARGIN: the sphere nodes' culling margins, one float per top-level node
+            bool any = false;
+            for (float m : bb.node_margin) any = any || m != 0.0f;
+            if (any) {
+                bb.node_margin.resize(nodes.size() / PT_NODE_WORDS, 0.0f);
+                w[PT_HDR_TOP_MARGIN] = (uint32_t)w.size();
+                for (float m : bb.node_margin) w.push_back(fbits(m));
+                pad16(w);
+            }
+        }
         w[PT_HDR_LIGHT_OFF] = (uint32_t)w.size(); w[PT_HDR_LIGHT_COUNT] = (uint32_t)lights.size();
         w.insert(w.end(), lights.begin(), lights.end());
         pad16(w);
