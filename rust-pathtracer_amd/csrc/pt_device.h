@@ -1569,7 +1569,10 @@ PT_HD void top_walk_init(SweepState& st) { sweep_state_init(st, 1ull); }
 #define PT_TOP_WHILE_WHILE 1
 #endif
 #ifndef PT_SPHERE_CULL
-#define PT_SPHERE_CULL 1   /* top-level nodes that hold untransformed spheres are culled by the closest hit with their certified margin (beyond_sphere, round 6); 0 = never, as before */
+#define PT_SPHERE_CULL 0   /* 1: top-level nodes that hold untransformed spheres are culled by the closest hit with their certified margin (beyond_sphere, round 6).  Built, bit-identical
+                              (4000 fuzz scenes of the many-sphere-lights class), and measured SLOWER on G2F — k_shadow_parked<TOP> 2171 -> 2219 us, k_extend_parked<TOP> 615 -> 655: a
+                              pre-order walk seldom holds a near hit when it reaches the far boxes, and the margin (3.5 r + 0.5 % of the distance) is wide against lights a tenth of a
+                              unit apart (profiles/r6l_ab_sphere.txt).  0 = such nodes are never culled, as before. */
 #endif
 // (the mesh walk's early end of the inner loop LOSES here — G2F k_shadow_parked 2313 us with the single loop, 2267 as a pure while-while, 3200 at 16 and 3660 at 32: a lane that
 // leaves the search early only waits through the others' leaf tests and searches on — so the kernels pass 0; the emulation's one lane passes 1 and leaves at every step)
