@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: one profile tag for every configuration (round-4 verdict, item 6) — tools/profile_gpu.sh for C2..C5, G1, G2, G2F on the kernels as they are,
 # the bench records of the same build (tools/bench_configs.sh) and the default bench.py record.  usage: tools/profile_all.sh <tag>
-TAG=${1:-r5z}
+TAG=${1:-r6z}
 mkdir -p gpurun_out
 p() { name=$1; shift; bash tools/profile_gpu.sh ${TAG}_$name "$@" > gpurun_out/${TAG}_prof_$name.log 2>&1; find gpurun_out/prof_${TAG}_$name -name "*.csv" -size +2M -delete; }
 p C2 --spp-per-step 120
