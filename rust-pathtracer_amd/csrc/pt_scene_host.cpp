@@ -793,6 +793,7 @@ static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::st
         std::vector<Box> light_boxes;
         for (uint32_t i = 0; i < d.instance_count; ++i) if (lightish(i)) light_boxes.push_back(ibox[i]);
         std::vector<int> mesh_closed(d.mesh_count, -1);
+        double work_left = 4e8;   // (the certificate is O(faces x vertices + faces^2) per INSTANCE: a scene of thousands of mesh instances certifies the first of them — about a second — and leaves the rest alone)
         std::vector<std::vector<uint32_t>> mesh_face_flags(d.mesh_count);
         bool any = false;
         for (uint32_t i = 0; i < d.instance_count && d.instance_count <= 65536u; ++i) {   // (a hit's instance word and the mark a ray carries name the instance in 16 bits: a scene of more instances takes no certificate)
@@ -804,6 +805,9 @@ static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::st
             if (m.face_count > 4096) continue;
             if (mesh_closed[in.mesh] < 0) mesh_closed[in.mesh] = mesh_is_closed(V, m.vertex_count, ix, m.face_count, mesh_box[in.mesh]) ? 1 : 0;
             if (!mesh_closed[in.mesh]) continue;
+            const double work = (double)m.face_count * m.vertex_count + 4.0 * (double)m.face_count * m.face_count;
+            if (work > work_left) continue;
+            work_left -= work;
             std::vector<uint32_t> face_flags;
             uint32_t cf = convex_certificate(V, m.vertex_count, ix, m.face_count, m.normal_offset >= 0 ? d.normals + 3 * (size_t)m.normal_offset : nullptr, in, ibox[i], light_boxes, &face_flags);
             if (cf != 0u) {
