@@ -19,3 +19,42 @@ def test_walk_stats_traces_the_mesh_walks():
         assert m, out[-2000:]
         assert int(m.group(1)) >= 128 and float(m.group(2)) > 3.0
     assert "while-while" in out and "evict" in out
+
+
+def test_light_walks_records_the_certificates_effect():
+    """tools/light_walks.py (round 6: the measurement behind the convex-body certificates) on C3's scene: with the certificates the light-sample rays that still walk the gem
+    no longer START on it going outward, and few start inside it; with them switched off (PTEMU_NO_CONVEX) most of the walks do."""
+    def run(env):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "light_walks.py"), "cornell_gem", "96", "2"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        m = re.search(r"light rays \(stop NONLIGHT\): (\d+) walks", r.stdout)
+        assert m, r.stdout[-2000:]
+        out = re.search(r"origin within 3e-3 outside\s+([0-9.]+) % of the walks", r.stdout[r.stdout.index("light rays"):])
+        return int(m.group(1)), (float(out.group(1)) if out else 0.0)
+    with_cert, outward_with = run({})
+    without, outward_without = run({"PTEMU_NO_CONVEX": "1"})
+    assert with_cert < 0.25 * without and outward_without > 40.0 and outward_with < 1.0, (with_cert, without, outward_with, outward_without)
+
+
+def test_profile_summary_writes_the_l2_counts_bench_reads(tmp_path):
+    """tools/summarize_profile.py turns a TCC_HIT_sum / TCC_MISS_sum pass into <tag>_tcc.txt, one line per kernel, and bench.py's roofline.l2 parses that line format."""
+    import ast
+    out = tmp_path / "prof"
+    (out / "pmc_tcc" / "x").mkdir(parents=True)
+    rows = ["Kernel_Name,Counter_Name,Counter_Value"]
+    for launch, (hit, miss) in enumerate(((100.0, 50.0), (300.0, 150.0))):
+        rows += ['"void ptk::k_shade<1, 1, 2, 0u, -1>(unsigned int const*)",TCC_HIT_sum,%r' % hit, '"void ptk::k_shade<1, 1, 2, 0u, -1>(unsigned int const*)",TCC_MISS_sum,%r' % miss]
+    (out / "pmc_tcc" / "x" / "1_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    tag = "zz_test_%d" % os.getpid()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_profile.py"), str(out), tag], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    made = [os.path.join(ROOT, "profiles", "%s_%s" % (tag, n)) for n in ("tcc.txt", "summary.json", "kernel_stats.csv")]
+    try:
+        line = open(made[0]).read().strip()
+        assert line.split(" ", 1)[0] == "k_shade" and line.endswith("launches 2")
+        c = ast.literal_eval(line[line.index("{"):line.rindex("}") + 1])          # (what bench.py does with the line)
+        assert float(c["TCC_HIT_sum"]) == 200.0 and float(c["TCC_MISS_sum"]) == 100.0
+    finally:
+        for f in made:
+            if os.path.exists(f):
+                os.remove(f)
