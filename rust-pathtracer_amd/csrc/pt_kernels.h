@@ -364,10 +364,7 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
             if (wants_item) {
                 float lam[NL]; lam[0] = pv.lambda;
                 if (NL > 1) hero_lambdas<NL>(rp, pv.lambda, lam);
-                // (a marked ray's instance: from the hit record — read again from its queue where the form has one, rather than kept alive through the vertex code)
-                uint32_t item_flags = out.env_mask;
-                if (!(LACKS & PT_SCENE_NO_CERTS) && (out.env_mask & 0xff00u)) item_flags = shade_item_flags(out.env_mask, FUSE_TRAV != PT_NO_FUSE ? hit.instance : qu(hits, HS_INST, i));
-                qsu(shadow, Layout<NL>::sh_slot, ipos, pv.slot); qsu(shadow, Layout<NL>::sh_flags, ipos, item_flags);
+                qsu(shadow, Layout<NL>::sh_slot, ipos, pv.slot); qsu(shadow, Layout<NL>::sh_flags, ipos, out.env_mask);
                 for (int k = 0; k < NL; ++k) qsf(shadow, Layout<NL>::sh_lambda + k, ipos, lam[k]);
                 if (!out.has_item) clear_shadow_item<NL>(shadow, ipos, rp.light_samples);  // vertex dropped (NaN pdf, utils.rs:261-263)
             }

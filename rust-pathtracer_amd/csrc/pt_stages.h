@@ -265,16 +265,19 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     // "cannot hit this instance again" (ShadeOutT::env_mask, bits 8.. and 16..), its inward light rays are dead here, and so is marked the path's next segment if it
     // leaves outward.  A scene without such an instance: one scalar test.
     const bool certs = scene_has_certificates(s);   // (wave-uniform, a scalar: everything the certificates add stands behind it)
-    // (what the certificates say about this vertex is worked out from the hit's instance word WHERE it is needed — per light sample, and once more for the path's next segment:
-    // one register alive through the sampling code, not a threshold and three predicates: the NO_ENV form runs at its register cap)
-    auto certificate = [&](bool* cv_out, bool* cv_in, bool* cv_path, float* cv_tau) {
+    // (three lane predicates made here, so that neither the instance's flag word nor the hit's instance word stays alive through the sampling code below: the NO_ENV form
+    // runs at its register cap)
+    bool cv_out = false, cv_in = false, cv_path = false;   // outward rays are marked; inward light rays from this face are dead; the path's next segment is marked too
+    float cv_tau = 2.0f;                                    // the face's outward threshold: a direction's cosine to the hit normal must exceed it
+    if (certs) {
+        PT_KEEP_BRANCH_NOFENCE();
         const uint32_t id = hit.instance & PT_HIT_INDEX_MASK, tq = (hit.instance >> PT_HIT_OUT_SHIFT) & 0x7fffu;
         const uint32_t cf = bu(s, bu(s, PT_HDR_INSTANCE_OFF) + id * PT_INST_WORDS + PT_INST_FLAGS);
-        *cv_out = (cf & PT_INST_CONVEX_OUT) != 0u && tq != 0u;             // outward rays above the face's threshold are marked
-        *cv_tau = (float)tq * (1.0f / 32768.0f);
-        *cv_in = (cf & PT_INST_CONVEX_IN) != 0u && (hit.instance & PT_HIT_IN_SAFE) != 0u;   // inward light rays from this face are dead
-        *cv_path = *cv_out && bu(s, PT_HDR_CONVEX_INST) == id + 1u;           // the path's next segment is marked too
-    };
+        cv_out = (cf & PT_INST_CONVEX_OUT) != 0u && tq != 0u;
+        cv_tau = (float)tq * (1.0f / 32768.0f);
+        cv_in = (cf & PT_INST_CONVEX_IN) != 0u && (hit.instance & PT_HIT_IN_SAFE) != 0u;
+        cv_path = cv_out && bu(s, PT_HDR_CONVEX_INST) == id + 1u;
+    }
     pt_f32x4 r = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples));
     float f, pdf; F3 wo;
     // (per-wavelength loops stay rolled, their arrays in registers: pl_get / pl_set, pt_device.h)
@@ -344,15 +347,13 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                             ray.factor[k] = pv.beta[k] * weight * rk * env_emission(s, ep, lam[k], ec[k]) * pt_abs(local_wo.z) * (1.0f / light_pdf);
                         }
                         out.shadow_count += 1;
-                        if (certs) {
+                        if (certs && (cv_out | cv_in)) {
                             PT_KEEP_BRANCH_NOFENCE();
-                            bool cv_out, cv_in, cv_path; float cv_tau;
-                            certificate(&cv_out, &cv_in, &cv_path, &cv_tau);
                             // An environment ray always LEAVES on the normal's side (local_wo.z > 0) but starts on the side of the WORLD z of its direction (pt.rs:256, a kept
                             // quirk): with direction.z < 0 it starts 1e-3 INSIDE a certified body and must cross its closed surface — any hit blocks an environment ray
                             // (pt.rs:300-330): dead here; with direction.z > 0 it starts outside and cannot hit the body again.
                             if (cv_in && direction.z < 0.0f) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
-                            if (cv_out && local_wo.z > cv_tau && direction.z > 0.0f) out.shadow_count |= 0x100u << l;   // (the marks ride in the counter's upper bits until the loop is over)
+                            if (cv_out && local_wo.z > cv_tau && direction.z > 0.0f) out.env_mask |= 0x100u << l;
                         }
                         // a contribution of exactly 0 adds 0 whether or not the ray is occluded: not traced
                         if (ray_is_live<NL>(ray)) out.env_mask |= 1u << l;
@@ -382,13 +383,11 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                         // (the microfacet evaluation is a big body: rolled; the Lambertian one a few instructions: the compiler's choice)
                         if (GGX) { PT_ROLLED for (int k = 1; k < NL; ++k) passenger(k); } else { for (int k = 1; k < NL; ++k) passenger(k); }
                         out.shadow_count += 1;
-                        if (certs) {
+                        if (certs && (cv_out | cv_in)) {
                             PT_KEEP_BRANCH_NOFENCE();
-                            bool cv_out, cv_in, cv_path; float cv_tau;
-                            certificate(&cv_out, &cv_in, &cv_path, &cv_tau);
                             // inward from a certified body: the reference's closest hit is the body's own surface, or something inside it — no light (pt.rs:177-189): the sample adds 0
                             if (cv_in && bsdf_wo.z < 0.0f) for (int k = 0; k < NL; ++k) ray.factor[k] = 0.0f;
-                            if (cv_out && bsdf_wo.z > cv_tau) out.shadow_count |= 0x100u << l;
+                            if (cv_out && bsdf_wo.z > cv_tau) out.env_mask |= 0x100u << l;
                         }
                         // The scene's ONLY light: a ray that misses it meets no light at all — the light-sample kernel's search bound (shadow_light_bound:
                         // nearest_light_hit = +inf) would drop it untraced, with the same test on the same ray.  Found here it makes the ray dead, and an
@@ -404,9 +403,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
                 }
                 sink(l, ray);
             }
-            // (the marks, collected in the upper bits of the ray counter — one register alive through the sampling code instead of two: the NO_ENV form runs at its register cap —,
-            // move to the item's flag word; the CALLER adds the instance the marked rays may skip, word << 16, from the hit record it holds: pt_stages.h shade_item_flags)
-            if (certs) { out.env_mask |= out.shadow_count & 0xff00u; out.shadow_count &= 0xffu; }   // (the instance the marked rays may skip; certified instances are numbered below 65536)
+            if (certs && (out.env_mask & 0xff00u)) out.env_mask |= hit.instance << 16;   // (the hit's face claims fall off the top: the instance's index is its low 16 bits)   // (the instance the marked rays may skip; certified instances are numbered below 65536)
             out.has_item = true;
         }
     }
@@ -431,18 +428,9 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     out.next.prev_pdf = pdf_forward; out.next.prev_n = hit.n; out.next.prev_p = hit.p;
     // The next segment leaves the scene's one certified convex body outward (it starts 1e-3 outside the face it left, hit.n being that face's normal, and moves away): it
     // cannot hit that instance again.  Marked in the sign of the previous-pdf word — every reader takes its magnitude (load_path) — for the parked closest-hit kernel.
-    if (certs) {
-        PT_KEEP_BRANCH_NOFENCE();
-        bool cv_out, cv_in, cv_path; float cv_tau;
-        certificate(&cv_out, &cv_in, &cv_path, &cv_tau);
-        if (cv_path && wo.z > cv_tau) out.next.prev_pdf = -pdf_forward;
-    }
+    if (certs && cv_path && wo.z > cv_tau) out.next.prev_pdf = -pdf_forward;
     return out;
 }
-
-// The flag word of a light-sample item (Layout::sh_flags): stage_shade's env_mask — bit l an environment sample, bit 8 + l a marked ray — and, where any ray is marked, the
-// instance the marked rays cannot hit again in its upper half (the hit's instance word: its face claims fall off the top).
-PT_HD uint32_t shade_item_flags(uint32_t env_mask, uint32_t hit_instance_word) { return (env_mask & 0xff00u) ? env_mask | hit_instance_word << 16 : env_mask; }
 
 // ------------------------------------------------------------------------------------------------ shade, medium-aware
 // One vertex of random_walk_medium (utils.rs:708-1103) + the matching iteration of color()'s second pass, which only looks at pairs of

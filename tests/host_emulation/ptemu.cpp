@@ -158,7 +158,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
                     items++;
                     float lam[NL]; lam[0] = pv.lambda;
                     if (NL > 1) hero_lambdas<NL>(rp, pv.lambda, lam);
-                    qsu(qs, LY::sh_slot, ipos, pv.slot); qsu(qs, LY::sh_flags, ipos, shade_item_flags(out.env_mask, hit.instance));
+                    qsu(qs, LY::sh_slot, ipos, pv.slot); qsu(qs, LY::sh_flags, ipos, out.env_mask);
                     for (int k = 0; k < NL; ++k) qsf(qs, LY::sh_lambda + k, ipos, lam[k]);
                     if (!out.has_item) clear_shadow_item<NL>(qs, ipos, rp.light_samples);
                 }
