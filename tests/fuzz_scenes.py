@@ -101,6 +101,34 @@ def random_scene(seed):
                               face_materials=api.material_id(api.TAG_MATERIAL, mats[k % len(mats)] & 0xFFFF))
             b.add_mesh_instance(mesh, mats[int(rng2.integers(len(mats)))] if rng2.random() < 0.5 else None,
                                 S.transform_from_data(None, None, rng2.uniform(-1.0, 1.0, 3).tolist()) if rng2.random() < 0.7 else None)
+    if 150000 <= seed < 200000:  # (a seed space of its own, round 6; below 200000: rendered by the plain walk) closed CONVEX bodies of every kind the host certifies or refuses
+        # (pt_blob.h PT_INST_CONVEX_*): the brilliant cut (flat-shaded, sharp edges), the prism (smooth-shaded: vertex normals up to 47 degrees off their faces), cubes, octahedra
+        # with and without vertex normals — under random transform stacks (uneven scales, rotations), in glass, metal and Lambertian, several instances of one mesh, bodies that
+        # overlap, lights of every kind next to, above and INSIDE their boxes, skies that light samples pick
+        rng5 = np.random.default_rng(seed + 2468)
+        cube_p = np.array([(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)], np.float32) - 0.5
+        cube_f = np.array([(0, 2, 1), (0, 3, 2), (4, 5, 6), (4, 6, 7), (0, 1, 5), (0, 5, 4), (1, 2, 6), (1, 6, 5), (2, 3, 7), (2, 7, 6), (3, 0, 4), (3, 4, 7)], np.uint32)
+        shared = {}
+        for k in range(int(rng5.integers(1, 5))):
+            kind = int(rng5.integers(0, 5))
+            if kind == 0: pm, fm_, nm, _ = S._npz_mesh("brilliant_diamond"); size = 0.5
+            elif kind == 1: pm, fm_, nm, _ = S._npz_mesh("prism"); size = 2.5
+            elif kind == 2: pm, fm_, nm = cube_p, cube_f, None; size = 0.8
+            elif kind == 3: pm, fm_, nm = S._octahedron(); size = 0.7
+            else: pm, fm_, nm = S._octahedron(); nm = None; size = 0.7
+            if kind in shared and rng5.random() < 0.5: mesh = shared[kind]            # a second instance of a mesh already there
+            else:
+                mesh = b.add_mesh(pm, fm_, nm, face_materials=api.material_id(api.TAG_MATERIAL, mats[int(rng5.integers(len(mats)))] & 0xFFFF))
+                shared[kind] = mesh
+            scale = (rng5.uniform(0.5, 1.5, 3) * size).tolist() if rng5.random() < 0.6 else (size, size, size)
+            rot = [(rng5.normal(size=3).tolist(), float(rng5.uniform(-180, 180))) for _ in range(int(rng5.integers(0, 3)))] or None
+            at = rng5.uniform(-1.0, 1.0, 3)
+            b.add_mesh_instance(mesh, mats[int(rng5.integers(len(mats)))] if rng5.random() < 0.7 else None, S.transform_from_data(scale, rot, at.tolist()))
+            if rng5.random() < 0.4:   # a small lamp next to, above, or inside the body's box
+                off = rng5.normal(size=3) * float(rng5.choice([0.2, 0.6, 1.5]))
+                lm = lights[int(rng5.integers(len(lights)))]
+                if rng5.random() < 0.5: b.add_sphere(float(rng5.uniform(0.03, 0.15)), (at + off).tolist(), lm)
+                else: b.add_rect((float(rng5.uniform(0.1, 0.4)), float(rng5.uniform(0.1, 0.4))), (at + off).tolist(), "XYZ"[int(rng5.integers(3))], True, lm)
     if seed >= 200000:  # (its own seed space again) participating media for the medium-aware walk: HG and Rayleigh mediums behind passthrough
         # boundaries and inside glass, nested and overlapping, so that the list of tracked mediums grows, shrinks and overflows
         rng3 = np.random.default_rng(seed + 4242)
