@@ -233,6 +233,8 @@
 #define PT_HDR_CONVEX_INST 69        /* 1 + the id of the scene's ONLY instance with PT_INST_CONVEX_OUT (0: none, or several): a path segment that leaves it outward carries a mark
                                        — the sign of its record's previous-pdf word, which every reader squares — and the parked closest-hit kernel drops the instance from that
                                        ray's leaf mask, as the light-sample kernel does for marked light rays */
+#define PT_PATH_INSIDE_MARK 0x80000000u /* in a path record's slot word (slots are numbered below 2^30): the segment starts INSIDE the scene's one certified convex body (it left an
+                                          inward-safe face inward) — the parked closest-hit kernel ends that body's sweep at the first triangle accepted well inside itself (mesh_walk) */
 #define PT_HDR_CORE_WORDS 61        /* words of the core section; the mesh-data section follows it */
 #define PT_HDR_SWEEP_MESH_MASK 57  /* 2 words: the bits that stand for mesh instances (no primitive of their own) */
 #define PT_HDR_SWEEP_OWNER_MASK 62 /* 2 words: the bits whose primitive test needs the ray itself (analytic shapes, triangles of transformed

@@ -1005,8 +1005,14 @@ static __device__ float g_tl_rays[1 + 4096 * 12];
 // `*aux` = the mask of their groups still to do (the caller parks both: two words an entry of a path segment has to spare); a later wave of 64 such rays goes straight to its groups.
 #define PT_GROUPS_EVICTED 0xfffffffeu
 template <bool SPEC = false>
+// `inside` (round 6): the ray is KNOWN to start inside this instance, a certified closed convex body (a path segment that left an inward-safe face inward: pt_blob.h
+// PT_INST_CONVEX_IN, the mark in its record's slot word).  The ray's line crosses such a body's surface twice, once behind the origin and once in front: only the
+// triangle in front can be accepted — so once a triangle is accepted WELL INSIDE itself (every barycentric coordinate >= PT_INSIDE_BARY: the ray passes no edge or vertex of
+// the accepted triangle within the reach of rounding, where a neighbour might be accepted too and, later in the order, win a tie), no later leaf of this mesh can be:
+// the grouped and plain sweeps end there for this lane.  (The while-while walk does not use it.)
+#define PT_INSIDE_BARY 1e-3f
 PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, F3 d, float bound, int stop, SweepState& st,
-                     uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true, uint64_t* aux = nullptr) {
+                     uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true, uint64_t* aux = nullptr, bool inside = false) {
     const uint32_t NONE = 0xffffffffu;
     const uint32_t flags = bu(s, PT_HDR_FLAGS);
     const bool cull = (flags & PT_FLAG_NO_CULL) == 0;
@@ -1078,6 +1084,7 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                 if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
                     st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th;
                     limit = __builtin_fminf(st.closest, bound);
+                    if (inside && __builtin_fminf(__builtin_fminf(th.b0, th.b1), th.b2) >= PT_INSIDE_BARY) return true;   // (this mesh is done for this lane; the ray's other leaves are not)
                     if (stop == PT_STOP_ANY) { st.hit = 0; return true; }
                     if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
                         uint32_t im = bu(s, inst + PT_INST_MATERIAL);
@@ -1442,7 +1449,7 @@ PT_HD bool mesh_surely_missed(const SceneView& s, uint32_t inst, F3 o, F3 d, flo
 #endif
 template <bool WALKS = true>
 PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bound, int stop, SweepState& st, bool park_at_walked,
-                     uint32_t known_inst = 0xffffffffu, float known_t = 0.0f) {
+                     uint32_t known_inst = 0xffffffffu, float known_t = 0.0f, uint32_t inside_inst = 0xffffffffu) {   // (inside_inst: mesh_walk's `inside`, for that instance)
     const uint32_t bits_off = bu(s, PT_HDR_SWEEP_BITS_OFF);
 #if PT_SWEEP_ENTRY_REJECT
     const RayPrep erp = ray_prepare(o, d);
@@ -1460,7 +1467,7 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
             if (PT_MESH_DOP_TRIES(stop) && mesh_surely_missed(s, inst, o, d, __builtin_fminf(bound, st.closest))) { st.hit &= st.hit - 1; continue; }   // (through a corner of the mesh's box: nothing to walk for)
             if (park_at_walked) return true;
             st.hit &= st.hit - 1;
-            mesh_walk(s, inst, kf >> 16, o, d, bound, stop, st);
+            mesh_walk(s, inst, kf >> 16, o, d, bound, stop, st, nullptr, 0u, true, nullptr, (kf >> 16) == inside_inst);
             continue;
         }
         st.hit &= st.hit - 1;
@@ -1526,7 +1533,7 @@ PT_HD bool sweep_run(const SceneView& s, F3 o, F3 d, const TriRay& wtr, float bo
 // a `policy` that evicts, the walk may be left unfinished (mesh_walk): true then too, the bit still set and `*cursor` where the walk goes on.
 template <bool SPEC = false>
 PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, SweepState& st, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f,
-                        uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true, uint64_t* aux = nullptr) {
+                        uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true, uint64_t* aux = nullptr, uint32_t inside_inst = 0xffffffffu) {
     const uint32_t k = alive ? ctz64(st.hit) : 0u;
     const F4 be = bf4(s, bu(s, PT_HDR_SWEEP_BITS_OFF) + k * PT_SWEEP_BIT_WORDS);
     uint32_t inst = pt_f2u(be.x);
@@ -1535,13 +1542,13 @@ PT_HD bool sweep_resume(const SceneView& s, F3 o, F3 d, float bound, int stop, S
         const uint32_t lead = PT_WAVE_READ(inst, ctz64(PT_WAVE_BALLOT(alive)));
         inst = alive ? inst : lead;
     }
-    if (mesh_walk<SPEC>(s, inst, pt_f2u(be.w) >> 16, o, d, bound, stop, st, cursor, policy, alive, aux)) return true;
+    if (mesh_walk<SPEC>(s, inst, pt_f2u(be.w) >> 16, o, d, bound, stop, st, cursor, policy, alive, aux, alive && (pt_f2u(be.w) >> 16) == inside_inst)) return true;
     if (!alive) return false;
     if (cursor != nullptr) *cursor = 0u;
     st.hit &= st.hit - 1;   // (zero already after an early stop)
     if (st.hit == 0) return false;
     const TriRay wtr = tri_ray_prepare(o, d);
-    return sweep_run<true>(s, o, d, wtr, bound, stop, st, true, known_inst, known_t);
+    return sweep_run<true>(s, o, d, wtr, bound, stop, st, true, known_inst, known_t, inside_inst);
 }
 // ---- the two-level walk, in the parked kernels' protocol (round 3) ------------------------------------------------------------------
 // Scenes without a sweep table (more than 64 instances, or PT_FLAG_NO_SWEEP): the top-level tree is walked lane by lane as in world_hit_walk,
@@ -1901,7 +1908,8 @@ PT_HD uint64_t sweep_instance_mask(const SceneView& s, uint32_t instance) {
     return (uint64_t)bu(s, io + PT_INST_SWEEP_MASK) | (uint64_t)bu(s, io + PT_INST_SWEEP_MASK + 1) << 32;
 }
 template <bool WALKS = true, bool LIGHT_ONLY = false>
-PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, int stop, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f, uint32_t skip_inst = 0xffffffffu) {
+PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound, int stop, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f, uint32_t skip_inst = 0xffffffffu,
+                           uint32_t inside_inst = 0xffffffffu) {
     SweepState st;
     sweep_state_init(st, sweep_masks(s, o, d, bound));
     if (WALKS && skip_inst != 0xffffffffu) st.hit &= ~sweep_instance_mask(s, skip_inst);
@@ -1913,12 +1921,12 @@ PT_HD bool world_hit_sweep(const SceneView& s, F3 o, F3 d, Hit* out, float bound
     if ((bu(s, PT_HDR_FLAGS) & (PT_FLAG_REPLAY | PT_FLAG_SWEEP_WALKS)) == (PT_FLAG_REPLAY | PT_FLAG_SWEEP_WALKS)) {
         // the parked kernels' protocol, lane by lane: park at a walked mesh, resume, and leave the walk at every chance (mesh_walk's eviction)
         uint32_t cursor = 0u;
-        bool parked = sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, true, known_inst, known_t);
+        bool parked = sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, true, known_inst, known_t, inside_inst);
         uint64_t aux = 0ull;   // (the grouped sweep's group loop too is left at every chance: 2 << 17 against the emulation's one busy lane)
-        while (parked) parked = sweep_resume(s, o, d, bound, stop, st, known_inst, known_t, &cursor, 0x201u | PT_WALK_SCAN_AXIS | (2u << 17), true, &aux);
+        while (parked) parked = sweep_resume(s, o, d, bound, stop, st, known_inst, known_t, &cursor, 0x201u | PT_WALK_SCAN_AXIS | (2u << 17), true, &aux, inside_inst);
     } else
 #endif
-    sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, false, known_inst, known_t);
+    sweep_run<WALKS>(s, o, d, wtr, bound, stop, st, false, known_inst, known_t, inside_inst);
     if (LIGHT_ONLY && st.best_inst != 0xffffffffu && !sweep_best_is_light(s, st)) { out->valid = true; out->material = PT_MATERIAL_ID(PT_TAG_MATERIAL, 0); return true; }
     return sweep_finish(s, o, d, st, out);
 }
@@ -2035,9 +2043,10 @@ PT_HD bool world_hit_walk(const SceneView& s, F3 o, F3 d, Hit* out, float bound,
 PT_HD bool scene_uses_sweep(const SceneView& s) { return bu(s, PT_HDR_SWEEP_OFF) != 0u && !(bu(s, PT_HDR_FLAGS) & PT_FLAG_NO_SWEEP); }
 template <int TRAV = PT_TRAV_ANY, bool LIGHT_ONLY = false>
 PT_HD bool world_hit(const SceneView& s, F3 o, F3 d, Hit* out, float bound = PT_INF, int stop = PT_STOP_NONE, uint32_t known_inst = 0xffffffffu, float known_t = 0.0f,
-                     uint32_t skip_inst = 0xffffffffu) {   // (skip_inst: an instance the ray is known not to hit — optional knowledge: the walk forms do not use it)
+                     uint32_t skip_inst = 0xffffffffu, uint32_t inside_inst = 0xffffffffu) {   // (skip_inst: an instance the ray is known not to hit; inside_inst: one it is known to start
+                                                                                          // inside of, mesh_walk — optional knowledge: the walk forms do not use it)
     if (TRAV == PT_TRAV_SWEEP) return world_hit_sweep<false, LIGHT_ONLY>(s, o, d, out, bound, stop, known_inst, known_t);
-    if (TRAV == PT_TRAV_ANY && scene_uses_sweep(s)) return world_hit_sweep<true, LIGHT_ONLY>(s, o, d, out, bound, stop, known_inst, known_t, skip_inst);
+    if (TRAV == PT_TRAV_ANY && scene_uses_sweep(s)) return world_hit_sweep<true, LIGHT_ONLY>(s, o, d, out, bound, stop, known_inst, known_t, skip_inst, inside_inst);
 #if !defined(__HIP_DEVICE_COMPILE__)
     if (bu(s, PT_HDR_FLAGS) & PT_FLAG_REPLAY) {
         // (host emulation: the parked kernels' protocol over the top-level tree, lane by lane — park at every mesh, resume, leave the walk at every chance)

@@ -348,6 +348,7 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
                 pv = load_path<NL>(paths_in, i, FORM != PT_SHADE_NO_ENV && bounce == 0u);
                 hit = load_hit<PT_SHADE_EAGER && FORM == PT_SHADE_LEAN>(hits, i);
             }
+            if (!(LACKS & PT_SCENE_NO_CERTS)) pv.slot &= ~PT_PATH_INSIDE_MARK;   // (the forms of scenes with certificates: the previous vertex' mark for the closest-hit kernel)
             wants_item = shade_wants_item(s, rp, hit);
         }
         // reserve the light-sample item first, so its rays stream straight from registers to the queue
@@ -927,7 +928,7 @@ k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const fl
                 sweep_state_init(st, sweep_masks(s, o, d, PT_INF));
                 if (PT_CONVEX_SKIP && path_marks != 0u && qf(paths, PS_PREV_PDF, base + j) < 0.0f) st.hit &= ~sweep_instance_mask(s, path_marks - 1u);
                 const TriRay wtr = tri_ray_prepare(o, d);
-                parks = sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true);
+                parks = sweep_run(s, o, d, wtr, PT_INF, PT_STOP_NONE, st, true);   // (parks at the walked mesh: `inside` is looked up again when the ray is resumed)
             }
             settle(j, o, d, st, parks, evicted ? PT_TOP_EVICTED : 0u);
         }
@@ -936,8 +937,10 @@ k_extend_parked(const uint32_t* __restrict__ blob, uint32_t blob_words, const fl
             F3 o = f3(0.0f, 0.0f, 0.0f), d = f3(0.0f, 0.0f, 0.0f);
             if (mine) ray_of(base + j2, &o, &d);
             uint64_t aux = (uint64_t)aux_lo | (uint64_t)aux_hi << 32;
+            // (a segment marked "starts inside the scene's one certified body", PT_PATH_INSIDE_MARK: mesh_walk may end that body's sweep at the first triangle accepted well inside itself)
+            const uint32_t inside_inst = (PT_CONVEX_SKIP && path_marks != 0u && mine && (qu(paths, PS_SLOT, base + j2) & PT_PATH_INSIDE_MARK)) ? path_marks - 1u : 0xffffffffu;
             const bool again = TOP ? top_walk_resume<PT_WALK_SPEC_EXTEND>(s, o, d, PT_INF, PT_STOP_NONE, st, &cursor, policy, mine)
-                                   : sweep_resume<PT_WALK_SPEC_EXTEND>(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy, mine, &aux);
+                                   : sweep_resume<PT_WALK_SPEC_EXTEND>(s, o, d, PT_INF, PT_STOP_NONE, st, 0xffffffffu, 0.0f, &cursor, policy, mine, &aux, inside_inst);
             if (mine) settle(j2, o, d, st, again, cursor, aux);
         });
     }

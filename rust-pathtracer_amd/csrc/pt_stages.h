@@ -267,7 +267,7 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     const bool certs = scene_has_certificates(s);   // (wave-uniform, a scalar: everything the certificates add stands behind it)
     // (three lane predicates made here, so that neither the instance's flag word nor the hit's instance word stays alive through the sampling code below: the NO_ENV form
     // runs at its register cap)
-    bool cv_out = false, cv_in = false, cv_path = false;   // outward rays are marked; inward light rays from this face are dead; the path's next segment is marked too
+    bool cv_out = false, cv_in = false, cv_path = false, cv_only = false;   // outward rays are marked; inward light rays from this face are dead; the path's next segment is marked too
     float cv_tau = 2.0f;                                    // the face's outward threshold: a direction's cosine to the hit normal must exceed it
     if (certs) {
         PT_KEEP_BRANCH_NOFENCE();
@@ -276,7 +276,8 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
         cv_out = (cf & PT_INST_CONVEX_OUT) != 0u && tq != 0u;
         cv_tau = (float)tq * (1.0f / 32768.0f);
         cv_in = (cf & PT_INST_CONVEX_IN) != 0u && (hit.instance & PT_HIT_IN_SAFE) != 0u;
-        cv_path = cv_out && bu(s, PT_HDR_CONVEX_INST) == id + 1u;
+        cv_only = bu(s, PT_HDR_CONVEX_INST) == id + 1u;   // (the scene's one certified body: path marks name no instance)
+        cv_path = cv_out && cv_only;
     }
     pt_f32x4 r = pt_draw4(rp.seed, pixel, sample, pt_dim_bounce(bounce, rp.light_samples));
     float f, pdf; F3 wo;
@@ -429,6 +430,9 @@ PT_HD ShadeOutT<NL> stage_shade(const SceneView& s, const RenderParams& rp, uint
     // The next segment leaves the scene's one certified convex body outward (it starts 1e-3 outside the face it left, hit.n being that face's normal, and moves away): it
     // cannot hit that instance again.  Marked in the sign of the previous-pdf word — every reader takes its magnitude (load_path) — for the parked closest-hit kernel.
     if (certs && cv_path && wo.z > cv_tau) out.next.prev_pdf = -pdf_forward;
+    // ... and one that leaves it INWARD from an inward-safe face starts inside the closed body: marked in the slot word's top bit (PT_PATH_INSIDE_MARK; the vertex kernel of
+    // the next bounce takes it off again), for mesh_walk's `inside`
+    if (certs && cv_in && cv_only && wo.z < 0.0f) out.next.slot |= PT_PATH_INSIDE_MARK;
     return out;
 }
 

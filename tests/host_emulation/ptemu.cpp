@@ -124,13 +124,17 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
                 Hit h;
                 // (k_extend_parked's path_marks: a marked segment — the sign of its previous-pdf word, from bounce 1 on — cannot hit the scene's one certified convex body)
                 const bool marked = bounce > 0 && !rd.medium_aware && (bu(s, PT_HDR_FLAGS) & PT_FLAG_CONVEX) && bu(s, PT_HDR_CONVEX_INST) != 0u && qf(qin, PS_PREV_PDF, i) < 0.0f;
+                const bool path_certs = bounce > 0 && !rd.medium_aware && (bu(s, PT_HDR_FLAGS) & PT_FLAG_CONVEX) && bu(s, PT_HDR_CONVEX_INST) != 0u;
+                static const bool no_inside = getenv("PTEMU_NO_INSIDE") != nullptr;   // (test switch: the mark is made and ignored)
+                const bool inside = path_certs && !no_inside && (qu(qin, PS_SLOT, i) & PT_PATH_INSIDE_MARK) != 0u;   // (PT_PATH_INSIDE_MARK: mesh_walk's `inside`)
                 world_hit(s, f3(qf(qin, PS_OX, i), qf(qin, PS_OY, i), qf(qin, PS_OZ, i)), f3(qf(qin, PS_DX, i), qf(qin, PS_DY, i), qf(qin, PS_DZ, i)), &h, PT_INF, PT_STOP_NONE, 0xffffffffu, 0.0f,
-                          marked ? bu(s, PT_HDR_CONVEX_INST) - 1u : 0xffffffffu);
+                          marked ? bu(s, PT_HDR_CONVEX_INST) - 1u : 0xffffffffu, inside ? bu(s, PT_HDR_CONVEX_INST) - 1u : 0xffffffffu);
                 store_hit(qh, i, h);
             }
             uint32_t next = 0, items = 0;
             for (uint32_t i = 0; i < live; ++i) {
                 PathVertexT<NL> pv = load_path<NL>(qin, i, rp.camera_record != 0u && bounce == 0u);
+                if (bounce > 0) pv.slot &= ~PT_PATH_INSIDE_MARK;   // (the previous vertex' mark for the closest-hit step)
                 Hit hit = load_hit(qh, i);
                 bool wants = shade_wants_item(s, rp, hit);   // (the medium-aware walk overrides this below)
                 uint32_t ipos = items;
