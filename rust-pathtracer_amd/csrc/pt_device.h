@@ -50,6 +50,9 @@
 #define PT_STAT_WALK(lo, ld, bound, closest, stop)   /* a mesh walk begins (tools/light_walks.cpp): the ray in the instance's own space, its bound, the closest hit so far */
 #define PT_STAT_WALK_END(over)                       /* ... and ends: whether the search is over (an early stop) */
 #endif
+#ifndef PT_STAT_INSIDE_STOP
+#define PT_STAT_INSIDE_STOP()                        /* a sweep ended by mesh_walk's `inside` rule (tests/host_emulation counts them) */
+#endif
 
 // Wave-level helpers: device code sees the wave, the host emulation one lane at a time.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1084,7 +1087,7 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
                 if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
                     st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th;
                     limit = __builtin_fminf(st.closest, bound);
-                    if (inside && __builtin_fminf(__builtin_fminf(th.b0, th.b1), th.b2) >= PT_INSIDE_BARY) return true;   // (this mesh is done for this lane; the ray's other leaves are not)
+                    if (inside && __builtin_fminf(__builtin_fminf(th.b0, th.b1), th.b2) >= PT_INSIDE_BARY) { PT_STAT_INSIDE_STOP(); return true; }   // (this mesh is done for this lane; the ray's other leaves are not)
                     if (stop == PT_STOP_ANY) { st.hit = 0; return true; }
                     if (stop == PT_STOP_NONLIGHT && st.closest < bound) {
                         uint32_t im = bu(s, inst + PT_INST_MATERIAL);

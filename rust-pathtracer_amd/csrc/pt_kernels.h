@@ -58,6 +58,12 @@ inline void go_block(const LaunchCfg& c, int block, uint32_t lds_bytes, K kernel
 // (forms of k_shade, see the kernel: FULL = PT_SHADE_WAVES / PT_SHADE4_WAVES above; measured with tools/shade_occupancy.sh.  FULL on C4:
 // 11442 us at 3 waves, 14735 at 2, 11869 at 4; NO_ENV on C3: 3564 at 3 or 2, 3902 at 4)
 #ifndef PT_SHADE_NO_ENV_WAVES
+#ifndef PT_SHADE_SORT
+#define PT_SHADE_SORT 0   /* 1: k_shade's NO_ENV and FULL forms shade their surface vertices sorted by material kind (kSort in the kernel; round 6, EXPERIMENT).  Built, bit-identical
+                             (233 GPU tests) and measured on one box, alternating (profiles/r6q_ab_sort.txt): C3 k_shade 2442 / 2469 -> 2305 / 2427 us (C3 +1.5 % / +0.1 %), but G1 2699 ->
+                             2811, C4 7312 -> 7553 and G2F 2385 -> 2979 us (-10 %): the classifying turn is one more exposed round trip to the hit queue per 64 vertices and the sorted waves
+                             gather their records from several tiles; the vertex kernel is not short of lanes but of memory latency.  Off. */
+#endif
 #define PT_SHADE_NO_ENV_WAVES 4   // (round 4, built without machine LICM: 141 VGPRs of demand; at four waves C3's k_shade 2650 -> 2505 us, profiles/r4t_noenv4.txt; round 2's 156-register form lost at four)
 #endif
 #ifndef PT_SHADE4_NO_ENV_WAVES
@@ -307,28 +313,51 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_OCC k_shade(const uint32_t* _
     // whenever the list holds that many (and what is left at the end): full waves in the expensive part.  No vertex' result depends on
     // when it is shaded (queue appends are order-free, energy is keyed by slot).  One call site of the vertex body for both.
     constexpr bool kSplit = FORM == PT_SHADE_FULL;
-    __shared__ uint32_t later[kSplit ? kBlock * 2 : 1];   // per wave: 128 item indices (fewer than 64 left over + at most 64 new)
-    uint32_t* my_later = later + (kSplit ? (threadIdx.x >> 6) * 128u : 0u);
-    uint32_t later_count = 0;   // (wave-uniform)
+    // SORTED forms (round 6; the forms that hold the microfacet code, unfused): the surface vertices go to TWO lists per wave, by the kind of their material — the microfacet
+    // vertices (GGX, PassthroughFilter) to the second — and each list is shaded 64 at a time: a wave of C3's gem scene that held glass and wall vertices ran the two BSDFs one
+    // after the other, each with the other's lanes idle (lane utilisation 0.47).  Same order-free argument as above; one more read of the hit's material word per vertex.
+    constexpr bool kSort = PT_SHADE_SORT && FUSE_TRAV == PT_NO_FUSE && (FORM == PT_SHADE_FULL || FORM == PT_SHADE_NO_ENV);
+    constexpr uint32_t kLists = kSort ? 2u : 1u;
+    __shared__ uint32_t later[(kSplit || kSort) ? kBlock * 2 * kLists : 1];   // per wave and list: 128 item indices (fewer than 64 left over + at most 64 new)
+    uint32_t* my_later = later + ((kSplit || kSort) ? (threadIdx.x >> 6) * 128u * kLists : 0u);
+    uint32_t* my_later2 = my_later + (kSort ? 128u : 0u);
+    uint32_t later_count = 0, later2_count = 0;   // (wave-uniform)
     for (uint32_t r = 0;;) {  // whole waves stay in the loop: the appends are ballots
         uint32_t i = 0;
         bool active = false;
-        if (kSplit && (later_count >= 64u || (r == rounds && later_count > 0u))) {
+        if ((kSplit || kSort) && (later_count >= 64u || (r == rounds && later_count > 0u))) {
             const uint32_t take = later_count < 64u ? later_count : 64u;
             later_count -= take;
             active = lane_id() < take;
             if (active) i = my_later[later_count + lane_id()];
+        } else if (kSort && (later2_count >= 64u || (r == rounds && later2_count > 0u))) {
+            const uint32_t take = later2_count < 64u ? later2_count : 64u;
+            later2_count -= take;
+            active = lane_id() < take;
+            if (active) i = my_later2[later2_count + lane_id()];
         } else if (r < rounds) {
             const uint32_t j = r * blockDim.x + threadIdx.x;
             ++r;
             active = j < n; i = base + j;
-            if (kSplit) {
-                const bool surface = active && qf(hits, HS_T, i) >= 0.0f;
-                const unsigned long long m = __ballot(surface);
-                if (surface) my_later[later_count + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = i;
+            if (kSplit || kSort) {
+                // (FULL: a path that left the scene is shaded now; NO_ENV: every vertex goes through a list)
+                const bool surface = active && (kSplit ? qf(hits, HS_T, i) >= 0.0f : true);
+                bool second = false;
+                if (kSort && surface && (kSplit || qf(hits, HS_T, i) >= 0.0f)) {
+                    const uint32_t mat = qu(hits, HS_MAT, i);
+                    if (PT_MATERIAL_TAG(mat) != PT_TAG_LIGHT) { const uint32_t kind = bu(s, material_record(s, mat) + PT_MAT_KIND); second = kind == PT_MATERIAL_GGX || kind == PT_MATERIAL_PASSTHROUGH; }
+                }
+                const unsigned long long m = __ballot(surface && !second);
+                if (surface && !second) my_later[later_count + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = i;
                 later_count += (uint32_t)__popcll(m);
+                if (kSort) {
+                    const unsigned long long m2 = __ballot(second);
+                    if (second) my_later2[later2_count + (uint32_t)__popcll(m2 & ((1ull << lane_id()) - 1ull))] = i;
+                    later2_count += (uint32_t)__popcll(m2);
+                }
                 active = active && !surface;
-                __builtin_amdgcn_wave_barrier();   // (the list is the wave's own: its writes are in LDS before any of its lanes reads them)
+                __builtin_amdgcn_wave_barrier();   // (the lists are the wave's own: its writes are in LDS before any of its lanes reads them)
+                if (!kSplit) continue;   // (nothing to shade in this turn)
             }
         } else break;
         PathVertexT<NL> pv; Hit hit; hit.valid = false;

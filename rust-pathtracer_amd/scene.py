@@ -854,11 +854,11 @@ def test_bokeh_small():
     return test_bokeh(hdri_size=(64, 32), importance=(32, 32))
 
 
-def test_bokeh_floor(hdri_size=(1024, 512), importance=(1024, 1024)):
+def test_bokeh_floor(hdri_size=(1024, 512), importance=(1024, 1024), lights_per_row=41):
     """NOT a reference scene: test_bokeh with a white Lambertian floor 0.05 under the lights and three non-emissive spheres on it.  In test_bokeh itself every
     surface is a light — a light vertex takes no light samples (pt.rs:512-561), so its renders never trace a light-sample ray; with the floor the 82-entry
     light list is sampled at every floor vertex and the light-sample rays take the top-level walk too (G2F of DESIGN section 6)."""
-    b = test_bokeh(hdri_size, importance)
+    b = test_bokeh(hdri_size, importance, lights_per_row)
     cam = b.cameras.pop()
     white = add_library_material(b, "lambertian_white")
     glass = add_library_material(b, "ggx_glass_rough")
@@ -869,6 +869,39 @@ def test_bokeh_floor(hdri_size=(1024, 512), importance=(1024, 1024)):
     b.add_sphere(0.10, (0.35, 1.5, 0.05), white)
     b.cameras.append(cam)
     return b
+
+
+def test_bokeh_floor_58(hdri_size=(1024, 512), importance=(1024, 1024)):
+    """NOT a reference scene, a measurement: test_bokeh_floor with 29 lights per row — 62 instances, so the scene HAS a leaf-sweep table; with PT_AMD_NO_SWEEP=1 it takes the
+    top-level walk as G2F does: the two forms on one scene (profiles/r6_experiments.md section 10)."""
+    return test_bokeh_floor(hdri_size, importance, lights_per_row=29)
+
+
+def rect_room(spheres=28):
+    """NOT a reference scene, a measurement: a closed room of six rectangles (1 x 1 x 1, Lambertian) with a rectangular lamp under its ceiling and `spheres` Lambertian and
+    GGX spheres of radius 0.04 on a grid inside — a DENSE scene of analytic instances (every ray hits something), against test_bokeh_floor's sparse one: which form of the
+    closest-hit and light-sample kernels such a scene wants (profiles/r6_experiments.md section 10)."""
+    b = SceneBuilder()
+    add_library_curves(b, ["flat_zero"])
+    b.set_environment_constant(b.curve("flat_zero"), 0.0)
+    b.env_sampling_probability = 0.0
+    light = add_library_material(b, "diffuse_light_cornell")
+    white, red, green = (add_library_material(b, n) for n in ("lambertian_white", "lambertian_red", "lambertian_green"))
+    gold = add_library_material(b, "ggx_gold")
+    b.add_rect((0.3, 0.3), (0.5, 0.5, 0.999), "Z", False, light)
+    b.add_rect((1.0, 1.0), (0.5, 0.5, 0.0), "Z", True, white); b.add_rect((1.0, 1.0), (0.5, 0.5, 1.0), "Z", True, white)
+    b.add_rect((1.0, 1.0), (0.0, 0.5, 0.5), "X", True, white); b.add_rect((1.0, 1.0), (1.0, 0.5, 0.5), "X", True, white)
+    b.add_rect((1.0, 1.0), (0.5, 0.0, 0.5), "Y", True, red); b.add_rect((1.0, 1.0), (0.5, 1.0, 0.5), "Y", True, green)
+    for k in range(spheres):
+        i, j, l = k % 4, (k // 4) % 4, k // 16
+        b.add_sphere(0.04, (0.35 + 0.15 * i, 0.2 + 0.2 * j, 0.15 + 0.3 * l), gold if k % 3 == 0 else white)
+    b.add_camera((0.02, 0.5, 0.5), (1.0, 0.5, 0.45), 60.0, focal_distance=0.6, aperture_diameter=0.005)
+    return b
+
+
+def _bokeh_floor_rows(n):
+    """(measurement scenes: test_bokeh_floor with n lights per row, 2 n + 4 instances — where the leaf sweep stops paying, profiles/r6_experiments.md section 10)"""
+    return lambda hdri_size=(1024, 512), importance=(1024, 1024): test_bokeh_floor(hdri_size, importance, lights_per_row=n)
 
 
 def test_bokeh_floor_gem(hdri_size=(1024, 512), importance=(1024, 1024)):
@@ -1061,7 +1094,8 @@ REFERENCE_TREE_SCENES = {"candela_calibration": ref_candela_calibration, "cornel
                          "test_sampling_methods": ref_test_sampling_methods}   # file name in the reference's data/scenes -> builder
 
 
-SCENES = {"test_bokeh_floor_gem": test_bokeh_floor_gem, "test_bokeh_floor_gem_small": test_bokeh_floor_gem_small, "test_bokeh_floor": test_bokeh_floor, "test_bokeh_floor_small": test_bokeh_floor_small, "test_bokeh": test_bokeh, "test_bokeh_small": test_bokeh_small, "test_prism": test_prism, "test_prism_small": test_prism_small, "hdri_emissive_mesh": hdri_emissive_mesh, "hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
+SCENES = {"rect_room": rect_room, "rect_room_12": lambda: rect_room(12), "rect_room_44": lambda: rect_room(44), "test_bokeh_floor_10": _bokeh_floor_rows(5), "test_bokeh_floor_18": _bokeh_floor_rows(9), "test_bokeh_floor_26": _bokeh_floor_rows(13), "test_bokeh_floor_42": _bokeh_floor_rows(21),
+          "test_bokeh_floor_58": test_bokeh_floor_58, "test_bokeh_floor_gem": test_bokeh_floor_gem, "test_bokeh_floor_gem_small": test_bokeh_floor_gem_small, "test_bokeh_floor": test_bokeh_floor, "test_bokeh_floor_small": test_bokeh_floor_small, "test_bokeh": test_bokeh, "test_bokeh_small": test_bokeh_small, "test_prism": test_prism, "test_prism_small": test_prism_small, "hdri_emissive_mesh": hdri_emissive_mesh, "hdri_test": hdri_test, "hdri_small": hdri_small, "hdri_c4_small": hdri_c4_small, "cornell_box": cornell_box, "cornell_gem": cornell_gem, "white_furnace": white_furnace,
           "mixed_primitives": mixed_primitives, "mixed_small": mixed_small, "sun_test": sun_test, "panorama_test": panorama_test, "empty_env": empty_env,
           "big_sphere_light": big_sphere_light, "disk_lamp": disk_lamp, "fog_ball": fog_ball}
 SCENES.update({"ref_" + name: fn for name, fn in REFERENCE_TREE_SCENES.items()})

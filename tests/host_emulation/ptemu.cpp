@@ -7,6 +7,9 @@
 #include <string>
 #include <vector>
 
+static unsigned long long g_inside_stops = 0;   // sweeps ended by mesh_walk's `inside` rule since the library was loaded (ptemu_debug_scene_info 18)
+#define PT_STAT_INSIDE_STOP() (++g_inside_stops)
+
 #include "../../rust-pathtracer_amd/csrc/pt_plan.h"
 #include "../../rust-pathtracer_amd/csrc/pt_scene_host.h"
 #include "../../rust-pathtracer_amd/csrc/pt_stages.h"
@@ -55,6 +58,7 @@ uint32_t ptemu_debug_scene_info(pt_scene* sc, int what) {
         }
         return 0;
     }
+    if (what == 18) return (uint32_t)g_inside_stops;
     if (what == 4) return w[PT_HDR_SWEEP_OFF] != 0 && !(w[PT_HDR_FLAGS] & PT_FLAG_NO_SWEEP) ? 1u : 0u;
     if ((what == 5 || what == 6) && w[PT_HDR_SWEEP_OFF] != 0) {  // 5: mask bits in use, 6: bits whose box test is a copy
         uint32_t bits = 0, copies = 0;
@@ -117,6 +121,7 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
             has_ggx = has_ggx || kind == PT_MATERIAL_GGX || kind == PT_MATERIAL_PASSTHROUGH;
         }
         const int forced = getenv("PTEMU_SHADE_FORM") ? atoi(getenv("PTEMU_SHADE_FORM")) : 0;
+        const bool no_inside = getenv("PTEMU_NO_INSIDE") != nullptr;   // (test switch: PT_PATH_INSIDE_MARK is made and ignored)
         const int shade_form = (bf(s, PT_HDR_ENV_PROB) != 0.0f || forced == 2) ? 2 : (has_ggx || forced == 1) ? 1 : 0;
         for (uint32_t bounce = 0; bounce < bounce_limit; ++bounce) {
             Queue qin = (bounce & 1) ? qb : qa, qout = (bounce & 1) ? qa : qb;
@@ -125,7 +130,6 @@ static pt_status render_t(pt_scene* sc, const pt_render_desc& rd, float* film, p
                 // (k_extend_parked's path_marks: a marked segment — the sign of its previous-pdf word, from bounce 1 on — cannot hit the scene's one certified convex body)
                 const bool marked = bounce > 0 && !rd.medium_aware && (bu(s, PT_HDR_FLAGS) & PT_FLAG_CONVEX) && bu(s, PT_HDR_CONVEX_INST) != 0u && qf(qin, PS_PREV_PDF, i) < 0.0f;
                 const bool path_certs = bounce > 0 && !rd.medium_aware && (bu(s, PT_HDR_FLAGS) & PT_FLAG_CONVEX) && bu(s, PT_HDR_CONVEX_INST) != 0u;
-                static const bool no_inside = getenv("PTEMU_NO_INSIDE") != nullptr;   // (test switch: the mark is made and ignored)
                 const bool inside = path_certs && !no_inside && (qu(qin, PS_SLOT, i) & PT_PATH_INSIDE_MARK) != 0u;   // (PT_PATH_INSIDE_MARK: mesh_walk's `inside`)
                 world_hit(s, f3(qf(qin, PS_OX, i), qf(qin, PS_OY, i), qf(qin, PS_OZ, i)), f3(qf(qin, PS_DX, i), qf(qin, PS_DY, i), qf(qin, PS_DZ, i)), &h, PT_INF, PT_STOP_NONE, 0xffffffffu, 0.0f,
                           marked ? bu(s, PT_HDR_CONVEX_INST) - 1u : 0xffffffffu, inside ? bu(s, PT_HDR_CONVEX_INST) - 1u : 0xffffffffu);

@@ -318,6 +318,18 @@ def test_convex_certificates_change_nothing(emu, oracle, pkg, monkeypatch, case)
     monkeypatch.delenv("PTEMU_NO_CONVEX")
     assert np.array_equal(with_cert.view(np.uint32), without.view(np.uint32))
     assert (pw.bounce_rays, pw.shadow_rays, pw.env_hits) == (po.bounce_rays, po.shadow_rays, po.env_hits)
+    # a path segment that starts inside the body ends the body's sweep at its first interior acceptance (PT_PATH_INSIDE_MARK, mesh_walk's `inside`): with the mark ignored, the same bits
+    sc = emu.create_scene(b)
+    stops = lambda: int(sc.library._debug_scene_info(sc.handle, 18))
+    before = stops()
+    monkeypatch.setenv("PTEMU_NO_INSIDE", "1")
+    full_sweep, pf = sc.render(rd)
+    monkeypatch.delenv("PTEMU_NO_INSIDE")
+    assert stops() == before
+    sc.render(rd)
+    assert (stops() > before + 1000) == case.startswith("cornell_gem"), (case, stops() - before)   # (the glass gem's inner bounces; a Lambertian body has none)
+    assert np.array_equal(with_cert.view(np.uint32), full_sweep.view(np.uint32))
+    assert (pw.bounce_rays, pw.shadow_rays, pw.env_hits) == (pf.bounce_rays, pf.shadow_rays, pf.env_hits)
     ref, pr = oracle.create_scene(b).render(rd)
     ps.check_film(with_cert, ref, pw, pr)
     assert with_cert[..., :3].max() > 0.0
