@@ -1012,7 +1012,7 @@ template <bool SPEC = false>
 // PT_INST_CONVEX_IN, the mark in its record's slot word).  The ray's line crosses such a body's surface twice, once behind the origin and once in front: only the
 // triangle in front can be accepted — so once a triangle is accepted WELL INSIDE itself (every barycentric coordinate >= PT_INSIDE_BARY: the ray passes no edge or vertex of
 // the accepted triangle within the reach of rounding, where a neighbour might be accepted too and, later in the order, win a tie), no later leaf of this mesh can be:
-// the grouped and plain sweeps end there for this lane.  (The while-while walk does not use it.)
+// the grouped and plain sweeps and the while-while walk of this mesh end there for this lane.
 #define PT_INSIDE_BARY 1e-3f
 PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, F3 d, float bound, int stop, SweepState& st,
                      uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true, uint64_t* aux = nullptr, bool inside = false) {
@@ -1325,6 +1325,10 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
             const bool opaque = PT_MATERIAL_TAG(im != PT_MATERIAL_NONE ? im : pt_f2u(q0.w)) != PT_TAG_LIGHT;
             over = accepted & ((stop == PT_STOP_ANY) | ((stop == PT_STOP_NONLIGHT) & (st.closest < bound) & opaque));
             st.hit = over ? 0ull : st.hit;
+            // (`inside`: the walk of THIS mesh ends at the first interior acceptance — no node left, no leaf held; the ray's other leaves are not touched)
+            const bool last = inside && accepted && __builtin_fminf(__builtin_fminf(th.b0, th.b1), th.b2) >= PT_INSIDE_BARY;
+            if (last) { PT_STAT_INSIDE_STOP(); }
+            i = last ? node_count : i; pending2 = last ? NONE : pending2;
         }
         pending = pending2; pend_node = pend2_node; pending2 = NONE;   // (without SPEC: NONE — every turn begins without a leaf)
         if (over || (i >= node_count && pending == NONE)) break;

@@ -50,6 +50,7 @@ def random_scene(seed):
     n_light = 0
     for _ in range(rng.integers(2, 9)):
         kind = rng.integers(0, 4)
+        if 190000 <= seed < 200000 and kind == 3: kind = 1   # (the one-glass-body class below: no other mesh that the host could certify)
         origin = rng.uniform(-1.2, 1.2, 3).tolist()
         m = material()
         n_light += (m >> 16) == 1
@@ -109,7 +110,10 @@ def random_scene(seed):
         cube_p = np.array([(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)], np.float32) - 0.5
         cube_f = np.array([(0, 2, 1), (0, 3, 2), (4, 5, 6), (4, 6, 7), (0, 1, 5), (0, 5, 4), (1, 2, 6), (1, 6, 5), (2, 3, 7), (2, 7, 6), (3, 0, 4), (3, 4, 7)], np.uint32)
         shared = {}
-        for k in range(int(rng5.integers(1, 5))):
+        # 190000 ..: ONE body, of glass — the scene's only certified instance: the path segments refracted into it carry PT_PATH_INSIDE_MARK and its sweep ends at the first
+        # interior acceptance (pt_device.h mesh_walk `inside`); the floor, the lamps and the other shapes may run through it
+        solo = seed >= 190000
+        for k in range(1 if solo else int(rng5.integers(1, 5))):
             kind = int(rng5.integers(0, 5))
             if kind == 0: pm, fm_, nm, _ = S._npz_mesh("brilliant_diamond"); size = 0.5
             elif kind == 1: pm, fm_, nm, _ = S._npz_mesh("prism"); size = 2.5
@@ -123,7 +127,7 @@ def random_scene(seed):
             scale = (rng5.uniform(0.5, 1.5, 3) * size).tolist() if rng5.random() < 0.6 else (size, size, size)
             rot = [(rng5.normal(size=3).tolist(), float(rng5.uniform(-180, 180))) for _ in range(int(rng5.integers(0, 3)))] or None
             at = rng5.uniform(-1.0, 1.0, 3)
-            b.add_mesh_instance(mesh, mats[int(rng5.integers(len(mats)))] if rng5.random() < 0.7 else None, S.transform_from_data(scale, rot, at.tolist()))
+            b.add_mesh_instance(mesh, mats[5 + int(rng5.integers(3))] if solo else (mats[int(rng5.integers(len(mats)))] if rng5.random() < 0.7 else None), S.transform_from_data(scale, rot, at.tolist()))
             if rng5.random() < 0.4:   # a small lamp next to, above, or inside the body's box
                 off = rng5.normal(size=3) * float(rng5.choice([0.2, 0.6, 1.5]))
                 lm = lights[int(rng5.integers(len(lights)))]

@@ -298,7 +298,7 @@ def test_convex_certificates(emu, pkg):
     assert int(inside.sum()) == 238
 
 
-@pytest.mark.parametrize("case", ["cornell_gem", "cornell_gem_hero", "cube", "cube_transformed", "cube_lamp_close", "cube_sky", "cube_sky_hero", "prism_smooth", "prism_smooth_sky"])
+@pytest.mark.parametrize("case", ["cornell_gem", "cornell_gem_hero", "cube", "cube_transformed", "cube_lamp_close", "cube_sky", "cube_sky_hero", "prism_smooth", "prism_smooth_sky", "test_prism_glass"])
 def test_convex_certificates_change_nothing(emu, oracle, pkg, monkeypatch, case):
     """A light-sample ray that leaves a certified body inward is dead where it is made, one that leaves it outward drops the body from its leaf mask (stage_shade,
     world_hit_sweep): with the certificates ignored (PTEMU_NO_CONVEX = pt_tuning's PT_TUNE_NO_CONVEX) the film and the counters are the same bit for bit — and both are the oracle's."""
@@ -310,7 +310,9 @@ def test_convex_certificates_change_nothing(emu, oracle, pkg, monkeypatch, case)
          "cube_sky": lambda: _mesh_scene(pkg, p, f, transform=xf, sky=True), "cube_sky_hero": lambda: _mesh_scene(pkg, p, f, sky=True),
          # (a smooth-shaded convex body: the hit normals are up to 47 degrees off their faces, every face has its own outward threshold)
          "prism_smooth": lambda: _mesh_scene(pkg, *pkg.scene._npz_mesh("prism")[:3], transform=pkg.scene.transform_from_data(scale=(3.0, 3.0, 3.0), rotate=[((0, 0, 1), 90.0)])),
-         "prism_smooth_sky": lambda: _mesh_scene(pkg, *pkg.scene._npz_mesh("prism")[:3], transform=pkg.scene.transform_from_data(scale=(2.0, 3.0, 2.5)), sky=True)}[case]()
+         "prism_smooth_sky": lambda: _mesh_scene(pkg, *pkg.scene._npz_mesh("prism")[:3], transform=pkg.scene.transform_from_data(scale=(2.0, 3.0, 2.5)), sky=True),
+         # (G1's scene: the prism in GLASS, 836 triangles — walked, not swept: the inside rule in mesh_walk's while-while form)
+         "test_prism_glass": pkg.scene.test_prism_small}[case]()
     rd = pkg.api.render_desc(48, 40, 8, 10, light_samples=3, seed=12, hero_wavelengths=4 if case.endswith("hero") else 1)
     with_cert, pw = emu.create_scene(b).render(rd)
     monkeypatch.setenv("PTEMU_NO_CONVEX", "1")
@@ -327,7 +329,7 @@ def test_convex_certificates_change_nothing(emu, oracle, pkg, monkeypatch, case)
     monkeypatch.delenv("PTEMU_NO_INSIDE")
     assert stops() == before
     sc.render(rd)
-    assert (stops() > before + 1000) == case.startswith("cornell_gem"), (case, stops() - before)   # (the glass gem's inner bounces; a Lambertian body has none)
+    assert (stops() > before + 1000) == (case.startswith("cornell_gem") or case == "test_prism_glass"), (case, stops() - before)   # (a glass body's inner bounces; a Lambertian body has none)
     assert np.array_equal(with_cert.view(np.uint32), full_sweep.view(np.uint32))
     assert (pw.bounce_rays, pw.shadow_rays, pw.env_hits) == (pf.bounce_rays, pf.shadow_rays, pf.env_hits)
     ref, pr = oracle.create_scene(b).render(rd)

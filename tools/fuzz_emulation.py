@@ -31,5 +31,6 @@ for seed in range(first, first + count):
         ps.check_film(film, ref, prof, rprof)
     except Exception as e:  # noqa: BLE001
         bad.append((seed, repr(e)[:200]))
-print("seeds", first, "..", first + count - 1, "failures:", len(bad), bad[:5])
+stops = int(se.library._debug_scene_info(se.handle, 18)) if count else 0   # (sweeps ended by mesh_walk's `inside` rule in this process: that the soak reached the rule at all)
+print("seeds", first, "..", first + count - 1, "inside stops:", stops, "failures:", len(bad), bad[:5])
 sys.exit(1 if bad else 0)
