@@ -50,6 +50,9 @@
 #define PT_STAT_WALK(lo, ld, bound, closest, stop)   /* a mesh walk begins (tools/light_walks.cpp): the ray in the instance's own space, its bound, the closest hit so far */
 #define PT_STAT_WALK_END(over)                       /* ... and ends: whether the search is over (an early stop) */
 #endif
+#ifndef PT_STAT_FIRST_GROUP
+#define PT_STAT_FIRST_GROUP(found, spoiled)          /* the grouped sweep tried an inside ray's farthest-reaching group first: with what result */
+#endif
 #ifndef PT_STAT_INSIDE_STOP
 #define PT_STAT_INSIDE_STOP()                        /* a sweep ended by mesh_walk's `inside` rule (tests/host_emulation counts them) */
 #endif
@@ -508,7 +511,7 @@ PT_HD void aabb_classify_wave_by(uint32_t code, F4 a, F4 b, const RayPrep& rp, f
     }
 }
 // (the same as one three-way value, for the per-lane loops — BVH walk steps, mesh sweep — whose compiled form is better with it)
-PT_HD int aabb_classify(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry) {
+PT_HD int aabb_classify(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry, float* exit = nullptr) {   // (`exit`: the distance at which the ray leaves the box, for callers that rank boxes)
     PT_STAT(box_tests);
     float p0 = approx_fma(a.x, rp.r.x, rp.nor.x), q0 = approx_fma(b.x, rp.r.x, rp.nor.x);
     float p1 = approx_fma(a.y, rp.r.y, rp.nor.y), q1 = approx_fma(b.y, rp.r.y, rp.nor.y);
@@ -519,8 +522,10 @@ PT_HD int aabb_classify(F4 a, F4 b, const RayPrep& rp, bool flat, float* entry) 
         float lo = slab_entry(n0, n1, n2), hi = slab_exit(x0, x1, x2);
         float e = approx_fma(PT_SLAB_EPS, lo + pt_abs(hi), rp.base), gap = lo - hi;
         *entry = lo;
+        if (exit != nullptr) *exit = hi;
         return gap > e ? 0 : (gap < -e ? 1 : 2);
     }
+    if (exit != nullptr) *exit = slab_exit(x0, x1, x2);
     float m0 = __builtin_fmaxf(__builtin_fmaxf(n1, n2), 0.0f), m1 = __builtin_fmaxf(__builtin_fmaxf(n0, n2), 0.0f), m2 = __builtin_fmaxf(__builtin_fmaxf(n0, n1), 0.0f);
     float e0 = approx_fma(PT_SLAB_EPS, m0 + pt_abs(x0), rp.base), e1 = approx_fma(PT_SLAB_EPS, m1 + pt_abs(x1), rp.base), e2 = approx_fma(PT_SLAB_EPS, m2 + pt_abs(x2), rp.base);
     *entry = __builtin_fmaxf(m0, n0);
@@ -1014,6 +1019,12 @@ template <bool SPEC = false>
 // the accepted triangle within the reach of rounding, where a neighbour might be accepted too and, later in the order, win a tie), no later leaf of this mesh can be:
 // the grouped and plain sweeps and the while-while walk of this mesh end there for this lane.
 #define PT_INSIDE_BARY 1e-3f
+#ifndef PT_FIRST_RANK
+#define PT_FIRST_RANK 0
+#endif
+#ifndef PT_INSIDE_FIRST_GROUP
+#define PT_INSIDE_FIRST_GROUP 0   /* 1: the grouped sweep tries the group an inside ray leaves last first (below; round 6, EXPERIMENT) */
+#endif
 PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, F3 d, float bound, int stop, SweepState& st,
                      uint32_t* cursor = nullptr, uint32_t policy = 0u, bool alive = true, uint64_t* aux = nullptr, bool inside = false) {
     const uint32_t NONE = 0xffffffffu;
@@ -1106,6 +1117,10 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
             const uint32_t groups = (leaf_count + PT_MESH_GROUP - 1u) / PT_MESH_GROUP;
             static_assert((PT_MESH_SWEEP_MAX + PT_MESH_GROUP - 1) / PT_MESH_GROUP <= 64 && PT_MESH_GROUP <= 32, "one bit per group, one per leaf of a group");
             uint64_t entered = 0;
+            float far_leave = -PT_INF; uint32_t far_group = NONE;   // (PT_INSIDE_FIRST_GROUP: the entered group an inside ray leaves last)
+            const bool try_first = PT_INSIDE_FIRST_GROUP && inside && quick && !regroup && stop == PT_STOP_NONE;
+            const bool rank = PT_INSIDE_FIRST_GROUP && !PT_GROUP_WAVE_MASKS && PT_WAVE_ANY(try_first);   // (wave-uniform: some lane's ray starts inside this body; the wave-mask form of the group boxes keeps no exit distance: no ranking there)
+            (void)far_leave;
 #if PT_GROUP_WAVE_MASKS && defined(__HIP_DEVICE_COMPILE__)
             {   // (round 5: the group boxes — every lane the same box — decided as wave masks, as the leaf sweep's boxes are: aabb_classify_wave; a group counts as entered when its
                 // box is hit OR too close to call, as below)
@@ -1130,13 +1145,56 @@ PT_HD bool mesh_walk(const SceneView& s, uint32_t inst, uint32_t inst_id, F3 o, 
             for (uint32_t g = 0; g < groups; ++g) {
                 const uint32_t e = PT_UNIFORM(group_off + g * 8u);
                 const F4 ga = mf4(s, e), gb = mf4(s, e + 4);
-                float entry = 0.0f;
-                int ct = quick ? aabb_classify(ga, gb, cr, PT_UNIFORM(pt_f2u(gb.w)) != 0u, &entry) : 2;
+                float entry = 0.0f, leave = 0.0f;
+                int ct = quick ? aabb_classify(ga, gb, cr, PT_UNIFORM(pt_f2u(gb.w)) != 0u, &entry, rank ? &leave : nullptr) : 2;
                 if (ct == 1 && cull && beyond(entry, limit, cr.base)) ct = 0;
                 entered |= ct != 0 ? 1ull << g : 0ull;
+                if (rank) { const float key = PT_FIRST_RANK == 0 ? leave : (PT_FIRST_RANK == 1 ? entry : entry + leave); const bool far = (ct != 0) & (key > far_leave); far_leave = far ? key : far_leave; far_group = far ? g : far_group; }
             }
 #endif
             if (regroup) entered = *aux;   // (a resumed ray's own groups; the box tests above were the fresh rays' — the loop's addresses are the wave's)
+#if PT_INSIDE_FIRST_GROUP
+            // A ray that starts INSIDE this certified convex body leaves it through exactly one triangle, and that triangle's group box reaches at least as far along the ray
+            // as the exit point: the entered group that the ray leaves LAST is tried first — without side effects: an acceptance well inside the triangle (the `inside` rule
+            // above) is the search's only possible acceptance, committed, and the lane is done with this mesh; an acceptance near an edge spoils the attempt (ties go to
+            // pre-order: the lane takes all its groups in order, as if nothing had been tried); no acceptance means none in the ordered search either (the interval only
+            // shrinks, and the tests are monotone in it), and the group is dropped.  The choice of the group decides nothing but the time.
+            if (rank) {
+                PT_KEEP_BRANCH();
+                if (try_first && far_group != NONE) {
+                    const uint32_t first = far_group * PT_MESH_GROUP, chunk = leaf_count - first < PT_MESH_GROUP ? leaf_count - first : PT_MESH_GROUP;
+                    uint32_t hit = 0;
+                    for (uint32_t t = 0; t < PT_MESH_GROUP; ++t) {
+                        if (t >= chunk) break;
+                        const uint32_t e = leaf_off + (first + t) * 8u;
+                        F4 ta = mf4(s, e), tb = mf4(s, e + 4);
+                        ta.w = pt_u2f(pt_f2u(tb.w) != 0u ? PT_NODE_FLAT : 0u);
+                        float entry = 0.0f;
+                        const bool box = walk_box(ta, tb, cr, quick, &entry) & !(cull & beyond(entry, limit, cr.base));
+                        hit |= box ? 1u << t : 0u;
+                    }
+                    bool found = false, spoiled = false;
+                    while (hit != 0u && !found && !spoiled) {
+                        const uint32_t k = (uint32_t)__builtin_ctz(hit);
+                        hit &= hit - 1u;
+                        const uint32_t t = mu(s, leaf_off + (first + k) * 8u + 3u);
+                        const F4 q0 = mf4(s, t), q1 = mf4(s, t + 4), q2 = mf4(s, t + 8);
+                        TriHit th;
+                        if (triangle_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), tr, 0.0f, st.closest, &th)) {
+                            if (__builtin_fminf(__builtin_fminf(th.b0, th.b1), th.b2) >= PT_INSIDE_BARY) {
+                                st.closest = th.t; st.best_inst = inst_id; st.best_triw = t; st.bh = th;
+                                limit = __builtin_fminf(st.closest, bound);
+                                found = true;
+                                PT_STAT_INSIDE_STOP();
+                            } else spoiled = true;
+                        }
+                    }
+                    PT_STAT_FIRST_GROUP(found, spoiled);
+                    if (found) entered = 0;
+                    else if (!spoiled) entered &= ~(1ull << far_group);
+                }
+            }
+#endif
             const uint32_t group_evict = aux != nullptr ? (policy >> 17) & 0x7fu : 0u;
 #if PT_SWEEP_FIFO
             // The leaves of the entered groups, per lane — but a lane's triangle tests do not follow its box tests at once: the leaves whose box

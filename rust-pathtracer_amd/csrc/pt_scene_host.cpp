@@ -790,8 +790,27 @@ static bool build_host_scene_with(const pt_scene_desc& d, HostScene* hs, std::st
             if (in.material != PT_MATERIAL_NONE) return PT_MATERIAL_TAG(in.material) == PT_TAG_LIGHT;
             return in.kind == PT_SHAPE_MESH && mesh_light_faces[in.mesh] != 0;
         };
+        // (a Disk's box in the tree is the reference's, half the radius — disk.rs:24-28, a kept quirk — and does not hold the disk: the certificate's "no light near the body"
+        // is about where the light IS.  Found by the soak, seed 197995: a lit disk whose reference box cleared a glass cube's while its rim reached into the cube.)
+        auto true_box = [&](uint32_t i) {
+            const pt_instance& in = d.instances[i];
+            if (in.kind != PT_SHAPE_DISK) return ibox[i];
+            float lo[3], hi[3];
+            const float v[3] = {in.radius, in.radius, 0.001f};
+            for (int k = 0; k < 3; ++k) { lo[k] = in.origin[k] - v[k]; hi[k] = in.origin[k] + v[k]; }
+            Box b = box_of_corners(lo, hi);
+            if (in.has_transform) {
+                Box t = box_empty();
+                for (int c = 0; c < 8; ++c) {
+                    float p[3] = {(c & 1) == 0 ? b.mn[0] : b.mx[0], ((c >> 1) & 1) == 0 ? b.mn[1] : b.mx[1], ((c >> 2) & 1) == 0 ? b.mn[2] : b.mx[2]}, q[3];
+                    xf_point(in.forward, p, q); box_grow(t, q);
+                }
+                b = t;
+            }
+            return b;
+        };
         std::vector<Box> light_boxes;
-        for (uint32_t i = 0; i < d.instance_count; ++i) if (lightish(i)) light_boxes.push_back(ibox[i]);
+        for (uint32_t i = 0; i < d.instance_count; ++i) if (lightish(i)) light_boxes.push_back(true_box(i));
         std::vector<int> mesh_closed(d.mesh_count, -1);
         double work_left = 4e8;   // (the certificate is O(faces x vertices + faces^2) per INSTANCE: a scene of thousands of mesh instances certifies the first of them — about a second — and leaves the rest alone)
         std::vector<std::vector<uint32_t>> mesh_face_flags(d.mesh_count);

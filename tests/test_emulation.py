@@ -229,7 +229,7 @@ def _cube(split_edge=False):
     return np.asarray(p, np.float32), np.asarray(f, np.uint32)
 
 
-def _mesh_scene(pkg, p, f, n=None, transform=None, light_at=(0.0, 0.0, 3.0), sky=False):
+def _mesh_scene(pkg, p, f, n=None, transform=None, light_at=(0.0, 0.0, 3.0), sky=False, lit_disk=None):
     b = pkg.scene.SceneBuilder()
     pkg.scene.add_library_curves(b, ["flat_zero", "flat_one"])
     b.set_environment_constant(b.curve("flat_one" if sky else "flat_zero"), 1.0 if sky else 0.0)
@@ -238,6 +238,8 @@ def _mesh_scene(pkg, p, f, n=None, transform=None, light_at=(0.0, 0.0, 3.0), sky
     white = pkg.scene.add_library_material(b, "lambertian_white")
     glass = pkg.scene.add_library_material(b, "ggx_glass_rough")
     b.add_rect((1.0, 1.0), light_at, "Z", True, lamp)
+    if lit_disk is not None:
+        b.add_disk(lit_disk[0], lit_disk[1], True, lamp)
     b.add_rect((12, 12), (0.0, 0.0, -2.0), "Z", True, white)
     m = b.add_mesh(p, f, n, face_materials=pkg.api.material_id(pkg.api.TAG_MATERIAL, 0))
     b.add_mesh_instance(m, glass, transform)
@@ -277,6 +279,10 @@ def test_convex_certificates(emu, pkg):
     assert flags(_mesh_scene(pkg, p, f, transform=xf)) == (OUT | IN, 0, 12)
     assert flags(_mesh_scene(pkg, p, f[:, ::-1].copy()))[0] == 0                        # inside out
     assert flags(_mesh_scene(pkg, p, f, light_at=(0.5, 0.5, 1.0005)))[0] == OUT          # a lamp 5e-4 above the cube: its box touches the cube's
+    # a lit DISK beside the cube whose rim reaches into it: the reference's box of a disk has HALF its radius (disk.rs:24-28, a kept quirk) and clears the cube's — the
+    # certificate asks where the light is, not where its box is (found by the GPU soak, seed 197995: inward light rays killed that reach the rim inside the cube)
+    assert flags(_mesh_scene(pkg, p, f, lit_disk=(0.55, (1.3, 0.5, 0.5))))[0] == OUT
+    assert flags(_mesh_scene(pkg, p, f, lit_disk=(0.55, (2.3, 0.5, 0.5))))[0] == (OUT | IN)  # (the same disk a unit farther away: clear)
     pm, fm, nm, _ = pkg.scene._npz_mesh("monkey")
     assert flags(_mesh_scene(pkg, pm, fm))[0] == 0
     pg, fg, ng, _ = pkg.scene._npz_mesh("gem")
@@ -298,7 +304,7 @@ def test_convex_certificates(emu, pkg):
     assert int(inside.sum()) == 238
 
 
-@pytest.mark.parametrize("case", ["cornell_gem", "cornell_gem_hero", "cube", "cube_transformed", "cube_lamp_close", "cube_sky", "cube_sky_hero", "prism_smooth", "prism_smooth_sky", "test_prism_glass"])
+@pytest.mark.parametrize("case", ["cornell_gem", "cornell_gem_hero", "cube", "cube_transformed", "cube_lamp_close", "cube_sky", "cube_sky_hero", "prism_smooth", "prism_smooth_sky", "test_prism_glass", "cube_lit_disk"])
 def test_convex_certificates_change_nothing(emu, oracle, pkg, monkeypatch, case):
     """A light-sample ray that leaves a certified body inward is dead where it is made, one that leaves it outward drops the body from its leaf mask (stage_shade,
     world_hit_sweep): with the certificates ignored (PTEMU_NO_CONVEX = pt_tuning's PT_TUNE_NO_CONVEX) the film and the counters are the same bit for bit — and both are the oracle's."""
@@ -312,7 +318,10 @@ def test_convex_certificates_change_nothing(emu, oracle, pkg, monkeypatch, case)
          "prism_smooth": lambda: _mesh_scene(pkg, *pkg.scene._npz_mesh("prism")[:3], transform=pkg.scene.transform_from_data(scale=(3.0, 3.0, 3.0), rotate=[((0, 0, 1), 90.0)])),
          "prism_smooth_sky": lambda: _mesh_scene(pkg, *pkg.scene._npz_mesh("prism")[:3], transform=pkg.scene.transform_from_data(scale=(2.0, 3.0, 2.5)), sky=True),
          # (G1's scene: the prism in GLASS, 836 triangles — walked, not swept: the inside rule in mesh_walk's while-while form)
-         "test_prism_glass": pkg.scene.test_prism_small}[case]()
+         "test_prism_glass": pkg.scene.test_prism_small,
+         # (a lit disk whose rim reaches into the cube while its reference box — half the radius — clears the cube's: inward light rays reach it)
+         # (with the certificate as it was before the fix this film is off by 3.4e-4)
+         "cube_lit_disk": lambda: _mesh_scene(pkg, p, f, lit_disk=(0.55, (1.3, 0.5, 0.5)))}[case]()
     rd = pkg.api.render_desc(48, 40, 8, 10, light_samples=3, seed=12, hero_wavelengths=4 if case.endswith("hero") else 1)
     with_cert, pw = emu.create_scene(b).render(rd)
     monkeypatch.setenv("PTEMU_NO_CONVEX", "1")

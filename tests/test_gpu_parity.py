@@ -410,12 +410,13 @@ def test_forms_without_transforms_change_nothing(engine, pkg, monkeypatch, scene
         parity_suite.assert_hits_equal(hits, other.intersect(o, d))
 
 
-@pytest.mark.parametrize("case", ["cornell_gem", "cornell_gem_hero", "fuzz_49682", "fuzz_100003", "cube_sky", "prism_smooth_sky", "test_prism_small"])
+@pytest.mark.parametrize("case", ["cornell_gem", "cornell_gem_hero", "fuzz_49682", "fuzz_100003", "fuzz_197995", "cube_sky", "prism_smooth_sky", "test_prism_small", "cube_lit_disk"])
 def test_convex_certificates_change_nothing(engine, oracle, pkg, monkeypatch, case):
     """Round 6 (pt_blob.h PT_INST_CONVEX_*): a light-sample ray that leaves a certified closed convex mesh instance inward is dead where it is made, one that leaves it outward
     drops the instance from its leaf mask and never parks at it.  With the certificates ignored (PT_AMD_NO_CONVEX = PT_TUNE_NO_CONVEX) — and through the other traversal
     forms, which do not use the marks — the film and the counters are the same bit for bit, and they are the oracle's.  fuzz_49682: octahedra under a sky that light samples
-    pick (an environment ray starts on the side of its direction's world z, pt.rs:256: half of the outward ones start INSIDE the body — the case that caught the first version)."""
+    pick (an environment ray starts on the side of its direction's world z, pt.rs:256: half of the outward ones start INSIDE the body — the case that caught the first version).
+    fuzz_197995, cube_lit_disk: a lit disk whose rim reaches into a glass cube while its reference box (half the radius, disk.rs:24-28) clears the cube's — the soak's find."""
     import fuzz_scenes
     from test_emulation import _cube, _mesh_scene
     if case.startswith("fuzz_"):
@@ -427,6 +428,9 @@ def test_convex_certificates_change_nothing(engine, oracle, pkg, monkeypatch, ca
         b = _mesh_scene(pkg, *pkg.scene._npz_mesh("prism")[:3], transform=pkg.scene.transform_from_data(scale=(2.0, 3.0, 2.5)), sky=True)
     elif case == "test_prism_small":   # (G1's scene: the reference tree's test_prism.toml)
         b = pkg.scene.test_prism_small()
+    elif case == "cube_lit_disk":
+        p, f = _cube()
+        b = _mesh_scene(pkg, p, f, lit_disk=(0.55, (1.3, 0.5, 0.5)))
     else:
         b = pkg.scene.cornell_gem()
     rd = pkg.api.render_desc(192, 160, 10, 10, light_samples=3, seed=12, hero_wavelengths=4 if case.endswith("hero") else 1)
