@@ -102,7 +102,8 @@ def random_scene(seed):
                               face_materials=api.material_id(api.TAG_MATERIAL, mats[k % len(mats)] & 0xFFFF))
             b.add_mesh_instance(mesh, mats[int(rng2.integers(len(mats)))] if rng2.random() < 0.5 else None,
                                 S.transform_from_data(None, None, rng2.uniform(-1.0, 1.0, 3).tolist()) if rng2.random() < 0.7 else None)
-    if 150000 <= seed < 200000:  # (a seed space of its own, round 6; below 200000: rendered by the plain walk) closed CONVEX bodies of every kind the host certifies or refuses
+    if 140000 <= seed < 200000:  # (a seed space of its own, round 6; below 200000: rendered by the plain walk) closed CONVEX bodies of every kind the host certifies or refuses
+        # (140000 .. 149999: the same under MIRRORING transforms — scales of either sign: the winding seen from outside is reversed, the normals are not)
         # (pt_blob.h PT_INST_CONVEX_*): the brilliant cut (flat-shaded, sharp edges), the prism (smooth-shaded: vertex normals up to 47 degrees off their faces), cubes, octahedra
         # with and without vertex normals — under random transform stacks (uneven scales, rotations), in glass, metal and Lambertian, several instances of one mesh, bodies that
         # overlap, lights of every kind next to, above and INSIDE their boxes, skies that light samples pick
@@ -125,6 +126,7 @@ def random_scene(seed):
                 mesh = b.add_mesh(pm, fm_, nm, face_materials=api.material_id(api.TAG_MATERIAL, mats[int(rng5.integers(len(mats)))] & 0xFFFF))
                 shared[kind] = mesh
             scale = (rng5.uniform(0.5, 1.5, 3) * size).tolist() if rng5.random() < 0.6 else (size, size, size)
+            if seed < 150000: scale = [float(v) * float(rng5.choice([-1.0, 1.0])) for v in scale]
             rot = [(rng5.normal(size=3).tolist(), float(rng5.uniform(-180, 180))) for _ in range(int(rng5.integers(0, 3)))] or None
             at = rng5.uniform(-1.0, 1.0, 3)
             b.add_mesh_instance(mesh, mats[5 + int(rng5.integers(3))] if solo else (mats[int(rng5.integers(len(mats)))] if rng5.random() < 0.7 else None), S.transform_from_data(scale, rot, at.tolist()))

@@ -58,3 +58,26 @@ def test_profile_summary_writes_the_l2_counts_bench_reads(tmp_path):
         for f in made:
             if os.path.exists(f):
                 os.remove(f)
+
+
+def test_round_table_is_the_committed_records():
+    """tools/round_table.py: the table of profiles/r6_experiments.md section 0 is made from the committed bench records of the tag it names — the figures of the experiments
+    file are the records' (the default run's and C3's throughput, to the digit)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "round_table.py"), "r6z", "r5z"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l for l in r.stdout.split("\n") if l.startswith("| C") or l.startswith("| G")]
+    assert len(rows) == 8, r.stdout
+    text = open(os.path.join(ROOT, "profiles", "r6_experiments.md")).read()
+    for cfg in ("default", "C3", "G1"):
+        d = json.loads(open(os.path.join(ROOT, "profiles", "r6z_bench_%s.json" % cfg)).read().strip().split("\n")[-1])
+        assert "**%.0f**" % d["value"] in r.stdout and "**%.0f**" % d["value"] in text, cfg
+
+
+def test_the_soak_tools_take_a_switch(tmp_path):
+    """tools/fuzz_emulation.py with PT_FUZZ_SWITCH: every scene is rendered once more under that switch of the emulated library and compared BIT FOR BIT (a wrong decision of a
+    certificate that moves the film by less than the parity bar still changes bits); a few scenes of the one-glass-body class, whose segments take the inside rule."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_emulation.py"), "190000", "6"], capture_output=True, text=True, timeout=900, env=dict(os.environ, PT_FUZZ_SWITCH="PTEMU_NO_CONVEX"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    m = re.search(r"inside stops: (\d+) failures: 0", r.stdout)
+    assert m and int(m.group(1)) > 50, r.stdout
