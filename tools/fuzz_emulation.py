@@ -20,7 +20,7 @@ if len(sys.argv) > 6:
     os.environ["PTEMU_FLAGS"] = sys.argv[6]
 emu = pkg.api.Library(os.path.join(ROOT, "tests", "host_emulation", "libptemu.so"), "ptemu_", optional=("render_device", "device_info"))
 oracle = oracle_loader.load(pkg)
-SWITCH = os.environ.get("PT_FUZZ_SWITCH", "")   # e.g. PT_AMD_NO_CONVEX (GPU) / PTEMU_NO_CONVEX, PTEMU_NO_INSIDE (emulation)
+SWITCH = os.environ.get("PT_FUZZ_SWITCH", "")   # (several: comma-separated) e.g. PT_AMD_NO_CONVEX (GPU) / PTEMU_NO_CONVEX, PTEMU_NO_INSIDE (emulation)
 bad = []
 for seed in range(first, first + count):
     try:
@@ -32,15 +32,16 @@ for seed in range(first, first + count):
         film, prof = se.render(rd)
         ref, rprof = so.render(rd)
         ps.check_film(film, ref, prof, rprof)
-        if SWITCH:   # the same render with a switch of the library set (read when the scene is created): the same BITS — a check of every decision the switch governs, not only of
+        for switch in [w for w in SWITCH.split(",") if w]:
+            # the same render with a switch of the library set (read when the scene is created): the same BITS — a check of every decision the switch governs, not only of
             # those that move the film by more than the parity bar
-            os.environ[SWITCH] = "1"
+            os.environ[switch] = "1"
             try:
                 film2, prof2 = emu.create_scene(b).render(rd)
             finally:
-                del os.environ[SWITCH]
-            assert np.array_equal(film.view(np.uint32), film2.view(np.uint32)), ("bits differ under " + SWITCH, float(np.abs(film - film2).max()))
-            assert (prof.bounce_rays, prof.shadow_rays, prof.env_hits) == (prof2.bounce_rays, prof2.shadow_rays, prof2.env_hits), "counters differ under " + SWITCH
+                del os.environ[switch]
+            assert np.array_equal(film.view(np.uint32), film2.view(np.uint32)), ("bits differ under " + switch, float(np.abs(film - film2).max()))
+            assert (prof.bounce_rays, prof.shadow_rays, prof.env_hits) == (prof2.bounce_rays, prof2.shadow_rays, prof2.env_hits), "counters differ under " + switch
     except Exception as e:  # noqa: BLE001
         bad.append((seed, repr(e)[:200]))
 stops = int(se.library._debug_scene_info(se.handle, 18)) if count else 0   # (sweeps ended by mesh_walk's `inside` rule in this process: that the soak reached the rule at all)
