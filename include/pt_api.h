@@ -251,7 +251,8 @@ enum {
     PT_TUNE_NO_ONE_LIGHT = 1u << 14,   /* PT_AMD_NO_ONE_LIGHT: in a scene with ONE light the lean vertex kernel does not run that light's shape test on its light-sample rays
                                           (by default a ray that misses the only light is dead where it is made and its item, if no ray of it lives, never read) */
     PT_TUNE_NO_CONVEX = 1u << 15,      /* PT_AMD_NO_CONVEX: no use of the host's convex-body certificates (a light-sample ray that leaves a closed convex mesh instance inward is
-                                          dead where it is made, one that leaves it outward does not park at that mesh again: pt_blob.h PT_INST_CONVEX_*, round 6) */
+                                          dead where it is made, one that leaves it outward does not park at that mesh again, a path segment refracted into it ends that mesh's search at its first
+                                          interior acceptance: pt_blob.h PT_INST_CONVEX_*, PT_PATH_INSIDE_MARK, round 6) */
     PT_TUNE_NO_AXIS_SCAN = 1u << 13    /* PT_AMD_NO_AXIS_SCAN: the parked kernels walk a ray that is parallel to an axis of its mesh like any other (by default the
                                           whole wave scans the mesh's leaves for it: such a ray passes most boxes, AABB::hit ignoring the axes its direction is zero along) */
 };
