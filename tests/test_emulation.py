@@ -375,3 +375,41 @@ def test_specialised_shade_forms_change_nothing(emu, pkg, monkeypatch):
             monkeypatch.delenv("PTEMU_SHADE_FORM")
             assert np.array_equal(lean.view(np.uint32), general.view(np.uint32)), (scene, form)
             assert (plean.bounce_rays, plean.shadow_rays) == (pgen.bounce_rays, pgen.shadow_rays)
+
+
+def many_analytic_scene(pkg, n=80, seed=5, disks=True):
+    """More than 64 instances, none a mesh — rectangles of every axis, spheres (some under uneven scales and rotations), disks (one lit: the reference's box of a disk has
+    half its radius, so nothing is culled at the top level beside one) — the scenes that have no sweep table and park at nothing."""
+    rng = np.random.default_rng(seed)
+    b = pkg.scene.SceneBuilder()
+    pkg.scene.add_library_curves(b, ["flat_zero", "flat_one"])
+    b.set_environment_constant(b.curve("flat_one"), 0.3)
+    b.env_sampling_probability = 0.3
+    lamp = pkg.scene.add_library_material(b, "diffuse_light_flat_x5")
+    mats = [pkg.scene.add_library_material(b, m) for m in ("lambertian_white", "lambertian_red", "ggx_gold", "ggx_glass_rough")]
+    b.add_rect((10, 10), (0.0, 0.0, -1.2), "Z", True, mats[0])
+    b.add_rect((1.0, 1.0), (0.0, 0.0, 2.5), "Z", True, lamp)
+    for k in range(n - 2):
+        at = rng.uniform(-1.5, 1.5, 3).tolist()
+        m = lamp if k % 9 == 0 else mats[int(rng.integers(len(mats)))]
+        xf = pkg.scene.transform_from_data(rng.uniform(0.5, 1.5, 3).tolist(), [(rng.normal(size=3).tolist(), float(rng.uniform(-180, 180)))], None) if k % 4 == 0 else None
+        kind = int(rng.integers(3)) if disks else int(rng.integers(2))
+        if kind == 0: b.add_sphere(float(rng.uniform(0.05, 0.25)), at, m, xf)
+        elif kind == 1: b.add_rect(tuple(rng.uniform(0.1, 0.6, 2).tolist()), at, "XYZ"[int(rng.integers(3))], bool(rng.integers(2)), m, xf)
+        else: b.add_disk(float(rng.uniform(0.1, 0.4)), at, bool(rng.integers(2)), m, xf)
+    b.add_camera((-5.0, 0.3, 0.8), (0.0, 0.0, 0.0), 40.0)
+    return b
+
+
+@pytest.mark.parametrize("case", ["many_analytic", "many_analytic_no_disk", "many_analytic_300"])
+def test_many_analytic_instances(emu, oracle, pkg, case):
+    """More than 64 instances of every analytic kind, none a mesh, through the top-level walk in the parked kernels' protocol: the oracle's film.  (The scenes were made for
+    round 6's top level by GROUPS — the leaves of the tree six at a time under the union of their boxes, bit-identical on them and on the GPU, and slower than the walk:
+    profiles/r6_experiments.md section 13, the code in profiles/r6_scripts/r6_topgroups.patch.)"""
+    b = {"many_analytic": lambda: many_analytic_scene(pkg), "many_analytic_no_disk": lambda: many_analytic_scene(pkg, 90, 8, disks=False),
+         "many_analytic_300": lambda: many_analytic_scene(pkg, 300, 11)}[case]()
+    rd = pkg.api.render_desc(48, 40, 6, 8, light_samples=3, seed=9, hero_wavelengths=4 if case == "many_analytic_no_disk" else 1)
+    film, prof = emu.create_scene(b).render(rd)
+    ref, rp = oracle.create_scene(b).render(rd)
+    ps.check_film(film, ref, prof, rp)
+    assert film[..., :3].max() > 0.0

@@ -661,3 +661,26 @@ def test_bench_line_contract(pkg):
     assert "traffic" in rf and rf["kernel"].startswith("k_")
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "Msamples/s" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+@pytest.mark.parametrize("case", ["many_analytic", "many_analytic_no_disk", "many_analytic_300"])
+def test_many_analytic_instances(engine, oracle, pkg, monkeypatch, case):
+    """More than 64 instances of every analytic kind, none a mesh (the emulation tier's case of the same name): the top-level walk in the parked kernels, through the per-lane
+    walk kernels (PT_AMD_NO_PARK), with the light pre-pass forced on (bounded searches that stop at the first opaque hit), without culling, with the exact box test and with the
+    blob in HBM: one film and one set of counters, bit for bit — and the oracle's."""
+    from test_emulation import many_analytic_scene
+    b = {"many_analytic": lambda: many_analytic_scene(pkg), "many_analytic_no_disk": lambda: many_analytic_scene(pkg, 90, 8, disks=False),
+         "many_analytic_300": lambda: many_analytic_scene(pkg, 300, 11)}[case]()
+    rd = pkg.api.render_desc(192, 160, 8, 8, light_samples=3, seed=9, hero_wavelengths=4 if case == "many_analytic_no_disk" else 1)
+    monkeypatch.setenv("PT_AMD_BLOCKS_PER_CU", "2")
+    base, pbase = engine.create_scene(b).render(rd)
+    for env in ({"PT_AMD_NO_PARK": "1"}, {"PT_AMD_LIGHT_PREPASS_MAX": "4294967295"}, {"PT_AMD_NO_CULL": "1"}, {"PT_AMD_EXACT_SLAB": "1"}, {"PT_AMD_NO_LDS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        film, prof = engine.create_scene(b).render(rd)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(base.view(np.uint32), film.view(np.uint32)), env
+        assert (pbase.bounce_rays, pbase.shadow_rays, pbase.env_hits) == (prof.bounce_rays, prof.shadow_rays, prof.env_hits), env
+    ref, rprof = oracle.create_scene(b).render(rd)
+    ps.check_film(base, ref, pbase, rprof)
