@@ -253,6 +253,8 @@ enum {
     PT_TUNE_NO_CONVEX = 1u << 15,      /* PT_AMD_NO_CONVEX: no use of the host's convex-body certificates (a light-sample ray that leaves a closed convex mesh instance inward is
                                           dead where it is made, one that leaves it outward does not park at that mesh again, a path segment refracted into it ends that mesh's search at its first
                                           interior acceptance: pt_blob.h PT_INST_CONVEX_*, PT_PATH_INSIDE_MARK, round 6) */
+    PT_TUNE_NO_MESH_SHORTCUTS = 1u << 16, /* PT_AMD_NO_MESH_SHORTCUTS: no mesh is decided without its triangle tests — a closed mesh's inner balls (a bounded light ray through one is blocked)
+                                          and its 18-DOP slabs (a ray outside one misses) are not used; the searches they cut short run in full.  A diagnostic: the films are the same bit for bit */
     PT_TUNE_NO_AXIS_SCAN = 1u << 13    /* PT_AMD_NO_AXIS_SCAN: the parked kernels walk a ray that is parallel to an axis of its mesh like any other (by default the
                                           whole wave scans the mesh's leaves for it: such a ray passes most boxes, AABB::hit ignoring the axes its direction is zero along) */
 };

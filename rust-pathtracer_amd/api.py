@@ -124,7 +124,7 @@ class Profile(C.Structure):
 
 # pt_tuning flags (include/pt_api.h)
 TUNE_NO_LDS, TUNE_NO_CORE_LDS, TUNE_NO_PARK, TUNE_NO_LIVE_LIST, TUNE_EXACT_SLAB, TUNE_NO_CULL, TUNE_NO_SWEEP, TUNE_NO_MESH_SWEEP, TUNE_NO_KNOWN_LIGHT, \
-    TUNE_GENERAL_FORMS, TUNE_NO_FUSE, TUNE_NO_STAGE_TIMING, TUNE_MULTI_RCCL, TUNE_NO_AXIS_SCAN, TUNE_NO_ONE_LIGHT, TUNE_NO_CONVEX = (1 << i for i in range(16))
+    TUNE_GENERAL_FORMS, TUNE_NO_FUSE, TUNE_NO_STAGE_TIMING, TUNE_MULTI_RCCL, TUNE_NO_AXIS_SCAN, TUNE_NO_ONE_LIGHT, TUNE_NO_CONVEX, TUNE_NO_MESH_SHORTCUTS = (1 << i for i in range(17))
 
 
 class Tuning(C.Structure):

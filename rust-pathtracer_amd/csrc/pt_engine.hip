@@ -505,6 +505,14 @@ static pt_status scene_to_device(pt_scene* sc) {
     if (tn.flags & PT_TUNE_NO_MESH_SWEEP) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_MESH_SWEEP;
     if (tn.flags & PT_TUNE_NO_KNOWN_LIGHT) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_KNOWN_LIGHT;
     if (tn.flags & PT_TUNE_NO_ONE_LIGHT) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_ONE_LIGHT;
+    if (tn.flags & PT_TUNE_NO_MESH_SHORTCUTS) {   // (the mesh records' inner ball and slab table: mesh_surely_blocks / mesh_surely_missed claim nothing without them)
+        std::vector<uint32_t>& bl = sc->host.blob;
+        for (uint32_t i = 0; i < bl[PT_HDR_INSTANCE_COUNT]; ++i) {
+            const uint32_t inst = bl[PT_HDR_INSTANCE_OFF] + i * PT_INST_WORDS;
+            if (bl[inst + PT_INST_KIND] != (uint32_t)PT_SHAPE_MESH) continue;
+            bl[bl[inst + PT_INST_MESH] + PT_MESH_INNER_R] = 0u; bl[bl[inst + PT_INST_MESH] + PT_MESH_DOP_OFF] = 0u;
+        }
+    }
     if (tn.flags & PT_TUNE_NO_CONVEX) sc->host.blob[PT_HDR_FLAGS] &= ~PT_FLAG_CONVEX;   // (the vertex code looks at an instance's certificate only under this flag, and only it makes marks)
     if (sc->host.blob[PT_HDR_LIGHT_COUNT] > tuned(tn.light_prepass_max, kLightPrepassMax)) sc->host.blob[PT_HDR_FLAGS] |= PT_FLAG_NO_LIGHT_PREPASS;
     sc->blob_words = (uint32_t)sc->host.blob.size();
@@ -546,7 +554,7 @@ void pt_tuning_default(pt_tuning* t) {
 #endif
 
         {"PT_AMD_EXACT_SLAB", PT_TUNE_EXACT_SLAB}, {"PT_AMD_NO_CULL", PT_TUNE_NO_CULL}, {"PT_AMD_NO_SWEEP", PT_TUNE_NO_SWEEP}, {"PT_AMD_NO_MESH_SWEEP", PT_TUNE_NO_MESH_SWEEP},
-        {"PT_AMD_NO_KNOWN_LIGHT", PT_TUNE_NO_KNOWN_LIGHT}, {"PT_AMD_GENERAL_FORMS", PT_TUNE_GENERAL_FORMS}, {"PT_AMD_NO_FUSE", PT_TUNE_NO_FUSE}, {"PT_AMD_MULTI_RCCL", PT_TUNE_MULTI_RCCL}, {"PT_AMD_NO_AXIS_SCAN", PT_TUNE_NO_AXIS_SCAN}, {"PT_AMD_NO_ONE_LIGHT", PT_TUNE_NO_ONE_LIGHT}, {"PT_AMD_NO_CONVEX", PT_TUNE_NO_CONVEX},
+        {"PT_AMD_NO_KNOWN_LIGHT", PT_TUNE_NO_KNOWN_LIGHT}, {"PT_AMD_GENERAL_FORMS", PT_TUNE_GENERAL_FORMS}, {"PT_AMD_NO_FUSE", PT_TUNE_NO_FUSE}, {"PT_AMD_MULTI_RCCL", PT_TUNE_MULTI_RCCL}, {"PT_AMD_NO_AXIS_SCAN", PT_TUNE_NO_AXIS_SCAN}, {"PT_AMD_NO_ONE_LIGHT", PT_TUNE_NO_ONE_LIGHT}, {"PT_AMD_NO_CONVEX", PT_TUNE_NO_CONVEX}, {"PT_AMD_NO_MESH_SHORTCUTS", PT_TUNE_NO_MESH_SHORTCUTS},
         {"PT_AMD_NO_LIVE_LIST", PT_TUNE_NO_LIVE_LIST},
     };
     for (const auto& f : flags) if (env_u32(f.name, 0)) t->flags |= f.bit;

@@ -30,6 +30,14 @@ pt_status ptemu_scene_create(const pt_scene_desc* d, pt_scene** out) {
     const char* f = getenv("PTEMU_FLAGS");
     if (f) sc->host.blob[PT_HDR_FLAGS] |= (uint32_t)strtoul(f, nullptr, 0);
     if (getenv("PTEMU_NO_CONVEX")) sc->host.blob[PT_HDR_FLAGS] &= ~PT_FLAG_CONVEX;   // (pt_engine.hip: PT_TUNE_NO_CONVEX)
+    if (getenv("PTEMU_NO_MESH_SHORTCUTS")) {   // (the mesh records' inner ball and slab table: mesh_surely_blocks / mesh_surely_missed claim nothing without them)
+        std::vector<uint32_t>& bl = sc->host.blob;
+        for (uint32_t i = 0; i < bl[PT_HDR_INSTANCE_COUNT]; ++i) {
+            const uint32_t inst = bl[PT_HDR_INSTANCE_OFF] + i * PT_INST_WORDS;
+            if (bl[inst + PT_INST_KIND] != (uint32_t)PT_SHAPE_MESH) continue;
+            bl[bl[inst + PT_INST_MESH] + PT_MESH_INNER_R] = 0u; bl[bl[inst + PT_INST_MESH] + PT_MESH_DOP_OFF] = 0u;
+        }
+    }   // (pt_engine.hip: PT_TUNE_NO_MESH_SHORTCUTS)
     *out = sc;
     return PT_OK;
 }

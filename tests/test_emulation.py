@@ -413,3 +413,20 @@ def test_many_analytic_instances(emu, oracle, pkg, case):
     ref, rp = oracle.create_scene(b).render(rd)
     ps.check_film(film, ref, prof, rp)
     assert film[..., :3].max() > 0.0
+
+
+@pytest.mark.parametrize("scene", ["cornell_gem", "hdri_c4_small", "test_prism_small", "test_bokeh_floor_gem_small"])
+def test_mesh_shortcuts_change_nothing(emu, pkg, monkeypatch, scene):
+    """mesh_surely_blocks (a closed mesh's inner balls) and mesh_surely_missed (its 18-DOP slabs) decide a ray at a mesh without the triangle tests the reference runs —
+    on f32 error budgets.  With both switched off (PTEMU_NO_MESH_SHORTCUTS = PT_TUNE_NO_MESH_SHORTCUTS: the mesh records lose their ball and their slab table, the searches run
+    in full) the film and the counters are the same bit for bit — every decision of theirs, not only those that move the film by more than the parity bar."""
+    b = pkg.scene.SCENES[scene]()
+    rd = pkg.api.render_desc(64, 48, 6, 8, light_samples=3, seed=17)
+    film, prof = emu.create_scene(b).render(rd)
+    monkeypatch.setenv("PTEMU_NO_MESH_SHORTCUTS", "1")
+    full_sc = emu.create_scene(b)
+    assert int(full_sc.library._debug_scene_info(full_sc.handle, 11)) == 0   # (the first mesh's inner ball radius: gone)
+    full, pf = full_sc.render(rd)
+    monkeypatch.delenv("PTEMU_NO_MESH_SHORTCUTS")
+    assert np.array_equal(film.view(np.uint32), full.view(np.uint32))
+    assert (prof.bounce_rays, prof.shadow_rays, prof.env_hits) == (pf.bounce_rays, pf.shadow_rays, pf.env_hits)
